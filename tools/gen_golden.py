@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by importing the READ-ONLY reference (/root/reference) on CPU.
+
+Runs only in the build container (the reference never travels to the GPU box).  Weights and
+inputs are NOT stored: both sides regenerate them from dpmn_amd.utils.synth (name-seeded
+uniform draws), so a fixture holds only the reference's outputs, the state-dict manifest
+(names + shapes) and a float64 checksum of the synthetic weights.
+
+usage: python tools/gen_golden.py [pgrm|parts|cmm|distill|loss|metrics|tsrn|tatt|tbsrn|step|all]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_shims  # noqa: E402
+
+ref_shims.install()
+from dpmn_amd.utils import synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+def manifest(sd):
+    return np.array(["%s|%s|%s" % (k, ",".join(map(str, v.shape)), str(v.dtype).replace("torch.", ""))
+                     for k, v in sd.items()])
+
+
+def checksum(sd):
+    skip = ("relative_position_index", "attn_mask", "num_batches_tracked")
+    return float(sum(v.double().sum().item() for k, v in sd.items()
+                     if torch.is_floating_point(v) and not any(s in k for s in skip)))
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (v.numpy() if isinstance(v, torch.Tensor) else v) for k, v in arrs.items()})
+    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+
+
+def pgrm_args(n=6, dim=96, windows=(2, 4, 8), heads=6):
+    return dict(patch_size=[2] * n, embed_dim=[dim] * n, depths=[1] * n, num_heads=[[heads]] * n,
+                window_size=[list(windows)] * n, mlp_ratio=[4.] * n, drop_rate=[0.] * n,
+                attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
+
+
+# ------------------------------------------------------------------------------------ PGRM
+def gen_pgrm():
+    from model import pgrm
+    B = 2
+    for tag, it, mode in (("mode0_iter0", 0, False), ("mode1_iter2", 2, True)):
+        m = pgrm.PGRM(iter=it, mode=mode, hidden_size=3, **pgrm_args()).eval()
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=11 + it)
+        m.load_state_dict(sd)
+        cq = 3 if mode else 2
+        if mode:
+            x_q = (synth.uniform("x_q", (B, 1, 32, 128), 0, 1, 5) > 0.5).float().repeat(1, 3, 1, 1)
+        else:
+            x_q = torch.floor(synth.uniform("x_q", (B, cq, 32, 128), 0, 256, 5))
+        x_kv = synth.uniform("x_kv", (B, 3, 32, 128), 0, 1, 5)
+        res = [synth.uniform("res%d" % i, (B, 3, 32, 128), 0, 1, 5) for i in range(it)]
+        out = m(x_q, x_kv, res)
+        save("pgrm_" + tag, out=out, manifest=manifest(sd), checksum=checksum(sd),
+             meta=np.array([B, it, int(mode), 11 + it, 5]))
+
+
+def gen_parts():
+    """Sub-module pins: WindowAttention (cat tensor fed to SKConv, shift 0 and shifted), SKConv,
+    Mlp at config-1 dims, and one BasicLayer at the stress dims."""
+    from model import pgrm
+    import torch.nn as nn
+    B, H, W, C = 1, 16, 64, 96
+    for tag, shift in (("shift0", [0, 0, 0]), ("shifted", [1, 2, 4])):
+        wa = pgrm.WindowAttention(C, window_size=[2, 4, 8], shift_size=list(shift), num_heads=6,
+                                  act_layer=nn.GELU, input_resolution=(H, W)).eval()
+        sd = wa.state_dict()
+        synth.synth_fill_(sd, seed=21)
+        wa.load_state_dict(sd)
+        grabbed = {}
+        wa.sknet.register_forward_hook(lambda mod, inp, out: grabbed.__setitem__("cat", inp[0].clone()))
+        xq = synth.uniform("wa_xq", (B, H, W, C), -1, 1, 6)
+        xkv = synth.uniform("wa_xkv", (B, H, W, C), -1, 1, 6)
+        out = wa(xq, xkv)
+        save("wattn_" + tag, cat=grabbed["cat"].reshape(B, H * W, C), out=out.contiguous(),
+             manifest=manifest(sd), checksum=checksum(sd))
+    mlp = pgrm.Mlp(C, 4 * C).eval()
+    sd = mlp.state_dict()
+    synth.synth_fill_(sd, seed=22)
+    mlp.load_state_dict(sd)
+    x = synth.uniform("mlp_x", (2, H * W, C), -1, 1, 6)
+    save("mlp", out=mlp(x), manifest=manifest(sd), checksum=checksum(sd))
+    # stress dims: dim 192, windows 4/8/16, 32x128 tokens, B=1 (quirk Q7: only pinned at layer level)
+    Hs, Ws, Cs = 32, 128, 192
+    bl = pgrm.BasicLayer(Cs, (Hs, Ws), depth=2, num_heads=6, window_size=[4, 8, 16], mlp_ratio=4.,
+                         drop=0., attn_drop=0., drop_path=0.).eval()
+    sd = bl.state_dict()
+    synth.synth_fill_(sd, seed=23)
+    bl.load_state_dict(sd)
+    xq = synth.uniform("bl_xq", (1, Hs * Ws, Cs), -1, 1, 6)
+    xkv = synth.uniform("bl_xkv", (1, Hs * Ws, Cs), -1, 1, 6)
+    _, o = bl(xq, xkv)
+    save("basiclayer_stress", out=o[:, ::7].contiguous(), manifest=manifest(sd), checksum=checksum(sd))
+
+
+GENS = {"pgrm": gen_pgrm, "parts": gen_parts}
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["all"]
+    for name, fn in GENS.items():
+        if "all" in which or name in which:
+            fn()
