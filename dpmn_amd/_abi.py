@@ -1,0 +1,110 @@
+"""ctypes binding of libdpmn_hip.so (include/dpmn_hip.h).
+
+The HIP library IS the product path: there is no CPU fallback.  Importing this module loads the
+shared object and fails loudly if it is missing or lacks a declared symbol; calling any op with
+non-CUDA tensors raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdpmn_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        "dpmn_amd: %s not found -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C dpmn_amd/csrc`).  There is no CPU fallback for the DPMN hot path." % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+fp = C.c_void_p  # device float*
+
+
+class PgrmBlock(C.Structure):
+    _fields_ = [(n, fp) for n in (
+        "norm1_q_w", "norm1_q_b", "norm1_kv_w", "norm1_kv_b", "q_w", "q_b", "kv_w", "kv_b")] + [
+        ("bias_table", fp * 4)] + [(n, fp) for n in (
+            "sk_proj_w", "sk_proj_b", "sk_fc1_w", "sk_fc1_b", "sk_fc2_w", "sk_fc2_b", "sk_head_w", "sk_head_b",
+            "norm2_w", "norm2_b", "fc1_w", "fc1_b", "dw_w", "dw_b", "pw_w", "pw_b", "fc2_w", "fc2_b")]
+
+
+class PgrmWeights(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "img_h", "img_w", "patch", "dim", "n_groups", "heads_per_group", "mlp_hidden", "hidden_size",
+        "n_weight_list")] + [("window", C.c_int * 4)] + [(n, fp) for n in (
+            "prior_fusion_w", "prior_fusion_b", "pe_w", "pe_b", "pe_norm_w", "pe_norm_b")] + [
+        ("blocks", PgrmBlock * 2)] + [(n, fp) for n in ("tail0_w", "tail0_b", "tail1_w", "tail1_b")] + [
+        ("weight_list", fp * 8)]
+
+
+_i, _f, _sz = C.c_int, C.c_float, C.c_size_t
+_PP = C.POINTER(fp)
+_IP = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); must list every symbol include/dpmn_hip.h declares
+SIGNATURES = {
+    "dpmn_abi_version": (_i, []),
+    "dpmn_last_error": (C.c_char_p, []),
+    "dpmn_linear_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _f, fp]),
+    "dpmn_add_linear_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_ln_linear_f32": (_i, [fp, fp, fp, _f, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_sk_proj_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, fp]),
+    "dpmn_sk_select_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_pointwise_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
+    "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_dwconv3x3_gelu_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_pgrm_tail_f32": (_i, [fp, fp, fp, fp, fp, _PP, _PP, _i, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "dpmn_pgrm_workspace_bytes": (_sz, [C.POINTER(PgrmWeights), _i]),
+    "dpmn_pgrm_forward_f32": (_i, [C.POINTER(PgrmWeights), fp, _i, fp, _PP, _i, fp, fp, _sz, _i, fp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    try:
+        _fn = getattr(lib, _name)
+    except AttributeError as e:  # pragma: no cover
+        raise RuntimeError("dpmn_amd: %s does not export %s (stale build?)" % (LIB_PATH, _name)) from e
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+class DpmnError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        raise DpmnError("libdpmn_hip error %d: %s" % (rc, lib.dpmn_last_error().decode()))
+
+
+def dptr(t, allow_none=False):
+    """Device pointer of a contiguous fp32 CUDA tensor (the only thing the C ABI accepts)."""
+    if t is None:
+        if allow_none:
+            return None
+        raise DpmnError("dpmn_amd: required tensor is None")
+    if not t.is_cuda:
+        raise DpmnError("dpmn_amd: the DPMN hot path runs on the GPU only (got a %s tensor); "
+                        "there is no CPU fallback" % t.device)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise DpmnError("dpmn_amd: expected a contiguous float32 tensor, got %s %s" % (t.dtype, tuple(t.stride())))
+    return t.data_ptr()
+
+
+def ptr_array(tensors, n=None):
+    n = len(tensors) if n is None else n
+    arr = (fp * max(n, 1))()
+    for i, t in enumerate(tensors):
+        arr[i] = dptr(t)
+    return arr
+
+
+def int_array(vals):
+    return (C.c_int * len(vals))(*[int(v) for v in vals])
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

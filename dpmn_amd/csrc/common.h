@@ -1,0 +1,65 @@
+// Shared device helpers for the DPMN gfx950 kernels (fp32 path).
+// MFMA: v_mfma_f32_16x16x4_f32 -- exact f32, 32-cycle issue per SIMD, 157 TF chip peak
+// (MI355X_MICROARCH.md "Matrix cores").  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dpmn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DPMN_CHECK_LAUNCH()                                                         \
+  do {                                                                              \
+    hipError_t e__ = hipGetLastError();                                             \
+    if (e__ != hipSuccess) return dpmn_set_error(DPMN_ERR_LAUNCH, hipGetErrorString(e__)); \
+  } while (0)
+
+#define DPMN_REQUIRE(cond, msg)                                    \
+  do {                                                             \
+    if (!(cond)) return dpmn_set_error(DPMN_ERR_ARG, msg);         \
+  } while (0)
+
+int dpmn_set_error(int code, const char* msg);
+
+// D(16x16) += A(16x4) * B(4x16).  Lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
+// result lane l holds D[row = (l>>4)*4 + r][col = l&15], r = 0..3.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // F.softplus threshold 20
+__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_t(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// activation codes shared by GEMM / conv epilogues and conv prologues
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_LEAKY02 = 3, ACT_LEAKY001 = 4, ACT_MISH = 5, ACT_PRELU = 6,
+       ACT_TANH = 7, ACT_SIGMOID = 8 };
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case ACT_GELU: return gelu_erf(v);
+    case ACT_RELU: return v > 0.f ? v : 0.f;
+    case ACT_LEAKY02: return v > 0.f ? v : 0.2f * v;
+    case ACT_LEAKY001: return v > 0.f ? v : 0.01f * v;
+    case ACT_MISH: return mish_f(v);
+    case ACT_PRELU: return v > 0.f ? v : slope * v;
+    case ACT_TANH: return tanhf(v);
+    case ACT_SIGMOID: return sigmoid_f(v);
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline hipStream_t as_stream(dpmn_stream_t s) { return (hipStream_t)s; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

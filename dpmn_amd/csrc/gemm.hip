@@ -1,0 +1,484 @@
+// fp32 MFMA GEMM family for the DPMN token path (PGRM linears, TATT linears).
+//
+//   y[m][n] = epi( pro(x)[m][:] . w[n][:] + bias[n] )          x: (M,K) row-major, w: (N,K) row-major
+//
+// Layout / mapping (gfx950, wave64, v_mfma_f32_16x16x4_f32):
+//   * the MFMA "A" operand carries W rows (output features) and the "B" operand carries X rows
+//     (tokens), so a lane ends up with 4 CONSECUTIVE output features of one token -> one 16-byte
+//     store per 16x16 tile and float4 bias / residual loads in the epilogue;
+//   * operands come from LDS tiles with K contiguous and a +4 float row pad; one ds_read_b128
+//     feeds 4 MFMA k-steps (lane-quad kq at step s consumes k = 4*kq + s of a 16-deep chunk --
+//     a k permutation applied identically to both operands);
+//   * whole-K kernels (K <= 192) keep the full X tile resident so LayerNorm (two-pass, like
+//     at::layer_norm) or the SK select runs as a prologue on the tile already in LDS;
+//   * the k-loop kernel double-buffers 32-deep chunks through registers.
+// Reference call sites replaced: pgrm.py:188,194 (q/kv Linear after norm1_q/norm1_kv 322-323),
+// pgrm.py:82 (SKConv.proj), 92-95 (select + proj_head + residual), 30-31 (fc1+GELU after norm2 330),
+// 39 (fc2), tatt.py:209 / transformer_v2.py linears.
+#include "common.h"
+
+namespace {
+
+constexpr int PAD = 4;
+
+struct EpiArgs {
+  const float* bias;   // (N) or null
+  const float* res1;   // (M,N) or null, added after activation
+  const float* res2;   // (M,N) or null
+  float* colsum;       // (gridDim.x, N) per-block column sums of GELU(y) (SKConv GAP partials) or null
+  int act;             // ACT_*
+  float slope;         // PReLU slope
+};
+
+struct ProArgs {
+  const float* ln_w;   // LayerNorm affine (K) -- PRO_LN
+  const float* ln_b;
+  float eps;
+  const float* sel;    // PRO_SKSEL: attention vectors A (B, G, K) ; x is (M, G*K)
+  int rows_per_image;  // PRO_SKSEL: L
+  int groups;          // PRO_SKSEL: G
+  const float* addv;   // PRO_ADD: second (M,K) operand added to x before the GEMM (pos-embed add)
+};
+
+enum { PRO_NONE = 0, PRO_LN = 1, PRO_SKSEL = 2, PRO_ADD = 3 };
+
+// ---------------------------------------------------------------------------------- epilogue
+// tile (nt, mt): lane holds y[m = m_base + (l&15)][n = n_base + (l>>4)*4 + r]
+template <int NT, int MT>
+__device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, int M, int N, int ldy, float* y,
+                                         const EpiArgs& e, float* red /*LDS >= 4*BN floats or null*/, int bn_cols,
+                                         int n_block0) {
+  const int lane = threadIdx.x & 63;
+  const int lm = lane & 15, lq = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + nt * 16 + lq * 4;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool nfull = (n + 3 < N);
+    if (e.bias) {
+      if (nfull) b4 = *reinterpret_cast<const float4*>(e.bias + n);
+      else {
+        float t[4] = {0, 0, 0, 0};
+        for (int r = 0; r < 4; ++r) if (n + r < N) t[r] = e.bias[n + r];
+        b4 = make_float4(t[0], t[1], t[2], t[3]);
+      }
+    }
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = m0 + mt * 16 + lm;
+      float v[4] = {acc[nt][mt][0] + b4.x, acc[nt][mt][1] + b4.y, acc[nt][mt][2] + b4.z, acc[nt][mt][3] + b4.w};
+      if (m < M) {
+        if (e.colsum) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cs[r] += gelu_erf(v[r]);
+        }
+        if (e.act != ACT_NONE) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], e.act, e.slope);
+        }
+        const size_t off = (size_t)m * ldy + n;
+        if (nfull) {
+          if (e.res1) { float4 q = *reinterpret_cast<const float4*>(e.res1 + off); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+          if (e.res2) { float4 q = *reinterpret_cast<const float4*>(e.res2 + off); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
+          *reinterpret_cast<float4*>(y + off) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+          for (int r = 0; r < 4; ++r) if (n + r < N) {
+            float o = v[r];
+            if (e.res1) o += e.res1[off + r];
+            if (e.res2) o += e.res2[off + r];
+            y[off + r] = o;
+          }
+        }
+      }
+    }
+    if (e.colsum) {
+      // reduce over the 16 token lanes of each quad (xor 1,2,4,8 stays inside l&15), then over waves via LDS
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = cs[r];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        cs[r] = s;
+      }
+      if (lm == 0) {
+        const int wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave * bn_cols + (n - n_block0) + r] = cs[r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- whole-K
+// Block: 256 threads, tile BM=64 tokens x BN=96 features; waves 2(m) x 2(n): 32 tokens x 48 features each.
+template <int K, int PRO>
+__global__ __launch_bounds__(256) void k_gemm_wholeK(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                      float* __restrict__ y, int ldy, int M, int N, ProArgs p, EpiArgs e) {
+  constexpr int BM = 64, BN = 96, LDK = K + PAD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;               // [BM][LDK]
+  float* Ws = smem + BM * LDK;    // [BN][LDK]
+  float* red = Ws + BN * LDK;     // [4][BN] colsum scratch
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+
+  // ---- stage W tile (BN x K), zero rows beyond N
+  constexpr int KV = K / 4;
+  for (int i = tid; i < BN * KV; i += 256) {
+    const int r = i / KV, c = (i % KV) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n_blk + r < N) v = *reinterpret_cast<const float4*>(w + (size_t)(n_blk + r) * K + c);
+    *reinterpret_cast<float4*>(Ws + r * LDK + c) = v;
+  }
+  // ---- stage X tile
+  if (PRO == PRO_SKSEL) {
+    // x is (M, G*K); V[m][c] = sum_g A[b][g][c] * x[m][g*K + c]   (pgrm.py:90-92)
+    for (int i = tid; i < BM * KV; i += 256) {
+      const int r = i / KV, c = (i % KV) * 4;
+      const int m = m_blk + r;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        const int b = m / p.rows_per_image;
+        for (int g = 0; g < p.groups; ++g) {
+          const float4 a = *reinterpret_cast<const float4*>(p.sel + ((size_t)b * p.groups + g) * K + c);
+          const float4 v = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + g * K + c);
+          acc.x += a.x * v.x; acc.y += a.y * v.y; acc.z += a.z * v.z; acc.w += a.w * v.w;
+        }
+      }
+      *reinterpret_cast<float4*>(Xs + r * LDK + c) = acc;
+    }
+  } else {
+    for (int i = tid; i < BM * KV; i += 256) {
+      const int r = i / KV, c = (i % KV) * 4;
+      const int m = m_blk + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        v = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + c);
+        if (PRO == PRO_ADD) {
+          const float4 a = *reinterpret_cast<const float4*>(p.addv + (size_t)m * ldx + c);
+          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+      }
+      *reinterpret_cast<float4*>(Xs + r * LDK + c) = v;
+    }
+  }
+  __syncthreads();
+
+  if (PRO == PRO_LN) {
+    // 4 threads per row, two-pass mean / variance, normalise in place
+    const int r = tid >> 2, part = tid & 3;
+    constexpr int PER = K / 4;
+    float* row = Xs + r * LDK + part * PER;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += row[i];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+    const float mean = s * (1.0f / K);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = row[i] - mean; q += d * d; }
+    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / K) + p.eps);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int k = part * PER + i;
+      row[i] = (row[i] - mean) * rstd * p.ln_w[k] + p.ln_b[k];
+    }
+    __syncthreads();
+  }
+
+  // ---- MFMA: wave (wm, wn) -> 2 m-tiles x 3 n-tiles
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const float* xa = Xs + (wm * 32 + lr) * LDK + kq * 4;
+  const float* wa = Ws + (wn * 48 + lr) * LDK + kq * 4;
+#pragma unroll
+  for (int kc = 0; kc < K; kc += 16) {
+    float4 xf[2], wf[3];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const float4*>(xa + j * 16 * LDK + kc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const float4*>(wa + i * 16 * LDK + kc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        acc[i][j] = mfma16(wf[i].x, xf[j].x, acc[i][j]);
+        acc[i][j] = mfma16(wf[i].y, xf[j].y, acc[i][j]);
+        acc[i][j] = mfma16(wf[i].z, xf[j].z, acc[i][j]);
+        acc[i][j] = mfma16(wf[i].w, xf[j].w, acc[i][j]);
+      }
+  }
+
+  epilogue<3, 2>(acc, m_blk + wm * 32, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk);
+
+  if (e.colsum) {
+    __syncthreads();
+    // waves with the same wn cover the same columns: sum the two wm halves
+    for (int c = tid; c < BN; c += 256) {
+      const int wn_c = c / 48;
+      const float s = red[(wn_c * 2 + 0) * BN + c] + red[(wn_c * 2 + 1) * BN + c];
+      if (n_blk + c < N) e.colsum[(size_t)blockIdx.x * N + n_blk + c] = s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- k-loop
+// Block 256 threads; tile BM=64 x BN=96, BK=32, register-prefetch double buffering.
+__global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
+                                                     float* __restrict__ y, int ldy, int M, int N, int K, EpiArgs e) {
+  constexpr int BM = 64, BN = 96, BK = 32, LDK = BK + PAD;
+  __shared__ __attribute__((aligned(16))) float Xs[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  // loader mapping: 8 float4 per row
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;   // rows 0..31 (+32 per pass)
+  float4 xr[2], wr[3];
+
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int m = m_blk + lrow + p * 32;
+      xr[p] = (m < M) ? *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k0 + lcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int n = n_blk + lrow + p * 32;
+      wr[p] = (n < N) ? *reinterpret_cast<const float4*>(w + (size_t)n * ldw + k0 + lcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * 32) * LDK + lcol]) = xr[p];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * 32) * LDK + lcol]) = wr[p];
+  };
+
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int nk = K / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const float* xa = &Xs[buf][(wm * 32 + lr) * LDK + kq * 4];
+    const float* wa = &Ws[buf][(wn * 48 + lr) * LDK + kq * 4];
+#pragma unroll
+    for (int kc = 0; kc < BK; kc += 16) {
+      float4 xf[2], wf[3];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const float4*>(xa + j * 16 * LDK + kc);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const float4*>(wa + i * 16 * LDK + kc);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j] = mfma16(wf[i].x, xf[j].x, acc[i][j]);
+          acc[i][j] = mfma16(wf[i].y, xf[j].y, acc[i][j]);
+          acc[i][j] = mfma16(wf[i].z, xf[j].z, acc[i][j]);
+          acc[i][j] = mfma16(wf[i].w, xf[j].w, acc[i][j]);
+        }
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  epilogue<3, 2>(acc, m_blk + wm * 32, n_blk + wn * 48, M, N, ldy, y, e, nullptr, BN, n_blk);
+}
+
+// ---------------------------------------------------------------------------------- batched NN
+// z[b][co][s] = sum_c w[co][c] * g[b][c][s] + bias[co]      (pointwise 1x1 conv, pgrm.py:37)
+// g, z are the raw (B, Ch, L) views of token buffers (quirk Q2).  Output is s-contiguous, so the
+// MFMA "A" operand carries s (from the [k][s] tile via ds_read_b32) and "B" carries co.
+// Block 256 threads, tile 128 (s) x 128 (co), BK = 16; waves 2(s) x 2(co): 64 x 64 each.
+__global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ z, int Ch, int L) {
+  constexpr int BS = 128, BC = 128, BK = 16, LDS_G = BS + 4, LDS_W = BK + PAD;
+  __shared__ __attribute__((aligned(16))) float Gs[2][BK * LDS_G];
+  __shared__ __attribute__((aligned(16))) float Wsm[2][BC * LDS_W];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s_blk = blockIdx.x * BS, c_blk = blockIdx.y * BC, b = blockIdx.z;
+  const float* gb = g + (size_t)b * Ch * L;
+  float* zb = z + (size_t)b * Ch * L;
+
+  // loaders: G chunk = 16 rows(k) x 128 s = 512 float4 -> 2 per thread ; W chunk = 128 rows x 16 k = 512 float4
+  const int grow = tid >> 5, gcol = (tid & 31) * 4;   // rows 0..7 (+8)
+  const int wrow = tid >> 2, wcol = (tid & 3) * 4;    // rows 0..63 (+64)
+  float4 g0, g1, w0, w1;
+#define PW_GLOAD(k0)                                                                                   \
+  do {                                                                                                 \
+    g0 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + grow) * L + s_blk + gcol);              \
+    g1 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + grow + 8) * L + s_blk + gcol);          \
+    w0 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow) * Ch + (k0) + wcol);              \
+    w1 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 64) * Ch + (k0) + wcol);         \
+  } while (0)
+#define PW_SSTORE(buf)                                                                                 \
+  do {                                                                                                 \
+    *reinterpret_cast<float4*>(&Gs[buf][grow * LDS_G + gcol]) = g0;                                    \
+    *reinterpret_cast<float4*>(&Gs[buf][(grow + 8) * LDS_G + gcol]) = g1;                              \
+    *reinterpret_cast<float4*>(&Wsm[buf][wrow * LDS_W + wcol]) = w0;                                   \
+    *reinterpret_cast<float4*>(&Wsm[buf][(wrow + 64) * LDS_W + wcol]) = w1;                            \
+  } while (0)
+
+  const int ws_ = wave & 1, wc_ = wave >> 1;
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[4][4];   // [s tile][co tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  PW_GLOAD(0);
+  PW_SSTORE(0);
+  __syncthreads();
+  const int nk = Ch / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) PW_GLOAD((kt + 1) * BK);
+    f32x4 wf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const f32x4*>(&Wsm[buf][(wc_ * 64 + j * 16 + lr) * LDS_W + kq * 4]);
+    const float* gp = &Gs[buf][(kq * 4) * LDS_G + ws_ * 64 + lr];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float a0 = gp[st * LDS_G], a1 = gp[st * LDS_G + 16], a2 = gp[st * LDS_G + 32], a3 = gp[st * LDS_G + 48];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float bv = wf[j][st];
+        acc[0][j] = mfma16(a0, bv, acc[0][j]);
+        acc[1][j] = mfma16(a1, bv, acc[1][j]);
+        acc[2][j] = mfma16(a2, bv, acc[2][j]);
+        acc[3][j] = mfma16(a3, bv, acc[3][j]);
+      }
+    }
+    if (kt + 1 < nk) PW_SSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef PW_GLOAD
+#undef PW_SSTORE
+  // lane holds z[co = c0 + j*16 + (l&15)][s = s0 + i*16 + (l>>4)*4 + r]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int co = c_blk + wc_ * 64 + j * 16 + lr;
+    const float bv = bias[co];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = s_blk + ws_ * 64 + i * 16 + kq * 4;
+      *reinterpret_cast<float4*>(zb + (size_t)co * L + s) =
+          make_float4(acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+    }
+  }
+}
+
+template <int K, int PRO>
+int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
+                  const EpiArgs& e, hipStream_t st) {
+  const size_t smem = (size_t)((64 + 96) * (K + PAD) + 4 * 96) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wholeK<K, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(cdiv(M, 64), cdiv(N, 96));
+  hipLaunchKernelGGL((k_gemm_wholeK<K, PRO>), grid, dim3(256), smem, st, x, ldx, w, y, ldy, M, N, p, e);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+template <int PRO>
+int dispatch_wholeK(int K, const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
+                    const EpiArgs& e, hipStream_t st) {
+  switch (K) {
+    case 32: return launch_wholeK<32, PRO>(x, ldx, w, y, ldy, M, N, p, e, st);
+    case 64: return launch_wholeK<64, PRO>(x, ldx, w, y, ldy, M, N, p, e, st);
+    case 96: return launch_wholeK<96, PRO>(x, ldx, w, y, ldy, M, N, p, e, st);
+    case 128: return launch_wholeK<128, PRO>(x, ldx, w, y, ldy, M, N, p, e, st);
+    case 192: return launch_wholeK<192, PRO>(x, ldx, w, y, ldy, M, N, p, e, st);
+    default: return dpmn_set_error(DPMN_ERR_ARG, "whole-K GEMM supports K in {32,64,96,128,192}");
+  }
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" {
+
+int dpmn_linear_f32(const float* x, const float* w, const float* bias, const float* res1, const float* res2, float* y,
+                    int M, int N, int K, int act, float slope, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, "linear: null pointer or empty shape");
+  DPMN_REQUIRE(N % 4 == 0, "linear: N must be a multiple of 4");
+  EpiArgs e{bias, res1, res2, nullptr, act, slope};
+  ProArgs p{};
+  if (K == 32 || K == 64 || K == 96 || K == 128 || K == 192)
+    return dispatch_wholeK<PRO_NONE>(K, x, K, w, y, N, M, N, p, e, as_stream(stream));
+  DPMN_REQUIRE(K % 32 == 0, "linear: K must be a multiple of 32");
+  dim3 grid(cdiv(M, 64), cdiv(N, 96));
+  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_add_linear_f32(const float* x, const float* addv, const float* w, const float* bias, float* y, int M, int N,
+                        int K, int act, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && addv && w && y && M > 0 && N % 4 == 0, "add_linear: bad arguments");
+  EpiArgs e{bias, nullptr, nullptr, nullptr, act, 0.f};
+  ProArgs p{};
+  p.addv = addv;
+  return dispatch_wholeK<PRO_ADD>(K, x, K, w, y, N, M, N, p, e, as_stream(stream));
+}
+
+int dpmn_ln_linear_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* w,
+                       const float* bias, float* y, int M, int N, int K, int act, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && ln_w && ln_b && w && y && M > 0 && N % 4 == 0, "ln_linear: bad arguments");
+  EpiArgs e{bias, nullptr, nullptr, nullptr, act, 0.f};
+  ProArgs p{};
+  p.ln_w = ln_w; p.ln_b = ln_b; p.eps = eps;
+  return dispatch_wholeK<PRO_LN>(K, x, K, w, y, N, M, N, p, e, as_stream(stream));
+}
+
+int dpmn_sk_proj_f32(const float* cat, const float* w, const float* bias, float* feats, float* colsum_partials, int M,
+                     int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(cat && w && feats && colsum_partials && C % 4 == 0, "sk_proj: bad arguments");
+  EpiArgs e{bias, nullptr, nullptr, colsum_partials, ACT_NONE, 0.f};
+  ProArgs p{};
+  return dispatch_wholeK<PRO_NONE>(C, cat, C, w, feats, C, M, C, p, e, as_stream(stream));
+}
+
+int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_head, const float* b_head,
+                       const float* feats, const float* shortcut, float* out, int M, int rows_per_image, int C,
+                       int groups, dpmn_stream_t stream) {
+  DPMN_REQUIRE(cat && attn_vec && w_head && feats && shortcut && out && C % groups == 0, "sk_select: bad arguments");
+  EpiArgs e{b_head, feats, shortcut, nullptr, ACT_NONE, 0.f};
+  ProArgs p{};
+  p.sel = attn_vec; p.rows_per_image = rows_per_image; p.groups = groups;
+  return dispatch_wholeK<PRO_SKSEL>(C / groups, cat, C, w_head, out, C, M, C, p, e, as_stream(stream));
+}
+
+int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
+                       dpmn_stream_t stream) {
+  DPMN_REQUIRE(g && w && bias && z && Ch % 128 == 0 && L % 128 == 0, "pointwise: Ch and L must be multiples of 128");
+  dim3 grid(L / 128, Ch / 128, B);
+  hipLaunchKernelGGL(k_gemm_pw, grid, dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,477 @@
+// PGRM-specific kernels (everything that is not a plain GEMM) and the native forward driver.
+//
+// Token layout: (B, L, C) row-major fp32 with token t <-> (t / W, t % W) -- the reference's own
+// layout (pgrm.py:423), i.e. NHWC over the 16x64 patch grid.  The window-attention output is
+// written in WINDOW-MAJOR order without un-roll / window_reverse (quirk Q1, pgrm.py:263), which is
+// exactly the contiguous order in which a per-window workgroup produces it.
+//
+// Reference lines: PatchEmbed 419-426 (+prior_fusion 548), WindowAttention.forward 197-266,
+// SKConv gate 86-91, Mlp depthwise 34-36, tail 559-565, SwinTransformerBlock.forward 315-331,
+// PGRM.forward 546-565.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- patch embed
+// One wave = 16 tokens; lane -> (token = l>>2, channel quarter = l&3).  Optional fused
+// prior_fusion conv3x3 (2->3, pad 1) evaluated on the 2x2 pixels of the patch.
+template <int C>
+__global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict__ img, int cin, const float* __restrict__ pf_w,
+                                                         const float* __restrict__ pf_b, const float* __restrict__ pe_w,
+                                                         const float* __restrict__ pe_b, const float* __restrict__ ln_w,
+                                                         const float* __restrict__ ln_b, float* __restrict__ tok, int B,
+                                                         int Hi, int Wi, int patch) {
+  constexpr int CQ = C / 4;
+  const int Ht = Hi / patch, Wt = Wi / patch;
+  const int lane = threadIdx.x & 63;
+  const long token = (long)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + (lane >> 2);
+  const int part = lane & 3;
+  if (token >= (long)B * Ht * Wt) return;
+  const int b = token / (Ht * Wt), t = token % (Ht * Wt);
+  const int th = t / Wt, tw = t % Wt;
+  const int KP = 3 * patch * patch;  // inputs per token after fusion (3 channels)
+  float in[48];                      // patch <= 4 -> 3*16
+  if (pf_w) {
+    // fused pixels p(c, dy, dx) = b[c] + sum_{ci,ky,kx} w[c][ci][ky][kx] * img[ci][y+ky-1][x+kx-1]
+    for (int dy = 0; dy < patch; ++dy)
+      for (int dx = 0; dx < patch; ++dx) {
+        const int y = th * patch + dy, x = tw * patch + dx;
+        float a[3] = {pf_b[0], pf_b[1], pf_b[2]};
+        for (int ci = 0; ci < cin; ++ci)
+          for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            if (yy < 0 || yy >= Hi) continue;
+            for (int kx = 0; kx < 3; ++kx) {
+              const int xx = x + kx - 1;
+              if (xx < 0 || xx >= Wi) continue;
+              const float v = img[(((size_t)b * cin + ci) * Hi + yy) * Wi + xx];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) a[c] += pf_w[((c * cin + ci) * 3 + ky) * 3 + kx] * v;
+            }
+          }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) in[(c * patch + dy) * patch + dx] = a[c];
+      }
+  } else {
+    for (int c = 0; c < 3; ++c)
+      for (int dy = 0; dy < patch; ++dy)
+        for (int dx = 0; dx < patch; ++dx)
+          in[(c * patch + dy) * patch + dx] = img[(((size_t)b * cin + c) * Hi + th * patch + dy) * Wi + tw * patch + dx];
+  }
+  float o[CQ];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int c = part * CQ + i;
+    float a = pe_b[c];
+    for (int k = 0; k < KP; ++k) a += pe_w[c * KP + k] * in[k];
+    o[i] = a;
+    s += a;
+  }
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+  const float mean = s * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) { const float d = o[i] - mean; q += d * d; }
+  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+  float* dst = tok + (size_t)token * C + part * CQ;
+#pragma unroll
+  for (int i = 0; i < CQ; i += 4) {
+    const int c = part * CQ + i;
+    *reinterpret_cast<float4*>(dst + i) = make_float4((o[i] - mean) * rstd * ln_w[c] + ln_b[c],
+                                                      (o[i + 1] - mean) * rstd * ln_w[c + 1] + ln_b[c + 1],
+                                                      (o[i + 2] - mean) * rstd * ln_w[c + 2] + ln_b[c + 2],
+                                                      (o[i + 3] - mean) * rstd * ln_w[c + 3] + ln_b[c + 3]);
+  }
+}
+
+// ---------------------------------------------------------------------------------- window attention
+// Work unit ("slab") = 64 consecutive window-major tokens of one (image, group): 1 window of 8x8,
+// 4 of 4x4, 16 of 2x2 (or a quarter of a 16x16 window's queries in the stress config).
+// Block = 256 threads = 2 slabs x 2 heads, one wave per (slab, head), lane = query row.
+// K/V (and Q, for coalescing) of the slab's windows are staged in LDS: rows of CG floats; every lane
+// of a window reads the same K/V row at a time (LDS broadcast).  Softmax is online over 16-key chunks.
+// HBM-bound: 4*L*C*4 bytes per image per block against 11 MFLOP.
+template <int WS, int D>   // D = head dim; channels per group CG = 2*D (two heads per group)
+__global__ __launch_bounds__(256) void k_window_attn(const float* __restrict__ q, const float* __restrict__ kv,
+                                                      const float* __restrict__ bias_table, float* __restrict__ out, int B,
+                                                      int H, int W, int C, int g, int shift) {
+  constexpr int N = WS * WS;
+  constexpr int CG = 2 * D;
+  constexpr int QROWS = 64;                     // queries per slab
+  constexpr int KROWS = (N > 64) ? N : 64;      // keys resident per slab (whole windows)
+  constexpr int LDR = CG + 4;                   // padded row (floats)
+  constexpr int TBL = (2 * WS - 1) * (2 * WS - 1);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tbl = smem;                            // [TBL][2]
+  float* base = smem + ((TBL * 2 + 3) & ~3);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slab_in_blk = wave >> 1, head = wave & 1;
+  float* Qs = base + slab_in_blk * (QROWS + 2 * KROWS) * LDR;
+  float* Ks = Qs + QROWS * LDR;
+  float* Vs = Ks + KROWS * LDR;
+  int* reg_s = reinterpret_cast<int*>(base + 2 * (QROWS + 2 * KROWS) * LDR) + slab_in_blk * KROWS;
+
+  const int L = H * W;
+  const int slabs_per_img = L / QROWS;
+  const long slab = (long)blockIdx.x * 2 + slab_in_blk;
+  const int b = slab / slabs_per_img;
+  const int t0 = (slab % slabs_per_img) * QROWS;        // first window-major token of the slab
+  const int nWc = W / WS;
+  const bool active = b < B;
+
+  for (int i = threadIdx.x; i < TBL * 2; i += 256) tbl[i] = bias_table[i];
+
+  // key range: whole windows covering the slab
+  const int k0 = (N > 64) ? (t0 / N) * N : t0;
+  // ---- stage Q (64 rows), K, V (KROWS rows) of this slab: the 128 threads of the slab's two waves cooperate
+  if (active) {
+    const int tl = threadIdx.x & 127;
+    constexpr int V4 = CG / 4;
+    for (int i = tl; i < KROWS * V4; i += 128) {
+      const int r = i / V4, c4 = (i % V4) * 4;
+      const int t = k0 + r;
+      const int win = t / N, n = t % N;
+      const int wr = win / nWc, wc = win % nWc;
+      const int hr = wr * WS + n / WS, wcol = wc * WS + n % WS;      // rolled-frame coordinates
+      const int sh = (hr + shift) % H, sw = (wcol + shift) % W;     // source token (roll by -shift)
+      const size_t src = (size_t)b * L + sh * W + sw;
+      *reinterpret_cast<float4*>(Ks + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + src * 2 * C + g * CG + c4);
+      *reinterpret_cast<float4*>(Vs + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + src * 2 * C + C + g * CG + c4);
+      if (t >= t0 && t < t0 + QROWS)
+        *reinterpret_cast<float4*>(Qs + (t - t0) * LDR + c4) = *reinterpret_cast<const float4*>(q + src * C + g * CG + c4);
+      if (c4 == 0) {
+        int rh = hr < H - WS ? 0 : (hr < H - shift ? 1 : 2);
+        int rw = wcol < W - WS ? 0 : (wcol < W - shift ? 1 : 2);
+        reg_s[r] = 3 * rh + rw;
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+
+  // ---- lane = query row
+  const int tq = t0 + lane;
+  const int nq = tq % N;
+  const int krow0 = (N > 64) ? 0 : (lane / N) * N;   // first key row (in Ks) of this lane's window
+  const int iq = nq / WS, jq = nq % WS;
+  const int my_reg = reg_s[tq - k0];
+  float qv[D];
+  const float scale = 1.0f / sqrtf((float)D);
+#pragma unroll
+  for (int d = 0; d < D; d += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(Qs + lane * LDR + head * D + d);
+    qv[d] = v.x * scale; qv[d + 1] = v.y * scale; qv[d + 2] = v.z * scale; qv[d + 3] = v.w * scale;
+  }
+  float o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+  float mx = -INFINITY, den = 0.f;
+  constexpr int CH = (N < 16) ? N : 16;
+  for (int m0 = 0; m0 < N; m0 += CH) {
+    float sc[CH];
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int mm = 0; mm < CH; ++mm) {
+      const int m = m0 + mm;
+      const float* kr = Ks + (krow0 + m) * LDR + head * D;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; d += 4) {
+        const float4 kk = *reinterpret_cast<const float4*>(kr + d);
+        a += qv[d] * kk.x + qv[d + 1] * kk.y + qv[d + 2] * kk.z + qv[d + 3] * kk.w;
+      }
+      const int im = m / WS, jm = m % WS;
+      a += tbl[((iq - im + WS - 1) * (2 * WS - 1) + (jq - jm + WS - 1)) * 2 + head];
+      if (shift > 0 && reg_s[krow0 + m] != my_reg) a += -100.0f;
+      sc[mm] = a;
+      cmax = fmaxf(cmax, a);
+    }
+    const float nmx = fmaxf(mx, cmax);
+    const float resc = expf(mx - nmx);   // exp(-inf) = 0 on the first chunk
+    den *= resc;
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[d] *= resc;
+#pragma unroll
+    for (int mm = 0; mm < CH; ++mm) {
+      const float p = expf(sc[mm] - nmx);
+      den += p;
+      const float* vr = Vs + (krow0 + m0 + mm) * LDR + head * D;
+#pragma unroll
+      for (int d = 0; d < D; d += 4) {
+        const float4 vv = *reinterpret_cast<const float4*>(vr + d);
+        o[d] += p * vv.x; o[d + 1] += p * vv.y; o[d + 2] += p * vv.z; o[d + 3] += p * vv.w;
+      }
+    }
+    mx = nmx;
+  }
+  const float inv = 1.0f / den;
+  float* dst = out + ((size_t)b * L + tq) * C + g * CG + head * D;
+#pragma unroll
+  for (int d = 0; d < D; d += 4)
+    *reinterpret_cast<float4*>(dst + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+}
+
+template <int WS, int D>
+int launch_window_attn(const float* q, const float* kv, const float* table, float* out, int B, int H, int W, int C, int g,
+                       int shift, hipStream_t st) {
+  constexpr int N = WS * WS, CG = 2 * D, KROWS = (N > 64) ? N : 64, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
+  const size_t smem = (size_t)(((TBL * 2 + 3) & ~3) + 2 * (64 + 2 * KROWS) * LDR) * 4 + 2 * KROWS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn<WS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const long slabs = (long)B * (H * W / 64);
+  hipLaunchKernelGGL((k_window_attn<WS, D>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, table, out, B, H, W,
+                     C, g, shift);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// ---------------------------------------------------------------------------------- SK gate
+// per image: S = mean_t GELU(feats) (from per-block partials) -> fc1 -> GELU -> fc2 -> softmax over groups
+__global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image, int L, const float* __restrict__ fc1_w,
+                          const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, const float* __restrict__ fc2_b,
+                          float* __restrict__ attn_vec, int C, int G, int dmid) {
+  extern __shared__ float sm[];
+  float* S = sm;            // [C]
+  float* Z = sm + C;        // [dmid]
+  float* A = Z + dmid;      // [C]
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < parts_per_image; ++p) s += partial[((size_t)b * parts_per_image + p) * C + c];
+    S[c] = s / (float)L;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < dmid; j += blockDim.x) {
+    float a = fc1_b[j];
+    for (int c = 0; c < C; ++c) a += fc1_w[j * C + c] * S[c];
+    Z[j] = gelu_erf(a);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = fc2_b[c];
+    for (int j = 0; j < dmid; ++j) a += fc2_w[c * dmid + j] * Z[j];
+    A[c] = a;
+  }
+  __syncthreads();
+  const int cg = C / G;
+  for (int c = threadIdx.x; c < cg; c += blockDim.x) {
+    float mx = -INFINITY;
+    for (int g = 0; g < G; ++g) mx = fmaxf(mx, A[g * cg + c]);
+    float den = 0.f;
+    for (int g = 0; g < G; ++g) den += expf(A[g * cg + c] - mx);
+    for (int g = 0; g < G; ++g) attn_vec[((size_t)b * G + g) * cg + c] = expf(A[g * cg + c] - mx) / den;
+  }
+}
+
+// ---------------------------------------------------------------------------------- depthwise 3x3 + GELU
+// planes of r x r (raw reinterpretation of the (B, L, Ch) fc1 output, quirk Q2); one block per 4 planes
+__global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ g, int Ch, int r,
+                                                      long planes) {
+  extern __shared__ float sm[];   // [ (r+2) * (r+2) ] per wave
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long plane = (long)blockIdx.x * 4 + wave;
+  const bool valid = plane < planes;
+  const int c = valid ? (int)(plane % Ch) : 0;
+  const int LD = r + 2;
+  float* t = sm + wave * LD * LD;
+  if (valid) {
+    const float* src = y + plane * r * r;
+    for (int i = lane; i < LD * LD; i += 64) {
+      const int yy = i / LD - 1, xx = i % LD - 1;
+      t[i] = (yy >= 0 && yy < r && xx >= 0 && xx < r) ? src[yy * r + xx] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+  float k[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) k[i] = w[c * 9 + i];
+  const float bv = bias[c];
+  float* dst = g + plane * r * r;
+  for (int i = lane; i < r * r; i += 64) {
+    const int yy = i / r, xx = i % r;
+    const float* p = t + yy * LD + xx;
+    float a = bv;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) a += k[ky * 3 + kx] * p[ky * LD + kx];
+    dst[i] = gelu_erf(a);
+  }
+}
+
+// ---------------------------------------------------------------------------------- tail
+// conv3x3 C->Cm on the token grid (NHWC in, NHWC out), direct VALU: small Cm (12).
+// thread = (pixel, output channel); weights in reference layout (Cm, C, 3, 3).
+__global__ __launch_bounds__(256) void k_tail_conv1(const float* __restrict__ tok, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ mid, int B, int H, int W,
+                                                     int C, int Cm) {
+  extern __shared__ float wsm[];  // [9][C][Cm] repacked
+  for (int i = threadIdx.x; i < 9 * C * Cm; i += blockDim.x) {
+    const int co = i % Cm, ci = (i / Cm) % C, tap = i / (Cm * C);
+    wsm[i] = w[(co * C + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W * Cm;
+  if (idx >= total) return;
+  const int co = idx % Cm;
+  const long pix = idx / Cm;
+  const int x = pix % W, y = (pix / W) % H, b = pix / ((long)W * H);
+  float a = bias[co];
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = y + ky - 1;
+    if (yy < 0 || yy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = x + kx - 1;
+      if (xx < 0 || xx >= W) continue;
+      const float* src = tok + (((size_t)b * H + yy) * W + xx) * C;
+      const float* wp = wsm + (size_t)(ky * 3 + kx) * C * Cm + co;
+      for (int ci = 0; ci < C; ci += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(src + ci);
+        a += v.x * wp[ci * Cm] + v.y * wp[(ci + 1) * Cm] + v.z * wp[(ci + 2) * Cm] + v.w * wp[(ci + 3) * Cm];
+      }
+    }
+  }
+  mid[idx] = a;
+}
+
+// conv3x3 Cm->Cm + LeakyReLU(0.01) + PixelShuffle(p) + * weight_list_0 + sum_i residual_i * weight_list_i
+// output NCHW (B, hid, H*p, W*p); thread = (pixel, output channel)
+struct TailResid {
+  const float* res[8];
+  const float* wl[8];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_tail_conv2(const float* __restrict__ mid, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, const float* __restrict__ wl0, TailResid tr,
+                                                     float* __restrict__ out, int B, int H, int W, int Cm, int p) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W * Cm;
+  if (idx >= total) return;
+  const int co = idx % Cm;
+  const long pix = idx / Cm;
+  const int x = pix % W, y = (pix / W) % H, b = pix / ((long)W * H);
+  float a = bias[co];
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = y + ky - 1;
+    if (yy < 0 || yy >= H) continue;
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = x + kx - 1;
+      if (xx < 0 || xx >= W) continue;
+      const float* src = mid + (((size_t)b * H + yy) * W + xx) * Cm;
+      for (int ci = 0; ci < Cm; ++ci) a += src[ci] * w[((co * Cm + ci) * 3 + ky) * 3 + kx];
+    }
+  }
+  a = a > 0.f ? a : 0.01f * a;
+  // PixelShuffle: out[b, c, y*p+dy, x*p+dx] = in[b, c*p*p + dy*p + dx, y, x]
+  const int hid = Cm / (p * p);
+  const int c = co / (p * p), dy = (co / p) % p, dx = co % p;
+  const int Ho = H * p, Wo = W * p;
+  const size_t plane_off = ((size_t)c * Ho + (y * p + dy)) * Wo + (x * p + dx);   // within (hid, Ho, Wo)
+  const size_t o = (size_t)b * hid * Ho * Wo + plane_off;
+  float v = a * wl0[plane_off];
+  for (int i = 0; i < tr.n; ++i) v += tr.res[i][o] * tr.wl[i][plane_off];
+  out[o] = v;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" {
+
+int dpmn_patch_embed_ln_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                            const float* pe_b, const float* ln_w, const float* ln_b, float* tokens, int B, int Hi, int Wi,
+                            int patch, int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(img && pe_w && pe_b && ln_w && ln_b && tokens, "patch_embed: null pointer");
+  DPMN_REQUIRE(patch >= 1 && patch <= 4 && Hi % patch == 0 && Wi % patch == 0, "patch_embed: bad patch size");
+  DPMN_REQUIRE((pf_w != nullptr) || cin >= 3, "patch_embed: need 3 input channels without prior_fusion");
+  const long tokens_n = (long)B * (Hi / patch) * (Wi / patch);
+  dim3 grid((unsigned)((tokens_n + 63) / 64));
+  if (C == 96)
+    hipLaunchKernelGGL((k_patch_embed_ln<96>), grid, dim3(256), 0, as_stream(stream), img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, ln_b, tokens, B, Hi, Wi, patch);
+  else if (C == 192)
+    hipLaunchKernelGGL((k_patch_embed_ln<192>), grid, dim3(256), 0, as_stream(stream), img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, ln_b, tokens, B, Hi, Wi, patch);
+  else
+    return dpmn_set_error(DPMN_ERR_ARG, "patch_embed: embed dim must be 96 or 192");
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_window_attn_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                         const int* shifts, int n_groups, int heads_per_group, float* out, int B, int H, int W, int C,
+                         dpmn_stream_t stream) {
+  DPMN_REQUIRE(q && kv && bias_tables && windows && shifts && out, "window_attn: null pointer");
+  DPMN_REQUIRE(heads_per_group == 2, "window_attn: two heads per group (num_heads = 2 * n_groups)");
+  DPMN_REQUIRE(C % n_groups == 0, "window_attn: C must divide into groups");
+  const int D = C / n_groups / heads_per_group;
+  DPMN_REQUIRE((H * W) % 64 == 0, "window_attn: token count must be a multiple of 64");
+  hipStream_t st = as_stream(stream);
+  for (int g = 0; g < n_groups; ++g) {
+    const int ws = windows[g], sh = shifts[g];
+    DPMN_REQUIRE(H % ws == 0 && W % ws == 0, "window_attn: padding path (H or W not divisible by window) would crash the reference (quirk Q1)");
+    DPMN_REQUIRE(sh >= 0 && sh < ws, "window_attn: shift must be in [0, window)");
+    int rc = DPMN_ERR_ARG;
+#define WA_CASE(WSV, DV) if (ws == WSV && D == DV) rc = launch_window_attn<WSV, DV>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st); else
+    WA_CASE(2, 16) WA_CASE(4, 16) WA_CASE(8, 16) WA_CASE(4, 32) WA_CASE(8, 32)
+    return dpmn_set_error(DPMN_ERR_ARG, "window_attn: unsupported (window, head_dim); built: {2,4,8}x16, {4,8}x32");
+#undef WA_CASE
+    if (rc != DPMN_OK) return rc;
+  }
+  return DPMN_OK;
+}
+
+int dpmn_sk_gate_f32(const float* colsum_partials, int parts_per_image, int L, const float* fc1_w, const float* fc1_b,
+                     const float* fc2_w, const float* fc2_b, float* attn_vec, int B, int C, int groups, int dmid,
+                     dpmn_stream_t stream) {
+  DPMN_REQUIRE(colsum_partials && fc1_w && fc1_b && fc2_w && fc2_b && attn_vec, "sk_gate: null pointer");
+  DPMN_REQUIRE(B >= 2, "sk_gate: per-rank batch of 1 changes SKConv semantics in the reference (squeeze(), quirk Q3)");
+  hipLaunchKernelGGL(k_sk_gate, dim3(B), dim3(128), (size_t)(2 * C + dmid) * 4, as_stream(stream), colsum_partials,
+                     parts_per_image, L, fc1_w, fc1_b, fc2_w, fc2_b, attn_vec, C, groups, dmid);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r,
+                            dpmn_stream_t stream) {
+  DPMN_REQUIRE(y && w && bias && g && r >= 3 && r <= 64, "dwconv: bad arguments");
+  const long planes = (long)B * Ch;
+  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), (size_t)4 * (r + 2) * (r + 2) * 4,
+                     as_stream(stream), y, w, bias, g, Ch, r, planes);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, const float* w1, const float* b1,
+                       const float* const* weight_list, const float* const* residuals, int n_residuals, float* mid_ws,
+                       float* out, int B, int H, int W, int C, int hidden, int patch, dpmn_stream_t stream) {
+  DPMN_REQUIRE(tokens && w0 && b0 && w1 && b1 && weight_list && mid_ws && out, "tail: null pointer");
+  DPMN_REQUIRE(n_residuals >= 0 && n_residuals <= 8, "tail: at most 8 residuals");
+  const int Cm = hidden * patch * patch;
+  const size_t smem = (size_t)9 * C * Cm * 4;
+  DPMN_REQUIRE(smem <= 64 * 1024, "tail: conv weights must fit 64 KB of LDS");
+  const long total = (long)B * H * W * Cm;
+  hipLaunchKernelGGL(k_tail_conv1, dim3((unsigned)((total + 255) / 256)), dim3(256), smem, as_stream(stream), tokens, w0, b0,
+                     mid_ws, B, H, W, C, Cm);
+  DPMN_CHECK_LAUNCH();
+  TailResid tr{};
+  // quirk Q11: residual_list[0] is never added -- the loop starts at 1 (pgrm.py:563)
+  tr.n = 0;
+  for (int i = 1; i < n_residuals; ++i) {
+    tr.res[tr.n] = residuals[i];
+    tr.wl[tr.n] = weight_list[i];
+    ++tr.n;
+  }
+  hipLaunchKernelGGL(k_tail_conv2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), mid_ws, w1, b1,
+                     weight_list[0], tr, out, B, H, W, Cm, patch);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+}  // extern "C"

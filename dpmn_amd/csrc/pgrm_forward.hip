@@ -1,0 +1,96 @@
+// Native driver for one PGRM forward: launches the fused kernels in order on one stream.
+// Replaces PGRM.forward / BasicLayer.forward / SwinTransformerBlock.forward / WindowAttention.forward
+// / SKConv.forward / Mlp.forward (pgrm.py:546-565, 375-384, 315-331, 184-271, 79-96, 29-41).
+#include "common.h"
+#include <math.h>
+
+namespace {
+struct Ws {
+  float *tq, *tkv, *q, *kv, *cat, *feats, *x1, *y, *g, *partial, *avec, *mid;
+  size_t total;
+};
+
+Ws carve(const dpmn_pgrm_weights* w, int B, char* base) {
+  const size_t L = (size_t)(w->img_h / w->patch) * (w->img_w / w->patch);
+  const size_t C = w->dim, Ch = w->mlp_hidden;
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += ((n * sizeof(float) + 255) / 256) * 256;
+    return p;
+  };
+  Ws s;
+  s.tq = take(B * L * C);
+  s.tkv = take(B * L * C);
+  s.q = take(B * L * C);
+  s.kv = take(B * L * 2 * C);
+  s.cat = take(B * L * C);
+  s.feats = take(B * L * C);
+  s.x1 = take(B * L * C);
+  s.y = take(B * L * Ch);
+  s.g = take(B * L * Ch);
+  s.partial = take((size_t)B * ((L + 63) / 64) * C);
+  s.avec = take((size_t)B * C);
+  s.mid = take(B * L * (size_t)w->hidden_size * w->patch * w->patch);
+  s.total = off;
+  return s;
+}
+}  // namespace
+
+extern "C" {
+
+size_t dpmn_pgrm_workspace_bytes(const dpmn_pgrm_weights* w, int B) {
+  if (!w || B <= 0) return 0;
+  return carve(w, B, nullptr).total;
+}
+
+int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_channels, const float* x_kv,
+                          const float* const* residuals, int n_residuals, float* out, void* workspace,
+                          size_t workspace_bytes, int B, dpmn_stream_t stream) {
+  DPMN_REQUIRE(w && x_q && x_kv && out && workspace, "pgrm_forward: null pointer");
+  DPMN_REQUIRE(B >= 2, "pgrm_forward: per-rank batch must be >= 2 (SKConv squeeze() quirk Q3)");
+  DPMN_REQUIRE(w->n_groups >= 1 && w->n_groups <= 4, "pgrm_forward: 1..4 window groups");
+  DPMN_REQUIRE(n_residuals <= w->n_weight_list, "pgrm_forward: more residuals than weight_list entries (iter)");
+  DPMN_REQUIRE((x_q_channels == 2) == (w->prior_fusion_w != nullptr) || x_q_channels == 3,
+               "pgrm_forward: a 2-channel text prior needs prior_fusion weights (mode=False)");
+  const int H = w->img_h / w->patch, Wd = w->img_w / w->patch, L = H * Wd, C = w->dim, Ch = w->mlp_hidden;
+  const int r = (int)lrintf(sqrtf((float)L));
+  DPMN_REQUIRE(r * r == L, "pgrm_forward: token count must be a perfect square (Mlp view, quirk Q2)");
+  Ws s = carve(w, B, static_cast<char*>(workspace));
+  if (s.total > workspace_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "pgrm_forward: workspace too small");
+  const int M = B * L;
+  int rc;
+#define RUN(call) do { rc = (call); if (rc != DPMN_OK) return rc; } while (0)
+  const bool fuse = (x_q_channels == 2);
+  RUN(dpmn_patch_embed_ln_f32(x_q, x_q_channels, fuse ? w->prior_fusion_w : nullptr, fuse ? w->prior_fusion_b : nullptr,
+                              w->pe_w, w->pe_b, w->pe_norm_w, w->pe_norm_b, s.tq, B, w->img_h, w->img_w, w->patch, C, stream));
+  RUN(dpmn_patch_embed_ln_f32(x_kv, 3, nullptr, nullptr, w->pe_w, w->pe_b, w->pe_norm_w, w->pe_norm_b, s.tkv, B, w->img_h,
+                              w->img_w, w->patch, C, stream));
+  for (int blk = 0; blk < 2; ++blk) {
+    const dpmn_pgrm_block& p = w->blocks[blk];
+    int win[4], shift[4];
+    for (int g = 0; g < w->n_groups; ++g) {
+      win[g] = w->window[g];
+      shift[g] = blk == 0 ? 0 : w->window[g] / 2;          // pgrm.py:362
+      if ((H < Wd ? H : Wd) <= win[g]) { win[g] = H < Wd ? H : Wd; shift[g] = 0; }  // pgrm.py:147-150
+    }
+    RUN(dpmn_ln_linear_f32(s.tq, p.norm1_q_w, p.norm1_q_b, 1e-5f, p.q_w, p.q_b, s.q, M, C, C, DPMN_ACT_NONE, stream));
+    RUN(dpmn_ln_linear_f32(s.tkv, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, p.kv_w, p.kv_b, s.kv, M, 2 * C, C, DPMN_ACT_NONE, stream));
+    RUN(dpmn_window_attn_f32(s.q, s.kv, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat, B, H, Wd, C, stream));
+    RUN(dpmn_sk_proj_f32(s.cat, p.sk_proj_w, p.sk_proj_b, s.feats, s.partial, M, C, stream));
+    const int cg = C / w->n_groups;
+    RUN(dpmn_sk_gate_f32(s.partial, (L + 63) / 64, L, p.sk_fc1_w, p.sk_fc1_b, p.sk_fc2_w, p.sk_fc2_b, s.avec, B, C,
+                         w->n_groups, cg / 2, stream));
+    RUN(dpmn_sk_select_f32(s.cat, s.avec, p.sk_head_w, p.sk_head_b, s.feats, s.tkv, s.x1, M, L, C, w->n_groups, stream));
+    RUN(dpmn_ln_linear_f32(s.x1, p.norm2_w, p.norm2_b, 1e-5f, p.fc1_w, p.fc1_b, s.y, M, Ch, C, DPMN_ACT_GELU, stream));
+    RUN(dpmn_dwconv3x3_gelu_f32(s.y, p.dw_w, p.dw_b, s.g, B, Ch, r, stream));
+    RUN(dpmn_pointwise_f32(s.g, p.pw_w, p.pw_b, s.y, B, Ch, L, stream));
+    RUN(dpmn_linear_f32(s.y, p.fc2_w, p.fc2_b, s.x1, nullptr, s.tkv, M, C, Ch, DPMN_ACT_NONE, 0.f, stream));
+  }
+  RUN(dpmn_pgrm_tail_f32(s.tkv, w->tail0_w, w->tail0_b, w->tail1_w, w->tail1_b, w->weight_list, residuals, n_residuals,
+                         s.mid, out, B, H, Wd, C, w->hidden_size, w->patch, stream));
+#undef RUN
+  return DPMN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's ``model/pgrm.py`` operator surface.
+
+Same constructor arguments, ``forward(x_q, x_kv, residual_list)`` signature and ``state_dict`` key
+layout as the reference PGRM (pgrm.py:460-565), so checkpoints written by
+either side load into the other.  The module only owns parameters; all arithmetic runs in
+libdpmn_hip.so (``dpmn_pgrm_forward_f32``, include/dpmn_hip.h).  There is no CPU path.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import _abi
+
+
+class _Affine(nn.Module):
+    """weight/bias holder standing in for nn.Linear / nn.Conv2d / nn.LayerNorm key names."""
+
+    def __init__(self, w_shape, b_shape=None, kind="linear"):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(*w_shape))
+        self.bias = nn.Parameter(torch.empty(*(b_shape or (w_shape[0],))))
+        self.kind = kind
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """pgrm.py:524-533: Linear trunc_normal(0.02)/0, LayerNorm (1,0), Conv2d xavier_uniform
+        with PyTorch's default bias init."""
+        w, b = self.weight, self.bias
+        with torch.no_grad():
+            if self.kind == "linear":
+                nn.init.trunc_normal_(w, std=0.02)
+                b.zero_()
+            elif self.kind == "norm":
+                w.fill_(1.0)
+                b.zero_()
+            else:
+                nn.init.xavier_uniform_(w)
+                fan_in = w[0].numel()
+                bound = 1.0 / math.sqrt(fan_in)
+                b.uniform_(-bound, bound)
+
+
+class _SK(nn.Module):
+    def __init__(self, dim, groups):
+        super().__init__()
+        ch = dim // groups
+        self.proj = _Affine((dim, dim))
+        self.fc1 = _Affine((ch // 2, dim))
+        self.fc2 = _Affine((dim, ch // 2))
+        self.proj_head = _Affine((dim, ch))
+
+
+def _rel_index(ws):
+    n = torch.arange(ws * ws)
+    i, j = n // ws, n % ws
+    return (i[:, None] - i[None, :] + ws - 1) * (2 * ws - 1) + (j[:, None] - j[None, :] + ws - 1)
+
+
+def _shift_mask(H, W, ws, shift):
+    def region(pos, size):
+        r = torch.full_like(pos, 2)
+        r[pos < size - shift] = 1
+        r[pos < size - ws] = 0
+        return r
+    t = torch.arange(H * W)
+    N = ws * ws
+    win, n = t // N, t % N
+    hr = (win // (W // ws)) * ws + n // ws
+    wr = (win % (W // ws)) * ws + n % ws
+    reg = (3 * region(hr, H) + region(wr, W)).reshape(-1, N)
+    same = reg[:, :, None] == reg[:, None, :]
+    return torch.where(same, torch.zeros(()), torch.full((), -100.0))
+
+
+class _Attn(nn.Module):
+    def __init__(self, dim, windows, shifts, num_heads, resolution):
+        super().__init__()
+        G = len(windows)
+        hpg = num_heads // G
+        assert dim % G == 0 and num_heads == hpg * G and (dim // G) % hpg == 0
+        H, W = resolution
+        for g, (ws, sh) in enumerate(zip(windows, shifts)):
+            tbl = nn.Parameter(torch.zeros((2 * ws - 1) * (2 * ws - 1), hpg))
+            nn.init.trunc_normal_(tbl, std=0.02)
+            self.register_parameter("relative_position_bias_table_%d" % g, tbl)
+            self.register_buffer("relative_position_index_%d" % g, _rel_index(ws))
+        for g, (ws, sh) in enumerate(zip(windows, shifts)):
+            # attn_mask_g is None (absent from state_dict) for unshifted blocks, like the reference
+            self.register_buffer("attn_mask_%d" % g, _shift_mask(H, W, ws, sh) if sh > 0 else None)
+        self.q = _Affine((dim, dim))
+        self.kv = _Affine((2 * dim, dim))
+        self.sknet = _SK(dim, G)
+
+
+class _Mlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = _Affine((hidden, dim))
+        self.fc2 = _Affine((dim, hidden))
+        self.depthwise_conv = _Affine((hidden, 1, 3, 3), kind="conv")
+        self.pointwise_conv = _Affine((hidden, hidden, 1, 1), kind="conv")
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, windows, shifts, num_heads, resolution, mlp_ratio):
+        super().__init__()
+        self.norm1_q = _Affine((dim,), kind="norm")
+        self.norm1_kv = _Affine((dim,), kind="norm")
+        self.attn = _Attn(dim, windows, shifts, num_heads, resolution)
+        self.norm2 = _Affine((dim,), kind="norm")
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+
+
+class _Layer(nn.Module):
+    def __init__(self, dim, windows, num_heads, resolution, mlp_ratio):
+        super().__init__()
+        H, W = resolution
+        blocks = []
+        for i in range(2):  # BasicLayer always has depth 2 (pgrm.py:506)
+            ws = [min(H, W) if min(H, W) <= w else w for w in windows]
+            sh = [0 if (i == 0 or min(H, W) <= w) else w // 2 for w in windows]
+            blocks.append(_Block(dim, ws, sh, num_heads, resolution, mlp_ratio))
+        self.blocks = nn.ModuleList(blocks)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, in_chans, dim, patch):
+        super().__init__()
+        self.proj = _Affine((dim, in_chans, patch, patch), kind="conv")
+        self.norm = _Affine((dim,), kind="norm")
+
+
+class PGRM(nn.Module):
+    """Drop-in for ``model.pgrm.PGRM`` (reference pgrm.py:462-467)."""
+
+    def __init__(self, img_size=[32, 128], patch_size=[2], in_chans=3, embed_dim=[96], depths=[1], num_heads=[[6]],
+                 window_size=[[2, 4, 8]], mlp_ratio=[4.], qkv_bias=True, qk_scale=None, drop_rate=[0.],
+                 attn_drop_rate=[0.], drop_path_rate=[0.1], iter=0, norm_layer=nn.LayerNorm, ape=False,
+                 patch_norm=True, mode=True, use_checkpoint=False, hidden_size=64, **kwargs):
+        super().__init__()
+        if depths[iter] != 1 or ape or not patch_norm or not qkv_bias or qk_scale is not None:
+            raise NotImplementedError("dpmn_amd PGRM: built for depths=1, ape=False, patch_norm=True, qkv_bias=True "
+                                      "(the only configuration interfaces/base.py:151 ever constructs)")
+        self.iter = iter
+        self.mode = mode
+        self.img_size = list(img_size)
+        self.patch = patch_size[iter]
+        self.embed_dim = embed_dim[iter]
+        self.window_size = list(window_size[iter])
+        self.num_heads = num_heads[iter][0]
+        self.mlp_ratio = mlp_ratio[iter]
+        self.hidden_size = hidden_size
+        self.drop_probs = (drop_rate[iter], attn_drop_rate[iter], drop_path_rate[iter])
+        H, W = img_size[0] // self.patch, img_size[1] // self.patch
+        self.patches_resolution = [H, W]
+        if not mode:
+            self.prior_fusion = _Affine((3, 2, 3, 3), kind="conv")
+        self.patch_embed = _PatchEmbed(in_chans, self.embed_dim, self.patch)
+        for i in range(iter + 1):
+            self.register_parameter("weight_list_%d" % i, nn.Parameter(torch.ones(1, hidden_size, *img_size)))
+        self.layers = nn.ModuleList([_Layer(self.embed_dim, self.window_size, self.num_heads, (H, W), self.mlp_ratio)])
+        pp = hidden_size * self.patch * self.patch
+        self.conv_before_upsample = nn.ModuleList([_Affine((pp, self.embed_dim, 3, 3), kind="conv"),
+                                                   _Affine((pp, pp, 3, 3), kind="conv")])
+        self._packed = None
+        self._ws = None
+
+    # ------------------------------------------------------------------ C-ABI weight table
+    def _weights(self):
+        params = list(self.parameters())
+        key = tuple(p.data_ptr() for p in params)
+        if self._packed is not None and self._packed[0] == key:
+            return self._packed[1]
+        w = _abi.PgrmWeights()
+        w.img_h, w.img_w, w.patch, w.dim = self.img_size[0], self.img_size[1], self.patch, self.embed_dim
+        w.n_groups = len(self.window_size)
+        w.heads_per_group = self.num_heads // w.n_groups
+        w.mlp_hidden = int(self.embed_dim * self.mlp_ratio)
+        w.hidden_size = self.hidden_size
+        w.n_weight_list = self.iter + 1
+        for g, ws in enumerate(self.window_size):
+            w.window[g] = ws
+        d = _abi.dptr
+        if not self.mode:
+            w.prior_fusion_w, w.prior_fusion_b = d(self.prior_fusion.weight), d(self.prior_fusion.bias)
+        pe = self.patch_embed
+        w.pe_w, w.pe_b, w.pe_norm_w, w.pe_norm_b = d(pe.proj.weight), d(pe.proj.bias), d(pe.norm.weight), d(pe.norm.bias)
+        for bi, blk in enumerate(self.layers[0].blocks):
+            b = w.blocks[bi]
+            a, sk, m = blk.attn, blk.attn.sknet, blk.mlp
+            b.norm1_q_w, b.norm1_q_b = d(blk.norm1_q.weight), d(blk.norm1_q.bias)
+            b.norm1_kv_w, b.norm1_kv_b = d(blk.norm1_kv.weight), d(blk.norm1_kv.bias)
+            b.q_w, b.q_b, b.kv_w, b.kv_b = d(a.q.weight), d(a.q.bias), d(a.kv.weight), d(a.kv.bias)
+            for g in range(w.n_groups):
+                b.bias_table[g] = d(getattr(a, "relative_position_bias_table_%d" % g))
+            b.sk_proj_w, b.sk_proj_b = d(sk.proj.weight), d(sk.proj.bias)
+            b.sk_fc1_w, b.sk_fc1_b, b.sk_fc2_w, b.sk_fc2_b = d(sk.fc1.weight), d(sk.fc1.bias), d(sk.fc2.weight), d(sk.fc2.bias)
+            b.sk_head_w, b.sk_head_b = d(sk.proj_head.weight), d(sk.proj_head.bias)
+            b.norm2_w, b.norm2_b = d(blk.norm2.weight), d(blk.norm2.bias)
+            b.fc1_w, b.fc1_b, b.fc2_w, b.fc2_b = d(m.fc1.weight), d(m.fc1.bias), d(m.fc2.weight), d(m.fc2.bias)
+            b.dw_w, b.dw_b = d(m.depthwise_conv.weight), d(m.depthwise_conv.bias)
+            b.pw_w, b.pw_b = d(m.pointwise_conv.weight), d(m.pointwise_conv.bias)
+        c0, c1 = self.conv_before_upsample[0], self.conv_before_upsample[1]
+        w.tail0_w, w.tail0_b, w.tail1_w, w.tail1_b = d(c0.weight), d(c0.bias), d(c1.weight), d(c1.bias)
+        for i in range(self.iter + 1):
+            w.weight_list[i] = d(getattr(self, "weight_list_%d" % i))
+        self._packed = (key, w)
+        return w
+
+    def forward(self, x_q, x_kv, residual_list):
+        if self.training and any(p > 0 for p in self.drop_probs):
+            raise NotImplementedError("dpmn_amd PGRM: train-mode dropout/DropPath kernels are not built yet; "
+                                      "use .eval() or zero drop rates")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("dpmn_amd PGRM: backward kernels are not built yet; call under torch.no_grad()")
+        B = x_kv.shape[0]
+        if x_q.shape[1] == 2 and self.mode:
+            raise _abi.DpmnError("PGRM(mode=True) has no prior_fusion: x_q must have 3 channels (pgrm.py:470,547)")
+        x_q = x_q.contiguous().float()
+        x_kv = x_kv.contiguous().float()
+        res = [r.contiguous().float() for r in residual_list]
+        w = self._weights()
+        need = _abi.lib.dpmn_pgrm_workspace_bytes(C.byref(w), B)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x_kv.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x_kv.device)
+        out = torch.empty(B, self.hidden_size, self.img_size[0], self.img_size[1], device=x_kv.device)
+        _abi.check(_abi.lib.dpmn_pgrm_forward_f32(C.byref(w), _abi.dptr(x_q), x_q.shape[1], _abi.dptr(x_kv),
+                                                  _abi.ptr_array(res), len(res), _abi.dptr(out), self._ws.data_ptr(),
+                                                  self._ws.numel(), B, _abi.stream()))
+        return out

@@ -1,0 +1,117 @@
+/* dpmn_hip.h -- C ABI of libdpmn_hip.so, the MI355X (gfx950) drop-in for the DPMN SR hot path.
+ *
+ * The reference (jdfxzzy/DPMN) is pure PyTorch and has no FFI of its own, so
+ * every entry point below cites the reference Python call site it replaces.  Conventions:
+ *   - plain device pointers (fp32 unless said otherwise), explicit sizes, no torch types;
+ *   - caller owns all memory, including scratch ("workspace" pointers, sizes from *_workspace_bytes);
+ *   - every call enqueues on the given hipStream_t (passed as void*) and returns immediately;
+ *   - returns DPMN_OK (0) or a negative DPMN_ERR_* code; dpmn_last_error() gives the message of the
+ *     calling thread's last failure.  No exceptions cross the boundary.  Re-entrant per stream.
+ *   - tensors use the reference's own layouts: images NCHW, PGRM tokens (B, L, C) row-major,
+ *     weights exactly as stored in the reference state_dict unless a
+ *     *_pack function is named.
+ */
+#ifndef DPMN_HIP_H
+#define DPMN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* dpmn_stream_t; /* hipStream_t */
+
+enum { DPMN_OK = 0, DPMN_ERR_ARG = -1, DPMN_ERR_LAUNCH = -2, DPMN_ERR_WORKSPACE = -3, DPMN_ERR_RUNTIME = -4 };
+
+/* activation codes (epilogues / conv prologues) */
+enum { DPMN_ACT_NONE = 0, DPMN_ACT_GELU = 1, DPMN_ACT_RELU = 2, DPMN_ACT_LEAKY02 = 3, DPMN_ACT_LEAKY001 = 4,
+       DPMN_ACT_MISH = 5, DPMN_ACT_PRELU = 6, DPMN_ACT_TANH = 7, DPMN_ACT_SIGMOID = 8 };
+
+int dpmn_abi_version(void);
+const char* dpmn_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM family (gemm.hip) */
+/* y = act(x . w^T + bias) + res1 + res2 ; x (M,K), w (N,K), y/res (M,N).  nn.Linear call sites:
+ * pgrm.py:39 (Mlp.fc2 + residual 330), tatt.py:209, transformer_v2.py:453/785 FFNs. */
+int dpmn_linear_f32(const float* x, const float* w, const float* bias, const float* res1, const float* res2,
+                    float* y, int M, int N, int K, int act, float slope, dpmn_stream_t stream);
+/* y = act((x + addv) . w^T + bias): with_pos_embed + in-projection, transformer_v2.py:462,826-828 */
+int dpmn_add_linear_f32(const float* x, const float* addv, const float* w, const float* bias, float* y, int M,
+                        int N, int K, int act, dpmn_stream_t stream);
+/* y = act(LayerNorm(x) . w^T + bias): pgrm.py:322-323 + 188/194 (q, kv), pgrm.py:330 + 30-31 (norm2+fc1+GELU) */
+int dpmn_ln_linear_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* w,
+                       const float* bias, float* y, int M, int N, int K, int act, dpmn_stream_t stream);
+/* SKConv.proj (pgrm.py:82) + per-64-row-block column sums of GELU(feats) for the global average pool
+ * (pgrm.py:84-86).  colsum_partials: (ceil(M/64), C). */
+int dpmn_sk_proj_f32(const float* cat, const float* w, const float* bias, float* feats, float* colsum_partials,
+                     int M, int C, dpmn_stream_t stream);
+/* out = shortcut + feats + (sum_g A[b,g,:] * cat[:, g-th slice]) . w_head^T + b_head
+ * (pgrm.py:92-95 + residual 329).  attn_vec: (B, groups, C/groups). */
+int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_head, const float* b_head,
+                       const float* feats, const float* shortcut, float* out, int M, int rows_per_image, int C,
+                       int groups, dpmn_stream_t stream);
+/* z[b] = w (Ch,Ch) . g[b] (Ch,L) + bias : Mlp.pointwise_conv on the raw (B,Ch,r,r) view (pgrm.py:34,37) */
+int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
+                       dpmn_stream_t stream);
+
+/* ------------------------------------------------------------------ PGRM kernels (pgrm.hip) */
+/* prior_fusion (optional, pf_w != NULL; pgrm.py:548) + PatchEmbed conv k=s=patch + LayerNorm (pgrm.py:419-426).
+ * img NCHW (B,cin,Hi,Wi) -> tokens (B, Hi/patch*Wi/patch, C). */
+int dpmn_patch_embed_ln_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                            const float* pe_b, const float* ln_w, const float* ln_b, float* tokens, int B, int Hi,
+                            int Wi, int patch, int C, dpmn_stream_t stream);
+/* multi-window cross attention core (pgrm.py:197-266): q (B,L,C), kv (B,L,2C) -> out (B,L,C) in
+ * window-major order per group (quirk Q1).  bias_tables / windows / shifts are HOST arrays of length
+ * n_groups (the table pointers themselves are device pointers). */
+int dpmn_window_attn_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                         const int* shifts, int n_groups, int heads_per_group, float* out, int B, int H, int W,
+                         int C, dpmn_stream_t stream);
+/* SKConv gate (pgrm.py:86-91): GAP partials -> fc1 -> GELU -> fc2 -> softmax over groups -> (B,G,C/G) */
+int dpmn_sk_gate_f32(const float* colsum_partials, int parts_per_image, int L, const float* fc1_w,
+                     const float* fc1_b, const float* fc2_w, const float* fc2_b, float* attn_vec, int B, int C,
+                     int groups, int dmid, dpmn_stream_t stream);
+/* Mlp.depthwise_conv + act_2 on the raw (B,Ch,r,r) view (pgrm.py:34-36) */
+int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r,
+                            dpmn_stream_t stream);
+/* conv_before_upsample (2 convs + LeakyReLU) + PixelShuffle + weight_list scaling + residuals
+ * (pgrm.py:559-565).  weight_list / residuals: HOST arrays of device pointers; residuals[0] is
+ * ignored like the reference does (quirk Q11).  mid_ws: B*H*W*hidden*patch^2 floats. */
+int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, const float* w1, const float* b1,
+                       const float* const* weight_list, const float* const* residuals, int n_residuals,
+                       float* mid_ws, float* out, int B, int H, int W, int C, int hidden, int patch,
+                       dpmn_stream_t stream);
+
+/* ------------------------------------------------------------------ PGRM module (pgrm_forward.hip) */
+typedef struct {
+  const float *norm1_q_w, *norm1_q_b, *norm1_kv_w, *norm1_kv_b;
+  const float *q_w, *q_b, *kv_w, *kv_b;
+  const float* bias_table[4];
+  const float *sk_proj_w, *sk_proj_b, *sk_fc1_w, *sk_fc1_b, *sk_fc2_w, *sk_fc2_b, *sk_head_w, *sk_head_b;
+  const float *norm2_w, *norm2_b;
+  const float *fc1_w, *fc1_b, *dw_w, *dw_b, *pw_w, *pw_b, *fc2_w, *fc2_b;
+} dpmn_pgrm_block;
+
+typedef struct {
+  int img_h, img_w, patch, dim, n_groups, heads_per_group, mlp_hidden, hidden_size, n_weight_list;
+  int window[4];
+  const float *prior_fusion_w, *prior_fusion_b; /* NULL when mode=True (mask prior, 3 channels) */
+  const float *pe_w, *pe_b, *pe_norm_w, *pe_norm_b;
+  dpmn_pgrm_block blocks[2];
+  const float *tail0_w, *tail0_b, *tail1_w, *tail1_b;
+  const float* weight_list[8];
+} dpmn_pgrm_weights;
+
+size_t dpmn_pgrm_workspace_bytes(const dpmn_pgrm_weights* w, int B);
+/* PGRM.forward(x_q, x_kv, residual_list) (pgrm.py:546-565), eval semantics (dropout / DropPath identity).
+ * x_q (B, 2|3, H, W), x_kv (B,3,H,W), residuals: HOST array of n_residuals device pointers (B,hid,H,W),
+ * out (B, hidden_size, H, W). */
+int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_channels, const float* x_kv,
+                          const float* const* residuals, int n_residuals, float* out, void* workspace,
+                          size_t workspace_bytes, int B, dpmn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPMN_HIP_H */

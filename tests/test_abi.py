@@ -1,0 +1,68 @@
+"""CPU checks of the drop-in boundary: the library loads, exports every symbol the header
+declares, the ctypes table covers the header, and the host mirror keeps the reference's
+state_dict layout.  No compute calls (no GPU here)."""
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "dpmn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpmn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dpmn_amd import _abi
+    syms = header_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(_abi.lib, s), "libdpmn_hip.so lacks %s" % s
+    assert sorted(_abi.SIGNATURES) == syms, "ctypes table and include/dpmn_hip.h disagree"
+    assert _abi.lib.dpmn_abi_version() >= 1
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    from dpmn_amd import _abi, ops
+    with pytest.raises(_abi.DpmnError):
+        ops.linear(torch.zeros(64, 96), torch.zeros(96, 96))
+
+
+def _manifest(name):
+    from helpers import load_golden
+    man = {}
+    for row in load_golden(name)["manifest"]:
+        k, shp, dt = str(row).split("|")
+        man[k] = (tuple(int(s) for s in shp.split(",")) if shp else (), dt)
+    return man
+
+
+def _layout(sd):
+    return {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in sd.items()}
+
+
+def test_pgrm_state_dict_layout_matches_reference_manifest():
+    from dpmn_amd.model.pgrm import PGRM
+    n = 6
+    args = dict(patch_size=[2] * n, embed_dim=[96] * n, depths=[1] * n, num_heads=[[6]] * n, window_size=[[2, 4, 8]] * n,
+                mlp_ratio=[4.] * n, drop_rate=[0.] * n, attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
+    for tag, it, mode in (("mode0_iter0", 0, False), ("mode1_iter2", 2, True)):
+        man = _manifest("pgrm_" + tag)
+        sd = PGRM(iter=it, mode=mode, hidden_size=3, **args).state_dict()
+        assert _layout(sd) == man
+        assert list(sd.keys()) == list(man.keys())
+
+
+def test_pgrm_derived_buffers_match_oracle():
+    from oracle import pgrm as opgrm
+    from dpmn_amd.model.pgrm import _rel_index, _shift_mask
+    for ws, sh in ((2, 1), (4, 2), (8, 4)):
+        m = _shift_mask(16, 64, ws, sh)
+        assert torch.equal(m, opgrm.shift_mask(16, 64, ws, sh))
+        tbl = torch.arange((2 * ws - 1) ** 2 * 2, dtype=torch.float32).reshape(-1, 2)
+        assert torch.equal(tbl[_rel_index(ws).reshape(-1)].reshape(ws * ws, ws * ws, 2).permute(2, 0, 1),
+                           opgrm.relative_bias(tbl, ws))

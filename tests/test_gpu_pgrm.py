@@ -1,0 +1,221 @@
+"""GPU parity: every PGRM kernel and the native PGRM forward vs the CPU oracle (oracle/pgrm.py),
+called through the C ABI (dpmn_amd.ops / dpmn_amd.model.pgrm).  fp32, tolerance stated per test.
+Run on the MI355X box:  python -m pytest tests -m gpu
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dpmn_amd.utils import synth
+from helpers import load_golden, sd_from_manifest, t, assert_close
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 1e-4   # fp32 MFMA (k-ordered fma chain) vs fp32 CPU; activations are O(1)
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+    return torch.device("cuda:0")
+
+
+def cu(sd, dev):
+    return {k: v.to(dev).contiguous() for k, v in sd.items()}
+
+
+def u(name, shape, lo=-1.0, hi=1.0, seed=40):
+    return synth.uniform(name, shape, lo, hi, seed)
+
+
+# ------------------------------------------------------------------------------ GEMM family
+@pytest.mark.parametrize("M,N,K", [(128, 96, 96), (1000, 192, 96), (256, 384, 96), (192, 96, 384), (64, 96, 32),
+                                   (130, 64, 64), (64, 100, 128), (4096, 192, 192)])
+def test_linear(dev, M, N, K):
+    from dpmn_amd import ops
+    x, w, b = u("x", (M, K)), u("w", (N, K), -0.2, 0.2), u("b", (N,))
+    r1, r2 = u("r1", (M, N)), u("r2", (M, N))
+    ref = F.gelu(F.linear(x, w, b)) + r1 + r2
+    got = ops.linear(x.to(dev), w.to(dev), b.to(dev), r1.to(dev), r2.to(dev), act="gelu")
+    assert_close(got, ref, ATOL, RTOL, "linear %s" % ((M, N, K),))
+    got = ops.linear(x.to(dev), w.to(dev))
+    assert_close(got, F.linear(x, w), ATOL, RTOL, "linear nobias")
+
+
+@pytest.mark.parametrize("K,N", [(96, 96), (96, 192), (96, 384), (192, 384), (64, 64)])
+def test_ln_linear(dev, K, N):
+    from dpmn_amd import ops
+    M = 320
+    x = u("x", (M, K), -2, 3)
+    g, be = u("g", (K,), 0.5, 1.5), u("be", (K,))
+    w, b = u("w", (N, K), -0.2, 0.2), u("b", (N,))
+    ref = F.linear(F.layer_norm(x, (K,), g, be), w, b)
+    got = ops.ln_linear(x.to(dev), g.to(dev), be.to(dev), w.to(dev), b.to(dev))
+    assert_close(got, ref, ATOL, RTOL, "ln_linear")
+    got = ops.ln_linear(x.to(dev), g.to(dev), be.to(dev), w.to(dev), b.to(dev), act="gelu")
+    assert_close(got, F.gelu(ref), ATOL, RTOL, "ln_linear gelu")
+
+
+def test_add_linear(dev):
+    from dpmn_amd import ops
+    x, a = u("x", (200, 64)), u("a", (200, 64))
+    w, b = u("w", (64, 64), -0.2, 0.2), u("b", (64,))
+    got = ops.add_linear(x.to(dev), a.to(dev), w.to(dev), b.to(dev))
+    assert_close(got, F.linear(x + a, w, b), ATOL, RTOL, "add_linear")
+
+
+def test_pointwise(dev):
+    from dpmn_amd import ops
+    B, L, Ch = 3, 1024, 384
+    g = u("g", (B, L, Ch))
+    w, b = u("w", (Ch, Ch), -0.1, 0.1), u("b", (Ch,))
+    ref = (torch.einsum("oc,bcs->bos", w, g.reshape(B, Ch, L)) + b[None, :, None]).reshape(B, L, Ch)
+    got = ops.pointwise(g.to(dev), w.to(dev), b.to(dev))
+    assert_close(got, ref, ATOL, RTOL, "pointwise")
+
+
+# ------------------------------------------------------------------------------ PGRM pieces
+def test_patch_embed(dev):
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    B = 3
+    sd = {"patch_embed.proj.weight": u("pw", (96, 3, 2, 2)), "patch_embed.proj.bias": u("pb", (96,)),
+          "patch_embed.norm.weight": u("nw", (96,), 0.5, 1.5), "patch_embed.norm.bias": u("nb", (96,))}
+    img = u("img", (B, 3, 32, 128), 0, 1)
+    ref = o.patch_embed(img, sd, 2)
+    d = cu(sd, dev)
+    got = ops.patch_embed_ln(img.to(dev), d["patch_embed.proj.weight"], d["patch_embed.proj.bias"],
+                             d["patch_embed.norm.weight"], d["patch_embed.norm.bias"], 2)
+    assert_close(got, ref, ATOL, RTOL, "patch_embed")
+    # with fused prior_fusion on a uint8-valued 2-channel text prior (quirk Q6)
+    pfw, pfb = u("pfw", (3, 2, 3, 3), -0.3, 0.3), u("pfb", (3,))
+    prior = torch.floor(u("prior", (B, 2, 32, 128), 0, 256))
+    ref = o.patch_embed(F.conv2d(prior, pfw, pfb, padding=1), sd, 2)
+    got = ops.patch_embed_ln(prior.to(dev), d["patch_embed.proj.weight"], d["patch_embed.proj.bias"],
+                             d["patch_embed.norm.weight"], d["patch_embed.norm.bias"], 2, pfw.to(dev), pfb.to(dev))
+    assert_close(got, ref, 2e-4, RTOL, "patch_embed + prior_fusion")
+
+
+@pytest.mark.parametrize("tag,shifts", [("shift0", [0, 0, 0]), ("shifted", [1, 2, 4])])
+def test_window_attention_vs_oracle_and_golden(dev, tag, shifts):
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    g = load_golden("wattn_" + tag)
+    sd = sd_from_manifest(g["manifest"], 21)
+    B, H, W, C = 1, 16, 64, 96
+    xq = synth.uniform("wa_xq", (B, H, W, C), -1, 1, 6).reshape(B, H * W, C)
+    xkv = synth.uniform("wa_xkv", (B, H, W, C), -1, 1, 6).reshape(B, H * W, C)
+    q = F.linear(xq, sd["q.weight"], sd["q.bias"])
+    kv = F.linear(xkv, sd["kv.weight"], sd["kv.bias"])
+    tables = [sd["relative_position_bias_table_%d" % i].to(dev) for i in range(3)]
+    got = ops.window_attn(q.to(dev).contiguous(), kv.to(dev).contiguous(), tables, [2, 4, 8], shifts, 2, H, W)
+    assert_close(got, t(g["cat"]), ATOL, RTOL, "window attention vs reference golden " + tag)
+    ref = o.window_attention_core(q, kv[..., :C], kv[..., C:], sd, "", H, W, [2, 4, 8], shifts, 2)
+    assert_close(got, ref, ATOL, RTOL, "window attention vs oracle " + tag)
+
+
+def test_window_attention_batch_and_dim192(dev):
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    for (B, H, W, C, wins) in ((5, 16, 64, 96, [2, 4, 8]), (2, 32, 128, 192, [4, 8, 8])):
+        q, kv = u("q", (B, H * W, C)), u("kv", (B, H * W, 2 * C))
+        sd = {"relative_position_bias_table_%d" % i: u("tb%d" % i, ((2 * w - 1) ** 2, 2)) for i, w in enumerate(wins)}
+        for shifts in ([0, 0, 0], [w // 2 for w in wins]):
+            ref = o.window_attention_core(q, kv[..., :C], kv[..., C:], sd, "", H, W, wins, shifts, 2)
+            got = ops.window_attn(q.to(dev), kv.to(dev), [sd["relative_position_bias_table_%d" % i].to(dev) for i in range(3)],
+                                  wins, shifts, 2, H, W)
+            assert_close(got, ref, ATOL, RTOL, "window attention B=%d C=%d shifts=%s" % (B, C, shifts))
+
+
+def test_sk_fuse(dev):
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    B, L, C = 3, 1024, 96
+    sd = {"proj.weight": u("a", (C, C), -0.2, 0.2), "proj.bias": u("b", (C,)),
+          "fc1.weight": u("c", (16, C), -0.3, 0.3), "fc1.bias": u("d", (16,)),
+          "fc2.weight": u("e", (C, 16), -0.5, 0.5), "fc2.bias": u("f", (C,)),
+          "proj_head.weight": u("g", (C, 32), -0.3, 0.3), "proj_head.bias": u("h", (C,))}
+    cat, sc = u("cat", (B, L, C)), u("sc", (B, L, C))
+    ref = sc + o.sk_fuse(cat, sd, "", 3)
+    d = cu(sd, dev)
+    got, _ = ops.sk_fuse(cat.to(dev), sc.to(dev), d["proj.weight"], d["proj.bias"], d["fc1.weight"], d["fc1.bias"],
+                         d["fc2.weight"], d["fc2.bias"], d["proj_head.weight"], d["proj_head.bias"], 3)
+    assert_close(got, ref, ATOL, RTOL, "shortcut + SKConv")
+
+
+def test_mlp_chain_vs_golden(dev):
+    from dpmn_amd import ops
+    g = load_golden("mlp")
+    sd = cu(sd_from_manifest(g["manifest"], 22), dev)
+    x = synth.uniform("mlp_x", (2, 1024, 96), -1, 1, 6).to(dev)
+    y = ops.linear(x.reshape(-1, 96), sd["fc1.weight"], sd["fc1.bias"], act="gelu").reshape(2, 1024, 384)
+    gg = ops.dwconv3x3_gelu(y, sd["depthwise_conv.weight"], sd["depthwise_conv.bias"], 32)
+    z = ops.pointwise(gg, sd["pointwise_conv.weight"], sd["pointwise_conv.bias"])
+    out = ops.linear(z.reshape(-1, 384), sd["fc2.weight"], sd["fc2.bias"]).reshape(2, 1024, 96)
+    assert_close(out, t(g["out"]), ATOL, RTOL, "Mlp chain vs reference golden")
+
+
+def test_tail(dev):
+    from dpmn_amd import ops
+    B, H, W, C = 2, 16, 64, 96
+    tok = u("tok", (B, H * W, C))
+    w0, b0 = u("w0", (12, C, 3, 3), -0.05, 0.05), u("b0", (12,))
+    w1, b1 = u("w1", (12, 12, 3, 3), -0.2, 0.2), u("b1", (12,))
+    wl = [u("wl%d" % i, (1, 3, 32, 128), 0.8, 1.2) for i in range(3)]
+    res = [u("res%d" % i, (B, 3, 32, 128), 0, 1) for i in range(3)]
+    x = tok.transpose(1, 2).reshape(B, C, H, W)
+    x = F.leaky_relu(F.conv2d(F.conv2d(x, w0, b0, padding=1), w1, b1, padding=1), 0.01)
+    ref = F.pixel_shuffle(x, 2) * wl[0] + res[1] * wl[1] + res[2] * wl[2]
+    got = ops.pgrm_tail(tok.to(dev), w0.to(dev), b0.to(dev), w1.to(dev), b1.to(dev), [w.to(dev) for w in wl],
+                        [r.to(dev) for r in res], H, W, 3, 2)
+    assert_close(got, ref, ATOL, RTOL, "tail with residuals (Q11: residual 0 skipped)")
+    ref0 = F.pixel_shuffle(x, 2) * wl[0]
+    got0 = ops.pgrm_tail(tok.to(dev), w0.to(dev), b0.to(dev), w1.to(dev), b1.to(dev), [wl[0].to(dev)], [], H, W, 3, 2)
+    assert_close(got0, ref0, ATOL, RTOL, "tail without residuals")
+
+
+# ------------------------------------------------------------------------------ whole module
+def _pgrm_args(n=6):
+    return dict(patch_size=[2] * n, embed_dim=[96] * n, depths=[1] * n, num_heads=[[6]] * n, window_size=[[2, 4, 8]] * n,
+                mlp_ratio=[4.] * n, drop_rate=[0.] * n, attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
+
+
+@pytest.mark.parametrize("tag,it,mode", [("mode0_iter0", 0, False), ("mode1_iter2", 2, True)])
+def test_pgrm_module_vs_reference_golden(dev, tag, it, mode):
+    from dpmn_amd.model.pgrm import PGRM
+    g = load_golden("pgrm_" + tag)
+    B, _, _, wseed, iseed = [int(v) for v in g["meta"]]
+    m = PGRM(iter=it, mode=mode, hidden_size=3, **_pgrm_args()).eval()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, wseed)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    if mode:
+        x_q = (synth.uniform("x_q", (B, 1, 32, 128), 0, 1, iseed) > 0.5).float().repeat(1, 3, 1, 1)
+    else:
+        x_q = torch.floor(synth.uniform("x_q", (B, 2, 32, 128), 0, 256, iseed))
+    x_kv = synth.uniform("x_kv", (B, 3, 32, 128), 0, 1, iseed)
+    res = [synth.uniform("res%d" % i, (B, 3, 32, 128), 0, 1, iseed).to(dev) for i in range(it)]
+    with torch.no_grad():
+        out = m(x_q.to(dev), x_kv.to(dev), res)
+    assert_close(out, t(g["out"]), 2e-4, 2e-4, "PGRM module vs reference golden " + tag)
+
+
+def test_pgrm_module_batch48_vs_oracle(dev):
+    """config-1 per-GPU batch; checks batch indexing at full size against the oracle."""
+    from dpmn_amd.model.pgrm import PGRM
+    from oracle import pgrm as o
+    B = 48
+    m = PGRM(iter=1, mode=False, hidden_size=3, **_pgrm_args()).eval()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 77)
+    m.load_state_dict(sd)
+    x_q = torch.floor(u("xq", (B, 2, 32, 128), 0, 256))
+    x_kv = u("xkv", (B, 3, 32, 128), 0, 1)
+    res = [u("r0", (B, 3, 32, 128), 0, 1)]
+    ref = o.pgrm_forward({k: v for k, v in sd.items()}, x_q, x_kv, res)
+    m = m.to(dev)
+    with torch.no_grad():
+        out = m(x_q.to(dev), x_kv.to(dev), [r.to(dev) for r in res])
+    assert_close(out, ref, 2e-4, 2e-4, "PGRM module B=48 vs oracle")

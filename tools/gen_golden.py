@@ -110,7 +110,61 @@ def gen_parts():
     save("basiclayer_stress", out=o[:, ::7].contiguous(), manifest=manifest(sd), checksum=checksum(sd))
 
 
-GENS = {"pgrm": gen_pgrm, "parts": gen_parts}
+# ------------------------------------------------------------------------------------ CMM etc.
+def gen_cmm():
+    from model import cmm
+    B = 2
+    x1 = synth.uniform("cmm_x1", (B, 3, 32, 128), 0, 1, 7)
+    x2 = synth.uniform("cmm_x2", (B, 3, 32, 128), 0, 1, 7)
+    for cnum in (8, 64):
+        m = cmm.ComplementationModulationModule(cnum=cnum)
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=31)
+        sd = {k: v.clone() for k, v in sd.items()}  # state_dict() aliases live buffers (BN stats mutate)
+        m.load_state_dict(sd)
+        outs = {}
+        for training in (False, True):
+            m.train(training)
+            outs["out_train" if training else "out_eval"] = m(x1, x2)
+        save("cmm_cnum%d" % cnum, manifest=manifest(sd), checksum=checksum(sd), **outs)
+
+
+def gen_distill():
+    from model import distill_module
+    B = 2
+    xd = synth.uniform("dist_deep", (B, 3, 32, 128), 0, 1, 8)
+    xs = synth.uniform("dist_shallow", (B, 3, 32, 128), 0, 1, 8)
+    m = distill_module.DistillModule()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, seed=32)
+    sd = {k: v.clone() for k, v in sd.items()}
+    m.load_state_dict(sd)
+    m.train()
+    loss, feat = m(xd, xs)
+    m.load_state_dict(sd)
+    m.eval()
+    loss_e, feat_e = m(xd, xs)
+    save("distill", loss_train=loss, feat_train=feat, loss_eval=loss_e, feat_eval=feat_e,
+         manifest=manifest(sd), checksum=checksum(sd))
+
+
+def gen_loss():
+    from loss import image_loss
+    sys.modules.setdefault("IPython", sys.modules["IPython"])
+    from utils import ssim_psnr
+    B = 4
+    a = synth.uniform("loss_a", (B, 3, 32, 128), 0, 1, 9)
+    b = synth.uniform("loss_b", (B, 4, 32, 128), 0, 1, 9)
+    b3 = (0.7 * a + 0.3 * b[:, :3])
+    crit = image_loss.ImageLoss(gradient=True, loss_weight=[1, 1])
+    crit_ng = image_loss.ImageLoss(gradient=False, loss_weight=[1, 1])
+    save("loss_metrics", loss_grad=crit(a, b3), loss_nograd=crit_ng(a, b3),
+         psnr=ssim_psnr.calculate_psnr(a, torch.cat([b3, b[:, 3:]], 1)),
+         ssim=ssim_psnr.SSIM()(a, torch.cat([b3, b[:, 3:]], 1)),
+         gradmap=image_loss.GradientPriorLoss.gradient_map(a)[:1])
+
+
+GENS = {"pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss}
 
 
 if __name__ == "__main__":
