@@ -39,6 +39,15 @@ class PgrmWeights(C.Structure):
         ("weight_list", fp * 8)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [("inp", fp * 3), ("in_scale", fp * 3), ("in_shift", fp * 3), ("cseg", C.c_int * 3)] + [
+        (n, C.c_int) for n in ("B", "Hin", "Win", "KH", "KW", "stride", "dil_y", "dil_x", "pad_y", "pad_x", "Hp", "Wp",
+                               "Hout", "Wout", "ostep", "ooy", "oox", "pro_act")] + [
+        ("w", fp), ("bias", fp), ("Cout", C.c_int), ("epi_act", C.c_int), ("slope", C.c_float), ("res", fp),
+        ("out", fp), ("out_ld", C.c_int), ("out_coff", C.c_int), ("out_nchw", C.c_int), ("pixel_shuffle", C.c_int),
+        ("stats", fp)]
+
+
 _i, _f, _sz = C.c_int, C.c_float, C.c_size_t
 _PP = C.POINTER(fp)
 _IP = C.POINTER(C.c_int)
@@ -53,6 +62,10 @@ SIGNATURES = {
     "dpmn_sk_proj_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, fp]),
     "dpmn_sk_select_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_pointwise_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_conv2d_nhwc_f32": (_i, [C.POINTER(ConvDesc), fp]),
+    "dpmn_nchw_to_nhwc_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_nhwc_to_nchw_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_se_gate_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

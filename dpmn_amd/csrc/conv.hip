@@ -1,0 +1,313 @@
+// NHWC implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_16x16x4_f32) for the CMM U-Net
+// (cmm.py:38-77, 120-161) and the TSRN/TATT/TBSRN conv stacks (tsrn.py:26-40,83-110; tatt.py:596-636).
+//
+//   out[b, oy, ox, co] = epi( bias[co] + sum_{tap, ci} W[co][tap][ci] * pro(in)[b, iy(tap), ix(tap), ci] )
+//
+//   M = B*Hp*Wp output pixels of one "phase" grid, N = Cout, K = KH*KW*Cin (Cin contiguous: NHWC).
+//   * up to 3 channel-concatenated input segments (decoder skip concats, cmm.py:150-158) are read in
+//     place -- the concat is never materialised;
+//   * prologue on load: per-channel affine (train-mode BatchNorm of the producer) then activation
+//     (LeakyReLU 0.2 / ReLU that opens every Encode/DecodeBlock) -- zero padding stays zero;
+//   * stride-2 ConvTranspose2d(4,2,1) runs as 4 output phases, each a 2x2 conv (dil = -1,
+//     pad = -phase) over pre-packed per-phase weights; ConvTranspose2d(3,1,1) is a flipped conv;
+//   * epilogue: bias, activation, residual add, optional per-channel sum / sum-of-squares for
+//     train-mode BatchNorm statistics, NHWC or NCHW store, optional PixelShuffle(2) store.
+// MFMA roles as in gemm.hip: "A" = weight rows (co), "B" = pixels, so a lane owns 4 consecutive co.
+#include "common.h"
+
+namespace {
+
+constexpr int PAD = 4, BK = 32, LDK = BK + PAD;
+
+struct ConvArgs {
+  const float* in[3];
+  const float* in_scale[3];   // per-channel affine on load (or null)
+  const float* in_shift[3];
+  int cseg[3];                // channels per segment (multiples of 4); unused segments 0
+  int cin;                    // sum of cseg (padded channel count used in the weight pack)
+  int B, Hin, Win;
+  int KH, KW, stride, dil_y, dil_x, pad_y, pad_x;   // iy = oy'*stride + ky*dil_y - pad_y
+  int Hp, Wp;                 // phase-grid size (number of output pixels computed per image = Hp*Wp)
+  int Hout, Wout, ostep, ooy, oox;                  // oy = oy'*ostep + ooy
+  int pro_act;                // activation applied to the loaded input (after affine)
+  const float* w;             // packed (Cout, Kp) with Kp = roundup(KH*KW*cin, 32), zero padded
+  int Kp;
+  const float* bias;          // (Cout) or null
+  int Cout;
+  int epi_act;
+  float slope;
+  const float* res;           // residual, same layout as the output, or null
+  float* out;
+  int out_ld, out_coff;       // NHWC: channel stride of the output buffer and channel offset
+  int out_nchw;               // 1: store NCHW (B, Cout, Hout, Wout)
+  int pixel_shuffle;          // 1: PixelShuffle(2) store: NHWC (B, 2*Hout, 2*Wout, Cout/4)
+  float* stats;               // (2, Cout) running sum / sum of squares of the pre-activation output, or null
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+  constexpr int APASS = BM / 32, BPASS = (BN + 31) / 32;
+  __shared__ __attribute__((aligned(16))) float Xs[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = a.B * a.Hp * a.Wp;
+  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+
+  // per-thread pixel rows of the A tile
+  int pb[APASS], py[APASS], px[APASS];
+#pragma unroll
+  for (int p = 0; p < APASS; ++p) {
+    const int m = m_blk + lrow + p * 32;
+    if (m < M) {
+      const int b = m / (a.Hp * a.Wp), r = m % (a.Hp * a.Wp);
+      pb[p] = b;
+      py[p] = (r / a.Wp) * a.stride - a.pad_y;
+      px[p] = (r % a.Wp) * a.stride - a.pad_x;
+    } else {
+      pb[p] = -1; py[p] = 0; px[p] = 0;
+    }
+  }
+  const int c01 = a.cseg[0] + a.cseg[1];
+  const int ktaps = a.KH * a.KW;
+
+  float4 xr[APASS], wr[BPASS];
+  auto gload = [&](int k0) {
+    const int k = k0 + lcol;
+    const int tap = k / a.cin, c = k - tap * a.cin;
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const int dy = ky * a.dil_y, dx = kx * a.dil_x;
+    // segment of channel c
+    int seg = 0, cl = c;
+    if (c >= c01) { seg = 2; cl = c - c01; }
+    else if (c >= a.cseg[0]) { seg = 1; cl = c - a.cseg[0]; }
+    const float* src = a.in[seg];
+    const int cs = a.cseg[seg];
+    const float* sc = a.in_scale[seg];
+    const float* sh = a.in_shift[seg];
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int iy = py[p] + dy, ix = px[p] + dx;
+      if (pb[p] >= 0 && tap < ktaps && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+        v = *reinterpret_cast<const float4*>(src + (((size_t)pb[p] * a.Hin + iy) * a.Win + ix) * cs + cl);
+        if (sc) {
+          const float4 s4 = *reinterpret_cast<const float4*>(sc + cl);
+          const float4 h4 = *reinterpret_cast<const float4*>(sh + cl);
+          v.x = v.x * s4.x + h4.x; v.y = v.y * s4.y + h4.y; v.z = v.z * s4.z + h4.z; v.w = v.w * s4.w + h4.w;
+        }
+        if (a.pro_act != ACT_NONE) {
+          v.x = apply_act(v.x, a.pro_act, 0.f); v.y = apply_act(v.y, a.pro_act, 0.f);
+          v.z = apply_act(v.z, a.pro_act, 0.f); v.w = apply_act(v.w, a.pro_act, 0.f);
+        }
+      }
+      xr[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) {
+      const int r = lrow + p * 32;
+      const int n = n_blk + r;
+      wr[p] = (r < BN && n < a.Cout) ? *reinterpret_cast<const float4*>(a.w + (size_t)n * a.Kp + k0 + lcol)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * 32) * LDK + lcol]) = xr[p];
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p)
+      if (lrow + p * 32 < BN) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * 32) * LDK + lcol]) = wr[p];
+  };
+
+  const int wm = wave % WM, wn = wave / WM;
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  const int nk = a.Kp / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) gload((kt + 1) * BK);
+    const float* xa = &Xs[buf][(wm * (MT * 16) + lr) * LDK + kq * 4];
+    const float* wa = &Ws[buf][(wn * (NT * 16) + lr) * LDK + kq * 4];
+#pragma unroll
+    for (int kc = 0; kc < BK; kc += 16) {
+      f32x4 xf[MT], wf[NT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xa + j * 16 * LDK + kc);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 16 * LDK + kc);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[i][s], xf[j][s], acc[i][j]);
+    }
+    if (kt + 1 < nk) sstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds out[pixel m = .. + (l&15)][co = .. + (l>>4)*4 + r]
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+
+#pragma unroll
+  for (int j = 0; j < MT; ++j) {
+    const int m = m_blk + wm * (MT * 16) + j * 16 + lr;
+    if (m >= M) continue;
+    const int b = m / (a.Hp * a.Wp), rr = m % (a.Hp * a.Wp);
+    const int oy = (rr / a.Wp) * a.ostep + a.ooy, ox = (rr % a.Wp) * a.ostep + a.oox;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n_blk + wn * (NT * 16) + i * 16 + kq * 4;
+      if (n >= a.Cout) continue;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ((a.bias && n + r < a.Cout) ? a.bias[n + r] : 0.f);
+      if (a.stats) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] += v[r] * v[r]; }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.epi_act, a.slope);
+      if (a.out_nchw) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (n + r < a.Cout) {
+            const size_t o = (((size_t)b * a.Cout + n + r) * a.Hout + oy) * a.Wout + ox;
+            a.out[o] = v[r] + (a.res ? a.res[o] : 0.f);
+          }
+      } else if (a.pixel_shuffle) {
+        // out[b, 2*oy+dy, 2*ox+dx, c] = conv[b, oy, ox, c*4 + dy*2 + dx]; the lane's 4 channels are one c
+        const int c = n >> 2, Co = a.Cout >> 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int dy = r >> 1, dx = r & 1;
+          a.out[(((size_t)b * 2 * a.Hout + 2 * oy + dy) * 2 * a.Wout + 2 * ox + dx) * Co + c] = v[r];
+        }
+      } else {
+        const size_t o = (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.out_ld + a.out_coff + n;
+        if (n + 3 < a.Cout) {
+          float4 q = make_float4(v[0], v[1], v[2], v[3]);
+          if (a.res) {
+            const float4 rs = *reinterpret_cast<const float4*>(a.res + o);
+            q.x += rs.x; q.y += rs.y; q.z += rs.z; q.w += rs.w;
+          }
+          *reinterpret_cast<float4*>(a.out + o) = q;
+        } else {
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.Cout) a.out[o + r] = v[r] + (a.res ? a.res[o + r] : 0.f);
+        }
+      }
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n_blk + wn * (NT * 16) + i * 16 + kq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = ssum[i][r], q = ssq[i][r];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+        if (lr == 0 && n + r < a.Cout) {
+          atomicAdd(a.stats + n + r, s);
+          atomicAdd(a.stats + a.Cout + n + r, q);
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(const ConvArgs& a, hipStream_t st) {
+  const int M = a.B * a.Hp * a.Wp;
+  dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN));
+  hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// NCHW (B, C, H, W) -> NHWC (B, H, W, Cp) with zero-filled channels C..Cp-1
+__global__ void k_nchw_to_nhwc(const float* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W, int Cp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W;
+  if (idx >= total) return;
+  const int b = idx / ((long)H * W);
+  const long hw = idx % ((long)H * W);
+  for (int c = 0; c < Cp; ++c) out[idx * Cp + c] = c < C ? in[((size_t)b * C + c) * H * W + hw] : 0.f;
+}
+
+// NHWC (B, H, W, C) -> NCHW
+__global__ void k_nhwc_to_nchw(const float* __restrict__ in, float* __restrict__ out, int B, int C, int H, int W) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * C * H * W;
+  if (idx >= total) return;
+  const int x = idx % W, y = (idx / W) % H, c = (idx / ((long)W * H)) % C, b = idx / ((long)W * H * C);
+  out[idx] = in[(((size_t)b * H + y) * W + x) * C + c];
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
+  DPMN_REQUIRE(d && d->in[0] && d->w && d->out, "conv2d: null pointer");
+  ConvArgs a{};
+  int cin = 0;
+  for (int s = 0; s < 3; ++s) {
+    a.in[s] = d->in[s]; a.in_scale[s] = d->in_scale[s]; a.in_shift[s] = d->in_shift[s]; a.cseg[s] = d->in[s] ? d->cseg[s] : 0;
+    DPMN_REQUIRE(a.cseg[s] % 4 == 0, "conv2d: segment channel counts must be multiples of 4");
+    DPMN_REQUIRE((d->in_scale[s] == nullptr) == (d->in_shift[s] == nullptr), "conv2d: scale and shift go together");
+    cin += a.cseg[s];
+  }
+  a.cin = cin;
+  a.B = d->B; a.Hin = d->Hin; a.Win = d->Win;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.dil_y = d->dil_y; a.dil_x = d->dil_x; a.pad_y = d->pad_y; a.pad_x = d->pad_x;
+  a.Hp = d->Hp; a.Wp = d->Wp; a.Hout = d->Hout; a.Wout = d->Wout; a.ostep = d->ostep; a.ooy = d->ooy; a.oox = d->oox;
+  a.pro_act = d->pro_act; a.w = d->w; a.bias = d->bias; a.Cout = d->Cout; a.epi_act = d->epi_act; a.slope = d->slope;
+  a.res = d->res; a.out = d->out; a.out_ld = d->out_ld > 0 ? d->out_ld : d->Cout; a.out_coff = d->out_coff;
+  a.out_nchw = d->out_nchw; a.pixel_shuffle = d->pixel_shuffle; a.stats = d->stats;
+  a.Kp = ((d->KH * d->KW * cin + 31) / 32) * 32;
+  DPMN_REQUIRE(d->B > 0 && d->Hp > 0 && d->Wp > 0 && d->Cout > 0, "conv2d: empty shape");
+  DPMN_REQUIRE(!(d->pixel_shuffle && (d->Cout % 4 != 0 || d->out_nchw || d->res)), "conv2d: bad pixel-shuffle epilogue");
+  DPMN_REQUIRE(d->out_nchw || (a.out_ld % 4 == 0 && a.out_coff % 4 == 0) || d->Cout < 4 || d->pixel_shuffle,
+               "conv2d: NHWC output needs 16-byte aligned channel rows");
+  hipStream_t st = as_stream(stream);
+  const int M = a.B * a.Hp * a.Wp;
+  if (a.Cout <= 16) return launch_conv<128, 16, 4, 1>(a, st);
+  if (a.Cout <= 32) return launch_conv<128, 32, 4, 1>(a, st);
+  if (a.Cout <= 64 || M < 4096) return launch_conv<64, 64, 2, 2>(a, st);
+  if (M >= 32768 && a.Cout >= 128) return launch_conv<128, 128, 2, 2>(a, st);
+  return launch_conv<128, 64, 4, 1>(a, st);
+}
+
+int dpmn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, dpmn_stream_t stream) {
+  DPMN_REQUIRE(in && out && Cpad >= C, "nchw_to_nhwc: bad arguments");
+  const long total = (long)B * H * W;
+  hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), in, out, B, C, H, W, Cpad);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, dpmn_stream_t stream) {
+  DPMN_REQUIRE(in && out, "nhwc_to_nchw: bad arguments");
+  const long total = (long)B * C * H * W;
+  hipLaunchKernelGGL(k_nhwc_to_nchw, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), in, out, B, C, H, W);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""Host-side mirror of the reference's ``model/cmm.py`` (ComplementationModulationModule).
+
+Same constructor, ``forward(x1, x2)`` and ``state_dict`` key layout as cmm.py:80-161; parameters are
+held by stock ``torch.nn`` containers that are NEVER called -- every convolution runs through the
+NHWC implicit-GEMM kernel in libdpmn_hip.so (csrc/conv.hip) and the channel gate through
+csrc/cmm.hip.  Activations stay NHWC between kernels; only the module boundary is NCHW.
+Eval-mode BatchNorm is folded into the producing conv at pack time (quirk Q12).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import packing
+
+
+def _encode_block(cin, cout):
+    # indices match cmm.py:38-55: [act, conv4x4 s2 d2, bn, act, conv3x3, bn]
+    return nn.Sequential(nn.Identity(), nn.Conv2d(cin, cin, 4, 2, dilation=2, padding=3), nn.BatchNorm2d(cin),
+                         nn.Identity(), nn.Conv2d(cin, cout, 3, 1, padding=1), nn.BatchNorm2d(cout))
+
+
+def _decode_block(cin, cout):
+    # cmm.py:58-77: [act, convT3x3, bn, act, convT4x4 s2, bn]
+    return nn.Sequential(nn.Identity(), nn.ConvTranspose2d(cin, cout, 3, 1, padding=1), nn.BatchNorm2d(cout),
+                         nn.Identity(), nn.ConvTranspose2d(cout, cout, 4, 2, padding=1), nn.BatchNorm2d(cout))
+
+
+class _Holder(nn.Module):
+    def __init__(self, seq, name):
+        super().__init__()
+        setattr(self, name, seq)
+
+
+class ComplementationModulationModule(nn.Module):
+    def __init__(self, c_img=3, norm='batch', act_en='leaky_relu', act_de='relu', cnum=64):
+        super().__init__()
+        if norm != 'batch' or act_en != 'leaky_relu' or act_de != 'relu':
+            raise NotImplementedError("dpmn_amd CMM: built for the only configuration the trainer constructs "
+                                      "(norm='batch', act_en='leaky_relu', act_de='relu'; super_resolution.py:72)")
+        self.c_img, self.cnum = c_img, cnum
+        c = cnum
+        for br in ("1", "2"):
+            setattr(self, "en_1_" + br, nn.Conv2d(c_img, c, 3, 1, padding=1))
+            setattr(self, "en_2_" + br, _Holder(_encode_block(c, 2 * c), "encode"))
+            setattr(self, "en_3_" + br, _Holder(_encode_block(2 * c, 4 * c), "encode"))
+            setattr(self, "en_4_" + br, _Holder(_encode_block(4 * c, 8 * c), "encode"))
+            setattr(self, "en_5_" + br, _Holder(_encode_block(8 * c, 8 * c), "encode"))
+            setattr(self, "en_6_" + br, nn.Sequential(nn.Identity(), nn.Conv2d(8 * c, 8 * c, 4, 2, padding=1)))
+        self.fc_1 = nn.Linear(16 * c, 4 * c)
+        self.fc_2 = nn.Linear(4 * c, 16 * c)
+        self.de_6 = nn.Sequential(nn.Identity(), nn.ConvTranspose2d(16 * c, 8 * c, 4, 2, padding=1), nn.BatchNorm2d(8 * c))
+        self.de_5 = _Holder(_decode_block(24 * c, 8 * c), "decode")
+        self.de_4 = _Holder(_decode_block(24 * c, 4 * c), "decode")
+        self.de_3 = _Holder(_decode_block(12 * c, 2 * c), "decode")
+        self.de_2 = _Holder(_decode_block(6 * c, c), "decode")
+        self.de_1 = nn.Sequential(nn.Identity(), nn.ConvTranspose2d(3 * c, c_img, 3, 1, padding=1))
+        self._pack = None
+
+    @staticmethod
+    def _bn(m):
+        return (m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+
+    def _packed(self):
+        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if self._pack is not None and self._pack[0] == key:
+            return self._pack[1]
+        P = {}
+        with torch.no_grad():
+            for br in ("1", "2"):
+                e1 = getattr(self, "en_1_" + br)
+                P["en_1_" + br] = packing.pack_conv(e1.weight, e1.bias, cin_pad=4)
+                for lvl in (2, 3, 4, 5):
+                    seq = getattr(self, "en_%d_%s" % (lvl, br)).encode
+                    P["en_%d_%s.a" % (lvl, br)] = packing.pack_conv(seq[1].weight, seq[1].bias, self._bn(seq[2]))
+                    P["en_%d_%s.b" % (lvl, br)] = packing.pack_conv(seq[4].weight, seq[4].bias, self._bn(seq[5]))
+                e6 = getattr(self, "en_6_" + br)[1]
+                P["en_6_" + br] = packing.pack_conv(e6.weight, e6.bias)
+            P["de_6"] = packing.pack_convT_s2k4(self.de_6[1].weight, self.de_6[1].bias, self._bn(self.de_6[2]))
+            for lvl in (5, 4, 3, 2):
+                seq = getattr(self, "de_%d" % lvl).decode
+                P["de_%d.a" % lvl] = packing.pack_convT_s1(seq[1].weight, seq[1].bias, self._bn(seq[2]))
+                P["de_%d.b" % lvl] = packing.pack_convT_s2k4(seq[4].weight, seq[4].bias, self._bn(seq[5]))
+            P["de_1"] = packing.pack_convT_s1(self.de_1[1].weight, self.de_1[1].bias)
+        self._pack = (key, P)
+        return P
+
+    def forward(self, x1, x2):
+        if self.training:
+            raise NotImplementedError("dpmn_amd CMM: train-mode BatchNorm (batch statistics) + backward are not built yet; "
+                                      "call .eval()")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("dpmn_amd CMM: backward kernels are not built yet; call under torch.no_grad()")
+        P = self._packed()
+        c = self.cnum
+        enc = []
+        for br, x in (("1", x1), ("2", x2)):
+            xin = ops.nchw_to_nhwc(x.contiguous().float(), 4)
+            o = [ops.conv2d([xin], *P["en_1_" + br], c, 3, pad=1)]
+            chans = {2: (c, 2 * c), 3: (2 * c, 4 * c), 4: (4 * c, 8 * c), 5: (8 * c, 8 * c)}
+            for lvl in (2, 3, 4, 5):
+                ci, co = chans[lvl]
+                t = ops.conv2d([o[-1]], *P["en_%d_%s.a" % (lvl, br)], ci, 4, stride=2, pad=3, dil=2, pro_act="leaky02")
+                o.append(ops.conv2d([t], *P["en_%d_%s.b" % (lvl, br)], co, 3, pad=1, pro_act="leaky02"))
+            o.append(ops.conv2d([o[-1]], *P["en_6_" + br], 8 * c, 4, stride=2, pad=1, pro_act="leaky02"))
+            enc.append(o)
+        a, b = enc
+        bott = torch.cat([a[5], b[5]], dim=3)  # (B,1,4,16c) tiny concat feeding the gate (device memory plumbing)
+        gated = ops.se_gate(bott, self.fc_1.weight, self.fc_1.bias, self.fc_2.weight, self.fc_2.bias)
+        d = ops.convT_s2k4([gated], P["de_6"], 8 * c, pro_act="relu")
+        outc = {5: 8 * c, 4: 4 * c, 3: 2 * c, 2: c}
+        for lvl, skip in ((5, 4), (4, 3), (3, 2), (2, 1)):
+            t = ops.conv2d([d, a[skip], b[skip]], *P["de_%d.a" % lvl], outc[lvl], 3, pad=1, pro_act="relu")
+            d = ops.convT_s2k4([t], P["de_%d.b" % lvl], outc[lvl], pro_act="relu")
+        return ops.conv2d([d, a[0], b[0]], *P["de_1"], self.c_img, 3, pad=1, pro_act="relu", out_nchw=True)

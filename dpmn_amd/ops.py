@@ -94,3 +94,83 @@ def pgrm_tail(tokens, w0, b0, w1, b1, weight_list, residuals, H, W, hidden, patc
                                  _abi.ptr_array(residuals), len(residuals), dptr(mid), dptr(out), B, H, W, Cd, hidden,
                                  patch, stream()))
     return out
+
+
+# ------------------------------------------------------------------------------ conv family
+def nchw_to_nhwc(x, cpad=None):
+    B, Cc, H, W = x.shape
+    cpad = cpad or Cc
+    out = torch.empty(B, H, W, cpad, device=x.device)
+    check(lib.dpmn_nchw_to_nhwc_f32(dptr(x), dptr(out), B, Cc, H, W, cpad, stream()))
+    return out
+
+
+def nhwc_to_nchw(x):
+    B, H, W, Cc = x.shape
+    out = torch.empty(B, Cc, H, W, device=x.device)
+    check(lib.dpmn_nhwc_to_nchw_f32(dptr(x), dptr(out), B, Cc, H, W, stream()))
+    return out
+
+
+def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", epi_act="none", slope=0.0, res=None,
+           affine=None, out=None, out_nchw=False, pixel_shuffle=False, stats=None, phase=None, out_hw=None):
+    """inputs: list of 1..3 NHWC tensors (channel-concatenated on the fly).  k: int or (KH, KW).
+    phase=(py, px): one output phase of ConvTranspose2d(4,2,1) (k=2, dil=-1, pad=-phase).
+    affine: optional list of (scale, shift) per input segment."""
+    d = _abi.ConvDesc()
+    B, Hin, Win, _ = inputs[0].shape
+    for i, t in enumerate(inputs):
+        d.inp[i] = dptr(t)
+        d.cseg[i] = t.shape[3]
+        if affine is not None and affine[i] is not None:
+            d.in_scale[i], d.in_shift[i] = dptr(affine[i][0]), dptr(affine[i][1])
+    kh, kw = (k, k) if isinstance(k, int) else k
+    d.B, d.Hin, d.Win, d.KH, d.KW = B, Hin, Win, kh, kw
+    if phase is None:
+        ph, pw = (pad, pad) if isinstance(pad, int) else pad
+        d.stride, d.dil_y, d.dil_x, d.pad_y, d.pad_x = stride, dil, dil, ph, pw
+        Ho = (Hin + 2 * ph - dil * (kh - 1) - 1) // stride + 1
+        Wo = (Win + 2 * pw - dil * (kw - 1) - 1) // stride + 1
+        d.Hp, d.Wp, d.Hout, d.Wout, d.ostep, d.ooy, d.oox = Ho, Wo, Ho, Wo, 1, 0, 0
+    else:
+        py, px = phase
+        d.stride, d.dil_y, d.dil_x, d.pad_y, d.pad_x = 1, -1, -1, -py, -px
+        Ho, Wo = 2 * Hin, 2 * Win
+        d.Hp, d.Wp, d.Hout, d.Wout, d.ostep, d.ooy, d.oox = Hin, Win, Ho, Wo, 2, py, px
+    d.pro_act, d.epi_act, d.slope = ACT[pro_act], ACT[epi_act], float(slope)
+    d.w, d.bias, d.Cout = dptr(wp), dptr(bias, True), cout
+    d.res = dptr(res, True)
+    if out is None:
+        if out_nchw:
+            out = torch.empty(B, cout, Ho, Wo, device=wp.device)
+        elif pixel_shuffle:
+            out = torch.empty(B, 2 * Ho, 2 * Wo, cout // 4, device=wp.device)
+        else:
+            out = torch.empty(B, Ho, Wo, cout, device=wp.device)
+    d.out = dptr(out)
+    d.out_ld, d.out_coff, d.out_nchw, d.pixel_shuffle = 0, 0, int(out_nchw), int(pixel_shuffle)
+    d.stats = dptr(stats, True)
+    import ctypes as _C
+    check(lib.dpmn_conv2d_nhwc_f32(_C.byref(d), stream()))
+    return out
+
+
+def convT_s2k4(inputs, packs, cout, pro_act="none", affine=None, stats=None):
+    """ConvTranspose2d(4, stride 2, padding 1) as 4 phase launches into one NHWC output."""
+    B, Hin, Win, _ = inputs[0].shape
+    out = torch.empty(B, 2 * Hin, 2 * Win, cout, device=inputs[0].device)
+    i = 0
+    for py in range(2):
+        for px in range(2):
+            wp, bias = packs[i]
+            conv2d(inputs, wp, bias, cout, 2, pro_act=pro_act, affine=affine, out=out, phase=(py, px), stats=stats)
+            i += 1
+    return out
+
+
+def se_gate(x, fc1_w, fc1_b, fc2_w, fc2_b):
+    B, H, W, Cc = x.shape
+    out = torch.empty_like(x)
+    check(lib.dpmn_se_gate_f32(dptr(x), dptr(fc1_w), dptr(fc1_b), dptr(fc2_w), dptr(fc2_b), dptr(out), B, H * W, Cc,
+                               fc1_w.shape[0], stream()))
+    return out

@@ -56,6 +56,42 @@ int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_h
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream);
 
+/* ------------------------------------------------------------------ NHWC implicit-GEMM conv (conv.hip) */
+/* One descriptor drives nn.Conv2d / nn.ConvTranspose2d call sites of cmm.py:44-71,86-118 and
+ * tsrn.py/tatt.py conv stacks.  Inputs are up to 3 channel-concatenated NHWC segments (torch.cat of
+ * cmm.py:150-158 is never materialised); weights are pre-packed (Cout, roundup(KH*KW*Cin,32)) with
+ * K index = (ky*KW + kx)*Cin + ci (see dpmn_amd/model/packing.py). */
+typedef struct {
+  const float* in[3];        /* NHWC (B,Hin,Win,cseg[s]) ; unused = NULL */
+  const float* in_scale[3];  /* optional per-channel affine applied on load (train-mode BatchNorm) */
+  const float* in_shift[3];
+  int cseg[3];
+  int B, Hin, Win;
+  int KH, KW, stride, dil_y, dil_x, pad_y, pad_x; /* iy = oy'*stride + ky*dil_y - pad_y (dil may be -1) */
+  int Hp, Wp;                                      /* pixels computed per image (phase grid) */
+  int Hout, Wout, ostep, ooy, oox;                 /* oy = oy'*ostep + ooy within the (Hout,Wout) output */
+  int pro_act;                                     /* DPMN_ACT_* applied to inputs after the affine */
+  const float* w;
+  const float* bias;
+  int Cout;
+  int epi_act;
+  float slope;
+  const float* res;          /* residual in output layout, or NULL */
+  float* out;
+  int out_ld, out_coff;      /* NHWC channel stride (0 = Cout) and channel offset */
+  int out_nchw;              /* store NCHW instead */
+  int pixel_shuffle;         /* PixelShuffle(2) store: NHWC (B,2Hout,2Wout,Cout/4) (tsrn.py:110-111) */
+  float* stats;              /* (2,Cout) += sum / sum of squares of pre-activation outputs, or NULL */
+} dpmn_conv_desc;
+int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream);
+/* layout plumbing at the module boundary: NCHW images <-> NHWC (channels zero-padded to Cpad) */
+int dpmn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, dpmn_stream_t stream);
+int dpmn_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, dpmn_stream_t stream);
+
+/* CMM channel gate (cmm.py:135-147) on the NHWC bottleneck x (B,P,C): out = x * sigmoid(fc2(relu(fc1(mean_p x)))) + x */
+int dpmn_se_gate_f32(const float* x, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
+                     float* out, int B, int P, int C, int Cmid, dpmn_stream_t stream);
+
 /* ------------------------------------------------------------------ PGRM kernels (pgrm.hip) */
 /* prior_fusion (optional, pf_w != NULL; pgrm.py:548) + PatchEmbed conv k=s=patch + LayerNorm (pgrm.py:419-426).
  * img NCHW (B,cin,Hi,Wi) -> tokens (B, Hi/patch*Wi/patch, C). */

@@ -1,0 +1,152 @@
+"""GPU parity: NHWC implicit-GEMM conv (all the Conv2d / ConvTranspose2d shapes of cmm.py), the CMM
+channel gate and the whole CMM module vs the oracle and the reference golden vectors."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dpmn_amd.utils import synth
+from helpers import load_golden, sd_from_manifest, t, assert_close
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 1e-4, 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def u(name, shape, lo=-1.0, hi=1.0, seed=50):
+    return synth.uniform(name, shape, lo, hi, seed)
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,H,W", [
+    (64, 64, 4, 2, 3, 2, 32, 128),    # EncodeBlock first conv (cmm.py:44)
+    (64, 128, 3, 1, 1, 1, 16, 64),    # EncodeBlock second conv (cmm.py:49)
+    (8, 16, 3, 1, 1, 1, 16, 64),      # cnum=8 variant: Cin not a multiple of 32
+    (512, 512, 4, 2, 1, 1, 2, 8),     # en_6 (cmm.py:93)
+    (32, 12, 3, 1, 1, 1, 16, 64),     # small Cout (N masking)
+    (64, 256, 3, 1, 1, 1, 16, 64),    # UpsampleBLock conv (tsrn.py:110)
+    (4, 64, 9, 1, 4, 1, 16, 64),      # TSRN block1 9x9 (tsrn.py:26), NHWC input padded to 4 channels
+    (64, 4, 9, 1, 4, 1, 32, 128),     # TSRN last conv 9x9 (tsrn.py:40)
+])
+def test_conv2d_matches_torch(dev, cin, cout, k, stride, pad, dil, H, W):
+    from dpmn_amd import ops
+    from dpmn_amd.model import packing
+    B = 3
+    x = u("x", (B, cin, H, W))
+    w = u("w", (cout, cin, k, k), -1, 1) * (1.0 / (cin * k * k) ** 0.5)
+    b = u("b", (cout,))
+    ref = F.conv2d(F.leaky_relu(x, 0.2), w, b, stride=stride, padding=pad, dilation=dil)
+    wp, bp = packing.pack_conv(w.to(dev), b.to(dev))
+    got = ops.conv2d([nhwc(x).to(dev)], wp, bp, cout, k, stride=stride, pad=pad, dil=dil, pro_act="leaky02")
+    assert_close(got.permute(0, 3, 1, 2), ref, ATOL, RTOL, "conv %s" % ((cin, cout, k, stride, pad, dil),))
+    got2 = ops.conv2d([nhwc(x).to(dev)], wp, bp, cout, k, stride=stride, pad=pad, dil=dil, pro_act="leaky02", out_nchw=True,
+                      epi_act="tanh")
+    assert_close(got2, torch.tanh(ref), ATOL, RTOL, "conv nchw+tanh")
+
+
+def test_conv2d_bn_fold_segments_residual_and_pixelshuffle(dev):
+    from dpmn_amd import ops
+    from dpmn_amd.model import packing
+    B, H, W = 2, 8, 32
+    xs = [u("s%d" % i, (B, c, H, W)) for i, c in enumerate((64, 32, 32))]
+    cin, cout = 128, 64
+    w = u("w", (cout, cin, 3, 3)) * 0.05
+    b = u("b", (cout,))
+    bn = (u("g", (cout,), 0.5, 1.5), u("be", (cout,)), u("mu", (cout,), -0.2, 0.2), u("var", (cout,), 0.5, 1.5), 1e-5)
+    res = u("res", (B, cout, H, W))
+    xcat = torch.cat(xs, 1)
+    ref = F.batch_norm(F.conv2d(F.relu(xcat), w, b, padding=1), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    wp, bp = packing.pack_conv(w.to(dev), b.to(dev), tuple(v.to(dev) if torch.is_tensor(v) else v for v in bn))
+    got = ops.conv2d([nhwc(x).to(dev) for x in xs], wp, bp, cout, 3, pad=1, pro_act="relu", epi_act="mish",
+                     res=nhwc(res).to(dev))
+    assert_close(got.permute(0, 3, 1, 2), ref * torch.tanh(F.softplus(ref)) + res, ATOL, RTOL, "segments+bn+mish+res")
+    # per-segment affine on load (train-mode BN of the producers) + stats accumulation
+    sc = [u("sc%d" % i, (c,), 0.5, 1.5) for i, c in enumerate((64, 32, 32))]
+    sh = [u("sh%d" % i, (c,), -0.3, 0.3) for i, c in enumerate((64, 32, 32))]
+    xa = torch.cat([x * s[None, :, None, None] + h[None, :, None, None] for x, s, h in zip(xs, sc, sh)], 1)
+    ref2 = F.conv2d(F.relu(xa), w, b, padding=1)
+    wp2, bp2 = packing.pack_conv(w.to(dev), b.to(dev))
+    stats = torch.zeros(2, cout, device=dev)
+    got2 = ops.conv2d([nhwc(x).to(dev) for x in xs], wp2, bp2, cout, 3, pad=1, pro_act="relu",
+                      affine=[(s.to(dev), h.to(dev)) for s, h in zip(sc, sh)], stats=stats)
+    assert_close(got2.permute(0, 3, 1, 2), ref2, ATOL, RTOL, "affine on load")
+    assert_close(stats[0], ref2.sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sum")
+    assert_close(stats[1], (ref2 * ref2).sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sumsq")
+    # PixelShuffle(2) epilogue (UpsampleBLock, tsrn.py:110-112)
+    w4 = u("w4", (256, 64, 3, 3)) * 0.05
+    b4 = u("b4", (256,))
+    x4 = u("x4", (B, 64, H, W))
+    r = F.pixel_shuffle(F.conv2d(x4, w4, b4, padding=1), 2)
+    ref3 = r * torch.tanh(F.softplus(r))
+    wp4, bp4 = packing.pack_conv(w4.to(dev), b4.to(dev))
+    got3 = ops.conv2d([nhwc(x4).to(dev)], wp4, bp4, 256, 3, pad=1, epi_act="mish", pixel_shuffle=True)
+    assert_close(got3.permute(0, 3, 1, 2), ref3, ATOL, RTOL, "pixel shuffle + mish")
+
+
+@pytest.mark.parametrize("cin,cout,H,W", [(64, 32, 4, 16), (1024, 512, 1, 4), (24, 8, 8, 32)])
+def test_conv_transpose_matches_torch(dev, cin, cout, H, W):
+    from dpmn_amd import ops
+    from dpmn_amd.model import packing
+    B = 2
+    x = u("x", (B, cin, H, W))
+    w3 = u("w3", (cin, cout, 3, 3)) * (1.0 / (cin * 9) ** 0.5)
+    w4 = u("w4", (cin, cout, 4, 4)) * (1.0 / (cin * 4) ** 0.5)
+    b = u("b", (cout,))
+    xd = nhwc(x).to(dev)
+    ref = F.conv_transpose2d(F.relu(x), w3, b, stride=1, padding=1)
+    wp, bp = packing.pack_convT_s1(w3.to(dev), b.to(dev))
+    got = ops.conv2d([xd], wp, bp, cout, 3, pad=1, pro_act="relu")
+    assert_close(got.permute(0, 3, 1, 2), ref, ATOL, RTOL, "convT 3x3 s1")
+    ref = F.conv_transpose2d(F.relu(x), w4, b, stride=2, padding=1)
+    got = ops.convT_s2k4([xd], packing.pack_convT_s2k4(w4.to(dev), b.to(dev)), cout, pro_act="relu")
+    assert_close(got.permute(0, 3, 1, 2), ref, ATOL, RTOL, "convT 4x4 s2")
+
+
+def test_layout_helpers(dev):
+    from dpmn_amd import ops
+    x = u("x", (3, 3, 32, 128))
+    y = ops.nchw_to_nhwc(x.to(dev), 4)
+    assert_close(y[..., :3], nhwc(x), 0, 0, "nchw->nhwc")
+    assert float(y[..., 3].abs().max()) == 0.0
+    assert_close(ops.nhwc_to_nchw(y), torch.cat([x, torch.zeros(3, 1, 32, 128)], 1), 0, 0, "nhwc->nchw")
+
+
+@pytest.mark.parametrize("cnum", [8, 64])
+def test_cmm_module_vs_reference_golden(dev, cnum):
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    g = load_golden("cmm_cnum%d" % cnum)
+    m = ComplementationModulationModule(cnum=cnum).eval()
+    sd = m.state_dict()
+    man = [str(r).split("|")[0] for r in g["manifest"]]
+    assert list(sd.keys()) == man
+    synth.synth_fill_(sd, 31)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x1 = synth.uniform("cmm_x1", (2, 3, 32, 128), 0, 1, 7).to(dev)
+    x2 = synth.uniform("cmm_x2", (2, 3, 32, 128), 0, 1, 7).to(dev)
+    with torch.no_grad():
+        out = m(x1, x2)
+    assert_close(out, t(g["out_eval"]), 2e-4, 2e-4, "CMM eval vs reference golden cnum=%d" % cnum)
+
+
+def test_cmm_module_batch48_vs_oracle(dev):
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    from oracle import cmm as ocmm
+    B = 48
+    m = ComplementationModulationModule(cnum=16).eval()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 33)
+    m.load_state_dict(sd)
+    x1, x2 = u("x1", (B, 3, 32, 128), 0, 1), u("x2", (B, 3, 32, 128), 0, 1)
+    ref = ocmm.cmm_forward({k: v.clone() for k, v in sd.items()}, x1, x2, False)
+    m = m.to(dev)
+    with torch.no_grad():
+        out = m(x1.to(dev), x2.to(dev))
+    assert_close(out, ref, 2e-4, 2e-4, "CMM B=48 vs oracle")
