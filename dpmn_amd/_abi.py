@@ -66,6 +66,12 @@ SIGNATURES = {
     "dpmn_nchw_to_nhwc_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_nhwc_to_nchw_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_se_gate_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_bigru_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _i, fp]),
+    "dpmn_small_linear_f32": (_i, [fp, fp, _i, fp, fp, fp, _i, _i, _i, _i, _f, fp]),
+    "dpmn_tatt_encoder_layer_f32": (_i, [fp, fp, _PP, fp, _i, _i, _i, _i, fp]),
+    "dpmn_cross_attn_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_add_layernorm64_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, _f, _i, C.c_long, fp]),
+    "dpmn_gru_gate_f32": (_i, [fp, fp, fp, fp, C.c_long, _i, _i, fp]),
     "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

@@ -1,0 +1,361 @@
+// Kernels for the PSN backbones TSRN / TATT beyond plain convs and GEMMs:
+//   * BiGRU recurrence of GruBlock (tsrn.py:139-150, tatt.py:1070-1083) -- persistent-register kernel,
+//     one wave per sequence (lane = direction x hidden unit), W_hh rows held in VGPRs, h broadcast via LDS;
+//     the input projection (conv1x1 folded with W_ih) is a separate implicit-GEMM launch;
+//   * TPInterpreter pieces (tatt.py:193-223, transformer_v2.py:198-244, 455-469, 806-833): tiny linear,
+//     fused 26-token encoder layer (one workgroup per image), 1024x26 cross attention, add+LayerNorm,
+//     and the gate step of the query-embedding GRU (batch_first quirk Q5).
+// Token tensors here are (N, L, E) row-major (N = image, L = 26 text slots or 1024 pixels, E = 64):
+// the reference's (L, N, E) differs only by a transpose no kernel needs.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- BiGRU recurrence
+// gi: (pixels, 2*3*HID) = [dir0: r z n | dir1: r z n] precomputed input projection (bias folded)
+// seq s -> base pixel = (s / inner) * outer_stride + (s % inner) * inner_stride ; step t adds t*step_stride (pixels)
+template <int HID>
+__global__ __launch_bounds__(256) void k_bigru(const float* __restrict__ gi, const float* __restrict__ w_hh /*(2,3H,H)*/,
+                                                const float* __restrict__ b_hh /*(2,3H)*/, const float* __restrict__ res,
+                                                float* __restrict__ out, int nseq, int T, int inner, long outer_stride,
+                                                long inner_stride, long step_stride) {
+  static_assert(HID == 32, "lane mapping assumes 32 hidden units per direction");
+  __shared__ __attribute__((aligned(16))) float hs[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int dir = lane >> 5, j = lane & 31;
+  const long s = (long)blockIdx.x * 4 + wave;
+  const bool active = s < nseq;
+  float wr[HID], wz[HID], wn[HID];
+  const float* wb = w_hh + (size_t)dir * 3 * HID * HID;
+#pragma unroll
+  for (int k = 0; k < HID; ++k) {
+    wr[k] = wb[(size_t)j * HID + k];
+    wz[k] = wb[(size_t)(HID + j) * HID + k];
+    wn[k] = wb[(size_t)(2 * HID + j) * HID + k];
+  }
+  const float br = b_hh[dir * 3 * HID + j], bz = b_hh[dir * 3 * HID + HID + j], bn = b_hh[dir * 3 * HID + 2 * HID + j];
+  const long base = active ? (s / inner) * outer_stride + (s % inner) * inner_stride : 0;
+  float h = 0.f;
+  for (int t = 0; t < T; ++t) {
+    const int tt = dir ? T - 1 - t : t;
+    const long pix = base + (long)tt * step_stride;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (active) {
+      const float* g = gi + pix * (6 * HID) + dir * 3 * HID + j;
+      gr = g[0]; gz = g[HID]; gn = g[2 * HID];
+    }
+    hs[wave][lane] = h;
+    __syncthreads();
+    float ar0 = br, az0 = bz, an0 = bn, ar1 = 0.f, az1 = 0.f, an1 = 0.f;
+    const float* hp = &hs[wave][dir * HID];
+#pragma unroll
+    for (int k = 0; k < HID; k += 8) {
+      const float4 h0 = *reinterpret_cast<const float4*>(hp + k);
+      const float4 h1 = *reinterpret_cast<const float4*>(hp + k + 4);
+      ar0 += wr[k] * h0.x + wr[k + 1] * h0.y + wr[k + 2] * h0.z + wr[k + 3] * h0.w;
+      az0 += wz[k] * h0.x + wz[k + 1] * h0.y + wz[k + 2] * h0.z + wz[k + 3] * h0.w;
+      an0 += wn[k] * h0.x + wn[k + 1] * h0.y + wn[k + 2] * h0.z + wn[k + 3] * h0.w;
+      ar1 += wr[k + 4] * h1.x + wr[k + 5] * h1.y + wr[k + 6] * h1.z + wr[k + 7] * h1.w;
+      az1 += wz[k + 4] * h1.x + wz[k + 5] * h1.y + wz[k + 6] * h1.z + wz[k + 7] * h1.w;
+      an1 += wn[k + 4] * h1.x + wn[k + 5] * h1.y + wn[k + 6] * h1.z + wn[k + 7] * h1.w;
+    }
+    __syncthreads();
+    const float r = sigmoid_f(gr + ar0 + ar1);
+    const float z = sigmoid_f(gz + az0 + az1);
+    const float n = tanhf(gn + r * (an0 + an1));
+    h = (1.f - z) * n + z * h;
+    if (active) {
+      const long o = pix * (2 * HID) + dir * HID + j;
+      out[o] = h + (res ? res[o] : 0.f);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- tiny linear
+// y[m][n] = act((x[m][:] (+ add[m % add_rows][:])) . w[n][:] + b[n]) -- one thread per output; for problems of a few MFLOP
+__global__ void k_small_linear(const float* __restrict__ x, const float* __restrict__ add, int add_rows,
+                               const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y, int M, int N,
+                               int K, int act, float slope) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)M * N) return;
+  const int m = idx / N, n = idx % N;
+  const float* xr = x + (size_t)m * K;
+  const float* ar = add ? add + (size_t)(m % add_rows) * K : nullptr;
+  const float* wr = w + (size_t)n * K;
+  float a = b ? b[n] : 0.f;
+  for (int k = 0; k < K; ++k) a += (xr[k] + (ar ? ar[k] : 0.f)) * wr[k];
+  y[idx] = apply_act(a, act, slope);
+}
+
+// ---------------------------------------------------------------------------------- encoder layer (L <= 32 tokens)
+// One workgroup per image n.  src (N, L, E); pos (L, E).  Implements TransformerEncoder with ONE layer:
+// layer input = src + src (transformer_v2.py:272-277), forward_post (455-469).  E = 64, 4 heads.
+struct EncW {
+  const float *in_w, *in_b, *out_w, *out_b, *l1_w, *l1_b, *l2_w, *l2_b, *n1_w, *n1_b, *n2_w, *n2_b;
+};
+template <int E, int NH>
+__global__ __launch_bounds__(256) void k_encoder_layer(const float* __restrict__ src, const float* __restrict__ pos, EncW w,
+                                                        float* __restrict__ mem, int L) {
+  constexpr int LMAX = 32, D = E / NH;
+  __shared__ float s2[LMAX][E], Q[LMAX][E], Kk[LMAX][E], V[LMAX][E], O[LMAX][E], P[NH][LMAX][LMAX];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < L * E; i += 256) {
+    const int l = i / E, e = i % E;
+    const float v = 2.0f * src[((size_t)n * L + l) * E + e];
+    s2[l][e] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < L * E; i += 256) {
+    const int l = i / E, e = i % E;
+    float aq = w.in_b[e], ak = w.in_b[E + e], av = w.in_b[2 * E + e];
+    for (int k = 0; k < E; ++k) {
+      const float sv = s2[l][k], qv = sv + pos[l * E + k];   // q = k = src + pos, v = src (transformer_v2.py:462-465)
+      aq += qv * w.in_w[e * E + k];
+      ak += qv * w.in_w[(E + e) * E + k];
+      av += sv * w.in_w[(2 * E + e) * E + k];
+    }
+    Q[l][e] = aq; Kk[l][e] = ak; V[l][e] = av;
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)D);
+  for (int i = tid; i < NH * L * L; i += 256) {
+    const int hh = i / (L * L), a = (i / L) % L, bb = i % L;
+    float sc = 0.f;
+    for (int d = 0; d < D; ++d) sc += Q[a][hh * D + d] * Kk[bb][hh * D + d];
+    P[hh][a][bb] = sc * scale;
+  }
+  __syncthreads();
+  for (int i = tid; i < NH * L; i += 256) {
+    const int hh = i / L, a = i % L;
+    float mx = -INFINITY;
+    for (int bb = 0; bb < L; ++bb) mx = fmaxf(mx, P[hh][a][bb]);
+    float den = 0.f;
+    for (int bb = 0; bb < L; ++bb) { const float p = expf(P[hh][a][bb] - mx); P[hh][a][bb] = p; den += p; }
+    const float inv = 1.0f / den;
+    for (int bb = 0; bb < L; ++bb) P[hh][a][bb] *= inv;
+  }
+  __syncthreads();
+  for (int i = tid; i < L * E; i += 256) {
+    const int l = i / E, e = i % E, hh = e / D;
+    float a = 0.f;
+    for (int bb = 0; bb < L; ++bb) a += P[hh][l][bb] * V[bb][e];
+    O[l][e] = a;
+  }
+  __syncthreads();
+  // out_proj + residual -> Q (reuse) ; then LayerNorm1 -> s2
+  for (int i = tid; i < L * E; i += 256) {
+    const int l = i / E, e = i % E;
+    float a = w.out_b[e];
+    for (int k = 0; k < E; ++k) a += O[l][k] * w.out_w[e * E + k];
+    Q[l][e] = s2[l][e] + a;
+  }
+  __syncthreads();
+  auto layer_norm_rows = [&](float (*in)[E], float (*outp)[E], const float* g, const float* be) {
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int l = wave; l < L; l += 4) {
+      const float v = in[l][lane];   // E == 64 == wave width
+      const float mean = wave_sum(v) * (1.0f / E);
+      const float dlt = v - mean;
+      const float var = wave_sum(dlt * dlt) * (1.0f / E);
+      outp[l][lane] = dlt * (1.0f / sqrtf(var + 1e-5f)) * g[lane] + be[lane];
+    }
+  };
+  layer_norm_rows(Q, s2, w.n1_w, w.n1_b);
+  __syncthreads();
+  for (int i = tid; i < L * E; i += 256) {
+    const int l = i / E, e = i % E;
+    float a = w.l1_b[e];
+    for (int k = 0; k < E; ++k) a += s2[l][k] * w.l1_w[e * E + k];
+    O[l][e] = a > 0.f ? a : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < L * E; i += 256) {
+    const int l = i / E, e = i % E;
+    float a = w.l2_b[e];
+    for (int k = 0; k < E; ++k) a += O[l][k] * w.l2_w[e * E + k];
+    Q[l][e] = s2[l][e] + a;
+  }
+  __syncthreads();
+  layer_norm_rows(Q, Kk, w.n2_w, w.n2_b);
+  __syncthreads();
+  for (int i = tid; i < L * E; i += 256) mem[(size_t)n * L * E + i] = Kk[i / E][i % E];
+}
+
+// ---------------------------------------------------------------------------------- cross attention (S <= 32 keys)
+// q (N, L, E) projected queries; k, v (N, S, E) projected keys/values.  One wave = 64 queries, lane = query;
+// all NH heads per lane.  Optional head-averaged weights pw (N, L, S) (MultiheadAttention need_weights).
+template <int E, int NH>
+__global__ __launch_bounds__(256) void k_cross_attn(const float* __restrict__ q, const float* __restrict__ k,
+                                                     const float* __restrict__ v, float* __restrict__ o, float* __restrict__ pw,
+                                                     int L, int S) {
+  constexpr int SMAX = 32, D = E / NH;
+  __shared__ __attribute__((aligned(16))) float Ks[SMAX][E], Vs[SMAX][E];
+  const int n = blockIdx.y, tid = threadIdx.x;
+  for (int i = tid; i < S * E; i += 256) {
+    Ks[i / E][i % E] = k[(size_t)n * S * E + i];
+    Vs[i / E][i % E] = v[(size_t)n * S * E + i];
+  }
+  __syncthreads();
+  const int l = blockIdx.x * 256 + tid;
+  if (l >= L) return;
+  const float* qr = q + ((size_t)n * L + l) * E;
+  float* orow = o + ((size_t)n * L + l) * E;
+  const float scale = 1.0f / sqrtf((float)D);
+  float pavg[SMAX];
+#pragma unroll
+  for (int s = 0; s < SMAX; ++s) pavg[s] = 0.f;
+#pragma unroll
+  for (int hh = 0; hh < NH; ++hh) {
+    float qv[D];
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      const float4 t4 = *reinterpret_cast<const float4*>(qr + hh * D + d);
+      qv[d] = t4.x * scale; qv[d + 1] = t4.y * scale; qv[d + 2] = t4.z * scale; qv[d + 3] = t4.w * scale;
+    }
+    float sc[SMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      float a = -INFINITY;
+      if (s < S) {
+        a = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) a += qv[d] * Ks[s][hh * D + d];
+      }
+      sc[s] = a;
+      mx = fmaxf(mx, a);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) { sc[s] = (s < S) ? expf(sc[s] - mx) : 0.f; den += sc[s]; }
+    const float inv = 1.0f / den;
+    float acc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc[d] = 0.f;
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      const float p = sc[s] * inv;
+      pavg[s] += p;
+      if (s < S) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc[d] += p * Vs[s][hh * D + d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; d += 4)
+      *reinterpret_cast<float4*>(orow + hh * D + d) = make_float4(acc[d], acc[d + 1], acc[d + 2], acc[d + 3]);
+  }
+  if (pw) {
+    float* pr = pw + ((size_t)n * L + l) * S;
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) if (s < S) pr[s] = pavg[s] * (1.0f / NH);
+  }
+}
+
+// ---------------------------------------------------------------------------------- (x + res) -> LayerNorm (E = 64)
+// y = LN(x + res) * g + b ; optionally acc_out += alpha * LN2(y) (decoder.norm on the intermediate, then mean over layers)
+__global__ __launch_bounds__(256) void k_add_layernorm64(const float* __restrict__ x, const float* __restrict__ res,
+                                                          const float* __restrict__ g, const float* __restrict__ b,
+                                                          float* __restrict__ y, const float* __restrict__ g2,
+                                                          const float* __restrict__ b2, float* __restrict__ acc_out, float alpha,
+                                                          int accumulate, long M) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= M) return;
+  float v = x[row * 64 + lane] + (res ? res[row * 64 + lane] : 0.f);
+  float mean = wave_sum(v) * (1.0f / 64);
+  float d = v - mean;
+  float var = wave_sum(d * d) * (1.0f / 64);
+  const float o = d * (1.0f / sqrtf(var + 1e-5f)) * g[lane] + b[lane];
+  y[row * 64 + lane] = o;
+  if (acc_out) {
+    mean = wave_sum(o) * (1.0f / 64);
+    d = o - mean;
+    var = wave_sum(d * d) * (1.0f / 64);
+    const float o2 = (d * (1.0f / sqrtf(var + 1e-5f)) * g2[lane] + b2[lane]) * alpha;
+    acc_out[row * 64 + lane] = accumulate ? acc_out[row * 64 + lane] + o2 : o2;
+  }
+}
+
+// ---------------------------------------------------------------------------------- GRU gate step (query-embed GRU)
+// gi (R, 3H) constant input projection (bias folded), gh (R, 3H) = h_prev . W_hh^T + b_hh ; h (R, H) updated in place;
+// hist (R, H) receives a copy (the GRU output at this step).
+__global__ void k_gru_gate(const float* __restrict__ gi, const float* __restrict__ gh, float* __restrict__ h,
+                           float* __restrict__ hist, long hist_row_stride, int R, int H) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)R * H) return;
+  const int r_ = idx / H, j = idx % H;
+  const float* a = gi + (size_t)r_ * 3 * H;
+  const float* c = gh + (size_t)r_ * 3 * H;
+  const float r = sigmoid_f(a[j] + c[j]);
+  const float z = sigmoid_f(a[H + j] + c[H + j]);
+  const float n = tanhf(a[2 * H + j] + r * c[2 * H + j]);
+  const float hn = (1.f - z) * n + z * h[idx];
+  h[idx] = hn;
+  hist[(size_t)r_ * hist_row_stride + j] = hn;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpmn_bigru_f32(const float* gi, const float* w_hh, const float* b_hh, const float* res, float* out, int nseq, int T,
+                   int inner, long outer_stride, long inner_stride, long step_stride, int hidden, dpmn_stream_t stream) {
+  DPMN_REQUIRE(gi && w_hh && b_hh && out && nseq > 0 && T > 0 && inner > 0, "bigru: bad arguments");
+  DPMN_REQUIRE(hidden == 32, "bigru: built for hidden_units=32 per direction (hd_u default, main.py:47)");
+  hipLaunchKernelGGL((k_bigru<32>), dim3((unsigned)((nseq + 3) / 4)), dim3(256), 0, as_stream(stream), gi, w_hh, b_hh, res, out,
+                     nseq, T, inner, outer_stride, inner_stride, step_stride);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_small_linear_f32(const float* x, const float* add, int add_rows, const float* w, const float* b, float* y, int M,
+                          int N, int K, int act, float slope, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, "small_linear: bad arguments");
+  const long total = (long)M * N;
+  hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, add,
+                     add_rows > 0 ? add_rows : 1, w, b, y, M, N, K, act, slope);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_tatt_encoder_layer_f32(const float* src, const float* pos, const float* const* w12, float* mem, int N, int L,
+                                int E, int nhead, dpmn_stream_t stream) {
+  DPMN_REQUIRE(src && pos && w12 && mem && N > 0, "encoder_layer: bad arguments");
+  DPMN_REQUIRE(E == 64 && nhead == 4 && L <= 32, "encoder_layer: built for d_model=64, 4 heads, <=32 tokens (tatt.py:171-178)");
+  EncW w{w12[0], w12[1], w12[2], w12[3], w12[4], w12[5], w12[6], w12[7], w12[8], w12[9], w12[10], w12[11]};
+  hipLaunchKernelGGL((k_encoder_layer<64, 4>), dim3(N), dim3(256), 0, as_stream(stream), src, pos, w, mem, L);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_cross_attn_f32(const float* q, const float* k, const float* v, float* o, float* pw, int N, int L, int S, int E,
+                        int nhead, dpmn_stream_t stream) {
+  DPMN_REQUIRE(q && k && v && o && N > 0, "cross_attn: bad arguments");
+  DPMN_REQUIRE(E == 64 && nhead == 4 && S <= 32, "cross_attn: built for d_model=64, 4 heads, <=32 keys");
+  hipLaunchKernelGGL((k_cross_attn<64, 4>), dim3(cdiv(L, 256), N), dim3(256), 0, as_stream(stream), q, k, v, o, pw, L, S);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_add_layernorm64_f32(const float* x, const float* res, const float* g, const float* b, float* y, const float* g2,
+                             const float* b2, float* acc_out, float alpha, int accumulate, long M, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && g && b && y && M > 0, "add_layernorm64: bad arguments");
+  DPMN_REQUIRE(!acc_out || (g2 && b2), "add_layernorm64: second norm parameters required with acc_out");
+  hipLaunchKernelGGL(k_add_layernorm64, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, as_stream(stream), x, res, g, b, y, g2, b2,
+                     acc_out, alpha, accumulate, M);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_gru_gate_f32(const float* gi, const float* gh, float* h, float* hist, long hist_row_stride, int R, int H,
+                      dpmn_stream_t stream) {
+  DPMN_REQUIRE(gi && gh && h && hist && R > 0 && H > 0, "gru_gate: bad arguments");
+  const long total = (long)R * H;
+  hipLaunchKernelGGL(k_gru_gate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), gi, gh, h, hist,
+                     hist_row_stride, R, H);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+}  // extern "C"

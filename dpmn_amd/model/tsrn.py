@@ -1,0 +1,158 @@
+"""Host-side mirrors of the reference PSN backbones ``model/tsrn.py::TSRN`` and
+``model/tatt.py::TSRN_TL_TRANS`` (TATT) -- eval mode, which is the only mode DPMN runs them in
+(frozen PSN, super_resolution.py:56-59).
+
+Same constructors, forward signatures/returns and ``state_dict`` key layouts as the reference; the
+``torch.nn`` layers below only HOLD parameters (they are never called).  All arithmetic runs in
+libdpmn_hip.so: NHWC implicit-GEMM convs with folded eval BatchNorm and fused mish / PReLU / tanh /
+PixelShuffle epilogues (csrc/conv.hip), the BiGRU recurrence with the 1x1 conv folded into the
+input projection, and the TPInterpreter transformer pieces (csrc/tatt.hip, csrc/gemm.hip).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import packing
+
+
+class _GruBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 1)
+        self.gru = nn.GRU(cout, cout // 2, bidirectional=True, batch_first=True)
+
+
+class _SRB(nn.Module):
+    def __init__(self, ch, text_ch=0):
+        super().__init__()
+        self.conv1 = nn.Conv2d(ch, ch, 3, padding=1)
+        self.bn1 = nn.BatchNorm2d(ch)
+        self.gru1 = _GruBlock(ch + text_ch, ch)
+        self.prelu = nn.Identity()   # mish, parameter-free
+        self.conv2 = nn.Conv2d(ch, ch, 3, padding=1)
+        self.bn2 = nn.BatchNorm2d(ch)
+        self.gru2 = _GruBlock(ch, ch)
+
+
+class _Upsample(nn.Module):
+    def __init__(self, ch, scale):
+        super().__init__()
+        self.conv = nn.Conv2d(ch, ch * scale * scale, 3, padding=1)
+
+
+def _bn(m):
+    return (m.weight, m.bias, m.running_mean, m.running_var, m.eps)
+
+
+def _pack_gru_block(gb):
+    """Fold conv1x1 into the GRU input projection: gi = W_ih (Wc x + bc) + b_ih, both directions stacked."""
+    g = gb.gru
+    wc = gb.conv1.weight.reshape(gb.conv1.weight.shape[0], -1)   # (C, Cin)
+    bc = gb.conv1.bias
+    wi = torch.cat([g.weight_ih_l0, g.weight_ih_l0_reverse], 0)  # (6H, C)
+    bi = torch.cat([g.bias_ih_l0, g.bias_ih_l0_reverse], 0)
+    w = (wi.double() @ wc.double()).float()
+    b = (wi.double() @ bc.double()).float() + bi
+    kp = (w.shape[1] + 31) // 32 * 32
+    if kp != w.shape[1]:
+        w = torch.cat([w, w.new_zeros(w.shape[0], kp - w.shape[1])], 1)
+    whh = torch.stack([g.weight_hh_l0, g.weight_hh_l0_reverse], 0).contiguous()
+    bhh = torch.stack([g.bias_hh_l0, g.bias_hh_l0_reverse], 0).contiguous()
+    return w.contiguous(), b.contiguous(), whh, bhh
+
+
+class _PSNBase(nn.Module):
+    """Shared conv/GRU trunk of TSRN and TATT."""
+
+    def _build_trunk(self, scale_factor, width, height, STN, srb_nums, mask, hidden_units, text_ch):
+        if STN:
+            raise NotImplementedError("dpmn_amd PSN: the STN/TPS head only runs in PSN train mode, which DPMN never "
+                                      "enters (super_resolution.py:59); construct with STN=False")
+        assert math.log(scale_factor, 2) % 1 == 0 and scale_factor == 2, "built for scale_factor=2"
+        self.in_planes = 4 if mask else 3
+        self.srb_nums = srb_nums
+        ch = 2 * hidden_units
+        self.ch = ch
+        self.block1 = nn.Sequential(nn.Conv2d(self.in_planes, ch, 9, padding=4), nn.PReLU())
+        for i in range(srb_nums):
+            setattr(self, "block%d" % (i + 2), _SRB(ch, text_ch))
+
+    def _build_tail(self, srb_nums):
+        ch = self.ch
+        setattr(self, "block%d" % (srb_nums + 2), nn.Sequential(nn.Conv2d(ch, ch, 3, padding=1), nn.BatchNorm2d(ch)))
+        setattr(self, "block%d" % (srb_nums + 3), nn.Sequential(_Upsample(ch, 2), nn.Conv2d(ch, self.in_planes, 9, padding=4)))
+
+    # ------------------------------------------------------------------ packing (cached)
+    def _trunk_pack(self):
+        key = tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+        if getattr(self, "_pk", None) is not None and self._pk[0] == key:
+            return self._pk[1]
+        P = {}
+        n = self.srb_nums
+        with torch.no_grad():
+            cin_p = 4
+            P["block1"] = packing.pack_conv(self.block1[0].weight, self.block1[0].bias, cin_pad=cin_p)
+            P["prelu"] = float(self.block1[1].weight.reshape(-1)[0].item())
+            for i in range(n):
+                blk = getattr(self, "block%d" % (i + 2))
+                P["srb%d.c1" % i] = packing.pack_conv(blk.conv1.weight, blk.conv1.bias, _bn(blk.bn1))
+                P["srb%d.c2" % i] = packing.pack_conv(blk.conv2.weight, blk.conv2.bias, _bn(blk.bn2))
+                P["srb%d.g1" % i] = _pack_gru_block(blk.gru1)
+                P["srb%d.g2" % i] = _pack_gru_block(blk.gru2)
+            b7 = getattr(self, "block%d" % (n + 2))
+            P["b7"] = packing.pack_conv(b7[0].weight, b7[0].bias, _bn(b7[1]))
+            b8 = getattr(self, "block%d" % (n + 3))
+            P["up"] = packing.pack_conv(b8[0].conv.weight, b8[0].conv.bias)
+            P["last"] = packing.pack_conv(b8[1].weight, b8[1].bias)
+            self._extra_pack(P)
+        self._pk = (key, P)
+        return P
+
+    def _extra_pack(self, P):
+        pass
+
+    def _check_mode(self):
+        if self.training:
+            raise NotImplementedError("dpmn_amd PSN: only eval mode is built (DPMN keeps the PSN frozen in .eval(), "
+                                      "super_resolution.py:56-59)")
+
+    # ------------------------------------------------------------------ kernels
+    def _srb(self, x, P, i, tp=None):
+        B, H, W, Cc = x.shape
+        r = ops.conv2d([x], *P["srb%d.c1" % i], Cc, 3, pad=1, epi_act="mish")
+        r = ops.conv2d([r], *P["srb%d.c2" % i], Cc, 3, pad=1)
+        w1, b1, whh1, bhh1 = P["srb%d.g1" % i]
+        gi = ops.conv2d([r] if tp is None else [r, tp], w1, b1, w1.shape[0], 1)
+        s = ops.bigru(gi, whh1, bhh1, B, H, W, "h", res=x)              # x + gru1(...) (vertical pass)
+        w2, b2, whh2, bhh2 = P["srb%d.g2" % i]
+        gi = ops.conv2d([s], w2, b2, w2.shape[0], 1)
+        return ops.bigru(gi, whh2, bhh2, B, H, W, "w")
+
+    def _head(self, x, P):
+        xin = ops.nchw_to_nhwc(x.contiguous().float(), 4)
+        return ops.conv2d([xin], *P["block1"], self.ch, 9, pad=4, epi_act="prelu", slope=P["prelu"])
+
+    def _tail(self, b1, f, P):
+        t = ops.conv2d([f], *P["b7"], self.ch, 3, pad=1, res=b1)
+        u = ops.conv2d([t], *P["up"], 4 * self.ch, 3, pad=1, epi_act="mish", pixel_shuffle=True)
+        return ops.conv2d([u], *P["last"], self.in_planes, 9, pad=4, epi_act="tanh", out_nchw=True)
+
+
+class TSRN(_PSNBase):
+    """Drop-in for ``model.tsrn.TSRN`` (tsrn.py:14-74), eval forward."""
+
+    def __init__(self, scale_factor=2, width=128, height=32, STN=False, srb_nums=5, mask=True, hidden_units=32):
+        super().__init__()
+        self._build_trunk(scale_factor, width, height, STN, srb_nums, mask, hidden_units, 0)
+        self._build_tail(srb_nums)
+
+    def forward(self, x):
+        self._check_mode()
+        P = self._trunk_pack()
+        b1 = self._head(x, P)
+        f = b1
+        for i in range(self.srb_nums):
+            f = self._srb(f, P, i)
+        return self._tail(b1, f, P)

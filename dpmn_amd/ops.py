@@ -174,3 +174,55 @@ def se_gate(x, fc1_w, fc1_b, fc2_w, fc2_b):
     check(lib.dpmn_se_gate_f32(dptr(x), dptr(fc1_w), dptr(fc1_b), dptr(fc2_w), dptr(fc2_b), dptr(out), B, H * W, Cc,
                                fc1_w.shape[0], stream()))
     return out
+
+
+# ------------------------------------------------------------------------------ TSRN / TATT pieces
+def bigru(gi, w_hh, b_hh, B, H, W, axis, res=None, hidden=32):
+    """gi: NHWC (B,H,W,6*hidden) input projections.  axis='w': sequences run along W (rows as batch);
+    axis='h': along H (the transposed gru1 call).  Returns NHWC (B,H,W,2*hidden) (+ res)."""
+    out = torch.empty(B, H, W, 2 * hidden, device=gi.device)
+    if axis == "w":
+        nseq, T, inner, outer, inner_s, step = B * H, W, 1, W, 0, 1
+    else:
+        nseq, T, inner, outer, inner_s, step = B * W, H, W, H * W, 1, W
+    check(lib.dpmn_bigru_f32(dptr(gi), dptr(w_hh), dptr(b_hh), dptr(res, True), dptr(out), nseq, T, inner, outer, inner_s,
+                             step, hidden, stream()))
+    return out
+
+
+def small_linear(x, w, b=None, add=None, act="none", slope=0.0):
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x.device)
+    check(lib.dpmn_small_linear_f32(dptr(x), dptr(add, True), 0 if add is None else add.shape[0], dptr(w), dptr(b, True),
+                                    dptr(y), M, N, K, ACT[act], float(slope), stream()))
+    return y
+
+
+def tatt_encoder_layer(src, pos, w12, nhead=4):
+    N, L, E = src.shape
+    mem = torch.empty_like(src)
+    check(lib.dpmn_tatt_encoder_layer_f32(dptr(src), dptr(pos), _abi.ptr_array(w12), dptr(mem), N, L, E, nhead, stream()))
+    return mem
+
+
+def cross_attn(q, k, v, nhead=4, need_weights=False):
+    N, L, E = q.shape
+    S = k.shape[1]
+    o = torch.empty_like(q)
+    pw = torch.empty(N, L, S, device=q.device) if need_weights else None
+    check(lib.dpmn_cross_attn_f32(dptr(q), dptr(k), dptr(v), dptr(o), dptr(pw, True), N, L, S, E, nhead, stream()))
+    return o, pw
+
+
+def add_layernorm64(x, res, g, b, g2=None, b2=None, acc_out=None, alpha=1.0, accumulate=False):
+    M = x.numel() // 64
+    y = torch.empty_like(x)
+    check(lib.dpmn_add_layernorm64_f32(dptr(x), dptr(res, True), dptr(g), dptr(b), dptr(y), dptr(g2, True), dptr(b2, True),
+                                       dptr(acc_out, True), float(alpha), int(accumulate), M, stream()))
+    return y
+
+
+def gru_gate(gi, gh, h, hist, hist_row_stride):
+    R, H = h.shape
+    check(lib.dpmn_gru_gate_f32(dptr(gi), dptr(gh), dptr(h), hist.data_ptr(), hist_row_stride, R, H, stream()))

@@ -92,6 +92,36 @@ int dpmn_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int 
 int dpmn_se_gate_f32(const float* x, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
                      float* out, int B, int P, int C, int Cmid, dpmn_stream_t stream);
 
+/* ------------------------------------------------------------------ TSRN / TATT kernels (tatt.hip) */
+/* BiGRU recurrence of GruBlock (tsrn.py:139-150; tatt.py:1070-1083).  gi: (pixels, 6*hidden) input
+ * projection for both directions [fwd r z n | bwd r z n] with b_ih (and the folded conv1x1) already added;
+ * w_hh (2, 3*hidden, hidden), b_hh (2, 3*hidden).  Sequence s starts at pixel
+ * (s / inner)*outer_stride + (s % inner)*inner_stride and advances step_stride pixels per time step, so
+ * the same kernel runs along W (rows as batch) or along H (the transposed gru1 call, tsrn.py:99).
+ * out (pixels, 2*hidden) = [h_fwd | h_bwd] + res. */
+int dpmn_bigru_f32(const float* gi, const float* w_hh, const float* b_hh, const float* res, float* out, int nseq,
+                   int T, int inner, long outer_stride, long inner_stride, long step_stride, int hidden,
+                   dpmn_stream_t stream);
+/* y = act((x + add[m % add_rows]) . w^T + b) for tiny problems (tatt.py:209 fc_in, K/V projections of 26 slots) */
+int dpmn_small_linear_f32(const float* x, const float* add, int add_rows, const float* w, const float* b, float* y,
+                          int M, int N, int K, int act, float slope, dpmn_stream_t stream);
+/* TransformerEncoder with one TransformerEncoderLayer.forward_post on (N, L<=32, 64) tokens
+ * (transformer_v2.py:256-281, 455-469).  w12: HOST array of 12 device pointers
+ * {in_proj_w, in_proj_b, out_proj_w, out_proj_b, linear1_w, linear1_b, linear2_w, linear2_b, norm1_w, norm1_b, norm2_w, norm2_b}. */
+int dpmn_tatt_encoder_layer_f32(const float* src, const float* pos, const float* const* w12, float* mem, int N,
+                                int L, int E, int nhead, dpmn_stream_t stream);
+/* softmax(q k^T / sqrt(d)) v over S<=32 keys, 4 heads (transformer_v2.py:821-824); pw (N,L,S) head-averaged or NULL */
+int dpmn_cross_attn_f32(const float* q, const float* k, const float* v, float* o, float* pw, int N, int L, int S, int E,
+                        int nhead, dpmn_stream_t stream);
+/* y = LayerNorm64(x + res); optional acc_out (+)= alpha * LayerNorm64'(y) (decoder.norm on intermediates,
+ * transformer_v2.py:377-378, then mean over layers tatt.py:218) */
+int dpmn_add_layernorm64_f32(const float* x, const float* res, const float* g, const float* b, float* y,
+                             const float* g2, const float* b2, float* acc_out, float alpha, int accumulate, long M,
+                             dpmn_stream_t stream);
+/* one gate step of the query-embedding GRU (transformer_v2.py:177,215-218; quirk Q5) */
+int dpmn_gru_gate_f32(const float* gi, const float* gh, float* h, float* hist, long hist_row_stride, int R, int H,
+                      dpmn_stream_t stream);
+
 /* ------------------------------------------------------------------ PGRM kernels (pgrm.hip) */
 /* prior_fusion (optional, pf_w != NULL; pgrm.py:548) + PatchEmbed conv k=s=patch + LayerNorm (pgrm.py:419-426).
  * img NCHW (B,cin,Hi,Wi) -> tokens (B, Hi/patch*Wi/patch, C). */

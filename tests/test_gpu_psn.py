@@ -1,0 +1,115 @@
+"""GPU parity: BiGRU / TPInterpreter kernels and the TSRN / TATT PSN modules vs oracle and golden."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dpmn_amd.utils import synth
+from helpers import load_golden, t, assert_close
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 1e-4, 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def u(name, shape, lo=-1.0, hi=1.0, seed=60):
+    return synth.uniform(name, shape, lo, hi, seed)
+
+
+@pytest.mark.parametrize("axis", ["w", "h"])
+def test_bigru_matches_oracle(dev, axis):
+    from dpmn_amd import ops
+    from oracle import tsrn as ot
+    B, H, W, C = 3, 16, 64, 64
+    sd = {}
+    for sfx in ("", "_reverse"):
+        sd["weight_ih_l0" + sfx] = u("wih" + sfx, (96, C), -0.3, 0.3)
+        sd["weight_hh_l0" + sfx] = u("whh" + sfx, (96, 32), -0.4, 0.4)
+        sd["bias_ih_l0" + sfx] = u("bih" + sfx, (96,), -0.2, 0.2)
+        sd["bias_hh_l0" + sfx] = u("bhh" + sfx, (96,), -0.2, 0.2)
+    x = u("x", (B, H, W, C))
+    res = u("res", (B, H, W, C))
+    seqs = x.reshape(B * H, W, C) if axis == "w" else x.permute(0, 2, 1, 3).reshape(B * W, H, C)
+    ref = ot.bigru(seqs, sd, "")
+    ref = ref.reshape(B, H, W, C) if axis == "w" else ref.reshape(B, W, H, C).permute(0, 2, 1, 3)
+    wi = torch.cat([sd["weight_ih_l0"], sd["weight_ih_l0_reverse"]], 0)
+    bi = torch.cat([sd["bias_ih_l0"], sd["bias_ih_l0_reverse"]], 0)
+    gi = F.linear(x, wi, bi)
+    whh = torch.stack([sd["weight_hh_l0"], sd["weight_hh_l0_reverse"]], 0)
+    bhh = torch.stack([sd["bias_hh_l0"], sd["bias_hh_l0_reverse"]], 0)
+    got = ops.bigru(gi.to(dev).contiguous(), whh.to(dev), bhh.to(dev), B, H, W, axis, res=res.to(dev))
+    assert_close(got, ref + res, ATOL, RTOL, "bigru axis " + axis)
+
+
+def test_small_linear_layernorm_cross_attn(dev):
+    from dpmn_amd import ops
+    from oracle import tsrn as ot
+    x, add = u("x", (52, 37)), u("add", (26, 37))
+    w, b = u("w", (64, 37), -0.3, 0.3), u("b", (64,))
+    ref = F.prelu(F.linear(x + add.repeat(2, 1), w, b), torch.tensor([0.2]))
+    assert_close(ops.small_linear(x.to(dev), w.to(dev), b.to(dev), add=add.to(dev), act="prelu", slope=0.2), ref, ATOL, RTOL, "small_linear")
+    a, r = u("a", (300, 64)), u("r", (300, 64))
+    g1, b1, g2, b2 = u("g1", (64,), 0.5, 1.5), u("b1", (64,)), u("g2", (64,), 0.5, 1.5), u("b2", (64,))
+    y = F.layer_norm(a + r, (64,), g1, b1)
+    acc = torch.full((300, 64), 0.25)
+    accd = acc.to(dev)
+    got = ops.add_layernorm64(a.to(dev), r.to(dev), g1.to(dev), b1.to(dev), g2.to(dev), b2.to(dev), accd, alpha=0.5, accumulate=True)
+    assert_close(got, y, ATOL, RTOL, "add_layernorm")
+    assert_close(accd, acc + 0.5 * F.layer_norm(y, (64,), g2, b2), ATOL, RTOL, "add_layernorm accumulate")
+    N, L, S, E = 3, 1024, 26, 64
+    q, k, v = u("q", (N, L, E), -2, 2), u("k", (N, S, E), -2, 2), u("v", (N, S, E))
+    qh = q.reshape(N, L, 4, 16).permute(0, 2, 1, 3)
+    kh = k.reshape(N, S, 4, 16).permute(0, 2, 1, 3)
+    vh = v.reshape(N, S, 4, 16).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) / 4.0, -1)
+    ref_o = (p @ vh).permute(0, 2, 1, 3).reshape(N, L, E)
+    o, pw = ops.cross_attn(q.to(dev), k.to(dev), v.to(dev), need_weights=True)
+    assert_close(o, ref_o, ATOL, RTOL, "cross_attn out")
+    assert_close(pw, p.mean(1), 1e-5, 1e-4, "cross_attn weights")
+
+
+def _load(cls, name, seed, dev, **kw):
+    g = load_golden(name)
+    m = cls(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32, **kw).eval()
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(r).split("|")[0] for r in g["manifest"]], "state_dict key layout differs from the reference"
+    synth.synth_fill_(sd, seed)
+    m.load_state_dict(sd)
+    return g, m.to(dev)
+
+
+def test_tsrn_module_vs_reference_golden(dev):
+    from dpmn_amd.model.tsrn import TSRN
+    g, m = _load(TSRN, "tsrn", 41, dev)
+    x = synth.synth_batch(2, seed=2)["images_lr"].to(dev)
+    with torch.no_grad():
+        out = m(x)
+    assert_close(out, t(g["out"]), 2e-4, 2e-4, "TSRN vs reference golden")
+
+
+@pytest.mark.parametrize("cache", [True, False])
+def test_tatt_module_vs_reference_golden(dev, cache):
+    from dpmn_amd.model.tatt import TSRN_TL_TRANS
+    g, m = _load(TSRN_TL_TRANS, "tatt", 42, dev, cache_query_embed=cache)
+    b = synth.synth_batch(2, seed=2)
+    with torch.no_grad():
+        for _ in range(2):   # second call exercises the cached query embedding
+            out, prw = m(b["images_lr"].to(dev), b["label_vecs"].to(dev))
+    assert_close(out, t(g["out"]), 2e-4, 2e-4, "TATT vs reference golden")
+    assert_close(prw[:, ::16], t(g["pr_weights"]), 1e-5, 1e-4, "TATT pr_weights vs reference golden")
+
+
+def test_tatt_batch48_vs_oracle(dev):
+    from dpmn_amd.model.tatt import TSRN_TL_TRANS
+    from oracle import tsrn as ot
+    _, m = _load(TSRN_TL_TRANS, "tatt", 43, dev)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    b = synth.synth_batch(48, seed=3)
+    ref, _ = ot.tatt_forward(sd, b["images_lr"], b["label_vecs"])
+    with torch.no_grad():
+        out, _ = m(b["images_lr"].to(dev), b["label_vecs"].to(dev))
+    assert_close(out, ref, 2e-4, 2e-4, "TATT B=48 vs oracle")

@@ -36,7 +36,7 @@ def manifest(sd):
 def checksum(sd):
     skip = ("relative_position_index", "attn_mask", "num_batches_tracked")
     return float(sum(v.double().sum().item() for k, v in sd.items()
-                     if torch.is_floating_point(v) and not any(s in k for s in skip)))
+                     if torch.is_floating_point(v) and not any(s in k for s in skip) and not k.endswith(".pe")))
 
 
 def save(name, **arrs):
@@ -164,7 +164,28 @@ def gen_loss():
          gradmap=image_loss.GradientPriorLoss.gradient_map(a)[:1])
 
 
-GENS = {"pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss}
+def gen_psn():
+    """PSN backbones in eval mode (frozen in DPMN, super_resolution.py:56-59): TSRN and TATT."""
+    from model import tsrn, tatt
+    b = synth.synth_batch(2, seed=2)
+    x, lv = b["images_lr"], b["label_vecs"]
+    m = tsrn.TSRN(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32).eval()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, seed=41)
+    sd = {k: v.clone() for k, v in sd.items()}
+    m.load_state_dict(sd)
+    save("tsrn", out=m(x), manifest=manifest(sd), checksum=checksum(sd))
+    m = tatt.TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32).eval()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, seed=42)
+    sd = {k: v.clone() for k, v in sd.items()}
+    m.load_state_dict(sd)
+    out, prw = m(x, lv)
+    save("tatt", out=out, pr_weights=prw[:, ::16].contiguous(), tp_map=m.block["1"][:1, :8].contiguous(),
+         manifest=manifest(sd), checksum=checksum(sd))
+
+
+GENS = {"psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss}
 
 
 if __name__ == "__main__":
