@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""bench.py -- SR images/sec of the DPMN forward stack on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one synthetic batch already resident in HBM:
+frozen TATT PSN -> 3 text-prior PGRMs -> 3 mask-prior PGRMs (toMask on the GPU) -> CMM -> alpha blend,
+fp32, per-GPU batch 48 (BASELINE.json configs[1]).  With N > 1 every rank runs the same step on its own
+batch shard (weak scaling, no data-path collective in the forward path); the timed region is bracketed by
+barrier + synchronize and the MAX over ranks is reported.
+
+Extra objects on the JSON line:
+  roofline     -- the dominant kernel (Mlp pointwise GEMM, csrc/gemm.hip::k_gemm_pw): algorithmic FLOPs per
+                  launch / mean launch duration measured live with HIP events on the launch stream, against
+                  the dense fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def roofline_pw(B, reps=30):
+    """Time the dominant kernel alone on the step's shapes: z[b] = Wp(384x384) . g[b](384x1024), b < B."""
+    from dpmn_amd import ops
+    from dpmn_amd.utils import synth
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = synth.uniform("rf_g", (B, 1024, 384), -1, 1, 5).to(dev)
+    w = synth.uniform("rf_w", (384, 384), -0.1, 0.1, 5).to(dev)
+    b = synth.uniform("rf_b", (384,), -0.1, 0.1, 5).to(dev)
+    for _ in range(3):
+        ops.pointwise(g, w, b)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for s, e in evs:
+        s.record()
+        ops.pointwise(g, w, b)
+        e.record()
+    torch.cuda.synchronize()
+    ms = sum(s.elapsed_time(e) for s, e in evs) / reps
+    flops = 2.0 * 384 * 384 * 1024 * B
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "k_gemm_pw (Mlp.pointwise_conv, pgrm.py:37)", "bound": "mfma", "achieved": round(achieved, 2),
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+            "traffic": None, "launch_ms": round(ms, 4), "flops_per_launch": flops}
+
+
+def cpu_baseline(workload_name, models, psn, n_img):
+    """Oracle (CPU restatement, test infrastructure) timed on the host cores: the reported baseline, not the target."""
+    from dpmn_amd import workload
+    from dpmn_amd.utils import synth
+    from oracle import dpmn as odpmn
+    arch, b1, b2, _ = workload.CONFIGS[workload_name]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    batch = synth.synth_batch(n_img, seed=2)
+    priors = [torch.floor(synth.uniform("text_prior_%d" % k, (n_img, 2, 32, 128), 0.0, 256.0, 2)) for k in range(b1)]
+    run = lambda: odpmn.refine(sd_psn, sds[:-1], sds[-1], arch, b1, b2, batch["images_lr"], batch["label_vecs"], priors, 0.5)
+    with torch.no_grad():
+        run()  # warm-up
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            run()
+            ts.append(time.perf_counter() - t0)
+    t = sorted(ts)[0]
+    return {"value": round(n_img / t, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%s forward on %d synthetic images, best of 2 after 1 warm-up, torch %s CPU fp32 oracle" % (
+                workload_name, n_img, torch.__version__)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from dpmn_amd import workload
+    sr, models, psn, inp = workload.build(args.workload, batch=args.batch)
+    B = inp["images_lr"].shape[0]
+    arch, b1, b2, _ = workload.CONFIGS[args.workload]
+
+    def step():
+        return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        line = {
+            "metric": "SR images/sec (16x64->32x128, bs=48 per GPU, fp32 forward)",
+            "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: %s PSN + %d+%d PGRM (embed 96, windows 2/4/8) + CMM, forward-only" % (
+                args.workload, arch.upper(), b1, b2), "per_gpu_batch": B, "global_batch": B * world,
+                "parallelism": "dp%d (independent batch shards, no forward collective)" % world},
+        }
+        line["roofline"] = roofline_pw(B)
+        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.workload, models, psn, args.cpu_sample)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,10 @@ SIGNATURES = {
     "dpmn_cross_attn_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_add_layernorm64_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, _f, _i, C.c_long, fp]),
     "dpmn_gru_gate_f32": (_i, [fp, fp, fp, fp, C.c_long, _i, _i, fp]),
+    "dpmn_to_mask_f32": (_i, [fp, C.c_long, fp, _i, _i, _i, fp]),
+    "dpmn_blend_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, _f, _i, _i, fp]),
+    "dpmn_psnr_ssim_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dpmn_psnr_ssim_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

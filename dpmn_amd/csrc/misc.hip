@@ -1,0 +1,140 @@
+// Image-space helpers of the SR path: branch-2 mask prior, eval blend, PSNR / SSIM metrics.
+//   toMask             utils/util.py:27-35     (per image: uint8 cast, PIL 'L', mean threshold)
+//   alpha blend        interfaces/super_resolution.py:449
+//   calculate_psnr     utils/ssim_psnr.py:9-13 ; SSIM._ssim utils/ssim_psnr.py:28-48
+// All tensors NCHW fp32 with an explicit per-image stride so a (B,4,H,W) tensor can be read as its first 3 channels.
+#include "common.h"
+
+namespace {
+
+// one workgroup per image; L values kept in LDS; exact integer mean test  L*HW <= sum(L)
+__global__ __launch_bounds__(256) void k_to_mask(const float* __restrict__ img, long img_stride, float* __restrict__ out, int HW) {
+  extern __shared__ int Ls[];
+  __shared__ long long wsum[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* p = img + (size_t)b * img_stride;
+  long long s = 0;
+  for (int i = tid; i < HW; i += 256) {
+    // ToPILImage: mul(255).byte() -> truncate toward zero, wrap modulo 256 (quirk Q13)
+    const int r = ((int)(p[i] * 255.0f)) & 255, g = ((int)(p[HW + i] * 255.0f)) & 255, bl = ((int)(p[2 * HW + i] * 255.0f)) & 255;
+    const int L = (r * 19595 + g * 38470 + bl * 7471 + 0x8000) >> 16;   // PIL ImagingConvert RGB -> L
+    Ls[i] = L;
+    s += L;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((tid & 63) == 0) wsum[tid >> 6] = s;
+  __syncthreads();
+  const long long total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  float* o = out + (size_t)b * 3 * HW;
+  for (int i = tid; i < HW; i += 256) {
+    const float m = ((long long)Ls[i] * HW <= total) ? 1.0f : 0.0f;   // 255 where L <= mean, then ToTensor /255
+    o[i] = m; o[HW + i] = m; o[2 * HW + i] = m;
+  }
+}
+
+__global__ void k_blend(const float* __restrict__ a, long a_stride, const float* __restrict__ b, long b_stride,
+                        float* __restrict__ out, float alpha, int chw, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const long n = idx / chw, r = idx % chw;
+  out[idx] = alpha * a[n * a_stride + r] + (1.0f - alpha) * b[n * b_stride + r];
+}
+
+// per-block partial sums of [squared error * 255^2, ssim map]; 11x11 Gaussian sigma 1.5 window, zero padding
+__global__ __launch_bounds__(256) void k_psnr_ssim_partial(const float* __restrict__ x, long x_stride, const float* __restrict__ y,
+                                                            long y_stride, float* __restrict__ partial, int C, int H, int W,
+                                                            long total) {
+  __shared__ float g[11];
+  __shared__ float red[2][4];
+  if (threadIdx.x < 11) {
+    float s = 0.f;
+    for (int i = 0; i < 11; ++i) s += expf(-(float)((i - 5) * (i - 5)) / 4.5f);
+    g[threadIdx.x] = expf(-(float)((threadIdx.x - 5) * (threadIdx.x - 5)) / 4.5f) / s;
+  }
+  __syncthreads();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float se = 0.f, sm = 0.f;
+  if (idx < total) {
+    const int px = idx % W, py = (idx / W) % H, c = (idx / ((long)W * H)) % C;
+    const long n = idx / ((long)W * H * C);
+    const float* xp = x + n * x_stride + (size_t)c * H * W;
+    const float* yp = y + n * y_stride + (size_t)c * H * W;
+    const float d = xp[py * W + px] * 255.0f - yp[py * W + px] * 255.0f;
+    se = d * d;
+    float mu1 = 0.f, mu2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    for (int ky = 0; ky < 11; ++ky) {
+      const int yy = py + ky - 5;
+      if (yy < 0 || yy >= H) continue;
+      for (int kx = 0; kx < 11; ++kx) {
+        const int xx = px + kx - 5;
+        if (xx < 0 || xx >= W) continue;
+        const float wgt = g[ky] * g[kx];
+        const float a = xp[yy * W + xx], b = yp[yy * W + xx];
+        mu1 += wgt * a; mu2 += wgt * b; s11 += wgt * a * a; s22 += wgt * b * b; s12 += wgt * a * b;
+      }
+    }
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float m11 = mu1 * mu1, m22 = mu2 * mu2, m12 = mu1 * mu2;
+    sm = ((2.f * m12 + C1) * (2.f * (s12 - m12) + C2)) / ((m11 + m22 + C1) * ((s11 - m11) + (s22 - m22) + C2));
+  }
+  se = wave_sum(se); sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = se; red[1][threadIdx.x >> 6] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ void k_psnr_ssim_final(const float* __restrict__ partial, int nblocks, float inv_count, float* __restrict__ out2) {
+  double se = 0.0, sm = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { se += partial[2 * i]; sm += partial[2 * i + 1]; }
+  for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); sm += __shfl_xor(sm, o, 64); }
+  if (threadIdx.x == 0) {
+    const double mse = se * inv_count;
+    out2[0] = (float)(20.0 * log10(255.0 / sqrt(mse)));
+    out2[1] = (float)(sm * inv_count);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpmn_to_mask_f32(const float* img, long img_stride, float* out, int B, int H, int W, dpmn_stream_t stream) {
+  DPMN_REQUIRE(img && out && B > 0 && H * W * 4 <= 64 * 1024, "to_mask: bad arguments (image must fit 64 KB of LDS as ints)");
+  hipLaunchKernelGGL(k_to_mask, dim3(B), dim3(256), (size_t)H * W * 4, as_stream(stream), img, img_stride, out, H * W);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_blend_f32(const float* a, long a_stride, const float* b, long b_stride, float* out, float alpha, int B, int chw,
+                   dpmn_stream_t stream) {
+  DPMN_REQUIRE(a && b && out && B > 0 && chw > 0, "blend: bad arguments");
+  const long total = (long)B * chw;
+  hipLaunchKernelGGL(k_blend, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), a, a_stride, b, b_stride,
+                     out, alpha, chw, total);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+size_t dpmn_psnr_ssim_workspace_bytes(int B, int C, int H, int W) {
+  const long total = (long)B * C * H * W;
+  return (size_t)((total + 255) / 256) * 2 * sizeof(float);
+}
+
+int dpmn_psnr_ssim_f32(const float* x, long x_stride, const float* y, long y_stride, float* out2, void* workspace, int B,
+                       int C, int H, int W, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && y && out2 && workspace && B > 0, "psnr_ssim: bad arguments");
+  const long total = (long)B * C * H * W;
+  const int nb = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(k_psnr_ssim_partial, dim3(nb), dim3(256), 0, as_stream(stream), x, x_stride, y, y_stride,
+                     static_cast<float*>(workspace), C, H, W, total);
+  DPMN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_psnr_ssim_final, dim3(1), dim3(64), 0, as_stream(stream), static_cast<const float*>(workspace), nb,
+                     1.0f / (float)total, out2);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+}  // extern "C"

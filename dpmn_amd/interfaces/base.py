@@ -1,0 +1,110 @@
+"""Mirror of ``interfaces/base.py::TextBase`` restricted to the SR hot path.
+
+Keeps the attribute names, the per-PGRM hyper-parameter string parsing (base.py:64-82, with a safe
+parser instead of eval()), ``generator_init`` (base.py:127-198) and the checkpoint format
+(base.py:328-373).  Out of scope here: LMDB datasets, recognisers, pygame renderer.
+"""
+import os
+
+import torch
+
+from ..model import pgrm, cmm, tsrn, tatt
+from ..utils import ssim_psnr
+
+
+def parse_list(s):
+    """'2,4,8,' -> [2, 4, 8]; replaces eval() of base.py:64-82."""
+    out = []
+    for tok in str(s).split(','):
+        tok = tok.strip()
+        if tok:
+            out.append(float(tok) if ('.' in tok or 'e' in tok.lower()) else int(tok))
+    return out
+
+
+class ImageLossSpec:
+    """Stand-in for loss.image_loss.ImageLoss until the loss/backward kernels land (training is round 2)."""
+
+    def __init__(self, gradient, loss_weight):
+        self.gradient, self.loss_weight = gradient, loss_weight
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError("dpmn_amd: ImageLoss forward/backward kernels are not built yet (training path)")
+
+
+class TextBase(object):
+    def __init__(self, config, args, opt_TPG=None):
+        self.config = config
+        self.args = args
+        self.scale_factor = self.config.TRAIN.down_sample_scale
+        self.rec_path = getattr(args, "rec_path", None)
+        self.resume = args.resume if getattr(args, "resume", None) is not None else config.TRAIN.resume
+        self.batch_size = args.batch_size if args.batch_size is not None else self.config.TRAIN.batch_size
+        if not torch.cuda.is_available():
+            raise RuntimeError("dpmn_amd: the DPMN hot path needs a MI355X (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.cal_psnr = ssim_psnr.calculate_psnr
+        self.cal_ssim = ssim_psnr.SSIM()
+        self.mask = self.args.mask
+        self.depths = parse_list(self.args.depths)
+        self.patch_size = parse_list(self.args.patch_size)
+        self.embed_dim = parse_list(self.args.embed_dim)
+        ws = parse_list(self.args.window_size)
+        nh = parse_list(self.args.num_heads)
+        self.window_size, self.num_heads = [], []
+        pre = 0
+        for _ in self.depths:
+            self.window_size.append(ws[pre:pre + self.args.window_num])
+            pre += self.args.window_num
+        pre = 0
+        for layer_num in self.depths:
+            self.num_heads.append(nh[pre:pre + layer_num])
+            pre += layer_num
+        self.mlp_ratio = parse_list(self.args.mlp_ratio)
+        self.drop_rate = parse_list(self.args.drop_rate)
+        self.attn_drop_rate = parse_list(self.args.attn_drop_rate)
+        self.drop_path_rate = parse_list(self.args.drop_path_rate)
+
+    def generator_init(self, iter=0, mode=True, psn=False, hidden_size=64, testing=False):
+        cfg = self.config.TRAIN
+        kw = dict(scale_factor=self.scale_factor, width=cfg.width, height=cfg.height, STN=self.args.STN, mask=self.mask,
+                  srb_nums=self.args.srb, hidden_units=self.args.hd_u)
+        if psn and self.args.arch in ('tsrn', 'tg'):
+            model = tsrn.TSRN(**kw)
+        elif psn and self.args.arch == 'tatt':
+            model = tatt.TSRN_TL_TRANS(**kw)
+        elif psn:
+            raise NotImplementedError("dpmn_amd: PSN arch %r is not built yet (built: tsrn, tg, tatt)" % self.args.arch)
+        else:
+            model = pgrm.PGRM(patch_size=self.patch_size, embed_dim=self.embed_dim, depths=self.depths,
+                              num_heads=self.num_heads, window_size=self.window_size, mlp_ratio=self.mlp_ratio,
+                              drop_rate=self.drop_rate, attn_drop_rate=self.attn_drop_rate,
+                              drop_path_rate=self.drop_path_rate, iter=iter, mode=mode, hidden_size=hidden_size)
+        image_crit = ImageLossSpec(gradient=self.args.gradient, loss_weight=[1, 1])
+        model = model.to(self.device)
+        if self.resume and (psn or testing):
+            if os.path.isdir(self.resume):
+                name = "model_{}.pth".format(self.args.arch) if psn else "model_best_" + str(iter) + ".pth"
+                path = os.path.join(self.resume, name)
+            else:
+                path = self.resume
+            print('loading pre-trained model from %s ' % path)
+            model.load_state_dict(torch.load(path, map_location=self.device)['state_dict_G'])
+        return {'model': model, 'crit': image_crit}
+
+    def save_checkpoint(self, netG_list, epoch, iters, best_acc_dict, best_model_info, is_best, converge_list,
+                        recognizer=None, name=None):
+        """Same files and dict keys as base.py:328-358 (all models overwrite checkpoint.pth when not best)."""
+        ckpt_path = os.path.join(self.vis_dir if hasattr(self, "vis_dir") else ".", 'ckpt')
+        os.makedirs(ckpt_path, exist_ok=True)
+        for i, netG in enumerate(netG_list):
+            save_dict = {'state_dict_G': netG.state_dict(),
+                         'info': {'arch': self.args.arch, 'iters': iters, 'epochs': epoch, 'batch_size': self.batch_size,
+                                  'voc_type': getattr(self, "voc_type", None), 'up_scale_factor': self.scale_factor},
+                         'best_history_res': best_acc_dict, 'best_model_info': best_model_info,
+                         'param_num': sum(p.numel() for p in netG.parameters()), 'converge': converge_list}
+            if is_best:
+                fname = 'model_best_' + (name + '_' if name else '') + str(epoch) + '_' + str(i) + '.pth'
+            else:
+                fname = 'checkpoint.pth'
+            torch.save(save_dict, os.path.join(ckpt_path, fname))

@@ -1,0 +1,109 @@
+"""Mirror of ``interfaces/super_resolution.py::TextSR`` for the SR hot path.
+
+``refine`` is the forward stack shared by eval()/test() in the reference (super_resolution.py:370-449 /
+628-704): frozen PSN -> branch 1 (text-prior PGRMs) -> branch 2 (mask-prior PGRMs) -> CMM -> alpha
+blend with the PSN image.  Every tensor op runs in libdpmn_hip.so.  Text priors come from a callable
+(``text_prior_fn(cascade_images, k) -> (B,2,H,W)`` uint8-valued floats, quirk Q6): the recogniser +
+glyph renderer that produce them in the reference are out of scope, so
+the synthetic source of dpmn_amd.utils.synth is the default.
+"""
+import torch
+
+from . import base
+from .. import ops
+from ..model.cmm import ComplementationModulationModule
+from ..utils import synth
+
+
+class TextSR(base.TextBase):
+    def build_models(self, testing=False):
+        """Model list in the reference's order (super_resolution.py:38-76): b1 PGRMs (mode=False), b2 PGRMs
+        (mode=True), CMM last; plus the frozen PSN."""
+        b1, b2 = self.args.stu_iter_b1, self.args.stu_iter_b2
+        share = self.args.sr_share
+        models = [self.generator_init(0, mode=False, hidden_size=3, testing=testing)['model']]
+        if not share:
+            for i in range(b1 - 1):
+                models.append(self.generator_init(i + 1, mode=False, hidden_size=3, testing=testing)['model'])
+        models.append(self.generator_init(b1, mode=True, hidden_size=3, testing=testing)['model'])
+        if not share:
+            for i in range(b1, b1 + b2 - 1):
+                models.append(self.generator_init(i + 1, mode=True, hidden_size=3, testing=testing)['model'])
+        psn = self.generator_init(0, psn=True)['model']
+        for p in psn.parameters():
+            p.requires_grad = False
+        psn.eval()
+        models.append(ComplementationModulationModule().to(self.device))
+        return models, psn
+
+    @staticmethod
+    def synthetic_text_prior(seed=2):
+        def fn(cascade, k):
+            B, _, H, W = cascade.shape
+            return torch.floor(synth.uniform("text_prior_%d" % k, (B, 2, H, W), 0.0, 256.0, seed)).to(cascade.device)
+        return fn
+
+    @torch.no_grad()
+    def refine(self, model_list, model_psn, images_lr, label_vecs=None, text_prior_fn=None, text_priors=None,
+               return_all=False):
+        """super_resolution.py:370-449.  text_priors: optional precomputed list of b1 tensors (B,2,H,W)."""
+        b1, b2 = self.args.stu_iter_b1, self.args.stu_iter_b2
+        share = self.args.sr_share
+        if self.args.arch in ('tsrn', 'tbsrn', 'tg'):
+            images_lr_psn = model_psn(images_lr)
+        elif self.args.arch == 'tatt':
+            images_lr_psn, _ = model_psn(images_lr, label_vecs)
+        else:
+            raise NotImplementedError(self.args.arch)
+        cascade = images_lr_psn
+        branch1 = []
+        for k in range(b1):
+            x_q = text_priors[k] if text_priors is not None else text_prior_fn(cascade, k)
+            x_kv = cascade[:, :3]
+            sr = model_list[0 if share else k](x_q, x_kv, branch1[:k])
+            branch1.append(sr)
+            cascade = sr
+        cascade = images_lr_psn
+        branch2 = []
+        for k in range(b1, b1 + b2):
+            x_q = ops.to_mask(cascade)                      # batched toMask (util.py:27-35) on the GPU
+            x_kv = cascade[:, :3]
+            sr = model_list[0 if share else k](x_q, x_kv, branch2[:(k - b2)])   # slice quirk Q11
+            branch2.append(sr)
+            cascade = sr
+        fused = model_list[-1](branch1[-1], branch2[-1])
+        out = ops.blend(fused, images_lr_psn, self.args.alpha)
+        if return_all:
+            return out, dict(psn=images_lr_psn, branch1=branch1, branch2=branch2, cmm=fused)
+        return out
+
+    @torch.no_grad()
+    def eval(self, model_list, val_loader, index=0, rec=None, aster_info=None, rec_list=None, model_psn=None, crnn_psn=None,
+             text_prior_fn=None):
+        """PSNR/SSIM part of super_resolution.py:340-513 (recognition accuracy needs the out-of-scope recognisers)."""
+        for m in model_list:
+            m.eval()
+        fn = text_prior_fn or self.synthetic_text_prior()
+        psnr, ssim, n = [], [], 0
+        for data in val_loader:
+            images_hr, images_lr = data[0].to(self.device), data[1].to(self.device)
+            label_vecs = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
+            sr = self.refine(model_list, model_psn, images_lr, label_vecs, fn)
+            p, s = ops.psnr_ssim(sr, images_hr)
+            psnr.append(p)
+            ssim.append(s)
+            n += images_lr.shape[0]
+        psnr_avg = float(torch.stack(psnr).mean().item())
+        ssim_avg = float(torch.stack(ssim).mean().item())
+        return {'psnr': psnr, 'ssim': ssim, 'accuracy': 0.0, 'psnr_avg': round(psnr_avg, 6), 'ssim_avg': round(ssim_avg, 6)}
+
+    def train(self):
+        raise NotImplementedError("dpmn_amd: the training step (loss + backward kernels + RCCL gradient all-reduce) is the "
+                                  "next scope row (DESIGN.md section (f)); round 1 ships the forward/eval path")
+
+    def test(self, loader=None):
+        models, psn = self.build_models(testing=bool(self.resume))
+        if loader is None:
+            raise RuntimeError("dpmn_amd: TextZoom LMDB loading is out of scope (SURVEY.md section 2 row 18); pass a loader of "
+                               "(images_hr, images_lr, label_vecs) batches, e.g. dpmn_amd.utils.synth.synth_batch")
+        return self.eval(models, loader, 0, model_psn=psn)

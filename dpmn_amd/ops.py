@@ -226,3 +226,44 @@ def add_layernorm64(x, res, g, b, g2=None, b2=None, acc_out=None, alpha=1.0, acc
 def gru_gate(gi, gh, h, hist, hist_row_stride):
     R, H = h.shape
     check(lib.dpmn_gru_gate_f32(dptr(gi), dptr(gh), dptr(h), hist.data_ptr(), hist_row_stride, R, H, stream()))
+
+
+# ------------------------------------------------------------------------------ image-space helpers
+def _nchw_view(x):
+    """(pointer, per-image stride) of an NCHW tensor whose images are contiguous (channel-sliced views allowed)."""
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise _abi.DpmnError("dpmn_amd: expected a float32 CUDA tensor")
+    B, Cc, H, W = x.shape
+    if x.stride()[1:] != (H * W, W, 1):
+        x = x.contiguous()
+    return x, x.data_ptr(), x.stride(0)
+
+
+def to_mask(img):
+    """toMask (utils/util.py:27-35) for a whole batch; img (B,>=3,H,W) -> (B,3,H,W) in {0,1}."""
+    img, p, st = _nchw_view(img)
+    B, _, H, W = img.shape
+    out = torch.empty(B, 3, H, W, device=img.device)
+    check(lib.dpmn_to_mask_f32(p, st, dptr(out), B, H, W, stream()))
+    return out
+
+
+def blend(a, b, alpha):
+    """alpha*a + (1-alpha)*b[:, :C] (super_resolution.py:449)."""
+    a, pa, sa = _nchw_view(a)
+    b, pb, sb = _nchw_view(b)
+    B, Cc, H, W = a.shape
+    out = torch.empty(B, Cc, H, W, device=a.device)
+    check(lib.dpmn_blend_f32(pa, sa, pb, sb, dptr(out), float(alpha), B, Cc * H * W, stream()))
+    return out
+
+
+def psnr_ssim(x, y):
+    """(psnr, ssim) device scalars over the first 3 channels (utils/ssim_psnr.py)."""
+    x, px, sx = _nchw_view(x)
+    y, py, sy = _nchw_view(y)
+    B, _, H, W = x.shape
+    ws = torch.empty(lib.dpmn_psnr_ssim_workspace_bytes(B, 3, H, W), dtype=torch.uint8, device=x.device)
+    out = torch.empty(2, device=x.device)
+    check(lib.dpmn_psnr_ssim_f32(px, sx, py, sy, dptr(out), ws.data_ptr(), B, 3, H, W, stream()))
+    return out[0], out[1]

@@ -1,0 +1,59 @@
+"""Named workloads of BASELINE.json (synthetic weights + inputs) for bench.py, the smoke
+test and the parity tests.  Host code only: builds the reference-compatible module stack and its inputs."""
+from types import SimpleNamespace
+
+import torch
+
+from .utils import synth
+
+CONFIGS = {
+    # name: (arch, b1, b2, per-GPU batch)
+    "cfg0": ("tsrn", 1, 1, 4),    # TSRN + 1+1 PGRM, B=4 (the reference's CPU-runnable plumbing case)
+    "cfg1": ("tatt", 3, 3, 48),   # TATT + 3+3 PGRM, embed 96, windows 2/4/8, B=48 fp32 forward (headline metric)
+}
+
+
+def make_args(arch, b1, b2, batch):
+    n = b1 + b2
+    rep = lambda v: ",".join([str(v)] * n) + ","
+    return SimpleNamespace(
+        arch=arch, test=False, test_data_dir=None, batch_size=batch, resume=None, vis_dir=None, rec="aster", mask=True,
+        gradient=True, hd_u=32, srb=5, STN=False, patch_size=rep(2), embed_dim=rep(96), window_size=rep("2,4,8"),
+        depths=rep(1), num_heads=rep(6), mlp_ratio=rep(4), drop_rate=rep(0), attn_drop_rate=rep(0), drop_path_rate=rep(0),
+        rotate_train=0.0, rotate_test=0.0, stu_iter_b1=b1, stu_iter_b2=b2, tpg="visionlan", rec_path=None, font_path=None,
+        sr_share=False, alpha=0.5, window_num=3)
+
+
+def make_config(batch):
+    train = SimpleNamespace(batch_size=batch, width=128, height=32, epochs=1, cuda=True, ngpu=1, workers=0, resume="",
+                            ckpt_dir="./ckpt", voc_type="all", saveInterval=20, displayInterval=20, lr=0.001,
+                            optimizer="Adam", beta1=0.5, manualSeed=2, max_len=100, keep_ratio=False, down_sample_scale=2)
+    return SimpleNamespace(TRAIN=train)
+
+
+def build(name, batch=None, seed=100, device=None):
+    """Returns (sr: TextSR, models, psn, inputs dict) with name-seeded synthetic weights (module i -> seed+i in the
+    order [PSN, PGRM_0.., CMM], identical to tools/gen_golden.py::gen_stack for cfg0)."""
+    from .interfaces.super_resolution import TextSR
+    arch, b1, b2, B = CONFIGS[name]
+    B = batch or B
+    sr = TextSR(make_config(B), make_args(arch, b1, b2, B))
+    models, psn = sr.build_models()
+    for i, m in enumerate([psn] + models):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=seed + i)
+        m.load_state_dict(sd)
+        m.eval()
+        for p in m.parameters():
+            p.requires_grad = False
+    dev = device or sr.device
+    batch_d = synth.synth_batch(B, seed=2)
+    inputs = {k: v.to(dev) for k, v in batch_d.items()}
+    inputs["text_priors"] = [torch.floor(synth.uniform("text_prior_%d" % k, (B, 2, 32, 128), 0.0, 256.0, 2)).to(dev)
+                             for k in range(b1)]
+    return sr, models, psn, inputs
+
+
+def state_dicts_cpu(models, psn):
+    return ([{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in models],
+            {k: v.detach().cpu().clone() for k, v in psn.state_dict().items()})

@@ -149,6 +149,18 @@ int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, co
                        float* mid_ws, float* out, int B, int H, int W, int C, int hidden, int patch,
                        dpmn_stream_t stream);
 
+/* ------------------------------------------------------------------ image-space helpers (misc.hip) */
+/* toMask (utils/util.py:27-35) for a batch: img NCHW, first 3 channels used, img_stride = floats between images;
+ * out (B,3,H,W) in {0,1}. */
+int dpmn_to_mask_f32(const float* img, long img_stride, float* out, int B, int H, int W, dpmn_stream_t stream);
+/* out = alpha*a + (1-alpha)*b over chw floats per image (interfaces/super_resolution.py:449) */
+int dpmn_blend_f32(const float* a, long a_stride, const float* b, long b_stride, float* out, float alpha, int B,
+                   int chw, dpmn_stream_t stream);
+/* out2[0] = PSNR (utils/ssim_psnr.py:9-13), out2[1] = SSIM (28-48, 62-79) over the first C channels */
+size_t dpmn_psnr_ssim_workspace_bytes(int B, int C, int H, int W);
+int dpmn_psnr_ssim_f32(const float* x, long x_stride, const float* y, long y_stride, float* out2, void* workspace,
+                       int B, int C, int H, int W, dpmn_stream_t stream);
+
 /* ------------------------------------------------------------------ PGRM module (pgrm_forward.hip) */
 typedef struct {
   const float *norm1_q_w, *norm1_q_b, *norm1_kv_w, *norm1_kv_b;

@@ -1,0 +1,58 @@
+"""GPU parity of the whole SR forward stack through the trainer surface (TextSR.refine):
+config 0 vs the reference-driven golden, config 1 (TATT + 3+3 PGRM + CMM) vs the oracle at a small batch and
+PSNR/SSIM agreement to 1e-3 (the tolerance BASELINE.json's north_star states)."""
+import pytest
+import torch
+
+from dpmn_amd.utils import synth
+from helpers import load_golden, t, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def test_stack_cfg0_vs_reference_golden():
+    from dpmn_amd import workload, ops
+    g = load_golden("stack_cfg0")
+    sr, models, psn, inp = workload.build("cfg0")
+    out, mid = sr.refine(models, psn, inp["images_lr"], None, text_priors=inp["text_priors"], return_all=True)
+    assert_close(mid["psn"], t(g["psn"]), 2e-4, 2e-4, "psn")
+    assert_close(mid["branch1"][-1], t(g["branch1"]), 3e-4, 3e-4, "branch1")
+    assert_close(mid["branch2"][-1], t(g["branch2"]), 3e-4, 3e-4, "branch2")
+    assert_close(out, t(g["out"]), 3e-4, 3e-4, "stack output vs reference golden")
+    p, s = ops.psnr_ssim(out, inp["images_hr"])
+    assert abs(float(p) - float(g["psnr"])) < 1e-3 and abs(float(s) - float(g["ssim"])) < 1e-3
+
+
+def test_stack_cfg1_vs_oracle_small_batch():
+    from dpmn_amd import workload, ops
+    from oracle import dpmn as odpmn, cmm as ocmm
+    B = 4
+    sr, models, psn, inp = workload.build("cfg1", batch=B)
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [x.cpu() for x in v]) for k, v in inp.items()}
+    ref, rmid = odpmn.refine(sd_psn, sds[:-1], sds[-1], "tatt", 3, 3, cpu["images_lr"], cpu["label_vecs"], cpu["text_priors"],
+                             0.5, True)
+    out, mid = sr.refine(models, psn, inp["images_lr"], inp["label_vecs"], text_priors=inp["text_priors"], return_all=True)
+    assert_close(mid["psn"], rmid["psn"], 2e-4, 2e-4, "tatt psn")
+    # mask priors are discrete: a pixel whose luminance sits on the threshold may flip under 1e-6 differences;
+    # require the masks themselves to agree (they do for these seeds), then compare images
+    assert torch.equal(ops.to_mask(mid["psn"]).cpu(), ocmm.to_mask(rmid["psn"][:, :3]))
+    for k in range(3):
+        assert_close(mid["branch1"][k], rmid["branch1"][k], 5e-4, 5e-4, "branch1[%d]" % k)
+    assert_close(out, ref, 1e-3, 1e-3, "cfg1 output vs oracle")
+    p, s = ops.psnr_ssim(out, inp["images_hr"])
+    assert abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"]))) < 1e-3
+    assert abs(float(s) - float(ocmm.ssim(ref, cpu["images_hr"]))) < 1e-3
+
+
+def test_to_mask_blend_metrics_kernels():
+    from dpmn_amd import ops
+    from oracle import cmm as ocmm
+    dev = torch.device("cuda:0")
+    img = synth.uniform("mask_img", (5, 4, 32, 128), -0.2, 1.2, 10)
+    assert torch.equal(ops.to_mask(img.to(dev)).cpu(), ocmm.to_mask(img[:, :3]))
+    a, b = synth.uniform("a", (5, 3, 32, 128), 0, 1, 11), synth.uniform("b", (5, 4, 32, 128), 0, 1, 11)
+    assert_close(ops.blend(a.to(dev), b.to(dev), 0.3), 0.3 * a + 0.7 * b[:, :3], 1e-6, 0, "blend")
+    p, s = ops.psnr_ssim(a.to(dev), b.to(dev))
+    assert_close(p, ocmm.psnr(a, b), 1e-3, 0, "psnr")
+    assert_close(s, ocmm.ssim(a, b), 1e-5, 0, "ssim")

@@ -1,0 +1,40 @@
+"""Pin the whole-stack oracle (config 0: TSRN + 1+1 PGRM + CMM, B=4) against the reference-driven golden."""
+import torch
+
+from dpmn_amd.utils import synth
+from oracle import dpmn as odpmn, cmm as ocmm
+from helpers import load_golden, t, assert_close
+
+
+def build_cfg0_state_dicts():
+    """Synthetic weights exactly as tools/gen_golden.py::gen_stack draws them (seed 100+i per module)."""
+    from dpmn_amd.model.tsrn import TSRN
+    from dpmn_amd.model.pgrm import PGRM
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    n = 2
+    args = dict(patch_size=[2] * n, embed_dim=[96] * n, depths=[1] * n, num_heads=[[6]] * n, window_size=[[2, 4, 8]] * n,
+                mlp_ratio=[4.] * n, drop_rate=[0.] * n, attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
+    mods = [TSRN(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32),
+            PGRM(iter=0, mode=False, hidden_size=3, **args), PGRM(iter=1, mode=True, hidden_size=3, **args),
+            ComplementationModulationModule()]
+    for i, m in enumerate(mods):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=100 + i)
+        m.load_state_dict(sd)
+        m.eval()
+    return mods
+
+
+def test_stack_cfg0_matches_reference():
+    g = load_golden("stack_cfg0")
+    mods = build_cfg0_state_dicts()
+    sds = [{k: v.clone() for k, v in m.state_dict().items()} for m in mods]
+    batch = synth.synth_batch(4, seed=2)
+    prior = torch.floor(synth.uniform("text_prior_0", (4, 2, 32, 128), 0.0, 256.0, 2))
+    out, mid = odpmn.refine(sds[0], sds[1:3], sds[3], "tsrn", 1, 1, batch["images_lr"], None, [prior], 0.5, True)
+    assert_close(mid["psn"], t(g["psn"]), 2e-5, 1e-5, "psn")
+    assert_close(mid["branch1"][-1], t(g["branch1"]), 5e-5, 1e-5, "branch1")
+    assert_close(mid["branch2"][-1], t(g["branch2"]), 5e-5, 1e-5, "branch2")
+    assert_close(out, t(g["out"]), 5e-5, 1e-5, "stack output")
+    assert_close(ocmm.psnr(out, batch["images_hr"]), t(g["psnr"]), 1e-3, 0, "psnr")
+    assert_close(ocmm.ssim(out, batch["images_hr"]), t(g["ssim"]), 1e-3, 0, "ssim")

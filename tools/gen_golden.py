@@ -185,7 +185,42 @@ def gen_psn():
          manifest=manifest(sd), checksum=checksum(sd))
 
 
-GENS = {"psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss}
+def gen_stack():
+    """config 0 (BASELINE.json): TSRN PSN + 1+1 PGRM + CMM, B=4, eval forward of
+    interfaces/super_resolution.py:370-449 re-stated around the IMPORTED reference modules.  toMask needs
+    torchvision (absent) -> the PIL-pinned restatement oracle.cmm.to_mask is used for the mask prior."""
+    from model import tsrn, pgrm, cmm
+    from oracle import cmm as ocmm
+    B, b1, b2, alpha = 4, 1, 1, 0.5
+    batch = synth.synth_batch(B, seed=2)
+    psn = tsrn.TSRN(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32).eval()
+    mods = [pgrm.PGRM(iter=0, mode=False, hidden_size=3, **pgrm_args(2)).eval(),
+            pgrm.PGRM(iter=1, mode=True, hidden_size=3, **pgrm_args(2)).eval()]
+    fuse = cmm.ComplementationModulationModule().eval()
+    for i, m in enumerate([psn] + mods + [fuse]):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=100 + i)
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    prior = torch.floor(synth.uniform("text_prior_0", (B, 2, 32, 128), 0.0, 256.0, 2))
+    lr_psn = psn(batch["images_lr"])
+    cascade, l1 = lr_psn, []
+    for k in range(b1):
+        sr = mods[k](prior, cascade[:, :3, :], l1[:k])
+        l1.append(sr)
+        cascade = sr
+    cascade, l2 = lr_psn, []
+    for k in range(b1, b1 + b2):
+        sr = mods[k](ocmm.to_mask(cascade[:, :3]), cascade[:, :3, :], l2[:(k - b2)])
+        l2.append(sr)
+        cascade = sr
+    out = alpha * fuse(l1[-1], l2[-1]) + (1 - alpha) * lr_psn[:, :3, :, :]
+    sys.modules.setdefault("IPython", sys.modules["IPython"])
+    from utils import ssim_psnr
+    save("stack_cfg0", out=out, psn=lr_psn, branch1=l1[-1], branch2=l2[-1],
+         psnr=ssim_psnr.calculate_psnr(out, batch["images_hr"]), ssim=ssim_psnr.SSIM()(out, batch["images_hr"]))
+
+
+GENS = {"stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss}
 
 
 if __name__ == "__main__":
