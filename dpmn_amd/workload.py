@@ -57,3 +57,26 @@ def build(name, batch=None, seed=100, device=None):
 def state_dicts_cpu(models, psn):
     return ([{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in models],
             {k: v.detach().cpu().clone() for k, v in psn.state_dict().items()})
+
+
+def cpu_state_dicts(workload_name, seed=100):
+    """CPU-only synthetic reference-keyed state dicts (same seeding as build()); used by bench.py's cpu_baseline child."""
+    from .model.pgrm import PGRM
+    from .model.cmm import ComplementationModulationModule
+    from .model.tsrn import TSRN
+    from .model.tatt import TSRN_TL_TRANS
+    arch, b1, b2, _ = CONFIGS[workload_name]
+    n = b1 + b2
+    args = dict(patch_size=[2] * n, embed_dim=[96] * n, depths=[1] * n, num_heads=[[6]] * n, window_size=[[2, 4, 8]] * n,
+                mlp_ratio=[4.] * n, drop_rate=[0.] * n, attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
+    kw = dict(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32)
+    psn = (TSRN_TL_TRANS if arch == "tatt" else TSRN)(**kw)
+    mods = [PGRM(iter=k, mode=False, hidden_size=3, **args) for k in range(b1)]
+    mods += [PGRM(iter=k, mode=True, hidden_size=3, **args) for k in range(b1, b1 + b2)]
+    mods.append(ComplementationModulationModule())
+    sds = []
+    for i, m in enumerate([psn] + mods):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=seed + i)
+        sds.append({k: v.clone() for k, v in sd.items()})
+    return arch, b1, b2, sds[0], sds[1:]
