@@ -45,7 +45,7 @@ class ConvDesc(C.Structure):
                                "Hout", "Wout", "ostep", "ooy", "oox", "pro_act")] + [
         ("w", fp), ("bias", fp), ("Cout", C.c_int), ("epi_act", C.c_int), ("slope", C.c_float), ("res", fp),
         ("out", fp), ("out_ld", C.c_int), ("out_coff", C.c_int), ("out_nchw", C.c_int), ("pixel_shuffle", C.c_int),
-        ("stats", fp)]
+        ("stats", fp), ("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t)]
 
 
 _i, _f, _sz = C.c_int, C.c_float, C.c_size_t
@@ -65,7 +65,7 @@ SIGNATURES = {
     "dpmn_conv2d_nhwc_f32": (_i, [C.POINTER(ConvDesc), fp]),
     "dpmn_nchw_to_nhwc_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_nhwc_to_nchw_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
-    "dpmn_se_gate_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_se_gate_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_bigru_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, C.c_long, C.c_long, C.c_long, _i, fp]),
     "dpmn_small_linear_f32": (_i, [fp, fp, _i, fp, fp, fp, _i, _i, _i, _i, _f, fp]),
     "dpmn_tatt_encoder_layer_f32": (_i, [fp, fp, _PP, fp, _i, _i, _i, _i, fp]),

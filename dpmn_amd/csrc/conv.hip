@@ -42,7 +42,53 @@ struct ConvArgs {
   int out_nchw;               // 1: store NCHW (B, Cout, Hout, Wout)
   int pixel_shuffle;          // 1: PixelShuffle(2) store: NHWC (B, 2*Hout, 2*Wout, Cout/4)
   float* stats;               // (2, Cout) running sum / sum of squares of the pre-activation output, or null
+  float* partial;             // split-K scratch (ksplit, M, Npad) or null
+  int ksplit;                 // number of K splits (gridDim.z)
+  int npad;                   // Cout rounded up to 4
 };
+
+// bias + stats + activation + residual + store of 4 consecutive output channels of one pixel
+__device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, float (&v)[4], float (&ssum)[4], float (&ssq)[4]) {
+  const int b = m / (a.Hp * a.Wp), rr = m % (a.Hp * a.Wp);
+  const int oy = (rr / a.Wp) * a.ostep + a.ooy, ox = (rr % a.Wp) * a.ostep + a.oox;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] += ((a.bias && n + r < a.Cout) ? a.bias[n + r] : 0.f);
+  if (a.stats) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[r] += v[r]; ssq[r] += v[r] * v[r]; }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.epi_act, a.slope);
+  if (a.out_nchw) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < a.Cout) {
+        const size_t o = (((size_t)b * a.Cout + n + r) * a.Hout + oy) * a.Wout + ox;
+        a.out[o] = v[r] + (a.res ? a.res[o] : 0.f);
+      }
+  } else if (a.pixel_shuffle) {
+    // out[b, 2*oy+dy, 2*ox+dx, c] = conv[b, oy, ox, c*4 + dy*2 + dx]; the lane's 4 channels are one c
+    const int c = n >> 2, Co = a.Cout >> 2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int dy = r >> 1, dx = r & 1;
+      a.out[(((size_t)b * 2 * a.Hout + 2 * oy + dy) * 2 * a.Wout + 2 * ox + dx) * Co + c] = v[r];
+    }
+  } else {
+    const size_t o = (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.out_ld + a.out_coff + n;
+    if (n + 3 < a.Cout) {
+      float4 q = make_float4(v[0], v[1], v[2], v[3]);
+      if (a.res) {
+        const float4 rs = *reinterpret_cast<const float4*>(a.res + o);
+        q.x += rs.x; q.y += rs.y; q.z += rs.z; q.w += rs.w;
+      }
+      *reinterpret_cast<float4*>(a.out + o) = q;
+    } else {
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.Cout) a.out[o + r] = v[r] + (a.res ? a.res[o + r] : 0.f);
+    }
+  }
+}
 
 template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
@@ -129,12 +175,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  gload(0);
-  sstore(0);
+  const int nk_all = a.Kp / BK;
+  const int cps = (nk_all + a.ksplit - 1) / a.ksplit;          // chunks per split
+  const int kt0 = blockIdx.z * cps;
+  const int nk = min(nk_all, kt0 + cps);
+  if (kt0 < nk) { gload(kt0 * BK); sstore(0); }
   __syncthreads();
-  const int nk = a.Kp / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
     const float* xa = &Xs[buf][(wm * (MT * 16) + lr) * LDK + kq * 4];
     const float* wa = &Ws[buf][(wn * (NT * 16) + lr) * LDK + kq * 4];
@@ -157,60 +205,36 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   }
 
   // ---- epilogue: lane holds out[pixel m = .. + (l&15)][co = .. + (l>>4)*4 + r]
+  if (a.ksplit > 1) {
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m_blk + wm * (MT * 16) + j * 16 + lr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = n_blk + wn * (NT * 16) + i * 16 + kq * 4;
+        if (n >= a.npad) continue;
+        *reinterpret_cast<float4*>(a.partial + ((size_t)blockIdx.z * M + m) * a.npad + n) =
+            make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+      }
+    }
+    return;
+  }
   float ssum[NT][4], ssq[NT][4];
 #pragma unroll
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
-
 #pragma unroll
   for (int j = 0; j < MT; ++j) {
     const int m = m_blk + wm * (MT * 16) + j * 16 + lr;
     if (m >= M) continue;
-    const int b = m / (a.Hp * a.Wp), rr = m % (a.Hp * a.Wp);
-    const int oy = (rr / a.Wp) * a.ostep + a.ooy, ox = (rr % a.Wp) * a.ostep + a.oox;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
       const int n = n_blk + wn * (NT * 16) + i * 16 + kq * 4;
       if (n >= a.Cout) continue;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r] + ((a.bias && n + r < a.Cout) ? a.bias[n + r] : 0.f);
-      if (a.stats) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { ssum[i][r] += v[r]; ssq[i][r] += v[r] * v[r]; }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.epi_act, a.slope);
-      if (a.out_nchw) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (n + r < a.Cout) {
-            const size_t o = (((size_t)b * a.Cout + n + r) * a.Hout + oy) * a.Wout + ox;
-            a.out[o] = v[r] + (a.res ? a.res[o] : 0.f);
-          }
-      } else if (a.pixel_shuffle) {
-        // out[b, 2*oy+dy, 2*ox+dx, c] = conv[b, oy, ox, c*4 + dy*2 + dx]; the lane's 4 channels are one c
-        const int c = n >> 2, Co = a.Cout >> 2;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int dy = r >> 1, dx = r & 1;
-          a.out[(((size_t)b * 2 * a.Hout + 2 * oy + dy) * 2 * a.Wout + 2 * ox + dx) * Co + c] = v[r];
-        }
-      } else {
-        const size_t o = (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.out_ld + a.out_coff + n;
-        if (n + 3 < a.Cout) {
-          float4 q = make_float4(v[0], v[1], v[2], v[3]);
-          if (a.res) {
-            const float4 rs = *reinterpret_cast<const float4*>(a.res + o);
-            q.x += rs.x; q.y += rs.y; q.z += rs.z; q.w += rs.w;
-          }
-          *reinterpret_cast<float4*>(a.out + o) = q;
-        } else {
-          for (int r = 0; r < 4; ++r)
-            if (n + r < a.Cout) a.out[o + r] = v[r] + (a.res ? a.res[o + r] : 0.f);
-        }
-      }
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      conv_store(a, m, n, v, ssum[i], ssq[i]);
     }
   }
   if (a.stats) {
@@ -231,12 +255,50 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+// sum the split-K partials and run the epilogue; thread = (pixel, 4 channels)
+__global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a) {
   const int M = a.B * a.Hp * a.Wp;
-  dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN));
+  const int n4 = a.npad / 4;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)M * n4) return;
+  const int m = idx / n4, n = (idx % n4) * 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < a.ksplit; ++z) {
+    const float4 p = *reinterpret_cast<const float4*>(a.partial + ((size_t)z * M + m) * a.npad + n);
+    v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+  }
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  conv_store(a, m, n, v, ssum, ssq);
+  if (a.stats) {
+    for (int r = 0; r < 4; ++r)
+      if (n + r < a.Cout) { atomicAdd(a.stats + n + r, ssum[r]); atomicAdd(a.stats + a.Cout + n + r, ssq[r]); }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
+  const int M = a.B * a.Hp * a.Wp;
+  const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN);
+  const int nk = a.Kp / BK;
+  int S = 1;
+  if (ws && tiles < 256 && nk >= 16) {
+    S = cdiv(768, tiles);
+    if (S > nk / 8) S = nk / 8;
+    if (S > 64) S = 64;
+    while (S > 1 && (size_t)S * M * a.npad * sizeof(float) > ws_bytes) --S;
+    const int cps = cdiv(nk, S);
+    S = cdiv(nk, cps);   // no empty splits
+  }
+  a.ksplit = S;
+  a.partial = S > 1 ? ws : nullptr;
+  dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN), S);
   hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
   DPMN_CHECK_LAUNCH();
+  if (S > 1) {
+    const long total = (long)M * (a.npad / 4);
+    hipLaunchKernelGGL(k_conv_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    DPMN_CHECK_LAUNCH();
+  }
   return DPMN_OK;
 }
 
@@ -287,11 +349,14 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
                "conv2d: NHWC output needs 16-byte aligned channel rows");
   hipStream_t st = as_stream(stream);
   const int M = a.B * a.Hp * a.Wp;
-  if (a.Cout <= 16) return launch_conv<128, 16, 4, 1>(a, st);
-  if (a.Cout <= 32) return launch_conv<128, 32, 4, 1>(a, st);
-  if (a.Cout <= 64 || M < 4096) return launch_conv<64, 64, 2, 2>(a, st);
-  if (M >= 32768 && a.Cout >= 128) return launch_conv<128, 128, 2, 2>(a, st);
-  return launch_conv<128, 64, 4, 1>(a, st);
+  a.npad = (a.Cout + 3) / 4 * 4;
+  float* ws = d->splitk_ws;
+  const size_t wsb = d->splitk_ws_bytes;
+  if (a.Cout <= 16) return launch_conv<128, 16, 4, 1>(a, ws, wsb, st);
+  if (a.Cout <= 32) return launch_conv<128, 32, 4, 1>(a, ws, wsb, st);
+  if (a.Cout <= 64 || M < 4096) return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
+  if (M >= 32768 && a.Cout >= 128) return launch_conv<128, 128, 2, 2>(a, ws, wsb, st);
+  return launch_conv<128, 64, 4, 1>(a, ws, wsb, st);
 }
 
 int dpmn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, dpmn_stream_t stream) {

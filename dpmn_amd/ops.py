@@ -97,6 +97,18 @@ def pgrm_tail(tokens, w0, b0, w1, b1, weight_list, residuals, H, W, hidden, patc
 
 
 # ------------------------------------------------------------------------------ conv family
+_SPLITK_WS = {}
+
+
+def _splitk_workspace(device, floats=16 << 20):
+    """One 64 MB scratch per device for split-K partial sums (stream-ordered reuse: every conv consumes it before
+    the next launch on the same stream)."""
+    key = (device.type, device.index)
+    if key not in _SPLITK_WS:
+        _SPLITK_WS[key] = torch.empty(floats, device=device)
+    return _SPLITK_WS[key]
+
+
 def nchw_to_nhwc(x, cpad=None):
     B, Cc, H, W = x.shape
     cpad = cpad or Cc
@@ -150,6 +162,8 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
     d.out = dptr(out)
     d.out_ld, d.out_coff, d.out_nchw, d.pixel_shuffle = 0, 0, int(out_nchw), int(pixel_shuffle)
     d.stats = dptr(stats, True)
+    ws = _splitk_workspace(wp.device)
+    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     import ctypes as _C
     check(lib.dpmn_conv2d_nhwc_f32(_C.byref(d), stream()))
     return out
@@ -171,8 +185,9 @@ def convT_s2k4(inputs, packs, cout, pro_act="none", affine=None, stats=None):
 def se_gate(x, fc1_w, fc1_b, fc2_w, fc2_b):
     B, H, W, Cc = x.shape
     out = torch.empty_like(x)
-    check(lib.dpmn_se_gate_f32(dptr(x), dptr(fc1_w), dptr(fc1_b), dptr(fc2_w), dptr(fc2_b), dptr(out), B, H * W, Cc,
-                               fc1_w.shape[0], stream()))
+    hid = torch.empty(B, fc1_w.shape[0], device=x.device)
+    check(lib.dpmn_se_gate_f32(dptr(x), dptr(fc1_w), dptr(fc1_b), dptr(fc2_w), dptr(fc2_b), dptr(out), dptr(hid), B, H * W,
+                               Cc, fc1_w.shape[0], stream()))
     return out
 
 

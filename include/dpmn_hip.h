@@ -82,15 +82,18 @@ typedef struct {
   int out_nchw;              /* store NCHW instead */
   int pixel_shuffle;         /* PixelShuffle(2) store: NHWC (B,2Hout,2Wout,Cout/4) (tsrn.py:110-111) */
   float* stats;              /* (2,Cout) += sum / sum of squares of pre-activation outputs, or NULL */
+  float* splitk_ws;          /* optional scratch enabling split-K for small-M / large-K convs (deep CMM levels) */
+  size_t splitk_ws_bytes;
 } dpmn_conv_desc;
 int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream);
 /* layout plumbing at the module boundary: NCHW images <-> NHWC (channels zero-padded to Cpad) */
 int dpmn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, dpmn_stream_t stream);
 int dpmn_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, dpmn_stream_t stream);
 
-/* CMM channel gate (cmm.py:135-147) on the NHWC bottleneck x (B,P,C): out = x * sigmoid(fc2(relu(fc1(mean_p x)))) + x */
+/* CMM channel gate (cmm.py:135-147) on the NHWC bottleneck x (B,P,C): out = x * sigmoid(fc2(relu(fc1(mean_p x)))) + x.
+ * hidden_ws: B*Cmid floats of scratch. */
 int dpmn_se_gate_f32(const float* x, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,
-                     float* out, int B, int P, int C, int Cmid, dpmn_stream_t stream);
+                     float* out, float* hidden_ws, int B, int P, int C, int Cmid, dpmn_stream_t stream);
 
 /* ------------------------------------------------------------------ TSRN / TATT kernels (tatt.hip) */
 /* BiGRU recurrence of GruBlock (tsrn.py:139-150; tatt.py:1070-1083).  gi: (pixels, 6*hidden) input
