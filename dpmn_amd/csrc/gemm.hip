@@ -109,21 +109,31 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, i
   }
 }
 
-// ---------------------------------------------------------------------------------- whole-K
-// Block: 256 threads, tile BM=64 tokens x BN=96 features; waves 2(m) x 2(n): 32 tokens x 48 features each.
+// ---------------------------------------------------------------------------------- whole-K, W-stationary
+// Persistent blocks: the (BN=96 x K) weight tile is loaded into LDS ONCE per block; the block then walks over
+// BM=32-token tiles.  Tile i+1 is fetched into registers while tile i runs on the MFMA pipe; the prologue
+// transform (LayerNorm two-pass in registers across the 8 threads of a row / SK select / add) is applied on
+// the way from registers to the other LDS buffer.  One barrier per tile.  2 blocks per CU (64 KB LDS at K=96)
+// so one block's VALU prologue/epilogue overlaps the other's MFMAs.
+// Block: 256 threads; waves 2(m: 16 tokens) x 2(n: 48 features): acc[3 n-tiles][1 m-tile].
+constexpr int WS_BM = 32, WS_BN = 96;
+
 template <int K, int PRO>
-__global__ __launch_bounds__(256) void k_gemm_wholeK(const float* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                      float* __restrict__ y, int ldy, int M, int N, ProArgs p, EpiArgs e) {
-  constexpr int BM = 64, BN = 96, LDK = K + PAD;
+__global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                     float* __restrict__ y, int ldy, int M, int N, ProArgs p, EpiArgs e) {
+  constexpr int BM = WS_BM, BN = WS_BN, LDK = K + PAD;
+  constexpr int VPT = K / 32;                       // float4 per thread per tile (8 threads per row)
+  constexpr int NRAW = (PRO == PRO_SKSEL) ? 4 : (PRO == PRO_ADD ? 2 : 1);
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Xs = smem;               // [BM][LDK]
-  float* Ws = smem + BM * LDK;    // [BN][LDK]
-  float* red = Ws + BN * LDK;     // [4][BN] colsum scratch
+  float* Ws = smem;                       // [BN][LDK]
+  float* Xs = Ws + BN * LDK;              // [2][BM][LDK]
+  float* red = Xs + 2 * BM * LDK;         // [4][BN] colsum scratch
+  float* lng = red + 4 * BN;              // [K] LayerNorm gamma, [K] beta
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  const int n_blk = blockIdx.y * BN;
+  const int tiles = (M + BM - 1) / BM;
 
-  // ---- stage W tile (BN x K), zero rows beyond N
   constexpr int KV = K / 4;
   for (int i = tid; i < BN * KV; i += 256) {
     const int r = i / KV, c = (i % KV) * 4;
@@ -131,102 +141,113 @@ __global__ __launch_bounds__(256) void k_gemm_wholeK(const float* __restrict__ x
     if (n_blk + r < N) v = *reinterpret_cast<const float4*>(w + (size_t)(n_blk + r) * K + c);
     *reinterpret_cast<float4*>(Ws + r * LDK + c) = v;
   }
-  // ---- stage X tile
-  if (PRO == PRO_SKSEL) {
-    // x is (M, G*K); V[m][c] = sum_g A[b][g][c] * x[m][g*K + c]   (pgrm.py:90-92)
-    for (int i = tid; i < BM * KV; i += 256) {
-      const int r = i / KV, c = (i % KV) * 4;
-      const int m = m_blk + r;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M) {
-        const int b = m / p.rows_per_image;
-        for (int g = 0; g < p.groups; ++g) {
-          const float4 a = *reinterpret_cast<const float4*>(p.sel + ((size_t)b * p.groups + g) * K + c);
-          const float4 v = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + g * K + c);
-          acc.x += a.x * v.x; acc.y += a.y * v.y; acc.z += a.z * v.z; acc.w += a.w * v.w;
-        }
-      }
-      *reinterpret_cast<float4*>(Xs + r * LDK + c) = acc;
-    }
-  } else {
-    for (int i = tid; i < BM * KV; i += 256) {
-      const int r = i / KV, c = (i % KV) * 4;
-      const int m = m_blk + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M) {
-        v = *reinterpret_cast<const float4*>(x + (size_t)m * ldx + c);
-        if (PRO == PRO_ADD) {
-          const float4 a = *reinterpret_cast<const float4*>(p.addv + (size_t)m * ldx + c);
-          v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
-        }
-      }
-      *reinterpret_cast<float4*>(Xs + r * LDK + c) = v;
-    }
-  }
-  __syncthreads();
+  if (PRO == PRO_LN)
+    for (int i = tid; i < K; i += 256) { lng[i] = p.ln_w[i]; lng[K + i] = p.ln_b[i]; }
 
-  if (PRO == PRO_LN) {
-    // 4 threads per row, two-pass mean / variance, normalise in place
-    const int r = tid >> 2, part = tid & 3;
-    constexpr int PER = K / 4;
-    float* row = Xs + r * LDK + part * PER;
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) s += row[i];
-    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
-    const float mean = s * (1.0f / K);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) { const float d = row[i] - mean; q += d * d; }
-    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / K) + p.eps);
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int k = part * PER + i;
-      row[i] = (row[i] - mean) * rstd * p.ln_w[k] + p.ln_b[k];
-    }
-    __syncthreads();
-  }
+  const int srow = tid >> 3, spart = tid & 7;       // staging: row in tile, eighth of the row
+  const int scol = spart * (K / 8);
+  float4 raw[NRAW][VPT];
 
-  // ---- MFMA: wave (wm, wn) -> 2 m-tiles x 3 n-tiles
+  auto issue = [&](int tile) {
+    const int m = tile * BM + srow;
+    const bool ok = m < M;
+#pragma unroll
+    for (int v = 0; v < VPT; ++v) {
+      if (PRO == PRO_SKSEL) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          raw[g][v] = (ok && g < p.groups) ? *reinterpret_cast<const float4*>(x + (size_t)m * ldx + g * K + scol + v * 4)
+                                           : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else {
+        raw[0][v] = ok ? *reinterpret_cast<const float4*>(x + (size_t)m * ldx + scol + v * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PRO == PRO_ADD)
+          raw[NRAW - 1][v] = ok ? *reinterpret_cast<const float4*>(p.addv + (size_t)m * ldx + scol + v * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  };
+  auto commit = [&](int tile, int buf) {
+    float* dst = Xs + (size_t)buf * BM * LDK + srow * LDK + scol;
+    float vals[VPT * 4];
+    if (PRO == PRO_SKSEL) {
+      const int m = tile * BM + srow;
+      const int b = (m < M ? m : M - 1) / p.rows_per_image;
+#pragma unroll
+      for (int v = 0; v < VPT; ++v) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (g < p.groups) {
+            const float4 a = *reinterpret_cast<const float4*>(p.sel + ((size_t)b * p.groups + g) * K + scol + v * 4);
+            acc.x += a.x * raw[g][v].x; acc.y += a.y * raw[g][v].y; acc.z += a.z * raw[g][v].z; acc.w += a.w * raw[g][v].w;
+          }
+        vals[v * 4] = acc.x; vals[v * 4 + 1] = acc.y; vals[v * 4 + 2] = acc.z; vals[v * 4 + 3] = acc.w;
+      }
+    } else {
+#pragma unroll
+      for (int v = 0; v < VPT; ++v) {
+        float4 t = raw[0][v];
+        if (PRO == PRO_ADD) { const float4 a = raw[NRAW - 1][v]; t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
+        vals[v * 4] = t.x; vals[v * 4 + 1] = t.y; vals[v * 4 + 2] = t.z; vals[v * 4 + 3] = t.w;
+      }
+    }
+    if (PRO == PRO_LN) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPT * 4; ++i) s += vals[i];
+      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      const float mean = s * (1.0f / K);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < VPT * 4; ++i) { const float d = vals[i] - mean; q += d * d; }
+      q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+      const float rstd = 1.0f / sqrtf(q * (1.0f / K) + p.eps);
+#pragma unroll
+      for (int i = 0; i < VPT * 4; ++i) vals[i] = (vals[i] - mean) * rstd * lng[scol + i] + lng[K + scol + i];
+    }
+#pragma unroll
+    for (int v = 0; v < VPT; ++v)
+      *reinterpret_cast<float4*>(dst + v * 4) = make_float4(vals[v * 4], vals[v * 4 + 1], vals[v * 4 + 2], vals[v * 4 + 3]);
+  };
+
   const int wm = wave & 1, wn = wave >> 1;
   const int lr = lane & 15, kq = lane >> 4;
-  f32x4 acc[3][2];
+  int tile = blockIdx.x;
+  if (tile < tiles) issue(tile);
+  __syncthreads();                       // Ws / lng visible
+  if (tile < tiles) commit(tile, 0);
+  int buf = 0;
+  for (; tile < tiles; tile += gridDim.x) {
+    __syncthreads();                     // Xs[buf] committed by everyone; previous MFMA reads of Xs[buf^1] done
+    const int next = tile + gridDim.x;
+    if (next < tiles) issue(next);
+    f32x4 acc[3][1];
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < 3; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xa = Xs + (size_t)buf * BM * LDK + (wm * 16 + lr) * LDK + kq * 4;
+    const float* wa = Ws + (wn * 48 + lr) * LDK + kq * 4;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const float* xa = Xs + (wm * 32 + lr) * LDK + kq * 4;
-  const float* wa = Ws + (wn * 48 + lr) * LDK + kq * 4;
+    for (int kc = 0; kc < K; kc += 16) {
+      const f32x4 xf = *reinterpret_cast<const f32x4*>(xa + kc);
+      f32x4 wf[3];
 #pragma unroll
-  for (int kc = 0; kc < K; kc += 16) {
-    float4 xf[2], wf[3];
+      for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 16 * LDK + kc);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const float4*>(xa + j * 16 * LDK + kc);
+      for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const float4*>(wa + i * 16 * LDK + kc);
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        acc[i][j] = mfma16(wf[i].x, xf[j].x, acc[i][j]);
-        acc[i][j] = mfma16(wf[i].y, xf[j].y, acc[i][j]);
-        acc[i][j] = mfma16(wf[i].z, xf[j].z, acc[i][j]);
-        acc[i][j] = mfma16(wf[i].w, xf[j].w, acc[i][j]);
-      }
-  }
-
-  epilogue<3, 2>(acc, m_blk + wm * 32, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk);
-
-  if (e.colsum) {
-    __syncthreads();
-    // waves with the same wn cover the same columns: sum the two wm halves
-    for (int c = tid; c < BN; c += 256) {
-      const int wn_c = c / 48;
-      const float s = red[(wn_c * 2 + 0) * BN + c] + red[(wn_c * 2 + 1) * BN + c];
-      if (n_blk + c < N) e.colsum[(size_t)blockIdx.x * N + n_blk + c] = s;
+        for (int i = 0; i < 3; ++i) acc[i][0] = mfma16(wf[i][s4], xf[s4], acc[i][0]);
     }
+    epilogue<3, 1>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk);
+    if (e.colsum) {
+      __syncthreads();
+      for (int c = tid; c < BN; c += 256) {
+        const int wn_c = c / 48;
+        const float s = red[(wn_c * 2 + 0) * BN + c] + red[(wn_c * 2 + 1) * BN + c];
+        if (n_blk + c < N) e.colsum[(size_t)tile * N + n_blk + c] = s;
+      }
+    }
+    if (next < tiles) commit(next, buf ^ 1);
+    buf ^= 1;
   }
 }
 
@@ -391,14 +412,18 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
 template <int K, int PRO>
 int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
                   const EpiArgs& e, hipStream_t st) {
-  const size_t smem = (size_t)((64 + 96) * (K + PAD) + 4 * 96) * sizeof(float);
+  const size_t smem = (size_t)((WS_BN + 2 * WS_BM) * (K + PAD) + 4 * WS_BN + 2 * K) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wholeK<K, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstat<K, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  dim3 grid(cdiv(M, 64), cdiv(N, 96));
-  hipLaunchKernelGGL((k_gemm_wholeK<K, PRO>), grid, dim3(256), smem, st, x, ldx, w, y, ldy, M, N, p, e);
+  const int tiles = cdiv(M, WS_BM), ny = cdiv(N, WS_BN);
+  int gx = 512 / ny;                      // ~2 resident blocks per CU in total
+  if (gx < 1) gx = 1;
+  if (gx > tiles) gx = tiles;
+  dim3 grid(gx, ny);
+  hipLaunchKernelGGL((k_gemm_wstat<K, PRO>), grid, dim3(256), smem, st, x, ldx, w, y, ldy, M, N, p, e);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -13,50 +13,64 @@
 namespace {
 
 // ---------------------------------------------------------------------------------- patch embed
-// One wave = 16 tokens; lane -> (token = l>>2, channel quarter = l&3).  Optional fused
-// prior_fusion conv3x3 (2->3, pad 1) evaluated on the 2x2 pixels of the patch.
-template <int C>
+// One wave = 16 tokens; lane -> (token = l>>2, part = l&3).  Each lane produces C/4 embedding channels of its
+// token; with the fused prior_fusion conv3x3 (2->3, pad 1) each lane first evaluates ONE of the 2x2 patch pixels
+// and the four lanes of a token exchange results by shuffle.  pe weights sit in LDS transposed ([k][c]) so the
+// four parts read distinct banks.
+template <int C, int PATCH, bool FUSE>
 __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict__ img, int cin, const float* __restrict__ pf_w,
                                                          const float* __restrict__ pf_b, const float* __restrict__ pe_w,
                                                          const float* __restrict__ pe_b, const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, float* __restrict__ tok, int B,
-                                                         int Hi, int Wi, int patch) {
-  constexpr int CQ = C / 4;
-  const int Ht = Hi / patch, Wt = Wi / patch;
+                                                         int Hi, int Wi) {
+  constexpr int CQ = C / 4, KP = 3 * PATCH * PATCH;
+  static_assert(!FUSE || PATCH == 2, "fused prior conv assumes 2x2 patches (one pixel per lane of the token quad)");
+  __shared__ float wt[KP * C];
+  __shared__ float pfw[3 * 2 * 9 + 3];
+  for (int i = threadIdx.x; i < KP * C; i += 256) wt[(i % KP) * C + i / KP] = pe_w[i];   // pe_w (C, KP) -> [k][c]
+  if (FUSE && threadIdx.x < 57) pfw[threadIdx.x] = threadIdx.x < 54 ? pf_w[threadIdx.x] : pf_b[threadIdx.x - 54];
+  __syncthreads();
+  const int Ht = Hi / PATCH, Wt = Wi / PATCH;
   const int lane = threadIdx.x & 63;
-  const long token = (long)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + (lane >> 2);
+  long token = (long)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + (lane >> 2);
+  const long ntok = (long)B * Ht * Wt;
+  const bool valid = token < ntok;
+  if (!valid) token = ntok - 1;
   const int part = lane & 3;
-  if (token >= (long)B * Ht * Wt) return;
   const int b = token / (Ht * Wt), t = token % (Ht * Wt);
   const int th = t / Wt, tw = t % Wt;
-  const int KP = 3 * patch * patch;  // inputs per token after fusion (3 channels)
-  float in[48];                      // patch <= 4 -> 3*16
-  if (pf_w) {
-    // fused pixels p(c, dy, dx) = b[c] + sum_{ci,ky,kx} w[c][ci][ky][kx] * img[ci][y+ky-1][x+kx-1]
-    for (int dy = 0; dy < patch; ++dy)
-      for (int dx = 0; dx < patch; ++dx) {
-        const int y = th * patch + dy, x = tw * patch + dx;
-        float a[3] = {pf_b[0], pf_b[1], pf_b[2]};
-        for (int ci = 0; ci < cin; ++ci)
-          for (int ky = 0; ky < 3; ++ky) {
-            const int yy = y + ky - 1;
-            if (yy < 0 || yy >= Hi) continue;
-            for (int kx = 0; kx < 3; ++kx) {
-              const int xx = x + kx - 1;
-              if (xx < 0 || xx >= Wi) continue;
-              const float v = img[(((size_t)b * cin + ci) * Hi + yy) * Wi + xx];
+  float in[KP];
+  if (FUSE) {
+    const int dy = part >> 1, dx = part & 1;
+    const int y = th * 2 + dy, x = tw * 2 + dx;
+    float a[3] = {pfw[54], pfw[55], pfw[56]};
 #pragma unroll
-              for (int c = 0; c < 3; ++c) a[c] += pf_w[((c * cin + ci) * 3 + ky) * 3 + kx] * v;
-            }
-          }
+    for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) in[(c * patch + dy) * patch + dx] = a[c];
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = x + kx - 1;
+          const bool inb = yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
+          const float v = inb ? img[(((size_t)b * 2 + ci) * Hi + yy) * Wi + xx] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a[c] += pfw[((c * 2 + ci) * 3 + ky) * 3 + kx] * v;
+        }
       }
-  } else {
+    const int base = lane & ~3;
+#pragma unroll
     for (int c = 0; c < 3; ++c)
-      for (int dy = 0; dy < patch; ++dy)
-        for (int dx = 0; dx < patch; ++dx)
-          in[(c * patch + dy) * patch + dx] = img[(((size_t)b * cin + c) * Hi + th * patch + dy) * Wi + tw * patch + dx];
+#pragma unroll
+      for (int pix = 0; pix < 4; ++pix) in[c * 4 + pix] = __shfl(a[c], base + pix, 64);   // (c, dy, dx) order = conv weight order
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int dy = 0; dy < PATCH; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < PATCH; ++dx)
+          in[(c * PATCH + dy) * PATCH + dx] = img[(((size_t)b * cin + c) * Hi + th * PATCH + dy) * Wi + tw * PATCH + dx];
   }
   float o[CQ];
   float s = 0.f;
@@ -64,7 +78,8 @@ __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict_
   for (int i = 0; i < CQ; ++i) {
     const int c = part * CQ + i;
     float a = pe_b[c];
-    for (int k = 0; k < KP; ++k) a += pe_w[c * KP + k] * in[k];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) a += wt[k * C + c] * in[k];
     o[i] = a;
     s += a;
   }
@@ -75,6 +90,7 @@ __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict_
   for (int i = 0; i < CQ; ++i) { const float d = o[i] - mean; q += d * d; }
   q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
   const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+  if (!valid) return;
   float* dst = tok + (size_t)token * C + part * CQ;
 #pragma unroll
   for (int i = 0; i < CQ; i += 4) {
@@ -307,41 +323,6 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
 }
 
 // ---------------------------------------------------------------------------------- tail
-// conv3x3 C->Cm on the token grid (NHWC in, NHWC out), direct VALU: small Cm (12).
-// thread = (pixel, output channel); weights in reference layout (Cm, C, 3, 3).
-__global__ __launch_bounds__(256) void k_tail_conv1(const float* __restrict__ tok, const float* __restrict__ w,
-                                                     const float* __restrict__ bias, float* __restrict__ mid, int B, int H, int W,
-                                                     int C, int Cm) {
-  extern __shared__ float wsm[];  // [9][C][Cm] repacked
-  for (int i = threadIdx.x; i < 9 * C * Cm; i += blockDim.x) {
-    const int co = i % Cm, ci = (i / Cm) % C, tap = i / (Cm * C);
-    wsm[i] = w[(co * C + ci) * 9 + tap];
-  }
-  __syncthreads();
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * H * W * Cm;
-  if (idx >= total) return;
-  const int co = idx % Cm;
-  const long pix = idx / Cm;
-  const int x = pix % W, y = (pix / W) % H, b = pix / ((long)W * H);
-  float a = bias[co];
-  for (int ky = 0; ky < 3; ++ky) {
-    const int yy = y + ky - 1;
-    if (yy < 0 || yy >= H) continue;
-    for (int kx = 0; kx < 3; ++kx) {
-      const int xx = x + kx - 1;
-      if (xx < 0 || xx >= W) continue;
-      const float* src = tok + (((size_t)b * H + yy) * W + xx) * C;
-      const float* wp = wsm + (size_t)(ky * 3 + kx) * C * Cm + co;
-      for (int ci = 0; ci < C; ci += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src + ci);
-        a += v.x * wp[ci * Cm] + v.y * wp[(ci + 1) * Cm] + v.z * wp[(ci + 2) * Cm] + v.w * wp[(ci + 3) * Cm];
-      }
-    }
-  }
-  mid[idx] = a;
-}
-
 // conv3x3 Cm->Cm + LeakyReLU(0.01) + PixelShuffle(p) + * weight_list_0 + sum_i residual_i * weight_list_i
 // output NCHW (B, hid, H*p, W*p); thread = (pixel, output channel)
 struct TailResid {
@@ -351,34 +332,75 @@ struct TailResid {
 };
 __global__ __launch_bounds__(256) void k_tail_conv2(const float* __restrict__ mid, const float* __restrict__ w,
                                                      const float* __restrict__ bias, const float* __restrict__ wl0, TailResid tr,
-                                                     float* __restrict__ out, int B, int H, int W, int Cm, int p) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)B * H * W * Cm;
-  if (idx >= total) return;
-  const int co = idx % Cm;
-  const long pix = idx / Cm;
+                                                     float* __restrict__ out, int B, int H, int W) {
+  // hidden 3, patch 2: Cm = 12 channels in and out; thread = one low-res pixel, all 12 outputs
+  constexpr int Cm = 12;
+  __shared__ __attribute__((aligned(16))) float ws[9 * Cm * Cm];   // [tap][ci][co]
+  for (int i = threadIdx.x; i < 9 * Cm * Cm; i += 256) {
+    const int co = i % Cm, ci = (i / Cm) % Cm, tap = i / (Cm * Cm);
+    ws[i] = w[(co * Cm + ci) * 9 + tap];
+  }
+  __syncthreads();
+  const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= (long)B * H * W) return;
   const int x = pix % W, y = (pix / W) % H, b = pix / ((long)W * H);
-  float a = bias[co];
+  float a[Cm];
+#pragma unroll
+  for (int co = 0; co < Cm; ++co) a[co] = bias[co];
+#pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int yy = y + ky - 1;
     if (yy < 0 || yy >= H) continue;
+#pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int xx = x + kx - 1;
       if (xx < 0 || xx >= W) continue;
       const float* src = mid + (((size_t)b * H + yy) * W + xx) * Cm;
-      for (int ci = 0; ci < Cm; ++ci) a += src[ci] * w[((co * Cm + ci) * 3 + ky) * 3 + kx];
+      float v[Cm];
+#pragma unroll
+      for (int q = 0; q < Cm; q += 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(src + q);
+        v[q] = t4.x; v[q + 1] = t4.y; v[q + 2] = t4.z; v[q + 3] = t4.w;
+      }
+      const float* wp = ws + (ky * 3 + kx) * Cm * Cm;
+#pragma unroll
+      for (int ci = 0; ci < Cm; ++ci)
+#pragma unroll
+        for (int co = 0; co < Cm; co += 4) {
+          const float4 w4 = *reinterpret_cast<const float4*>(wp + ci * Cm + co);
+          a[co] += v[ci] * w4.x; a[co + 1] += v[ci] * w4.y; a[co + 2] += v[ci] * w4.z; a[co + 3] += v[ci] * w4.w;
+        }
     }
   }
-  a = a > 0.f ? a : 0.01f * a;
-  // PixelShuffle: out[b, c, y*p+dy, x*p+dx] = in[b, c*p*p + dy*p + dx, y, x]
-  const int hid = Cm / (p * p);
-  const int c = co / (p * p), dy = (co / p) % p, dx = co % p;
-  const int Ho = H * p, Wo = W * p;
-  const size_t plane_off = ((size_t)c * Ho + (y * p + dy)) * Wo + (x * p + dx);   // within (hid, Ho, Wo)
-  const size_t o = (size_t)b * hid * Ho * Wo + plane_off;
-  float v = a * wl0[plane_off];
-  for (int i = 0; i < tr.n; ++i) v += tr.res[i][o] * tr.wl[i][plane_off];
-  out[o] = v;
+  // LeakyReLU(0.01) + PixelShuffle(2): out[b, c, 2y+dy, 2x+dx] = in[b, 4c + 2dy + dx, y, x]; then weight_list / residuals
+  const int Ho = 2 * H, Wo = 2 * W;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+      float v0 = a[4 * c + 2 * dy], v1 = a[4 * c + 2 * dy + 1];
+      v0 = v0 > 0.f ? v0 : 0.01f * v0;
+      v1 = v1 > 0.f ? v1 : 0.01f * v1;
+      const size_t po = ((size_t)c * Ho + (2 * y + dy)) * Wo + 2 * x;
+      const size_t o = (size_t)b * 3 * Ho * Wo + po;
+      const float2 l0 = *reinterpret_cast<const float2*>(wl0 + po);
+      float2 r = make_float2(v0 * l0.x, v1 * l0.y);
+      for (int i = 0; i < tr.n; ++i) {
+        const float2 rs = *reinterpret_cast<const float2*>(tr.res[i] + o);
+        const float2 li = *reinterpret_cast<const float2*>(tr.wl[i] + po);
+        r.x += rs.x * li.x; r.y += rs.y * li.y;
+      }
+      *reinterpret_cast<float2*>(out + o) = r;
+    }
+}
+
+// (Cout, Cin, KH, KW) reference conv weight -> (Cout, Kp) implicit-GEMM pack, K index = (ky*KW+kx)*Cin + ci
+__global__ void k_pack_conv_w(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin, int taps, int Kp) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Cout * Kp) return;
+  const int co = idx / Kp, k = idx % Kp;
+  const int tap = k / Cin, ci = k % Cin;
+  wp[idx] = tap < taps ? w[((size_t)co * Cin + ci) * taps + tap] : 0.f;
 }
 
 }  // namespace
@@ -394,12 +416,16 @@ int dpmn_patch_embed_ln_f32(const float* img, int cin, const float* pf_w, const 
   DPMN_REQUIRE((pf_w != nullptr) || cin >= 3, "patch_embed: need 3 input channels without prior_fusion");
   const long tokens_n = (long)B * (Hi / patch) * (Wi / patch);
   dim3 grid((unsigned)((tokens_n + 63) / 64));
-  if (C == 96)
-    hipLaunchKernelGGL((k_patch_embed_ln<96>), grid, dim3(256), 0, as_stream(stream), img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, ln_b, tokens, B, Hi, Wi, patch);
-  else if (C == 192)
-    hipLaunchKernelGGL((k_patch_embed_ln<192>), grid, dim3(256), 0, as_stream(stream), img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, ln_b, tokens, B, Hi, Wi, patch);
-  else
-    return dpmn_set_error(DPMN_ERR_ARG, "patch_embed: embed dim must be 96 or 192");
+  DPMN_REQUIRE(patch == 2, "patch_embed: built for patch_size=2 (the --patch_size the DPMN recipe uses, README.md:34)");
+  DPMN_REQUIRE(pf_w == nullptr || cin == 2, "patch_embed: prior_fusion expects a 2-channel text prior");
+  hipStream_t st = as_stream(stream);
+#define PE_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_ln<CV, 2, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, ln_b, tokens, B, Hi, Wi)
+  if (C == 96 && pf_w) PE_LAUNCH(96, true);
+  else if (C == 96) PE_LAUNCH(96, false);
+  else if (C == 192 && pf_w) PE_LAUNCH(192, true);
+  else if (C == 192) PE_LAUNCH(192, false);
+  else return dpmn_set_error(DPMN_ERR_ARG, "patch_embed: embed dim must be 96 or 192");
+#undef PE_LAUNCH
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -453,13 +479,20 @@ int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, co
                        float* out, int B, int H, int W, int C, int hidden, int patch, dpmn_stream_t stream) {
   DPMN_REQUIRE(tokens && w0 && b0 && w1 && b1 && weight_list && mid_ws && out, "tail: null pointer");
   DPMN_REQUIRE(n_residuals >= 0 && n_residuals <= 8, "tail: at most 8 residuals");
+  DPMN_REQUIRE(hidden == 3 && patch == 2 && C % 4 == 0, "tail: built for hidden_size=3, patch_size=2 (super_resolution.py:38-53)");
   const int Cm = hidden * patch * patch;
-  const size_t smem = (size_t)9 * C * Cm * 4;
-  DPMN_REQUIRE(smem <= 64 * 1024, "tail: conv weights must fit 64 KB of LDS");
-  const long total = (long)B * H * W * Cm;
-  hipLaunchKernelGGL(k_tail_conv1, dim3((unsigned)((total + 255) / 256)), dim3(256), smem, as_stream(stream), tokens, w0, b0,
-                     mid_ws, B, H, W, C, Cm);
+  const int Kp = ((9 * C + 31) / 32) * 32;
+  // mid_ws layout: [B*H*W*Cm mid activations][Cm*Kp packed conv0 weights]
+  float* wp = mid_ws + (size_t)B * H * W * Cm;
+  hipLaunchKernelGGL(k_pack_conv_w, dim3((Cm * Kp + 255) / 256), dim3(256), 0, as_stream(stream), w0, wp, Cm, C, 9, Kp);
   DPMN_CHECK_LAUNCH();
+  dpmn_conv_desc d{};
+  d.in[0] = tokens; d.cseg[0] = C; d.B = B; d.Hin = H; d.Win = W;
+  d.KH = 3; d.KW = 3; d.stride = 1; d.dil_y = 1; d.dil_x = 1; d.pad_y = 1; d.pad_x = 1;
+  d.Hp = H; d.Wp = W; d.Hout = H; d.Wout = W; d.ostep = 1;
+  d.w = wp; d.bias = b0; d.Cout = Cm; d.out = mid_ws;
+  int rc = dpmn_conv2d_nhwc_f32(&d, stream);   // conv_before_upsample[0] on the MFMA implicit-GEMM path
+  if (rc != DPMN_OK) return rc;
   TailResid tr{};
   // quirk Q11: residual_list[0] is never added -- the loop starts at 1 (pgrm.py:563)
   tr.n = 0;
@@ -468,8 +501,9 @@ int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, co
     tr.wl[tr.n] = weight_list[i];
     ++tr.n;
   }
-  hipLaunchKernelGGL(k_tail_conv2, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), mid_ws, w1, b1,
-                     weight_list[0], tr, out, B, H, W, Cm, patch);
+  const long pixels = (long)B * H * W;
+  hipLaunchKernelGGL(k_tail_conv2, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, as_stream(stream), mid_ws, w1, b1,
+                     weight_list[0], tr, out, B, H, W);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

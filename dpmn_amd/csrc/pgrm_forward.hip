@@ -29,9 +29,9 @@ Ws carve(const dpmn_pgrm_weights* w, int B, char* base) {
   s.x1 = take(B * L * C);
   s.y = take(B * L * Ch);
   s.g = take(B * L * Ch);
-  s.partial = take((size_t)B * ((L + 63) / 64) * C);
+  s.partial = take((size_t)B * ((L + 31) / 32) * C);
   s.avec = take((size_t)B * C);
-  s.mid = take(B * L * (size_t)w->hidden_size * w->patch * w->patch);
+  s.mid = take(B * L * (size_t)w->hidden_size * w->patch * w->patch + (size_t)16 * (9 * C + 32));
   s.total = off;
   return s;
 }
@@ -79,7 +79,7 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
     RUN(dpmn_window_attn_f32(s.q, s.kv, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat, B, H, Wd, C, stream));
     RUN(dpmn_sk_proj_f32(s.cat, p.sk_proj_w, p.sk_proj_b, s.feats, s.partial, M, C, stream));
     const int cg = C / w->n_groups;
-    RUN(dpmn_sk_gate_f32(s.partial, (L + 63) / 64, L, p.sk_fc1_w, p.sk_fc1_b, p.sk_fc2_w, p.sk_fc2_b, s.avec, B, C,
+    RUN(dpmn_sk_gate_f32(s.partial, (L + 31) / 32, L, p.sk_fc1_w, p.sk_fc1_b, p.sk_fc2_w, p.sk_fc2_b, s.avec, B, C,
                          w->n_groups, cg / 2, stream));
     RUN(dpmn_sk_select_f32(s.cat, s.avec, p.sk_head_w, p.sk_head_b, s.feats, s.tkv, s.x1, M, L, C, w->n_groups, stream));
     RUN(dpmn_ln_linear_f32(s.x1, p.norm2_w, p.norm2_b, 1e-5f, p.fc1_w, p.fc1_b, s.y, M, Ch, C, DPMN_ACT_GELU, stream));

@@ -60,7 +60,7 @@ def sk_fuse(cat, shortcut, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, head_w, h
     B, L, Cd = cat.shape
     M = B * L
     feats = torch.empty_like(cat)
-    parts = (L + 63) // 64
+    parts = (L + 31) // 32
     partial = torch.empty(B * parts, Cd, device=cat.device)
     avec = torch.empty(B, groups, Cd // groups, device=cat.device)
     out = torch.empty_like(cat)
@@ -88,7 +88,7 @@ def pointwise(g, w, bias):
 
 def pgrm_tail(tokens, w0, b0, w1, b1, weight_list, residuals, H, W, hidden, patch):
     B, L, Cd = tokens.shape
-    mid = torch.empty(B * L * hidden * patch * patch, device=tokens.device)
+    mid = torch.empty(B * L * hidden * patch * patch + 16 * (9 * Cd + 32), device=tokens.device)
     out = torch.empty(B, hidden, H * patch, W * patch, device=tokens.device)
     check(lib.dpmn_pgrm_tail_f32(dptr(tokens), dptr(w0), dptr(b0), dptr(w1), dptr(b1), _abi.ptr_array(weight_list),
                                  _abi.ptr_array(residuals), len(residuals), dptr(mid), dptr(out), B, H, W, Cd, hidden,

@@ -43,8 +43,8 @@ int dpmn_add_linear_f32(const float* x, const float* addv, const float* w, const
 /* y = act(LayerNorm(x) . w^T + bias): pgrm.py:322-323 + 188/194 (q, kv), pgrm.py:330 + 30-31 (norm2+fc1+GELU) */
 int dpmn_ln_linear_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* w,
                        const float* bias, float* y, int M, int N, int K, int act, dpmn_stream_t stream);
-/* SKConv.proj (pgrm.py:82) + per-64-row-block column sums of GELU(feats) for the global average pool
- * (pgrm.py:84-86).  colsum_partials: (ceil(M/64), C). */
+/* SKConv.proj (pgrm.py:82) + per-32-row-tile column sums of GELU(feats) for the global average pool
+ * (pgrm.py:84-86).  colsum_partials: (ceil(M/32), C); rows per image must be a multiple of 32. */
 int dpmn_sk_proj_f32(const float* cat, const float* w, const float* bias, float* feats, float* colsum_partials,
                      int M, int C, dpmn_stream_t stream);
 /* out = shortcut + feats + (sum_g A[b,g,:] * cat[:, g-th slice]) . w_head^T + b_head
@@ -146,7 +146,7 @@ int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, f
                             dpmn_stream_t stream);
 /* conv_before_upsample (2 convs + LeakyReLU) + PixelShuffle + weight_list scaling + residuals
  * (pgrm.py:559-565).  weight_list / residuals: HOST arrays of device pointers; residuals[0] is
- * ignored like the reference does (quirk Q11).  mid_ws: B*H*W*hidden*patch^2 floats. */
+ * ignored like the reference does (quirk Q11).  mid_ws: B*H*W*hidden*patch^2 + 16*(9*C+32) floats. */
 int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, const float* w1, const float* b1,
                        const float* const* weight_list, const float* const* residuals, int n_residuals,
                        float* mid_ws, float* out, int B, int H, int W, int C, int hidden, int patch,
