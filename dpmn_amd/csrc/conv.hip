@@ -275,6 +275,193 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------- halo-tile direct conv
+// Stride-1 "same" KxK convs (3x3 of the CMM / PSN trunks, 9x9 output conv) with the INPUT tile resident in LDS:
+// a block owns 8x16 output pixels of one image x BN output channels.  Per 32-channel chunk the (8+K-1)x(16+K-1)
+// halo tile is fetched once (prologue affine/activation applied on the way in) and every tap reads its shifted
+// window straight from LDS, so activations cross L2->LDS once instead of K*K times (the im2col redundancy that
+// made k_conv_igemm L2-bound); only the (BN x 32) weight slice of each (chunk, tap) is streamed, double-buffered.
+// One output row of the tile = one 16-pixel MFMA column block; waves 4(m: 2 rows each) x 1(n).
+template <int KS, int BN>
+__global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
+  constexpr int TH = 8, TW = 16, HH = TH + KS - 1, HW_ = TW + KS - 1, NPX = HH * HW_;
+  constexpr int NT = BN / 16, T = KS * KS;
+  constexpr bool PREFETCH = (KS <= 3);                   // large halos are staged directly (few chunks, many taps)
+  constexpr int HBUF = PREFETCH ? 2 : 1;
+  constexpr int HV = PREFETCH ? (NPX * 8 + 255) / 256 : 1;   // halo float4 per thread held in registers
+  constexpr int WV = (BN * 8 + 255) / 256;               // weight float4 per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;                                    // [HBUF][NPX][LDK]
+  float* Wt = smem + HBUF * NPX * LDK;                   // [2][BN][LDK]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = a.Win / TW, tiles_y = a.Hin / TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y), trem = blockIdx.x % (tiles_x * tiles_y);
+  const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+  const int n_blk = blockIdx.y * BN;
+  const int padk = (KS - 1) / 2;
+  const int c01 = a.cseg[0] + a.cseg[1];
+  const int nchunks = a.cin / BK;
+
+  float4 hraw[HV], wraw[WV];
+  // fetch (and transform) halo element i of channel chunk `chunk`
+  auto halo_elem = [&](int chunk, int i) -> float4 {
+    const int c0 = chunk * BK;
+    int seg = 0, cl0 = c0;
+    if (c0 >= c01) { seg = 2; cl0 = c0 - c01; }
+    else if (c0 >= a.cseg[0]) { seg = 1; cl0 = c0 - a.cseg[0]; }
+    const float* src = a.in[seg];
+    const int cs = a.cseg[seg];
+    const float* sc = a.in_scale[seg];
+    const float* sh = a.in_shift[seg];
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int px = i >> 3, c4 = (i & 7) * 4;
+    const int iy = ty0 + px / HW_ - padk, ix = tx0 + px % HW_ - padk;
+    if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+      val = *reinterpret_cast<const float4*>(src + (((size_t)b * a.Hin + iy) * a.Win + ix) * cs + cl0 + c4);
+      if (sc) {
+        const float4 s4 = *reinterpret_cast<const float4*>(sc + cl0 + c4);
+        const float4 h4 = *reinterpret_cast<const float4*>(sh + cl0 + c4);
+        val.x = val.x * s4.x + h4.x; val.y = val.y * s4.y + h4.y; val.z = val.z * s4.z + h4.z; val.w = val.w * s4.w + h4.w;
+      }
+      if (a.pro_act != ACT_NONE) {
+        val.x = apply_act(val.x, a.pro_act, 0.f); val.y = apply_act(val.y, a.pro_act, 0.f);
+        val.z = apply_act(val.z, a.pro_act, 0.f); val.w = apply_act(val.w, a.pro_act, 0.f);
+      }
+    }
+    return val;
+  };
+  auto stage_halo_direct = [&](int chunk) {
+    for (int i = tid; i < NPX * 8; i += 256)
+      *reinterpret_cast<float4*>(halo + (i >> 3) * LDK + (i & 7) * 4) = halo_elem(chunk, i);
+  };
+  auto issue_halo = [&](int chunk) {
+#pragma unroll
+    for (int v = 0; v < HV; ++v) {
+      const int i = tid + v * 256;
+      hraw[v] = (i < NPX * 8) ? halo_elem(chunk, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit_halo = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < HV; ++v) {
+      const int i = tid + v * 256;
+      if (i < NPX * 8) *reinterpret_cast<float4*>(halo + (size_t)buf * NPX * LDK + (i >> 3) * LDK + (i & 7) * 4) = hraw[v];
+    }
+  };
+  auto issue_w = [&](int chunk, int tap) {
+    const size_t k0 = (size_t)tap * a.cin + chunk * BK;
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+      const int i = tid + v * 256;
+      const int r = i >> 3, c4 = (i & 7) * 4;
+      wraw[v] = (i < BN * 8 && n_blk + r < a.Cout) ? *reinterpret_cast<const float4*>(a.w + (size_t)(n_blk + r) * a.Kp + k0 + c4)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto commit_w = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < WV; ++v) {
+      const int i = tid + v * 256;
+      if (i < BN * 8) *reinterpret_cast<float4*>(Wt + (size_t)buf * BN * LDK + (i >> 3) * LDK + (i & 7) * 4) = wraw[v];
+    }
+  };
+
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+  if (PREFETCH) { issue_halo(0); commit_halo(0); }
+  issue_w(0, 0);
+  commit_w(0);
+  __syncthreads();
+  int wb = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    const int hb = PREFETCH ? (chunk & 1) : 0;
+    const bool more = chunk + 1 < nchunks;
+    if (PREFETCH) {
+      if (more) issue_halo(chunk + 1);
+    } else {
+      stage_halo_direct(chunk);     // all reads of the previous chunk finished at the last barrier
+      __syncthreads();
+    }
+    for (int tap = 0; tap < T; ++tap) {
+      const bool lastt = tap == T - 1;
+      if (!lastt) issue_w(chunk, tap + 1);
+      else if (more) issue_w(chunk + 1, 0);
+      const int ky = tap / KS, kx = tap % KS;
+      const float* hp = halo + (size_t)hb * NPX * LDK + ((2 * wave + ky) * HW_ + lr + kx) * LDK + kq * 4;
+      const float* wp = Wt + (size_t)wb * BN * LDK + lr * LDK + kq * 4;
+#pragma unroll
+      for (int kc = 0; kc < BK; kc += 16) {
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(hp + kc);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(hp + HW_ * LDK + kc);
+        f32x4 wf[NT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wp + i * 16 * LDK + kc);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int i = 0; i < NT; ++i) {
+            acc[i][0] = mfma16(wf[i][s4], x0[s4], acc[i][0]);
+            acc[i][1] = mfma16(wf[i][s4], x1[s4], acc[i][1]);
+          }
+      }
+      if (!lastt || more) commit_w(wb ^ 1);
+      if (PREFETCH && lastt && more) commit_halo(hb ^ 1);
+      __syncthreads();
+      wb ^= 1;
+    }
+  }
+
+  float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int oy = ty0 + 2 * wave + j, ox = tx0 + lr;
+    const int m = (b * a.Hin + oy) * a.Win + ox;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n_blk + i * 16 + kq * 4;
+      if (n >= a.Cout) continue;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      conv_store(a, m, n, v, ssum[i], ssq[i]);
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const int n = n_blk + i * 16 + kq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s_ = ssum[i][r], q = ssq[i][r];
+        s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64); s_ += __shfl_xor(s_, 8, 64);
+        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+        if (lr == 0 && n + r < a.Cout) { atomicAdd(a.stats + n + r, s_); atomicAdd(a.stats + a.Cout + n + r, q); }
+      }
+    }
+  }
+}
+
+template <int KS, int BN>
+int launch_halo(const ConvArgs& a, hipStream_t st) {
+  constexpr int NPX = (8 + KS - 1) * (16 + KS - 1);
+  const size_t smem = (size_t)((KS <= 3 ? 2 : 1) * NPX + 2 * BN) * LDK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<KS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(a.B * (a.Hin / 8) * (a.Win / 16), cdiv(a.Cout, BN));
+  hipLaunchKernelGGL((k_conv_halo<KS, BN>), grid, dim3(256), smem, st, a);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   const int M = a.B * a.Hp * a.Wp;
@@ -352,6 +539,15 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   a.npad = (a.Cout + 3) / 4 * 4;
   float* ws = d->splitk_ws;
   const size_t wsb = d->splitk_ws_bytes;
+  // stride-1 "same" 3x3 / 9x9 convs on 8x16-tileable maps: input tile resident in LDS
+  const bool halo_ok = a.stride == 1 && a.dil_y == 1 && a.dil_x == 1 && a.KH == a.KW && (a.KH == 3 || a.KH == 9) &&
+                       a.pad_y == (a.KH - 1) / 2 && a.pad_x == a.pad_y && a.Hin % 8 == 0 && a.Win % 16 == 0 && a.ostep == 1 &&
+                       a.Hp == a.Hin && a.Wp == a.Win && cin % 32 == 0 && a.cseg[0] % 32 == 0 && a.cseg[1] % 32 == 0 &&
+                       a.cseg[2] % 32 == 0 && M >= 1024;
+  if (halo_ok) {
+    if (a.KH == 3) return a.Cout <= 16 ? launch_halo<3, 16>(a, st) : launch_halo<3, 64>(a, st);
+    return a.Cout <= 16 ? launch_halo<9, 16>(a, st) : launch_halo<9, 64>(a, st);
+  }
   if (a.Cout <= 16) return launch_conv<128, 16, 4, 1>(a, ws, wsb, st);
   if (a.Cout <= 32) return launch_conv<128, 32, 4, 1>(a, ws, wsb, st);
   if (a.Cout <= 64 || M < 4096) return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);

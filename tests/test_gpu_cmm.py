@@ -54,7 +54,7 @@ def test_conv2d_matches_torch(dev, cin, cout, k, stride, pad, dil, H, W):
 def test_conv2d_bn_fold_segments_residual_and_pixelshuffle(dev):
     from dpmn_amd import ops
     from dpmn_amd.model import packing
-    B, H, W = 2, 8, 32
+    B, H, W = 4, 8, 32   # M = 1024 pixels: exercises the LDS halo-tile kernel with 3 input segments
     xs = [u("s%d" % i, (B, c, H, W)) for i, c in enumerate((64, 32, 32))]
     cin, cout = 128, 64
     w = u("w", (cout, cin, 3, 3)) * 0.05
