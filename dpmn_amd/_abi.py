@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdpmn_hip.so")
+# DPMN_HIP_LIB: alternative build of the same library (A/B kernel experiments from tools/); never a fallback
+LIB_PATH = os.environ.get("DPMN_HIP_LIB") or os.path.join(_HERE, "lib", "libdpmn_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise RuntimeError(
@@ -58,6 +59,7 @@ SIGNATURES = {
     "dpmn_last_error": (C.c_char_p, []),
     "dpmn_linear_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _f, fp]),
     "dpmn_add_linear_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_cat2_linear_f32": (_i, [fp, _i, fp, _i, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_ln_linear_f32": (_i, [fp, fp, fp, _f, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_proj_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, fp]),
     "dpmn_sk_select_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

@@ -38,7 +38,14 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float softplus_t(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // F.softplus threshold 20
-__device__ __forceinline__ float mish_f(float x) { return x * tanhf(softplus_t(x)); }
+// mish(x) = x*tanh(softplus(x)) = x * n/(n+2) with n = e^x (e^x + 2)  (exact identity; one exp, no log/tanh).
+// For x > 20 softplus(x) = x (F.softplus threshold) and tanh(x) = 1 in fp32.
+__device__ __forceinline__ float mish_f(float x) {
+  if (x > 20.0f) return x;
+  const float t = __expf(x);
+  const float n = t * (t + 2.0f);
+  return x * (n / (n + 2.0f));
+}
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // activation codes shared by GEMM / conv epilogues and conv prologues
@@ -56,6 +63,28 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     case ACT_TANH: return tanhf(v);
     case ACT_SIGMOID: return sigmoid_f(v);
     default: return v;
+  }
+}
+
+// 4 values at once with the (wave-uniform) activation switch hoisted out of the per-value loop
+__device__ __forceinline__ void apply_act4(float (&v)[4], int act, float slope) {
+  switch (act) {
+    case ACT_NONE: break;
+    case ACT_GELU:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      break;
+    case ACT_RELU:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+      break;
+    case ACT_MISH:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = mish_f(v[r]);
+      break;
+    default:
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], act, slope);
   }
 }
 

@@ -57,8 +57,7 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, floa
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[r] += v[r]; ssq[r] += v[r] * v[r]; }
   }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], a.epi_act, a.slope);
+  apply_act4(v, a.epi_act, a.slope);
   if (a.out_nchw) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -286,7 +285,9 @@ template <int KS, int BN>
 __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   constexpr int TH = 8, TW = 16, HH = TH + KS - 1, HW_ = TW + KS - 1, NPX = HH * HW_;
   constexpr int NT = BN / 16, T = KS * KS;
-  constexpr bool PREFETCH = (KS <= 3);                   // large halos are staged directly (few chunks, many taps)
+  constexpr bool PREFETCH = false;   // halo staged directly into ONE LDS buffer: 3 blocks per CU hide the staging latency
+                                     // (measured: tatt 3x3 60.6 -> 55.3 us, en2b 118 -> 84 us vs the register-prefetch variant;
+                                     //  weights straight from L1/L2 to registers instead of LDS measured 76 / 146 us: rejected)
   constexpr int HBUF = PREFETCH ? 2 : 1;
   constexpr int HV = PREFETCH ? (NPX * 8 + 255) / 256 : 1;   // halo float4 per thread held in registers
   constexpr int WV = (BN * 8 + 255) / 256;               // weight float4 per thread
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
 template <int KS, int BN>
 int launch_halo(const ConvArgs& a, hipStream_t st) {
   constexpr int NPX = (8 + KS - 1) * (16 + KS - 1);
-  const size_t smem = (size_t)((KS <= 3 ? 2 : 1) * NPX + 2 * BN) * LDK * sizeof(float);
+  const size_t smem = (size_t)(NPX + 2 * BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<KS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -468,7 +469,7 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN);
   const int nk = a.Kp / BK;
   int S = 1;
-  if (ws && tiles < 256 && nk >= 16) {
+  if (ws && tiles < 384 && nk >= 16) {
     S = cdiv(768, tiles);
     if (S > nk / 8) S = nk / 8;
     if (S > 64) S = 64;
@@ -550,9 +551,10 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   }
   if (a.Cout <= 16) return launch_conv<128, 16, 4, 1>(a, ws, wsb, st);
   if (a.Cout <= 32) return launch_conv<128, 32, 4, 1>(a, ws, wsb, st);
-  if (a.Cout <= 64 || M < 4096) return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
-  if (M >= 32768 && a.Cout >= 128) return launch_conv<128, 128, 2, 2>(a, ws, wsb, st);
-  return launch_conv<128, 64, 4, 1>(a, ws, wsb, st);
+  // 128x128 tiles halve the L2->LDS bytes per FLOP of the 64x64 tile (which is L2-bound); small-M convs regain
+  // parallelism through split-K (deep CMM levels: K = 2304..13824)
+  if (a.Cout >= 128 && M >= 128) return launch_conv<128, 128, 2, 2>(a, ws, wsb, st);
+  return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
 }
 
 int dpmn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, dpmn_stream_t stream) {

@@ -38,9 +38,11 @@ struct ProArgs {
   int rows_per_image;  // PRO_SKSEL: L
   int groups;          // PRO_SKSEL: G
   const float* addv;   // PRO_ADD: second (M,K) operand added to x before the GEMM (pos-embed add)
+  const float* x2;     // PRO_CAT2: x = [x (M,k1) | x2 (M,K-k1)] channel concat read in place
+  int k1;
 };
 
-enum { PRO_NONE = 0, PRO_LN = 1, PRO_SKSEL = 2, PRO_ADD = 3 };
+enum { PRO_NONE = 0, PRO_LN = 1, PRO_SKSEL = 2, PRO_ADD = 3, PRO_CAT2 = 4 };
 
 // ---------------------------------------------------------------------------------- epilogue
 // tile (nt, mt): lane holds y[m = m_base + (l&15)][n = n_base + (l>>4)*4 + r]
@@ -73,10 +75,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, i
 #pragma unroll
           for (int r = 0; r < 4; ++r) cs[r] += gelu_erf(v[r]);
         }
-        if (e.act != ACT_NONE) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = apply_act(v[r], e.act, e.slope);
-        }
+        apply_act4(v, e.act, e.slope);
         const size_t off = (size_t)m * ldy + n;
         if (nfull) {
           if (e.res1) { float4 q = *reinterpret_cast<const float4*>(e.res1 + off); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
@@ -146,9 +145,9 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
 
   const int srow = tid >> 3, spart = tid & 7;       // staging: row in tile, eighth of the row
   const int scol = spart * (K / 8);
-  float4 raw[NRAW][VPT];
+  float4 rawA[NRAW][VPT], rawB[NRAW][VPT];   // two tiles in flight: HBM latency under load exceeds one tile of MFMA work
 
-  auto issue = [&](int tile) {
+  auto issue = [&](float4 (&raw)[NRAW][VPT], int tile) {
     const int m = tile * BM + srow;
     const bool ok = m < M;
 #pragma unroll
@@ -158,6 +157,10 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
         for (int g = 0; g < 4; ++g)
           raw[g][v] = (ok && g < p.groups) ? *reinterpret_cast<const float4*>(x + (size_t)m * ldx + g * K + scol + v * 4)
                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+      } else if (PRO == PRO_CAT2) {
+        const int col = scol + v * 4;
+        const float* src = col < p.k1 ? x + (size_t)m * p.k1 + col : p.x2 + (size_t)m * (K - p.k1) + (col - p.k1);
+        raw[0][v] = ok ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
       } else {
         raw[0][v] = ok ? *reinterpret_cast<const float4*>(x + (size_t)m * ldx + scol + v * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         if (PRO == PRO_ADD)
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
       }
     }
   };
-  auto commit = [&](int tile, int buf) {
+  auto commit = [&](float4 (&raw)[NRAW][VPT], int tile, int buf) {
     float* dst = Xs + (size_t)buf * BM * LDK + srow * LDK + scol;
     float vals[VPT * 4];
     if (PRO == PRO_SKSEL) {
@@ -212,43 +215,62 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
 
   const int wm = wave & 1, wn = wave >> 1;
   const int lr = lane & 15, kq = lane >> 4;
+  const int stride = gridDim.x;
   int tile = blockIdx.x;
-  if (tile < tiles) issue(tile);
+  if (tile < tiles) issue(rawA, tile);
+  if (tile + stride < tiles) issue(rawB, tile + stride);
   __syncthreads();                       // Ws / lng visible
-  if (tile < tiles) commit(tile, 0);
+  if (tile < tiles) commit(rawA, tile, 0);
+  if (tile + 2 * stride < tiles) issue(rawA, tile + 2 * stride);
   int buf = 0;
-  for (; tile < tiles; tile += gridDim.x) {
-    __syncthreads();                     // Xs[buf] committed by everyone; previous MFMA reads of Xs[buf^1] done
-    const int next = tile + gridDim.x;
-    if (next < tiles) issue(next);
-    f32x4 acc[3][1];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* xa = Xs + (size_t)buf * BM * LDK + (wm * 16 + lr) * LDK + kq * 4;
-    const float* wa = Ws + (wn * 48 + lr) * LDK + kq * 4;
-#pragma unroll
-    for (int kc = 0; kc < K; kc += 16) {
-      const f32x4 xf = *reinterpret_cast<const f32x4*>(xa + kc);
-      f32x4 wf[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 16 * LDK + kc);
-#pragma unroll
-      for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-        for (int i = 0; i < 3; ++i) acc[i][0] = mfma16(wf[i][s4], xf[s4], acc[i][0]);
-    }
-    epilogue<3, 1>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk);
-    if (e.colsum) {
-      __syncthreads();
-      for (int c = tid; c < BN; c += 256) {
-        const int wn_c = c / 48;
-        const float s = red[(wn_c * 2 + 0) * BN + c] + red[(wn_c * 2 + 1) * BN + c];
-        if (n_blk + c < N) e.colsum[(size_t)tile * N + n_blk + c] = s;
-      }
-    }
-    if (next < tiles) commit(next, buf ^ 1);
-    buf ^= 1;
+  // one pipeline step: MFMA on Xs[buf] (tile), commit tile+stride from RAWN into Xs[buf^1], refill RAWN with tile+3*stride
+// experiment hooks (tools/variants): -DWSTAT_NOMFMA runs one k-chunk only, -DWSTAT_NOEPI skips the epilogue
+#ifdef WSTAT_NOMFMA
+#define WSTAT_KLIM 16
+#else
+#define WSTAT_KLIM K
+#endif
+#ifdef WSTAT_NOEPI
+#define WSTAT_EPI_GUARD if (acc[0][0][0] == 12345.678f)
+#else
+#define WSTAT_EPI_GUARD
+#endif
+#define WSTAT_STEP(RAWN)                                                                                     \
+  {                                                                                                          \
+    __syncthreads(); /* Xs[buf] committed by everyone; previous MFMA reads of Xs[buf^1] done */               \
+    f32x4 acc[3][1];                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};                    \
+    const float* xa = Xs + (size_t)buf * BM * LDK + (wm * 16 + lr) * LDK + kq * 4;                            \
+    const float* wa = Ws + (wn * 48 + lr) * LDK + kq * 4;                                                    \
+    _Pragma("unroll") for (int kc = 0; kc < WSTAT_KLIM; kc += 16) {                                          \
+      const f32x4 xf = *reinterpret_cast<const f32x4*>(xa + kc);                                             \
+      f32x4 wf[3];                                                                                           \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 16 * LDK + kc); \
+      _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                                                       \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i][0] = mfma16(wf[i][s4], xf[s4], acc[i][0]);       \
+    }                                                                                                        \
+    /* commit BEFORE the epilogue's stores: vmcnt retires in order, waiting for loads issued after stores   \
+       would also wait for those stores */                                                                   \
+    if (tile + stride < tiles) commit(RAWN, tile + stride, buf ^ 1);                                         \
+    if (tile + 3 * stride < tiles) issue(RAWN, tile + 3 * stride);                                           \
+    WSTAT_EPI_GUARD epilogue<3, 1>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk); \
+    if (e.colsum) {                                                                                          \
+      __syncthreads();                                                                                       \
+      for (int c = tid; c < BN; c += 256) {                                                                  \
+        const int wn_c = c / 48;                                                                             \
+        const float s_ = red[(wn_c * 2 + 0) * BN + c] + red[(wn_c * 2 + 1) * BN + c];                        \
+        if (n_blk + c < N) e.colsum[(size_t)tile * N + n_blk + c] = s_;                                      \
+      }                                                                                                      \
+    }                                                                                                        \
+    buf ^= 1;                                                                                                \
+    tile += stride;                                                                                          \
   }
+  while (tile < tiles) {
+    WSTAT_STEP(rawB)
+    if (tile >= tiles) break;
+    WSTAT_STEP(rawA)
+  }
+#undef WSTAT_STEP
 }
 
 // ---------------------------------------------------------------------------------- k-loop
@@ -468,6 +490,15 @@ int dpmn_add_linear_f32(const float* x, const float* addv, const float* w, const
   ProArgs p{};
   p.addv = addv;
   return dispatch_wholeK<PRO_ADD>(K, x, K, w, y, N, M, N, p, e, as_stream(stream));
+}
+
+int dpmn_cat2_linear_f32(const float* x1, int k1, const float* x2, int k2, const float* w, const float* bias, float* y,
+                         int M, int N, int act, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x1 && x2 && w && y && M > 0 && N % 4 == 0 && k1 % 4 == 0 && k2 % 4 == 0, "cat2_linear: bad arguments");
+  EpiArgs e{bias, nullptr, nullptr, nullptr, act, 0.f};
+  ProArgs p{};
+  p.x2 = x2; p.k1 = k1;
+  return dispatch_wholeK<PRO_CAT2>(k1 + k2, x1, k1 + k2, w, y, N, M, N, p, e, as_stream(stream));
 }
 
 int dpmn_ln_linear_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* w,

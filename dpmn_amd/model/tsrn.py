@@ -123,11 +123,16 @@ class _PSNBase(nn.Module):
         B, H, W, Cc = x.shape
         r = ops.conv2d([x], *P["srb%d.c1" % i], Cc, 3, pad=1, epi_act="mish")
         r = ops.conv2d([r], *P["srb%d.c2" % i], Cc, 3, pad=1)
+        # GruBlock.conv1 (1x1) is folded into the GRU input projection: one (pixels, Cin) x (Cin, 192) GEMM
         w1, b1, whh1, bhh1 = P["srb%d.g1" % i]
-        gi = ops.conv2d([r] if tp is None else [r, tp], w1, b1, w1.shape[0], 1)
+        M = B * H * W
+        if tp is None:
+            gi = ops.linear(r.reshape(M, Cc), w1, b1)
+        else:
+            gi = ops.cat2_linear(r.reshape(M, Cc), tp.reshape(M, tp.shape[3]), w1, b1)
         s = ops.bigru(gi, whh1, bhh1, B, H, W, "h", res=x)              # x + gru1(...) (vertical pass)
         w2, b2, whh2, bhh2 = P["srb%d.g2" % i]
-        gi = ops.conv2d([s], w2, b2, w2.shape[0], 1)
+        gi = ops.linear(s.reshape(M, Cc), w2, b2)
         return ops.bigru(gi, whh2, bhh2, B, H, W, "w")
 
     def _head(self, x, P):

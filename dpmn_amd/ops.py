@@ -29,6 +29,15 @@ def add_linear(x, addv, w, bias=None, act="none"):
     return y
 
 
+def cat2_linear(x1, x2, w, bias=None, act="none"):
+    M, k1 = x1.shape
+    k2 = x2.shape[1]
+    N = w.shape[0]
+    y = torch.empty(M, N, device=x1.device)
+    check(lib.dpmn_cat2_linear_f32(dptr(x1), k1, dptr(x2), k2, dptr(w), dptr(bias, True), dptr(y), M, N, ACT[act], stream()))
+    return y
+
+
 def ln_linear(x, ln_w, ln_b, w, bias, act="none", eps=1e-5):
     M, K = x.shape
     N = w.shape[0]

@@ -40,6 +40,10 @@ int dpmn_linear_f32(const float* x, const float* w, const float* bias, const flo
 /* y = act((x + addv) . w^T + bias): with_pos_embed + in-projection, transformer_v2.py:462,826-828 */
 int dpmn_add_linear_f32(const float* x, const float* addv, const float* w, const float* bias, float* y, int M,
                         int N, int K, int act, dpmn_stream_t stream);
+/* y = act([x1 | x2] . w^T + bias): 1x1 conv over a channel concat read in place (GruBlock.conv1 folded into the
+ * GRU input projection on cat([residual, text_emb]), tatt.py:902-907, 1078) */
+int dpmn_cat2_linear_f32(const float* x1, int k1, const float* x2, int k2, const float* w, const float* bias, float* y,
+                         int M, int N, int act, dpmn_stream_t stream);
 /* y = act(LayerNorm(x) . w^T + bias): pgrm.py:322-323 + 188/194 (q, kv), pgrm.py:330 + 30-31 (norm2+fc1+GELU) */
 int dpmn_ln_linear_f32(const float* x, const float* ln_w, const float* ln_b, float eps, const float* w,
                        const float* bias, float* y, int M, int N, int K, int act, dpmn_stream_t stream);

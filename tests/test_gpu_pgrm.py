@@ -65,6 +65,14 @@ def test_add_linear(dev):
     assert_close(got, F.linear(x + a, w, b), ATOL, RTOL, "add_linear")
 
 
+def test_cat2_linear(dev):
+    from dpmn_amd import ops
+    x1, x2 = u("x1", (300, 64)), u("x2", (300, 64))
+    w, b = u("w", (192, 128), -0.2, 0.2), u("b", (192,))
+    got = ops.cat2_linear(x1.to(dev), x2.to(dev), w.to(dev), b.to(dev))
+    assert_close(got, F.linear(torch.cat([x1, x2], 1), w, b), ATOL, RTOL, "cat2_linear")
+
+
 def test_pointwise(dev):
     from dpmn_amd import ops
     B, L, Ch = 3, 1024, 384
