@@ -78,6 +78,35 @@ SIGNATURES = {
     "dpmn_blend_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, _f, _i, _i, fp]),
     "dpmn_psnr_ssim_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpmn_psnr_ssim_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_gemm_tn_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_colsum_f32": (_i, [fp, fp, C.c_long, _i, fp]),
+    "dpmn_layernorm_bwd_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp]),
+    "dpmn_layernorm_f32": (_i, [fp, fp, fp, _f, fp, C.c_long, _i, fp]),
+    "dpmn_act_bwd_f32": (_i, [fp, fp, fp, _i, _f, C.c_long, fp]),
+    "dpmn_act_fwd_f32": (_i, [fp, fp, _i, _f, C.c_long, fp]),
+    "dpmn_axpby_f32": (_i, [fp, fp, fp, _f, _f, _i, C.c_long, fp]),
+    "dpmn_rowsum_mod_f32": (_i, [fp, fp, C.c_long, _i, _i, fp]),
+    "dpmn_image_loss_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dpmn_image_loss_fwd_f32": (_i, [fp, C.c_long, fp, C.c_long, _f, _f, _i, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_image_loss_bwd_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, fp, fp, _f, _f, _i, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_window_attn_bwd_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _i, _i, _i, _i, fp]),
+    "dpmn_sk_select_only_f32": (_i, [fp, fp, fp, C.c_long, _i, _i, _i, fp]),
+    "dpmn_sk_select_bwd_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_sk_gate_bwd_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_sk_feats_grad_f32": (_i, [fp, fp, fp, fp, C.c_long, _i, _i, fp]),
+    "dpmn_dwconv3x3_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_dwconv3x3_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_pointwise_wgrad_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_pgrm_tail_elem_f32": (_i, [fp, _PP, _PP, _i, fp, _i, _i, _i, fp]),
+    "dpmn_pgrm_tail_elem_bwd_f32": (_i, [fp, fp, _PP, _PP, _PP, _PP, _i, fp, _i, _i, _i, fp]),
+    "dpmn_patch_embed_bwd_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_patch_scatter_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_prior_fusion_wgrad_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), fp, fp, fp]),
+    "dpmn_bn_finalize_f32": (_i, [fp, fp, fp, _f, _f, _f, fp, fp, fp, fp, fp, fp, _i, fp]),
+    "dpmn_affine_act_bwd_f32": (_i, [fp, fp, fp, fp, _i, fp, _i, C.c_long, _i, fp]),
+    "dpmn_bn_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_long, _i, fp]),
+    "dpmn_se_gate_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

@@ -1,0 +1,349 @@
+// Backward building blocks of the DPMN training step (interfaces/super_resolution.py:140-278; autograd of
+// model/pgrm.py, model/cmm.py, loss/image_loss.py in the reference).
+//   * k_gemm_tn        dW[N][K] += dY[M][N]^T . X[M][K]   -- every nn.Linear weight gradient (reduction over tokens)
+//   * k_colsum         db[N]    += sum_m dY[m][n]
+//   * k_ln_bwd         LayerNorm backward (dx, dgamma, dbeta) from the saved pre-norm input
+//   * k_act_bwd        dpre = dy * act'(pre)  (GELU / ReLU / LeakyReLU / mish)
+//   * k_image_loss_*   ImageLoss = MSE + L1 of gradient-magnitude maps (loss/image_loss.py:15-43), forward + backward
+// Data-gradients of linears / convs reuse the forward GEMM / implicit-GEMM kernels with transposed weights.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- dW += dY^T X
+// MFMA roles: D[n][k] += sum_m A[n][m] B[m][k] with A = dY^T, B = X; both operands are read from [m][.] LDS tiles
+// with ds_read_b32 (row = 4*kq + s of a 16-row chunk, column = l & 15).
+// Block 256 threads: 96 (n) x 96 (k) output tile, waves 2 x 2 -> 48 x 48 each (3 x 3 MFMA tiles); grid.z splits M;
+// partial results are accumulated into dW with fp32 atomics (gradient accumulation semantics: caller zeroes).
+__global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
+                                                  float* __restrict__ dw, int ldw, int M, int N, int K, int rows_per_block) {
+  constexpr int BT = 96, BMc = 32, LD = BT + 4;
+  __shared__ __attribute__((aligned(16))) float Ys[2][BMc * LD];
+  __shared__ __attribute__((aligned(16))) float Xs[2][BMc * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_blk = blockIdx.x * BT, k_blk = blockIdx.y * BT;
+  const int m_lo = blockIdx.z * rows_per_block;
+  const int m_hi = min(M, m_lo + rows_per_block);
+  // loaders: 32 rows x 24 float4 per operand = 768 float4 -> 3 per thread
+  float4 yr[3], xr[3];
+  auto gload = [&](int m0) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int i = tid + p * 256;
+      const int r = i / 24, c = (i % 24) * 4;
+      const int m = m0 + r;
+      yr[p] = (m < m_hi && n_blk + c < N) ? *reinterpret_cast<const float4*>(dy + (size_t)m * ldy + n_blk + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[p] = (m < m_hi && k_blk + c < K) ? *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k_blk + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      const int i = tid + p * 256;
+      const int r = i / 24, c = (i % 24) * 4;
+      *reinterpret_cast<float4*>(&Ys[buf][r * LD + c]) = yr[p];
+      *reinterpret_cast<float4*>(&Xs[buf][r * LD + c]) = xr[p];
+    }
+  };
+  const int wn = wave & 1, wk = wave >> 1;
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (m_lo < m_hi) { gload(m_lo); sstore(0); }
+  __syncthreads();
+  int buf = 0;
+  for (int m0 = m_lo; m0 < m_hi; m0 += BMc) {
+    if (m0 + BMc < m_hi) gload(m0 + BMc);
+#pragma unroll
+    for (int mc = 0; mc < BMc; mc += 16) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int row = mc + kq * 4 + s;
+        float a[3], b[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a[i] = Ys[buf][row * LD + wn * 48 + i * 16 + lr];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) b[j] = Xs[buf][row * LD + wk * 48 + j * 16 + lr];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+      }
+    }
+    if (m0 + BMc < m_hi) sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // lane holds D[n = .. + kq*4 + r][k = .. + lr]
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int k = k_blk + wk * 48 + j * 16 + lr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_blk + wn * 48 + i * 16 + kq * 4 + r;
+        if (n < N && k < K) atomicAdd(dw + (size_t)n * ldw + k, acc[i][j][r]);
+      }
+    }
+}
+
+// db[n] += sum_m dy[m][n]; block = 32 rows-groups x columns
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, int ldy, float* __restrict__ db, long M, int N,
+                                                 int rows_per_block) {
+  const long m_lo = (long)blockIdx.x * rows_per_block;
+  const long m_hi = m_lo + rows_per_block < M ? m_lo + rows_per_block : M;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    float s = 0.f;
+    for (long m = m_lo; m < m_hi; ++m) s += dy[m * ldy + n];
+    atomicAdd(db + n, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------- LayerNorm backward
+// x: pre-norm input (M,C); dy: grad wrt LN output; dx (M,C) written (or accumulated); dgamma/dbeta accumulated.
+template <int C>
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+                                                 const float* __restrict__ gamma, float eps, float* __restrict__ dx,
+                                                 int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long M) {
+  constexpr int PER = C / 32;
+  __shared__ float red_g[8][C], red_b[8][C];
+  const int sub = threadIdx.x >> 5, t = threadIdx.x & 31;   // 8 rows per block pass, 32 threads per row
+  float gam[PER], ag[PER], ab[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { gam[i] = gamma[t + 32 * i]; ag[i] = 0.f; ab[i] = 0.f; }
+  for (long row = (long)blockIdx.x * 8 + sub; row < M; row += (long)gridDim.x * 8) {
+    float xv[PER], dv[PER];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { xv[i] = x[row * C + t + 32 * i]; dv[i] = dy[row * C + t + 32 * i]; s += xv[i]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { const float d = xv[i] - mean; q += d * d; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    float s1 = 0.f, s2 = 0.f;
+    float xh[PER], dg[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      xh[i] = (xv[i] - mean) * rstd;
+      dg[i] = dv[i] * gam[i];
+      s1 += dg[i];
+      s2 += dg[i] * xh[i];
+      ag[i] += dv[i] * xh[i];
+      ab[i] += dv[i];
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+    s1 *= (1.0f / C); s2 *= (1.0f / C);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const float g = rstd * (dg[i] - s1 - xh[i] * s2);
+      const long o = row * C + t + 32 * i;
+      dx[o] = accumulate_dx ? dx[o] + g : g;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { red_g[sub][t + 32 * i] = ag[i]; red_b[sub][t + 32 * i] = ab[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float g = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { g += red_g[r][c]; b += red_b[r][c]; }
+    atomicAdd(dgamma + c, g);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
+// ---------------------------------------------------------------------------------- activation backward
+__device__ __forceinline__ float act_grad(float pre, int act, float slope) {
+  switch (act) {
+    case ACT_GELU: {
+      const float cdf = 0.5f * (1.0f + erf_as(pre * 0.70710678118654752440f));
+      return cdf + pre * 0.3989422804014327f * __expf(-0.5f * pre * pre);
+    }
+    case ACT_RELU: return pre > 0.f ? 1.f : 0.f;
+    case ACT_LEAKY02: return pre > 0.f ? 1.f : 0.2f;
+    case ACT_LEAKY001: return pre > 0.f ? 1.f : 0.01f;
+    case ACT_PRELU: return pre > 0.f ? 1.f : slope;
+    case ACT_MISH: {
+      const float sp = softplus_t(pre), th = tanhf(sp);
+      return th + pre * (1.f - th * th) * sigmoid_f(pre);
+    }
+    case ACT_TANH: { const float th = tanhf(pre); return 1.f - th * th; }
+    case ACT_SIGMOID: { const float sg = sigmoid_f(pre); return sg * (1.f - sg); }
+    default: return 1.f;
+  }
+}
+__global__ void k_act_bwd(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dpre, int act,
+                          float slope, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 d = reinterpret_cast<const float4*>(dy)[i];
+  const float4 p = reinterpret_cast<const float4*>(pre)[i];
+  reinterpret_cast<float4*>(dpre)[i] = make_float4(d.x * act_grad(p.x, act, slope), d.y * act_grad(p.y, act, slope),
+                                                   d.z * act_grad(p.z, act, slope), d.w * act_grad(p.w, act, slope));
+}
+
+// ---------------------------------------------------------------------------------- ImageLoss
+// out/tgt: NCHW with per-image strides (tgt may be a (B,4,H,W) tensor read as its first C channels).
+// part[2*blk] = sum (o-t)^2 , part[2*blk+1] = sum |G(o)-G(t)| over channels < 3; optional U,V planes for backward.
+__device__ __forceinline__ float at(const float* p, int y, int x, int H, int W) {
+  return (y >= 0 && y < H && x >= 0 && x < W) ? p[y * W + x] : 0.f;
+}
+__global__ __launch_bounds__(256) void k_image_loss_fwd(const float* __restrict__ o, long o_stride, const float* __restrict__ t,
+                                                         long t_stride, float* __restrict__ part, float* __restrict__ U,
+                                                         float* __restrict__ V, int C, int H, int W, long total) {
+  __shared__ float red[2][4];
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float se = 0.f, l1 = 0.f;
+  if (idx < total) {
+    const int x = idx % W, y = (idx / W) % H, c = (idx / ((long)W * H)) % C;
+    const long n = idx / ((long)W * H * C);
+    const float* op = o + n * o_stride + (size_t)c * H * W;
+    const float* tp = t + n * t_stride + (size_t)c * H * W;
+    const float d = op[y * W + x] - tp[y * W + x];
+    se = d * d;
+    if (c < 3) {
+      const float gxo = (at(op, y, x + 1, H, W) - at(op, y, x - 1, H, W)) * 0.5f;
+      const float gyo = (at(op, y - 1, x, H, W) - at(op, y + 1, x, H, W)) * 0.5f;
+      const float gxt = (at(tp, y, x + 1, H, W) - at(tp, y, x - 1, H, W)) * 0.5f;
+      const float gyt = (at(tp, y - 1, x, H, W) - at(tp, y + 1, x, H, W)) * 0.5f;
+      const float Go = sqrtf(gxo * gxo + gyo * gyo + 1e-6f), Gt = sqrtf(gxt * gxt + gyt * gyt + 1e-6f);
+      const float df = Go - Gt;
+      l1 = fabsf(df);
+      if (U) {
+        const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        const long u = (n * 3 + c) * (long)H * W + y * W + x;
+        U[u] = sgn * gxo / (2.f * Go);
+        V[u] = sgn * gyo / (2.f * Go);
+      }
+    }
+  }
+  se = wave_sum(se); l1 = wave_sum(l1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = se; red[1][threadIdx.x >> 6] = l1; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    part[2 * blockIdx.x + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+__global__ void k_image_loss_final(const float* __restrict__ part, int nblocks, float w_mse, float inv_n_mse, float w_grad,
+                                   float inv_n_grad, float* __restrict__ loss) {
+  double se = 0.0, l1 = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 64) { se += part[2 * i]; l1 += part[2 * i + 1]; }
+  for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); l1 += __shfl_xor(l1, o, 64); }
+  if (threadIdx.x == 0) loss[0] = (float)(w_mse * se * inv_n_mse + w_grad * l1 * inv_n_grad);
+}
+// grad_out = gscale * ( w_mse*2(o-t)/N + w_grad/N3 * (U[x-1] - U[x+1] + V[y+1] - V[y-1]) )   (c < 3 for the second term)
+__global__ void k_image_loss_bwd(const float* __restrict__ o, long o_stride, const float* __restrict__ t, long t_stride,
+                                 const float* __restrict__ U, const float* __restrict__ V, const float* __restrict__ gscale,
+                                 float c_mse, float c_grad, float* __restrict__ grad, int accumulate, int C, int H, int W,
+                                 long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int x = idx % W, y = (idx / W) % H, c = (idx / ((long)W * H)) % C;
+  const long n = idx / ((long)W * H * C);
+  const float gs = gscale[0];
+  float g = c_mse * (o[n * o_stride + (size_t)c * H * W + y * W + x] - t[n * t_stride + (size_t)c * H * W + y * W + x]);
+  if (c < 3 && U) {
+    const float* up = U + (n * 3 + c) * (long)H * W;
+    const float* vp = V + (n * 3 + c) * (long)H * W;
+    g += c_grad * (at(up, y, x - 1, H, W) - at(up, y, x + 1, H, W) + at(vp, y + 1, x, H, W) - at(vp, y - 1, x, H, W));
+  }
+  g *= gs;
+  grad[idx] = accumulate ? grad[idx] + g : g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, int M, int N, int K, dpmn_stream_t stream) {
+  DPMN_REQUIRE(dy && x && dw && M > 0 && N % 4 == 0 && K % 4 == 0, "gemm_tn: bad arguments (N, K multiples of 4)");
+  const int tiles = cdiv(N, 96) * cdiv(K, 96);
+  int splits = cdiv(1024, tiles);
+  int rows = cdiv(cdiv(M, splits), 32) * 32;
+  if (rows < 32) rows = 32;
+  splits = cdiv(M, rows);
+  dim3 grid(cdiv(N, 96), cdiv(K, 96), splits);
+  hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, as_stream(stream), dy, N, x, K, dw, K, M, N, K, rows);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream) {
+  DPMN_REQUIRE(dy && db && M > 0 && N > 0, "colsum: bad arguments");
+  const int rows = 128;
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, as_stream(stream), dy, N, db, M, N, rows);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
+                           float* dgamma, float* dbeta, long M, int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && M > 0, "layernorm_bwd: bad arguments");
+  const unsigned blocks = (unsigned)(M / 8 < 1024 ? (M + 7) / 8 : 1024);
+  if (C == 96)
+    hipLaunchKernelGGL((k_ln_bwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
+  else if (C == 192)
+    hipLaunchKernelGGL((k_ln_bwd<192>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
+  else if (C == 64)
+    hipLaunchKernelGGL((k_ln_bwd<64>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
+  else
+    return dpmn_set_error(DPMN_ERR_ARG, "layernorm_bwd: C must be 64, 96 or 192");
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_act_bwd_f32(const float* dy, const float* pre, float* dpre, int act, float slope, long n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(dy && pre && dpre && n > 0 && n % 4 == 0, "act_bwd: bad arguments (n multiple of 4)");
+  const long n4 = n / 4;
+  hipLaunchKernelGGL(k_act_bwd, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, as_stream(stream), dy, pre, dpre, act, slope, n4);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+size_t dpmn_image_loss_workspace_bytes(int B, int C, int H, int W) {
+  const long total = (long)B * C * H * W;
+  return (size_t)((total + 255) / 256) * 2 * sizeof(float);
+}
+
+int dpmn_image_loss_fwd_f32(const float* out, long out_stride, const float* tgt, long tgt_stride, float w_mse, float w_grad,
+                            int gradient, float* loss, float* U, float* V, void* workspace, int B, int C, int H, int W,
+                            dpmn_stream_t stream) {
+  DPMN_REQUIRE(out && tgt && loss && workspace && B > 0 && C >= 1, "image_loss_fwd: bad arguments");
+  const long total = (long)B * C * H * W;
+  const int nb = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(k_image_loss_fwd, dim3(nb), dim3(256), 0, as_stream(stream), out, out_stride, tgt, tgt_stride,
+                     static_cast<float*>(workspace), gradient ? U : nullptr, gradient ? V : nullptr, C, H, W, total);
+  DPMN_CHECK_LAUNCH();
+  const int c3 = C < 3 ? C : 3;
+  hipLaunchKernelGGL(k_image_loss_final, dim3(1), dim3(64), 0, as_stream(stream), static_cast<const float*>(workspace), nb, w_mse,
+                     1.0f / (float)total, gradient ? w_grad : 0.f, 1.0f / (float)((long)B * c3 * H * W), loss);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_image_loss_bwd_f32(const float* out, long out_stride, const float* tgt, long tgt_stride, const float* U,
+                            const float* V, const float* grad_scale, float w_mse, float w_grad, int gradient, float* grad_out,
+                            int accumulate, int B, int C, int H, int W, dpmn_stream_t stream) {
+  DPMN_REQUIRE(out && tgt && grad_scale && grad_out && B > 0, "image_loss_bwd: bad arguments");
+  DPMN_REQUIRE(!gradient || (U && V), "image_loss_bwd: U/V planes from the forward pass are required");
+  const long total = (long)B * C * H * W;
+  const int c3 = C < 3 ? C : 3;
+  hipLaunchKernelGGL(k_image_loss_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), out, out_stride,
+                     tgt, tgt_stride, gradient ? U : nullptr, gradient ? V : nullptr, grad_scale, w_mse * 2.0f / (float)total,
+                     gradient ? w_grad / (float)((long)B * c3 * H * W) : 0.f, grad_out, accumulate, C, H, W, total);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+}  // extern "C"

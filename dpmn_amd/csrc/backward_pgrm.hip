@@ -1,0 +1,738 @@
+// PGRM-specific backward kernels (autograd of model/pgrm.py in the reference): window attention, SKConv gate,
+// depthwise conv, elementwise helpers.  Linear / conv data- and weight-gradients use gemm.hip / conv*.hip / backward.hip.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------- window attention backward
+// Same slab decomposition as k_window_attn (pgrm.hip): block = 2 slabs x 2 heads, one wave per (slab, head).
+// Pass 1 (lane = query row): recompute the softmax statistics (max, 1/sum), O = P.V, delta = dO.O, and dQ.
+// Pass 2 (lane = key row):  dK, dV and the relative-position-bias table gradient (LDS atomics, then global atomics).
+// All gathers/scatters use the forward's roll + window-major token map (quirk Q1); every token belongs to exactly
+// one window per group, so dq / dkv are plain stores.
+template <int WS, int D>
+__global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict__ q, const float* __restrict__ kv,
+                                                          const float* __restrict__ bias_table, const float* __restrict__ dout,
+                                                          float* __restrict__ dq, float* __restrict__ dkv,
+                                                          float* __restrict__ dtable, int B, int H, int W, int C, int g, int shift) {
+  constexpr int N = WS * WS, CG = 2 * D, ROWS = 64, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
+  static_assert(N <= 64, "windows larger than 64 tokens are not built yet");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tbl = smem;                                 // [TBL*2]
+  float* dtb = smem + ((TBL * 2 + 3) & ~3);          // [TBL*2] gradient accumulator
+  float* base = dtb + ((TBL * 2 + 3) & ~3);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slab_in_blk = wave >> 1, head = wave & 1;
+  float* Qs = base + slab_in_blk * (4 * ROWS * LDR + 6 * ROWS);
+  float* Ks = Qs + ROWS * LDR;
+  float* Vs = Ks + ROWS * LDR;
+  float* Gs = Vs + ROWS * LDR;                       // dO rows
+  float* stat = Gs + ROWS * LDR;                     // [2 heads][3][ROWS]: max, 1/sum, delta
+  int* reg_s = reinterpret_cast<int*>(base + 2 * (4 * ROWS * LDR + 6 * ROWS)) + slab_in_blk * ROWS;
+
+  const int L = H * W, slabs_per_img = L / ROWS;
+  const long slab = (long)blockIdx.x * 2 + slab_in_blk;
+  const int b = slab / slabs_per_img;
+  const int t0 = (slab % slabs_per_img) * ROWS;
+  const int nWc = W / WS;
+  const bool active = b < B;
+  for (int i = threadIdx.x; i < TBL * 2; i += 256) { tbl[i] = bias_table[i]; dtb[i] = 0.f; }
+  size_t src_tok = 0;
+  if (active) {
+    const int tl = threadIdx.x & 127;
+    constexpr int V4 = CG / 4;
+    for (int i = tl; i < ROWS * V4; i += 128) {
+      const int r = i / V4, c4 = (i % V4) * 4;
+      const int t = t0 + r, win = t / N, n = t % N;
+      const int hr = (win / nWc) * WS + n / WS, wcol = (win % nWc) * WS + n % WS;
+      const size_t src = (size_t)b * L + ((hr + shift) % H) * W + (wcol + shift) % W;
+      *reinterpret_cast<float4*>(Qs + r * LDR + c4) = *reinterpret_cast<const float4*>(q + src * C + g * CG + c4);
+      *reinterpret_cast<float4*>(Ks + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + src * 2 * C + g * CG + c4);
+      *reinterpret_cast<float4*>(Vs + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + src * 2 * C + C + g * CG + c4);
+      *reinterpret_cast<float4*>(Gs + r * LDR + c4) = *reinterpret_cast<const float4*>(dout + ((size_t)b * L + t) * C + g * CG + c4);
+      if (c4 == 0) {
+        const int rh = hr < H - WS ? 0 : (hr < H - shift ? 1 : 2), rw = wcol < W - WS ? 0 : (wcol < W - shift ? 1 : 2);
+        reg_s[r] = 3 * rh + rw;
+      }
+    }
+    const int t = t0 + lane, win = t / N, n = t % N;
+    const int hr = (win / nWc) * WS + n / WS, wcol = (win % nWc) * WS + n % WS;
+    src_tok = (size_t)b * L + ((hr + shift) % H) * W + (wcol + shift) % W;
+  }
+  __syncthreads();
+  const float scale = 1.0f / sqrtf((float)D);
+  const int nl = (t0 + lane) % N;                       // row index inside its window
+  const int krow0 = (lane / N) * N;
+  const int il = nl / WS, jl = nl % WS;
+  const int my_reg = active ? reg_s[lane] : 0;
+  float* smax = stat + head * 3 * ROWS, *sinv = smax + ROWS, *sdel = sinv + ROWS;
+
+  if (active) {
+    // ---------------- pass 1: lane = query
+    float qv[D], go[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { qv[d] = Qs[lane * LDR + head * D + d] * scale; go[d] = Gs[lane * LDR + head * D + d]; }
+    float mx = -INFINITY;
+    for (int m = 0; m < N; ++m) {
+      const float* kr = Ks + (krow0 + m) * LDR + head * D;
+      float a = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) a += qv[d] * kr[d];
+      a += tbl[((il - m / WS + WS - 1) * (2 * WS - 1) + (jl - m % WS + WS - 1)) * 2 + head];
+      if (shift > 0 && reg_s[krow0 + m] != my_reg) a += -100.0f;
+      mx = fmaxf(mx, a);
+    }
+    float den = 0.f, dlt = 0.f;
+    for (int m = 0; m < N; ++m) {
+      const float* kr = Ks + (krow0 + m) * LDR + head * D;
+      const float* vr = Vs + (krow0 + m) * LDR + head * D;
+      float a = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { a += qv[d] * kr[d]; dp += go[d] * vr[d]; }
+      a += tbl[((il - m / WS + WS - 1) * (2 * WS - 1) + (jl - m % WS + WS - 1)) * 2 + head];
+      if (shift > 0 && reg_s[krow0 + m] != my_reg) a += -100.0f;
+      const float p = expf(a - mx);
+      den += p;
+      dlt += p * dp;                                    // sum_m P dP = dO . O
+    }
+    const float inv = 1.0f / den;
+    dlt *= inv;
+    smax[lane] = mx; sinv[lane] = inv; sdel[lane] = dlt;
+    float dqa[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) dqa[d] = 0.f;
+    for (int m = 0; m < N; ++m) {
+      const float* kr = Ks + (krow0 + m) * LDR + head * D;
+      const float* vr = Vs + (krow0 + m) * LDR + head * D;
+      float a = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { a += qv[d] * kr[d]; dp += go[d] * vr[d]; }
+      a += tbl[((il - m / WS + WS - 1) * (2 * WS - 1) + (jl - m % WS + WS - 1)) * 2 + head];
+      if (shift > 0 && reg_s[krow0 + m] != my_reg) a += -100.0f;
+      const float ds = expf(a - mx) * inv * (dp - dlt);
+#pragma unroll
+      for (int d = 0; d < D; ++d) dqa[d] += ds * kr[d];
+    }
+    float* dst = dq + src_tok * C + g * CG + head * D;
+#pragma unroll
+    for (int d = 0; d < D; d += 4)
+      *reinterpret_cast<float4*>(dst + d) = make_float4(dqa[d] * scale, dqa[d + 1] * scale, dqa[d + 2] * scale, dqa[d + 3] * scale);
+  }
+  __syncthreads();
+  if (active) {
+    // ---------------- pass 2: lane = key
+    float kvv[D], vv[D], dk[D], dv[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { kvv[d] = Ks[lane * LDR + head * D + d]; vv[d] = Vs[lane * LDR + head * D + d]; dk[d] = 0.f; dv[d] = 0.f; }
+    for (int n = 0; n < N; ++n) {
+      const float* qr = Qs + (krow0 + n) * LDR + head * D;
+      const float* gr = Gs + (krow0 + n) * LDR + head * D;
+      float a = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) { a += qr[d] * kvv[d]; dp += gr[d] * vv[d]; }
+      a *= scale;
+      const int tix = ((n / WS - il + WS - 1) * (2 * WS - 1) + (n % WS - jl + WS - 1)) * 2 + head;
+      a += tbl[tix];
+      if (shift > 0 && reg_s[krow0 + n] != my_reg) a += -100.0f;
+      const float p = expf(a - smax[krow0 + n]) * sinv[krow0 + n];
+      const float ds = p * (dp - sdel[krow0 + n]);
+#pragma unroll
+      for (int d = 0; d < D; ++d) { dv[d] += p * gr[d]; dk[d] += ds * scale * qr[d]; }
+      atomicAdd(dtb + tix, ds);
+    }
+    float* dkp = dkv + src_tok * 2 * C + g * CG + head * D;
+    float* dvp = dkp + C;
+#pragma unroll
+    for (int d = 0; d < D; d += 4) {
+      *reinterpret_cast<float4*>(dkp + d) = make_float4(dk[d], dk[d + 1], dk[d + 2], dk[d + 3]);
+      *reinterpret_cast<float4*>(dvp + d) = make_float4(dv[d], dv[d + 1], dv[d + 2], dv[d + 3]);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < TBL * 2; i += 256) atomicAdd(dtable + i, dtb[i]);
+}
+
+template <int WS, int D>
+int launch_wattn_bwd(const float* q, const float* kv, const float* tbl, const float* dout, float* dq, float* dkv, float* dtable,
+                     int B, int H, int W, int C, int g, int shift, hipStream_t st) {
+  constexpr int CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
+  const size_t smem = (size_t)(2 * ((TBL * 2 + 3) & ~3) + 2 * (4 * 64 * LDR + 6 * 64)) * 4 + 2 * 64 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn_bwd<WS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const long slabs = (long)B * (H * W / 64);
+  hipLaunchKernelGGL((k_window_attn_bwd<WS, D>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, tbl, dout, dq, dkv,
+                     dtable, B, H, W, C, g, shift);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// ---------------------------------------------------------------------------------- SKConv backward pieces
+// V[m][c] = sum_g A[b][g][c] * cat[m][g*cg + c]
+__global__ void k_sk_select(const float* __restrict__ cat, const float* __restrict__ A, float* __restrict__ V, long M, int L,
+                            int C, int G) {
+  const int cg = C / G;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * cg) return;
+  const long m = idx / cg;
+  const int c = idx % cg, b = m / L;
+  float v = 0.f;
+  for (int g = 0; g < G; ++g) v += A[((size_t)b * G + g) * cg + c] * cat[m * C + g * cg + c];
+  V[idx] = v;
+}
+// dcat[m][g*cg+c] (+)= A[b][g][c] * dV[m][c] ; dA[b][g][c] += sum over the block's tokens of cat * dV
+__global__ __launch_bounds__(256) void k_sk_select_bwd(const float* __restrict__ cat, const float* __restrict__ A,
+                                                        const float* __restrict__ dV, float* __restrict__ dcat,
+                                                        float* __restrict__ dA, int L, int C, int G, int rows_per_block) {
+  const int cg = C / G;
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  for (int col = threadIdx.x; col < C; col += blockDim.x) {
+    const int g = col / cg, c = col % cg;
+    const float a = A[((size_t)b * G + g) * cg + c];
+    float acc = 0.f;
+    for (int r = r0; r < r0 + rows_per_block && r < L; ++r) {
+      const size_t m = (size_t)b * L + r;
+      const float dv = dV[m * cg + c];
+      acc += cat[m * C + col] * dv;
+      dcat[m * C + col] += a * dv;
+    }
+    atomicAdd(dA + ((size_t)b * G + g) * cg + c, acc);
+  }
+}
+// one workgroup per image: gate MLP backward (pgrm.py:86-91).  S = mean_t GELU(feats) from the forward partials.
+__global__ void k_sk_gate_bwd(const float* __restrict__ partial, int parts_per_image, int L, const float* __restrict__ fc1_w,
+                              const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, const float* __restrict__ A,
+                              const float* __restrict__ dA, float* __restrict__ dS, float* __restrict__ dfc1_w,
+                              float* __restrict__ dfc1_b, float* __restrict__ dfc2_w, float* __restrict__ dfc2_b, int C, int G,
+                              int dmid) {
+  extern __shared__ float sm[];
+  float* S = sm;             // [C]
+  float* zp = S + C;         // [dmid] pre-GELU
+  float* Z = zp + dmid;      // [dmid]
+  float* dl = Z + dmid;      // [C] dlogit
+  float* dz = dl + C;        // [dmid] grad wrt pre-GELU
+  const int b = blockIdx.x, cg = C / G;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int p = 0; p < parts_per_image; ++p) s += partial[((size_t)b * parts_per_image + p) * C + c];
+    S[c] = s / (float)L;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < dmid; j += blockDim.x) {
+    float a = fc1_b[j];
+    for (int c = 0; c < C; ++c) a += fc1_w[j * C + c] * S[c];
+    zp[j] = a;
+    Z[j] = gelu_erf(a);
+  }
+  for (int c = threadIdx.x; c < cg; c += blockDim.x) {
+    float dot = 0.f;
+    for (int g = 0; g < G; ++g) dot += A[((size_t)b * G + g) * cg + c] * dA[((size_t)b * G + g) * cg + c];
+    for (int g = 0; g < G; ++g) {
+      const float a = A[((size_t)b * G + g) * cg + c];
+      dl[g * cg + c] = a * (dA[((size_t)b * G + g) * cg + c] - dot);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * dmid; i += blockDim.x) atomicAdd(dfc2_w + i, dl[i / dmid] * Z[i % dmid]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(dfc2_b + c, dl[c]);
+  for (int j = threadIdx.x; j < dmid; j += blockDim.x) {
+    float a = 0.f;
+    for (int c = 0; c < C; ++c) a += dl[c] * fc2_w[c * dmid + j];
+    const float x = zp[j];
+    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
+    dz[j] = a * (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < dmid * C; i += blockDim.x) atomicAdd(dfc1_w + i, dz[i / C] * S[i % C]);
+  for (int j = threadIdx.x; j < dmid; j += blockDim.x) atomicAdd(dfc1_b + j, dz[j]);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float a = 0.f;
+    for (int j = 0; j < dmid; ++j) a += dz[j] * fc1_w[j * C + c];
+    dS[(size_t)b * C + c] = a;
+  }
+}
+// dfeats[m][c] = dout[m][c] + gelu'(feats[m][c]) * dS[b][c] / L
+__global__ void k_sk_feats_grad(const float* __restrict__ dout, const float* __restrict__ feats, const float* __restrict__ dS,
+                                float* __restrict__ dfeats, long M, int L, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * C) return;
+  const long m = idx / C;
+  const int c = idx % C, b = m / L;
+  const float x = feats[idx];
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
+  dfeats[idx] = dout[idx] + (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x)) * dS[(size_t)b * C + c] / (float)L;
+}
+
+// ---------------------------------------------------------------------------------- depthwise 3x3 backward
+// per plane (b, c'): dP = full-correlation of dg with the kernel, dW[c'] += sum dg * shifted P, db[c'] += sum dg
+__global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P, const float* __restrict__ dg,
+                                                     const float* __restrict__ w, float* __restrict__ dP, float* __restrict__ dw,
+                                                     float* __restrict__ db, int Ch, int r, long planes) {
+  extern __shared__ float sm[];   // per wave: P tile and dg tile with 1-pixel halo
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long plane = (long)blockIdx.x * 4 + wave;
+  const bool valid = plane < planes;
+  const int c = valid ? (int)(plane % Ch) : 0;
+  const int LD = r + 2;
+  float* tp = sm + wave * 2 * LD * LD;
+  float* tg = tp + LD * LD;
+  if (valid) {
+    const float* ps = P + plane * r * r;
+    const float* gs = dg + plane * r * r;
+    for (int i = lane; i < LD * LD; i += 64) {
+      const int yy = i / LD - 1, xx = i % LD - 1;
+      const bool in = yy >= 0 && yy < r && xx >= 0 && xx < r;
+      tp[i] = in ? ps[yy * r + xx] : 0.f;
+      tg[i] = in ? gs[yy * r + xx] : 0.f;
+    }
+  }
+  __syncthreads();
+  if (!valid) return;
+  float k[9], aw[9], ab = 0.f;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { k[i] = w[c * 9 + i]; aw[i] = 0.f; }
+  float* dst = dP + plane * r * r;
+  for (int i = lane; i < r * r; i += 64) {
+    const int yy = i / r, xx = i % r;
+    const float* pg = tg + yy * LD + xx;     // dg halo window centred at (yy, xx): pg[(dy)*LD + dx], dy,dx in 0..2
+    const float* pp = tp + yy * LD + xx;
+    float a = 0.f;
+    const float gc = pg[LD + 1];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        a += k[ky * 3 + kx] * pg[(2 - ky) * LD + (2 - kx)];   // dP[y][x] = sum dg[y-ky+1][x-kx+1] w[ky][kx]
+        aw[ky * 3 + kx] += gc * pp[ky * LD + kx];              // dW[ky][kx] += dg[y][x] P[y+ky-1][x+kx-1]
+      }
+    ab += gc;
+    dst[i] = a;
+  }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { const float s = wave_sum(aw[i]); if (lane == 0) atomicAdd(dw + c * 9 + i, s); }
+  ab = wave_sum(ab);
+  if (lane == 0) atomicAdd(db + c, ab);
+}
+
+// ---------------------------------------------------------------------------------- small elementwise helpers
+__global__ void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, int act, float slope, long n4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 p = reinterpret_cast<const float4*>(x)[i];
+  float v[4] = {p.x, p.y, p.z, p.w};
+  apply_act4(v, act, slope);
+  reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+// y = LayerNorm(x) (E = C), one row per 32 threads
+template <int C>
+__global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                 const float* __restrict__ beta, float eps, float* __restrict__ y, long M) {
+  constexpr int PER = C / 32;
+  const long row = (long)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int t = threadIdx.x & 31;
+  if (row >= M) return;
+  float xv[PER], s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { xv[i] = x[row * C + t + 32 * i]; s += xv[i]; }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { const float d = xv[i] - mean; q += d * d; }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
+#pragma unroll
+  for (int i = 0; i < PER; ++i) y[row * C + t + 32 * i] = (xv[i] - mean) * rstd * gamma[t + 32 * i] + beta[t + 32 * i];
+}
+// y (+)= a*x (+ b*z)
+__global__ void k_axpby(const float* __restrict__ x, const float* __restrict__ z, float* __restrict__ y, float a, float b,
+                        int accumulate, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = a * x[i] + (z ? b * z[i] : 0.f);
+  y[i] = accumulate ? y[i] + v : v;
+}
+// rowsum: out[r] += sum_c x[r*cols + c]  (bias gradient of the pointwise conv over the raw (B*Ch, L) view folded per channel)
+__global__ __launch_bounds__(256) void k_rowsum_mod(const float* __restrict__ x, float* __restrict__ out, long rows, int cols,
+                                                     int mod) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  float s = 0.f;
+  for (int c = lane; c < cols; c += 64) s += x[row * cols + c];
+  s = wave_sum(s);
+  if (lane == 0) atomicAdd(out + row % mod, s);
+}
+
+// ---------------------------------------------------------------------------------- PGRM tail (training variant)
+// out[b,c,Y,X] = lrelu(c1[b, Y/2, X/2, 4c + 2(Y%2) + X%2]) * wl0[c,Y,X] + sum_i res_i[b,c,Y,X] * wl_i[c,Y,X]   (pgrm.py:560-565)
+struct TailElem {
+  const float* res[8];
+  const float* wl[8];
+  float* dres[8];
+  float* dwl[8];
+  int n;
+};
+__global__ void k_tail_elem_fwd(const float* __restrict__ c1, const float* __restrict__ wl0, TailElem t, float* __restrict__ out,
+                                int B, int H, int W) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Ho = 2 * H, Wo = 2 * W;
+  if (idx >= (long)B * 3 * Ho * Wo) return;
+  const int X = idx % Wo, Y = (idx / Wo) % Ho, c = (idx / ((long)Wo * Ho)) % 3, b = idx / ((long)Wo * Ho * 3);
+  const long pos = ((long)c * Ho + Y) * Wo + X;
+  float v = c1[(((size_t)b * H + Y / 2) * W + X / 2) * 12 + 4 * c + 2 * (Y & 1) + (X & 1)];
+  v = (v > 0.f ? v : 0.01f * v) * wl0[pos];
+  for (int i = 0; i < t.n; ++i) v += t.res[i][idx] * t.wl[i][pos];
+  out[idx] = v;
+}
+// thread = one (c,Y,X) position, loops over the batch: no atomics for the weight_list gradients
+__global__ void k_tail_elem_bwd(const float* __restrict__ dout, const float* __restrict__ c1, const float* __restrict__ wl0,
+                                TailElem t, float* __restrict__ dc1, float* __restrict__ dwl0, int B, int H, int W) {
+  const long pos = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Ho = 2 * H, Wo = 2 * W;
+  if (pos >= (long)3 * Ho * Wo) return;
+  const int X = pos % Wo, Y = (pos / Wo) % Ho, c = pos / ((long)Wo * Ho);
+  const int ch = 4 * c + 2 * (Y & 1) + (X & 1);
+  const float w0 = wl0[pos];
+  float a0 = 0.f, ai[8];
+  float wli[8];
+  for (int i = 0; i < t.n; ++i) { ai[i] = 0.f; wli[i] = t.wl[i][pos]; }
+  for (int b = 0; b < B; ++b) {
+    const long idx = (long)b * 3 * Ho * Wo + pos;
+    const float g = dout[idx];
+    const size_t ci = (((size_t)b * H + Y / 2) * W + X / 2) * 12 + ch;
+    const float pre = c1[ci];
+    a0 += g * (pre > 0.f ? pre : 0.01f * pre);
+    dc1[ci] = g * w0 * (pre > 0.f ? 1.f : 0.01f);
+    for (int i = 0; i < t.n; ++i) {
+      ai[i] += g * t.res[i][idx];
+      if (t.dres[i]) t.dres[i][idx] += g * wli[i];
+    }
+  }
+  dwl0[pos] += a0;
+  for (int i = 0; i < t.n; ++i) t.dwl[i][pos] += ai[i];
+}
+
+// ---------------------------------------------------------------------------------- patch embed backward
+// Recomputes the embedding (optionally through prior_fusion) per token, applies the LayerNorm backward and emits
+//   dconv (M, C)   gradient wrt the conv output (for dW = dconv^T . patches, db = colsum(dconv))
+//   patches (M, 16) the 12 (fused) input values of the token, zero padded
+// dgamma / dbeta are accumulated with atomics.
+template <int C, bool FUSE>
+__global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict__ img, int cin, const float* __restrict__ pf_w,
+                                                          const float* __restrict__ pf_b, const float* __restrict__ pe_w,
+                                                          const float* __restrict__ pe_b, const float* __restrict__ ln_w,
+                                                          const float* __restrict__ dtok, float* __restrict__ dconv,
+                                                          float* __restrict__ patches, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, int B, int Hi, int Wi) {
+  constexpr int CQ = C / 4, KP = 12;
+  __shared__ float wt[KP * C];
+  __shared__ float pfw[57];
+  __shared__ float rg[C], rb[C];
+  for (int i = threadIdx.x; i < KP * C; i += 256) wt[(i % KP) * C + i / KP] = pe_w[i];
+  if (FUSE && threadIdx.x < 57) pfw[threadIdx.x] = threadIdx.x < 54 ? pf_w[threadIdx.x] : pf_b[threadIdx.x - 54];
+  for (int i = threadIdx.x; i < C; i += 256) { rg[i] = 0.f; rb[i] = 0.f; }
+  __syncthreads();
+  const int Ht = Hi / 2, Wt = Wi / 2;
+  const int lane = threadIdx.x & 63;
+  long token = (long)blockIdx.x * 64 + (threadIdx.x >> 6) * 16 + (lane >> 2);
+  const long ntok = (long)B * Ht * Wt;
+  const bool valid = token < ntok;
+  if (!valid) token = ntok - 1;
+  const int part = lane & 3;
+  const int b = token / (Ht * Wt), t = token % (Ht * Wt);
+  const int th = t / Wt, tw = t % Wt;
+  float in[KP];
+  if (FUSE) {
+    const int dy = part >> 1, dx = part & 1;
+    const int y = th * 2 + dy, x = tw * 2 + dx;
+    float a[3] = {pfw[54], pfw[55], pfw[56]};
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int yy = y + ky - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int xx = x + kx - 1;
+          const bool inb = yy >= 0 && yy < Hi && xx >= 0 && xx < Wi;
+          const float v = inb ? img[(((size_t)b * 2 + ci) * Hi + yy) * Wi + xx] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) a[c] += pfw[((c * 2 + ci) * 3 + ky) * 3 + kx] * v;
+        }
+      }
+    const int base = lane & ~3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int pix = 0; pix < 4; ++pix) in[c * 4 + pix] = __shfl(a[c], base + pix, 64);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) in[(c * 2 + dy) * 2 + dx] = img[(((size_t)b * cin + c) * Hi + th * 2 + dy) * Wi + tw * 2 + dx];
+  }
+  float o[CQ], s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int c = part * CQ + i;
+    float a = pe_b[c];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) a += wt[k * C + c] * in[k];
+    o[i] = a;
+    s += a;
+  }
+  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+  const float mean = s * (1.0f / C);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) { const float d = o[i] - mean; q += d * d; }
+  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+  const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+  float dg[CQ], xh[CQ], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int c = part * CQ + i;
+    const float d = valid ? dtok[(size_t)token * C + c] : 0.f;
+    xh[i] = (o[i] - mean) * rstd;
+    dg[i] = d * ln_w[c];
+    s1 += dg[i];
+    s2 += dg[i] * xh[i];
+    atomicAdd(&rg[c], d * xh[i]);
+    atomicAdd(&rb[c], d);
+  }
+  s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+  s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+  s1 *= (1.0f / C); s2 *= (1.0f / C);
+  if (valid) {
+#pragma unroll
+    for (int i = 0; i < CQ; ++i) dconv[(size_t)token * C + part * CQ + i] = rstd * (dg[i] - s1 - xh[i] * s2);
+    if (part == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) patches[(size_t)token * 16 + k] = k < KP ? in[k] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(dgamma + i, rg[i]); atomicAdd(dbeta + i, rb[i]); }
+}
+// din (M,16): gradient wrt the 12 patch inputs of each token.  Without prior fusion: scatter (+=) into the NCHW image
+// gradient.  With prior fusion: accumulate the 3x3 conv weight / bias gradients (the text prior itself needs no gradient).
+__global__ void k_patch_scatter(const float* __restrict__ din, float* __restrict__ dimg, int cimg, int B, int Hi, int Wi) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * 3 * Hi * Wi) return;
+  const int x = idx % Wi, y = (idx / Wi) % Hi, c = (idx / ((long)Wi * Hi)) % 3, b = idx / ((long)Wi * Hi * 3);
+  const long token = ((long)b * (Hi / 2) + y / 2) * (Wi / 2) + x / 2;
+  dimg[(((size_t)b * cimg + c) * Hi + y) * Wi + x] += din[token * 16 + (c * 2 + (y & 1)) * 2 + (x & 1)];
+}
+__global__ __launch_bounds__(256) void k_prior_fusion_wgrad(const float* __restrict__ din, const float* __restrict__ prior,
+                                                             float* __restrict__ dpf_w, float* __restrict__ dpf_b, int B, int Hi,
+                                                             int Wi) {
+  __shared__ float acc[57];
+  if (threadIdx.x < 57) acc[threadIdx.x] = 0.f;
+  __syncthreads();
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float loc[57];
+#pragma unroll
+  for (int i = 0; i < 57; ++i) loc[i] = 0.f;
+  if (idx < (long)B * Hi * Wi) {
+    const int x = idx % Wi, y = (idx / Wi) % Hi, b = idx / ((long)Wi * Hi);
+    const long token = ((long)b * (Hi / 2) + y / 2) * (Wi / 2) + x / 2;
+    float d[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { d[c] = din[token * 16 + (c * 2 + (y & 1)) * 2 + (x & 1)]; loc[54 + c] = d[c]; }
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int yy = y + ky - 1, xx = x + kx - 1;
+          const float v = (yy >= 0 && yy < Hi && xx >= 0 && xx < Wi) ? prior[(((size_t)b * 2 + ci) * Hi + yy) * Wi + xx] : 0.f;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) loc[((c * 2 + ci) * 3 + ky) * 3 + kx] = d[c] * v;
+        }
+  }
+#pragma unroll
+  for (int i = 0; i < 57; ++i) {
+    const float s = wave_sum(loc[i]);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&acc[i], s);
+  }
+  __syncthreads();
+  if (threadIdx.x < 54) atomicAdd(dpf_w + threadIdx.x, acc[threadIdx.x]);
+  else if (threadIdx.x < 57) atomicAdd(dpf_b + threadIdx.x - 54, acc[threadIdx.x]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpmn_window_attn_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                             const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
+                             float* const* dtables, int B, int H, int W, int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(q && kv && bias_tables && windows && shifts && dout && dq && dkv && dtables, "window_attn_bwd: null pointer");
+  DPMN_REQUIRE(heads_per_group == 2 && C % n_groups == 0 && (H * W) % 64 == 0, "window_attn_bwd: unsupported geometry");
+  const int D = C / n_groups / heads_per_group;
+  hipStream_t st = as_stream(stream);
+  for (int g = 0; g < n_groups; ++g) {
+    const int ws = windows[g], sh = shifts[g];
+    DPMN_REQUIRE(H % ws == 0 && W % ws == 0 && sh >= 0 && sh < ws, "window_attn_bwd: bad window / shift");
+    int rc = DPMN_ERR_ARG;
+#define WB_CASE(WSV, DV) if (ws == WSV && D == DV) rc = launch_wattn_bwd<WSV, DV>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, st); else
+    WB_CASE(2, 16) WB_CASE(4, 16) WB_CASE(8, 16) WB_CASE(4, 32) WB_CASE(8, 32)
+    return dpmn_set_error(DPMN_ERR_ARG, "window_attn_bwd: unsupported (window, head_dim)");
+#undef WB_CASE
+    if (rc != DPMN_OK) return rc;
+  }
+  return DPMN_OK;
+}
+
+int dpmn_sk_select_only_f32(const float* cat, const float* attn_vec, float* V, long M, int L, int C, int G, dpmn_stream_t stream) {
+  DPMN_REQUIRE(cat && attn_vec && V && M > 0 && C % G == 0, "sk_select_only: bad arguments");
+  const long total = M * (C / G);
+  hipLaunchKernelGGL(k_sk_select, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), cat, attn_vec, V, M, L, C, G);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_sk_select_bwd_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA, int B, int L, int C,
+                           int G, dpmn_stream_t stream) {
+  DPMN_REQUIRE(cat && attn_vec && dV && dcat && dA && B > 0, "sk_select_bwd: bad arguments");
+  const int rows = 32;
+  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA, L, C, G, rows);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_sk_gate_bwd_f32(const float* colsum_partials, int parts_per_image, int L, const float* fc1_w, const float* fc1_b,
+                         const float* fc2_w, const float* attn_vec, const float* dA, float* dS, float* dfc1_w, float* dfc1_b,
+                         float* dfc2_w, float* dfc2_b, int B, int C, int G, int dmid, dpmn_stream_t stream) {
+  DPMN_REQUIRE(colsum_partials && fc1_w && fc1_b && fc2_w && attn_vec && dA && dS && dfc1_w && dfc1_b && dfc2_w && dfc2_b,
+               "sk_gate_bwd: null pointer");
+  hipLaunchKernelGGL(k_sk_gate_bwd, dim3(B), dim3(128), (size_t)(2 * C + 3 * dmid) * 4, as_stream(stream), colsum_partials,
+                     parts_per_image, L, fc1_w, fc1_b, fc2_w, attn_vec, dA, dS, dfc1_w, dfc1_b, dfc2_w, dfc2_b, C, G, dmid);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_sk_feats_grad_f32(const float* dout, const float* feats, const float* dS, float* dfeats, long M, int L, int C,
+                           dpmn_stream_t stream) {
+  DPMN_REQUIRE(dout && feats && dS && dfeats && M > 0, "sk_feats_grad: bad arguments");
+  const long total = M * C;
+  hipLaunchKernelGGL(k_sk_feats_grad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), dout, feats, dS, dfeats, M, L, C);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, float* dP, float* dw, float* db, int B, int Ch, int r,
+                           dpmn_stream_t stream) {
+  DPMN_REQUIRE(P && dg && w && dP && dw && db && r >= 3 && r <= 64, "dwconv_bwd: bad arguments");
+  const long planes = (long)B * Ch;
+  hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), (size_t)8 * (r + 2) * (r + 2) * 4, as_stream(stream),
+                     P, dg, w, dP, dw, db, Ch, r, planes);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_act_fwd_f32(const float* x, float* y, int act, float slope, long n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && y && n > 0 && n % 4 == 0, "act_fwd: bad arguments");
+  hipLaunchKernelGGL(k_act_fwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, act, slope, n / 4);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, long M, int C,
+                       dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && gamma && beta && y && M > 0, "layernorm: bad arguments");
+  const unsigned blocks = (unsigned)((M + 7) / 8);
+  if (C == 96) hipLaunchKernelGGL((k_ln_fwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, y, M);
+  else if (C == 192) hipLaunchKernelGGL((k_ln_fwd<192>), dim3(blocks), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, y, M);
+  else if (C == 64) hipLaunchKernelGGL((k_ln_fwd<64>), dim3(blocks), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, y, M);
+  else return dpmn_set_error(DPMN_ERR_ARG, "layernorm: C must be 64, 96 or 192");
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_axpby_f32(const float* x, const float* z, float* y, float a, float b, int accumulate, long n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && y && n > 0, "axpby: bad arguments");
+  hipLaunchKernelGGL(k_axpby, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), x, z, y, a, b, accumulate, n);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_rowsum_mod_f32(const float* x, float* out, long rows, int cols, int mod, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && out && rows > 0 && cols > 0 && mod > 0, "rowsum_mod: bad arguments");
+  hipLaunchKernelGGL(k_rowsum_mod, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, out, rows, cols, mod);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_pgrm_tail_elem_f32(const float* c1, const float* const* weight_list, const float* const* residuals, int n_residuals,
+                            float* out, int B, int H, int W, dpmn_stream_t stream) {
+  DPMN_REQUIRE(c1 && weight_list && out && n_residuals >= 0 && n_residuals <= 8, "tail_elem: bad arguments");
+  TailElem t{};
+  for (int i = 1; i < n_residuals; ++i) { t.res[t.n] = residuals[i]; t.wl[t.n] = weight_list[i]; ++t.n; }   // quirk Q11
+  const long total = (long)B * 3 * 4 * H * W;
+  hipLaunchKernelGGL(k_tail_elem_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), c1, weight_list[0], t, out, B, H, W);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_pgrm_tail_elem_bwd_f32(const float* dout, const float* c1, const float* const* weight_list,
+                                const float* const* residuals, float* const* dresiduals, float* const* dweight_list,
+                                int n_residuals, float* dc1, int B, int H, int W, dpmn_stream_t stream) {
+  DPMN_REQUIRE(dout && c1 && weight_list && dweight_list && dc1 && n_residuals >= 0 && n_residuals <= 8, "tail_elem_bwd: bad arguments");
+  TailElem t{};
+  for (int i = 1; i < n_residuals; ++i) {
+    t.res[t.n] = residuals[i]; t.wl[t.n] = weight_list[i]; t.dres[t.n] = dresiduals ? dresiduals[i] : nullptr; t.dwl[t.n] = dweight_list[i];
+    ++t.n;
+  }
+  const long total = (long)3 * 4 * H * W;
+  hipLaunchKernelGGL(k_tail_elem_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), dout, c1, weight_list[0],
+                     t, dc1, dweight_list[0], B, H, W);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_patch_embed_bwd_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                             const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
+                             float* dgamma, float* dbeta, int B, int Hi, int Wi, int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(img && pe_w && pe_b && ln_w && dtok && dconv && patches && dgamma && dbeta, "patch_embed_bwd: null pointer");
+  const long tokens_n = (long)B * (Hi / 2) * (Wi / 2);
+  dim3 grid((unsigned)((tokens_n + 63) / 64));
+  hipStream_t st = as_stream(stream);
+#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi)
+  if (C == 96 && pf_w) PB_LAUNCH(96, true);
+  else if (C == 96) PB_LAUNCH(96, false);
+  else if (C == 192 && pf_w) PB_LAUNCH(192, true);
+  else if (C == 192) PB_LAUNCH(192, false);
+  else return dpmn_set_error(DPMN_ERR_ARG, "patch_embed_bwd: embed dim must be 96 or 192");
+#undef PB_LAUNCH
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_patch_scatter_f32(const float* din, float* dimg, int cimg, int B, int Hi, int Wi, dpmn_stream_t stream) {
+  DPMN_REQUIRE(din && dimg && cimg >= 3, "patch_scatter: bad arguments");
+  const long total = (long)B * 3 * Hi * Wi;
+  hipLaunchKernelGGL(k_patch_scatter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), din, dimg, cimg, B, Hi, Wi);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_prior_fusion_wgrad_f32(const float* din, const float* prior, float* dpf_w, float* dpf_b, int B, int Hi, int Wi,
+                                dpmn_stream_t stream) {
+  DPMN_REQUIRE(din && prior && dpf_w && dpf_b, "prior_fusion_wgrad: bad arguments");
+  const long total = (long)B * Hi * Wi;
+  hipLaunchKernelGGL(k_prior_fusion_wgrad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), din, prior, dpf_w, dpf_b, B, Hi, Wi);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+}  // extern "C"

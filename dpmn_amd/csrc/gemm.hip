@@ -28,6 +28,7 @@ struct EpiArgs {
   float* colsum;       // (gridDim.x, N) per-block column sums of GELU(y) (SKConv GAP partials) or null
   int act;             // ACT_*
   float slope;         // PReLU slope
+  int atomic;          // 1: y += acc with fp32 atomics (split-K weight gradients); bias/act/res ignored
 };
 
 struct ProArgs {
@@ -70,7 +71,10 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, i
     for (int mt = 0; mt < MT; ++mt) {
       const int m = m0 + mt * 16 + lm;
       float v[4] = {acc[nt][mt][0] + b4.x, acc[nt][mt][1] + b4.y, acc[nt][mt][2] + b4.z, acc[nt][mt][3] + b4.w};
-      if (m < M) {
+      if (m < M && e.atomic) {
+        for (int r = 0; r < 4; ++r)
+          if (n + r < N) atomicAdd(y + (size_t)m * ldy + n + r, acc[nt][mt][r]);
+      } else if (m < M) {
         if (e.colsum) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) cs[r] += gelu_erf(v[r]);
@@ -275,8 +279,12 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
 
 // ---------------------------------------------------------------------------------- k-loop
 // Block 256 threads; tile BM=64 x BN=96, BK=32, register-prefetch double buffering.
+// Batched-K mode (kb_len > 0): the reduction axis is split into segments of kb_len that live in different images,
+// element (row, k) sits at base + (k / kb_len) * batch_stride + row * kb_len + k % kb_len -- the pointwise-conv
+// weight gradient dWp = sum_b dz_b . g_b^T over the raw (B, Ch, L) views (pgrm.py:37).
 __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
-                                                     float* __restrict__ y, int ldy, int M, int N, int K, EpiArgs e) {
+                                                     float* __restrict__ y, int ldy, int M, int N, int K, EpiArgs e, int kb_len,
+                                                     long x_bstride, long w_bstride) {
   constexpr int BM = 64, BN = 96, BK = 32, LDK = BK + PAD;
   __shared__ __attribute__((aligned(16))) float Xs[2][BM * LDK];
   __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
@@ -288,15 +296,18 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
   float4 xr[2], wr[3];
 
   auto gload = [&](int k0) {
+    int kk = k0;
+    size_t xoff = 0, woff = 0;
+    if (kb_len > 0) { const int kb = k0 / kb_len; kk = k0 - kb * kb_len; xoff = (size_t)kb * x_bstride; woff = (size_t)kb * w_bstride; }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       const int m = m_blk + lrow + p * 32;
-      xr[p] = (m < M) ? *reinterpret_cast<const float4*>(x + (size_t)m * ldx + k0 + lcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xr[p] = (m < M) ? *reinterpret_cast<const float4*>(x + xoff + (size_t)m * ldx + kk + lcol) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
       const int n = n_blk + lrow + p * 32;
-      wr[p] = (n < N) ? *reinterpret_cast<const float4*>(w + (size_t)n * ldw + k0 + lcol) : make_float4(0.f, 0.f, 0.f, 0.f);
+      wr[p] = (n < N) ? *reinterpret_cast<const float4*>(w + woff + (size_t)n * ldw + kk + lcol) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto sstore = [&](int buf) {
@@ -314,12 +325,16 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  gload(0);
+  const int nk_all = K / BK;
+  const int cps = (nk_all + gridDim.z - 1) / gridDim.z;      // K chunks per split (grid.z > 1 only with e.atomic)
+  const int kt0 = blockIdx.z * cps;
+  const int nk = min(nk_all, kt0 + cps);
+  if (kt0 >= nk) return;
+  gload(kt0 * BK);
   sstore(0);
   __syncthreads();
-  const int nk = K / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
+  for (int kt = kt0; kt < nk; ++kt) {
+    const int buf = (kt - kt0) & 1;
     if (kt + 1 < nk) gload((kt + 1) * BK);
     const float* xa = &Xs[buf][(wm * 32 + lr) * LDK + kq * 4];
     const float* wa = &Ws[buf][(wn * 48 + lr) * LDK + kq * 4];
@@ -478,7 +493,7 @@ int dpmn_linear_f32(const float* x, const float* w, const float* bias, const flo
     return dispatch_wholeK<PRO_NONE>(K, x, K, w, y, N, M, N, p, e, as_stream(stream));
   DPMN_REQUIRE(K % 32 == 0, "linear: K must be a multiple of 32");
   dim3 grid(cdiv(M, 64), cdiv(N, 96));
-  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e);
+  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -526,6 +541,17 @@ int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_h
   ProArgs p{};
   p.sel = attn_vec; p.rows_per_image = rows_per_image; p.groups = groups;
   return dispatch_wholeK<PRO_SKSEL>(C / groups, cat, C, w_head, out, C, M, C, p, e, as_stream(stream));
+}
+
+int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, int Ch, int L, dpmn_stream_t stream) {
+  // dw[co][c] += sum_{b,s} dz[b][co][s] * g[b][c][s]  -- x = dz, w = g, reduction over (b, s)
+  DPMN_REQUIRE(dz && g && dw && L % 32 == 0 && Ch % 4 == 0, "pointwise_wgrad: bad arguments");
+  EpiArgs e{nullptr, nullptr, nullptr, nullptr, ACT_NONE, 0.f, 1};   // split over (b, s), atomic accumulation
+  dim3 grid(cdiv(Ch, 64), cdiv(Ch, 96), 32);
+  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, dw, Ch, Ch, Ch, B * L, e, L,
+                     (long)Ch * L, (long)Ch * L);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
 }
 
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,

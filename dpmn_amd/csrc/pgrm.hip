@@ -288,7 +288,7 @@ __global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image
 // planes of r x r (raw reinterpretation of the (B, L, Ch) fc1 output, quirk Q2); one block per 4 planes
 __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ g, int Ch, int r,
-                                                      long planes) {
+                                                      long planes, int apply_gelu) {
   extern __shared__ float sm[];   // [ (r+2) * (r+2) ] per wave
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long plane = (long)blockIdx.x * 4 + wave;
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) a += k[ky * 3 + kx] * p[ky * LD + kx];
-    dst[i] = gelu_erf(a);
+    dst[i] = apply_gelu ? gelu_erf(a) : a;
   }
 }
 
@@ -469,7 +469,16 @@ int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, f
   DPMN_REQUIRE(y && w && bias && g && r >= 3 && r <= 64, "dwconv: bad arguments");
   const long planes = (long)B * Ch;
   hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), (size_t)4 * (r + 2) * (r + 2) * 4,
-                     as_stream(stream), y, w, bias, g, Ch, r, planes);
+                     as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream) {
+  DPMN_REQUIRE(y && w && bias && g && r >= 3 && r <= 64, "dwconv: bad arguments");
+  const long planes = (long)B * Ch;
+  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), (size_t)4 * (r + 2) * (r + 2) * 4,
+                     as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

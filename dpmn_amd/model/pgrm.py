@@ -213,8 +213,9 @@ class PGRM(nn.Module):
         if self.training and any(p > 0 for p in self.drop_probs):
             raise NotImplementedError("dpmn_amd PGRM: train-mode dropout/DropPath kernels are not built yet; "
                                       "use .eval() or zero drop rates")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("dpmn_amd PGRM: backward kernels are not built yet; call under torch.no_grad()")
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or x_kv.requires_grad):
+            from ..train import pgrm_train           # explicit HIP forward + backward behind torch.autograd
+            return pgrm_train.apply(self, x_q, x_kv, list(residual_list))
         B = x_kv.shape[0]
         if x_q.shape[1] == 2 and self.mode:
             raise _abi.DpmnError("PGRM(mode=True) has no prior_fusion: x_q must have 3 channels (pgrm.py:470,547)")

@@ -133,11 +133,9 @@ def nhwc_to_nchw(x):
     return out
 
 
-def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", epi_act="none", slope=0.0, res=None,
-           affine=None, out=None, out_nchw=False, pixel_shuffle=False, stats=None, phase=None, out_hw=None):
-    """inputs: list of 1..3 NHWC tensors (channel-concatenated on the fly).  k: int or (KH, KW).
-    phase=(py, px): one output phase of ConvTranspose2d(4,2,1) (k=2, dil=-1, pad=-phase).
-    affine: optional list of (scale, shift) per input segment."""
+def conv_desc(inputs, k, stride=1, pad=0, dil=1, cout=0, pro_act="none", affine=None, phase=None, geom=None):
+    """Geometry part of a dpmn_conv_desc.  geom: optional dict overriding (stride, dil, pad_y, pad_x, Hp, Wp, Hout, Wout,
+    ostep, ooy, oox) for the odd-pixel scatter of the dilated stride-2 conv's data gradient."""
     d = _abi.ConvDesc()
     B, Hin, Win, _ = inputs[0].shape
     for i, t in enumerate(inputs):
@@ -147,7 +145,10 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
             d.in_scale[i], d.in_shift[i] = dptr(affine[i][0]), dptr(affine[i][1])
     kh, kw = (k, k) if isinstance(k, int) else k
     d.B, d.Hin, d.Win, d.KH, d.KW = B, Hin, Win, kh, kw
-    if phase is None:
+    if geom is not None:
+        for key, val in geom.items():
+            setattr(d, key, val)
+    elif phase is None:
         ph, pw = (pad, pad) if isinstance(pad, int) else pad
         d.stride, d.dil_y, d.dil_x, d.pad_y, d.pad_x = stride, dil, dil, ph, pw
         Ho = (Hin + 2 * ph - dil * (kh - 1) - 1) // stride + 1
@@ -156,10 +157,21 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
     else:
         py, px = phase
         d.stride, d.dil_y, d.dil_x, d.pad_y, d.pad_x = 1, -1, -1, -py, -px
-        Ho, Wo = 2 * Hin, 2 * Win
-        d.Hp, d.Wp, d.Hout, d.Wout, d.ostep, d.ooy, d.oox = Hin, Win, Ho, Wo, 2, py, px
-    d.pro_act, d.epi_act, d.slope = ACT[pro_act], ACT[epi_act], float(slope)
-    d.w, d.bias, d.Cout = dptr(wp), dptr(bias, True), cout
+        d.Hp, d.Wp, d.Hout, d.Wout, d.ostep, d.ooy, d.oox = Hin, Win, 2 * Hin, 2 * Win, 2, py, px
+    d.pro_act, d.Cout = ACT[pro_act], cout
+    return d
+
+
+def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", epi_act="none", slope=0.0, res=None,
+           affine=None, out=None, out_nchw=False, pixel_shuffle=False, stats=None, phase=None, geom=None):
+    """inputs: list of 1..3 NHWC tensors (channel-concatenated on the fly).  k: int or (KH, KW).
+    phase=(py, px): one output phase of ConvTranspose2d(4,2,1) (k=2, dil=-1, pad=-phase).
+    affine: optional list of (scale, shift) per input segment."""
+    d = conv_desc(inputs, k, stride, pad, dil, cout, pro_act, affine, phase, geom)
+    B = d.B
+    Ho, Wo = d.Hout, d.Wout
+    d.epi_act, d.slope = ACT[epi_act], float(slope)
+    d.w, d.bias = dptr(wp), dptr(bias, True)
     d.res = dptr(res, True)
     if out is None:
         if out_nchw:

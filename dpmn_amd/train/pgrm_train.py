@@ -1,0 +1,272 @@
+"""Training-mode PGRM: explicit forward (keeps the activations the backward needs) and explicit backward, both
+composed from libdpmn_hip.so kernels.  Replaces autograd through model/pgrm.py (loss.backward(),
+interfaces/super_resolution.py:270) for PGRM.forward (pgrm.py:546-565).
+
+The forward here is the unfused variant of csrc/pgrm_forward.hip (LayerNorm, GELU kept as separate kernels so that
+pre-activations are available); dropout / DropPath must be zero (the train-mode RNG kernels are not built).
+"""
+import ctypes as C
+
+import torch
+
+from .. import _abi, ops
+from .._abi import dptr, lib, check, stream
+from ..model import packing
+
+GELU = ops.ACT["gelu"]
+
+
+def _e(*shape, like):
+    return torch.empty(*shape, device=like.device)
+
+
+def _z(*shape, like):
+    return torch.zeros(*shape, device=like.device)
+
+
+def layernorm(x, w, b):
+    y = torch.empty_like(x)
+    check(lib.dpmn_layernorm_f32(dptr(x), dptr(w), dptr(b), 1e-5, dptr(y), x.shape[0], x.shape[1], stream()))
+    return y
+
+
+def layernorm_bwd(x, dy, w, dx, accumulate, dgamma, dbeta):
+    check(lib.dpmn_layernorm_bwd_f32(dptr(x), dptr(dy), dptr(w), 1e-5, dptr(dx), int(accumulate), dptr(dgamma), dptr(dbeta),
+                                     x.shape[0], x.shape[1], stream()))
+
+
+def act_fwd(x, act=GELU):
+    y = torch.empty_like(x)
+    check(lib.dpmn_act_fwd_f32(dptr(x), dptr(y), act, 0.0, x.numel(), stream()))
+    return y
+
+
+def act_bwd(dy, pre, act=GELU):
+    d = torch.empty_like(pre)
+    check(lib.dpmn_act_bwd_f32(dptr(dy), dptr(pre), dptr(d), act, 0.0, pre.numel(), stream()))
+    return d
+
+
+def gemm_tn(dy, x, dw):
+    """dw (N,K) += dy (M,N)^T x (M,K)"""
+    check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dy.shape[0], dy.shape[1], x.shape[1], stream()))
+
+
+def colsum(dy, db):
+    check(lib.dpmn_colsum_f32(dptr(dy), dptr(db), dy.shape[0], dy.shape[1], stream()))
+
+
+def linear_bwd(dy, x, w, dw, db):
+    """y = x w^T + b : returns dx; accumulates dw, db."""
+    gemm_tn(dy, x, dw)
+    if db is not None:
+        colsum(dy, db)
+    return ops.linear(dy, w.t().contiguous())
+
+
+class ConvSpec:
+    """Geometry + packed weights of one conv in the reference layout (Cout, Cin, k, k), stride 1, 'same' padding."""
+
+    def __init__(self, weight, bias):
+        self.weight, self.bias = weight, bias
+        self.cout, self.cin, self.k = weight.shape[0], weight.shape[1], weight.shape[2]
+        self.pad = (self.k - 1) // 2
+
+    def forward(self, x):
+        wp, bp = packing.pack_conv(self.weight, self.bias)
+        return ops.conv2d([x], wp, bp, self.cout, self.k, pad=self.pad)
+
+    def backward(self, x, dy, dweight, dbias, need_dx=True):
+        """x (B,H,W,Cin) input of the forward, dy (B,H,W,Cout); accumulates dweight/dbias; returns dx."""
+        B, H, W, _ = x.shape
+        kp = (self.k * self.k * self.cin + 31) // 32 * 32
+        dwp = torch.zeros(self.cout, kp, device=x.device)
+        d = ops.conv_desc([x], self.k, pad=self.pad, cout=self.cout)
+        check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dy), dptr(dwp), stream()))
+        dweight += dwp[:, :self.k * self.k * self.cin].reshape(self.cout, self.k, self.k, self.cin).permute(0, 3, 1, 2)
+        colsum(dy.reshape(-1, self.cout), dbias)
+        if not need_dx:
+            return None
+        wt, _ = packing.pack_convT_s1(self.weight)      # data gradient = transposed conv with the same weight tensor
+        return ops.conv2d([dy], wt, None, self.cin, self.k, pad=self.pad)
+
+
+def forward(m, x_q, x_kv, residuals):
+    """Returns (out, saved).  m: dpmn_amd.model.pgrm.PGRM."""
+    B = x_kv.shape[0]
+    H, Wd = m.patches_resolution
+    L, Cd = H * Wd, m.embed_dim
+    M, Ch, G = B * L, int(m.embed_dim * m.mlp_ratio), len(m.window_size)
+    hpg = m.num_heads // G
+    pe = m.patch_embed
+    fuse = not m.mode
+    pf = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
+    tq = ops.patch_embed_ln(x_q, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch, *pf).reshape(M, Cd)
+    tkv = ops.patch_embed_ln(x_kv, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch).reshape(M, Cd)
+    sv = dict(x_q=x_q, x_kv=x_kv, tq=tq, residuals=list(residuals), blocks=[])
+    parts = (L + 31) // 32
+    for bi, blk in enumerate(m.layers[0].blocks):
+        a, sk, mlp = blk.attn, blk.attn.sknet, blk.mlp
+        win = [min(H, Wd) if min(H, Wd) <= w else w for w in m.window_size]
+        shift = [0 if (bi == 0 or min(H, Wd) <= w) else w // 2 for w in m.window_size]
+        tables = [getattr(a, "relative_position_bias_table_%d" % g) for g in range(G)]
+        s = dict(tkv_in=tkv, win=win, shift=shift, tables=tables)
+        s["nq"] = layernorm(tq, blk.norm1_q.weight, blk.norm1_q.bias)
+        s["nkv"] = layernorm(tkv, blk.norm1_kv.weight, blk.norm1_kv.bias)
+        s["q"] = ops.linear(s["nq"], a.q.weight, a.q.bias)
+        s["kv"] = ops.linear(s["nkv"], a.kv.weight, a.kv.bias)
+        s["cat"] = ops.window_attn(s["q"].reshape(B, L, Cd), s["kv"].reshape(B, L, 2 * Cd), tables, win, shift, hpg, H, Wd).reshape(M, Cd)
+        s["feats"] = _e(M, Cd, like=tkv)
+        s["partial"] = _e(B * parts, Cd, like=tkv)
+        check(lib.dpmn_sk_proj_f32(dptr(s["cat"]), dptr(sk.proj.weight), dptr(sk.proj.bias), dptr(s["feats"]), dptr(s["partial"]), M, Cd, stream()))
+        s["avec"] = _e(B, G, Cd // G, like=tkv)
+        check(lib.dpmn_sk_gate_f32(dptr(s["partial"]), parts, L, dptr(sk.fc1.weight), dptr(sk.fc1.bias), dptr(sk.fc2.weight),
+                                   dptr(sk.fc2.bias), dptr(s["avec"]), B, Cd, G, sk.fc1.weight.shape[0], stream()))
+        s["V"] = _e(M, Cd // G, like=tkv)
+        check(lib.dpmn_sk_select_only_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(s["V"]), M, L, Cd, G, stream()))
+        s["x1"] = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"], res2=tkv)
+        s["n2"] = layernorm(s["x1"], blk.norm2.weight, blk.norm2.bias)
+        s["ypre"] = ops.linear(s["n2"], mlp.fc1.weight, mlp.fc1.bias)
+        s["y"] = act_fwd(s["ypre"])
+        r = int(round(L ** 0.5))
+        s["gpre"] = _e(M, Ch, like=tkv)
+        check(lib.dpmn_dwconv3x3_f32(dptr(s["y"]), dptr(mlp.depthwise_conv.weight), dptr(mlp.depthwise_conv.bias), dptr(s["gpre"]), B, Ch, r, stream()))
+        s["g"] = act_fwd(s["gpre"])
+        s["z"] = ops.pointwise(s["g"].reshape(B, L, Ch), mlp.pointwise_conv.weight.reshape(Ch, Ch), mlp.pointwise_conv.bias).reshape(M, Ch)
+        tkv = ops.linear(s["z"], mlp.fc2.weight, mlp.fc2.bias, res1=s["x1"])
+        sv["blocks"].append(s)
+    sv["tkv_out"] = tkv
+    c0s, c1s = ConvSpec(m.conv_before_upsample[0].weight, m.conv_before_upsample[0].bias), ConvSpec(m.conv_before_upsample[1].weight, m.conv_before_upsample[1].bias)
+    sv["c0"] = c0s.forward(tkv.reshape(B, H, Wd, Cd))
+    sv["c1"] = c1s.forward(sv["c0"])
+    wl = [getattr(m, "weight_list_%d" % i) for i in range(m.iter + 1)]
+    out = torch.empty(B, m.hidden_size, m.img_size[0], m.img_size[1], device=x_kv.device)
+    check(lib.dpmn_pgrm_tail_elem_f32(dptr(sv["c1"]), _abi.ptr_array(wl), _abi.ptr_array(residuals), len(residuals), dptr(out), B, H, Wd, stream()))
+    return out, sv
+
+
+def backward(m, sv, dout, need_dx_kv=True):
+    """Returns (dx_kv or None, [dresidual_i or None], {param: grad}).  Gradients are freshly allocated tensors."""
+    B = sv["x_kv"].shape[0]
+    H, Wd = m.patches_resolution
+    L, Cd = H * Wd, m.embed_dim
+    M, Ch, G = B * L, int(m.embed_dim * m.mlp_ratio), len(m.window_size)
+    hpg = m.num_heads // G
+    parts = (L + 31) // 32
+    gr = {p: torch.zeros_like(p) for p in m.parameters()}
+    residuals = sv["residuals"]
+    dres = [None] + [torch.zeros_like(r) for r in residuals[1:]]
+    wl = [getattr(m, "weight_list_%d" % i) for i in range(m.iter + 1)]
+    dwl = [gr[w] for w in wl]
+    dout = dout.contiguous()
+    dc1 = torch.empty_like(sv["c1"])
+    n_res = len(residuals)
+    dres_ptrs = (_abi.fp * max(n_res, 1))()
+    for i in range(1, n_res):
+        dres_ptrs[i] = dptr(dres[i])
+    check(lib.dpmn_pgrm_tail_elem_bwd_f32(dptr(dout), dptr(sv["c1"]), _abi.ptr_array(wl), _abi.ptr_array(residuals), dres_ptrs,
+                                          _abi.ptr_array(dwl), n_res, dptr(dc1), B, H, Wd, stream()))
+    c0m, c1m = m.conv_before_upsample[0], m.conv_before_upsample[1]
+    dc0 = ConvSpec(c1m.weight, c1m.bias).backward(sv["c0"], dc1, gr[c1m.weight], gr[c1m.bias])
+    dtkv = ConvSpec(c0m.weight, c0m.bias).backward(sv["tkv_out"].reshape(B, H, Wd, Cd), dc0, gr[c0m.weight], gr[c0m.bias]).reshape(M, Cd)
+    dtq = torch.zeros(M, Cd, device=dout.device)
+    for bi in (1, 0):
+        blk = m.layers[0].blocks[bi]
+        a, sk, mlp = blk.attn, blk.attn.sknet, blk.mlp
+        s = sv["blocks"][bi]
+        dx2 = dtkv
+        # fc2 (+ residual x1)
+        dz = linear_bwd(dx2, s["z"], mlp.fc2.weight, gr[mlp.fc2.weight], gr[mlp.fc2.bias])
+        # pointwise conv on the raw (B, Ch, L) views
+        wp = mlp.pointwise_conv.weight.reshape(Ch, Ch)
+        dg = ops.pointwise(dz.reshape(B, L, Ch), wp.t().contiguous(), torch.zeros(Ch, device=dz.device)).reshape(M, Ch)
+        check(lib.dpmn_pointwise_wgrad_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, stream()))
+        check(lib.dpmn_rowsum_mod_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, stream()))
+        dgpre = act_bwd(dg, s["gpre"])
+        dy = torch.empty_like(dgpre)
+        r = int(round(L ** 0.5))
+        check(lib.dpmn_dwconv3x3_bwd_f32(dptr(s["y"]), dptr(dgpre), dptr(mlp.depthwise_conv.weight), dptr(dy),
+                                         dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]), B, Ch, r, stream()))
+        dypre = act_bwd(dy, s["ypre"])
+        dn2 = linear_bwd(dypre, s["n2"], mlp.fc1.weight, gr[mlp.fc1.weight], gr[mlp.fc1.bias])
+        dx1 = dx2.clone()
+        layernorm_bwd(s["x1"], dn2, blk.norm2.weight, dx1, True, gr[blk.norm2.weight], gr[blk.norm2.bias])
+        # x1 = tkv_in + feats + V Wh^T + bh
+        dV = linear_bwd(dx1, s["V"], sk.proj_head.weight, gr[sk.proj_head.weight], gr[sk.proj_head.bias])
+        dcat = torch.zeros(M, Cd, device=dout.device)
+        dA = torch.zeros(B, G, Cd // G, device=dout.device)
+        check(lib.dpmn_sk_select_bwd_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(dV), dptr(dcat), dptr(dA), B, L, Cd, G, stream()))
+        dS = torch.empty(B, Cd, device=dout.device)
+        check(lib.dpmn_sk_gate_bwd_f32(dptr(s["partial"]), parts, L, dptr(sk.fc1.weight), dptr(sk.fc1.bias), dptr(sk.fc2.weight),
+                                       dptr(s["avec"]), dptr(dA), dptr(dS), dptr(gr[sk.fc1.weight]), dptr(gr[sk.fc1.bias]),
+                                       dptr(gr[sk.fc2.weight]), dptr(gr[sk.fc2.bias]), B, Cd, G, sk.fc1.weight.shape[0], stream()))
+        dfeats = torch.empty(M, Cd, device=dout.device)
+        check(lib.dpmn_sk_feats_grad_f32(dptr(dx1), dptr(s["feats"]), dptr(dS), dptr(dfeats), M, L, Cd, stream()))
+        gemm_tn(dfeats, s["cat"], gr[sk.proj.weight])
+        colsum(dfeats, gr[sk.proj.bias])
+        dcat = ops.linear(dfeats, sk.proj.weight.t().contiguous(), None, res1=dcat)
+        # window attention
+        dq = torch.empty(M, Cd, device=dout.device)
+        dkv = torch.empty(M, 2 * Cd, device=dout.device)
+        dtab = [gr[t] for t in s["tables"]]
+        check(lib.dpmn_window_attn_bwd_f32(dptr(s["q"]), dptr(s["kv"]), _abi.ptr_array(s["tables"]), _abi.int_array(s["win"]),
+                                           _abi.int_array(s["shift"]), G, hpg, dptr(dcat), dptr(dq), dptr(dkv), _abi.ptr_array(dtab),
+                                           B, H, Wd, Cd, stream()))
+        dnq = linear_bwd(dq, s["nq"], a.q.weight, gr[a.q.weight], gr[a.q.bias])
+        layernorm_bwd(sv["tq"], dnq, blk.norm1_q.weight, dtq, True, gr[blk.norm1_q.weight], gr[blk.norm1_q.bias])
+        dnkv = linear_bwd(dkv, s["nkv"], a.kv.weight, gr[a.kv.weight], gr[a.kv.bias])
+        layernorm_bwd(s["tkv_in"], dnkv, blk.norm1_kv.weight, dx1, True, gr[blk.norm1_kv.weight], gr[blk.norm1_kv.bias])
+        dtkv = dx1
+    # patch embeddings (shared weights): kv path gives the image gradient, q path the prior_fusion gradients
+    pe = m.patch_embed
+    dx_kv = None
+    for which, img, dtok in (("kv", sv["x_kv"], dtkv), ("q", sv["x_q"], dtq)):
+        fuse = which == "q" and not m.mode
+        pfw, pfb = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
+        dconv = torch.empty(M, Cd, device=dout.device)
+        patches = torch.empty(M, 16, device=dout.device)
+        check(lib.dpmn_patch_embed_bwd_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
+                                           dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
+                                           dptr(gr[pe.norm.weight]), dptr(gr[pe.norm.bias]), B, img.shape[2], img.shape[3], Cd, stream()))
+        dw16 = torch.zeros(Cd, 16, device=dout.device)
+        gemm_tn(dconv, patches, dw16)
+        gr[pe.proj.weight] += dw16[:, :12].reshape(pe.proj.weight.shape)
+        colsum(dconv, gr[pe.proj.bias])
+        need_din = fuse or (which == "kv" and need_dx_kv)
+        if need_din:
+            w16 = torch.zeros(16, Cd, device=dout.device)
+            w16[:12] = pe.proj.weight.reshape(Cd, 12).t()
+            din = ops.linear(dconv, w16)
+            if fuse:
+                check(lib.dpmn_prior_fusion_wgrad_f32(dptr(din), dptr(img), dptr(gr[m.prior_fusion.weight]), dptr(gr[m.prior_fusion.bias]),
+                                                      B, img.shape[2], img.shape[3], stream()))
+            else:
+                dx_kv = torch.zeros_like(img)
+                check(lib.dpmn_patch_scatter_f32(dptr(din), dptr(dx_kv), img.shape[1], B, img.shape[2], img.shape[3], stream()))
+    return dx_kv, dres, gr
+
+
+class PGRMFunction(torch.autograd.Function):
+    """autograd bridge: inputs (x_q, x_kv, n_res, *residuals, *params)."""
+
+    @staticmethod
+    def forward(ctx, m, x_q, x_kv, n_res, *rest):
+        residuals = list(rest[:n_res])
+        out, sv = forward(m, x_q.contiguous().float(), x_kv.contiguous().float(), [r.contiguous().float() for r in residuals])
+        ctx.m, ctx.sv, ctx.n_res = m, sv, n_res
+        ctx.need_kv = x_kv.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        m = ctx.m
+        dx_kv, dres, gr = backward(m, ctx.sv, dout, need_dx_kv=ctx.need_kv)
+        ctx.sv = None
+        params = list(m.parameters())
+        dres_out = [None if d is None else d for d in dres] + [None] * (ctx.n_res - len(dres))
+        return (None, None, dx_kv, None) + tuple(dres_out[:ctx.n_res]) + tuple(gr[p] for p in params)
+
+
+def apply(m, x_q, x_kv, residual_list):
+    params = list(m.parameters())
+    return PGRMFunction.apply(m, x_q, x_kv, len(residual_list), *residual_list, *params)

@@ -168,6 +168,83 @@ size_t dpmn_psnr_ssim_workspace_bytes(int B, int C, int H, int W);
 int dpmn_psnr_ssim_f32(const float* x, long x_stride, const float* y, long y_stride, float* out2, void* workspace,
                        int B, int C, int H, int W, dpmn_stream_t stream);
 
+/* ------------------------------------------------------------------ training: backward building blocks
+ * (backward.hip, backward_pgrm.hip).  Autograd of the reference (loss.backward(), super_resolution.py:270) is
+ * replaced by explicit kernels; weight-gradient entries ACCUMULATE into their output (caller zeroes, like
+ * optimizer.zero_grad, super_resolution.py:141). */
+/* dw (N,K) += dy (M,N)^T . x (M,K): nn.Linear weight gradient */
+int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, int M, int N, int K, dpmn_stream_t stream);
+/* db (N) += column sums of dy (M,N) */
+int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream);
+/* LayerNorm backward from the saved pre-norm input x; dx written or accumulated; dgamma/dbeta accumulated */
+int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
+                           float* dgamma, float* dbeta, long M, int C, dpmn_stream_t stream);
+int dpmn_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, long M, int C,
+                       dpmn_stream_t stream);
+/* dpre = dy * act'(pre) ; y = act(x) */
+int dpmn_act_bwd_f32(const float* dy, const float* pre, float* dpre, int act, float slope, long n, dpmn_stream_t stream);
+int dpmn_act_fwd_f32(const float* x, float* y, int act, float slope, long n, dpmn_stream_t stream);
+/* y (+)= a*x + b*z (z may be NULL) */
+int dpmn_axpby_f32(const float* x, const float* z, float* y, float a, float b, int accumulate, long n, dpmn_stream_t stream);
+/* out[row % mod] += sum_c x[row][c] */
+int dpmn_rowsum_mod_f32(const float* x, float* out, long rows, int cols, int mod, dpmn_stream_t stream);
+/* ImageLoss (loss/image_loss.py:15-43): loss = w_mse*MSE + w_grad*L1(gradient maps of the first 3 channels).
+ * U, V: (B,3,H,W) scratch written by the forward and consumed by the backward (may be NULL when gradient == 0).
+ * grad_out (B,C,H,W) (+)= grad_scale[0] * dloss/dout. */
+size_t dpmn_image_loss_workspace_bytes(int B, int C, int H, int W);
+int dpmn_image_loss_fwd_f32(const float* out, long out_stride, const float* tgt, long tgt_stride, float w_mse,
+                            float w_grad, int gradient, float* loss, float* U, float* V, void* workspace, int B, int C,
+                            int H, int W, dpmn_stream_t stream);
+int dpmn_image_loss_bwd_f32(const float* out, long out_stride, const float* tgt, long tgt_stride, const float* U,
+                            const float* V, const float* grad_scale, float w_mse, float w_grad, int gradient,
+                            float* grad_out, int accumulate, int B, int C, int H, int W, dpmn_stream_t stream);
+/* window attention backward (pgrm.py:197-266): dq (B,L,C), dkv (B,L,2C) written; dtables[g] accumulated */
+int dpmn_window_attn_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                             const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq,
+                             float* dkv, float* const* dtables, int B, int H, int W, int C, dpmn_stream_t stream);
+/* SKConv backward pieces (pgrm.py:79-96) */
+int dpmn_sk_select_only_f32(const float* cat, const float* attn_vec, float* V, long M, int L, int C, int G, dpmn_stream_t stream);
+int dpmn_sk_select_bwd_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA, int B, int L,
+                           int C, int G, dpmn_stream_t stream);
+int dpmn_sk_gate_bwd_f32(const float* colsum_partials, int parts_per_image, int L, const float* fc1_w, const float* fc1_b,
+                         const float* fc2_w, const float* attn_vec, const float* dA, float* dS, float* dfc1_w,
+                         float* dfc1_b, float* dfc2_w, float* dfc2_b, int B, int C, int G, int dmid, dpmn_stream_t stream);
+int dpmn_sk_feats_grad_f32(const float* dout, const float* feats, const float* dS, float* dfeats, long M, int L, int C,
+                           dpmn_stream_t stream);
+/* Mlp depthwise conv without the activation (training keeps the pre-activation), its backward, and the
+ * pointwise-conv weight gradient dw (Ch,Ch) += sum_b dz_b . g_b^T over the raw (B,Ch,L) views */
+int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream);
+int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, float* dP, float* dw, float* db, int B, int Ch,
+                           int r, dpmn_stream_t stream);
+int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, int Ch, int L, dpmn_stream_t stream);
+
+/* PGRM tail in training form: out = lrelu(c1) pixel-shuffled * weight_list_0 + sum_i residual_i * weight_list_i
+ * (pgrm.py:560-565; residual 0 skipped, Q11) and its backward (dresiduals[i] may be NULL; dweight_list accumulated) */
+int dpmn_pgrm_tail_elem_f32(const float* c1, const float* const* weight_list, const float* const* residuals,
+                            int n_residuals, float* out, int B, int H, int W, dpmn_stream_t stream);
+int dpmn_pgrm_tail_elem_bwd_f32(const float* dout, const float* c1, const float* const* weight_list,
+                                const float* const* residuals, float* const* dresiduals, float* const* dweight_list,
+                                int n_residuals, float* dc1, int B, int H, int W, dpmn_stream_t stream);
+/* PatchEmbed (+prior_fusion) backward (pgrm.py:419-426, 548): see backward_pgrm.hip */
+int dpmn_patch_embed_bwd_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                             const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
+                             float* dgamma, float* dbeta, int B, int Hi, int Wi, int C, dpmn_stream_t stream);
+int dpmn_patch_scatter_f32(const float* din, float* dimg, int cimg, int B, int Hi, int Wi, dpmn_stream_t stream);
+int dpmn_prior_fusion_wgrad_f32(const float* din, const float* prior, float* dpf_w, float* dpf_b, int B, int Hi, int Wi,
+                                dpmn_stream_t stream);
+/* conv weight gradient in the packed (Cout, Kp) layout, train-mode BatchNorm plumbing, CMM gate backward (conv_bwd.hip) */
+int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, dpmn_stream_t stream);
+int dpmn_bn_finalize_f32(const float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,
+                         float* scale, float* shift, float* mean, float* rstd, float* running_mean, float* running_var,
+                         int C, dpmn_stream_t stream);
+int dpmn_affine_act_bwd_f32(const float* dA, const float* r, const float* scale, const float* shift, int act, float* G,
+                            int accumulate, long pixels, int C, dpmn_stream_t stream);
+int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const float* mean, const float* rstd, float* sums_ws,
+                    float* dr, float* dgamma, float* dbeta, long pixels, int C, dpmn_stream_t stream);
+int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, const float* fc1_b, const float* fc2_w,
+                         const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b, int B,
+                         int P, int C, int Cmid, dpmn_stream_t stream);
+
 /* ------------------------------------------------------------------ PGRM module (pgrm_forward.hip) */
 typedef struct {
   const float *norm1_q_w, *norm1_q_b, *norm1_kv_w, *norm1_kv_b;
