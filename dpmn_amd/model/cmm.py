@@ -86,10 +86,13 @@ class ComplementationModulationModule(nn.Module):
 
     def forward(self, x1, x2):
         if self.training:
-            raise NotImplementedError("dpmn_amd CMM: train-mode BatchNorm (batch statistics) + backward are not built yet; "
-                                      "call .eval()")
+            from ..train import cmm_train       # train-mode BatchNorm (batch statistics) + explicit HIP backward
+            if torch.is_grad_enabled():
+                return cmm_train.apply(self, x1, x2)
+            with torch.no_grad():
+                return cmm_train.build(self, x1, x2)[0]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("dpmn_amd CMM: backward kernels are not built yet; call under torch.no_grad()")
+            raise NotImplementedError("dpmn_amd CMM: gradients in eval mode (running-stat BatchNorm) are not built; use .train()")
         P = self._packed()
         c = self.cnum
         enc = []

@@ -57,3 +57,34 @@ def pack_convT_s2k4(weight, bias=None, bn=None):
 def bn_tuple(mod_sd, prefix, eps=1e-5):
     return (mod_sd[prefix + "weight"], mod_sd[prefix + "bias"], mod_sd[prefix + "running_mean"],
             mod_sd[prefix + "running_var"], eps)
+
+
+# ---------------------------------------------------------------------------------------- training: un-packing
+def unpack_conv(dwp, weight_shape, cin_pad=None):
+    """inverse of pack_conv for the weight gradient: (Cout, Kp) -> (Cout, Cin, KH, KW)."""
+    cout, cin, kh, kw = weight_shape
+    cp = cin_pad or cin
+    return dwp[:, :kh * kw * cp].reshape(cout, kh, kw, cp)[..., :cin].permute(0, 3, 1, 2)
+
+
+def unpack_convT_s1(dwp, weight_shape):
+    """inverse of pack_convT_s1: packed (Cout, KH*KW*Cin) -> ConvTranspose2d weight gradient (Cin, Cout, KH, KW)."""
+    cin, cout, kh, kw = weight_shape
+    return dwp[:, :kh * kw * cin].reshape(cout, kh, kw, cin).flip(1, 2).permute(3, 0, 1, 2)
+
+
+def unpack_convT_s2k4_into(dweight, dwps):
+    """accumulate the 4 phase gradients (each (Cout, 4*Cin) packed) into the (Cin, Cout, 4, 4) weight gradient."""
+    cin, cout = dweight.shape[0], dweight.shape[1]
+    i = 0
+    for py in range(2):
+        for px in range(2):
+            g = dwps[i][:, :4 * cin].reshape(cout, 2, 2, cin).permute(3, 0, 1, 2)
+            dweight[:, :, (1 - py)::2, (1 - px)::2] += g
+            i += 1
+
+
+def pack_bwd_data_generic(weight):
+    """Conv2d weight (Cout, Cin, KH, KW) -> (Cin, KH*KW*Cout) pack for the data gradient run as a dil=-1 conv of dY."""
+    cout, cin, kh, kw = weight.shape
+    return _finish(weight.permute(1, 2, 3, 0), None, None)

@@ -1,0 +1,256 @@
+"""Training-mode CMM (model/cmm.py:120-161): train-mode BatchNorm (batch statistics, cmm.py:12) forward and the full
+explicit backward, composed from the NHWC implicit-GEMM conv kernels.
+
+Every conv writes its RAW output plus per-channel sum / sum-of-squares (conv epilogue); BatchNorm becomes a per-channel
+(scale, shift) that the CONSUMERS apply on load together with their LeakyReLU / ReLU -- normalised tensors are never
+materialised.  Backward walks the fixed graph in reverse: consumer data-gradient -> activation backward through the
+affine (accumulated per producer) -> BatchNorm backward through the batch statistics -> producer weight / data gradients.
+"""
+import ctypes as C
+
+import torch
+
+from .. import ops
+from .._abi import dptr, lib, check, stream
+from ..model import packing
+from .pgrm_train import colsum
+
+ACT = ops.ACT
+
+
+class T:
+    """raw NHWC tensor + optional BatchNorm affine; consumers see act(scale * r + shift)."""
+
+    def __init__(self, r, bn=None, scale=None, shift=None, mean=None, rstd=None):
+        self.r, self.bn, self.scale, self.shift, self.mean, self.rstd = r, bn, scale, shift, mean, rstd
+        self.G = None     # dL/d(scale*r+shift), accumulated over consumers
+
+    @property
+    def aff(self):
+        return None if self.scale is None else (self.scale, self.shift)
+
+    def grad_buf(self):
+        if self.G is None:
+            self.G = torch.zeros_like(self.r)
+        return self.G
+
+
+def _bn_finalize(stats, bn, count):
+    Cc = bn.weight.shape[0]
+    dev = stats.device
+    scale, shift, mean, rstd = (torch.empty(Cc, device=dev) for _ in range(4))
+    check(lib.dpmn_bn_finalize_f32(dptr(stats), dptr(bn.weight), dptr(bn.bias), float(count), float(bn.eps), float(bn.momentum),
+                                   dptr(scale), dptr(shift), dptr(mean), dptr(rstd), dptr(bn.running_mean), dptr(bn.running_var),
+                                   Cc, stream()))
+    bn.num_batches_tracked += 1
+    return scale, shift, mean, rstd
+
+
+class Unit:
+    """One convolution of the CMM graph with its (optional) BatchNorm."""
+
+    def __init__(self, kind, conv, bn, inputs, pro_act, cin_pad=None):
+        self.kind, self.conv, self.bn, self.inputs, self.pro_act, self.cin_pad = kind, conv, bn, inputs, pro_act, cin_pad
+        self.out = None
+
+    # geometry of the forward conv on the packed weights
+    def _fw(self):
+        k = self.kind
+        if k == "conv3":
+            return dict(k=3, stride=1, pad=1, dil=1)
+        if k == "conv4s2d2":
+            return dict(k=4, stride=2, pad=3, dil=2)
+        if k == "conv4s2":
+            return dict(k=4, stride=2, pad=1, dil=1)
+        if k == "convT3":
+            return dict(k=3, stride=1, pad=1, dil=1)
+        raise ValueError(k)
+
+    def forward(self):
+        w, b = self.conv.weight, self.conv.bias
+        xs = [t.r for t in self.inputs]
+        aff = [t.aff for t in self.inputs]
+        transposed = self.kind in ("convT3", "convT4s2")
+        cout = w.shape[1] if transposed else w.shape[0]
+        stats = torch.zeros(2, cout, device=w.device) if self.bn is not None else None
+        if self.kind == "convT4s2":
+            packs = packing.pack_convT_s2k4(w, b)
+            r = ops.convT_s2k4(xs, packs, cout, pro_act=self.pro_act, affine=aff, stats=stats)
+        else:
+            if self.kind == "convT3":
+                wp, bp = packing.pack_convT_s1(w, b)
+            else:
+                wp, bp = packing.pack_conv(w, b, cin_pad=self.cin_pad)
+            r = ops.conv2d(xs, wp, bp, cout, pro_act=self.pro_act, affine=aff, stats=stats, **self._fw())
+        if self.bn is not None:
+            count = r.numel() // cout
+            self.out = T(r, self.bn, *_bn_finalize(stats, self.bn, count))
+        else:
+            self.out = T(r)
+        return self.out
+
+    def backward(self, gr):
+        """Consumes self.out.G; accumulates parameter grads into gr; pushes gradients to the inputs' G buffers."""
+        o = self.out
+        w, b = self.conv.weight, self.conv.bias
+        transposed = self.kind in ("convT3", "convT4s2")
+        cout = w.shape[1] if transposed else w.shape[0]
+        G = o.G
+        pixels = G.numel() // cout
+        if self.bn is not None:
+            dr = torch.empty_like(G)
+            ws = torch.empty(2, cout, device=G.device)
+            check(lib.dpmn_bn_bwd_f32(dptr(G), dptr(o.r), dptr(self.bn.weight), dptr(o.mean), dptr(o.rstd), dptr(ws), dptr(dr),
+                                      dptr(gr[self.bn.weight]), dptr(gr[self.bn.bias]), pixels, cout, stream()))
+        else:
+            dr = G
+        colsum(dr.reshape(pixels, cout), gr[b])
+        cout_real = cout
+        if cout % 4 != 0:   # de_1 (Cout = 3): pad the output-gradient channels so NHWC rows stay 16-byte aligned
+            cout = (cout + 3) // 4 * 4
+            dr = torch.cat([dr, dr.new_zeros(*dr.shape[:3], cout - cout_real)], dim=3)
+        xs = [t.r for t in self.inputs]
+        aff = [t.aff for t in self.inputs]
+        cin = sum(x.shape[3] for x in xs)
+        dev = dr.device
+        # ---- weight gradient
+        if self.kind == "convT4s2":
+            dwps = []
+            for py in range(2):
+                for px in range(2):
+                    d = ops.conv_desc(xs, 2, cout=cout, pro_act=self.pro_act, affine=aff, phase=(py, px))
+                    dwp = torch.zeros(cout, (4 * cin + 31) // 32 * 32, device=dev)
+                    check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dr), dptr(dwp), stream()))
+                    dwps.append(dwp)
+            packing.unpack_convT_s2k4_into(gr[w], dwps)
+        else:
+            f = self._fw()
+            d = ops.conv_desc(xs, f["k"], f["stride"], f["pad"], f["dil"], cout=cout, pro_act=self.pro_act, affine=aff)
+            dwp = torch.zeros(cout, (f["k"] * f["k"] * cin + 31) // 32 * 32, device=dev)
+            check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dr), dptr(dwp), stream()))
+            if self.kind == "convT3":
+                gr[w] += packing.unpack_convT_s1(dwp[:cout_real], w.shape)
+            else:
+                gr[w] += packing.unpack_conv(dwp, w.shape, self.cin_pad)
+        # ---- data gradients, one launch per input segment, then activation backward through the producer's affine
+        c0 = 0
+        for t in self.inputs:
+            cs = t.r.shape[3]
+            if t.G is False:       # leaf that needs no gradient
+                c0 += cs
+                continue
+            B, Hi, Wi, _ = t.r.shape
+            if self.kind == "conv3":
+                wt, _ = packing.pack_convT_s1(w[:, c0:c0 + cs])
+                dA = ops.conv2d([dr], wt, None, cs, 3, pad=1)
+            elif self.kind == "convT3":
+                wt, _ = packing.pack_conv(w[c0:c0 + cs], cin_pad=cout)   # (Cin_seg, Cout, 3, 3) seen as Conv2d (out=Cin_seg, in=Cout)
+                dA = ops.conv2d([dr], wt, None, cs, 3, pad=1)
+            elif self.kind == "convT4s2":
+                wt, _ = packing.pack_conv(w[c0:c0 + cs])
+                dA = ops.conv2d([dr], wt, None, cs, 4, stride=2, pad=1)
+            elif self.kind == "conv4s2":
+                packs = packing.pack_convT_s2k4(w[:, c0:c0 + cs])  # Conv2d weight (Cout, Cin, 4, 4) seen as ConvTranspose (in=Cout, out=Cin)
+                dA = ops.convT_s2k4([dr], packs, cs)
+            elif self.kind == "conv4s2d2":
+                # iy = 2*oy + 2*ky - 3 is always odd: dX[2s+1] = sum_ky dY[s + 2 - ky] W[ky]; even pixels get zero gradient
+                wt, _ = packing.pack_bwd_data_generic(w[:, c0:c0 + cs])
+                dA = torch.zeros(B, Hi, Wi, cs, device=dev)
+                Ho, Wo = dr.shape[1], dr.shape[2]
+                geom = dict(stride=1, dil_y=-1, dil_x=-1, pad_y=-2, pad_x=-2, Hp=Hi // 2, Wp=Wi // 2, Hout=Hi, Wout=Wi, ostep=2, ooy=1, oox=1)
+                ops.conv2d([dr], wt, None, cs, 4, out=dA, geom=geom)
+            else:
+                raise ValueError(self.kind)
+            sc, sh = (t.scale, t.shift) if t.scale is not None else (None, None)
+            Gt = t.grad_buf()
+            check(lib.dpmn_affine_act_bwd_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(Gt), 1,
+                                              t.r.numel() // cs, cs, stream()))
+            c0 += cs
+
+
+def build(m, x1, x2):
+    """Forward in training mode; returns (out NCHW, graph) where graph lists the units in execution order."""
+    units = []
+
+    def run(kind, conv, bn, inputs, act, cin_pad=None):
+        u = Unit(kind, conv, bn, inputs, act, cin_pad)
+        units.append(u)
+        return u.forward()
+
+    enc, leaves = [], []
+    for br, x in (("1", x1), ("2", x2)):
+        leaf = T(ops.nchw_to_nhwc(x.contiguous().float(), 4))
+        leaves.append(leaf)
+        o = [run("conv3", getattr(m, "en_1_" + br), None, [leaf], "none", cin_pad=4)]
+        for lvl in (2, 3, 4, 5):
+            seq = getattr(m, "en_%d_%s" % (lvl, br)).encode
+            t = run("conv4s2d2", seq[1], seq[2], [o[-1]], "leaky02")
+            o.append(run("conv3", seq[4], seq[5], [t], "leaky02"))
+        o.append(run("conv4s2", getattr(m, "en_6_" + br)[1], None, [o[-1]], "leaky02"))
+        enc.append(o)
+    a, b = enc
+    bott = torch.cat([a[5].r, b[5].r], dim=3)
+    gated = T(ops.se_gate(bott, m.fc_1.weight, m.fc_1.bias, m.fc_2.weight, m.fc_2.bias))
+    d = run("convT4s2", m.de_6[1], m.de_6[2], [gated], "relu")
+    for lvl, skip in ((5, 4), (4, 3), (3, 2), (2, 1)):
+        seq = getattr(m, "de_%d" % lvl).decode
+        t = run("convT3", seq[1], seq[2], [d, a[skip], b[skip]], "relu")
+        d = run("convT4s2", seq[4], seq[5], [t], "relu")
+    last = Unit("convT3", m.de_1[1], None, [d, a[0], b[0]], "relu")
+    units.append(last)
+    wp, bp = packing.pack_convT_s1(m.de_1[1].weight, m.de_1[1].bias)
+    out = ops.conv2d([d.r, a[0].r, b[0].r], wp, bp, m.c_img, 3, pad=1, pro_act="relu", affine=[d.aff, a[0].aff, b[0].aff], out_nchw=True)
+    last.out = T(None)
+    return out, dict(units=units, bott=bott, gated=gated, enc=enc, leaves=leaves, last=last)
+
+
+def backward(m, graph, dout, need_dx=(True, True)):
+    gr = {p: torch.zeros_like(p) for p in m.parameters()}
+    units, last = graph["units"], graph["last"]
+    a, b = graph["enc"]
+    for leaf, need in zip(graph["leaves"], need_dx):
+        if not need:
+            leaf.G = False
+    # de_1: output was stored NCHW with 3 channels -> NHWC for the backward kernels
+    B, Cc, H, W = dout.shape
+    last.out.G = dout.permute(0, 2, 3, 1).contiguous()     # layout plumbing of a (B,3,32,128) tensor
+    last.out.r = last.out.G
+    for u in reversed(units):
+        if u is last or u.out.G is not None:
+            if u.kind == "convT4s2" and u.inputs[0] is graph["gated"]:
+                pass
+            u.backward(gr)
+        if u.inputs and u.inputs[0] is graph["gated"]:
+            # channel gate backward, then split the bottleneck gradient into the two en_6 outputs
+            g = graph["gated"]
+            dbott = torch.empty_like(graph["bott"])
+            check(lib.dpmn_se_gate_bwd_f32(dptr(graph["bott"]), dptr(g.G), dptr(m.fc_1.weight), dptr(m.fc_1.bias), dptr(m.fc_2.weight),
+                                           dptr(m.fc_2.bias), dptr(dbott), dptr(gr[m.fc_1.weight]), dptr(gr[m.fc_1.bias]),
+                                           dptr(gr[m.fc_2.weight]), dptr(gr[m.fc_2.bias]), dbott.shape[0], dbott.shape[1] * dbott.shape[2],
+                                           dbott.shape[3], m.fc_1.weight.shape[0], stream()))
+            half = dbott.shape[3] // 2
+            a[5].G = dbott[..., :half].contiguous()
+            b[5].G = dbott[..., half:].contiguous()
+    dxs = []
+    for leaf, need in zip(graph["leaves"], need_dx):
+        dxs.append(ops.nhwc_to_nchw(leaf.G)[:, :3].contiguous() if need else None)
+    return dxs, gr
+
+
+class CMMFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, m, x1, x2, *params):
+        out, graph = build(m, x1, x2)
+        ctx.m, ctx.graph = m, graph
+        ctx.need = (x1.requires_grad, x2.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dxs, gr = backward(ctx.m, ctx.graph, dout.contiguous(), ctx.need)
+        ctx.graph = None
+        return (None, dxs[0], dxs[1]) + tuple(gr[p] for p in ctx.m.parameters())
+
+
+def apply(m, x1, x2):
+    return CMMFunction.apply(m, x1, x2, *list(m.parameters()))
