@@ -107,6 +107,11 @@ SIGNATURES = {
     "dpmn_affine_act_bwd_f32": (_i, [fp, fp, fp, fp, _i, fp, _i, C.c_long, _i, fp]),
     "dpmn_bn_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_long, _i, fp]),
     "dpmn_se_gate_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_affine_act_fwd_f32": (_i, [fp, fp, fp, _i, fp, C.c_long, _i, fp]),
+    "dpmn_l1_loss_fwd_f32": (_i, [fp, fp, _f, fp, fp, C.c_long, fp]),
+    "dpmn_l1_loss_bwd_f32": (_i, [fp, fp, fp, _f, fp, fp, fp, C.c_long, fp]),
+    "dpmn_sumsq_f32": (_i, [fp, fp, fp, C.c_long, fp]),
+    "dpmn_adam_clip_f32": (_i, [fp, fp, fp, fp, fp, _f, _f, _f, _f, _f, _i, C.c_long, fp]),
     "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

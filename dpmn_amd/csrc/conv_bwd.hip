@@ -259,6 +259,68 @@ __global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ x
   for (int i = tid; i < P * C; i += 256) db_[i] = gb[i] * (1.f + Wg[i % C]) + dSm[i % C];
 }
 
+// ---------------------------------------------------------------------------------- DistillModule tail + optimizer
+// f = relu(scale*r + shift) on NHWC (pixels, C) ; distill_module.py:21-27
+__global__ void k_affine_act_fwd(const float* __restrict__ r, const float* __restrict__ scale, const float* __restrict__ shift,
+                                 int act, float* __restrict__ y, long pixels, int C) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pixels * C) return;
+  const int c = idx % C;
+  const float z = scale ? r[idx] * scale[c] + shift[c] : r[idx];
+  y[idx] = apply_act(z, act, 0.f);
+}
+// L1 between two feature maps: part[blk] = sum |a-b| ; optional gradient kernel below
+__global__ __launch_bounds__(256) void k_l1_partial(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+                                                     long n) {
+  __shared__ float red[4];
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  float v = i < n ? fabsf(a[i] - b[i]) : 0.f;
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void k_sum_final(const float* __restrict__ part, int n, float mul, float* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 64) s += part[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) out[0] = (float)(s * mul);
+}
+// da = gs*c*sign(a-b) (+ extra) ; db = -gs*c*sign(a-b)
+__global__ void k_l1_bwd(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ gscale, float c,
+                         const float* __restrict__ extra_a, float* __restrict__ da, float* __restrict__ db, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float d = a[i] - b[i];
+  const float g = gscale[0] * c * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+  da[i] = g + (extra_a ? extra_a[i] : 0.f);
+  db[i] = -g;
+}
+// sum of squares of a flat buffer -> part[blk]; final: out[0] = sum
+__global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__ x, float* __restrict__ part, long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) { const float v = x[i]; s += v * v; }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// clip_grad_norm_(max_norm) + Adam (torch.optim.Adam semantics, no weight decay / amsgrad); normsq[0] = ||g||^2
+__global__ void k_adam_clip(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ normsq, float max_norm, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float coef = 1.f;
+  if (max_norm > 0.f) { coef = max_norm / (sqrtf(normsq[0]) + 1e-6f); coef = coef < 1.f ? coef : 1.f; }
+  const float gi = g[i] * coef;
+  const float mi = b1 * m[i] + (1.f - b1) * gi;
+  const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  p[i] -= (lr / bc1) * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+
 }  // namespace
 
 extern "C" {
@@ -331,6 +393,55 @@ int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, co
   DPMN_REQUIRE(x && dg && fc1_w && fc1_b && fc2_w && fc2_b && dx && dfc1_w && dfc1_b && dfc2_w && dfc2_b && B > 0, "se_gate_bwd: bad arguments");
   hipLaunchKernelGGL(k_se_gate_bwd, dim3(B), dim3(256), (size_t)(4 * C + 2 * Cmid) * 4, as_stream(stream), x, dg, fc1_w, fc1_b, fc2_w,
                      fc2_b, dx, dfc1_w, dfc1_b, dfc2_w, dfc2_b, P, C, Cmid);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_affine_act_fwd_f32(const float* r, const float* scale, const float* shift, int act, float* y, long pixels, int C,
+                            dpmn_stream_t stream) {
+  DPMN_REQUIRE(r && y && pixels > 0 && C > 0, "affine_act_fwd: bad arguments");
+  const long total = pixels * C;
+  hipLaunchKernelGGL(k_affine_act_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), r, scale, shift, act, y, pixels, C);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_l1_loss_fwd_f32(const float* a, const float* b, float inv_count, float* loss, float* part_ws, long n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(a && b && loss && part_ws && n > 0, "l1_loss_fwd: bad arguments (part_ws: ceil(n/256) floats)");
+  const int nb = (int)((n + 255) / 256);
+  hipLaunchKernelGGL(k_l1_partial, dim3(nb), dim3(256), 0, as_stream(stream), a, b, part_ws, n);
+  DPMN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, as_stream(stream), part_ws, nb, inv_count, loss);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_l1_loss_bwd_f32(const float* a, const float* b, const float* grad_scale, float inv_count, const float* extra_a, float* da,
+                         float* db, long n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(a && b && grad_scale && da && db && n > 0, "l1_loss_bwd: bad arguments");
+  hipLaunchKernelGGL(k_l1_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), a, b, grad_scale, inv_count, extra_a, da, db, n);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_sumsq_f32(const float* x, float* out, float* part_ws, long n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && out && part_ws && n > 0, "sumsq: bad arguments (part_ws: 1024 floats)");
+  const int nb = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  hipLaunchKernelGGL(k_sumsq_partial, dim3(nb), dim3(256), 0, as_stream(stream), x, part_ws, n);
+  DPMN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_sum_final, dim3(1), dim3(64), 0, as_stream(stream), part_ws, nb, 1.0f, out);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_adam_clip_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* grad_normsq, float max_norm,
+                       float lr, float beta1, float beta2, float eps, int step, long n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_clip: bad arguments");
+  DPMN_REQUIRE(max_norm <= 0.f || grad_normsq, "adam_clip: grad_normsq required when clipping");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(k_adam_clip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
+                     grad_normsq, max_norm, lr, beta1, beta2, eps, bc1, bc2s, n);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -245,6 +245,18 @@ int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, co
                          const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b, int B,
                          int P, int C, int Cmid, dpmn_stream_t stream);
 
+/* DistillModule pieces (distill_module.py:18-31): y = act(scale*r+shift); L1 loss forward / backward */
+int dpmn_affine_act_fwd_f32(const float* r, const float* scale, const float* shift, int act, float* y, long pixels, int C,
+                            dpmn_stream_t stream);
+int dpmn_l1_loss_fwd_f32(const float* a, const float* b, float inv_count, float* loss, float* part_ws, long n, dpmn_stream_t stream);
+int dpmn_l1_loss_bwd_f32(const float* a, const float* b, const float* grad_scale, float inv_count, const float* extra_a,
+                         float* da, float* db, long n, dpmn_stream_t stream);
+/* optimizer (super_resolution.py:272-278, base.py:221): ||g||^2 of a flat gradient bucket, then
+ * clip_grad_norm_(max_norm) fused with torch.optim.Adam's update on flat (param, grad, exp_avg, exp_avg_sq) buffers */
+int dpmn_sumsq_f32(const float* x, float* out, float* part_ws, long n, dpmn_stream_t stream);
+int dpmn_adam_clip_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* grad_normsq,
+                       float max_norm, float lr, float beta1, float beta2, float eps, int step, long n, dpmn_stream_t stream);
+
 /* ------------------------------------------------------------------ PGRM module (pgrm_forward.hip) */
 typedef struct {
   const float *norm1_q_w, *norm1_q_b, *norm1_kv_w, *norm1_kv_b;

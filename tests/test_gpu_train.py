@@ -136,3 +136,56 @@ def test_cmm_train_forward_backward_vs_oracle_autograd(dev, cnum):
     assert_close(bn.running_mean, rm, 1e-5, 1e-4, "running_mean")
     assert_close(bn.running_var, rv, 1e-5, 1e-4, "running_var")
     assert int(bn.num_batches_tracked) == 1
+
+
+def test_distill_module_train_vs_oracle_autograd(dev):
+    from dpmn_amd.model.distill_module import DistillModule
+    from oracle import cmm as ocmm
+    from helpers import load_golden
+    B = 4
+    m = DistillModule()
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(r).split("|")[0] for r in load_golden("distill")["manifest"]]
+    synth.synth_fill_(sd, 32)
+    m.load_state_dict(sd)
+    xd, xs = u("xd", (B, 3, 32, 128), 0, 1), u("xs", (B, 3, 32, 128), 0, 1)
+    cot = u("cotf", (B, 3, 32, 128), -0.01, 0.01)
+    sd_ref = {k: v.clone().requires_grad_(torch.is_floating_point(v) and "running" not in k) for k, v in sd.items()}
+    xdr, xsr = xd.clone().requires_grad_(True), xs.clone().requires_grad_(True)
+    loss_ref, feat_ref = ocmm.distill_forward(sd_ref, xdr, xsr, True)
+    (loss_ref * 100 + (feat_ref * cot).sum()).backward()
+    m = m.to(dev).train()
+    xdd, xsd = xd.to(dev).requires_grad_(True), xs.to(dev).requires_grad_(True)
+    loss, feat = m(xdd, xsd)
+    assert abs(float(loss) - float(loss_ref)) < 1e-5
+    assert_close(feat, feat_ref.detach(), 1e-4, 1e-4, "distill feature")
+    (loss * 100 + (feat * cot.to(dev)).sum()).backward()
+    assert l2_err(xdd.grad, xdr.grad) < 2e-2 and l2_err(xsd.grad, xsr.grad) < 2e-2
+    for name, p in m.named_parameters():
+        g_ref = sd_ref[name].grad
+        if float(g_ref.abs().max()) < 2e-3:
+            assert float(p.grad.abs().max()) < 5e-3, name
+        else:
+            assert l2_err(p.grad, g_ref) < 2e-2, name
+
+
+def test_clip_adam_matches_torch(dev):
+    from dpmn_amd.train.optim import FlatBucket
+    lin = torch.nn.Sequential(torch.nn.Linear(40, 30), torch.nn.Linear(30, 7))
+    ref = torch.nn.Sequential(torch.nn.Linear(40, 30), torch.nn.Linear(30, 7))
+    ref.load_state_dict(lin.state_dict())
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    lin = lin.to(dev)
+    b = FlatBucket(lin)
+    for step in range(1, 4):
+        gs = [u("g%d_%d" % (step, i), p.shape, -1, 1) for i, p in enumerate(ref.parameters())]
+        for p, g in zip(ref.parameters(), gs):
+            p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.25)
+        opt.step()
+        b.zero_grad()
+        for p, g in zip(lin.parameters(), gs):
+            p.grad += g.to(dev)
+        b.step(step, 1e-3, 0.5)
+        for p, q in zip(lin.parameters(), ref.parameters()):
+            assert_close(p.detach(), q.detach(), 1e-6, 1e-5, "adam step %d" % step)
