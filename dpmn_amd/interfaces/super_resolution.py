@@ -97,9 +97,86 @@ class TextSR(base.TextBase):
         ssim_avg = float(torch.stack(ssim).mean().item())
         return {'psnr': psnr, 'ssim': ssim, 'accuracy': 0.0, 'psnr_avg': round(psnr_avg, 6), 'ssim_avg': round(ssim_avg, 6)}
 
-    def train(self):
-        raise NotImplementedError("dpmn_amd: the training step (loss + backward kernels + RCCL gradient all-reduce) is the "
-                                  "next scope row (DESIGN.md section (f)); round 1 ships the forward/eval path")
+    # ------------------------------------------------------------------ training (super_resolution.py:113-278)
+    def build_training(self, world_size=1, group=None):
+        """models (PGRMs + CMM), frozen PSN, DistillModules, ImageLoss and the flat-bucket clip+Adam / all-reduce trainer."""
+        from ..loss.image_loss import ImageLoss
+        from ..model.distill_module import DistillModule
+        from ..train.optim import Trainer
+        models, psn = self.build_models()
+        b1, b2 = self.args.stu_iter_b1, self.args.stu_iter_b2
+        distill = [DistillModule().to(self.device) for _ in range(b1 + b2 - 2)]
+        crit = ImageLoss(gradient=self.args.gradient, loss_weight=[1, 1])
+        cfg = self.config.TRAIN
+        trainer = Trainer(models + distill, lr=cfg.lr, beta1=cfg.beta1, max_norm=0.25, world_size=world_size, group=group)
+        for m in models + distill:
+            m.train()
+            for p in m.parameters():
+                p.requires_grad = True
+        return models, psn, distill, crit, trainer
+
+    def train_step(self, models, psn, distill, crit, trainer, images_lr, images_hr, label_vecs=None, text_priors=None,
+                   text_prior_fn=None):
+        """One optimisation step = super_resolution.py:140-278 (loss sum / (b1+b2+1), per-model clip 0.25, Adam)."""
+        b1, b2 = self.args.stu_iter_b1, self.args.stu_iter_b2
+        share = self.args.sr_share
+        trainer.zero_grad()
+        hr3 = images_hr[:, :3, :]
+        with torch.no_grad():
+            if self.args.arch in ('tsrn', 'tbsrn', 'tg'):
+                images_lr_psn = psn(images_lr)
+            else:
+                images_lr_psn, _ = psn(images_lr, label_vecs)
+        loss = 0
+        cascade, br1 = images_lr_psn, []
+        for k in range(b1):
+            x_q = text_priors[k] if text_priors is not None else text_prior_fn(cascade.detach(), k)
+            sr = models[0 if share else k](x_q, cascade[:, :3, :], br1[:k])
+            br1.append(sr)
+            cascade = sr
+            loss = loss + crit(sr, hr3).mean() * 100
+        cascade, br2 = images_lr_psn, []
+        for k in range(b1, b1 + b2):
+            with torch.no_grad():
+                x_q = ops.to_mask(cascade.detach())      # toMask is not differentiable (PIL round trip in the reference)
+            sr = models[0 if share else k](x_q, cascade[:, :3, :], br2[:(k - b2)])
+            br2.append(sr)
+            cascade = sr
+            loss = loss + crit(sr, hr3).mean() * 100
+        feat = br1[-1]
+        for k in range(b1 - 1, 0, -1):
+            ld, feat = distill[k - 1](feat, br1[k - 1])
+            loss = loss + ld.sum() * 100
+        feat = br2[-1]
+        for k in range(b2 - 1, 0, -1):
+            ld, feat = distill[k + b1 - 2](feat, br2[k - 1])
+            loss = loss + ld.sum() * 100
+        sr = models[-1](br1[-1], br2[-1])
+        loss = loss + crit(sr, hr3).mean() * 100
+        loss = loss / (b1 + b2 + 1)
+        loss.backward()
+        trainer.step()
+        return loss.detach()
+
+    def train(self, loader=None, steps=None):
+        """Training loop over a loader of (images_hr, images_lr, label_vecs) batches (the TextZoom LMDB reader and the
+        recogniser-driven text priors are out of scope: synthetic batches / priors by default)."""
+        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        models, psn, distill, crit, trainer = self.build_training(world)
+        fn = self.synthetic_text_prior()
+        if loader is None:
+            raise RuntimeError("dpmn_amd: pass a loader of (images_hr, images_lr, label_vecs) batches")
+        it = 0
+        for data in loader:
+            hr, lr = data[0].to(self.device), data[1].to(self.device)
+            lv = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
+            loss = self.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_prior_fn=fn)
+            it += 1
+            if it % self.config.TRAIN.displayInterval == 0:
+                print('iter %d | Loss: %f' % (it, float(loss)))
+            if steps is not None and it >= steps:
+                break
+        return models, distill
 
     def test(self, loader=None):
         models, psn = self.build_models(testing=bool(self.resume))

@@ -6,6 +6,8 @@ import torch
 
 from .utils import synth
 
+CONFIGS_TRAIN = {"cfg2": "cfg1"}   # config 2 = the training step on config 1's stack
+
 CONFIGS = {
     # name: (arch, b1, b2, per-GPU batch)
     "cfg0": ("tsrn", 1, 1, 4),    # TSRN + 1+1 PGRM, B=4 (the reference's CPU-runnable plumbing case)

@@ -189,3 +189,68 @@ def test_clip_adam_matches_torch(dev):
         b.step(step, 1e-3, 0.5)
         for p, q in zip(lin.parameters(), ref.parameters()):
             assert_close(p.detach(), q.detach(), 1e-6, 1e-5, "adam step %d" % step)
+
+
+def test_full_train_step_vs_oracle_autograd(dev):
+    """TSRN PSN + 2+2 PGRM + 2 DistillModules + CMM, B=2: loss value and every parameter after ONE step
+    (zero_grad -> forward -> loss -> backward -> per-model clip 0.25 -> Adam) vs torch autograd on the CPU oracle."""
+    from types import SimpleNamespace
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    from oracle import dpmn as odpmn, pgrm as opgrm, cmm as ocmm, tsrn as otsrn
+    B, b1, b2 = 2, 2, 2
+    sr_ = TextSR(workload.make_config(B), workload.make_args("tsrn", b1, b2, B))
+    models, psn, distill, crit, trainer = sr_.build_training()
+    for i, m in enumerate([psn] + models + distill):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, 300 + i)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                v.copy_(sd[k])
+    psn.eval()
+    sd0 = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in [psn] + models + distill]
+    batch = synth.synth_batch(B, seed=4)
+    priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)) for k in range(b1)]
+    loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev), None,
+                          text_priors=[p.to(dev) for p in priors])
+    # ---- oracle step on the CPU
+    ref = [{k: v.clone().requires_grad_(torch.is_floating_point(v) and "running" not in k and "index" not in k and "mask" not in k)
+            for k, v in sd.items()} for sd in sd0]
+    with torch.no_grad():
+        lr_psn = otsrn.tsrn_forward(sd0[0], batch["images_lr"])
+    hr3 = batch["images_hr"][:, :3]
+    tot, casc, l1, l2 = 0, lr_psn, [], []
+    for k in range(b1):
+        o = opgrm.pgrm_forward(ref[1 + k], priors[k], casc[:, :3], l1[:k]); l1.append(o); casc = o
+        tot = tot + ocmm.image_loss(o, hr3, True) * 100
+    casc = lr_psn
+    for k in range(b1, b1 + b2):
+        o = opgrm.pgrm_forward(ref[1 + k], ocmm.to_mask(casc.detach()[:, :3]), casc[:, :3], l2[:k - b2]); l2.append(o); casc = o
+        tot = tot + ocmm.image_loss(o, hr3, True) * 100
+    nm = 1 + b1 + b2 + 1
+    feat = l1[-1]
+    for k in range(b1 - 1, 0, -1):
+        ld, feat = ocmm.distill_forward(ref[nm + k - 1], feat, l1[k - 1], True); tot = tot + ld * 100
+    feat = l2[-1]
+    for k in range(b2 - 1, 0, -1):
+        ld, feat = ocmm.distill_forward(ref[nm + k + b1 - 2], feat, l2[k - 1], True); tot = tot + ld * 100
+    o = ocmm.cmm_forward(ref[1 + b1 + b2], l1[-1], l2[-1], True)
+    tot = (tot + ocmm.image_loss(o, hr3, True) * 100) / (b1 + b2 + 1)
+    tot.backward()
+    assert abs(float(loss) - float(tot)) < 2e-4 * abs(float(tot)), (float(loss), float(tot))
+    # gradients of every model vs oracle autograd (the fused clip+Adam kernel is pinned separately above; comparing
+    # Adam's first, sign-like update would amplify round-off on near-zero gradients)
+    mods = models + distill
+    for i, m in enumerate(mods):
+        rsd = ref[1 + i]
+        num, den, worst = 0.0, 0.0, ("", 0.0)
+        for n, p_ in m.named_parameters():
+            g_ref = rsd[n].grad if rsd[n].grad is not None else torch.zeros_like(rsd[n])
+            d = (p_.grad.detach().cpu().double() - g_ref.double())
+            num += float((d * d).sum()); den += float((g_ref.double() ** 2).sum())
+            if float(g_ref.abs().max()) > 1e-3:
+                e = float(d.norm() / g_ref.double().norm())
+                worst = max(worst, (n, e), key=lambda t_: t_[1])
+        tot_err = (num / max(den, 1e-30)) ** 0.5
+        print("model %d: whole-gradient L2 err %.2e, worst tensor %s %.2e" % (i, tot_err, worst[0], worst[1]))
+        assert tot_err < 2e-2, "model %d gradient differs from oracle autograd: %.3e (%s %.3e)" % (i, tot_err, worst[0], worst[1])
