@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
+                    help="fwd: BASELINE.json configs[1] (headline metric); train: configs[2] step (loss, backward, clip+Adam, RCCL all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     return ap.parse_args()
@@ -120,8 +122,24 @@ def main():
     B = inp["images_lr"].shape[0]
     arch, b1, b2, _ = workload.CONFIGS[args.workload]
 
-    def step():
-        return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
+    if args.mode == "train":
+        from dpmn_amd.loss.image_loss import ImageLoss
+        from dpmn_amd.model.distill_module import DistillModule
+        from dpmn_amd.train.optim import Trainer
+        distill = [DistillModule().to(sr.device) for _ in range(b1 + b2 - 2)]
+        crit = ImageLoss(gradient=True, loss_weight=[1, 1])
+        for m in models + distill:
+            m.train()
+            for p in m.parameters():
+                p.requires_grad = True
+        trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=world)
+
+        def step():
+            return sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
+                                 text_priors=inp["text_priors"])
+    else:
+        def step():
+            return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
 
     for _ in range(args.warmup):
         step()
@@ -143,13 +161,16 @@ def main():
         elapsed = float(tt.item())
     if rank == 0:
         line = {
-            "metric": "SR images/sec (16x64->32x128, bs=48 per GPU, fp32 forward)",
+            "metric": "SR images/sec (16x64->32x128, bs=48 per GPU, fp32 %s)" % ("forward" if args.mode == "fwd" else "training step"),
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s PSN + %d+%d PGRM (embed 96, windows 2/4/8) + CMM, forward-only" % (
-                args.workload, arch.upper(), b1, b2), "per_gpu_batch": B, "global_batch": B * world,
-                "parallelism": "dp%d (independent batch shards, no forward collective)" % world},
+            "config": {"workload": "%s: %s PSN + %d+%d PGRM (embed 96, windows 2/4/8) + CMM, %s" % (
+                args.workload, arch.upper(), b1, b2,
+                "forward-only" if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"),
+                "per_gpu_batch": B, "global_batch": B * world,
+                "parallelism": ("dp%d (independent batch shards, no forward collective)" % world) if args.mode == "fwd" else
+                               ("dp%d (per-model flat gradient buckets, RCCL all-reduce overlapped with backward)" % world)},
         }
         line["roofline"] = roofline_pw(B)
         line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.workload, args.cpu_sample)
