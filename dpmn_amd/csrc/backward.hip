@@ -91,15 +91,28 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, i
     }
 }
 
-// db[n] += sum_m dy[m][n]; block = 32 rows-groups x columns
+// db[n] += sum_m dy[m][n].  Block = 256 threads over a (rows_per_block x N) slab: thread -> (row lane = tid / cols4,
+// float4 column = tid % cols4); LDS reduction over the row lanes, one atomic per column per block.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, int ldy, float* __restrict__ db, long M, int N,
                                                  int rows_per_block) {
+  __shared__ float4 red[256];
+  const int cols4 = (N + 3) / 4;                       // N % 4 == 0 for every caller
+  const int lanes = 256 / cols4 > 0 ? 256 / cols4 : 1; // row lanes per column group
+  const int cg = threadIdx.x % cols4, rl = threadIdx.x / cols4;
   const long m_lo = (long)blockIdx.x * rows_per_block;
   const long m_hi = m_lo + rows_per_block < M ? m_lo + rows_per_block : M;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    float s = 0.f;
-    for (long m = m_lo; m < m_hi; ++m) s += dy[m * ldy + n];
-    atomicAdd(db + n, s);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rl < lanes && cg * 4 < N && cols4 <= 256)
+    for (long m = m_lo + rl; m < m_hi; m += lanes) {
+      const float4 v = *reinterpret_cast<const float4*>(dy + m * ldy + cg * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && cg * 4 < N) {
+    float4 a = red[cg];
+    for (int r = 1; r < lanes; ++r) { const float4 v = red[r * cols4 + cg]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    atomicAdd(db + cg * 4, a.x); atomicAdd(db + cg * 4 + 1, a.y); atomicAdd(db + cg * 4 + 2, a.z); atomicAdd(db + cg * 4 + 3, a.w);
   }
 }
 
@@ -280,8 +293,8 @@ int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, int M, int N, i
 }
 
 int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream) {
-  DPMN_REQUIRE(dy && db && M > 0 && N > 0, "colsum: bad arguments");
-  const int rows = 128;
+  DPMN_REQUIRE(dy && db && M > 0 && N > 0 && N % 4 == 0 && N <= 1024, "colsum: N must be a multiple of 4 (<= 1024)");
+  const int rows = 256;
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, as_stream(stream), dy, N, db, M, N, rows);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;

@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int PAD = 4, BK = 32, LDK = BK + PAD;
+constexpr int STAT_SLOTS = 32;   // BatchNorm statistics are accumulated into (STAT_SLOTS, 2, Cout) and summed by bn_finalize
 
 struct ConvArgs {
   const float* in[3];
@@ -246,31 +247,60 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
         q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
         if (lr == 0 && n + r < a.Cout) {
-          atomicAdd(a.stats + n + r, s);
-          atomicAdd(a.stats + a.Cout + n + r, q);
+          float* st = a.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;   // slotted: spreads same-address atomics
+          atomicAdd(st + n + r, s);
+          atomicAdd(st + a.Cout + n + r, q);
         }
       }
     }
   }
 }
 
-// sum the split-K partials and run the epilogue; thread = (pixel, 4 channels)
+// sum the split-K partials and run the epilogue.  Block = 64 channel-quads x 4 row lanes, 64 rows per block, so the
+// BatchNorm statistics are reduced over 64 rows in registers / LDS before one (slotted) atomic per channel.
 __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a) {
+  __shared__ float red[4][64][8];
   const int M = a.B * a.Hp * a.Wp;
   const int n4 = a.npad / 4;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)M * n4) return;
-  const int m = idx / n4, n = (idx % n4) * 4;
-  float v[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int z = 0; z < a.ksplit; ++z) {
-    const float4 p = *reinterpret_cast<const float4*>(a.partial + ((size_t)z * M + m) * a.npad + n);
-    v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
-  }
+  const int cq = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int n = cq * 4;
+  const int m_lo = blockIdx.y * 64;
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-  conv_store(a, m, n, v, ssum, ssq);
+  const size_t zs = (size_t)M * a.npad;
+  if (cq < n4) {
+    for (int m = m_lo + rl; m < m_lo + 64 && m < M; m += 4) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* pp = a.partial + (size_t)m * a.npad + n;
+      int z = 0;
+      for (; z + 4 <= a.ksplit; z += 4) {     // 4 independent loads in flight
+        const float4 p0 = *reinterpret_cast<const float4*>(pp + (size_t)z * zs);
+        const float4 p1 = *reinterpret_cast<const float4*>(pp + (size_t)(z + 1) * zs);
+        const float4 p2 = *reinterpret_cast<const float4*>(pp + (size_t)(z + 2) * zs);
+        const float4 p3 = *reinterpret_cast<const float4*>(pp + (size_t)(z + 3) * zs);
+        v[0] += (p0.x + p1.x) + (p2.x + p3.x); v[1] += (p0.y + p1.y) + (p2.y + p3.y);
+        v[2] += (p0.z + p1.z) + (p2.z + p3.z); v[3] += (p0.w + p1.w) + (p2.w + p3.w);
+      }
+      for (; z < a.ksplit; ++z) {
+        const float4 p = *reinterpret_cast<const float4*>(pp + (size_t)z * zs);
+        v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+      }
+      conv_store(a, m, n, v, ssum, ssq);
+    }
+  }
   if (a.stats) {
-    for (int r = 0; r < 4; ++r)
-      if (n + r < a.Cout) { atomicAdd(a.stats + n + r, ssum[r]); atomicAdd(a.stats + a.Cout + n + r, ssq[r]); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[rl][threadIdx.x & 63][r] = ssum[r]; red[rl][threadIdx.x & 63][4 + r] = ssq[r]; }
+    __syncthreads();
+    if (rl == 0 && cq < n4) {
+      float* st = a.stats + (size_t)(blockIdx.y % STAT_SLOTS) * 2 * a.Cout;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.Cout) {
+          const int c = threadIdx.x & 63;
+          atomicAdd(st + n + r, red[0][c][r] + red[1][c][r] + red[2][c][r] + red[3][c][r]);
+          atomicAdd(st + a.Cout + n + r, red[0][c][4 + r] + red[1][c][4 + r] + red[2][c][4 + r] + red[3][c][4 + r]);
+        }
+    }
   }
 }
 
@@ -442,7 +472,10 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
         float s_ = ssum[i][r], q = ssq[i][r];
         s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64); s_ += __shfl_xor(s_, 8, 64);
         q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
-        if (lr == 0 && n + r < a.Cout) { atomicAdd(a.stats + n + r, s_); atomicAdd(a.stats + a.Cout + n + r, q); }
+        if (lr == 0 && n + r < a.Cout) {
+          float* st = a.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
+          atomicAdd(st + n + r, s_); atomicAdd(st + a.Cout + n + r, q);
+        }
       }
     }
   }
@@ -473,7 +506,8 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     S = cdiv(768, tiles);
     if (S > nk / 8) S = nk / 8;
     if (S > 64) S = 64;
-    while (S > 1 && (size_t)S * M * a.npad * sizeof(float) > ws_bytes) --S;
+    const size_t cap = ws_bytes < ((size_t)16 << 20) ? ws_bytes : ((size_t)16 << 20);   // keep the partial-sum round trip small
+    while (S > 1 && (size_t)S * M * a.npad * sizeof(float) > cap) --S;
     const int cps = cdiv(nk, S);
     S = cdiv(nk, cps);   // no empty splits
   }
@@ -483,8 +517,7 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
   DPMN_CHECK_LAUNCH();
   if (S > 1) {
-    const long total = (long)M * (a.npad / 4);
-    hipLaunchKernelGGL(k_conv_splitk_reduce, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(cdiv(a.npad / 4, 64), cdiv(M, 64)), dim3(256), 0, st, a);
     DPMN_CHECK_LAUNCH();
   }
   return DPMN_OK;

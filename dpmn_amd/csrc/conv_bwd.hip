@@ -131,15 +131,17 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
 }
 
 // ---------------------------------------------------------------------------------- train-mode BatchNorm
-// stats (2,C) = (sum, sumsq) over `count` values per channel (accumulated by the conv epilogue)
+// stats (32,2,C) = slotted (sum, sumsq) over `count` values per channel (accumulated by the conv epilogue)
 __global__ void k_bn_finalize(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                               float count, float eps, float momentum, float* __restrict__ scale, float* __restrict__ shift,
                               float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ running_mean,
                               float* __restrict__ running_var, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float mean = stats[c] / count;
-  float var = stats[C + c] / count - mean * mean;   // biased variance used for normalisation
+  float s1 = 0.f, s2 = 0.f;
+  for (int slot = 0; slot < 32; ++slot) { s1 += stats[(size_t)slot * 2 * C + c]; s2 += stats[(size_t)slot * 2 * C + C + c]; }   // STAT_SLOTS
+  const float mean = s1 / count;
+  float var = s2 / count - mean * mean;   // biased variance used for normalisation
   var = var > 0.f ? var : 0.f;
   const float rstd = 1.0f / sqrtf(var + eps);
   const float s = gamma[c] * rstd;

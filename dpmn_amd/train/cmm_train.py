@@ -72,7 +72,7 @@ class Unit:
         aff = [t.aff for t in self.inputs]
         transposed = self.kind in ("convT3", "convT4s2")
         cout = w.shape[1] if transposed else w.shape[0]
-        stats = torch.zeros(2, cout, device=w.device) if self.bn is not None else None
+        stats = torch.zeros(32, 2, cout, device=w.device) if self.bn is not None else None
         if self.kind == "convT4s2":
             packs = packing.pack_convT_s2k4(w, b)
             r = ops.convT_s2k4(xs, packs, cout, pro_act=self.pro_act, affine=aff, stats=stats)
@@ -104,11 +104,15 @@ class Unit:
                                       dptr(gr[self.bn.weight]), dptr(gr[self.bn.bias]), pixels, cout, stream()))
         else:
             dr = G
-        colsum(dr.reshape(pixels, cout), gr[b])
         cout_real = cout
         if cout % 4 != 0:   # de_1 (Cout = 3): pad the output-gradient channels so NHWC rows stay 16-byte aligned
             cout = (cout + 3) // 4 * 4
             dr = torch.cat([dr, dr.new_zeros(*dr.shape[:3], cout - cout_real)], dim=3)
+            tmp = torch.zeros(cout, device=dr.device)
+            colsum(dr.reshape(pixels, cout), tmp)
+            gr[b] += tmp[:cout_real]
+        else:
+            colsum(dr.reshape(pixels, cout), gr[b])
         xs = [t.r for t in self.inputs]
         aff = [t.aff for t in self.inputs]
         cin = sum(x.shape[3] for x in xs)

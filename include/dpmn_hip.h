@@ -85,7 +85,8 @@ typedef struct {
   int out_ld, out_coff;      /* NHWC channel stride (0 = Cout) and channel offset */
   int out_nchw;              /* store NCHW instead */
   int pixel_shuffle;         /* PixelShuffle(2) store: NHWC (B,2Hout,2Wout,Cout/4) (tsrn.py:110-111) */
-  float* stats;              /* (2,Cout) += sum / sum of squares of pre-activation outputs, or NULL */
+  float* stats;              /* (32,2,Cout) slotted += sum / sum of squares of pre-activation outputs (summed by
+                              * dpmn_bn_finalize_f32), or NULL */
   float* splitk_ws;          /* optional scratch enabling split-K for small-M / large-K convs (deep CMM levels) */
   size_t splitk_ws_bytes;
 } dpmn_conv_desc;

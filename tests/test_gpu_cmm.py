@@ -73,12 +73,12 @@ def test_conv2d_bn_fold_segments_residual_and_pixelshuffle(dev):
     xa = torch.cat([x * s[None, :, None, None] + h[None, :, None, None] for x, s, h in zip(xs, sc, sh)], 1)
     ref2 = F.conv2d(F.relu(xa), w, b, padding=1)
     wp2, bp2 = packing.pack_conv(w.to(dev), b.to(dev))
-    stats = torch.zeros(2, cout, device=dev)
+    stats = torch.zeros(32, 2, cout, device=dev)
     got2 = ops.conv2d([nhwc(x).to(dev) for x in xs], wp2, bp2, cout, 3, pad=1, pro_act="relu",
                       affine=[(s.to(dev), h.to(dev)) for s, h in zip(sc, sh)], stats=stats)
     assert_close(got2.permute(0, 3, 1, 2), ref2, ATOL, RTOL, "affine on load")
-    assert_close(stats[0], ref2.sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sum")
-    assert_close(stats[1], (ref2 * ref2).sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sumsq")
+    assert_close(stats.sum(0)[0], ref2.sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sum")
+    assert_close(stats.sum(0)[1], (ref2 * ref2).sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sumsq")
     # PixelShuffle(2) epilogue (UpsampleBLock, tsrn.py:110-112)
     w4 = u("w4", (256, 64, 3, 3)) * 0.05
     b4 = u("b4", (256,))
