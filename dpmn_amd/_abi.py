@@ -49,7 +49,7 @@ class ConvDesc(C.Structure):
         ("stats", fp), ("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t)]
 
 
-_i, _f, _sz = C.c_int, C.c_float, C.c_size_t
+_i, _f, _sz, _l = C.c_int, C.c_float, C.c_size_t, C.c_long
 _PP = C.POINTER(fp)
 _IP = C.POINTER(C.c_int)
 
@@ -103,6 +103,8 @@ SIGNATURES = {
     "dpmn_patch_scatter_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_prior_fusion_wgrad_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), fp, fp, fp]),
+    "dpmn_conv2d_wgrad_unpack_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, fp]),
+    "dpmn_conv2d_wgrad_strided_f32": (_i, [C.POINTER(ConvDesc), fp, fp, _i, _i, _l, _l, _l, _l, _l, fp]),
     "dpmn_bn_finalize_f32": (_i, [fp, fp, fp, _f, _f, _f, fp, fp, fp, fp, fp, fp, _i, fp]),
     "dpmn_affine_act_bwd_f32": (_i, [fp, fp, fp, fp, _i, fp, _i, C.c_long, _i, fp]),
     "dpmn_bn_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_long, _i, fp]),

@@ -1,5 +1,5 @@
 // Convolution weight gradients and train-mode BatchNorm plumbing for the NHWC implicit-GEMM convs (conv.hip).
-//   k_conv_wgrad      dWp[co][k] += sum_pixels dY[pix][co] * pro(in)[pix @ tap(k)][ci(k)]   (packed (Cout, Kp) layout)
+//   k_conv_wgrad      dW[co][k] += sum_pixels dY[pix][co] * pro(in)[pix @ tap(k)][ci(k)]   (packed or parameter layout)
 //   k_bn_finalize     per-channel (sum, sumsq) -> (scale, shift) for the consumers' affine-on-load + running stats
 //   k_affine_act_bwd  G (+)= dA * act'(scale*r + shift)          (consumer-side activation backward)
 //   k_bn_bwd_*        BatchNorm backward through batch statistics: dgamma, dbeta, d(raw conv output)
@@ -19,115 +19,204 @@ struct WgArgs {
   int Hout, Wout, ostep, ooy, oox;
   int pro_act;
   const float* dy;      // NHWC (B, Hout, Wout, Cout)
-  int Cout, Kp;
-  float* dwp;           // (Cout, Kp), accumulated with atomics
+  int Cout, K;          // K = KH*KW*cin
+  float* dw;            // dw[base + co*s_co + ci*s_ci + ky*s_ky + kx*s_kx] += ..., for co < co_lim, ci < ci_lim
+  long s_co, s_ci, s_ky, s_kx, base;
+  int co_lim, ci_lim;
   int pix_per_block;
+  int gx, gy, gz;       // logical grid (co tiles, k tiles, pixel splits)
+  float inv_hw, inv_w;
 };
 
-// Block 256 threads: 64 (co) x 64 (k) tile of dWp, loops over its pixel range in chunks of 32.
+// exact m / d for 0 <= m < 2^24 through one float multiply and a +-1 fix-up
+__device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r) {
+  q = (int)((float)m * inv);
+  r = m - q * d;
+  if (r < 0) { --q; r += d; }
+  if (r >= d) { ++q; r -= d; }
+}
+
+// Weight gradient of the implicit-GEMM conv: dW[co][k] = sum_pixels dY[pix][co] * pro(in)[pix @ tap(k)][ci(k)].
+// Block = BN_ (co) x BKT (k) tile of dW over its pixel range, staged 32 pixels at a time as [pixel][channel] LDS
+// tiles.  The contraction index of the 16x16x4 MFMA is the pixel; each lane's co / k indices are interleaved
+// (co = 4*i + ti, k = NJ*j + tj) so that ONE ds_read_b128 along the channel axis feeds 4 MFMA tiles.  The 4 waves split
+// the k columns, every wave holds all BN_ rows: no cross-wave reduction, one atomic per tile element per block.
+template <int BN_, int BKT>
 __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
-  constexpr int BT = 64, BMc = 32, LD = BT + 4;
-  __shared__ __attribute__((aligned(16))) float Ys[2][BMc * LD];
-  __shared__ __attribute__((aligned(16))) float Xs[2][BMc * LD];
+  constexpr int BMc = 32, NI = BN_ / 16, NJ = BKT / 64, LDY = BN_ + 4, LDX = BKT + 4;
+  constexpr int YC4 = BN_ / 4, XC4 = BKT / 4;             // float4 columns
+  constexpr int YRS = 256 / YC4, XRS = 256 / XC4;         // row stride between a thread's loads
+  constexpr int YP = (BMc + YRS - 1) / YRS, XP = BMc / XRS;
+  __shared__ __attribute__((aligned(16))) float Ys[BMc * LDY];
+  __shared__ __attribute__((aligned(16))) float Xs[BMc * LDX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_blk = blockIdx.x * BT, k_blk = blockIdx.y * BT;
-  const int M = a.B * a.Hp * a.Wp;
-  const int m_lo = blockIdx.z * a.pix_per_block;
+  // XCD-aware decode: workgroups are dealt round-robin to the 8 XCDs; keep the tiles of one pixel range (which share
+  // dY and the input rows) on one XCD's L2.
+  int vid = blockIdx.x;
+  const int total = a.gx * a.gy * a.gz;
+  if ((total & 7) == 0) vid = (vid & 7) * (total >> 3) + (vid >> 3);
+  const int n_blk = (vid % a.gx) * BN_, k_blk = ((vid / a.gx) % a.gy) * BKT;
+  const int bz = vid / (a.gx * a.gy);
+  const int M = a.B * a.Hp * a.Wp, HW = a.Hp * a.Wp;
+  const int m_lo = bz * a.pix_per_block;
   const int m_hi = min(M, m_lo + a.pix_per_block);
   const int c01 = a.cseg[0] + a.cseg[1];
-  const int ktaps = a.KH * a.KW;
-  // loader: 32 pixels x 16 float4 per operand -> 2 per thread; thread -> (row = tid>>4 (+16), col4 = tid & 15)
-  const int lrow = tid >> 4, lc4 = (tid & 15) * 4;
-  // k column of this thread is fixed: decode tap / channel / segment once
-  const int kcol = k_blk + lc4;
+  // ---- X loader: fixed k column per thread
+  const int xrow0 = tid / XC4, xc = (tid % XC4) * 4;
+  const int kcol = k_blk + xc;
   const int tap = kcol / a.cin, cch = kcol - tap * a.cin;
   const int ky = tap / a.KW, kx = tap - ky * a.KW;
   int seg = 0, cl = cch;
   if (cch >= c01) { seg = 2; cl = cch - c01; }
   else if (cch >= a.cseg[0]) { seg = 1; cl = cch - a.cseg[0]; }
-  const float* src = a.in[seg];
-  const int cs = a.cseg[seg];
-  const bool kvalid = tap < ktaps;
+  // (selects, not a.in[seg]: a runtime index would push the argument struct into scratch)
+  const float* src = seg == 0 ? a.in[0] : (seg == 1 ? a.in[1] : a.in[2]);
+  const int cs = seg == 0 ? a.cseg[0] : (seg == 1 ? a.cseg[1] : a.cseg[2]);
+  const float* scp = seg == 0 ? a.in_scale[0] : (seg == 1 ? a.in_scale[1] : a.in_scale[2]);
+  const float* shp = seg == 0 ? a.in_shift[0] : (seg == 1 ? a.in_shift[1] : a.in_shift[2]);
+  const bool kvalid = kcol < a.K;
   float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  const bool aff = a.in_scale[seg] != nullptr;
-  if (aff && kvalid) { s4 = *reinterpret_cast<const float4*>(a.in_scale[seg] + cl); h4 = *reinterpret_cast<const float4*>(a.in_shift[seg] + cl); }
-  float4 yr[2], xr[2];
+  const bool aff = scp != nullptr;
+  if (aff && kvalid) { s4 = *reinterpret_cast<const float4*>(scp + cl); h4 = *reinterpret_cast<const float4*>(shp + cl); }
+  const int iy_off = ky * a.dil_y - a.pad_y, ix_off = kx * a.dil_x - a.pad_x;
+  // ---- Y loader
+  const int yrow0 = tid / YC4, yc = (tid % YC4) * 4;
+  const int yn = n_blk + yc;
+  float4 yr[YP], xr[XP];
   auto gload = [&](int m0) {
+    {
+      int b, rr, py, px;
+      fdivmod(m0 + yrow0, HW, a.inv_hw, b, rr);
+      fdivmod(rr, a.Wp, a.inv_w, py, px);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int m = m0 + lrow + p * 16;
-      float4 yv = make_float4(0.f, 0.f, 0.f, 0.f), xv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < m_hi) {
-        const int b = m / (a.Hp * a.Wp), rr = m % (a.Hp * a.Wp);
-        const int py = rr / a.Wp, px = rr % a.Wp;
-        const int oy = py * a.ostep + a.ooy, ox = px * a.ostep + a.oox;
-        const int n = n_blk + lc4;
-        if (n < a.Cout) {
-          const float* yp = a.dy + (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.Cout + n;
-          if (n + 3 < a.Cout) yv = *reinterpret_cast<const float4*>(yp);
-          else { float t4[4] = {0, 0, 0, 0}; for (int r = 0; r < 4; ++r) if (n + r < a.Cout) t4[r] = yp[r]; yv = make_float4(t4[0], t4[1], t4[2], t4[3]); }
+      for (int p = 0; p < YP; ++p) {
+        const int row = yrow0 + p * YRS, m = m0 + row;
+        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < BMc && m < m_hi && yn < a.Cout) {
+          const int oy = py * a.ostep + a.ooy, ox = px * a.ostep + a.oox;
+          const float* yp = a.dy + (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.Cout + yn;
+          if (yn + 3 < a.Cout) yv = *reinterpret_cast<const float4*>(yp);
+          else { float t4[4] = {0, 0, 0, 0}; for (int r = 0; r < 4; ++r) if (yn + r < a.Cout) t4[r] = yp[r]; yv = make_float4(t4[0], t4[1], t4[2], t4[3]); }
         }
-        const int iy = py * a.stride - a.pad_y + ky * a.dil_y, ix = px * a.stride - a.pad_x + kx * a.dil_x;
-        if (kvalid && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
-          xv = *reinterpret_cast<const float4*>(src + (((size_t)b * a.Hin + iy) * a.Win + ix) * cs + cl);
-          if (aff) { xv.x = xv.x * s4.x + h4.x; xv.y = xv.y * s4.y + h4.y; xv.z = xv.z * s4.z + h4.z; xv.w = xv.w * s4.w + h4.w; }
-          float v4[4] = {xv.x, xv.y, xv.z, xv.w};
-          apply_act4(v4, a.pro_act, 0.f);
-          xv = make_float4(v4[0], v4[1], v4[2], v4[3]);
-        }
+        yr[p] = yv;
+        px += YRS;                                     // advance the pixel by the row stride without dividing
+        while (px >= a.Wp) { px -= a.Wp; if (++py >= a.Hp) { py = 0; ++b; } }
       }
-      yr[p] = yv; xr[p] = xv;
     }
-  };
-  auto sstore = [&](int buf) {
+    {
+      int b, rr, py, px;
+      fdivmod(m0 + xrow0, HW, a.inv_hw, b, rr);
+      fdivmod(rr, a.Wp, a.inv_w, py, px);
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      *reinterpret_cast<float4*>(&Ys[buf][(lrow + p * 16) * LD + lc4]) = yr[p];
-      *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * 16) * LD + lc4]) = xr[p];
+      for (int p = 0; p < XP; ++p) {
+        const int m = m0 + xrow0 + p * XRS;
+        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kvalid && m < m_hi) {
+          const int iy = py * a.stride + iy_off, ix = px * a.stride + ix_off;
+          if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+            xv = *reinterpret_cast<const float4*>(src + (((size_t)b * a.Hin + iy) * a.Win + ix) * cs + cl);
+            if (aff) { xv.x = xv.x * s4.x + h4.x; xv.y = xv.y * s4.y + h4.y; xv.z = xv.z * s4.z + h4.z; xv.w = xv.w * s4.w + h4.w; }
+            float v4[4] = {xv.x, xv.y, xv.z, xv.w};
+            apply_act4(v4, a.pro_act, 0.f);
+            xv = make_float4(v4[0], v4[1], v4[2], v4[3]);
+          }
+        }
+        xr[p] = xv;
+        px += XRS;
+        while (px >= a.Wp) { px -= a.Wp; if (++py >= a.Hp) { py = 0; ++b; } }
+      }
     }
   };
-  const int wn = wave & 1, wk = wave >> 1;
+  auto sstore = [&]() {
+#pragma unroll
+    for (int p = 0; p < YP; ++p) {
+      const int row = yrow0 + p * YRS;
+      if (row < BMc) *reinterpret_cast<float4*>(&Ys[row * LDY + yc]) = yr[p];
+    }
+#pragma unroll
+    for (int p = 0; p < XP; ++p) *reinterpret_cast<float4*>(&Xs[(xrow0 + p * XRS) * LDX + xc]) = xr[p];
+  };
   const int lr = lane & 15, kq = lane >> 4;
-  f32x4 acc[2][2];
+  f32x4 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  if (m_lo < m_hi) { gload(m_lo); sstore(0); }
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (m_lo < m_hi) { gload(m_lo); sstore(); }
   __syncthreads();
-  int buf = 0;
   for (int m0 = m_lo; m0 < m_hi; m0 += BMc) {
-    if (m0 + BMc < m_hi) gload(m0 + BMc);
+#ifdef WG_NOLOAD
+    const bool more = false;
+#else
+    const bool more = m0 + BMc < m_hi;
+#endif
+    if (more) gload(m0 + BMc);
+#ifndef WG_NOMFMA
 #pragma unroll
-    for (int mc = 0; mc < BMc; mc += 16)
+    for (int ks = 0; ks < BMc / 4; ++ks) {
+      const int row = ks * 4 + kq;
+      float av[NI], bv[NJ];
+      if constexpr (NI == 1) av[0] = Ys[row * LDY + lr];
+      else {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int row = mc + kq * 4 + s;
-        float av[2], bv[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) av[i] = Ys[buf][row * LD + wn * 32 + i * 16 + lr];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bv[j] = Xs[buf][row * LD + wk * 32 + j * 16 + lr];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(av[i], bv[j], acc[i][j]);
+        for (int h = 0; h < NI / 4; ++h) {
+          const float4 t4 = *reinterpret_cast<const float4*>(&Ys[row * LDY + h * 64 + lr * 4]);
+          av[h * 4 + 0] = t4.x; av[h * 4 + 1] = t4.y; av[h * 4 + 2] = t4.z; av[h * 4 + 3] = t4.w;
+        }
       }
-    if (m0 + BMc < m_hi) sstore(buf ^ 1);
+      if constexpr (NJ == 4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(&Xs[row * LDX + wave * 64 + lr * 4]);
+        bv[0] = t4.x; bv[1] = t4.y; bv[2] = t4.z; bv[3] = t4.w;
+      } else {
+        const float2 t2 = *reinterpret_cast<const float2*>(&Xs[row * LDX + wave * 32 + lr * 2]);
+        bv[0] = t2.x; bv[1] = t2.y;
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(av[i], bv[j], acc[i][j]);
+    }
+#endif
     __syncthreads();
-    buf ^= 1;
+    if (more) sstore();
+    __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < NJ; ++j) {
+    const int k = k_blk + wave * (NJ * 16) + lr * NJ + j;
+    if (k >= a.K) continue;
+    const int tp = k / a.cin, ci = k - tp * a.cin;
+    if (ci >= a.ci_lim) continue;
+    const int ty = tp / a.KW, tx = tp - ty * a.KW;
+    float* dst = a.dw + a.base + (long)ci * a.s_ci + (long)ty * a.s_ky + (long)tx * a.s_kx;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = k_blk + wk * 32 + j * 16 + lr;
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n_blk + wn * 32 + i * 16 + kq * 4 + r;
-        if (n < a.Cout && k < a.Kp) atomicAdd(a.dwp + (size_t)n * a.Kp + k, acc[i][j][r]);
+        const int ii = kq * 4 + r;
+        const int n = n_blk + (NI == 1 ? ii : (i >> 2) * 64 + ii * 4 + (i & 3));
+#ifdef WG_NOATOMIC
+        if (n < a.co_lim && acc[i][j][r] == 1.2345f) dst[(long)n * a.s_co] = 1.f;
+#else
+        if (n < a.co_lim) atomicAdd(dst + (long)n * a.s_co, acc[i][j][r]);
+#endif
       }
-    }
+  }
+}
+
+// packed (Cout, Kp) gradient -> += into the parameter's layout, and clear the packed workspace for its next use
+__global__ void k_wgrad_unpack(float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Kp, int K, int cin, int KW, int co_lim,
+                               int ci_lim, long s_co, long s_ci, long s_ky, long s_kx, long base, int clear) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cout * Kp) return;
+  const int co = (int)(idx / Kp), k = (int)(idx - (long)co * Kp);
+  const float v = dwp[idx];
+  if (clear) dwp[idx] = 0.f;
+  if (k >= K || co >= co_lim) return;
+  const int tp = k / cin, ci = k - tp * cin;
+  if (ci >= ci_lim) return;
+  const int ty = tp / KW, tx = tp - ty * KW;
+  dw[base + co * s_co + ci * s_ci + ty * s_ky + tx * s_kx] += v;
 }
 
 // ---------------------------------------------------------------------------------- train-mode BatchNorm
@@ -215,10 +304,15 @@ __global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ x
   float* dlog = Wg + C;     // [C] grad wrt fc2 output (pre-sigmoid)
   float* dh = dlog + C;     // [Cm] grad wrt fc1 output (pre-relu)
   float* dSm = dh + Cm;     // [C] grad wrt S
+  float* Dw = dSm + C;      // [C] sum_p dg * x
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* xb = x + (size_t)b * P * C;
   const float* gb = dg + (size_t)b * P * C;
-  for (int c = tid; c < C; c += 256) { float s = 0.f; for (int p = 0; p < P; ++p) s += xb[p * C + c]; S[c] = s / (float)P; }
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f, dw = 0.f;
+    for (int p = 0; p < P; ++p) { const float xv = xb[p * C + c]; s += xv; dw += gb[p * C + c] * xv; }
+    S[c] = s / (float)P; Dw[c] = dw;
+  }
   __syncthreads();
   for (int j = wave; j < Cm; j += 4) {
     float a = 0.f;
@@ -234,9 +328,7 @@ __global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ x
     if (lane == 0) {
       const float w = sigmoid_f(a + fc2_b[c]);
       Wg[c] = w;
-      float dwsum = 0.f;
-      for (int p = 0; p < P; ++p) dwsum += gb[p * C + c] * xb[p * C + c];
-      dlog[c] = dwsum * w * (1.f - w);
+      dlog[c] = Dw[c] * w * (1.f - w);
     }
   }
   __syncthreads();
@@ -327,8 +419,9 @@ __global__ void k_adam_clip(float* __restrict__ p, const float* __restrict__ g, 
 
 extern "C" {
 
-int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, dpmn_stream_t stream) {
-  DPMN_REQUIRE(d && d->in[0] && dy && dwp, "conv2d_wgrad: null pointer");
+static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co, long s_ci,
+                        long s_ky, long s_kx, long base, dpmn_stream_t stream) {
+  DPMN_REQUIRE(d && d->in[0] && dy && dw, "conv2d_wgrad: null pointer");
   WgArgs a{};
   int cin = 0;
   for (int s = 0; s < 3; ++s) {
@@ -339,19 +432,56 @@ int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, 
   a.cin = cin; a.B = d->B; a.Hin = d->Hin; a.Win = d->Win; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride;
   a.dil_y = d->dil_y; a.dil_x = d->dil_x; a.pad_y = d->pad_y; a.pad_x = d->pad_x; a.Hp = d->Hp; a.Wp = d->Wp;
   a.Hout = d->Hout; a.Wout = d->Wout; a.ostep = d->ostep; a.ooy = d->ooy; a.oox = d->oox; a.pro_act = d->pro_act;
-  a.dy = dy; a.Cout = d->Cout; a.dwp = dwp;
-  a.Kp = ((d->KH * d->KW * cin + 31) / 32) * 32;
-  const int M = a.B * a.Hp * a.Wp;
-  const int tiles = cdiv(a.Cout, 64) * cdiv(a.Kp, 64);
-  int splits = cdiv(1024, tiles);
+  a.dy = dy; a.Cout = d->Cout; a.dw = dw;
+  a.K = d->KH * d->KW * cin;
+  a.s_co = s_co; a.s_ci = s_ci; a.s_ky = s_ky; a.s_kx = s_kx; a.base = base;
+  a.co_lim = co_lim < a.Cout ? co_lim : a.Cout; a.ci_lim = ci_lim < cin ? ci_lim : cin;
+  const long Ml = (long)a.B * a.Hp * a.Wp;
+  DPMN_REQUIRE(Ml > 0 && Ml < (1L << 24), "conv2d_wgrad: pixel count must be below 2^24");
+  const int M = (int)Ml;
+  a.inv_hw = 1.0f / (float)(a.Hp * a.Wp); a.inv_w = 1.0f / (float)a.Wp;
+  const int bn = a.Cout <= 16 ? 16 : (a.Cout <= 64 ? 64 : 128);
+  int bk = bn == 128 ? 128 : 256;
+  if (bn == 64 && cdiv(a.K, 128) * 128 < cdiv(a.K, 256) * 256) bk = 128;   // less padding in the last k tile
+  a.gx = cdiv(a.Cout, bn); a.gy = cdiv(a.K, bk);
+  const int tiles = a.gx * a.gy;
+  // every block ends with one atomic per tile element: keep >= 512 pixels of MFMA work behind each of them
+  int splits = cdiv(2048, tiles);
   int ppb = cdiv(cdiv(M, splits), 32) * 32;
-  if (ppb < 32) ppb = 32;
+  if (ppb < 512) ppb = 512;
   splits = cdiv(M, ppb);
-  a.pix_per_block = ppb;
-  dim3 grid(cdiv(a.Cout, 64), cdiv(a.Kp, 64), splits);
-  hipLaunchKernelGGL(k_conv_wgrad, grid, dim3(256), 0, as_stream(stream), a);
+  a.pix_per_block = ppb; a.gz = splits;
+  const dim3 grid((unsigned)(tiles * splits));
+  if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256>), grid, dim3(256), 0, as_stream(stream), a);
+  else if (bn == 64 && bk == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, as_stream(stream), a);
+  else if (bn == 64) hipLaunchKernelGGL((k_conv_wgrad<64, 256>), grid, dim3(256), 0, as_stream(stream), a);
+  else hipLaunchKernelGGL((k_conv_wgrad<128, 128>), grid, dim3(256), 0, as_stream(stream), a);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
+}
+
+int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, dpmn_stream_t stream) {
+  DPMN_REQUIRE(d, "conv2d_wgrad: null descriptor");
+  int cin = 0;
+  for (int s = 0; s < 3; ++s) cin += d->in[s] ? d->cseg[s] : 0;
+  const long Kp = ((long)(d->KH * d->KW * cin + 31) / 32) * 32;
+  return launch_wgrad(d, dy, dwp, d->Cout, cin, Kp, 1, (long)d->KW * cin, cin, 0, stream);
+}
+
+int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
+                                 long s_ci, long s_ky, long s_kx, long base, int clear, dpmn_stream_t stream) {
+  DPMN_REQUIRE(dwp && dw && Cout > 0 && cin > 0 && KH > 0 && KW > 0, "conv2d_wgrad_unpack: bad arguments");
+  const int K = KH * KW * cin, Kp = (K + 31) / 32 * 32;
+  const long total = (long)Cout * Kp;
+  hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), dwp, dw, Cout, Kp, K, cin,
+                     KW, co_lim < Cout ? co_lim : Cout, ci_lim < cin ? ci_lim : cin, s_co, s_ci, s_ky, s_kx, base, clear);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_conv2d_wgrad_strided_f32(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co,
+                                  long s_ci, long s_ky, long s_kx, long base, dpmn_stream_t stream) {
+  return launch_wgrad(d, dy, dw, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base, stream);
 }
 
 int dpmn_bn_finalize_f32(const float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,
@@ -393,7 +523,7 @@ int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, co
                          const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b, int B, int P,
                          int C, int Cmid, dpmn_stream_t stream) {
   DPMN_REQUIRE(x && dg && fc1_w && fc1_b && fc2_w && fc2_b && dx && dfc1_w && dfc1_b && dfc2_w && dfc2_b && B > 0, "se_gate_bwd: bad arguments");
-  hipLaunchKernelGGL(k_se_gate_bwd, dim3(B), dim3(256), (size_t)(4 * C + 2 * Cmid) * 4, as_stream(stream), x, dg, fc1_w, fc1_b, fc2_w,
+  hipLaunchKernelGGL(k_se_gate_bwd, dim3(B), dim3(256), (size_t)(5 * C + 2 * Cmid) * 4, as_stream(stream), x, dg, fc1_w, fc1_b, fc2_w,
                      fc2_b, dx, dfc1_w, dfc1_b, dfc2_w, dfc2_b, P, C, Cmid);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;

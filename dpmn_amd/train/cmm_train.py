@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from .._abi import dptr, lib, check, stream
 from ..model import packing
-from .pgrm_train import colsum
+from .pgrm_train import colsum, conv_wgrad_into
 
 ACT = ops.ACT
 
@@ -119,23 +119,14 @@ class Unit:
         dev = dr.device
         # ---- weight gradient
         if self.kind == "convT4s2":
-            dwps = []
             for py in range(2):
                 for px in range(2):
                     d = ops.conv_desc(xs, 2, cout=cout, pro_act=self.pro_act, affine=aff, phase=(py, px))
-                    dwp = torch.zeros(cout, (4 * cin + 31) // 32 * 32, device=dev)
-                    check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dr), dptr(dwp), stream()))
-                    dwps.append(dwp)
-            packing.unpack_convT_s2k4_into(gr[w], dwps)
+                    conv_wgrad_into(d, dr, gr[w], "convT_s2k4", (py, px))
         else:
             f = self._fw()
             d = ops.conv_desc(xs, f["k"], f["stride"], f["pad"], f["dil"], cout=cout, pro_act=self.pro_act, affine=aff)
-            dwp = torch.zeros(cout, (f["k"] * f["k"] * cin + 31) // 32 * 32, device=dev)
-            check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dr), dptr(dwp), stream()))
-            if self.kind == "convT3":
-                gr[w] += packing.unpack_convT_s1(dwp[:cout_real], w.shape)
-            else:
-                gr[w] += packing.unpack_conv(dwp, w.shape, self.cin_pad)
+            conv_wgrad_into(d, dr, gr[w], "convT_s1" if self.kind == "convT3" else "conv")
         # ---- data gradients, one launch per input segment, then activation backward through the producer's affine
         c0 = 0
         for t in self.inputs:

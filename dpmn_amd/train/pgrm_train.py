@@ -64,6 +64,36 @@ def linear_bwd(dy, x, w, dw, db):
     return ops.linear(dy, w.t().contiguous())
 
 
+def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
+    """Accumulate the weight gradient of the conv described by `d` straight into the parameter-layout tensor `dweight`:
+    layout "conv" = nn.Conv2d (Cout,Cin,KH,KW); "convT_s1" = nn.ConvTranspose2d(stride 1) (Cin,Cout,KH,KW), flipped taps;
+    "convT_s2k4" = phase (py,px) of nn.ConvTranspose2d(4,2,1) (tap ky' -> ky = (1-py)+2ky', packing.pack_convT_s2k4).
+    Channels the descriptor only carries as padding (beyond dweight's real Cin / Cout) are dropped."""
+    assert dweight.is_contiguous()
+    if layout == "conv":
+        co, ci, kh, kw = dweight.shape
+        st = (ci * kh * kw, kh * kw, kw, 1, 0)
+    elif layout == "convT_s1":
+        ci, co, kh, kw = dweight.shape
+        st = (kh * kw, co * kh * kw, -kw, -1, (kh - 1) * kw + (kw - 1))
+    else:
+        ci, co = dweight.shape[:2]
+        st = (16, co * 16, 8, 2, (1 - phase[0]) * 4 + (1 - phase[1]))
+    # coalesced atomics into a persistent packed (Cout, Kp) workspace, then one unpack kernel that also re-zeroes it
+    # (scattering the atomics straight into the parameter layout, dpmn_conv2d_wgrad_strided_f32, measured 3x slower)
+    cin_d = sum(d.cseg[i] for i in range(3) if d.inp[i])
+    kp = (d.KH * d.KW * cin_d + 31) // 32 * 32
+    key = (dy.device, d.Cout, kp)
+    ws = _WGRAD_WS.get(key)
+    if ws is None:
+        ws = _WGRAD_WS[key] = torch.zeros(d.Cout, kp, device=dy.device)
+    check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dy), dptr(ws), stream()))
+    check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 1, stream()))
+
+
+_WGRAD_WS = {}
+
+
 class ConvSpec:
     """Geometry + packed weights of one conv in the reference layout (Cout, Cin, k, k), stride 1, 'same' padding."""
 
@@ -79,11 +109,8 @@ class ConvSpec:
     def backward(self, x, dy, dweight, dbias, need_dx=True):
         """x (B,H,W,Cin) input of the forward, dy (B,H,W,Cout); accumulates dweight/dbias; returns dx."""
         B, H, W, _ = x.shape
-        kp = (self.k * self.k * self.cin + 31) // 32 * 32
-        dwp = torch.zeros(self.cout, kp, device=x.device)
         d = ops.conv_desc([x], self.k, pad=self.pad, cout=self.cout)
-        check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dy), dptr(dwp), stream()))
-        dweight += dwp[:, :self.k * self.k * self.cin].reshape(self.cout, self.k, self.k, self.cin).permute(0, 3, 1, 2)
+        conv_wgrad_into(d, dy, dweight)
         colsum(dy.reshape(-1, self.cout), dbias)
         if not need_dx:
             return None

@@ -235,6 +235,15 @@ int dpmn_prior_fusion_wgrad_f32(const float* din, const float* prior, float* dpf
                                 dpmn_stream_t stream);
 /* conv weight gradient in the packed (Cout, Kp) layout, train-mode BatchNorm plumbing, CMM gate backward (conv_bwd.hip) */
 int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, dpmn_stream_t stream);
+/* same, accumulated straight into the parameter's own layout (nn.Conv2d (Cout,Cin,KH,KW), nn.ConvTranspose2d
+ * (Cin,Cout,KH,KW) flipped, or one phase of ConvTranspose2d(4,2,1)):
+ *   dw[base + co*s_co + ci*s_ci + ky*s_ky + kx*s_kx] += ...   for co < co_lim, ci < ci_lim (padding channels dropped) */
+/* packed (Cout,Kp) gradient -> += into the parameter layout (same stride convention as below); clear != 0 zeroes the
+ * packed buffer afterwards so that a persistent workspace needs no memset before its next dpmn_conv2d_wgrad_f32 */
+int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
+                                 long s_ci, long s_ky, long s_kx, long base, int clear, dpmn_stream_t stream);
+int dpmn_conv2d_wgrad_strided_f32(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co,
+                                  long s_ci, long s_ky, long s_kx, long base, dpmn_stream_t stream);
 int dpmn_bn_finalize_f32(const float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,
                          float* scale, float* shift, float* mean, float* rstd, float* running_mean, float* running_var,
                          int C, dpmn_stream_t stream);

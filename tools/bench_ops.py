@@ -82,3 +82,30 @@ conv_case("cmm de3a 3x3 768->128 @8x32", 768, 128, 3, 8, 32, segs=[256, 256, 256
 conv_case("cmm de2a 3x3 384->64 @16x64", 384, 64, 3, 16, 64, segs=[128, 128, 128], pro_act="relu")
 conv_case("cmm de1 3x3 192->3 @32x128", 192, 3, 3, 32, 128, segs=[64, 64, 64], pro_act="relu", out_nchw=True)
 conv_case("pgrm tail 3x3 96->12 @16x64", 96, 12, 3, 16, 64)
+
+
+# ---- conv weight gradients (training): packed layout vs straight into the nn.Conv2d layout
+def wgrad_case(name, cin, cout, k, H, W):
+    if flt and flt not in "wgrad " + name:
+        return
+    import ctypes as C_
+    from dpmn_amd._abi import lib, check, dptr, stream
+    from dpmn_amd.train.pgrm_train import conv_wgrad_into
+    x = u("wgx" + name, (B, H, W, cin)); dy = u("wgy" + name, (B, H, W, cout))
+    d = ops.conv_desc([x], k, pad=(k - 1) // 2, cout=cout)
+    kp = (k * k * cin + 31) // 32 * 32
+    dwp = torch.zeros(cout, kp, device=dev); dw = torch.zeros(cout, cin, k, k, device=dev)
+    fl = 2.0 * B * H * W * cout * cin * k * k
+    by = 4.0 * B * H * W * (cin + cout)
+    timeit("wgrad packed " + name, lambda: check(lib.dpmn_conv2d_wgrad_f32(C_.byref(d), dptr(dy), dptr(dwp), stream())), fl, by)
+    timeit("wgrad param  " + name, lambda: conv_wgrad_into(d, dy, dw), fl, by)
+
+
+wgrad_case("96->64 k3 16x64", 96, 64, 3, 16, 64)
+wgrad_case("64->64 k3 32x128", 64, 64, 3, 32, 128)
+wgrad_case("128->128 k3 16x64", 128, 128, 3, 16, 64)
+wgrad_case("256->256 k3 8x32", 256, 256, 3, 8, 32)
+wgrad_case("256->512 k3 4x16", 256, 512, 3, 4, 16)
+wgrad_case("512->512 k3 2x8", 512, 512, 3, 2, 8)
+wgrad_case("192->4 k3 32x128", 192, 4, 3, 32, 128)
+wgrad_case("8->4 k3 32x128", 8, 4, 3, 32, 128)
