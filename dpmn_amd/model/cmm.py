@@ -32,6 +32,7 @@ class _Holder(nn.Module):
 
 
 class ComplementationModulationModule(nn.Module):
+    direct_grad = True   # see train/optim.py (direct mode)
     def __init__(self, c_img=3, norm='batch', act_en='leaky_relu', act_de='relu', cnum=64):
         super().__init__()
         if norm != 'batch' or act_en != 'leaky_relu' or act_de != 'relu':

@@ -135,6 +135,8 @@ class _PatchEmbed(nn.Module):
 class PGRM(nn.Module):
     """Drop-in for ``model.pgrm.PGRM`` (reference pgrm.py:462-467)."""
 
+    direct_grad = True   # train/optim.py: the explicit backward accumulates straight into the optimizer's flat bucket
+
     def __init__(self, img_size=[32, 128], patch_size=[2], in_chans=3, embed_dim=[96], depths=[1], num_heads=[[6]],
                  window_size=[[2, 4, 8]], mlp_ratio=[4.], qkv_bias=True, qk_scale=None, drop_rate=[0.],
                  attn_drop_rate=[0.], drop_path_rate=[0.1], iter=0, norm_layer=nn.LayerNorm, ape=False,

@@ -13,7 +13,7 @@ import torch
 from .. import ops
 from .._abi import dptr, lib, check, stream
 from ..model import packing
-from .pgrm_train import colsum, conv_wgrad_into
+from .pgrm_train import colsum, conv_wgrad_into, grad_targets, finish_grads
 
 ACT = ops.ACT
 
@@ -200,7 +200,7 @@ def build(m, x1, x2):
 
 
 def backward(m, graph, dout, need_dx=(True, True)):
-    gr = {p: torch.zeros_like(p) for p in m.parameters()}
+    gr, direct = grad_targets(m)
     units, last = graph["units"], graph["last"]
     a, b = graph["enc"]
     for leaf, need in zip(graph["leaves"], need_dx):
@@ -229,7 +229,7 @@ def backward(m, graph, dout, need_dx=(True, True)):
     dxs = []
     for leaf, need in zip(graph["leaves"], need_dx):
         dxs.append(ops.nhwc_to_nchw(leaf.G)[:, :3].contiguous() if need else None)
-    return dxs, gr
+    return dxs, gr, direct
 
 
 class CMMFunction(torch.autograd.Function):
@@ -242,9 +242,9 @@ class CMMFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        dxs, gr = backward(ctx.m, ctx.graph, dout.contiguous(), ctx.need)
+        dxs, gr, direct = backward(ctx.m, ctx.graph, dout.contiguous(), ctx.need)
         ctx.graph = None
-        return (None, dxs[0], dxs[1]) + tuple(gr[p] for p in ctx.m.parameters())
+        return (None, dxs[0], dxs[1]) + finish_grads(ctx.m, gr, direct)
 
 
 def apply(m, x1, x2):

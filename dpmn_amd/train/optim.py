@@ -5,8 +5,12 @@ Each model (PGRM_k, DistillModule_j, CMM) becomes ONE flat bucket: parameters an
 buffers, so
   * clip_grad_norm_(model.parameters(), 0.25) is one sum-of-squares kernel,
   * Adam(lr, betas=(beta1, 0.999)) is one fused kernel (clip coefficient applied on the fly, no host sync),
-  * the RCCL all-reduce is one collective per model, launched from a post-accumulate-grad hook as soon as the model's
-    last gradient lands -- CMM's 214 MB bucket goes first (its backward runs first) and overlaps with the PGRM backward.
+  * the RCCL all-reduce is one collective per model, launched as soon as the model's last gradient lands -- CMM's
+    214 MB bucket goes first (its backward runs first) and overlaps with the PGRM backward.
+PGRM and CMM (explicit backward kernels, train/pgrm_train.py, train/cmm_train.py) run in DIRECT mode: their backward
+accumulates straight into the bucket's gradient views and reports completion itself, so autograd never allocates,
+zero-fills or adds a per-parameter gradient tensor (that was ~1500 tiny launches per step).  Every other module keeps the
+ordinary post-accumulate-grad hooks.
 Gradient averaging over ranks = the single-device semantics of the reference (mean of per-shard means).
 """
 import torch
@@ -16,12 +20,14 @@ from .._abi import lib, check, dptr, stream
 
 
 class FlatBucket:
-    def __init__(self, module, name=""):
+    def __init__(self, module, name="", direct=False):
         self.name = name
+        self.direct = direct
         self.params = [p for p in module.parameters()]
-        n = sum(p.numel() for p in self.params)
+        align = 64      # floats: every parameter / gradient view starts on a 256-byte boundary (float4 + atomics friendly)
+        n = sum((p.numel() + align - 1) // align * align for p in self.params)
         dev = self.params[0].device
-        self.flat_p = torch.empty(n, device=dev)
+        self.flat_p = torch.zeros(n, device=dev)
         self.flat_g = torch.zeros(n, device=dev)
         off = 0
         for p in self.params:
@@ -29,7 +35,11 @@ class FlatBucket:
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
-            off += k
+            off += (k + align - 1) // align * align
+        if direct:
+            for p in self.params:
+                p._dpmn_sink = p.grad
+            module._dpmn_bucket = self
         self.n = n
         self.m = torch.zeros(n, device=dev)
         self.v = torch.zeros(n, device=dev)
@@ -42,6 +52,8 @@ class FlatBucket:
     def install_hooks(self, world_size, group=None):
         """all-reduce this bucket as soon as every parameter has accumulated its gradient in the current backward."""
         self.world, self.group = world_size, group
+        if self.direct:
+            return          # the module's backward calls grads_ready() itself
         trainable = [p for p in self.params if p.requires_grad]
         self._expect = len(trainable)
 
@@ -52,6 +64,10 @@ class FlatBucket:
                 self.launch_allreduce()
         for p in trainable:
             p.register_post_accumulate_grad_hook(hook)
+
+    def grads_ready(self):
+        """direct mode: called by the module's backward once every gradient of this bucket has been accumulated."""
+        self.launch_allreduce()
 
     def launch_allreduce(self):
         if getattr(self, "world", 1) > 1:
@@ -80,7 +96,7 @@ class Trainer:
     """zero_grad / backward hooks / clip+Adam over a list of models, in the reference's order."""
 
     def __init__(self, models, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=1, group=None):
-        self.buckets = [FlatBucket(m, "model%d" % i) for i, m in enumerate(models)]
+        self.buckets = [FlatBucket(m, "model%d" % i, direct=getattr(m, "direct_grad", False)) for i, m in enumerate(models)]
         self.lr, self.beta1, self.max_norm = lr, beta1, max_norm
         self.t = 0
         for b in self.buckets:

@@ -64,6 +64,23 @@ def linear_bwd(dy, x, w, dw, db):
     return ops.linear(dy, w.t().contiguous())
 
 
+def grad_targets(m):
+    """{param: tensor the backward kernels accumulate into}, direct?  Direct mode (train/optim.py FlatBucket(direct=True)):
+    the targets are the flat bucket's zeroed gradient views; otherwise freshly zeroed tensors handed back to autograd."""
+    ps = list(m.parameters())
+    if getattr(m, "_dpmn_bucket", None) is not None:
+        return {p: p._dpmn_sink for p in ps}, True
+    return {p: torch.zeros_like(p) for p in ps}, False
+
+
+def finish_grads(m, gr, direct):
+    """tuple of per-parameter gradients for autograd (None in direct mode, after signalling the bucket)."""
+    if direct:
+        m._dpmn_bucket.grads_ready()
+        return tuple(None for _ in m.parameters())
+    return tuple(gr[p] for p in m.parameters())
+
+
 def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
     """Accumulate the weight gradient of the conv described by `d` straight into the parameter-layout tensor `dweight`:
     layout "conv" = nn.Conv2d (Cout,Cin,KH,KW); "convT_s1" = nn.ConvTranspose2d(stride 1) (Cin,Cout,KH,KW), flipped taps;
@@ -173,14 +190,14 @@ def forward(m, x_q, x_kv, residuals):
 
 
 def backward(m, sv, dout, need_dx_kv=True):
-    """Returns (dx_kv or None, [dresidual_i or None], {param: grad}).  Gradients are freshly allocated tensors."""
+    """Returns (dx_kv or None, [dresidual_i or None], {param: grad}, direct) -- see grad_targets."""
     B = sv["x_kv"].shape[0]
     H, Wd = m.patches_resolution
     L, Cd = H * Wd, m.embed_dim
     M, Ch, G = B * L, int(m.embed_dim * m.mlp_ratio), len(m.window_size)
     hpg = m.num_heads // G
     parts = (L + 31) // 32
-    gr = {p: torch.zeros_like(p) for p in m.parameters()}
+    gr, direct = grad_targets(m)
     residuals = sv["residuals"]
     dres = [None] + [torch.zeros_like(r) for r in residuals[1:]]
     wl = [getattr(m, "weight_list_%d" % i) for i in range(m.iter + 1)]
@@ -270,7 +287,7 @@ def backward(m, sv, dout, need_dx_kv=True):
             else:
                 dx_kv = torch.zeros_like(img)
                 check(lib.dpmn_patch_scatter_f32(dptr(din), dptr(dx_kv), img.shape[1], B, img.shape[2], img.shape[3], stream()))
-    return dx_kv, dres, gr
+    return dx_kv, dres, gr, direct
 
 
 class PGRMFunction(torch.autograd.Function):
@@ -287,11 +304,10 @@ class PGRMFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         m = ctx.m
-        dx_kv, dres, gr = backward(m, ctx.sv, dout, need_dx_kv=ctx.need_kv)
+        dx_kv, dres, gr, direct = backward(m, ctx.sv, dout, need_dx_kv=ctx.need_kv)
         ctx.sv = None
-        params = list(m.parameters())
         dres_out = [None if d is None else d for d in dres] + [None] * (ctx.n_res - len(dres))
-        return (None, None, dx_kv, None) + tuple(dres_out[:ctx.n_res]) + tuple(gr[p] for p in params)
+        return (None, None, dx_kv, None) + tuple(dres_out[:ctx.n_res]) + finish_grads(m, gr, direct)
 
 
 def apply(m, x_q, x_kv, residual_list):

@@ -37,7 +37,7 @@ def _worker(rank, world, port, q):
     loss.backward()                       # hooks fire: b's bucket first (its backward runs first), then a's
     for bk in buckets:
         bk.wait()
-    mine = torch.cat([bk.flat_g for bk in buckets]).clone()
+    mine = torch.cat([p.grad.reshape(-1) for bk in buckets for p in bk.params]).clone()   # views into the (padded) flat buffers
     # reference: local gradients recomputed without hooks, averaged with an explicit all_reduce
     a2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Linear(5, 3))
     b2 = torch.nn.Linear(3, 2)

@@ -15,7 +15,7 @@ runs=[]
 with torch.no_grad():
     for it in range(4):
         out, graph = cmm_train.build(m, x1, x2)
-        dxs, gr = cmm_train.backward(m, graph, cot.clone())
+        dxs, gr, _ = cmm_train.backward(m, graph, cot.clone())
         torch.cuda.synchronize()
         runs.append(([u_.out.G.clone() if (u_.out.G is not None and u_.out.G is not False) else None for u_ in graph['units']], [u_.out.r.clone() if u_.out.r is not None else None for u_ in graph['units']], dxs, graph))
 names=[(u_.kind, tuple(u_.out.r.shape) if u_.out.r is not None else None) for u_ in runs[0][3]['units']]
