@@ -78,7 +78,7 @@ SIGNATURES = {
     "dpmn_blend_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, _f, _i, _i, fp]),
     "dpmn_psnr_ssim_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpmn_psnr_ssim_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, fp, _i, _i, _i, _i, fp]),
-    "dpmn_gemm_tn_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_gemm_tn_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp, _sz, fp]),
     "dpmn_colsum_f32": (_i, [fp, fp, C.c_long, _i, fp]),
     "dpmn_layernorm_bwd_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp]),
     "dpmn_layernorm_f32": (_i, [fp, fp, fp, _f, fp, C.c_long, _i, fp]),
@@ -108,7 +108,7 @@ SIGNATURES = {
     "dpmn_bn_finalize_f32": (_i, [fp, fp, fp, _f, _f, _f, fp, fp, fp, fp, fp, fp, _i, fp]),
     "dpmn_affine_act_bwd_f32": (_i, [fp, fp, fp, fp, _i, fp, _i, C.c_long, _i, fp]),
     "dpmn_bn_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_long, _i, fp]),
-    "dpmn_se_gate_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_se_gate_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_affine_act_fwd_f32": (_i, [fp, fp, fp, _i, fp, C.c_long, _i, fp]),
     "dpmn_l1_loss_fwd_f32": (_i, [fp, fp, _f, fp, fp, C.c_long, fp]),
     "dpmn_l1_loss_bwd_f32": (_i, [fp, fp, fp, _f, fp, fp, fp, C.c_long, fp]),

@@ -6,6 +6,7 @@
 //   * k_act_bwd        dpre = dy * act'(pre)  (GELU / ReLU / LeakyReLU / mish)
 //   * k_image_loss_*   ImageLoss = MSE + L1 of gradient-magnitude maps (loss/image_loss.py:15-43), forward + backward
 // Data-gradients of linears / convs reuse the forward GEMM / implicit-GEMM kernels with transposed weights.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -16,7 +17,8 @@ namespace {
 // Block 256 threads: 96 (n) x 96 (k) output tile, waves 2 x 2 -> 48 x 48 each (3 x 3 MFMA tiles); grid.z splits M;
 // partial results are accumulated into dW with fp32 atomics (gradient accumulation semantics: caller zeroes).
 __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, int ldy, const float* __restrict__ x, int ldx,
-                                                  float* __restrict__ dw, int ldw, int M, int N, int K, int rows_per_block) {
+                                                  float* __restrict__ dw, int ldw, int M, int N, int K, int rows_per_block,
+                                                  float* __restrict__ db, float* __restrict__ part) {
   constexpr int BT = 96, BMc = 32, LD = BT + 4;
   __shared__ __attribute__((aligned(16))) float Ys[2][BMc * LD];
   __shared__ __attribute__((aligned(16))) float Xs[2][BMc * LD];
@@ -52,6 +54,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, i
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // bias gradient db[n] = sum_m dY[m][n] rides along as dY^T . 1 on the waves of the first k tile (wave-uniform branch)
+  const bool with_db = db != nullptr && blockIdx.y == 0 && wk == 0;
+  f32x4 accb[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (m_lo < m_hi) { gload(m_lo); sstore(0); }
   __syncthreads();
   int buf = 0;
@@ -71,6 +78,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, i
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(a[i], b[j], acc[i][j]);
+        if (with_db) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) accb[i] = mfma16(a[i], 1.0f, accb[i]);
+        }
       }
     }
     if (m0 + BMc < m_hi) sstore(buf ^ 1);
@@ -78,6 +89,30 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, i
     buf ^= 1;
   }
   // lane holds D[n = .. + kq*4 + r][k = .. + lr]
+  if (part) {     // deterministic path: this split's tile goes to part[z][n][k] (+ part[z][N*K + n] for db), summed by k_tn_reduce
+    float* pz = part + (size_t)blockIdx.z * ((size_t)N * K + N);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int k = k_blk + wk * 48 + j * 16 + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n_blk + wn * 48 + i * 16 + kq * 4 + r;
+          if (n < N && k < K) pz[(size_t)n * K + k] = acc[i][j][r];
+        }
+      }
+    if (with_db && lr == 0) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n_blk + wn * 48 + i * 16 + kq * 4 + r;
+          if (n < N) pz[(size_t)N * K + n] = accb[i][r];
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -89,6 +124,40 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, i
         if (n < N && k < K) atomicAdd(dw + (size_t)n * ldw + k, acc[i][j][r]);
       }
     }
+  if (with_db && lr == 0) {       // every column of accb holds the same sum
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n_blk + wn * 48 + i * 16 + kq * 4 + r;
+        if (n < N) atomicAdd(db + n, accb[i][r]);
+      }
+  }
+}
+
+// dw[e] += sum_z part[z][e] for e < N*K ; db[n] += sum_z part[z][N*K + n].  Block = 64 elements x 4 split groups.
+__global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                    int NK, int N, int splits) {
+  __shared__ float red[4][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), zg = threadIdx.x >> 6;
+  const int tot = NK + (db ? N : 0);
+  const size_t zs = (size_t)NK + N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < tot) {
+    int z = zg;
+    for (; z + 12 < splits; z += 16) {
+      s0 += part[(size_t)z * zs + e]; s1 += part[(size_t)(z + 4) * zs + e];
+      s2 += part[(size_t)(z + 8) * zs + e]; s3 += part[(size_t)(z + 12) * zs + e];
+    }
+    for (; z < splits; z += 4) s0 += part[(size_t)z * zs + e];
+  }
+  red[zg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (zg == 0 && e < tot) {
+    const int c = threadIdx.x;
+    const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (e < NK) dw[e] += v; else db[e - NK] += v;
+  }
 }
 
 // db[n] += sum_m dy[m][n].  Block = 256 threads over a (rows_per_block x N) slab: thread -> (row lane = tid / cols4,
@@ -279,16 +348,26 @@ __global__ void k_image_loss_bwd(const float* __restrict__ o, long o_stride, con
 
 extern "C" {
 
-int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, int M, int N, int K, dpmn_stream_t stream) {
+int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
+                     dpmn_stream_t stream) {
   DPMN_REQUIRE(dy && x && dw && M > 0 && N % 4 == 0 && K % 4 == 0, "gemm_tn: bad arguments (N, K multiples of 4)");
   const int tiles = cdiv(N, 96) * cdiv(K, 96);
-  int splits = cdiv(1024, tiles);
+  int splits = cdiv(256, tiles);
   int rows = cdiv(cdiv(M, splits), 32) * 32;
   if (rows < 32) rows = 32;
   splits = cdiv(M, rows);
   dim3 grid(cdiv(N, 96), cdiv(K, 96), splits);
-  hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, as_stream(stream), dy, N, x, K, dw, K, M, N, K, rows);
+  // with a workspace the splits are reduced by a second kernel (deterministic, no same-address atomic pile-up);
+  // without one they are accumulated with fp32 atomics
+  const size_t need = (size_t)splits * ((size_t)N * K + N) * sizeof(float);
+  float* part = (ws && ws_bytes >= need && splits > 1) ? ws : nullptr;
+  hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, as_stream(stream), dy, N, x, K, dw, K, M, N, K, rows, db, part);
   DPMN_CHECK_LAUNCH();
+  if (part) {
+    const int tot = N * K + (db ? N : 0);
+    hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(tot, 64)), dim3(256), 0, as_stream(stream), part, dw, db, N * K, N, splits);
+    DPMN_CHECK_LAUNCH();
+  }
   return DPMN_OK;
 }
 

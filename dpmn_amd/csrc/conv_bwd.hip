@@ -291,12 +291,13 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ G, const float* __restr
 }
 
 // ---------------------------------------------------------------------------------- CMM channel gate backward
-// g = x * (1 + w), w = sigmoid(fc2(relu(fc1(mean_p x)))) ; one workgroup per image
+// g = x * (1 + w), w = sigmoid(fc2(relu(fc1(mean_p x)))).
+// Pass 1, one workgroup per image: recompute the gate, form dx and leave (S, relu(h), dlogit, dh) in ws[b].
+// Pass 2, one thread per weight element: reduce the per-image outer products over the batch (no atomics).
 __global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ x, const float* __restrict__ dg,
                                                       const float* __restrict__ fc1_w, const float* __restrict__ fc1_b,
                                                       const float* __restrict__ fc2_w, const float* __restrict__ fc2_b,
-                                                      float* __restrict__ dx, float* __restrict__ dfc1_w, float* __restrict__ dfc1_b,
-                                                      float* __restrict__ dfc2_w, float* __restrict__ dfc2_b, int P, int C, int Cm) {
+                                                      float* __restrict__ dx, float* __restrict__ ws, int P, int C, int Cm) {
   extern __shared__ float sm[];
   float* S = sm;            // [C] mean
   float* Hp = S + C;        // [Cm] pre-relu
@@ -332,8 +333,6 @@ __global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ x
     }
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) atomicAdd(dfc2_b + c, dlog[c]);
-  for (int i = tid; i < C * Cm; i += 256) atomicAdd(dfc2_w + i, dlog[i / Cm] * fmaxf(Hp[i % Cm], 0.f));
   for (int j = wave; j < Cm; j += 4) {
     float a = 0.f;
     for (int c = lane; c < C; c += 64) a += dlog[c] * fc2_w[(size_t)c * Cm + j];
@@ -341,16 +340,40 @@ __global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ x
     if (lane == 0) dh[j] = Hp[j] > 0.f ? a : 0.f;
   }
   __syncthreads();
-  for (int j = tid; j < Cm; j += 256) atomicAdd(dfc1_b + j, dh[j]);
-  for (int i = tid; i < Cm * C; i += 256) atomicAdd(dfc1_w + i, dh[i / C] * S[i % C]);
   for (int c = tid; c < C; c += 256) {
     float a = 0.f;
     for (int j = 0; j < Cm; ++j) a += dh[j] * fc1_w[(size_t)j * C + c];
     dSm[c] = a / (float)P;
   }
+  float* wb = ws + (size_t)b * (2 * C + 2 * Cm);     // [S | dlog | relu(h) | dh]
+  for (int c = tid; c < C; c += 256) { wb[c] = S[c]; wb[C + c] = dlog[c]; }
+  for (int j = tid; j < Cm; j += 256) { wb[2 * C + j] = fmaxf(Hp[j], 0.f); wb[2 * C + Cm + j] = dh[j]; }
   __syncthreads();
   float* db_ = dx + (size_t)b * P * C;
   for (int i = tid; i < P * C; i += 256) db_[i] = gb[i] * (1.f + Wg[i % C]) + dSm[i % C];
+}
+__global__ void k_se_gate_bwd_w(const float* __restrict__ ws, float* __restrict__ dfc1_w, float* __restrict__ dfc1_b,
+                                float* __restrict__ dfc2_w, float* __restrict__ dfc2_b, int B, int C, int Cm) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nw = C * Cm, st = 2 * C + 2 * Cm;
+  float a = 0.f;
+  if (idx < nw) {                       // dfc2_w[c][j] = sum_b dlog[b][c] * relu(h)[b][j]
+    const int c = idx / Cm, j = idx - c * Cm;
+    for (int b = 0; b < B; ++b) a += ws[(size_t)b * st + C + c] * ws[(size_t)b * st + 2 * C + j];
+    dfc2_w[idx] += a;
+  } else if (idx < 2 * nw) {            // dfc1_w[j][c] = sum_b dh[b][j] * S[b][c]
+    const int e = idx - nw, j = e / C, c = e - j * C;
+    for (int b = 0; b < B; ++b) a += ws[(size_t)b * st + 2 * C + Cm + j] * ws[(size_t)b * st + c];
+    dfc1_w[e] += a;
+  } else if (idx < 2 * nw + C) {
+    const int c = idx - 2 * nw;
+    for (int b = 0; b < B; ++b) a += ws[(size_t)b * st + C + c];
+    dfc2_b[c] += a;
+  } else if (idx < 2 * nw + C + Cm) {
+    const int j = idx - 2 * nw - C;
+    for (int b = 0; b < B; ++b) a += ws[(size_t)b * st + 2 * C + Cm + j];
+    dfc1_b[j] += a;
+  }
 }
 
 // ---------------------------------------------------------------------------------- DistillModule tail + optimizer
@@ -520,11 +543,16 @@ int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const fl
 }
 
 int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, const float* fc1_b, const float* fc2_w,
-                         const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b, int B, int P,
-                         int C, int Cmid, dpmn_stream_t stream) {
-  DPMN_REQUIRE(x && dg && fc1_w && fc1_b && fc2_w && fc2_b && dx && dfc1_w && dfc1_b && dfc2_w && dfc2_b && B > 0, "se_gate_bwd: bad arguments");
+                         const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b, float* ws,
+                         int B, int P, int C, int Cmid, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && dg && fc1_w && fc1_b && fc2_w && fc2_b && dx && dfc1_w && dfc1_b && dfc2_w && dfc2_b && ws && B > 0,
+               "se_gate_bwd: bad arguments (ws: B*(2C+2Cmid) floats)");
   hipLaunchKernelGGL(k_se_gate_bwd, dim3(B), dim3(256), (size_t)(5 * C + 2 * Cmid) * 4, as_stream(stream), x, dg, fc1_w, fc1_b, fc2_w,
-                     fc2_b, dx, dfc1_w, dfc1_b, dfc2_w, dfc2_b, P, C, Cmid);
+                     fc2_b, dx, ws, P, C, Cmid);
+  DPMN_CHECK_LAUNCH();
+  const int total = 2 * C * Cmid + C + Cmid;
+  hipLaunchKernelGGL(k_se_gate_bwd_w, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), ws, dfc1_w, dfc1_b, dfc2_w, dfc2_b, B,
+                     C, Cmid);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

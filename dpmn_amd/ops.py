@@ -109,7 +109,7 @@ def pgrm_tail(tokens, w0, b0, w1, b1, weight_list, residuals, H, W, hidden, patc
 _SPLITK_WS = {}
 
 
-def _splitk_workspace(device, floats=16 << 20):
+def splitk_workspace(device, floats=16 << 20):
     """One 64 MB scratch per device for split-K partial sums (stream-ordered reuse: every conv consumes it before
     the next launch on the same stream)."""
     key = (device.type, device.index)
@@ -183,7 +183,7 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
     d.out = dptr(out)
     d.out_ld, d.out_coff, d.out_nchw, d.pixel_shuffle = 0, 0, int(out_nchw), int(pixel_shuffle)
     d.stats = dptr(stats, True)
-    ws = _splitk_workspace(wp.device)
+    ws = splitk_workspace(wp.device)
     d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     import ctypes as _C
     check(lib.dpmn_conv2d_nhwc_f32(_C.byref(d), stream()))

@@ -219,9 +219,10 @@ def backward(m, graph, dout, need_dx=(True, True)):
             # channel gate backward, then split the bottleneck gradient into the two en_6 outputs
             g = graph["gated"]
             dbott = torch.empty_like(graph["bott"])
+            se_ws = torch.empty(dbott.shape[0], 2 * dbott.shape[3] + 2 * m.fc_1.weight.shape[0], device=dbott.device)
             check(lib.dpmn_se_gate_bwd_f32(dptr(graph["bott"]), dptr(g.G), dptr(m.fc_1.weight), dptr(m.fc_1.bias), dptr(m.fc_2.weight),
                                            dptr(m.fc_2.bias), dptr(dbott), dptr(gr[m.fc_1.weight]), dptr(gr[m.fc_1.bias]),
-                                           dptr(gr[m.fc_2.weight]), dptr(gr[m.fc_2.bias]), dbott.shape[0], dbott.shape[1] * dbott.shape[2],
+                                           dptr(gr[m.fc_2.weight]), dptr(gr[m.fc_2.bias]), dptr(se_ws), dbott.shape[0], dbott.shape[1] * dbott.shape[2],
                                            dbott.shape[3], m.fc_1.weight.shape[0], stream()))
             half = dbott.shape[3] // 2
             a[5].G = dbott[..., :half].contiguous()

@@ -47,9 +47,11 @@ def act_bwd(dy, pre, act=GELU):
     return d
 
 
-def gemm_tn(dy, x, dw):
-    """dw (N,K) += dy (M,N)^T x (M,K)"""
-    check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dy.shape[0], dy.shape[1], x.shape[1], stream()))
+def gemm_tn(dy, x, dw, db=None):
+    """dw (N,K) += dy (M,N)^T x (M,K) ; db (N) += column sums of dy (fused into the same kernel)"""
+    ws = ops.splitk_workspace(dy.device)
+    check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), dy.shape[0], dy.shape[1], x.shape[1], dptr(ws),
+                               ws.numel() * 4, stream()))
 
 
 def colsum(dy, db):
@@ -58,9 +60,7 @@ def colsum(dy, db):
 
 def linear_bwd(dy, x, w, dw, db):
     """y = x w^T + b : returns dx; accumulates dw, db."""
-    gemm_tn(dy, x, dw)
-    if db is not None:
-        colsum(dy, db)
+    gemm_tn(dy, x, dw, db)
     return ops.linear(dy, w.t().contiguous())
 
 
@@ -246,8 +246,7 @@ def backward(m, sv, dout, need_dx_kv=True):
                                        dptr(gr[sk.fc2.weight]), dptr(gr[sk.fc2.bias]), B, Cd, G, sk.fc1.weight.shape[0], stream()))
         dfeats = torch.empty(M, Cd, device=dout.device)
         check(lib.dpmn_sk_feats_grad_f32(dptr(dx1), dptr(s["feats"]), dptr(dS), dptr(dfeats), M, L, Cd, stream()))
-        gemm_tn(dfeats, s["cat"], gr[sk.proj.weight])
-        colsum(dfeats, gr[sk.proj.bias])
+        gemm_tn(dfeats, s["cat"], gr[sk.proj.weight], gr[sk.proj.bias])
         dcat = ops.linear(dfeats, sk.proj.weight.t().contiguous(), None, res1=dcat)
         # window attention
         dq = torch.empty(M, Cd, device=dout.device)
@@ -273,9 +272,8 @@ def backward(m, sv, dout, need_dx_kv=True):
                                            dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
                                            dptr(gr[pe.norm.weight]), dptr(gr[pe.norm.bias]), B, img.shape[2], img.shape[3], Cd, stream()))
         dw16 = torch.zeros(Cd, 16, device=dout.device)
-        gemm_tn(dconv, patches, dw16)
+        gemm_tn(dconv, patches, dw16, gr[pe.proj.bias])
         gr[pe.proj.weight] += dw16[:, :12].reshape(pe.proj.weight.shape)
-        colsum(dconv, gr[pe.proj.bias])
         need_din = fuse or (which == "kv" and need_dx_kv)
         if need_din:
             w16 = torch.zeros(16, Cd, device=dout.device)

@@ -174,7 +174,9 @@ int dpmn_psnr_ssim_f32(const float* x, long x_stride, const float* y, long y_str
  * replaced by explicit kernels; weight-gradient entries ACCUMULATE into their output (caller zeroes, like
  * optimizer.zero_grad, super_resolution.py:141). */
 /* dw (N,K) += dy (M,N)^T . x (M,K): nn.Linear weight gradient */
-int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, int M, int N, int K, dpmn_stream_t stream);
+int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db /* (N) += column sums of dy, or NULL */, int M,
+                     int N, int K, float* ws /* split partials; NULL or too small: fp32 atomics instead */, size_t ws_bytes,
+                     dpmn_stream_t stream);
 /* db (N) += column sums of dy (M,N) */
 int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream);
 /* LayerNorm backward from the saved pre-norm input x; dx written or accumulated; dgamma/dbeta accumulated */
@@ -252,8 +254,8 @@ int dpmn_affine_act_bwd_f32(const float* dA, const float* r, const float* scale,
 int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const float* mean, const float* rstd, float* sums_ws,
                     float* dr, float* dgamma, float* dbeta, long pixels, int C, dpmn_stream_t stream);
 int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, const float* fc1_b, const float* fc2_w,
-                         const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b, int B,
-                         int P, int C, int Cmid, dpmn_stream_t stream);
+                         const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b,
+                         float* ws /* B*(2C+2Cmid) floats */, int B, int P, int C, int Cmid, dpmn_stream_t stream);
 
 /* DistillModule pieces (distill_module.py:18-31): y = act(scale*r+shift); L1 loss forward / backward */
 int dpmn_affine_act_fwd_f32(const float* r, const float* scale, const float* shift, int act, float* y, long pixels, int C,

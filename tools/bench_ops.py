@@ -109,3 +109,17 @@ wgrad_case("256->512 k3 4x16", 256, 512, 3, 4, 16)
 wgrad_case("512->512 k3 2x8", 512, 512, 3, 2, 8)
 wgrad_case("192->4 k3 32x128", 192, 4, 3, 32, 128)
 wgrad_case("8->4 k3 32x128", 8, 4, 3, 32, 128)
+
+
+# ---- linear weight gradients dW = dY^T X (+ fused bias gradient), tokens M = 49152
+def gemm_tn_case(N, K):
+    from dpmn_amd.train.pgrm_train import gemm_tn
+    dy = u("tn_dy%d" % N, (M, N)); xx = u("tn_x%d" % K, (M, K))
+    big = torch.zeros(64 << 20, device=dev)          # cold destination, like the optimizer's flat gradient bucket
+    dw = big[(32 << 20):(32 << 20) + N * K].view(N, K); db = big[(48 << 20):(48 << 20) + N]
+    timeit("gemm_tn N=%d K=%d" % (N, K), lambda: gemm_tn(dy, xx, dw), 2.0 * M * N * K, 4.0 * M * (N + K))
+    timeit("gemm_tn+db N=%d K=%d" % (N, K), lambda: gemm_tn(dy, xx, dw, db), 2.0 * M * N * K, 4.0 * M * (N + K))
+
+
+for N_, K_ in ((96, 96), (192, 96), (384, 96), (96, 384)):
+    gemm_tn_case(N_, K_)
