@@ -219,6 +219,24 @@ __global__ void k_wgrad_unpack(float* __restrict__ dwp, float* __restrict__ dw, 
   dw[base + co * s_co + ci * s_ci + ty * s_ky + tx * s_kx] += v;
 }
 
+// parameter layout -> packed (Cout_p, Kp), zero filled outside (co_lim, ci_lim, K): the inverse gather of k_wgrad_unpack.
+// One launch per conv per step replaces the permute / flip / cat / contiguous chain of the host-side packers.
+__global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Kp, int K, int cin, int KW, int co_lim,
+                            int ci_lim, long s_co, long s_ci, long s_ky, long s_kx, long base) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)Cout * Kp) return;
+  const int co = (int)(idx / Kp), k = (int)(idx - (long)co * Kp);
+  float v = 0.f;
+  if (k < K && co < co_lim) {
+    const int tp = k / cin, ci = k - tp * cin;
+    if (ci < ci_lim) {
+      const int ty = tp / KW, tx = tp - ty * KW;
+      v = w[base + co * s_co + ci * s_ci + ty * s_ky + tx * s_kx];
+    }
+  }
+  wp[idx] = v;
+}
+
 // ---------------------------------------------------------------------------------- train-mode BatchNorm
 // stats (32,2,C) = slotted (sum, sumsq) over `count` values per channel (accumulated by the conv epilogue)
 __global__ void k_bn_finalize(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -489,6 +507,17 @@ int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, 
   for (int s = 0; s < 3; ++s) cin += d->in[s] ? d->cseg[s] : 0;
   const long Kp = ((long)(d->KH * d->KW * cin + 31) / 32) * 32;
   return launch_wgrad(d, dy, dwp, d->Cout, cin, Kp, 1, (long)d->KW * cin, cin, 0, stream);
+}
+
+int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co, long s_ci,
+                       long s_ky, long s_kx, long base, dpmn_stream_t stream) {
+  DPMN_REQUIRE(w && wp && Cout > 0 && cin > 0 && KH > 0 && KW > 0, "conv_pack: bad arguments");
+  const int K = KH * KW * cin, Kp = (K + 31) / 32 * 32;
+  const long total = (long)Cout * Kp;
+  hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, wp, Cout, Kp, K, cin, KW,
+                     co_lim < Cout ? co_lim : Cout, ci_lim < cin ? ci_lim : cin, s_co, s_ci, s_ky, s_kx, base);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
 }
 
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,

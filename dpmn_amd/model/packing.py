@@ -88,3 +88,65 @@ def pack_bwd_data_generic(weight):
     """Conv2d weight (Cout, Cin, KH, KW) -> (Cin, KH*KW*Cout) pack for the data gradient run as a dil=-1 conv of dY."""
     cout, cin, kh, kw = weight.shape
     return _finish(weight.permute(1, 2, 3, 0), None, None)
+
+
+# ---------------------------------------------------------------------------------------- training: one-launch packers
+# The training step re-packs every conv weight every iteration (the parameters change), forward and data-gradient
+# variants alike.  These build the same (Cout_p, Kp) packs as the functions above with ONE dpmn_conv_pack_f32 launch
+# each, reading the parameter's own storage through (s_co, s_ci, s_ky, s_kx, base) strides.  `c0`/`cs` select an
+# input-channel segment (concat inputs get one data-gradient conv per segment).
+def _gpu_pack(w, cout_p, cin_p, kh, kw, co_lim, ci_lim, st):
+    from .._abi import lib, check, dptr, stream
+    assert w.is_contiguous() and w.is_cuda
+    kp = (kh * kw * cin_p + 31) // 32 * 32
+    wp = torch.empty(cout_p, kp, device=w.device)
+    check(lib.dpmn_conv_pack_f32(dptr(w), dptr(wp), cout_p, cin_p, kh, kw, co_lim, ci_lim, *st, stream()))
+    return wp
+
+
+def tpack_conv(w, cin_pad=None, cout_pad=None):
+    """== pack_conv(w, cin_pad=...)[0] for an nn.Conv2d weight (O, I, KH, KW)."""
+    o, i, kh, kw = w.shape
+    return _gpu_pack(w, cout_pad or o, cin_pad or i, kh, kw, o, i, (i * kh * kw, kh * kw, kw, 1, 0))
+
+
+def tpack_convT_s1(wt, cout_pad=None):
+    """== pack_convT_s1(wt)[0] for an nn.ConvTranspose2d weight (I, O, KH, KW): flipped taps, in/out swapped."""
+    i, o, kh, kw = wt.shape
+    return _gpu_pack(wt, cout_pad or o, i, kh, kw, o, i, (kh * kw, o * kh * kw, -kw, -1, kh * kw - 1))
+
+
+def tpack_convT_s2k4(wt):
+    """== [p[0] for p in pack_convT_s2k4(wt)]: the 4 phase packs of an nn.ConvTranspose2d(4,2,1) weight (I, O, 4, 4)."""
+    i, o = wt.shape[:2]
+    return [_gpu_pack(wt, o, i, 2, 2, o, i, (16, o * 16, 8, 2, (1 - py) * 4 + (1 - px))) for py in range(2) for px in range(2)]
+
+
+def tpack_dgrad_conv_s1(w, c0, cs):
+    """== pack_convT_s1(w[:, c0:c0+cs])[0]: data gradient of a stride-1 nn.Conv2d (O, I, KH, KW) w.r.t. input channels
+    [c0, c0+cs) as a conv of dY with the flipped, transposed kernel."""
+    o, i, kh, kw = w.shape
+    kk = kh * kw
+    return _gpu_pack(w, cs, o, kh, kw, cs, o, (kk, i * kk, -kw, -1, c0 * kk + kk - 1))
+
+
+def tpack_dgrad_convT(wt, c0, cs, cin_pad=None):
+    """== pack_conv(wt[c0:c0+cs], cin_pad=...)[0]: data gradient of an nn.ConvTranspose2d (I, O, KH, KW) w.r.t. input
+    channels [c0, c0+cs) is the plain Conv2d of dY with weight (out = I-segment, in = O)."""
+    i, o, kh, kw = wt.shape
+    kk = kh * kw
+    return _gpu_pack(wt, cs, cin_pad or o, kh, kw, cs, o, (o * kk, kk, kw, 1, c0 * o * kk))
+
+
+def tpack_dgrad_conv_s2k4(w, c0, cs):
+    """== [p[0] for p in pack_convT_s2k4(w[:, c0:c0+cs])]: data gradient of nn.Conv2d(4, stride 2, pad 1) (O, I, 4, 4) as the
+    4 phases of the matching transposed conv."""
+    o, i = w.shape[:2]
+    return [_gpu_pack(w, cs, o, 2, 2, cs, o, (16, i * 16, 8, 2, c0 * 16 + (1 - py) * 4 + (1 - px))) for py in range(2) for px in range(2)]
+
+
+def tpack_dgrad_generic(w, c0, cs):
+    """== pack_bwd_data_generic(w[:, c0:c0+cs])[0]: (Cin-seg, KH*KW*Cout), taps not flipped (used with dil = -1)."""
+    o, i, kh, kw = w.shape
+    kk = kh * kw
+    return _gpu_pack(w, cs, o, kh, kw, cs, o, (kk, i * kk, kw, 1, c0 * kk))

@@ -74,14 +74,11 @@ class Unit:
         cout = w.shape[1] if transposed else w.shape[0]
         stats = torch.zeros(32, 2, cout, device=w.device) if self.bn is not None else None
         if self.kind == "convT4s2":
-            packs = packing.pack_convT_s2k4(w, b)
+            packs = [(wp, b) for wp in packing.tpack_convT_s2k4(w)]
             r = ops.convT_s2k4(xs, packs, cout, pro_act=self.pro_act, affine=aff, stats=stats)
         else:
-            if self.kind == "convT3":
-                wp, bp = packing.pack_convT_s1(w, b)
-            else:
-                wp, bp = packing.pack_conv(w, b, cin_pad=self.cin_pad)
-            r = ops.conv2d(xs, wp, bp, cout, pro_act=self.pro_act, affine=aff, stats=stats, **self._fw())
+            wp = packing.tpack_convT_s1(w) if self.kind == "convT3" else packing.tpack_conv(w, cin_pad=self.cin_pad)
+            r = ops.conv2d(xs, wp, b, cout, pro_act=self.pro_act, affine=aff, stats=stats, **self._fw())
         if self.bn is not None:
             count = r.numel() // cout
             self.out = T(r, self.bn, *_bn_finalize(stats, self.bn, count))
@@ -136,20 +133,20 @@ class Unit:
                 continue
             B, Hi, Wi, _ = t.r.shape
             if self.kind == "conv3":
-                wt, _ = packing.pack_convT_s1(w[:, c0:c0 + cs])
+                wt = packing.tpack_dgrad_conv_s1(w, c0, cs)
                 dA = ops.conv2d([dr], wt, None, cs, 3, pad=1)
             elif self.kind == "convT3":
-                wt, _ = packing.pack_conv(w[c0:c0 + cs], cin_pad=cout)   # (Cin_seg, Cout, 3, 3) seen as Conv2d (out=Cin_seg, in=Cout)
+                wt = packing.tpack_dgrad_convT(w, c0, cs, cin_pad=cout)   # (Cin_seg, Cout, 3, 3) seen as Conv2d (out=Cin_seg, in=Cout)
                 dA = ops.conv2d([dr], wt, None, cs, 3, pad=1)
             elif self.kind == "convT4s2":
-                wt, _ = packing.pack_conv(w[c0:c0 + cs])
+                wt = packing.tpack_dgrad_convT(w, c0, cs)
                 dA = ops.conv2d([dr], wt, None, cs, 4, stride=2, pad=1)
             elif self.kind == "conv4s2":
-                packs = packing.pack_convT_s2k4(w[:, c0:c0 + cs])  # Conv2d weight (Cout, Cin, 4, 4) seen as ConvTranspose (in=Cout, out=Cin)
-                dA = ops.convT_s2k4([dr], packs, cs)
+                # Conv2d weight (Cout, Cin, 4, 4) seen as ConvTranspose (in=Cout, out=Cin)
+                dA = ops.convT_s2k4([dr], [(wp, None) for wp in packing.tpack_dgrad_conv_s2k4(w, c0, cs)], cs)
             elif self.kind == "conv4s2d2":
                 # iy = 2*oy + 2*ky - 3 is always odd: dX[2s+1] = sum_ky dY[s + 2 - ky] W[ky]; even pixels get zero gradient
-                wt, _ = packing.pack_bwd_data_generic(w[:, c0:c0 + cs])
+                wt = packing.tpack_dgrad_generic(w, c0, cs)
                 dA = torch.zeros(B, Hi, Wi, cs, device=dev)
                 Ho, Wo = dr.shape[1], dr.shape[2]
                 geom = dict(stride=1, dil_y=-1, dil_x=-1, pad_y=-2, pad_x=-2, Hp=Hi // 2, Wp=Wi // 2, Hout=Hi, Wout=Wi, ostep=2, ooy=1, oox=1)
@@ -157,9 +154,11 @@ class Unit:
             else:
                 raise ValueError(self.kind)
             sc, sh = (t.scale, t.shift) if t.scale is not None else (None, None)
-            Gt = t.grad_buf()
-            check(lib.dpmn_affine_act_bwd_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(Gt), 1,
-                                              t.r.numel() // cs, cs, stream()))
+            first = t.G is None          # first consumer writes, later ones accumulate: no zero fill of the activation
+            if first:
+                t.G = torch.empty_like(t.r)
+            check(lib.dpmn_affine_act_bwd_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
+                                              0 if first else 1, t.r.numel() // cs, cs, stream()))
             c0 += cs
 
 
@@ -193,7 +192,7 @@ def build(m, x1, x2):
         d = run("convT4s2", seq[4], seq[5], [t], "relu")
     last = Unit("convT3", m.de_1[1], None, [d, a[0], b[0]], "relu")
     units.append(last)
-    wp, bp = packing.pack_convT_s1(m.de_1[1].weight, m.de_1[1].bias)
+    wp, bp = packing.tpack_convT_s1(m.de_1[1].weight), m.de_1[1].bias
     out = ops.conv2d([d.r, a[0].r, b[0].r], wp, bp, m.c_img, 3, pad=1, pro_act="relu", affine=[d.aff, a[0].aff, b[0].aff], out_nchw=True)
     last.out = T(None)
     return out, dict(units=units, bott=bott, gated=gated, enc=enc, leaves=leaves, last=last)

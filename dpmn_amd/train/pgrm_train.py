@@ -120,8 +120,7 @@ class ConvSpec:
         self.pad = (self.k - 1) // 2
 
     def forward(self, x):
-        wp, bp = packing.pack_conv(self.weight, self.bias)
-        return ops.conv2d([x], wp, bp, self.cout, self.k, pad=self.pad)
+        return ops.conv2d([x], packing.tpack_conv(self.weight), self.bias, self.cout, self.k, pad=self.pad)
 
     def backward(self, x, dy, dweight, dbias, need_dx=True):
         """x (B,H,W,Cin) input of the forward, dy (B,H,W,Cout); accumulates dweight/dbias; returns dx."""
@@ -131,7 +130,7 @@ class ConvSpec:
         colsum(dy.reshape(-1, self.cout), dbias)
         if not need_dx:
             return None
-        wt, _ = packing.pack_convT_s1(self.weight)      # data gradient = transposed conv with the same weight tensor
+        wt = packing.tpack_dgrad_conv_s1(self.weight, 0, self.cin)   # data gradient = transposed conv with the same weight tensor
         return ops.conv2d([dy], wt, None, self.cin, self.k, pad=self.pad)
 
 

@@ -240,6 +240,11 @@ int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, 
 /* same, accumulated straight into the parameter's own layout (nn.Conv2d (Cout,Cin,KH,KW), nn.ConvTranspose2d
  * (Cin,Cout,KH,KW) flipped, or one phase of ConvTranspose2d(4,2,1)):
  *   dw[base + co*s_co + ci*s_ci + ky*s_ky + kx*s_kx] += ...   for co < co_lim, ci < ci_lim (padding channels dropped) */
+/* parameter layout -> packed (Cout,Kp) weights for dpmn_conv2d_nhwc_f32 (zero filled beyond co_lim / ci_lim / K):
+ *   wp[co][(ky*KW+kx)*cin + ci] = w[base + co*s_co + ci*s_ci + ky*s_ky + kx*s_kx]
+ * covers nn.Conv2d, flipped nn.ConvTranspose2d, the ConvTranspose2d(4,2,1) phases and every data-gradient re-pack */
+int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co, long s_ci,
+                       long s_ky, long s_kx, long base, dpmn_stream_t stream);
 /* packed (Cout,Kp) gradient -> += into the parameter layout (same stride convention as below); clear != 0 zeroes the
  * packed buffer afterwards so that a persistent workspace needs no memset before its next dpmn_conv2d_wgrad_f32 */
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
