@@ -13,6 +13,7 @@
 //   * epilogue: bias, activation, residual add, optional per-channel sum / sum-of-squares for
 //     train-mode BatchNorm statistics, NHWC or NCHW store, optional PixelShuffle(2) store.
 // MFMA roles as in gemm.hip: "A" = weight rows (co), "B" = pixels, so a lane owns 4 consecutive co.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -46,12 +47,35 @@ struct ConvArgs {
   float* partial;             // split-K scratch (ksplit, M, Npad) or null
   int ksplit;                 // number of K splits (gridDim.z)
   int npad;                   // Cout rounded up to 4
+  int nphase;                 // 4: the phases of ConvTranspose2d(4,2,1) in one launch (gridDim.z = nphase * ksplit):
+  long wps;                   //    phase p = 2*py + px uses w + p*wps, pad = -(py,px), output offset (py,px)
 };
 
+// phase-fused launch: the phase-dependent arguments of this workgroup (the kernel argument struct itself stays
+// read-only -- writing to it would spill it to scratch)
+struct PhaseSel {
+  int pad_y, pad_x, ooy, oox, zsplit;
+  const float* w;
+  float* partial;
+};
+__device__ __forceinline__ PhaseSel conv_select_phase(const ConvArgs& a, int z) {
+  PhaseSel s{a.pad_y, a.pad_x, a.ooy, a.oox, z, a.w, a.partial};
+  if (a.nphase > 1) {
+    const int ph = z / a.ksplit;
+    const int phy = ph >> 1, phx = ph & 1;
+    s.pad_y = -phy; s.pad_x = -phx; s.ooy = phy; s.oox = phx;
+    s.w = a.w + (size_t)ph * a.wps;
+    if (a.partial) s.partial = a.partial + (size_t)ph * a.ksplit * a.B * a.Hp * a.Wp * a.npad;
+    s.zsplit = z - ph * a.ksplit;
+  }
+  return s;
+}
+
 // bias + stats + activation + residual + store of 4 consecutive output channels of one pixel
-__device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, float (&v)[4], float (&ssum)[4], float (&ssq)[4]) {
+__device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, float (&v)[4], float (&ssum)[4], float (&ssq)[4], int ooy,
+                                           int oox) {
   const int b = m / (a.Hp * a.Wp), rr = m % (a.Hp * a.Wp);
-  const int oy = (rr / a.Wp) * a.ostep + a.ooy, ox = (rr % a.Wp) * a.ostep + a.oox;
+  const int oy = (rr / a.Wp) * a.ostep + ooy, ox = (rr % a.Wp) * a.ostep + oox;
 #pragma unroll
   for (int r = 0; r < 4; ++r) v[r] += ((a.bias && n + r < a.Cout) ? a.bias[n + r] : 0.f);
   if (a.stats) {
@@ -99,6 +123,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.B * a.Hp * a.Wp;
+  const PhaseSel ph = conv_select_phase(a, blockIdx.z);
+  const int zsplit = ph.zsplit;
   const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;
 
@@ -110,8 +136,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     if (m < M) {
       const int b = m / (a.Hp * a.Wp), r = m % (a.Hp * a.Wp);
       pb[p] = b;
-      py[p] = (r / a.Wp) * a.stride - a.pad_y;
-      px[p] = (r % a.Wp) * a.stride - a.pad_x;
+      py[p] = (r / a.Wp) * a.stride - ph.pad_y;
+      px[p] = (r % a.Wp) * a.stride - ph.pad_x;
     } else {
       pb[p] = -1; py[p] = 0; px[p] = 0;
     }
@@ -155,7 +181,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     for (int p = 0; p < BPASS; ++p) {
       const int r = lrow + p * 32;
       const int n = n_blk + r;
-      wr[p] = (r < BN && n < a.Cout) ? *reinterpret_cast<const float4*>(a.w + (size_t)n * a.Kp + k0 + lcol)
+      wr[p] = (r < BN && n < a.Cout) ? *reinterpret_cast<const float4*>(ph.w + (size_t)n * a.Kp + k0 + lcol)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -177,7 +203,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 
   const int nk_all = a.Kp / BK;
   const int cps = (nk_all + a.ksplit - 1) / a.ksplit;          // chunks per split
-  const int kt0 = blockIdx.z * cps;
+  const int kt0 = zsplit * cps;
   const int nk = min(nk_all, kt0 + cps);
   if (kt0 < nk) { gload(kt0 * BK); sstore(0); }
   __syncthreads();
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
       for (int i = 0; i < NT; ++i) {
         const int n = n_blk + wn * (NT * 16) + i * 16 + kq * 4;
         if (n >= a.npad) continue;
-        *reinterpret_cast<float4*>(a.partial + ((size_t)blockIdx.z * M + m) * a.npad + n) =
+        *reinterpret_cast<float4*>(ph.partial + ((size_t)zsplit * M + m) * a.npad + n) =
             make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }
@@ -234,7 +260,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
       const int n = n_blk + wn * (NT * 16) + i * 16 + kq * 4;
       if (n >= a.Cout) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      conv_store(a, m, n, v, ssum[i], ssq[i]);
+      conv_store(a, m, n, v, ssum[i], ssq[i], ph.ooy, ph.oox);
     }
   }
   if (a.stats) {
@@ -258,19 +284,20 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 
 // sum the split-K partials and run the epilogue.  Block = 64 channel-quads x 4 row lanes, 64 rows per block, so the
 // BatchNorm statistics are reduced over 64 rows in registers / LDS before one (slotted) atomic per channel.
-__global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a) {
+__global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows) {
   __shared__ float red[4][64][8];
+  const PhaseSel ph = conv_select_phase(a, blockIdx.z * a.ksplit);
   const int M = a.B * a.Hp * a.Wp;
   const int n4 = a.npad / 4;
   const int cq = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int n = cq * 4;
-  const int m_lo = blockIdx.y * 64;
+  const int m_lo = blockIdx.y * rows;
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   const size_t zs = (size_t)M * a.npad;
   if (cq < n4) {
-    for (int m = m_lo + rl; m < m_lo + 64 && m < M; m += 4) {
+    for (int m = m_lo + rl; m < m_lo + rows && m < M; m += 4) {
       float v[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* pp = a.partial + (size_t)m * a.npad + n;
+      const float* pp = ph.partial + (size_t)m * a.npad + n;
       int z = 0;
       for (; z + 4 <= a.ksplit; z += 4) {     // 4 independent loads in flight
         const float4 p0 = *reinterpret_cast<const float4*>(pp + (size_t)z * zs);
@@ -284,7 +311,7 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a) {
         const float4 p = *reinterpret_cast<const float4*>(pp + (size_t)z * zs);
         v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
       }
-      conv_store(a, m, n, v, ssum, ssq);
+      conv_store(a, m, n, v, ssum, ssq, ph.ooy, ph.oox);
     }
   }
   if (a.stats) {
@@ -460,7 +487,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
       const int n = n_blk + i * 16 + kq * 4;
       if (n >= a.Cout) continue;
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      conv_store(a, m, n, v, ssum[i], ssq[i]);
+      conv_store(a, m, n, v, ssum[i], ssq[i], a.ooy, a.oox);
     }
   }
   if (a.stats) {
@@ -499,25 +526,30 @@ int launch_halo(const ConvArgs& a, hipStream_t st) {
 template <int BM, int BN, int WM, int WN>
 int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   const int M = a.B * a.Hp * a.Wp;
-  const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN);
+  const int nph = a.nphase > 1 ? a.nphase : 1;
+  const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN) * nph;
   const int nk = a.Kp / BK;
   int S = 1;
   if (ws && tiles < 384 && nk >= 16) {
     S = cdiv(768, tiles);
     if (S > nk / 8) S = nk / 8;
     if (S > 64) S = 64;
-    const size_t cap = ws_bytes < ((size_t)16 << 20) ? ws_bytes : ((size_t)16 << 20);   // keep the partial-sum round trip small
-    while (S > 1 && (size_t)S * M * a.npad * sizeof(float) > cap) --S;
+    static const size_t cap_mb = getenv("DPMN_SPLITK_CAP_MB") ? (size_t)atoi(getenv("DPMN_SPLITK_CAP_MB")) : 32;
+    const size_t cap = ws_bytes < (cap_mb << 20) ? ws_bytes : (cap_mb << 20);   // keep the partial-sum round trip small
+    while (S > 1 && (size_t)S * nph * M * a.npad * sizeof(float) > cap) --S;
     const int cps = cdiv(nk, S);
     S = cdiv(nk, cps);   // no empty splits
   }
   a.ksplit = S;
   a.partial = S > 1 ? ws : nullptr;
-  dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN), S);
+  dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN), S * nph);
   hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
   DPMN_CHECK_LAUNCH();
   if (S > 1) {
-    hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(cdiv(a.npad / 4, 64), cdiv(M, 64)), dim3(256), 0, st, a);
+    // rows per block: 64 amortises the BatchNorm-statistics atomics on big outputs; small outputs need the parallelism
+    const int cb = cdiv(a.npad / 4, 64);
+    const int rows = cb * cdiv(M, 64) >= 1024 ? 64 : (cb * cdiv(M, 16) >= 1024 ? 16 : 4);
+    hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(cb, cdiv(M, rows), nph), dim3(256), 0, st, a, rows);
     DPMN_CHECK_LAUNCH();
   }
   return DPMN_OK;
@@ -564,6 +596,10 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   a.res = d->res; a.out = d->out; a.out_ld = d->out_ld > 0 ? d->out_ld : d->Cout; a.out_coff = d->out_coff;
   a.out_nchw = d->out_nchw; a.pixel_shuffle = d->pixel_shuffle; a.stats = d->stats;
   a.Kp = ((d->KH * d->KW * cin + 31) / 32) * 32;
+  a.nphase = d->nphase == 4 ? 4 : 1; a.wps = d->w_phase_stride;
+  DPMN_REQUIRE(d->nphase == 0 || d->nphase == 1 || (d->nphase == 4 && d->KH == 2 && d->KW == 2 && d->dil_y == -1 && d->dil_x == -1 &&
+                                                    d->ostep == 2 && d->w_phase_stride >= (long)d->Cout * a.Kp),
+               "conv2d: nphase = 4 is the fused ConvTranspose2d(4,2,1) launch (k 2, dil -1, ostep 2, 4 packed phase weights)");
   DPMN_REQUIRE(d->B > 0 && d->Hp > 0 && d->Wp > 0 && d->Cout > 0, "conv2d: empty shape");
   DPMN_REQUIRE(!(d->pixel_shuffle && (d->Cout % 4 != 0 || d->out_nchw || d->res)), "conv2d: bad pixel-shuffle epilogue");
   DPMN_REQUIRE(d->out_nchw || (a.out_ld % 4 == 0 && a.out_coff % 4 == 0) || d->Cout < 4 || d->pixel_shuffle,

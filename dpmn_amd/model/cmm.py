@@ -76,11 +76,11 @@ class ComplementationModulationModule(nn.Module):
                     P["en_%d_%s.b" % (lvl, br)] = packing.pack_conv(seq[4].weight, seq[4].bias, self._bn(seq[5]))
                 e6 = getattr(self, "en_6_" + br)[1]
                 P["en_6_" + br] = packing.pack_conv(e6.weight, e6.bias)
-            P["de_6"] = packing.pack_convT_s2k4(self.de_6[1].weight, self.de_6[1].bias, self._bn(self.de_6[2]))
+            P["de_6"] = ops.stack_phase_packs(packing.pack_convT_s2k4(self.de_6[1].weight, self.de_6[1].bias, self._bn(self.de_6[2])))
             for lvl in (5, 4, 3, 2):
                 seq = getattr(self, "de_%d" % lvl).decode
                 P["de_%d.a" % lvl] = packing.pack_convT_s1(seq[1].weight, seq[1].bias, self._bn(seq[2]))
-                P["de_%d.b" % lvl] = packing.pack_convT_s2k4(seq[4].weight, seq[4].bias, self._bn(seq[5]))
+                P["de_%d.b" % lvl] = ops.stack_phase_packs(packing.pack_convT_s2k4(seq[4].weight, seq[4].bias, self._bn(seq[5])))
             P["de_1"] = packing.pack_convT_s1(self.de_1[1].weight, self.de_1[1].bias)
         self._pack = (key, P)
         return P

@@ -95,13 +95,23 @@ def pack_bwd_data_generic(weight):
 # variants alike.  These build the same (Cout_p, Kp) packs as the functions above with ONE dpmn_conv_pack_f32 launch
 # each, reading the parameter's own storage through (s_co, s_ci, s_ky, s_kx, base) strides.  `c0`/`cs` select an
 # input-channel segment (concat inputs get one data-gradient conv per segment).
-def _gpu_pack(w, cout_p, cin_p, kh, kw, co_lim, ci_lim, st):
+def _gpu_pack(w, cout_p, cin_p, kh, kw, co_lim, ci_lim, st, out=None):
     from .._abi import lib, check, dptr, stream
     assert w.is_contiguous() and w.is_cuda
     kp = (kh * kw * cin_p + 31) // 32 * 32
-    wp = torch.empty(cout_p, kp, device=w.device)
+    wp = torch.empty(cout_p, kp, device=w.device) if out is None else out
     check(lib.dpmn_conv_pack_f32(dptr(w), dptr(wp), cout_p, cin_p, kh, kw, co_lim, ci_lim, *st, stream()))
     return wp
+
+
+def _gpu_pack_phases(w, cout_p, cin_p, st_of_phase):
+    """(4, Cout_p, Kp) phase-major pack for the fused ConvTranspose2d(4,2,1) launch (ops.convT_s2k4)."""
+    kp = (4 * cin_p + 31) // 32 * 32
+    wp4 = torch.empty(4, cout_p, kp, device=w.device)
+    for py in range(2):
+        for px in range(2):
+            _gpu_pack(w, cout_p, cin_p, 2, 2, cout_p, cin_p, st_of_phase(py, px), out=wp4[2 * py + px])
+    return wp4
 
 
 def tpack_conv(w, cin_pad=None, cout_pad=None):
@@ -117,9 +127,9 @@ def tpack_convT_s1(wt, cout_pad=None):
 
 
 def tpack_convT_s2k4(wt):
-    """== [p[0] for p in pack_convT_s2k4(wt)]: the 4 phase packs of an nn.ConvTranspose2d(4,2,1) weight (I, O, 4, 4)."""
+    """== stack of [p[0] for p in pack_convT_s2k4(wt)]: the 4 phase packs of an nn.ConvTranspose2d(4,2,1) weight (I, O, 4, 4)."""
     i, o = wt.shape[:2]
-    return [_gpu_pack(wt, o, i, 2, 2, o, i, (16, o * 16, 8, 2, (1 - py) * 4 + (1 - px))) for py in range(2) for px in range(2)]
+    return _gpu_pack_phases(wt, o, i, lambda py, px: (16, o * 16, 8, 2, (1 - py) * 4 + (1 - px)))
 
 
 def tpack_dgrad_conv_s1(w, c0, cs):
@@ -139,10 +149,10 @@ def tpack_dgrad_convT(wt, c0, cs, cin_pad=None):
 
 
 def tpack_dgrad_conv_s2k4(w, c0, cs):
-    """== [p[0] for p in pack_convT_s2k4(w[:, c0:c0+cs])]: data gradient of nn.Conv2d(4, stride 2, pad 1) (O, I, 4, 4) as the
-    4 phases of the matching transposed conv."""
+    """== stack of [p[0] for p in pack_convT_s2k4(w[:, c0:c0+cs])]: data gradient of nn.Conv2d(4, stride 2, pad 1)
+    (O, I, 4, 4) as the 4 phases of the matching transposed conv."""
     o, i = w.shape[:2]
-    return [_gpu_pack(w, cs, o, 2, 2, cs, o, (16, i * 16, 8, 2, c0 * 16 + (1 - py) * 4 + (1 - px))) for py in range(2) for px in range(2)]
+    return _gpu_pack_phases(w, cs, o, lambda py, px: (16, i * 16, 8, 2, c0 * 16 + (1 - py) * 4 + (1 - px)))
 
 
 def tpack_dgrad_generic(w, c0, cs):

@@ -190,16 +190,27 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
     return out
 
 
+def stack_phase_packs(packs):
+    """[(wp, bias)] * 4 from packing.pack_convT_s2k4 -> ((4, Cout, Kp) contiguous, bias) for the phase-fused launch."""
+    return torch.stack([p[0] for p in packs]).contiguous(), packs[0][1]
+
+
 def convT_s2k4(inputs, packs, cout, pro_act="none", affine=None, stats=None):
-    """ConvTranspose2d(4, stride 2, padding 1) as 4 phase launches into one NHWC output."""
+    """ConvTranspose2d(4, stride 2, padding 1): all 4 output phases in ONE launch (nphase = 4).
+    packs: ((4, Cout, Kp) phase-major packed weights, bias or None) -- see stack_phase_packs / packing.tpack_convT_s2k4."""
+    if isinstance(packs, list):
+        packs = stack_phase_packs(packs)
+    wp4, bias = packs
     B, Hin, Win, _ = inputs[0].shape
     out = torch.empty(B, 2 * Hin, 2 * Win, cout, device=inputs[0].device)
-    i = 0
-    for py in range(2):
-        for px in range(2):
-            wp, bias = packs[i]
-            conv2d(inputs, wp, bias, cout, 2, pro_act=pro_act, affine=affine, out=out, phase=(py, px), stats=stats)
-            i += 1
+    d = conv_desc(inputs, 2, cout=cout, pro_act=pro_act, affine=affine, phase=(0, 0))
+    d.nphase, d.w_phase_stride = 4, wp4.shape[1] * wp4.shape[2]
+    d.w, d.bias = dptr(wp4), dptr(bias, True)
+    d.out, d.stats = dptr(out), dptr(stats, True)
+    ws = splitk_workspace(out.device)
+    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+    import ctypes as _C
+    check(lib.dpmn_conv2d_nhwc_f32(_C.byref(d), stream()))
     return out
 
 

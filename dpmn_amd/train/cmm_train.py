@@ -74,8 +74,7 @@ class Unit:
         cout = w.shape[1] if transposed else w.shape[0]
         stats = torch.zeros(32, 2, cout, device=w.device) if self.bn is not None else None
         if self.kind == "convT4s2":
-            packs = [(wp, b) for wp in packing.tpack_convT_s2k4(w)]
-            r = ops.convT_s2k4(xs, packs, cout, pro_act=self.pro_act, affine=aff, stats=stats)
+            r = ops.convT_s2k4(xs, (packing.tpack_convT_s2k4(w), b), cout, pro_act=self.pro_act, affine=aff, stats=stats)
         else:
             wp = packing.tpack_convT_s1(w) if self.kind == "convT3" else packing.tpack_conv(w, cin_pad=self.cin_pad)
             r = ops.conv2d(xs, wp, b, cout, pro_act=self.pro_act, affine=aff, stats=stats, **self._fw())
@@ -143,7 +142,7 @@ class Unit:
                 dA = ops.conv2d([dr], wt, None, cs, 4, stride=2, pad=1)
             elif self.kind == "conv4s2":
                 # Conv2d weight (Cout, Cin, 4, 4) seen as ConvTranspose (in=Cout, out=Cin)
-                dA = ops.convT_s2k4([dr], [(wp, None) for wp in packing.tpack_dgrad_conv_s2k4(w, c0, cs)], cs)
+                dA = ops.convT_s2k4([dr], (packing.tpack_dgrad_conv_s2k4(w, c0, cs), None), cs)
             elif self.kind == "conv4s2d2":
                 # iy = 2*oy + 2*ky - 3 is always odd: dX[2s+1] = sum_ky dY[s + 2 - ky] W[ky]; even pixels get zero gradient
                 wt = packing.tpack_dgrad_generic(w, c0, cs)

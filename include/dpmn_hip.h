@@ -89,6 +89,10 @@ typedef struct {
                               * dpmn_bn_finalize_f32), or NULL */
   float* splitk_ws;          /* optional scratch enabling split-K for small-M / large-K convs (deep CMM levels) */
   size_t splitk_ws_bytes;
+  int nphase;                /* 0/1: one conv.  4: all phases of nn.ConvTranspose2d(4,2,1) (cmm.py:100-118) in one launch:
+                              * phase p = 2*py+px reads w + p*w_phase_stride, pad = -(py,px), writes output pixels
+                              * (2y+py, 2x+px); pad_y/pad_x/ooy/oox of the descriptor are ignored */
+  long w_phase_stride;       /* floats between consecutive packed phase weights */
 } dpmn_conv_desc;
 int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream);
 /* layout plumbing at the module boundary: NCHW images <-> NHWC (channels zero-padded to Cpad) */
