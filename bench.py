@@ -61,9 +61,22 @@ def roofline_pw(B, reps=30):
     ms = sum(s.elapsed_time(e) for s, e in evs) / reps
     flops = 2.0 * 384 * 384 * 1024 * B
     achieved = flops / (ms * 1e-3) / 1e12
+    # HBM bytes per launch: PMC counters cannot be read from inside this process; they come from the separate
+    # rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over tools/roofline_kernel.py (same kernel, same shapes),
+    # committed under profiles/ with the gfx950 correction already applied.  null when no pass matches this batch.
+    traffic, src = None, None
+    import glob
+    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_k_gemm_pw.json"))):
+        try:
+            rec = json.load(open(f))
+            if rec.get("workload", "").startswith("B=%d:" % B):
+                traffic, src = rec["hbm_bytes_per_launch"], os.path.basename(f)
+        except Exception:
+            pass
     return {"kernel": "k_gemm_pw (Mlp.pointwise_conv, pgrm.py:37)", "bound": "mfma", "achieved": round(achieved, 2),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": None, "launch_ms": round(ms, 4), "flops_per_launch": flops}
+            "traffic": traffic, "traffic_source": src, "algorithmic_bytes": 4.0 * (2 * B * 384 * 1024 + 384 * 384 + 384),
+            "launch_ms": round(ms, 4), "flops_per_launch": flops}
 
 
 def cpu_baseline_worker(workload_name, n_img, threads):

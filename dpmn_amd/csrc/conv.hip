@@ -614,7 +614,9 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
                        a.pad_y == (a.KH - 1) / 2 && a.pad_x == a.pad_y && a.Hin % 8 == 0 && a.Win % 16 == 0 && a.ostep == 1 &&
                        a.Hp == a.Hin && a.Wp == a.Win && cin % 32 == 0 && a.cseg[0] % 32 == 0 && a.cseg[1] % 32 == 0 &&
                        a.cseg[2] % 32 == 0 && M >= 1024;
-  if (halo_ok) {
+  // too few 8x16-pixel tiles to fill 256 CUs (deep decoder levels with 3-segment inputs): split-K implicit GEMM instead
+  const bool halo_starved = (M / 128) * cdiv(a.Cout, 64) < 256 && a.Cout >= 128 && ws != nullptr;
+  if (halo_ok && !halo_starved) {
     if (a.KH == 3) return a.Cout <= 16 ? launch_halo<3, 16>(a, st) : launch_halo<3, 64>(a, st);
     return a.Cout <= 16 ? launch_halo<9, 16>(a, st) : launch_halo<9, 64>(a, st);
   }
