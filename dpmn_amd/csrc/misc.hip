@@ -32,6 +32,34 @@ __global__ __launch_bounds__(256) void k_to_mask(const float* __restrict__ img, 
   }
 }
 
+// torch_rotate_img (utils/util.py:37-58): theta = [[cos, sin*r, 0], [-sin/r, cos, 0]] with r = H/W + (2*rand-1)*off_range,
+// F.affine_grid (align_corners=False: base x_j = (2j+1)/W - 1) and F.grid_sample (bilinear, zeros padding).
+// One thread per output pixel, all channels (the sampling position is channel-independent).
+__global__ void k_rotate_img(const float* __restrict__ img, const float* __restrict__ arc, const float* __restrict__ rand_off,
+                             float off_range, float* __restrict__ out, int N, int Cc, int H, int W) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)N * H * W) return;
+  const int x = idx % W, y = (idx / W) % H, n = idx / ((long)W * H);
+  const float ratio = (float)H / (float)W + rand_off[n] * off_range * 2.0f - off_range;
+  const float c = cosf(arc[n]), s = sinf(arc[n]);
+  const float bx = (2.0f * x + 1.0f) / (float)W - 1.0f, by = (2.0f * y + 1.0f) / (float)H - 1.0f;
+  const float gx = c * bx + (s * ratio) * by, gy = (-s / ratio) * bx + c * by;
+  const float ix = ((gx + 1.0f) * (float)W - 1.0f) * 0.5f, iy = ((gy + 1.0f) * (float)H - 1.0f) * 0.5f;
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x0 + 1 >= 0 && x0 + 1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y0 + 1 >= 0 && y0 + 1 < H;
+  for (int ch = 0; ch < Cc; ++ch) {
+    const float* p = img + ((size_t)n * Cc + ch) * H * W;
+    float v = 0.f;
+    if (vy0 && vx0) v += p[y0 * W + x0] * wy0 * wx0;
+    if (vy0 && vx1) v += p[y0 * W + x0 + 1] * wy0 * wx1;
+    if (vy1 && vx0) v += p[(y0 + 1) * W + x0] * wy1 * wx0;
+    if (vy1 && vx1) v += p[(y0 + 1) * W + x0 + 1] * wy1 * wx1;
+    out[((size_t)n * Cc + ch) * H * W + y * W + x] = v;
+  }
+}
+
 __global__ void k_blend(const float* __restrict__ a, long a_stride, const float* __restrict__ b, long b_stride,
                         float* __restrict__ out, float alpha, int chw, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -104,6 +132,16 @@ extern "C" {
 int dpmn_to_mask_f32(const float* img, long img_stride, float* out, int B, int H, int W, dpmn_stream_t stream) {
   DPMN_REQUIRE(img && out && B > 0 && H * W * 4 <= 64 * 1024, "to_mask: bad arguments (image must fit 64 KB of LDS as ints)");
   hipLaunchKernelGGL(k_to_mask, dim3(B), dim3(256), (size_t)H * W * 4, as_stream(stream), img, img_stride, out, H * W);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_rotate_img_f32(const float* img, const float* arc, const float* rand_offs, float off_range, float* out, int N, int C,
+                        int H, int W, dpmn_stream_t stream) {
+  DPMN_REQUIRE(img && arc && rand_offs && out && N > 0 && C > 0 && H > 0 && W > 0, "rotate_img: bad arguments");
+  const long total = (long)N * H * W;
+  hipLaunchKernelGGL(k_rotate_img, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), img, arc, rand_offs,
+                     off_range, out, N, C, H, W);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -88,6 +88,8 @@ class TextSR(base.TextBase):
         for data in val_loader:
             images_hr, images_lr = data[0].to(self.device), data[1].to(self.device)
             label_vecs = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
+            if getattr(self.args, "rotate_test", 0):      # super_resolution.py:358-365 (angle range from rotate_train, as there)
+                images_lr, images_hr = self.rotate_pair(images_lr, images_hr, self.args.rotate_train)
             sr = self.refine(model_list, model_psn, images_lr, label_vecs, fn)
             p, s = ops.psnr_ssim(sr, images_hr)
             psnr.append(p)
@@ -115,12 +117,27 @@ class TextSR(base.TextBase):
                 p.requires_grad = True
         return models, psn, distill, crit, trainer
 
+    @staticmethod
+    def rotate_pair(images_lr, images_hr, max_deg):
+        """Rotation augmentation (super_resolution.py:144-151 / 358-365): one random angle in [-max_deg, max_deg] and one
+        aspect-ratio jitter per sample (numpy RNG, like the reference), applied to the LR and HR image alike."""
+        import math
+        import numpy as np
+        from ..utils.util import torch_rotate_img
+        bs = images_lr.shape[0]
+        angle = np.random.rand(bs) * max_deg * 2 - max_deg
+        arc = torch.tensor(angle / 180. * math.pi).float().to(images_lr.device)
+        rand_offs = torch.tensor(np.random.rand(bs)).float().to(images_lr.device)
+        return torch_rotate_img(images_lr, arc, rand_offs), torch_rotate_img(images_hr, arc, rand_offs)
+
     def train_step(self, models, psn, distill, crit, trainer, images_lr, images_hr, label_vecs=None, text_priors=None,
                    text_prior_fn=None):
         """One optimisation step = super_resolution.py:140-278 (loss sum / (b1+b2+1), per-model clip 0.25, Adam)."""
         b1, b2 = self.args.stu_iter_b1, self.args.stu_iter_b2
         share = self.args.sr_share
         trainer.zero_grad()
+        if getattr(self.args, "rotate_train", 0):
+            images_lr, images_hr = self.rotate_pair(images_lr, images_hr, self.args.rotate_train)
         hr3 = images_hr[:, :3, :]
         with torch.no_grad():
             if self.args.arch in ('tsrn', 'tbsrn', 'tg'):

@@ -295,6 +295,16 @@ def to_mask(img):
     return out
 
 
+def rotate_img(img, arc, rand_offs, off_range=0.2):
+    """torch_rotate_img (utils/util.py:37-58): img (N,C,H,W), arc / rand_offs (N) -> rotated, aspect-jittered batch."""
+    img = img.contiguous().float()
+    N, Cc, H, W = img.shape
+    out = torch.empty_like(img)
+    check(lib.dpmn_rotate_img_f32(dptr(img), dptr(arc.contiguous().float()), dptr(rand_offs.contiguous().float()), float(off_range),
+                                  dptr(out), N, Cc, H, W, stream()))
+    return out
+
+
 def blend(a, b, alpha):
     """alpha*a + (1-alpha)*b[:, :C] (super_resolution.py:449)."""
     a, pa, sa = _nchw_view(a)

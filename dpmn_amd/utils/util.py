@@ -23,6 +23,11 @@ def toMask(img_tensor):
     return ops.to_mask(img_tensor[None])
 
 
+def torch_rotate_img(torch_image_batches, arc_batches, rand_offs, off_range=0.2):
+    """utils/util.py:37-58 -- same signature; one HIP kernel (affine_grid + bilinear grid_sample fused)."""
+    return ops.rotate_img(torch_image_batches, arc_batches, rand_offs, off_range)
+
+
 def str_filt(str_, voc_type):
     import string
     alpha_dict = {'digit': string.digits, 'lower': string.digits + string.ascii_lowercase,

@@ -165,6 +165,11 @@ int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, co
 /* toMask (utils/util.py:27-35) for a batch: img NCHW, first 3 channels used, img_stride = floats between images;
  * out (B,3,H,W) in {0,1}. */
 int dpmn_to_mask_f32(const float* img, long img_stride, float* out, int B, int H, int W, dpmn_stream_t stream);
+/* rotation augmentation of the trainer (utils/util.py:37-58 torch_rotate_img; super_resolution.py:144-151, 358-365):
+ * per-image affine with aspect-ratio jitter -> affine_grid (align_corners=False) -> bilinear grid_sample, zeros padding.
+ * img / out: contiguous NCHW (N,C,H,W); arc, rand_offs: (N) */
+int dpmn_rotate_img_f32(const float* img, const float* arc, const float* rand_offs, float off_range, float* out, int N, int C,
+                        int H, int W, dpmn_stream_t stream);
 /* out = alpha*a + (1-alpha)*b over chw floats per image (interfaces/super_resolution.py:449) */
 int dpmn_blend_f32(const float* a, long a_stride, const float* b, long b_stride, float* out, float alpha, int B,
                    int chw, dpmn_stream_t stream);

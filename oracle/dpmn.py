@@ -29,3 +29,29 @@ def refine(sd_psn, sd_pgrms, sd_cmm, arch, b1, b2, images_lr, label_vecs, text_p
     if return_all:
         return out, dict(psn=psn, branch1=br1, branch2=br2, cmm=fused)
     return out
+
+
+def rotate_img(img, arc, rand_offs, off_range=0.2):
+    """torch_rotate_img (utils/util.py:37-58) written out at index level: theta = [[cos, sin*r, 0], [-sin/r, cos, 0]],
+    r = H/W + (2*rand-1)*off_range (line 44); affine_grid with align_corners=False (base x_j = (2j+1)/W - 1) and
+    grid_sample bilinear / zeros padding (lines 55-56, torch defaults).  Pinned by tests/golden/rotate.npz."""
+    import torch
+    N, C, H, W = img.shape
+    ratio = H / float(W) + rand_offs.float() * off_range * 2 - off_range
+    c, s = torch.cos(arc.float()), torch.sin(arc.float())
+    bx = ((2 * torch.arange(W, dtype=torch.float32) + 1) / W - 1)[None, None, :]
+    by = ((2 * torch.arange(H, dtype=torch.float32) + 1) / H - 1)[None, :, None]
+    gx = c[:, None, None] * bx + (s * ratio)[:, None, None] * by
+    gy = (-s / ratio)[:, None, None] * bx + c[:, None, None] * by
+    ix, iy = ((gx + 1) * W - 1) / 2, ((gy + 1) * H - 1) / 2
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    out = torch.zeros_like(img, dtype=torch.float32)
+    flat = img.float().reshape(N, C, H * W)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xx, yy = x0 + dx, y0 + dy
+            wgt = (1 - (ix - xx).abs()) * (1 - (iy - yy).abs())
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            lin = (yy.clamp(0, H - 1) * W + xx.clamp(0, W - 1)).long().reshape(N, 1, H * W).expand(N, C, H * W)
+            out += (flat.gather(2, lin) * (wgt * ok).reshape(N, 1, H * W)).reshape(N, C, H, W)
+    return out

@@ -56,3 +56,18 @@ def test_to_mask_blend_metrics_kernels():
     p, s = ops.psnr_ssim(a.to(dev), b.to(dev))
     assert_close(p, ocmm.psnr(a, b), 1e-3, 0, "psnr")
     assert_close(s, ocmm.ssim(a, b), 1e-5, 0, "ssim")
+
+
+@pytest.mark.gpu
+def test_rotate_img_hip_vs_oracle_and_golden():
+    """a16 rotation augmentation: HIP kernel through the C ABI vs the oracle and the reference's own output."""
+    from test_oracle_stack import _rotate_inputs
+    from dpmn_amd.utils.util import torch_rotate_img
+    from oracle import dpmn as odpmn
+    g = load_golden("rotate")
+    lr, hr, arc, offs = _rotate_inputs()
+    dev = torch.device("cuda:0")
+    for img, key in ((lr, "out_lr"), (hr, "out_hr")):
+        got = torch_rotate_img(img.to(dev), arc.to(dev), offs.to(dev)).cpu()
+        assert_close(got, odpmn.rotate_img(img, arc, offs), 2e-5, 1e-5, "rotate vs oracle " + key)
+        assert_close(got, t(g[key]), 2e-5, 1e-5, "rotate vs golden " + key)

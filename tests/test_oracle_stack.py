@@ -38,3 +38,19 @@ def test_stack_cfg0_matches_reference():
     assert_close(out, t(g["out"]), 5e-5, 1e-5, "stack output")
     assert_close(ocmm.psnr(out, batch["images_hr"]), t(g["psnr"]), 1e-3, 0, "psnr")
     assert_close(ocmm.ssim(out, batch["images_hr"]), t(g["ssim"]), 1e-3, 0, "ssim")
+
+
+def _rotate_inputs():
+    import math
+    N = 4
+    deg = synth.uniform("rot_deg", (N,), -5.0, 5.0, 11)
+    return (synth.uniform("rot_img", (N, 4, 16, 64), 0, 1, 11), synth.uniform("rot_img_hr", (N, 4, 32, 128), 0, 1, 11),
+            deg / 180.0 * float(math.pi), synth.uniform("rot_off", (N,), 0, 1, 11))
+
+
+def test_rotate_img_matches_reference():
+    """a16: torch_rotate_img (utils/util.py:37-58), golden produced by the reference function itself."""
+    g = load_golden("rotate")
+    lr, hr, arc, offs = _rotate_inputs()
+    assert_close(odpmn.rotate_img(lr, arc, offs), t(g["out_lr"]), 1e-5, 1e-6, "rotate lr")   # fp32 sampling coordinates
+    assert_close(odpmn.rotate_img(hr, arc, offs), t(g["out_hr"]), 1e-5, 1e-6, "rotate hr")

@@ -164,6 +164,18 @@ def gen_loss():
          gradmap=image_loss.GradientPriorLoss.gradient_map(a)[:1])
 
 
+def gen_rotate():
+    """torch_rotate_img (utils/util.py:37-58) through the reference function itself (rotate_train = 5 degrees)."""
+    from utils import util
+    N = 4
+    img = synth.uniform("rot_img", (N, 4, 16, 64), 0, 1, 11)
+    deg = synth.uniform("rot_deg", (N,), -5.0, 5.0, 11)
+    arc = deg / 180.0 * float(np.pi)
+    offs = synth.uniform("rot_off", (N,), 0, 1, 11)
+    save("rotate", out_lr=util.torch_rotate_img(img, arc, offs),
+         out_hr=util.torch_rotate_img(synth.uniform("rot_img_hr", (N, 4, 32, 128), 0, 1, 11), arc, offs))
+
+
 def gen_psn():
     """PSN backbones in eval mode (frozen in DPMN, super_resolution.py:56-59): TSRN and TATT."""
     from model import tsrn, tatt
@@ -220,7 +232,7 @@ def gen_stack():
          psnr=ssim_psnr.calculate_psnr(out, batch["images_hr"]), ssim=ssim_psnr.SSIM()(out, batch["images_hr"]))
 
 
-GENS = {"stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss}
+GENS = {"stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate}
 
 
 if __name__ == "__main__":
