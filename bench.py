@@ -33,7 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1"])
+    ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1", "cfg3"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
                     help="fwd: BASELINE.json configs[1] (headline metric); train: configs[2] step (loss, backward, clip+Adam, RCCL all-reduce)")
@@ -174,7 +174,7 @@ def main():
         elapsed = float(tt.item())
     if rank == 0:
         line = {
-            "metric": "SR images/sec (16x64->32x128, bs=48 per GPU, fp32 %s)" % ("forward" if args.mode == "fwd" else "training step"),
+            "metric": "SR images/sec (16x64->32x128, bs=%d per GPU, fp32 %s)" % (B, "forward" if args.mode == "fwd" else "training step"),
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

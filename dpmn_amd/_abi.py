@@ -75,6 +75,8 @@ SIGNATURES = {
     "dpmn_add_layernorm64_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, _f, _i, C.c_long, fp]),
     "dpmn_gru_gate_f32": (_i, [fp, fp, fp, fp, C.c_long, _i, _i, fp]),
     "dpmn_to_mask_f32": (_i, [fp, C.c_long, fp, _i, _i, _i, fp]),
+    "dpmn_mha32_f32": (_i, [fp, fp, _i, _i, _i, _f, fp]),
+    "dpmn_layernorm_std_f32": (_i, [fp, fp, fp, _f, fp, _l, _i, fp]),
     "dpmn_rotate_img_f32": (_i, [fp, fp, fp, _f, fp, _i, _i, _i, _i, fp]),
     "dpmn_blend_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, _f, _i, _i, fp]),
     "dpmn_psnr_ssim_workspace_bytes": (_sz, [_i, _i, _i, _i]),

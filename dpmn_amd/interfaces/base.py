@@ -8,7 +8,7 @@ import os
 
 import torch
 
-from ..model import pgrm, cmm, tsrn, tatt
+from ..model import pgrm, cmm, tsrn, tatt, tbsrn
 from ..utils import ssim_psnr
 
 
@@ -73,8 +73,10 @@ class TextBase(object):
             model = tsrn.TSRN(**kw)
         elif psn and self.args.arch == 'tatt':
             model = tatt.TSRN_TL_TRANS(**kw)
+        elif psn and self.args.arch == 'tbsrn':
+            model = tbsrn.TBSRN(**kw)
         elif psn:
-            raise NotImplementedError("dpmn_amd: PSN arch %r is not built yet (built: tsrn, tg, tatt)" % self.args.arch)
+            raise NotImplementedError("dpmn_amd: PSN arch %r is not built (built: tsrn, tg, tatt, tbsrn)" % self.args.arch)
         else:
             model = pgrm.PGRM(patch_size=self.patch_size, embed_dim=self.embed_dim, depths=self.depths,
                               num_heads=self.num_heads, window_size=self.window_size, mlp_ratio=self.mlp_ratio,

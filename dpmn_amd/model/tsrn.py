@@ -99,8 +99,7 @@ class _PSNBase(nn.Module):
                 blk = getattr(self, "block%d" % (i + 2))
                 P["srb%d.c1" % i] = packing.pack_conv(blk.conv1.weight, blk.conv1.bias, _bn(blk.bn1))
                 P["srb%d.c2" % i] = packing.pack_conv(blk.conv2.weight, blk.conv2.bias, _bn(blk.bn2))
-                P["srb%d.g1" % i] = _pack_gru_block(blk.gru1)
-                P["srb%d.g2" % i] = _pack_gru_block(blk.gru2)
+                self._pack_block_extra(P, i, blk)
             b7 = getattr(self, "block%d" % (n + 2))
             P["b7"] = packing.pack_conv(b7[0].weight, b7[0].bias, _bn(b7[1]))
             b8 = getattr(self, "block%d" % (n + 3))
@@ -112,6 +111,10 @@ class _PSNBase(nn.Module):
 
     def _extra_pack(self, P):
         pass
+
+    def _pack_block_extra(self, P, i, blk):
+        P["srb%d.g1" % i] = _pack_gru_block(blk.gru1)
+        P["srb%d.g2" % i] = _pack_gru_block(blk.gru2)
 
     def _check_mode(self):
         if self.training:

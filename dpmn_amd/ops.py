@@ -163,7 +163,7 @@ def conv_desc(inputs, k, stride=1, pad=0, dil=1, cout=0, pro_act="none", affine=
 
 
 def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", epi_act="none", slope=0.0, res=None,
-           affine=None, out=None, out_nchw=False, pixel_shuffle=False, stats=None, phase=None, geom=None):
+           affine=None, out=None, out_nchw=False, pixel_shuffle=False, stats=None, phase=None, geom=None, out_coff=None):
     """inputs: list of 1..3 NHWC tensors (channel-concatenated on the fly).  k: int or (KH, KW).
     phase=(py, px): one output phase of ConvTranspose2d(4,2,1) (k=2, dil=-1, pad=-phase).
     affine: optional list of (scale, shift) per input segment."""
@@ -182,6 +182,8 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
             out = torch.empty(B, Ho, Wo, cout, device=wp.device)
     d.out = dptr(out)
     d.out_ld, d.out_coff, d.out_nchw, d.pixel_shuffle = 0, 0, int(out_nchw), int(pixel_shuffle)
+    if out_coff is not None:      # write channels [out_coff, out_coff + cout) of a wider NHWC buffer
+        d.out_ld, d.out_coff = out.shape[3], int(out_coff)
     d.stats = dptr(stats, True)
     ws = splitk_workspace(wp.device)
     d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
@@ -293,6 +295,20 @@ def to_mask(img):
     out = torch.empty(B, 3, H, W, device=img.device)
     check(lib.dpmn_to_mask_f32(p, st, dptr(out), B, H, W, stream()))
     return out
+
+
+def mha32(qkv, B, L, heads, scale):
+    """MultiHeadedAttention core of TBSRN (tbsrn.py:110-150): qkv (B*L, 3*heads*32) -> (B*L, heads*32)."""
+    out = torch.empty(B * L, heads * 32, device=qkv.device)
+    check(lib.dpmn_mha32_f32(dptr(qkv), dptr(out), B, L, heads, float(scale), stream()))
+    return out
+
+
+def layernorm_std(x, a2, b2, eps=1e-6):
+    """tbsrn.py:23-36 LayerNorm: a2 * (x - mean) / (unbiased std + eps) + b2 over the last axis of (M, C)."""
+    y = torch.empty_like(x)
+    check(lib.dpmn_layernorm_std_f32(dptr(x), dptr(a2), dptr(b2), float(eps), dptr(y), x.shape[0], x.shape[1], stream()))
+    return y
 
 
 def rotate_img(img, arc, rand_offs, off_range=0.2):

@@ -12,6 +12,7 @@ CONFIGS = {
     # name: (arch, b1, b2, per-GPU batch)
     "cfg0": ("tsrn", 1, 1, 4),    # TSRN + 1+1 PGRM, B=4 (the reference's CPU-runnable plumbing case)
     "cfg1": ("tatt", 3, 3, 48),   # TATT + 3+3 PGRM, embed 96, windows 2/4/8, B=48 fp32 forward (headline metric)
+    "cfg3": ("tbsrn", 3, 3, 64),  # TBSRN PSN + 3+3 PGRM, B=64 (config 3 without the out-of-scope in-loop VisionLAN recogniser)
 }
 
 
@@ -67,12 +68,13 @@ def cpu_state_dicts(workload_name, seed=100):
     from .model.cmm import ComplementationModulationModule
     from .model.tsrn import TSRN
     from .model.tatt import TSRN_TL_TRANS
+    from .model.tbsrn import TBSRN
     arch, b1, b2, _ = CONFIGS[workload_name]
     n = b1 + b2
     args = dict(patch_size=[2] * n, embed_dim=[96] * n, depths=[1] * n, num_heads=[[6]] * n, window_size=[[2, 4, 8]] * n,
                 mlp_ratio=[4.] * n, drop_rate=[0.] * n, attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
     kw = dict(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32)
-    psn = (TSRN_TL_TRANS if arch == "tatt" else TSRN)(**kw)
+    psn = {"tatt": TSRN_TL_TRANS, "tbsrn": TBSRN}.get(arch, TSRN)(**kw)
     mods = [PGRM(iter=k, mode=False, hidden_size=3, **args) for k in range(b1)]
     mods += [PGRM(iter=k, mode=True, hidden_size=3, **args) for k in range(b1, b1 + b2)]
     mods.append(ComplementationModulationModule())

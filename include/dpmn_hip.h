@@ -165,6 +165,13 @@ int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, co
 /* toMask (utils/util.py:27-35) for a batch: img NCHW, first 3 channels used, img_stride = floats between images;
  * out (B,3,H,W) in {0,1}. */
 int dpmn_to_mask_f32(const float* img, long img_stride, float* out, int B, int H, int W, dpmn_stream_t stream);
+/* TBSRN FeatureEnhancer (model/tbsrn.py:76-92, config 3's PSN), tbsrn.hip.
+ * mha32: MultiHeadedAttention core (tbsrn.py:110-150) -- qkv (B*L, 3*heads*32) rows [q|k|v] (the three input linears
+ * fused into one GEMM by the caller), out (B*L, heads*32) = softmax(q k^T * scale) v per head over the L positions of an
+ * image; L % 64 == 0.  layernorm_std: tbsrn.py:23-36, a2 * (x - mean) / (unbiased std + eps) + b2, C in {64,128,256}. */
+int dpmn_mha32_f32(const float* qkv, float* out, int B, int L, int heads, float scale, dpmn_stream_t stream);
+int dpmn_layernorm_std_f32(const float* x, const float* a2, const float* b2, float eps, float* y, long M, int C,
+                           dpmn_stream_t stream);
 /* rotation augmentation of the trainer (utils/util.py:37-58 torch_rotate_img; super_resolution.py:144-151, 358-365):
  * per-image affine with aspect-ratio jitter -> affine_grid (align_corners=False) -> bilinear grid_sample, zeros padding.
  * img / out: contiguous NCHW (N,C,H,W); arc, rand_offs: (N) */

@@ -12,6 +12,8 @@ from . import tsrn as otsrn
 def refine(sd_psn, sd_pgrms, sd_cmm, arch, b1, b2, images_lr, label_vecs, text_priors, alpha=0.5, return_all=False):
     if arch == "tatt":
         psn, _ = otsrn.tatt_forward(sd_psn, images_lr, label_vecs)
+    elif arch == "tbsrn":
+        psn = otsrn.tbsrn_forward(sd_psn, images_lr)
     else:
         psn = otsrn.tsrn_forward(sd_psn, images_lr)
     cascade, br1 = psn, []

@@ -2,11 +2,15 @@
 (TSRN_TL_TRANS) in eval mode (the only mode DPMN uses them in: super_resolution.py:56-59).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file.
-Pinned by tests/golden/{tsrn,tatt}.npz (tools/gen_golden.py, imported reference).
+Pinned by tests/golden/{tsrn,tatt,tbsrn}.npz (tools/gen_golden.py, imported reference).
 
 Reference lines restated:
   model/tsrn.py: TSRN.forward 58-74, RecurrentResidualBlock.forward 89-101, UpsampleBLock 113-117,
                  mish 125-129, GruBlock.forward 139-150
+  model/tbsrn.py: TBSRN.forward 214-226, RecurrentResidualBlock.forward 245-257 (gru1/gru2 are constructed
+                 but never called), FeatureEnhancer.forward 76-92, positionalencoding2d 39-60, MultiHeadedAttention
+                 110-129 + attention 132-150, PositionwiseFeedForward 161-162, LayerNorm 33-36 (unbiased std, eps
+                 added to the std)
   model/tatt.py: TSRN_TL_TRANS.forward 645-691, TPInterpreter.forward 193-223,
                  RecurrentResidualBlockTL.forward 891-909, GruBlock 1070-1083
   model/transformer_v2.py: PositionalEncoding 22-43, InfoTransformer.forward 198-244 (quirk Q5: the
@@ -88,6 +92,60 @@ def tsrn_forward(sd, x, srb_nums=5):
     f = b1
     for i in range(srb_nums):
         f = srb(f, sd, "block%d." % (i + 2))
+    return _tail(b1, f, sd, srb_nums)
+
+
+# ---------------------------------------------------------------------------------- TBSRN
+def tbsrn_pos2d(d_model, height, width):
+    """positionalencoding2d (tbsrn.py:39-60): first half of the channels encodes the column, second half the row."""
+    pe = torch.zeros(d_model, height, width)
+    half = d_model // 2
+    div = torch.exp(torch.arange(0., half, 2) * -(math.log(10000.0) / half))
+    pw = torch.arange(0., width)[:, None] * div       # (W, half/2)
+    ph = torch.arange(0., height)[:, None] * div
+    pe[0:half:2] = torch.sin(pw).t()[:, None, :].expand(-1, height, -1)
+    pe[1:half:2] = torch.cos(pw).t()[:, None, :].expand(-1, height, -1)
+    pe[half::2] = torch.sin(ph).t()[:, :, None].expand(-1, -1, width)
+    pe[half + 1::2] = torch.cos(ph).t()[:, :, None].expand(-1, -1, width)
+    return pe
+
+
+def tbsrn_ln(x, sd, pre, eps=1e-6):
+    mean = x.mean(-1, keepdim=True)
+    std = x.std(-1, keepdim=True)                      # unbiased, like torch.Tensor.std
+    return sd[pre + "a_2"] * (x - mean) / (std + eps) + sd[pre + "b_2"]
+
+
+def feature_enhancer(feat, sd, pre):
+    """feat (B, 64, 1024) -> (B, 64, 1024) (tbsrn.py:76-92); dropout layers are identity in eval."""
+    B = feat.shape[0]
+    pos = tbsrn_pos2d(64, 16, 64).reshape(1, 64, 1024).expand(B, -1, -1)
+    x = torch.cat([feat, pos], 1).permute(0, 2, 1)      # (B, 1024, 128)
+    h, dk = 4, 32
+    lin = lambda i, v: F.linear(v, sd[pre + "multihead.linears.%d.weight" % i], sd[pre + "multihead.linears.%d.bias" % i])
+    q, k, v = (lin(i, x).reshape(B, -1, h, dk).transpose(1, 2) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(dk), -1)
+    att = (p @ v).transpose(1, 2).reshape(B, -1, h * dk)
+    x = tbsrn_ln(x + lin(3, att), sd, pre + "mul_layernorm1.")
+    ff = F.linear(F.relu(F.linear(x, sd[pre + "pff.w_1.weight"], sd[pre + "pff.w_1.bias"])), sd[pre + "pff.w_2.weight"],
+                  sd[pre + "pff.w_2.bias"])
+    x = tbsrn_ln(x + ff, sd, pre + "mul_layernorm3.")
+    return F.linear(x, sd[pre + "linear.weight"], sd[pre + "linear.bias"]).permute(0, 2, 1)
+
+
+def tbsrn_block(x, sd, pre):
+    r = mish(bn_eval(F.conv2d(x, sd[pre + "conv1.weight"], sd[pre + "conv1.bias"], padding=1), sd, pre + "bn1."))
+    r = bn_eval(F.conv2d(r, sd[pre + "conv2.weight"], sd[pre + "conv2.bias"], padding=1), sd, pre + "bn2.")
+    B, C, H, W = r.shape
+    return x + feature_enhancer(r.reshape(B, C, H * W), sd, pre + "feature_enhancer.").reshape(B, C, H, W)
+
+
+def tbsrn_forward(sd, x, srb_nums=5):
+    """TBSRN.forward in eval mode (the STN branch is gated on self.training, tbsrn.py:215)."""
+    b1 = F.prelu(F.conv2d(x, sd["block1.0.weight"], sd["block1.0.bias"], padding=4), sd["block1.1.weight"])
+    f = b1
+    for i in range(srb_nums):
+        f = tbsrn_block(f, sd, "block%d." % (i + 2))
     return _tail(b1, f, sd, srb_nums)
 
 

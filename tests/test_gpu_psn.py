@@ -113,3 +113,33 @@ def test_tatt_batch48_vs_oracle(dev):
     with torch.no_grad():
         out, _ = m(b["images_lr"].to(dev), b["label_vecs"].to(dev))
     assert_close(out, ref, 2e-4, 2e-4, "TATT B=48 vs oracle")
+
+
+def test_mha32_and_layernorm_std_match_oracle(dev):
+    """TBSRN FeatureEnhancer kernels (tbsrn.py:110-150, 23-36) vs plain softmax attention / std LayerNorm."""
+    import math
+    from dpmn_amd import ops
+    B, L, Hh = 3, 1024, 4
+    qkv = u("mha_qkv", (B * L, 3 * Hh * 32), -2.0, 2.0)
+    q, k, v = (qkv[:, i * 128:(i + 1) * 128].reshape(B, L, Hh, 32).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-2, -1) / math.sqrt(32.0), -1) @ v).transpose(1, 2).reshape(B * L, 128)
+    assert_close(ops.mha32(qkv.to(dev), B, L, Hh, 1.0 / math.sqrt(32.0)), ref, ATOL, RTOL, "mha32")
+    x, a2, b2 = u("lns_x", (777, 128), -3, 3), u("lns_a", (128,), 0.5, 1.5), u("lns_b", (128,))
+    ref = a2 * (x - x.mean(-1, keepdim=True)) / (x.std(-1, keepdim=True) + 1e-6) + b2
+    assert_close(ops.layernorm_std(x.to(dev), a2.to(dev), b2.to(dev), 1e-6), ref, ATOL, RTOL, "layernorm_std")
+
+
+def test_tbsrn_module_vs_reference_golden_and_oracle(dev):
+    """a14: TBSRN mirror (eval) vs the reference's own output (B=2) and vs the oracle at B=5."""
+    from dpmn_amd.model.tbsrn import TBSRN
+    from oracle import tsrn as ot
+    g, m = _load(TBSRN, "tbsrn", 43, dev)
+    x = synth.synth_batch(2, seed=2)["images_lr"].to(dev)
+    with torch.no_grad():
+        out = m(x)
+    assert_close(out, t(g["out"]), 2e-4, 2e-4, "TBSRN vs reference golden")
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    xb = synth.synth_batch(5, seed=4)["images_lr"]
+    with torch.no_grad():
+        out = m(xb.to(dev))
+    assert_close(out, ot.tbsrn_forward(sd, xb), 2e-4, 2e-4, "TBSRN B=5 vs oracle")

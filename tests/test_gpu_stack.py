@@ -71,3 +71,18 @@ def test_rotate_img_hip_vs_oracle_and_golden():
         got = torch_rotate_img(img.to(dev), arc.to(dev), offs.to(dev)).cpu()
         assert_close(got, odpmn.rotate_img(img, arc, offs), 2e-5, 1e-5, "rotate vs oracle " + key)
         assert_close(got, t(g[key]), 2e-5, 1e-5, "rotate vs golden " + key)
+
+
+def test_stack_cfg3_tbsrn_vs_oracle_small_batch():
+    """config 3's stack (TBSRN PSN + 3+3 PGRM + CMM; the in-loop recogniser is out of scope, priors are inputs)."""
+    from dpmn_amd import workload, ops
+    from oracle import dpmn as odpmn, cmm as ocmm
+    B = 3
+    sr, models, psn, inp = workload.build("cfg3", batch=B)
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [x.cpu() for x in v]) for k, v in inp.items()}
+    ref, rmid = odpmn.refine(sd_psn, sds[:-1], sds[-1], "tbsrn", 3, 3, cpu["images_lr"], None, cpu["text_priors"], 0.5, True)
+    out, mid = sr.refine(models, psn, inp["images_lr"], None, text_priors=inp["text_priors"], return_all=True)
+    assert_close(mid["psn"], rmid["psn"], 2e-4, 2e-4, "tbsrn psn")
+    assert torch.equal(ops.to_mask(mid["psn"]).cpu(), ocmm.to_mask(rmid["psn"][:, :3]))
+    assert_close(out, ref, 1e-3, 1e-3, "cfg3 output vs oracle")

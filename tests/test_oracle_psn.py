@@ -23,3 +23,17 @@ def test_tatt_matches_reference():
     out, prw = ot.tatt_forward(sd, b["images_lr"], b["label_vecs"])
     assert_close(out, t(g["out"]), 2e-5, 1e-5, "tatt out")
     assert_close(prw[:, ::16], t(g["pr_weights"]), 1e-6, 1e-5, "tatt pr_weights")
+
+
+def test_tbsrn_matches_reference():
+    """a14: TBSRN eval forward + the first block's FeatureEnhancer output (every 8th position)."""
+    g, sd = _sd("tbsrn", 43)
+    x = synth.synth_batch(2, seed=2)["images_lr"]
+    assert_close(ot.tbsrn_forward(sd, x), t(g["out"]), 2e-5, 1e-5, "tbsrn")
+    import torch.nn.functional as F
+    b1 = F.prelu(F.conv2d(x, sd["block1.0.weight"], sd["block1.0.bias"], padding=4), sd["block1.1.weight"])
+    pre = "block2."
+    r = ot.mish(ot.bn_eval(F.conv2d(b1, sd[pre + "conv1.weight"], sd[pre + "conv1.bias"], padding=1), sd, pre + "bn1."))
+    r = ot.bn_eval(F.conv2d(r, sd[pre + "conv2.weight"], sd[pre + "conv2.bias"], padding=1), sd, pre + "bn2.")
+    fe = ot.feature_enhancer(r.reshape(2, 64, 1024), sd, pre + "feature_enhancer.")
+    assert_close(fe[:, ::8], t(g["fe_block2"]), 2e-5, 1e-5, "tbsrn feature enhancer")

@@ -176,6 +176,25 @@ def gen_rotate():
          out_hr=util.torch_rotate_img(synth.uniform("rot_img_hr", (N, 4, 32, 128), 0, 1, 11), arc, offs))
 
 
+def gen_tbsrn(x):
+    """TBSRN in eval mode (config 3's PSN).  FeatureEnhancer hard-codes .cuda() (tbsrn.py:83): identity on this CPU box."""
+    from model import tbsrn
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        m = tbsrn.TBSRN(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32).eval()
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=43)
+        sd = {k: v.clone() for k, v in sd.items()}
+        m.load_state_dict(sd)
+        feats = {}
+        m.block2.feature_enhancer.register_forward_hook(lambda mod, i, o: feats.setdefault("fe", o))
+        out = m(x)
+        save("tbsrn", out=out, fe_block2=feats["fe"][:, ::8].contiguous(), manifest=manifest(sd), checksum=checksum(sd))
+    finally:
+        torch.Tensor.cuda = orig
+
+
 def gen_psn():
     """PSN backbones in eval mode (frozen in DPMN, super_resolution.py:56-59): TSRN and TATT."""
     from model import tsrn, tatt
@@ -193,6 +212,7 @@ def gen_psn():
     sd = {k: v.clone() for k, v in sd.items()}
     m.load_state_dict(sd)
     out, prw = m(x, lv)
+    gen_tbsrn(x)
     save("tatt", out=out, pr_weights=prw[:, ::16].contiguous(), tp_map=m.block["1"][:1, :8].contiguous(),
          manifest=manifest(sd), checksum=checksum(sd))
 
