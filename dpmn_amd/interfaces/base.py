@@ -22,16 +22,6 @@ def parse_list(s):
     return out
 
 
-class ImageLossSpec:
-    """Stand-in for loss.image_loss.ImageLoss until the loss/backward kernels land (training is round 2)."""
-
-    def __init__(self, gradient, loss_weight):
-        self.gradient, self.loss_weight = gradient, loss_weight
-
-    def __call__(self, *a, **k):
-        raise NotImplementedError("dpmn_amd: ImageLoss forward/backward kernels are not built yet (training path)")
-
-
 class TextBase(object):
     def __init__(self, config, args, opt_TPG=None):
         self.config = config
@@ -82,7 +72,8 @@ class TextBase(object):
                               num_heads=self.num_heads, window_size=self.window_size, mlp_ratio=self.mlp_ratio,
                               drop_rate=self.drop_rate, attn_drop_rate=self.attn_drop_rate,
                               drop_path_rate=self.drop_path_rate, iter=iter, mode=mode, hidden_size=hidden_size)
-        image_crit = ImageLossSpec(gradient=self.args.gradient, loss_weight=[1, 1])
+        from ..loss.image_loss import ImageLoss
+        image_crit = ImageLoss(gradient=self.args.gradient, loss_weight=[1, 1])
         model = model.to(self.device)
         if self.resume and (psn or testing):
             if os.path.isdir(self.resume):
