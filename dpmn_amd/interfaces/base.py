@@ -91,7 +91,8 @@ class TextBase(object):
         ckpt_path = os.path.join(self.vis_dir if hasattr(self, "vis_dir") else ".", 'ckpt')
         os.makedirs(ckpt_path, exist_ok=True)
         for i, netG in enumerate(netG_list):
-            save_dict = {'state_dict_G': netG.state_dict(),
+            # parameters may be views into the trainer's flat buckets: store compact, storage-independent copies
+            save_dict = {'state_dict_G': {k: v.detach().clone() for k, v in netG.state_dict().items()},
                          'info': {'arch': self.args.arch, 'iters': iters, 'epochs': epoch, 'batch_size': self.batch_size,
                                   'voc_type': getattr(self, "voc_type", None), 'up_scale_factor': self.scale_factor},
                          'best_history_res': best_acc_dict, 'best_model_info': best_model_info,

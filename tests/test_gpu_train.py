@@ -1,5 +1,7 @@
 """GPU parity of the training path: HIP forward+backward (explicit backward kernels behind torch.autograd) vs
 torch autograd through the CPU oracle on the same weights / inputs / cotangent.  fp32; tolerances per test."""
+import os
+
 import pytest
 import torch
 
@@ -254,3 +256,28 @@ def test_full_train_step_vs_oracle_autograd(dev):
         tot_err = (num / max(den, 1e-30)) ** 0.5
         print("model %d: whole-gradient L2 err %.2e, worst tensor %s %.2e" % (i, tot_err, worst[0], worst[1]))
         assert tot_err < 2e-2, "model %d gradient differs from oracle autograd: %.3e (%s %.3e)" % (i, tot_err, worst[0], worst[1])
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    """base.py:328-358 / 163-197: files written from flat-bucket-backed models load back (reference dict keys) and the
+    restored model reproduces the forward bit for bit."""
+    from dpmn_amd import workload
+    from dpmn_amd.train.optim import Trainer
+    sr, models, psn, inp = workload.build("cfg0")
+    for m in models:
+        for p in m.parameters():
+            p.requires_grad = True
+    Trainer(models)                      # parameters become views into padded flat buffers
+    sr.vis_dir = str(tmp_path)
+    sr.save_checkpoint(models, epoch=3, iters=7, best_acc_dict={}, best_model_info={}, is_best=True, converge_list=[], name="sum")
+    x_q, x_kv = inp["text_priors"][0], inp["images_hr"][:, :3].contiguous()
+    with torch.no_grad():
+        ref = models[0](x_q, x_kv, [])
+    ck = torch.load(os.path.join(str(tmp_path), "ckpt", "model_best_sum_3_0.pth"), map_location="cpu")
+    assert set(ck.keys()) == {"state_dict_G", "info", "best_history_res", "best_model_info", "param_num", "converge"}
+    assert ck["info"]["arch"] == "tsrn" and ck["param_num"] == sum(p.numel() for p in models[0].parameters())
+    fresh = sr.generator_init(iter=0, mode=False, hidden_size=3)["model"].eval()
+    fresh.load_state_dict(ck["state_dict_G"])
+    with torch.no_grad():
+        out = fresh(x_q, x_kv, [])
+    assert torch.equal(out, ref)
