@@ -48,7 +48,7 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
                           const float* const* residuals, int n_residuals, float* out, void* workspace,
                           size_t workspace_bytes, int B, dpmn_stream_t stream) {
   DPMN_REQUIRE(w && x_q && x_kv && out && workspace, "pgrm_forward: null pointer");
-  DPMN_REQUIRE(B >= 2, "pgrm_forward: per-rank batch must be >= 2 (SKConv squeeze() quirk Q3)");
+  DPMN_REQUIRE(B >= 1, "pgrm_forward: empty batch");
   DPMN_REQUIRE(w->n_groups >= 1 && w->n_groups <= 4, "pgrm_forward: 1..4 window groups");
   DPMN_REQUIRE(n_residuals <= w->n_weight_list, "pgrm_forward: more residuals than weight_list entries (iter)");
   DPMN_REQUIRE((x_q_channels == 2) == (w->prior_fusion_w != nullptr) || x_q_channels == 3,

@@ -11,7 +11,7 @@ import math
 import torch
 import torch.nn as nn
 
-from .. import _abi
+from .. import _abi, ops
 
 
 class _Affine(nn.Module):
@@ -123,6 +123,47 @@ class _Layer(nn.Module):
             sh = [0 if (i == 0 or min(H, W) <= w) else w // 2 for w in windows]
             blocks.append(_Block(dim, ws, sh, num_heads, resolution, mlp_ratio))
         self.blocks = nn.ModuleList(blocks)
+
+
+class BasicLayer(_Layer):
+    """Drop-in for ``model.pgrm.BasicLayer`` (pgrm.py:347-384), eval forward composed from the per-kernel C ABI ops.
+    This is the level at which the stress configuration (dim 192, windows 4/8/16, 32x128 tokens) is pinned: the full
+    PGRM cannot run there in the reference either (quirk Q7, weight_list is hard-wired to 32x128 outputs)."""
+
+    def __init__(self, dim, input_resolution, depth=2, num_heads=6, window_size=(2, 4, 8), mlp_ratio=4., qkv_bias=True,
+                 qk_scale=None, drop=0., attn_drop=0., drop_path=0., norm_layer=None, downsample=None, use_checkpoint=False):
+        if depth != 2 or drop or attn_drop or downsample is not None or not qkv_bias or qk_scale is not None:
+            raise NotImplementedError("dpmn_amd BasicLayer: depth 2, no dropout, no downsample (what PGRM constructs, pgrm.py:500-512)")
+        if isinstance(drop_path, (list, tuple)) and any(drop_path) or (not isinstance(drop_path, (list, tuple)) and drop_path):
+            raise NotImplementedError("dpmn_amd BasicLayer: DropPath kernels are not built (the trainer's config has 0)")
+        super().__init__(dim, list(window_size), num_heads, tuple(input_resolution), mlp_ratio)
+        self.dim, self.input_resolution, self.num_heads = dim, tuple(input_resolution), num_heads
+        self.window_size, self.mlp_ratio = list(window_size), mlp_ratio
+
+    def forward(self, x_q, x_kv):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("dpmn_amd BasicLayer: training runs through PGRM (train/pgrm_train.py)")
+        H, W = self.input_resolution
+        B, L, Cd = x_kv.shape
+        M, G = B * L, len(self.window_size)
+        Ch = int(self.dim * self.mlp_ratio)
+        tq, tkv = x_q.reshape(M, Cd).contiguous().float(), x_kv.reshape(M, Cd).contiguous().float()
+        for bi, blk in enumerate(self.blocks):
+            a, sk, mlp = blk.attn, blk.attn.sknet, blk.mlp
+            win = [min(H, W) if min(H, W) <= w else w for w in self.window_size]
+            shift = [0 if (bi == 0 or min(H, W) <= w) else w // 2 for w in self.window_size]
+            tables = [getattr(a, "relative_position_bias_table_%d" % g) for g in range(G)]
+            q = ops.ln_linear(tq, blk.norm1_q.weight, blk.norm1_q.bias, a.q.weight, a.q.bias)
+            kv = ops.ln_linear(tkv, blk.norm1_kv.weight, blk.norm1_kv.bias, a.kv.weight, a.kv.bias)
+            cat = ops.window_attn(q.reshape(B, L, Cd), kv.reshape(B, L, 2 * Cd), tables, win, shift, self.num_heads // G, H, W)
+            x1, _ = ops.sk_fuse(cat, tkv.reshape(B, L, Cd), sk.proj.weight, sk.proj.bias, sk.fc1.weight, sk.fc1.bias, sk.fc2.weight,
+                                sk.fc2.bias, sk.proj_head.weight, sk.proj_head.bias, G)
+            x1 = x1.reshape(M, Cd)
+            y = ops.ln_linear(x1, blk.norm2.weight, blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, act="gelu")
+            g = ops.dwconv3x3_gelu(y.reshape(B, L, Ch), mlp.depthwise_conv.weight, mlp.depthwise_conv.bias, int(round(L ** 0.5)))
+            z = ops.pointwise(g, mlp.pointwise_conv.weight.reshape(Ch, Ch), mlp.pointwise_conv.bias)
+            tkv = ops.linear(z.reshape(M, Ch), mlp.fc2.weight, mlp.fc2.bias, res1=x1)
+        return x_q, tkv.reshape(B, L, Cd)      # x_q is returned untouched (quirk Q4)
 
 
 class _PatchEmbed(nn.Module):

@@ -227,3 +227,28 @@ def test_pgrm_module_batch48_vs_oracle(dev):
     with torch.no_grad():
         out = m(x_q.to(dev), x_kv.to(dev), [r.to(dev) for r in res])
     assert_close(out, ref, 2e-4, 2e-4, "PGRM module B=48 vs oracle")
+
+
+def test_basiclayer_stress_dims_vs_reference_golden_and_oracle(dev):
+    """Stress configuration (config 4 dims: dim 192, windows 4/8/16 -> a 256-token window, 32x128 tokens, L = 4096) at the
+    BasicLayer level, where the reference pins it (quirk Q7): reference golden at B=1, oracle at B=3."""
+    from dpmn_amd.model.pgrm import BasicLayer
+    from oracle import pgrm as opgrm
+    g = load_golden("basiclayer_stress")
+    m = BasicLayer(192, (32, 128), depth=2, num_heads=6, window_size=[4, 8, 16], mlp_ratio=4.).eval()
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == sorted(str(r).split("|")[0] for r in g["manifest"])
+    synth.synth_fill_(sd, 23)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    xq = synth.uniform("bl_xq", (1, 4096, 192), -1, 1, 6)
+    xkv = synth.uniform("bl_xkv", (1, 4096, 192), -1, 1, 6)
+    with torch.no_grad():
+        _, o = m(xq.to(dev), xkv.to(dev))
+    assert_close(o[:, ::7], t(g["out"]), 3e-4, 3e-4, "BasicLayer stress vs reference golden")
+    sdc = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    xq3, xkv3 = synth.uniform("bl_xq3", (3, 4096, 192), -1, 1, 7), synth.uniform("bl_xkv3", (3, 4096, 192), -1, 1, 7)
+    ref = opgrm.basic_layer(xq3, xkv3, sdc, "", 32, 128, [4, 8, 16], 6)
+    with torch.no_grad():
+        _, o3 = m(xq3.to(dev), xkv3.to(dev))
+    assert_close(o3, ref, 3e-4, 3e-4, "BasicLayer stress B=3 vs oracle")
