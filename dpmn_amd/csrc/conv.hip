@@ -145,7 +145,15 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   const int c01 = a.cseg[0] + a.cseg[1];
   const int ktaps = a.KH * a.KW;
 
+  // gload only ISSUES the global loads (raw values + the 2 affine vectors); the on-load transform -- BatchNorm affine and
+  // input activation, which must leave out-of-image taps at exactly 0 -- runs in sstore, after the MFMAs of the current
+  // chunk, so the loads are in flight during the matrix work instead of being waited for one by one.
+  // (Tried and measured slower: clamped always-valid addresses instead of the predicated loads, per-tile
+  // amdgpu_waves_per_eu caps.)
   float4 xr[APASS], wr[BPASS];
+  float4 s4r, h4r;
+  unsigned vmask = 0;        // bit p: xr[p] came from inside the image
+  bool has_aff = false;
   auto gload = [&](int k0) {
     const int k = k0 + lcol;
     const int tap = k / a.cin, c = k - tap * a.cin;
@@ -159,23 +167,17 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     const int cs = a.cseg[seg];
     const float* sc = a.in_scale[seg];
     const float* sh = a.in_shift[seg];
+    const bool tap_ok = tap < ktaps;
+    has_aff = sc != nullptr && tap_ok;
+    if (has_aff) { s4r = *reinterpret_cast<const float4*>(sc + cl); h4r = *reinterpret_cast<const float4*>(sh + cl); }
+    vmask = 0;
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int iy = py[p] + dy, ix = px[p] + dx;
-      if (pb[p] >= 0 && tap < ktaps && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
-        v = *reinterpret_cast<const float4*>(src + (((size_t)pb[p] * a.Hin + iy) * a.Win + ix) * cs + cl);
-        if (sc) {
-          const float4 s4 = *reinterpret_cast<const float4*>(sc + cl);
-          const float4 h4 = *reinterpret_cast<const float4*>(sh + cl);
-          v.x = v.x * s4.x + h4.x; v.y = v.y * s4.y + h4.y; v.z = v.z * s4.z + h4.z; v.w = v.w * s4.w + h4.w;
-        }
-        if (a.pro_act != ACT_NONE) {
-          v.x = apply_act(v.x, a.pro_act, 0.f); v.y = apply_act(v.y, a.pro_act, 0.f);
-          v.z = apply_act(v.z, a.pro_act, 0.f); v.w = apply_act(v.w, a.pro_act, 0.f);
-        }
-      }
-      xr[p] = v;
+      const bool ok = pb[p] >= 0 && tap_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      xr[p] = ok ? *reinterpret_cast<const float4*>(src + (((size_t)pb[p] * a.Hin + iy) * a.Win + ix) * cs + cl)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      vmask |= (ok ? 1u : 0u) << p;
     }
 #pragma unroll
     for (int p = 0; p < BPASS; ++p) {
@@ -187,7 +189,17 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int p = 0; p < APASS; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * 32) * LDK + lcol]) = xr[p];
+    for (int p = 0; p < APASS; ++p) {
+      float4 v = xr[p];
+      if ((vmask >> p) & 1u) {
+        if (has_aff) { v.x = v.x * s4r.x + h4r.x; v.y = v.y * s4r.y + h4r.y; v.z = v.z * s4r.z + h4r.z; v.w = v.w * s4r.w + h4r.w; }
+        if (a.pro_act != ACT_NONE) {
+          v.x = apply_act(v.x, a.pro_act, 0.f); v.y = apply_act(v.y, a.pro_act, 0.f);
+          v.z = apply_act(v.z, a.pro_act, 0.f); v.w = apply_act(v.w, a.pro_act, 0.f);
+        }
+      }
+      *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * 32) * LDK + lcol]) = v;
+    }
 #pragma unroll
     for (int p = 0; p < BPASS; ++p)
       if (lrow + p * 32 < BN) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * 32) * LDK + lcol]) = wr[p];
