@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
   const int yrow0 = tid / YC4, yc = (tid % YC4) * 4;
   const int yn = n_blk + yc;
   float4 yr[YP], xr[XP];
+  unsigned xmask = 0;      // bit p: xr[p] holds an in-image value
   auto gload = [&](int m0) {
     {
       int b, rr, py, px;
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
       int b, rr, py, px;
       fdivmod(m0 + xrow0, HW, a.inv_hw, b, rr);
       fdivmod(rr, a.Wp, a.inv_w, py, px);
+      xmask = 0;
 #pragma unroll
       for (int p = 0; p < XP; ++p) {
         const int m = m0 + xrow0 + p * XRS;
@@ -115,10 +117,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
           const int iy = py * a.stride + iy_off, ix = px * a.stride + ix_off;
           if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
             xv = *reinterpret_cast<const float4*>(src + (((size_t)b * a.Hin + iy) * a.Win + ix) * cs + cl);
-            if (aff) { xv.x = xv.x * s4.x + h4.x; xv.y = xv.y * s4.y + h4.y; xv.z = xv.z * s4.z + h4.z; xv.w = xv.w * s4.w + h4.w; }
-            float v4[4] = {xv.x, xv.y, xv.z, xv.w};
-            apply_act4(v4, a.pro_act, 0.f);
-            xv = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            xmask |= 1u << p;      // transformed (affine + activation) in sstore, once the MFMAs of this chunk are issued
           }
         }
         xr[p] = xv;
@@ -134,7 +133,16 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
       if (row < BMc) *reinterpret_cast<float4*>(&Ys[row * LDY + yc]) = yr[p];
     }
 #pragma unroll
-    for (int p = 0; p < XP; ++p) *reinterpret_cast<float4*>(&Xs[(xrow0 + p * XRS) * LDX + xc]) = xr[p];
+    for (int p = 0; p < XP; ++p) {
+      float4 xv = xr[p];
+      if ((xmask >> p) & 1u) {
+        if (aff) { xv.x = xv.x * s4.x + h4.x; xv.y = xv.y * s4.y + h4.y; xv.z = xv.z * s4.z + h4.z; xv.w = xv.w * s4.w + h4.w; }
+        float v4[4] = {xv.x, xv.y, xv.z, xv.w};
+        apply_act4(v4, a.pro_act, 0.f);
+        xv = make_float4(v4[0], v4[1], v4[2], v4[3]);
+      }
+      *reinterpret_cast<float4*>(&Xs[(xrow0 + p * XRS) * LDX + xc]) = xv;
+    }
   };
   const int lr = lane & 15, kq = lane >> 4;
   f32x4 acc[NI][NJ];
