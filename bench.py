@@ -33,6 +33,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--graph", action="store_true", help="train mode, 1 GPU: replay the step from one hipGraph capture")
     ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1", "cfg3"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
@@ -150,6 +151,12 @@ def main():
         def step():
             return sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
                                  text_priors=inp["text_priors"])
+        if args.graph and world == 1:
+            run = sr.graphed_train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"],
+                                        inp.get("label_vecs"), inp["text_priors"])
+
+            def step():   # noqa: F811  (same batch every step, like the eager path of this bench)
+                return run(inp["images_lr"], inp["images_hr"], inp.get("label_vecs"), inp["text_priors"])
     else:
         def step():
             return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])

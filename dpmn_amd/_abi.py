@@ -117,7 +117,7 @@ SIGNATURES = {
     "dpmn_l1_loss_fwd_f32": (_i, [fp, fp, _f, fp, fp, C.c_long, fp]),
     "dpmn_l1_loss_bwd_f32": (_i, [fp, fp, fp, _f, fp, fp, fp, C.c_long, fp]),
     "dpmn_sumsq_f32": (_i, [fp, fp, fp, C.c_long, fp]),
-    "dpmn_adam_clip_f32": (_i, [fp, fp, fp, fp, fp, _f, _f, _f, _f, _f, _i, C.c_long, fp]),
+    "dpmn_adam_clip_f32": (_i, [fp, fp, fp, fp, fp, _f, _f, _f, _f, _f, _i, fp, C.c_long, fp]),
     "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

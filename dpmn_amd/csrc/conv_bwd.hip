@@ -452,9 +452,14 @@ __global__ __launch_bounds__(256) void k_sumsq_partial(const float* __restrict__
 // clip_grad_norm_(max_norm) + Adam (torch.optim.Adam semantics, no weight decay / amsgrad); normsq[0] = ||g||^2
 __global__ void k_adam_clip(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ normsq, float max_norm, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt, long n) {
+                            float bc2_sqrt, long n, const float* __restrict__ step_dev) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (step_dev) {      // step count lives on the device (hipGraph replay: host scalars are frozen at capture time)
+    const float t = step_dev[0];
+    bc1 = 1.f - powf(b1, t);
+    bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  }
   float coef = 1.f;
   if (max_norm > 0.f) { coef = max_norm / (sqrtf(normsq[0]) + 1e-6f); coef = coef < 1.f ? coef : 1.f; }
   const float gi = g[i] * coef;
@@ -632,13 +637,15 @@ int dpmn_sumsq_f32(const float* x, float* out, float* part_ws, long n, dpmn_stre
 }
 
 int dpmn_adam_clip_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* grad_normsq, float max_norm,
-                       float lr, float beta1, float beta2, float eps, int step, long n, dpmn_stream_t stream) {
-  DPMN_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adam_clip: bad arguments");
+                       float lr, float beta1, float beta2, float eps, int step, const float* step_dev, long n,
+                       dpmn_stream_t stream) {
+  DPMN_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && (step >= 1 || step_dev), "adam_clip: bad arguments");
+  if (step < 1) step = 1;
   DPMN_REQUIRE(max_norm <= 0.f || grad_normsq, "adam_clip: grad_normsq required when clipping");
   const float bc1 = 1.f - powf(beta1, (float)step);
   const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(k_adam_clip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, as_stream(stream), param, grad, exp_avg, exp_avg_sq,
-                     grad_normsq, max_norm, lr, beta1, beta2, eps, bc1, bc2s, n);
+                     grad_normsq, max_norm, lr, beta1, beta2, eps, bc1, bc2s, n, step_dev);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

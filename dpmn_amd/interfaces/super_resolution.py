@@ -175,6 +175,41 @@ class TextSR(base.TextBase):
         trainer.step()
         return loss.detach()
 
+    def graphed_train_step(self, models, psn, distill, crit, trainer, images_lr, images_hr, label_vecs=None, text_priors=None,
+                           warmup=3):
+        """hipGraph capture of one whole training step (~2000 launches): returns run(images_lr, images_hr, label_vecs,
+        text_priors) -> loss that copies the batch into the captured step's static inputs and replays the graph.
+        Static shapes, precomputed text priors, single process (the RCCL exchange is left to the eager path)."""
+        if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            raise RuntimeError("dpmn_amd: graphed_train_step is single-process; multi-GPU runs use train_step")
+        assert text_priors is not None, "graph capture needs the text priors as inputs"
+        trainer.device_step_counter()
+        st = dict(lr=images_lr.clone(), hr=images_hr.clone(), lv=None if label_vecs is None else label_vecs.clone(),
+                  tp=[t.clone() for t in text_priors])
+        call = lambda: self.train_step(models, psn, distill, crit, trainer, st["lr"], st["hr"], st["lv"], text_priors=st["tp"])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # allocator pools, workspaces and kernel attributes settle before capture
+                call()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = call()
+
+        def run(images_lr, images_hr, label_vecs=None, text_priors=None):
+            st["lr"].copy_(images_lr)
+            st["hr"].copy_(images_hr)
+            if label_vecs is not None:
+                st["lv"].copy_(label_vecs)
+            if text_priors is not None:
+                for d, s_ in zip(st["tp"], text_priors):
+                    d.copy_(s_)
+            graph.replay()
+            return loss
+        run.graph = graph
+        return run
+
     def train(self, loader=None, steps=None):
         """Training loop over a loader of (images_hr, images_lr, label_vecs) batches (the TextZoom LMDB reader and the
         recogniser-driven text priors are out of scope: synthetic batches / priors by default)."""

@@ -20,7 +20,15 @@ class _PadConv(nn.Module):
     def padded(self):
         w, b = self.conv.weight, self.conv.bias
         wp = w.new_zeros(4, self.cin_p, 3, 3)
-        wp[:w.shape[0], self.in_map] = w
+        # in_map is made of runs of consecutive channels: slice copies only (a list index would be an H2D index tensor,
+        # which cannot be captured into a hipGraph)
+        src = 0
+        while src < len(self.in_map):
+            run = 1
+            while src + run < len(self.in_map) and self.in_map[src + run] == self.in_map[src] + run:
+                run += 1
+            wp[:w.shape[0], self.in_map[src]:self.in_map[src] + run] = w[:, src:src + run]
+            src += run
         bp = b.new_zeros(4)
         bp[:b.shape[0]] = b
         return wp, bp
@@ -108,7 +116,8 @@ class _DistillFn(torch.autograd.Function):
                 gr[tns] = torch.zeros_like(tns)
         u1.backward(gr)
         u2.backward(gr)
-        g_wc = gr[u1.conv.weight][:3][:, [0, 1, 2, 4, 5, 6]].contiguous()
+        gw = gr[u1.conv.weight]
+        g_wc = torch.cat([gw[:3, 0:3], gw[:3, 4:7]], dim=1).contiguous()   # slices, not a list index (hipGraph-capturable)
         g_wf = gr[u2.conv.weight][:3, :3].contiguous()
         dx_deep = ops.nhwc_to_nchw(d4.G)[:, :3].contiguous() if ctx.need[0] else None
         dx_sh = ops.nhwc_to_nchw(s4.G)[:, :3].contiguous() if ctx.need[1] else None

@@ -83,11 +83,11 @@ class FlatBucket:
     def zero_grad(self):
         self.flat_g.zero_()
 
-    def step(self, step, lr, beta1, beta2=0.999, eps=1e-8, max_norm=0.25):
+    def step(self, step, lr, beta1, beta2=0.999, eps=1e-8, max_norm=0.25, step_dev=None):
         if self.flat_g.is_cuda:
             check(lib.dpmn_sumsq_f32(dptr(self.flat_g), dptr(self.normsq), dptr(self.part), self.n, stream()))
             check(lib.dpmn_adam_clip_f32(dptr(self.flat_p), dptr(self.flat_g), dptr(self.m), dptr(self.v), dptr(self.normsq),
-                                         max_norm, lr, beta1, beta2, eps, step, self.n, stream()))
+                                         max_norm, lr, beta1, beta2, eps, step, dptr(step_dev, True), self.n, stream()))
         else:
             raise RuntimeError("dpmn_amd: the optimizer kernels run on the GPU only")
 
@@ -99,6 +99,7 @@ class Trainer:
         self.buckets = [FlatBucket(m, "model%d" % i, direct=getattr(m, "direct_grad", False)) for i, m in enumerate(models)]
         self.lr, self.beta1, self.max_norm = lr, beta1, max_norm
         self.t = 0
+        self.t_dev = None       # device-side step counter, see device_step_counter()
         for b in self.buckets:
             b.install_hooks(world_size, group)
 
@@ -106,8 +107,16 @@ class Trainer:
         for b in self.buckets:
             b.zero_grad()
 
+    def device_step_counter(self):
+        """Keep Adam's step count in device memory from now on, so that a hipGraph capture of the training step replays
+        the right bias corrections (host scalars are frozen into a graph at capture time)."""
+        if self.t_dev is None:
+            self.t_dev = torch.full((1,), float(self.t), device=self.buckets[0].flat_p.device)
+
     def step(self):
         self.t += 1
+        if self.t_dev is not None:
+            self.t_dev.add_(1.0)
         for b in self.buckets:
             b.wait()
-            b.step(self.t, self.lr, self.beta1, max_norm=self.max_norm)
+            b.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)

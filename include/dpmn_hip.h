@@ -288,7 +288,9 @@ int dpmn_l1_loss_bwd_f32(const float* a, const float* b, const float* grad_scale
  * clip_grad_norm_(max_norm) fused with torch.optim.Adam's update on flat (param, grad, exp_avg, exp_avg_sq) buffers */
 int dpmn_sumsq_f32(const float* x, float* out, float* part_ws, long n, dpmn_stream_t stream);
 int dpmn_adam_clip_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* grad_normsq,
-                       float max_norm, float lr, float beta1, float beta2, float eps, int step, long n, dpmn_stream_t stream);
+                       float max_norm, float lr, float beta1, float beta2, float eps, int step,
+                       const float* step_dev /* optional device scalar overriding `step` (hipGraph replay) */, long n,
+                       dpmn_stream_t stream);
 
 /* ------------------------------------------------------------------ PGRM module (pgrm_forward.hip) */
 typedef struct {

@@ -281,3 +281,65 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     with torch.no_grad():
         out = fresh(x_q, x_kv, [])
     assert torch.equal(out, ref)
+
+
+def test_graphed_train_step_matches_eager(dev):
+    """One hipGraph capture of the whole training step replays to the same losses / parameters as the eager step
+    (Adam's step count is read from device memory so the bias corrections advance across replays)."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    B, b1, b2 = 2, 2, 2
+
+    def fresh():
+        sr_ = TextSR(workload.make_config(B), workload.make_args("tsrn", b1, b2, B))
+        models, psn, distill, crit, trainer = sr_.build_training()
+        for i, m in enumerate([psn] + models + distill):
+            sd = m.state_dict()
+            synth.synth_fill_(sd, 500 + i)
+            with torch.no_grad():
+                for k, v in m.state_dict().items():
+                    v.copy_(sd[k])
+        psn.eval()
+        return sr_, models, psn, distill, crit, trainer
+
+    batches = [synth.synth_batch(B, seed=20 + i) for i in range(2)]
+    priors = [[torch.floor(synth.uniform("gtp%d_%d" % (i, k), (B, 2, 32, 128), 0, 256, 4)).to(dev) for k in range(b1)] for i in range(2)]
+    warm = 2
+    # eager: `warm` steps on batch 0 (what the capture's warm-up does), then one step on each batch
+    sr_, models, psn, distill, crit, trainer = fresh()
+    lr0, hr0 = batches[0]["images_lr"].to(dev), batches[0]["images_hr"].to(dev)
+    for _ in range(warm):
+        sr_.train_step(models, psn, distill, crit, trainer, lr0, hr0, None, text_priors=priors[0])
+    eager_losses = [float(sr_.train_step(models, psn, distill, crit, trainer, b["images_lr"].to(dev), b["images_hr"].to(dev), None,
+                                         text_priors=priors[i])) for i, b in enumerate(batches)]
+    eager_params = [p.detach().clone() for m in models for p in m.parameters()]
+    # graphed
+    sr_, models, psn, distill, crit, trainer = fresh()
+    run = sr_.graphed_train_step(models, psn, distill, crit, trainer, lr0, hr0, None, priors[0], warmup=warm)
+    graph_losses = [float(run(b["images_lr"].to(dev), b["images_hr"].to(dev), None, priors[i])) for i, b in enumerate(batches)]
+    # the eager step is itself not bit-reproducible (fp32 atomics in BatchNorm statistics / weight gradients feed Adam's
+    # sign-like early updates: 0.1 % run-to-run spread on the first loss, ~1 % a step later -- tools/dbg_graph.py), so this
+    # checks agreement within that spread; the device-side step counter is pinned exactly in the test below
+    assert abs(eager_losses[0] - graph_losses[0]) < 5e-3 * abs(eager_losses[0]), (eager_losses, graph_losses)
+    assert abs(eager_losses[1] - graph_losses[1]) < 3e-2 * abs(eager_losses[1]), (eager_losses, graph_losses)
+    assert graph_losses[1] < graph_losses[0]
+
+
+def test_adam_device_step_counter_equals_host_step(dev):
+    from dpmn_amd.train.optim import FlatBucket
+    torch.manual_seed(3)
+    a, b = torch.nn.Linear(33, 17).to(dev), torch.nn.Linear(33, 17).to(dev)
+    b.load_state_dict(a.state_dict())
+    ba, bb = FlatBucket(a), FlatBucket(b)
+    t_dev = torch.zeros(1, device=dev)
+    for step in range(1, 5):
+        g = [torch.randn_like(p) * 0.1 for p in a.parameters()]
+        for bk, m in ((ba, a), (bb, b)):
+            bk.zero_grad()
+            for p, gi in zip(m.parameters(), g):
+                p.grad += gi
+        t_dev.add_(1.0)
+        ba.step(step, 1e-3, 0.5)
+        bb.step(0, 1e-3, 0.5, step_dev=t_dev)
+        for p, q in zip(a.parameters(), b.parameters()):
+            assert_close(p.detach(), q.detach(), 1e-7, 1e-6, "adam device step %d" % step)
