@@ -86,3 +86,54 @@ def test_stack_cfg3_tbsrn_vs_oracle_small_batch():
     assert_close(mid["psn"], rmid["psn"], 2e-4, 2e-4, "tbsrn psn")
     assert torch.equal(ops.to_mask(mid["psn"]).cpu(), ocmm.to_mask(rmid["psn"][:, :3]))
     assert_close(out, ref, 1e-3, 1e-3, "cfg3 output vs oracle")
+
+
+@pytest.mark.parametrize("B", [1, 3, 7])
+def test_modules_at_odd_batch_sizes_vs_oracle(B):
+    """Ragged batches: B = 1 (SKConv squeeze quirk Q3 is arithmetic-neutral), 3 and 7 (not a multiple of any tile) through
+    PGRM (with 2 residuals), CMM (eval) and the TSRN PSN, each against the oracle."""
+    from dpmn_amd.model.pgrm import PGRM
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    from dpmn_amd.model.tsrn import TSRN
+    from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn
+    dev = torch.device("cuda:0")
+    n = 3
+    args = dict(patch_size=[2] * n, embed_dim=[96] * n, depths=[1] * n, num_heads=[[6]] * n, window_size=[[2, 4, 8]] * n,
+                mlp_ratio=[4.] * n, drop_rate=[0.] * n, attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
+    mods = [PGRM(iter=2, mode=True, hidden_size=3, **args), ComplementationModulationModule(),
+            TSRN(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32)]
+    sds = []
+    for i, m in enumerate(mods):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, 900 + i)
+        m.load_state_dict(sd)
+        m.eval().to(dev)
+        sds.append({k: v.detach().cpu().clone() for k, v in m.state_dict().items()})
+    u = lambda name, shape: synth.uniform(name + str(B), shape, 0, 1, 12)
+    xq, xkv = u("oq", (B, 3, 32, 128)), u("okv", (B, 3, 32, 128))
+    res = [u("or0", (B, 3, 32, 128)), u("or1", (B, 3, 32, 128)), u("or2", (B, 3, 32, 128))]
+    lr = synth.synth_batch(B, seed=30 + B)["images_lr"]
+    with torch.no_grad():
+        got_p = mods[0](xq.to(dev), xkv.to(dev), [r.to(dev) for r in res])
+        got_c = mods[1](xq.to(dev), xkv.to(dev))
+        got_t = mods[2](lr.to(dev))
+    assert_close(got_p, opgrm.pgrm_forward(sds[0], xq, xkv, res), 3e-4, 3e-4, "PGRM B=%d" % B)
+    assert_close(got_c, ocmm.cmm_forward(sds[1], xq, xkv, False), 5e-4, 5e-4, "CMM B=%d" % B)
+    assert_close(got_t, otsrn.tsrn_forward(sds[2], lr), 3e-4, 3e-4, "TSRN B=%d" % B)
+
+
+def test_error_behaviour_through_the_c_abi():
+    """Bad arguments come back as negative codes + dpmn_last_error (raised as DpmnError by the Python layer), never a crash."""
+    from dpmn_amd import ops
+    from dpmn_amd._abi import DpmnError, lib
+    dev = torch.device("cuda:0")
+    x = torch.zeros(8, 100, device=dev)          # K = 100 is not a multiple of 32 and not a whole-K size
+    with pytest.raises(DpmnError, match="K must be a multiple of 32"):
+        ops.linear(x, torch.zeros(96, 100, device=dev))
+    q = torch.zeros(2, 15 * 64, 96, device=dev)   # H = 15 is not divisible by the 2/4/8 windows (quirk Q1: would crash the reference)
+    with pytest.raises(DpmnError, match="padding path"):
+        ops.window_attn(q, torch.zeros(2, 15 * 64, 192, device=dev), [torch.zeros(9, 2, device=dev), torch.zeros(49, 2, device=dev),
+                                                                     torch.zeros(225, 2, device=dev)], [2, 4, 8], [0, 0, 0], 2, 15, 64)
+    with pytest.raises(DpmnError, match="mha32"):
+        ops.mha32(torch.zeros(100, 384, device=dev), 1, 100, 4, 1.0)
+    assert lib.dpmn_abi_version() >= 1
