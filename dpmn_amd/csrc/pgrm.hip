@@ -301,19 +301,23 @@ __global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image
 __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ g, int Ch, int r,
                                                       long planes, int apply_gelu) {
-  extern __shared__ float sm[];   // [ (r+2) * (r+2) ] per wave
+  // per wave: one r x r plane in an LDS tile of (r+2) rows x LD = r+8 floats; the plane starts at column 4 so that rows are
+  // 16-byte aligned for float4 traffic (global loads / stores and the centre taps); r % 4 == 0
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long plane = (long)blockIdx.x * 4 + wave;
   const bool valid = plane < planes;
   const int c = valid ? (int)(plane % Ch) : 0;
-  const int LD = r + 2;
-  float* t = sm + wave * LD * LD;
+  const int LD = r + 8, r4 = r >> 2;
+  float* t = sm + wave * (r + 2) * LD;
   if (valid) {
     const float* src = y + plane * r * r;
-    for (int i = lane; i < LD * LD; i += 64) {
-      const int yy = i / LD - 1, xx = i % LD - 1;
-      t[i] = (yy >= 0 && yy < r && xx >= 0 && xx < r) ? src[yy * r + xx] : 0.f;
+    for (int i = lane; i < r * r4; i += 64) {
+      const int yy = i / r4, x4 = (i - yy * r4) * 4;
+      *reinterpret_cast<float4*>(t + (yy + 1) * LD + 4 + x4) = *reinterpret_cast<const float4*>(src + yy * r + x4);
     }
+    for (int i = lane; i < LD; i += 64) { t[i] = 0.f; t[(r + 1) * LD + i] = 0.f; }       // top / bottom halo rows
+    for (int i = lane; i < r; i += 64) { t[(i + 1) * LD + 3] = 0.f; t[(i + 1) * LD + 4 + r] = 0.f; }   // left / right halo columns
   }
   __syncthreads();
   if (!valid) return;
@@ -322,15 +326,25 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
   for (int i = 0; i < 9; ++i) k[i] = w[c * 9 + i];
   const float bv = bias[c];
   float* dst = g + plane * r * r;
-  for (int i = lane; i < r * r; i += 64) {
-    const int yy = i / r, xx = i % r;
-    const float* p = t + yy * LD + xx;
-    float a = bv;
+  for (int i = lane; i < r * r4; i += 64) {
+    const int yy = i / r4, x4 = (i - yy * r4) * 4;
+    float a[4] = {bv, bv, bv, bv};
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
+    for (int ky = 0; ky < 3; ++ky) {
+      const float* p = t + (yy + ky) * LD + 4 + x4;
+      const float4 m = *reinterpret_cast<const float4*>(p);
+      const float l = p[-1], rr = p[4];
+      const float k0 = k[ky * 3], k1 = k[ky * 3 + 1], k2 = k[ky * 3 + 2];
+      a[0] += k0 * l + k1 * m.x + k2 * m.y;
+      a[1] += k0 * m.x + k1 * m.y + k2 * m.z;
+      a[2] += k0 * m.y + k1 * m.z + k2 * m.w;
+      a[3] += k0 * m.z + k1 * m.w + k2 * rr;
+    }
+    if (apply_gelu) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) a += k[ky * 3 + kx] * p[ky * LD + kx];
-    dst[i] = apply_gelu ? gelu_erf(a) : a;
+      for (int q = 0; q < 4; ++q) a[q] = gelu_erf(a[q]);
+    }
+    *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
   }
 }
 
@@ -479,19 +493,21 @@ int dpmn_sk_gate_f32(const float* colsum_partials, int parts_per_image, int L, c
 
 int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r,
                             dpmn_stream_t stream) {
-  DPMN_REQUIRE(y && w && bias && g && r >= 3 && r <= 64, "dwconv: bad arguments");
+  DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
-  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), (size_t)4 * (r + 2) * (r + 2) * 4,
-                     as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
+  const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
 
 int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream) {
-  DPMN_REQUIRE(y && w && bias && g && r >= 3 && r <= 64, "dwconv: bad arguments");
+  DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
-  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), (size_t)4 * (r + 2) * (r + 2) * 4,
-                     as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
+  const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
