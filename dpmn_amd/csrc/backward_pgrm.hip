@@ -271,22 +271,27 @@ __global__ void k_sk_feats_grad(const float* __restrict__ dout, const float* __r
 __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P, const float* __restrict__ dg,
                                                      const float* __restrict__ w, float* __restrict__ dP, float* __restrict__ dw,
                                                      float* __restrict__ db, int Ch, int r, long planes) {
-  extern __shared__ float sm[];   // per wave: P tile and dg tile with 1-pixel halo
+  // per wave: P tile and dg tile, (r+2) rows x LD = r+8 floats, plane starting at column 4 (16-byte aligned rows, r % 4 == 0)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long plane = (long)blockIdx.x * 4 + wave;
   const bool valid = plane < planes;
   const int c = valid ? (int)(plane % Ch) : 0;
-  const int LD = r + 2;
-  float* tp = sm + wave * 2 * LD * LD;
-  float* tg = tp + LD * LD;
+  const int LD = r + 8, r4 = r >> 2, TS = (r + 2) * LD;
+  float* tp = sm + wave * 2 * TS;
+  float* tg = tp + TS;
   if (valid) {
     const float* ps = P + plane * r * r;
     const float* gs = dg + plane * r * r;
-    for (int i = lane; i < LD * LD; i += 64) {
-      const int yy = i / LD - 1, xx = i % LD - 1;
-      const bool in = yy >= 0 && yy < r && xx >= 0 && xx < r;
-      tp[i] = in ? ps[yy * r + xx] : 0.f;
-      tg[i] = in ? gs[yy * r + xx] : 0.f;
+    for (int i = lane; i < r * r4; i += 64) {
+      const int yy = i / r4, x4 = (i - yy * r4) * 4;
+      *reinterpret_cast<float4*>(tp + (yy + 1) * LD + 4 + x4) = *reinterpret_cast<const float4*>(ps + yy * r + x4);
+      *reinterpret_cast<float4*>(tg + (yy + 1) * LD + 4 + x4) = *reinterpret_cast<const float4*>(gs + yy * r + x4);
+    }
+    for (int i = lane; i < LD; i += 64) { tp[i] = 0.f; tp[(r + 1) * LD + i] = 0.f; tg[i] = 0.f; tg[(r + 1) * LD + i] = 0.f; }
+    for (int i = lane; i < r; i += 64) {
+      tp[(i + 1) * LD + 3] = 0.f; tp[(i + 1) * LD + 4 + r] = 0.f;
+      tg[(i + 1) * LD + 3] = 0.f; tg[(i + 1) * LD + 4 + r] = 0.f;
     }
   }
   __syncthreads();
@@ -295,21 +300,31 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P,
 #pragma unroll
   for (int i = 0; i < 9; ++i) { k[i] = w[c * 9 + i]; aw[i] = 0.f; }
   float* dst = dP + plane * r * r;
-  for (int i = lane; i < r * r; i += 64) {
-    const int yy = i / r, xx = i % r;
-    const float* pg = tg + yy * LD + xx;     // dg halo window centred at (yy, xx): pg[(dy)*LD + dx], dy,dx in 0..2
-    const float* pp = tp + yy * LD + xx;
-    float a = 0.f;
-    const float gc = pg[LD + 1];
+  for (int i = lane; i < r * r4; i += 64) {
+    const int yy = i / r4, x4 = (i - yy * r4) * 4;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    const float4 gc = *reinterpret_cast<const float4*>(tg + (yy + 1) * LD + 4 + x4);     // dg at the 4 output pixels
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        a += k[ky * 3 + kx] * pg[(2 - ky) * LD + (2 - kx)];   // dP[y][x] = sum dg[y-ky+1][x-kx+1] w[ky][kx]
-        aw[ky * 3 + kx] += gc * pp[ky * LD + kx];              // dW[ky][kx] += dg[y][x] P[y+ky-1][x+kx-1]
-      }
-    ab += gc;
-    dst[i] = a;
+    for (int ky = 0; ky < 3; ++ky) {
+      // dP[y][x] = sum_k dg[y - ky + 1][x - kx + 1] w[ky][kx] : dg row (yy + 2 - ky) of the halo tile, columns x4 - 1 .. x4 + 4
+      const float* pg = tg + (yy + 2 - ky) * LD + 4 + x4;
+      const float4 gm = *reinterpret_cast<const float4*>(pg);
+      const float gl = pg[-1], gr = pg[4];
+      const float k0 = k[ky * 3], k1 = k[ky * 3 + 1], k2 = k[ky * 3 + 2];
+      a[0] += k0 * gm.y + k1 * gm.x + k2 * gl;
+      a[1] += k0 * gm.z + k1 * gm.y + k2 * gm.x;
+      a[2] += k0 * gm.w + k1 * gm.z + k2 * gm.y;
+      a[3] += k0 * gr + k1 * gm.w + k2 * gm.z;
+      // dW[ky][kx] += dg[y][x] P[y + ky - 1][x + kx - 1] : P row (yy + ky) of the halo tile
+      const float* pp = tp + (yy + ky) * LD + 4 + x4;
+      const float4 pm = *reinterpret_cast<const float4*>(pp);
+      const float pl = pp[-1], pr = pp[4];
+      aw[ky * 3] += gc.x * pl + gc.y * pm.x + gc.z * pm.y + gc.w * pm.z;
+      aw[ky * 3 + 1] += gc.x * pm.x + gc.y * pm.y + gc.z * pm.z + gc.w * pm.w;
+      aw[ky * 3 + 2] += gc.x * pm.y + gc.y * pm.z + gc.z * pm.w + gc.w * pr;
+    }
+    ab += (gc.x + gc.y) + (gc.z + gc.w);
+    *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
   }
 #pragma unroll
   for (int i = 0; i < 9; ++i) { const float s = wave_sum(aw[i]); if (lane == 0) atomicAdd(dw + c * 9 + i, s); }
@@ -632,10 +647,12 @@ int dpmn_sk_feats_grad_f32(const float* dout, const float* feats, const float* d
 
 int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, float* dP, float* dw, float* db, int B, int Ch, int r,
                            dpmn_stream_t stream) {
-  DPMN_REQUIRE(P && dg && w && dP && dw && db && r >= 3 && r <= 64, "dwconv_bwd: bad arguments");
+  DPMN_REQUIRE(P && dg && w && dP && dw && db && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_bwd: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
-  hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), (size_t)8 * (r + 2) * (r + 2) * 4, as_stream(stream),
-                     P, dg, w, dP, dw, db, Ch, r, planes);
+  const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+                     planes);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
