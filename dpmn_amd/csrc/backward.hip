@@ -197,39 +197,70 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
   float gam[PER], ag[PER], ab[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) { gam[i] = gamma[t + 32 * i]; ag[i] = 0.f; ab[i] = 0.f; }
-  for (long row = (long)blockIdx.x * 8 + sub; row < M; row += (long)gridDim.x * 8) {
-    float xv[PER], dv[PER];
-    float s = 0.f;
+  // R rows per 32-thread group are in flight at once: the loop is a chain of dependent cross-lane reductions, so the
+  // memory latency of a single row per iteration (measured 1.3 TB/s) has to be covered by independent rows
+  constexpr int R = 4;
+  const long stride = (long)gridDim.x * 8;
+  for (long row0 = (long)blockIdx.x * 8 + sub; row0 < M; row0 += stride * R) {
+    float xv[R][PER], dv[R][PER], s[R];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) { xv[i] = x[row * C + t + 32 * i]; dv[i] = dy[row * C + t + 32 * i]; s += xv[i]; }
+    for (int u = 0; u < R; ++u) {
+      const long row = row0 + u * stride;
+      s[u] = 0.f;
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s * (1.0f / C);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) { const float d = xv[i] - mean; q += d * d; }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
-    float s1 = 0.f, s2 = 0.f;
-    float xh[PER], dg[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      xh[i] = (xv[i] - mean) * rstd;
-      dg[i] = dv[i] * gam[i];
-      s1 += dg[i];
-      s2 += dg[i] * xh[i];
-      ag[i] += dv[i] * xh[i];
-      ab[i] += dv[i];
+      for (int i = 0; i < PER; ++i) {
+        xv[u][i] = row < M ? x[row * C + t + 32 * i] : 0.f;
+        dv[u][i] = row < M ? dy[row * C + t + 32 * i] : 0.f;
+        s[u] += xv[u][i];
+      }
     }
 #pragma unroll
-    for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-    s1 *= (1.0f / C); s2 *= (1.0f / C);
+    for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const float g = rstd * (dg[i] - s1 - xh[i] * s2);
-      const long o = row * C + t + 32 * i;
-      dx[o] = accumulate_dx ? dx[o] + g : g;
+      for (int u = 0; u < R; ++u) s[u] += __shfl_xor(s[u], o, 64);
+    float q[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      s[u] *= (1.0f / C);      // mean
+      q[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) { const float d = xv[u][i] - s[u]; q[u] += d * d; }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < R; ++u) q[u] += __shfl_xor(q[u], o, 64);
+    float s1[R], s2[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      q[u] = 1.0f / sqrtf(q[u] * (1.0f / C) + eps);   // rstd
+      s1[u] = 0.f; s2[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const float xh = (xv[u][i] - s[u]) * q[u];
+        const float dgi = dv[u][i] * gam[i];
+        s1[u] += dgi;
+        s2[u] += dgi * xh;
+        ag[i] += dv[u][i] * xh;      // rows past M carry dv = 0
+        ab[i] += dv[u][i];
+        xv[u][i] = xh; dv[u][i] = dgi;
+      }
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < R; ++u) { s1[u] += __shfl_xor(s1[u], o, 64); s2[u] += __shfl_xor(s2[u], o, 64); }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const long row = row0 + u * stride;
+      if (row >= M) continue;
+      const float m1 = s1[u] * (1.0f / C), m2 = s2[u] * (1.0f / C);
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const float g = q[u] * (dv[u][i] - m1 - xv[u][i] * m2);
+        const long o = row * C + t + 32 * i;
+        dx[o] = accumulate_dx ? dx[o] + g : g;
+      }
     }
   }
 #pragma unroll
@@ -382,7 +413,10 @@ int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t str
 int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
                            float* dgamma, float* dbeta, long M, int C, dpmn_stream_t stream) {
   DPMN_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && M > 0, "layernorm_bwd: bad arguments");
-  const unsigned blocks = (unsigned)(M / 8 < 1024 ? (M + 7) / 8 : 1024);
+  // every block ends with 2*C same-address atomics (dgamma, dbeta), which serialise: few, fat blocks (4 rows in flight per
+  // 32-thread group).  In-pipeline sweep at M = 49152: 256 blocks 46.6 us, 512: 36.9, 1024: 41.9, 2048: 59.9
+  static const long cap = getenv("DPMN_LNB_BLOCKS") ? atol(getenv("DPMN_LNB_BLOCKS")) : 512;
+  const unsigned blocks = (unsigned)(M / 8 < cap ? (M + 7) / 8 : cap);
   if (C == 96)
     hipLaunchKernelGGL((k_ln_bwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
   else if (C == 192)

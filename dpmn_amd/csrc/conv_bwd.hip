@@ -289,18 +289,36 @@ __global__ void k_affine_act_bwd(const float* __restrict__ dA, const float* __re
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ G, const float* __restrict__ r,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         float* __restrict__ sums, long pixels, int C, int pix_per_block) {
+  // thread = (pixel lane, channel quad): float4 loads, 256 / (C/4) pixels in flight per block, LDS reduction over the pixel
+  // lanes, then ONE atomic per channel per block (the launcher keeps the block count low: same-address atomics serialise)
+  __shared__ float red[256][8];
+  const int Cq = C >> 2;
+  const int PL = 256 / Cq;                    // C/4 divides 256 for every BatchNorm width on the path (64 ... 512 channels)
+  const int cq = threadIdx.x % Cq, pl = threadIdx.x / Cq;
   const long p0 = (long)blockIdx.x * pix_per_block;
   const long p1 = p0 + pix_per_block < pixels ? p0 + pix_per_block : pixels;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float mu = mean[c], rs = rstd[c];
-    float s1 = 0.f, s2 = 0.f;
-    for (long p = p0; p < p1; ++p) {
-      const float g = G[p * C + c];
-      s1 += g;
-      s2 += g * (r[p * C + c] - mu) * rs;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pl < PL) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + cq * 4), rs = *reinterpret_cast<const float4*>(rstd + cq * 4);
+    for (long p = p0 + pl; p < p1; p += PL) {
+      const float4 g = *reinterpret_cast<const float4*>(G + p * C + cq * 4);
+      const float4 x = *reinterpret_cast<const float4*>(r + p * C + cq * 4);
+      s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
+      s2[0] += g.x * (x.x - mu.x) * rs.x; s2[1] += g.y * (x.y - mu.y) * rs.y;
+      s2[2] += g.z * (x.z - mu.z) * rs.z; s2[3] += g.w * (x.w - mu.w) * rs.w;
     }
-    atomicAdd(sums + c, s1);
-    atomicAdd(sums + C + c, s2);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { red[threadIdx.x][q] = s1[q]; red[threadIdx.x][4 + q] = s2[q]; }
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a = 0.f, b2 = 0.f;
+      for (int l = 0; l < PL; ++l) { a += red[l * Cq + cq][q]; b2 += red[l * Cq + cq][4 + q]; }
+      atomicAdd(sums + cq * 4 + q, a);
+      atomicAdd(sums + C + cq * 4 + q, b2);
+    }
   }
 }
 // dr = gamma*rstd*(G - sums0/count - xhat*sums1/count) ; dgamma += sums1 ; dbeta += sums0 (done once by block 0)
@@ -573,7 +591,9 @@ int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const fl
                     float* dr, float* dgamma, float* dbeta, long pixels, int C, dpmn_stream_t stream) {
   DPMN_REQUIRE(G && r && gamma && mean && rstd && sums_ws && dr && dgamma && dbeta && pixels > 1, "bn_bwd: bad arguments");
   (void)hipMemsetAsync(sums_ws, 0, (size_t)2 * C * sizeof(float), as_stream(stream));
-  const int ppb = 64;
+  DPMN_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "bn_bwd: C/4 must divide 256");
+  int ppb = (int)((pixels + 511) / 512);       // <= 512 blocks
+  if (ppb < 64) ppb = 64;
   hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((unsigned)((pixels + ppb - 1) / ppb)), dim3(256), 0, as_stream(stream), G, r, mean, rstd,
                      sums_ws, pixels, C, ppb);
   DPMN_CHECK_LAUNCH();
