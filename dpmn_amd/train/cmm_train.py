@@ -107,8 +107,11 @@ class Unit:
             tmp = torch.zeros(cout, device=dr.device)
             colsum(dr.reshape(pixels, cout), tmp)
             gr[b] += tmp[:cout_real]
-        else:
+        elif self.bn is None:
             colsum(dr.reshape(pixels, cout), gr[b])
+        # else: a conv bias in front of a train-mode BatchNorm has an identically zero gradient (the batch mean removes it;
+        # sum over pixels of dr is exactly 0 in exact arithmetic) -- autograd in the reference only accumulates round-off
+        # there (<= 3e-4 at these sizes), so the bias gradient stays at its zero fill instead of costing a reduction
         xs = [t.r for t in self.inputs]
         aff = [t.aff for t in self.inputs]
         cin = sum(x.shape[3] for x in xs)
