@@ -338,86 +338,58 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ G, const float* __restr
 // g = x * (1 + w), w = sigmoid(fc2(relu(fc1(mean_p x)))).
 // Pass 1, one workgroup per image: recompute the gate, form dx and leave (S, relu(h), dlogit, dh) in ws[b].
 // Pass 2, one thread per weight element: reduce the per-image outer products over the batch (no atomics).
-__global__ __launch_bounds__(256) void k_se_gate_bwd(const float* __restrict__ x, const float* __restrict__ dg,
-                                                      const float* __restrict__ fc1_w, const float* __restrict__ fc1_b,
-                                                      const float* __restrict__ fc2_w, const float* __restrict__ fc2_b,
-                                                      float* __restrict__ dx, float* __restrict__ ws, int P, int C, int Cm) {
-  extern __shared__ float sm[];
-  float* S = sm;            // [C] mean
-  float* Hp = S + C;        // [Cm] pre-relu
-  float* Wg = Hp + Cm;      // [C] gate
-  float* dlog = Wg + C;     // [C] grad wrt fc2 output (pre-sigmoid)
-  float* dh = dlog + C;     // [Cm] grad wrt fc1 output (pre-relu)
-  float* dSm = dh + Cm;     // [C] grad wrt S
-  float* Dw = dSm + C;      // [C] sum_p dg * x
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// pass 1a: S[b][c] = mean_p x, Dw[b][c] = sum_p dg * x ; block = (image, 64 channels), 4 pixel lanes per channel
+__global__ __launch_bounds__(256) void k_se_gate_bwd_stats(const float* __restrict__ x, const float* __restrict__ dg,
+                                                            float* __restrict__ S, float* __restrict__ Dw, int P, int C) {
+  __shared__ float red[4][64][2];
+  const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
   const float* xb = x + (size_t)b * P * C;
   const float* gb = dg + (size_t)b * P * C;
-  for (int c = tid; c < C; c += 256) {
-    float s = 0.f, dw = 0.f;
-    for (int p = 0; p < P; ++p) { const float xv = xb[p * C + c]; s += xv; dw += gb[p * C + c] * xv; }
-    S[c] = s / (float)P; Dw[c] = dw;
-  }
+  float s = 0.f, dw = 0.f;
+  if (c < C)
+    for (int p = pl; p < P; p += 4) { const float xv = xb[(size_t)p * C + c]; s += xv; dw += gb[(size_t)p * C + c] * xv; }
+  red[pl][threadIdx.x & 63][0] = s; red[pl][threadIdx.x & 63][1] = dw;
   __syncthreads();
-  for (int j = wave; j < Cm; j += 4) {
-    float a = 0.f;
-    for (int k = lane; k < C; k += 64) a += fc1_w[(size_t)j * C + k] * S[k];
-    a = wave_sum(a);
-    if (lane == 0) Hp[j] = a + fc1_b[j];
+  if (pl == 0 && c < C) {
+    const int l = threadIdx.x;
+    S[(size_t)b * C + c] = (red[0][l][0] + red[1][l][0] + red[2][l][0] + red[3][l][0]) / (float)P;
+    Dw[(size_t)b * C + c] = red[0][l][1] + red[1][l][1] + red[2][l][1] + red[3][l][1];
   }
-  __syncthreads();
-  for (int c = wave; c < C; c += 4) {
-    float a = 0.f;
-    for (int k = lane; k < Cm; k += 64) a += fc2_w[(size_t)c * Cm + k] * fmaxf(Hp[k], 0.f);
-    a = wave_sum(a);
-    if (lane == 0) {
-      const float w = sigmoid_f(a + fc2_b[c]);
-      Wg[c] = w;
-      dlog[c] = Dw[c] * w * (1.f - w);
-    }
-  }
-  __syncthreads();
-  for (int j = wave; j < Cm; j += 4) {
-    float a = 0.f;
-    for (int c = lane; c < C; c += 64) a += dlog[c] * fc2_w[(size_t)c * Cm + j];
-    a = wave_sum(a);
-    if (lane == 0) dh[j] = Hp[j] > 0.f ? a : 0.f;
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    float a = 0.f;
-    for (int j = 0; j < Cm; ++j) a += dh[j] * fc1_w[(size_t)j * C + c];
-    dSm[c] = a / (float)P;
-  }
-  float* wb = ws + (size_t)b * (2 * C + 2 * Cm);     // [S | dlog | relu(h) | dh]
-  for (int c = tid; c < C; c += 256) { wb[c] = S[c]; wb[C + c] = dlog[c]; }
-  for (int j = tid; j < Cm; j += 256) { wb[2 * C + j] = fmaxf(Hp[j], 0.f); wb[2 * C + Cm + j] = dh[j]; }
-  __syncthreads();
-  float* db_ = dx + (size_t)b * P * C;
-  for (int i = tid; i < P * C; i += 256) db_[i] = gb[i] * (1.f + Wg[i % C]) + dSm[i % C];
 }
-__global__ void k_se_gate_bwd_w(const float* __restrict__ ws, float* __restrict__ dfc1_w, float* __restrict__ dfc1_b,
-                                float* __restrict__ dfc2_w, float* __restrict__ dfc2_b, int B, int C, int Cm) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nw = C * Cm, st = 2 * C + 2 * Cm;
-  float a = 0.f;
-  if (idx < nw) {                       // dfc2_w[c][j] = sum_b dlog[b][c] * relu(h)[b][j]
-    const int c = idx / Cm, j = idx - c * Cm;
-    for (int b = 0; b < B; ++b) a += ws[(size_t)b * st + C + c] * ws[(size_t)b * st + 2 * C + j];
-    dfc2_w[idx] += a;
-  } else if (idx < 2 * nw) {            // dfc1_w[j][c] = sum_b dh[b][j] * S[b][c]
-    const int e = idx - nw, j = e / C, c = e - j * C;
-    for (int b = 0; b < B; ++b) a += ws[(size_t)b * st + 2 * C + Cm + j] * ws[(size_t)b * st + c];
-    dfc1_w[e] += a;
-  } else if (idx < 2 * nw + C) {
-    const int c = idx - 2 * nw;
-    for (int b = 0; b < B; ++b) a += ws[(size_t)b * st + C + c];
-    dfc2_b[c] += a;
-  } else if (idx < 2 * nw + C + Cm) {
-    const int j = idx - 2 * nw - C;
-    for (int b = 0; b < B; ++b) a += ws[(size_t)b * st + 2 * C + Cm + j];
-    dfc1_b[j] += a;
-  }
+// gate elementwise: w = sigmoid(logit); dlog = Dw * w * (1 - w); onepw = 1 + w        (B x C)
+__global__ void k_se_gate_elem(const float* __restrict__ logit, const float* __restrict__ Dw, float* __restrict__ dlog,
+                               float* __restrict__ onepw, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float w = sigmoid_f(logit[i]);
+  dlog[i] = Dw[i] * w * (1.f - w);
+  onepw[i] = 1.f + w;
+}
+__global__ void k_relu_mask(const float* __restrict__ hrelu, float* __restrict__ dh, long n) {   // dh *= (h > 0)
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !(hrelu[i] > 0.f)) dh[i] = 0.f;
+}
+__global__ void k_transpose(const float* __restrict__ a, float* __restrict__ at, int R, int Cc) {   // a (R, Cc) -> at (Cc, R)
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8)
+    if (by + j < R && bx + tx < Cc) tile[j][tx] = a[(size_t)(by + j) * Cc + bx + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (bx + j < Cc && by + tx < R) at[(size_t)(bx + j) * R + by + tx] = tile[tx][j];
+}
+// pass 1c: dx = dg * (1 + gate) + dS / P, elementwise over (image, pixel, channel)
+__global__ void k_se_gate_bwd_dx(const float* __restrict__ dg, const float* __restrict__ onepw, const float* __restrict__ dS,
+                                 float* __restrict__ dx, int P, int C, float inv_p, long total4) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const long e = i * 4;
+  const int c = (int)(e % C);
+  const long b = e / ((long)P * C);
+  const float4 g = *reinterpret_cast<const float4*>(dg + e);
+  const float4 w1 = *reinterpret_cast<const float4*>(onepw + b * C + c), ds = *reinterpret_cast<const float4*>(dS + b * C + c);
+  *reinterpret_cast<float4*>(dx + e) = make_float4(g.x * w1.x + ds.x * inv_p, g.y * w1.y + ds.y * inv_p, g.z * w1.z + ds.z * inv_p,
+                                                   g.w * w1.w + ds.w * inv_p);
 }
 
 // ---------------------------------------------------------------------------------- DistillModule tail + optimizer
@@ -607,16 +579,36 @@ int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const fl
 int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                          const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b, float* ws,
                          int B, int P, int C, int Cmid, dpmn_stream_t stream) {
-  DPMN_REQUIRE(x && dg && fc1_w && fc1_b && fc2_w && fc2_b && dx && dfc1_w && dfc1_b && dfc2_w && dfc2_b && ws && B > 0,
-               "se_gate_bwd: bad arguments (ws: B*(2C+2Cmid) floats)");
-  hipLaunchKernelGGL(k_se_gate_bwd, dim3(B), dim3(256), (size_t)(5 * C + 2 * Cmid) * 4, as_stream(stream), x, dg, fc1_w, fc1_b, fc2_w,
-                     fc2_b, dx, ws, P, C, Cmid);
+  DPMN_REQUIRE(x && dg && fc1_w && fc1_b && fc2_w && fc2_b && dx && dfc1_w && dfc1_b && dfc2_w && dfc2_b && ws && B > 0 &&
+                   C % 32 == 0 && Cmid % 32 == 0,
+               "se_gate_bwd: bad arguments (ws: B*(5C+2Cmid) + 2*C*Cmid floats; C, Cmid multiples of 32)");
+  // g = x * (1 + w), w = sigmoid(fc2(relu(fc1(mean_p x)))).  The pooled vectors of the whole batch go through the two FC
+  // layers (forward and backward) as four small (B x .) GEMMs; the weight gradients are two dY^T.X GEMMs over the batch.
+  hipStream_t st = as_stream(stream);
+  const size_t BC = (size_t)B * C, BM = (size_t)B * Cmid;
+  float* S = ws; float* Dw = S + BC; float* logit = Dw + BC; float* dlog = logit + BC; float* dS = dlog + BC;   // Dw doubles as 1+w
+  float* hrelu = dS + BC; float* dh = hrelu + BM;
+  float* w1t = dh + BM;                     // fc1_w^T (C, Cmid)
+  float* w2t = w1t + (size_t)C * Cmid;      // fc2_w^T (Cmid, C)
+  hipLaunchKernelGGL(k_se_gate_bwd_stats, dim3(B, cdiv(C, 64)), dim3(256), 0, st, x, dg, S, Dw, P, C);
   DPMN_CHECK_LAUNCH();
-  const int total = 2 * C * Cmid + C + Cmid;
-  hipLaunchKernelGGL(k_se_gate_bwd_w, dim3(cdiv(total, 256)), dim3(256), 0, as_stream(stream), ws, dfc1_w, dfc1_b, dfc2_w, dfc2_b, B,
-                     C, Cmid);
+  int rc;
+  if ((rc = dpmn_linear_f32(S, fc1_w, fc1_b, nullptr, nullptr, hrelu, B, Cmid, C, ACT_RELU, 0.f, stream)) != DPMN_OK) return rc;
+  if ((rc = dpmn_linear_f32(hrelu, fc2_w, fc2_b, nullptr, nullptr, logit, B, C, Cmid, ACT_NONE, 0.f, stream)) != DPMN_OK) return rc;
+  hipLaunchKernelGGL(k_se_gate_elem, dim3((unsigned)((BC + 255) / 256)), dim3(256), 0, st, logit, Dw, dlog, Dw, (long)BC);
   DPMN_CHECK_LAUNCH();
-  return DPMN_OK;
+  hipLaunchKernelGGL(k_transpose, dim3(cdiv(C, 32), cdiv(Cmid, 32)), dim3(256), 0, st, fc1_w, w1t, Cmid, C);   // (Cmid,C) -> (C,Cmid)
+  hipLaunchKernelGGL(k_transpose, dim3(cdiv(Cmid, 32), cdiv(C, 32)), dim3(256), 0, st, fc2_w, w2t, C, Cmid);   // (C,Cmid) -> (Cmid,C)
+  DPMN_CHECK_LAUNCH();
+  if ((rc = dpmn_linear_f32(dlog, w2t, nullptr, nullptr, nullptr, dh, B, Cmid, C, ACT_NONE, 0.f, stream)) != DPMN_OK) return rc;
+  hipLaunchKernelGGL(k_relu_mask, dim3((unsigned)((BM + 255) / 256)), dim3(256), 0, st, hrelu, dh, (long)BM);
+  DPMN_CHECK_LAUNCH();
+  if ((rc = dpmn_linear_f32(dh, w1t, nullptr, nullptr, nullptr, dS, B, C, Cmid, ACT_NONE, 0.f, stream)) != DPMN_OK) return rc;
+  const long total4 = (long)B * P * C / 4;
+  hipLaunchKernelGGL(k_se_gate_bwd_dx, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, dg, Dw, dS, dx, P, C, 1.0f / (float)P, total4);
+  DPMN_CHECK_LAUNCH();
+  if ((rc = dpmn_gemm_tn_f32(dlog, hrelu, dfc2_w, dfc2_b, B, C, Cmid, nullptr, 0, stream)) != DPMN_OK) return rc;
+  return dpmn_gemm_tn_f32(dh, S, dfc1_w, dfc1_b, B, Cmid, C, nullptr, 0, stream);
 }
 
 int dpmn_affine_act_fwd_f32(const float* r, const float* scale, const float* shift, int act, float* y, long pixels, int C,

@@ -220,7 +220,8 @@ def backward(m, graph, dout, need_dx=(True, True)):
             # channel gate backward, then split the bottleneck gradient into the two en_6 outputs
             g = graph["gated"]
             dbott = torch.empty_like(graph["bott"])
-            se_ws = torch.empty(dbott.shape[0], 2 * dbott.shape[3] + 2 * m.fc_1.weight.shape[0], device=dbott.device)
+            _c, _cm = dbott.shape[3], m.fc_1.weight.shape[0]
+            se_ws = torch.empty(dbott.shape[0] * (5 * _c + 2 * _cm) + 2 * _c * _cm, device=dbott.device)
             check(lib.dpmn_se_gate_bwd_f32(dptr(graph["bott"]), dptr(g.G), dptr(m.fc_1.weight), dptr(m.fc_1.bias), dptr(m.fc_2.weight),
                                            dptr(m.fc_2.bias), dptr(dbott), dptr(gr[m.fc_1.weight]), dptr(gr[m.fc_1.bias]),
                                            dptr(gr[m.fc_2.weight]), dptr(gr[m.fc_2.bias]), dptr(se_ws), dbott.shape[0], dbott.shape[1] * dbott.shape[2],

@@ -276,7 +276,7 @@ int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const fl
                     float* dr, float* dgamma, float* dbeta, long pixels, int C, dpmn_stream_t stream);
 int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, const float* fc1_b, const float* fc2_w,
                          const float* fc2_b, float* dx, float* dfc1_w, float* dfc1_b, float* dfc2_w, float* dfc2_b,
-                         float* ws /* B*(2C+2Cmid) floats */, int B, int P, int C, int Cmid, dpmn_stream_t stream);
+                         float* ws /* B*(5C+2Cmid) + 2*C*Cmid floats */, int B, int P, int C, int Cmid, dpmn_stream_t stream);
 
 /* DistillModule pieces (distill_module.py:18-31): y = act(scale*r+shift); L1 loss forward / backward */
 int dpmn_affine_act_fwd_f32(const float* r, const float* scale, const float* shift, int act, float* y, long pixels, int C,
