@@ -127,10 +127,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU.  (Test hook: DPMN_DIST_BACKEND=gloo lets several ranks share one GPU to exercise the N > 1 code
+    # path on a single-GPU box -- RCCL itself refuses two ranks on one device.)
+    backend = os.environ.get("DPMN_DIST_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     from dpmn_amd import workload
     sr, models, psn, inp = workload.build(args.workload, batch=args.batch)
     B = inp["images_lr"].shape[0]
@@ -193,7 +200,7 @@ def main():
                                ("dp%d (per-model flat gradient buckets, RCCL all-reduce overlapped with backward)" % world)},
         }
         line["roofline"] = roofline_pw(B)
-        line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline(args.workload, args.cpu_sample)
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.workload, args.cpu_sample)   # N=1 only
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
