@@ -116,10 +116,13 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, i
 // Persistent blocks: the (BN=96 x K) weight tile is loaded into LDS ONCE per block; the block then walks over
 // BM=32-token tiles.  Tile i+1 is fetched into registers while tile i runs on the MFMA pipe; the prologue
 // transform (LayerNorm two-pass in registers across the 8 threads of a row / SK select / add) is applied on
-// the way from registers to the other LDS buffer.  One barrier per tile.  2 blocks per CU (64 KB LDS at K=96)
+// the way from registers to the LDS tile.  Two barriers per tile, 3 blocks per CU (51 KB LDS at K=96)
 // so one block's VALU prologue/epilogue overlaps the other's MFMAs.
 // Block: 256 threads; waves 2(m: 16 tokens) x 2(n: 48 features): acc[3 n-tiles][1 m-tile].
 constexpr int WS_BM = 32, WS_BN = 96;
+#ifndef WSTAT_NBUF
+#define WSTAT_NBUF 1   // single X buffer + second barrier: 51 KB LDS at K = 96 -> 3 blocks per CU (measured 5-8 % faster than 2 x 64 KB)
+#endif
 
 template <int K, int PRO>
 __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x, int ldx, const float* __restrict__ w,
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ws = smem;                       // [BN][LDK]
   float* Xs = Ws + BN * LDK;              // [2][BM][LDK]
-  float* red = Xs + 2 * BM * LDK;         // [4][BN] colsum scratch
+  float* red = Xs + WSTAT_NBUF * BM * LDK;   // [4][BN] colsum scratch
   float* lng = red + 4 * BN;              // [K] LayerNorm gamma, [K] beta
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
     }
   };
   auto commit = [&](float4 (&raw)[NRAW][VPT], int tile, int buf) {
-    float* dst = Xs + (size_t)buf * BM * LDK + srow * LDK + scol;
+    float* dst = Xs + (size_t)(WSTAT_NBUF == 1 ? 0 : buf) * BM * LDK + srow * LDK + scol;
     float vals[VPT * 4];
     if (PRO == PRO_SKSEL) {
       const int m = tile * BM + srow;
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
     __syncthreads(); /* Xs[buf] committed by everyone; previous MFMA reads of Xs[buf^1] done */               \
     f32x4 acc[3][1];                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 3; ++i) acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};                    \
-    const float* xa = Xs + (size_t)buf * BM * LDK + (wm * 16 + lr) * LDK + kq * 4;                            \
+    const float* xa = Xs + (size_t)(WSTAT_NBUF == 1 ? 0 : buf) * BM * LDK + (wm * 16 + lr) * LDK + kq * 4;     \
     const float* wa = Ws + (wn * 48 + lr) * LDK + kq * 4;                                                    \
     _Pragma("unroll") for (int kc = 0; kc < WSTAT_KLIM; kc += 16) {                                          \
       const f32x4 xf = *reinterpret_cast<const f32x4*>(xa + kc);                                             \
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
     }                                                                                                        \
     /* commit BEFORE the epilogue's stores: vmcnt retires in order, waiting for loads issued after stores   \
        would also wait for those stores */                                                                   \
+    if (WSTAT_NBUF == 1) __syncthreads(); /* single X buffer: everyone is done reading it */                 \
     if (tile + stride < tiles) commit(RAWN, tile + stride, buf ^ 1);                                         \
     if (tile + 3 * stride < tiles) issue(RAWN, tile + 3 * stride);                                           \
     WSTAT_EPI_GUARD epilogue<3, 1>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk); \
@@ -449,14 +453,14 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
 template <int K, int PRO>
 int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
                   const EpiArgs& e, hipStream_t st) {
-  const size_t smem = (size_t)((WS_BN + 2 * WS_BM) * (K + PAD) + 4 * WS_BN + 2 * K) * sizeof(float);
+  const size_t smem = (size_t)((WS_BN + WSTAT_NBUF * WS_BM) * (K + PAD) + 4 * WS_BN + 2 * K) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstat<K, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int tiles = cdiv(M, WS_BM), ny = cdiv(N, WS_BN);
-  int gx = 512 / ny;                      // ~2 resident blocks per CU in total
+  int gx = (WSTAT_NBUF == 1 ? 768 : 512) / ny;   // ~2 (3 with a single X buffer) resident blocks per CU in total
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
   dim3 grid(gx, ny);
