@@ -15,6 +15,7 @@
 // Reference call sites replaced: pgrm.py:188,194 (q/kv Linear after norm1_q/norm1_kv 322-323),
 // pgrm.py:82 (SKConv.proj), 92-95 (select + proj_head + residual), 30-31 (fc1+GELU after norm2 330),
 // 39 (fc2), tatt.py:209 / transformer_v2.py linears.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -124,10 +125,11 @@ constexpr int WS_BM = 32, WS_BN = 96;
 #define WSTAT_NBUF 1   // single X buffer + second barrier: 51 KB LDS at K = 96 -> 3 blocks per CU (measured 5-8 % faster than 2 x 64 KB)
 #endif
 
-template <int K, int PRO>
-__global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                     float* __restrict__ y, int ldy, int M, int N, ProArgs p, EpiArgs e) {
-  constexpr int BM = WS_BM, BN = WS_BN, LDK = K + PAD;
+template <int K, int PRO, int TH>   // TH threads: BM = TH/8 token rows per tile (32 or 64), waves (BM/16)(m) x 2(n)
+__global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                    float* __restrict__ y, int ldy, int M, int N, ProArgs p, EpiArgs e) {
+  constexpr int BM = TH / 8, BN = WS_BN, LDK = K + PAD;
+  constexpr int WMN = BM / 16;
   constexpr int VPT = K / 32;                       // float4 per thread per tile (8 threads per row)
   constexpr int NRAW = (PRO == PRO_SKSEL) ? 4 : (PRO == PRO_ADD ? 2 : 1);
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -141,14 +143,14 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
   const int tiles = (M + BM - 1) / BM;
 
   constexpr int KV = K / 4;
-  for (int i = tid; i < BN * KV; i += 256) {
+  for (int i = tid; i < BN * KV; i += TH) {
     const int r = i / KV, c = (i % KV) * 4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n_blk + r < N) v = *reinterpret_cast<const float4*>(w + (size_t)(n_blk + r) * K + c);
     *reinterpret_cast<float4*>(Ws + r * LDK + c) = v;
   }
   if (PRO == PRO_LN)
-    for (int i = tid; i < K; i += 256) { lng[i] = p.ln_w[i]; lng[K + i] = p.ln_b[i]; }
+    for (int i = tid; i < K; i += TH) { lng[i] = p.ln_w[i]; lng[K + i] = p.ln_b[i]; }
 
   const int srow = tid >> 3, spart = tid & 7;       // staging: row in tile, eighth of the row
   const int scol = spart * (K / 8);
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
       *reinterpret_cast<float4*>(dst + v * 4) = make_float4(vals[v * 4], vals[v * 4 + 1], vals[v * 4 + 2], vals[v * 4 + 3]);
   };
 
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WMN, wn = wave / WMN;
   const int lr = lane & 15, kq = lane >> 4;
   const int stride = gridDim.x;
   int tile = blockIdx.x;
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void k_gemm_wstat(const float* __restrict__ x,
     WSTAT_EPI_GUARD epilogue<3, 1>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk); \
     if (e.colsum) {                                                                                          \
       __syncthreads();                                                                                       \
-      for (int c = tid; c < BN; c += 256) {                                                                  \
+      for (int c = tid; c < BN; c += TH) {                                                                   \
         const int wn_c = c / 48;                                                                             \
         const float s_ = red[(wn_c * 2 + 0) * BN + c] + red[(wn_c * 2 + 1) * BN + c];                        \
         if (n_blk + c < N) e.colsum[(size_t)tile * N + n_blk + c] = s_;                                      \
@@ -450,23 +452,37 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
   }
 }
 
-template <int K, int PRO>
-int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
-                  const EpiArgs& e, hipStream_t st) {
-  const size_t smem = (size_t)((WS_BN + WSTAT_NBUF * WS_BM) * (K + PAD) + 4 * WS_BN + 2 * K) * sizeof(float);
+template <int K, int PRO, int TH>
+int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
+                     const EpiArgs& e, hipStream_t st, int target_blocks) {
+  constexpr int BM = TH / 8;
+  const size_t smem = (size_t)((WS_BN + WSTAT_NBUF * BM) * (K + PAD) + 4 * WS_BN + 2 * K) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstat<K, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstat<K, PRO, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  const int tiles = cdiv(M, WS_BM), ny = cdiv(N, WS_BN);
-  int gx = (WSTAT_NBUF == 1 ? 768 : 512) / ny;   // ~2 (3 with a single X buffer) resident blocks per CU in total
+  const int tiles = cdiv(M, BM), ny = cdiv(N, WS_BN);
+  int gx = target_blocks / ny;
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
   dim3 grid(gx, ny);
-  hipLaunchKernelGGL((k_gemm_wstat<K, PRO>), grid, dim3(256), smem, st, x, ldx, w, y, ldy, M, N, p, e);
+  hipLaunchKernelGGL((k_gemm_wstat<K, PRO, TH>), grid, dim3(TH), smem, st, x, ldx, w, y, ldy, M, N, p, e);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
+}
+
+template <int K, int PRO>
+int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
+                  const EpiArgs& e, hipStream_t st) {
+  // 512-thread blocks (64-token tiles, 8 waves sharing one W tile): 64 KB LDS at K = 96 -> 2 blocks = 16 waves per CU;
+  // 256-thread blocks (32-token tiles): 51 KB -> 3 blocks = 12 waves per CU, and the only variant with the per-32-row
+  // column-sum epilogue (SKConv GAP partials)
+  static const int big = getenv("DPMN_WSTAT_TH") ? atoi(getenv("DPMN_WSTAT_TH")) : 512;
+  if constexpr (K <= 128) {
+    if (big == 512 && !e.colsum && M >= 4096) return launch_wholeK_th<K, PRO, 512>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
+  }
+  return launch_wholeK_th<K, PRO, 256>(x, ldx, w, y, ldy, M, N, p, e, st, WSTAT_NBUF == 1 ? 768 : 512);
 }
 
 template <int PRO>
