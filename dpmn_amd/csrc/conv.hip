@@ -350,10 +350,10 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows
 // window straight from LDS, so activations cross L2->LDS once instead of K*K times (the im2col redundancy that
 // made k_conv_igemm L2-bound); only the (BN x 32) weight slice of each (chunk, tap) is streamed, double-buffered.
 // One output row of the tile = one 16-pixel MFMA column block; waves 4(m: 2 rows each) x 1(n).
-template <int KS, int BN>
+template <int KS, int BN, int TH>    // TH x 16 output pixels per block (TH = 8: 2 rows per wave, TH = 4: 1 row per wave)
 __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
-  constexpr int TH = 8, TW = 16, HH = TH + KS - 1, HW_ = TW + KS - 1, NPX = HH * HW_;
-  constexpr int NT = BN / 16, T = KS * KS;
+  constexpr int TW = 16, HH = TH + KS - 1, HW_ = TW + KS - 1, NPX = HH * HW_;
+  constexpr int NT = BN / 16, T = KS * KS, MR = TH / 4;
   constexpr bool PREFETCH = false;   // halo staged directly into ONE LDS buffer: 3 blocks per CU hide the staging latency
                                      // (measured: tatt 3x3 60.6 -> 55.3 us, en2b 118 -> 84 us vs the register-prefetch variant;
                                      //  weights straight from L1/L2 to registers instead of LDS measured 76 / 146 us: rejected)
@@ -438,9 +438,11 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   };
 
   const int lr = lane & 15, kq = lane >> 4;
-  f32x4 acc[NT][2];
+  f32x4 acc[NT][MR];
 #pragma unroll
-  for (int i = 0; i < NT; ++i) { acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  for (int i = 0; i < NT; ++i)
+#pragma unroll
+    for (int j = 0; j < MR; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   if (PREFETCH) { issue_halo(0); commit_halo(0); }
   issue_w(0, 0);
@@ -461,22 +463,22 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
       if (!lastt) issue_w(chunk, tap + 1);
       else if (more) issue_w(chunk + 1, 0);
       const int ky = tap / KS, kx = tap % KS;
-      const float* hp = halo + (size_t)hb * NPX * LDK + ((2 * wave + ky) * HW_ + lr + kx) * LDK + kq * 4;
+      const float* hp = halo + (size_t)hb * NPX * LDK + ((MR * wave + ky) * HW_ + lr + kx) * LDK + kq * 4;
       const float* wp = Wt + (size_t)wb * BN * LDK + lr * LDK + kq * 4;
 #pragma unroll
       for (int kc = 0; kc < BK; kc += 16) {
-        const f32x4 x0 = *reinterpret_cast<const f32x4*>(hp + kc);
-        const f32x4 x1 = *reinterpret_cast<const f32x4*>(hp + HW_ * LDK + kc);
+        f32x4 xf[MR];
+#pragma unroll
+        for (int j = 0; j < MR; ++j) xf[j] = *reinterpret_cast<const f32x4*>(hp + j * HW_ * LDK + kc);
         f32x4 wf[NT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wp + i * 16 * LDK + kc);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-          for (int i = 0; i < NT; ++i) {
-            acc[i][0] = mfma16(wf[i][s4], x0[s4], acc[i][0]);
-            acc[i][1] = mfma16(wf[i][s4], x1[s4], acc[i][1]);
-          }
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MR; ++j) acc[i][j] = mfma16(wf[i][s4], xf[j][s4], acc[i][j]);
       }
       if (!lastt || more) commit_w(wb ^ 1);
       if (PREFETCH && lastt && more) commit_halo(hb ^ 1);
@@ -491,8 +493,8 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int oy = ty0 + 2 * wave + j, ox = tx0 + lr;
+  for (int j = 0; j < MR; ++j) {
+    const int oy = ty0 + MR * wave + j, ox = tx0 + lr;
     const int m = (b * a.Hin + oy) * a.Win + ox;
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -520,19 +522,30 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   }
 }
 
-template <int KS, int BN>
-int launch_halo(const ConvArgs& a, hipStream_t st) {
-  constexpr int NPX = (8 + KS - 1) * (16 + KS - 1);
+template <int KS, int BN, int TH>
+int launch_halo_th(const ConvArgs& a, hipStream_t st) {
+  constexpr int NPX = (TH + KS - 1) * (16 + KS - 1);
   const size_t smem = (size_t)(NPX + 2 * BN) * LDK * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<KS, BN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<KS, BN, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  dim3 grid(a.B * (a.Hin / 8) * (a.Win / 16), cdiv(a.Cout, BN));
-  hipLaunchKernelGGL((k_conv_halo<KS, BN>), grid, dim3(256), smem, st, a);
+  dim3 grid(a.B * (a.Hin / TH) * (a.Win / 16), cdiv(a.Cout, BN));
+  hipLaunchKernelGGL((k_conv_halo<KS, BN, TH>), grid, dim3(256), smem, st, a);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
+}
+
+template <int KS, int BN>
+int launch_halo(const ConvArgs& a, hipStream_t st) {
+  // 8x16-pixel tiles amortise the weight staging best, but a map with fewer than ~3 tiles per CU leaves the CUs unevenly
+  // loaded (384 tiles on 256 CUs = 1 or 2 per CU): halve the tile there
+  static const int force = getenv("DPMN_HALO_TH") ? atoi(getenv("DPMN_HALO_TH")) : 0;
+  const long blocks8 = (long)a.B * (a.Hin / 8) * (a.Win / 16) * cdiv(a.Cout, BN);
+  const bool small = force ? force == 4 : blocks8 < 768;
+  if (KS == 3 && small) return launch_halo_th<KS, BN, 4>(a, st);
+  return launch_halo_th<KS, BN, 8>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN>
