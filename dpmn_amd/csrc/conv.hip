@@ -522,6 +522,164 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------- halo conv for Cout <= 4
+// A 16x16x4 MFMA with 4 output channels wastes 12 of its 16 feature rows.  Here the feature axis carries
+// n = 4*co + dx (4 channels x 4 horizontal sub-taps): with kx = 4q + dx,
+//     out[co][y][x] = sum_dx U_dx[co][y][x + dx],    U_dx[co][y][x'] = sum_{ky,q,c} W[co][ky][4q+dx][c] * X[y+ky-p][x'+4q-p][c],
+// and all four U_dx read the SAME input pixel, so they share one B operand: a KS x KS conv costs KS*ceil(KS/4) MFMA taps per
+// 16 pixels instead of KS*KS (27 vs 81 at 9x9, 3 vs 9 at 3x3).  The dx-shifted sum is 3 intra-row lane shuffles at the end;
+// a 16-column tile therefore yields 13 finished output columns (tiles advance by 13).  Weights are read from the ordinary
+// packed (Cout, Kp) layout with a different address map -- no extra pack.  Staging: halo tile per 32-channel chunk, weights
+// per group of 3 taps (one ky row at 9x9, everything at 3x3), double-buffered.
+template <int KS, int TH>
+__global__ __launch_bounds__(256) void k_conv_halo_c4(ConvArgs a) {
+  constexpr int TW = 16, VW = 13, HH = TH + KS - 1, HW_ = TW + KS - 1, NPX = HH * HW_;
+  constexpr int Q = (KS + 3) / 4, MR = TH / 4, NG = (KS * Q) / 3;     // tap groups of 3 per chunk
+  static_assert((KS * Q) % 3 == 0, "taps must come in groups of 3");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* halo = smem;                       // [NPX][LDK]
+  float* Wt = smem + NPX * LDK;             // [2][3 taps][16][LDK]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (a.Win + VW - 1) / VW, tiles_y = a.Hin / TH;
+  const int b = blockIdx.x / (tiles_x * tiles_y), trem = blockIdx.x % (tiles_x * tiles_y);
+  const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * VW;
+  const int padk = (KS - 1) / 2;
+  const int c01 = a.cseg[0] + a.cseg[1];
+  const int nchunks = a.cin / BK;
+
+  auto stage_halo = [&](int chunk) {
+    const int c0 = chunk * BK;
+    int seg = 0, cl0 = c0;
+    if (c0 >= c01) { seg = 2; cl0 = c0 - c01; }
+    else if (c0 >= a.cseg[0]) { seg = 1; cl0 = c0 - a.cseg[0]; }
+    const float* src = a.in[seg];
+    const int cs = a.cseg[seg];
+    const float* sc = a.in_scale[seg];
+    const float* sh = a.in_shift[seg];
+    for (int i = tid; i < NPX * 8; i += 256) {
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int px = i >> 3, c4 = (i & 7) * 4;
+      const int iy = ty0 + px / HW_ - padk, ix = tx0 + px % HW_ - padk;
+      if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
+        val = *reinterpret_cast<const float4*>(src + (((size_t)b * a.Hin + iy) * a.Win + ix) * cs + cl0 + c4);
+        if (sc) {
+          const float4 s4 = *reinterpret_cast<const float4*>(sc + cl0 + c4);
+          const float4 h4 = *reinterpret_cast<const float4*>(sh + cl0 + c4);
+          val.x = val.x * s4.x + h4.x; val.y = val.y * s4.y + h4.y; val.z = val.z * s4.z + h4.z; val.w = val.w * s4.w + h4.w;
+        }
+        if (a.pro_act != ACT_NONE) {
+          val.x = apply_act(val.x, a.pro_act, 0.f); val.y = apply_act(val.y, a.pro_act, 0.f);
+          val.z = apply_act(val.z, a.pro_act, 0.f); val.w = apply_act(val.w, a.pro_act, 0.f);
+        }
+      }
+      *reinterpret_cast<float4*>(halo + px * LDK + c4) = val;
+    }
+  };
+  // group g of chunk: taps t = 3g .. 3g+2 ; tap -> (ky, q) = (t / Q, t % Q) ; LDS row n = 4*co + dx
+  float4 wraw[2];
+  auto issue_w = [&](int chunk, int g) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int i = tid + v * 256;                 // 3 taps x 16 rows x 8 float4 = 384
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (i < 384) {
+        const int tl = i >> 7, n = (i >> 3) & 15, c4 = (i & 7) * 4;
+        const int tp = 3 * g + tl, ky = tp / Q, q = tp - ky * Q;
+        const int co = n >> 2, kx = 4 * q + (n & 3);
+        if (co < a.Cout && kx < KS)
+          val = *reinterpret_cast<const float4*>(a.w + (size_t)co * a.Kp + (size_t)(ky * KS + kx) * a.cin + chunk * BK + c4);
+      }
+      wraw[v] = val;
+    }
+  };
+  auto commit_w = [&](int buf) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int i = tid + v * 256;
+      if (i < 384) *reinterpret_cast<float4*>(Wt + (size_t)buf * 48 * LDK + (i >> 3) * LDK + (i & 7) * 4) = wraw[v];
+    }
+  };
+
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[MR];
+#pragma unroll
+  for (int j = 0; j < MR; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  issue_w(0, 0);
+  commit_w(0);
+  int wb = 0;
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();                 // previous chunk's halo fully consumed
+    stage_halo(chunk);
+    __syncthreads();
+    for (int g = 0; g < NG; ++g) {
+      const bool lastg = g == NG - 1, more = chunk + 1 < nchunks;
+      if (!lastg) issue_w(chunk, g + 1);
+      else if (more) issue_w(chunk + 1, 0);
+#pragma unroll
+      for (int tl = 0; tl < 3; ++tl) {
+        const int tp = 3 * g + tl, ky = tp / Q, q = tp - ky * Q;
+        const float* hp = halo + ((MR * wave + ky) * HW_ + lr + 4 * q) * LDK + kq * 4;
+        const float* wp = Wt + (size_t)wb * 48 * LDK + (tl * 16 + lr) * LDK + kq * 4;
+#pragma unroll
+        for (int kc = 0; kc < BK; kc += 16) {
+          const f32x4 wf = *reinterpret_cast<const f32x4*>(wp + kc);
+          f32x4 xf[MR];
+#pragma unroll
+          for (int j = 0; j < MR; ++j) xf[j] = *reinterpret_cast<const f32x4*>(hp + j * HW_ * LDK + kc);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int j = 0; j < MR; ++j) acc[j] = mfma16(wf[s4], xf[j][s4], acc[j]);
+        }
+      }
+      if (!lastg || more) commit_w(wb ^ 1);
+      __syncthreads();
+      wb ^= 1;
+    }
+  }
+  // lane (lr, kq = co): acc[j][r] = U_r[co][row j][x' = tx0 + lr].  out[x] = sum_r U_r[x + r]: shift within the 16-lane row.
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < MR; ++j) {
+    float o = acc[j][0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) o += __shfl(acc[j][r], (lane & 48) | ((lr + r) & 15), 64);
+    // gather the 4 channels of pixel lr into the kq = 0 lane, then the common epilogue (bias / act / stats / layout)
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = __shfl(o, lr + 16 * c, 64);
+    const int oy = ty0 + MR * wave + j, ox = tx0 + lr;
+    if (kq == 0 && lr < VW && ox < a.Win) conv_store(a, (b * a.Hin + oy) * a.Win + ox, 0, v, ssum, ssq, a.ooy, a.oox);
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float s_ = ssum[r], q_ = ssq[r];     // only kq == 0 lanes hold non-zero partials
+      s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64); s_ += __shfl_xor(s_, 8, 64);
+      q_ += __shfl_xor(q_, 1, 64); q_ += __shfl_xor(q_, 2, 64); q_ += __shfl_xor(q_, 4, 64); q_ += __shfl_xor(q_, 8, 64);
+      if (lane == 0 && r < a.Cout) {
+        float* st = a.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
+        atomicAdd(st + r, s_); atomicAdd(st + a.Cout + r, q_);
+      }
+    }
+  }
+}
+
+template <int KS, int TH>
+int launch_halo_c4(const ConvArgs& a, hipStream_t st) {
+  constexpr int NPX = (TH + KS - 1) * (16 + KS - 1);
+  const size_t smem = (size_t)(NPX + 2 * 48) * LDK * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo_c4<KS, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  dim3 grid(a.B * (a.Hin / TH) * cdiv(a.Win, 13));
+  hipLaunchKernelGGL((k_conv_halo_c4<KS, TH>), grid, dim3(256), smem, st, a);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
 template <int KS, int BN, int TH>
 int launch_halo_th(const ConvArgs& a, hipStream_t st) {
   constexpr int NPX = (TH + KS - 1) * (16 + KS - 1);
@@ -641,6 +799,9 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
                        a.cseg[2] % 32 == 0 && M >= 1024;
   // too few 8x16-pixel tiles to fill 256 CUs (deep decoder levels with 3-segment inputs): split-K implicit GEMM instead
   const bool halo_starved = (M / 128) * cdiv(a.Cout, 64) < 256 && a.Cout >= 128 && ws != nullptr;
+  static const bool c4_on = !(getenv("DPMN_CONV_C4") && atoi(getenv("DPMN_CONV_C4")) == 0);
+  if (halo_ok && a.Cout <= 4 && c4_on && !a.pixel_shuffle && !a.res)
+    return a.KH == 3 ? launch_halo_c4<3, 8>(a, st) : launch_halo_c4<9, 8>(a, st);   // (3x3: 4- and 16-row tiles measured no better)
   if (halo_ok && !halo_starved) {
     if (a.KH == 3) return a.Cout <= 16 ? launch_halo<3, 16>(a, st) : launch_halo<3, 64>(a, st);
     return a.Cout <= 16 ? launch_halo<9, 16>(a, st) : launch_halo<9, 64>(a, st);
