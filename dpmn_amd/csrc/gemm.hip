@@ -371,10 +371,12 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
 // z[b][co][s] = sum_c w[co][c] * g[b][c][s] + bias[co]      (pointwise 1x1 conv, pgrm.py:37)
 // g, z are the raw (B, Ch, L) views of token buffers (quirk Q2).  Output is s-contiguous, so the
 // MFMA "A" operand carries s (from the [k][s] tile via ds_read_b32) and "B" carries co.
-// Block 256 threads, tile 128 (s) x 128 (co), BK = 16; waves 2(s) x 2(co): 64 x 64 each.
+// Block 256 threads, tile 128 (s) x BC (co), BK = 16; waves 2(s) x 2(co): 64 x BC/2 each.  BC = 192 when Ch is a multiple
+// of 192 (Ch = 384: 8 x 2 x 48 = 768 tiles = exactly 3 per CU at 3 resident blocks, and 96 MFMAs per barrier), else 128.
+template <int BC>
 __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, const float* __restrict__ w,
                                                   const float* __restrict__ bias, float* __restrict__ z, int Ch, int L) {
-  constexpr int BS = 128, BC = 128, BK = 16, LDS_G = BS + 4, LDS_W = BK + PAD;
+  constexpr int BS = 128, BK = 16, LDS_G = BS + 4, LDS_W = BK + PAD, NJ = BC / 32, WP = BC / 64;
   __shared__ __attribute__((aligned(16))) float Gs[2][BK * LDS_G];
   __shared__ __attribute__((aligned(16))) float Wsm[2][BC * LDS_W];
 
@@ -383,16 +385,17 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
   const float* gb = g + (size_t)b * Ch * L;
   float* zb = z + (size_t)b * Ch * L;
 
-  // loaders: G chunk = 16 rows(k) x 128 s = 512 float4 -> 2 per thread ; W chunk = 128 rows x 16 k = 512 float4
+  // loaders: G chunk = 16 rows(k) x 128 s = 512 float4 -> 2 per thread ; W chunk = BC rows x 16 k = 4*BC float4 -> WP per thread
   const int grow = tid >> 5, gcol = (tid & 31) * 4;   // rows 0..7 (+8)
   const int wrow = tid >> 2, wcol = (tid & 3) * 4;    // rows 0..63 (+64)
-  float4 g0, g1, w0, w1;
+  float4 g0, g1, w0, w1, w2;      // named registers (an indexed array here ends up in scratch); w2 only for BC = 192
 #define PW_GLOAD(k0)                                                                                   \
   do {                                                                                                 \
     g0 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + grow) * L + s_blk + gcol);              \
     g1 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + grow + 8) * L + s_blk + gcol);          \
     w0 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow) * Ch + (k0) + wcol);              \
     w1 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 64) * Ch + (k0) + wcol);         \
+    if (WP == 3) w2 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 128) * Ch + (k0) + wcol); \
   } while (0)
 #define PW_SSTORE(buf)                                                                                 \
   do {                                                                                                 \
@@ -400,15 +403,16 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
     *reinterpret_cast<float4*>(&Gs[buf][(grow + 8) * LDS_G + gcol]) = g1;                              \
     *reinterpret_cast<float4*>(&Wsm[buf][wrow * LDS_W + wcol]) = w0;                                   \
     *reinterpret_cast<float4*>(&Wsm[buf][(wrow + 64) * LDS_W + wcol]) = w1;                            \
+    if (WP == 3) *reinterpret_cast<float4*>(&Wsm[buf][(wrow + 128) * LDS_W + wcol]) = w2;              \
   } while (0)
 
   const int ws_ = wave & 1, wc_ = wave >> 1;
   const int lr = lane & 15, kq = lane >> 4;
-  f32x4 acc[4][4];   // [s tile][co tile]
+  f32x4 acc[4][NJ];   // [s tile][co tile]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   PW_GLOAD(0);
   PW_SSTORE(0);
@@ -417,15 +421,15 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) PW_GLOAD((kt + 1) * BK);
-    f32x4 wf[4];
+    f32x4 wf[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wf[j] = *reinterpret_cast<const f32x4*>(&Wsm[buf][(wc_ * 64 + j * 16 + lr) * LDS_W + kq * 4]);
+    for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const f32x4*>(&Wsm[buf][(wc_ * (BC / 2) + j * 16 + lr) * LDS_W + kq * 4]);
     const float* gp = &Gs[buf][(kq * 4) * LDS_G + ws_ * 64 + lr];
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       float a0 = gp[st * LDS_G], a1 = gp[st * LDS_G + 16], a2 = gp[st * LDS_G + 32], a3 = gp[st * LDS_G + 48];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const float bv = wf[j][st];
         acc[0][j] = mfma16(a0, bv, acc[0][j]);
         acc[1][j] = mfma16(a1, bv, acc[1][j]);
@@ -440,8 +444,8 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
 #undef PW_SSTORE
   // lane holds z[co = c0 + j*16 + (l&15)][s = s0 + i*16 + (l>>4)*4 + r]
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int co = c_blk + wc_ * 64 + j * 16 + lr;
+  for (int j = 0; j < NJ; ++j) {
+    const int co = c_blk + wc_ * (BC / 2) + j * 16 + lr;
     const float bv = bias[co];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -577,8 +581,11 @@ int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, 
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream) {
   DPMN_REQUIRE(g && w && bias && z && Ch % 128 == 0 && L % 128 == 0, "pointwise: Ch and L must be multiples of 128");
-  dim3 grid(L / 128, Ch / 128, B);
-  hipLaunchKernelGGL(k_gemm_pw, grid, dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
+  static const int pw_bc = getenv("DPMN_PW_BC") ? atoi(getenv("DPMN_PW_BC")) : 192;
+  if (Ch % 192 == 0 && pw_bc == 192)
+    hipLaunchKernelGGL((k_gemm_pw<192>), dim3(L / 128, Ch / 192, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
+  else
+    hipLaunchKernelGGL((k_gemm_pw<128>), dim3(L / 128, Ch / 128, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
