@@ -25,6 +25,8 @@ struct WgArgs {
   int co_lim, ci_lim;
   int pix_per_block;
   int gx, gy, gz;       // logical grid (co tiles, k tiles, pixel splits)
+  int nslots;           // > 1: split z accumulates into copy (z % nslots) of dw, copies slot_stride floats apart
+  long slot_stride;
   float inv_hw, inv_w;
 };
 
@@ -196,7 +198,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
     const int tp = k / a.cin, ci = k - tp * a.cin;
     if (ci >= a.ci_lim) continue;
     const int ty = tp / a.KW, tx = tp - ty * a.KW;
-    float* dst = a.dw + a.base + (long)ci * a.s_ci + (long)ty * a.s_ky + (long)tx * a.s_kx;
+    float* dst = a.dw + (a.nslots > 1 ? (long)(bz % a.nslots) * a.slot_stride : 0L) + a.base + (long)ci * a.s_ci + (long)ty * a.s_ky +
+                 (long)tx * a.s_kx;
 #pragma unroll
     for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -214,12 +217,16 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
 
 // packed (Cout, Kp) gradient -> += into the parameter's layout, and clear the packed workspace for its next use
 __global__ void k_wgrad_unpack(float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Kp, int K, int cin, int KW, int co_lim,
-                               int ci_lim, long s_co, long s_ci, long s_ky, long s_kx, long base, int clear) {
+                               int ci_lim, long s_co, long s_ci, long s_ky, long s_kx, long base, int clear, int nslots) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)Cout * Kp) return;
+  const long n = (long)Cout * Kp;
+  if (idx >= n) return;
   const int co = (int)(idx / Kp), k = (int)(idx - (long)co * Kp);
-  const float v = dwp[idx];
-  if (clear) dwp[idx] = 0.f;
+  float v = 0.f;
+  for (int s = 0; s < nslots; ++s) {
+    v += dwp[s * n + idx];
+    if (clear) dwp[s * n + idx] = 0.f;
+  }
   if (k >= K || co >= co_lim) return;
   const int tp = k / cin, ci = k - tp * cin;
   if (ci >= ci_lim) return;
@@ -464,7 +471,7 @@ __global__ void k_adam_clip(float* __restrict__ p, const float* __restrict__ g, 
 extern "C" {
 
 static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co, long s_ci,
-                        long s_ky, long s_kx, long base, dpmn_stream_t stream) {
+                        long s_ky, long s_kx, long base, int nslots, long slot_stride, dpmn_stream_t stream) {
   DPMN_REQUIRE(d && d->in[0] && dy && dw, "conv2d_wgrad: null pointer");
   WgArgs a{};
   int cin = 0;
@@ -479,6 +486,7 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
   a.dy = dy; a.Cout = d->Cout; a.dw = dw;
   a.K = d->KH * d->KW * cin;
   a.s_co = s_co; a.s_ci = s_ci; a.s_ky = s_ky; a.s_kx = s_kx; a.base = base;
+  a.nslots = nslots > 1 ? nslots : 1; a.slot_stride = slot_stride;
   a.co_lim = co_lim < a.Cout ? co_lim : a.Cout; a.ci_lim = ci_lim < cin ? ci_lim : cin;
   const long Ml = (long)a.B * a.Hp * a.Wp;
   DPMN_REQUIRE(Ml > 0 && Ml < (1L << 24), "conv2d_wgrad: pixel count must be below 2^24");
@@ -489,10 +497,15 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
   if (bn == 64 && cdiv(a.K, 128) * 128 < cdiv(a.K, 256) * 256) bk = 128;   // less padding in the last k tile
   a.gx = cdiv(a.Cout, bn); a.gy = cdiv(a.K, bk);
   const int tiles = a.gx * a.gy;
-  // every block ends with one atomic per tile element: keep >= 512 pixels of MFMA work behind each of them
+  // every block ends with one atomic per VALID tile element: keep >= 1 pixel of MFMA work per 32 of them (512 pixels for a
+  // full 128x128 tile, down to 64 for the 4 x 72 tiles of the DistillModule convs, which are latency-bound and want blocks)
+  const int tile_elems = (a.Cout < bn ? a.Cout : bn) * (a.K < bk ? a.K : bk);
+  int min_ppb = tile_elems / 32 / a.nslots;      // slotted destinations divide the same-address pile-up
+  min_ppb = min_ppb < 64 ? 64 : (min_ppb > 512 ? 512 : min_ppb);
+  if (a.nslots == 1 && min_ppb < 512) min_ppb = 512;
   int splits = cdiv(2048, tiles);
   int ppb = cdiv(cdiv(M, splits), 32) * 32;
-  if (ppb < 512) ppb = 512;
+  if (ppb < min_ppb) ppb = min_ppb;
   splits = cdiv(M, ppb);
   a.pix_per_block = ppb; a.gz = splits;
   const dim3 grid((unsigned)(tiles * splits));
@@ -504,12 +517,12 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
   return DPMN_OK;
 }
 
-int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, dpmn_stream_t stream) {
+int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, int nslots, dpmn_stream_t stream) {
   DPMN_REQUIRE(d, "conv2d_wgrad: null descriptor");
   int cin = 0;
   for (int s = 0; s < 3; ++s) cin += d->in[s] ? d->cseg[s] : 0;
   const long Kp = ((long)(d->KH * d->KW * cin + 31) / 32) * 32;
-  return launch_wgrad(d, dy, dwp, d->Cout, cin, Kp, 1, (long)d->KW * cin, cin, 0, stream);
+  return launch_wgrad(d, dy, dwp, d->Cout, cin, Kp, 1, (long)d->KW * cin, cin, 0, nslots, (long)d->Cout * Kp, stream);
 }
 
 int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co, long s_ci,
@@ -524,19 +537,20 @@ int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int
 }
 
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
-                                 long s_ci, long s_ky, long s_kx, long base, int clear, dpmn_stream_t stream) {
+                                 long s_ci, long s_ky, long s_kx, long base, int clear, int nslots, dpmn_stream_t stream) {
   DPMN_REQUIRE(dwp && dw && Cout > 0 && cin > 0 && KH > 0 && KW > 0, "conv2d_wgrad_unpack: bad arguments");
   const int K = KH * KW * cin, Kp = (K + 31) / 32 * 32;
   const long total = (long)Cout * Kp;
   hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), dwp, dw, Cout, Kp, K, cin,
-                     KW, co_lim < Cout ? co_lim : Cout, ci_lim < cin ? ci_lim : cin, s_co, s_ci, s_ky, s_kx, base, clear);
+                     KW, co_lim < Cout ? co_lim : Cout, ci_lim < cin ? ci_lim : cin, s_co, s_ci, s_ky, s_kx, base, clear,
+                     nslots > 1 ? nslots : 1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
 
 int dpmn_conv2d_wgrad_strided_f32(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co,
                                   long s_ci, long s_ky, long s_kx, long base, dpmn_stream_t stream) {
-  return launch_wgrad(d, dy, dw, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base, stream);
+  return launch_wgrad(d, dy, dw, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base, 1, 0, stream);
 }
 
 int dpmn_bn_finalize_f32(const float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,

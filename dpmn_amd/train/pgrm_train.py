@@ -100,12 +100,13 @@ def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
     # (scattering the atomics straight into the parameter layout, dpmn_conv2d_wgrad_strided_f32, measured 3x slower)
     cin_d = sum(d.cseg[i] for i in range(3) if d.inp[i])
     kp = (d.KH * d.KW * cin_d + 31) // 32 * 32
-    key = (dy.device, d.Cout, kp)
+    nslots = 32 if d.Cout * kp <= 12288 else 1     # small gradients: spread the pixel splits' atomics over 32 copies
+    key = (dy.device, d.Cout, kp, nslots)
     ws = _WGRAD_WS.get(key)
     if ws is None:
-        ws = _WGRAD_WS[key] = torch.zeros(d.Cout, kp, device=dy.device)
-    check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dy), dptr(ws), stream()))
-    check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 1, stream()))
+        ws = _WGRAD_WS[key] = torch.zeros(nslots, d.Cout, kp, device=dy.device)
+    check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dy), dptr(ws), nslots, stream()))
+    check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 1, nslots, stream()))
 
 
 _WGRAD_WS = {}

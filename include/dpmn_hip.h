@@ -252,7 +252,10 @@ int dpmn_patch_scatter_f32(const float* din, float* dimg, int cimg, int B, int H
 int dpmn_prior_fusion_wgrad_f32(const float* din, const float* prior, float* dpf_w, float* dpf_b, int B, int Hi, int Wi,
                                 dpmn_stream_t stream);
 /* conv weight gradient in the packed (Cout, Kp) layout, train-mode BatchNorm plumbing, CMM gate backward (conv_bwd.hip) */
-int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, dpmn_stream_t stream);
+int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp,
+                          int nslots /* > 1: dwp holds nslots copies (Cout*Kp apart); pixel splits spread over them so that
+                                      * small tiles (DistillModule: 4 x 72) do not pile thousands of atomics on one address */,
+                          dpmn_stream_t stream);
 /* same, accumulated straight into the parameter's own layout (nn.Conv2d (Cout,Cin,KH,KW), nn.ConvTranspose2d
  * (Cin,Cout,KH,KW) flipped, or one phase of ConvTranspose2d(4,2,1)):
  *   dw[base + co*s_co + ci*s_ci + ky*s_ky + kx*s_kx] += ...   for co < co_lim, ci < ci_lim (padding channels dropped) */
@@ -264,7 +267,8 @@ int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int
 /* packed (Cout,Kp) gradient -> += into the parameter layout (same stride convention as below); clear != 0 zeroes the
  * packed buffer afterwards so that a persistent workspace needs no memset before its next dpmn_conv2d_wgrad_f32 */
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
-                                 long s_ci, long s_ky, long s_kx, long base, int clear, dpmn_stream_t stream);
+                                 long s_ci, long s_ky, long s_kx, long base, int clear, int nslots /* copies to sum */,
+                                 dpmn_stream_t stream);
 int dpmn_conv2d_wgrad_strided_f32(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co,
                                   long s_ci, long s_ky, long s_kx, long base, dpmn_stream_t stream);
 int dpmn_bn_finalize_f32(const float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,

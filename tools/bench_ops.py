@@ -97,7 +97,7 @@ def wgrad_case(name, cin, cout, k, H, W):
     dwp = torch.zeros(cout, kp, device=dev); dw = torch.zeros(cout, cin, k, k, device=dev)
     fl = 2.0 * B * H * W * cout * cin * k * k
     by = 4.0 * B * H * W * (cin + cout)
-    timeit("wgrad packed " + name, lambda: check(lib.dpmn_conv2d_wgrad_f32(C_.byref(d), dptr(dy), dptr(dwp), stream())), fl, by)
+    timeit("wgrad packed " + name, lambda: check(lib.dpmn_conv2d_wgrad_f32(C_.byref(d), dptr(dy), dptr(dwp), 1, stream())), fl, by)
     timeit("wgrad param  " + name, lambda: conv_wgrad_into(d, dy, dw), fl, by)
 
 
