@@ -36,16 +36,26 @@ __global__ __launch_bounds__(256) void k_bigru(const float* __restrict__ gi, con
   const float br = b_hh[dir * 3 * HID + j], bz = b_hh[dir * 3 * HID + HID + j], bn = b_hh[dir * 3 * HID + 2 * HID + j];
   const long base = active ? (s / inner) * outer_stride + (s % inner) * inner_stride : 0;
   float h = 0.f;
-  for (int t = 0; t < T; ++t) {
-    const int tt = dir ? T - 1 - t : t;
-    const long pix = base + (long)tt * step_stride;
-    float gr = 0.f, gz = 0.f, gn = 0.f;
-    if (active) {
-      const float* g = gi + pix * (6 * HID) + dir * 3 * HID + j;
-      gr = g[0]; gz = g[HID]; gn = g[2 * HID];
-    }
+  // the recurrence is a pure latency chain (one wave per sequence, at most one wave per SIMD at these sizes): the hidden
+  // state goes through a wave-private LDS row (in-order within a wave: no block barrier), and the next step's gate
+  // pre-activations are fetched while the current step computes
+  // ping-pong gate registers (A / B), loop unrolled by two: a "cur = next" copy at the end of a step would make the
+  // compiler wait for the prefetch it just issued
+  float gA[4] = {0.f, 0.f, 0.f, 0.f}, gB[4] = {0.f, 0.f, 0.f, 0.f};     // r, z, n pre-activations + residual
+  // branch-free (a conditional load makes the compiler drain every outstanding load at the join): steps past the end and
+  // idle waves re-read a valid element, the residual pointer falls back to gi when there is no residual
+  const float* rp = res ? res : gi;
+  const float rmul = res ? 1.f : 0.f;
+  auto fetch = [&](float (&g4)[4], int t) {
+    const int tc = t < T ? t : T - 1;
+    const long pn = base + (long)(dir ? T - 1 - tc : tc) * step_stride;
+    const float* g = gi + pn * (6 * HID) + dir * 3 * HID + j;
+    g4[0] = g[0]; g4[1] = g[HID]; g4[2] = g[2 * HID];
+    g4[3] = rp[pn * (2 * HID) + dir * HID + j] * rmul;   // the residual too: a load feeding this step's store would stall it
+  };
+  auto step = [&](const float (&g4)[4], int t) {
     hs[wave][lane] = h;
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     float ar0 = br, az0 = bz, an0 = bn, ar1 = 0.f, az1 = 0.f, an1 = 0.f;
     const float* hp = &hs[wave][dir * HID];
 #pragma unroll
@@ -59,15 +69,23 @@ __global__ __launch_bounds__(256) void k_bigru(const float* __restrict__ gi, con
       az1 += wz[k + 4] * h1.x + wz[k + 5] * h1.y + wz[k + 6] * h1.z + wz[k + 7] * h1.w;
       an1 += wn[k + 4] * h1.x + wn[k + 5] * h1.y + wn[k + 6] * h1.z + wn[k + 7] * h1.w;
     }
-    __syncthreads();
-    const float r = sigmoid_f(gr + ar0 + ar1);
-    const float z = sigmoid_f(gz + az0 + az1);
-    const float n = tanhf(gn + r * (an0 + an1));
+    __builtin_amdgcn_wave_barrier();
+    const float r = sigmoid_f(g4[0] + ar0 + ar1);
+    const float z = sigmoid_f(g4[1] + az0 + az1);
+    const float n = tanhf(g4[2] + r * (an0 + an1));
     h = (1.f - z) * n + z * h;
     if (active) {
-      const long o = pix * (2 * HID) + dir * HID + j;
-      out[o] = h + (res ? res[o] : 0.f);
+      const long pix = base + (long)(dir ? T - 1 - t : t) * step_stride;
+      out[pix * (2 * HID) + dir * HID + j] = h + g4[3];
     }
+  };
+  fetch(gA, 0);
+  for (int t = 0; t < T; t += 2) {
+    fetch(gB, t + 1);
+    step(gA, t);
+    if (t + 1 >= T) break;
+    fetch(gA, t + 2);
+    step(gB, t + 1);
   }
 }
 
