@@ -86,43 +86,44 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
   const int yn = n_blk + yc;
   float4 yr[YP], xr[XP];
   unsigned xmask = 0;      // bit p: xr[p] holds an in-image value
+  // Branch-free loads: every lane reads a clamped, always-valid address and out-of-range elements are zeroed through the
+  // masks in sstore.  (A predicated load leaves a PHI at the join; its register copies come with an s_waitcnt vmcnt(0) that
+  // lands BEFORE the MFMA block and serialises load latency with compute.)
+  const float* src_v = kvalid ? src : a.in[0];
+  const int cs_v = kvalid ? cs : a.cseg[0], cl_v = kvalid ? cl : 0;
+  const int yn_v = yn < a.Cout ? yn : 0;
+  unsigned ymask = 0;
   auto gload = [&](int m0) {
     {
       int b, rr, py, px;
-      fdivmod(m0 + yrow0, HW, a.inv_hw, b, rr);
+      fdivmod(min(m0 + yrow0, M - 1), HW, a.inv_hw, b, rr);
       fdivmod(rr, a.Wp, a.inv_w, py, px);
+      ymask = 0;
 #pragma unroll
       for (int p = 0; p < YP; ++p) {
         const int row = yrow0 + p * YRS, m = m0 + row;
-        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < BMc && m < m_hi && yn < a.Cout) {
-          const int oy = py * a.ostep + a.ooy, ox = px * a.ostep + a.oox;
-          const float* yp = a.dy + (((size_t)b * a.Hout + oy) * a.Wout + ox) * a.Cout + yn;
-          if (yn + 3 < a.Cout) yv = *reinterpret_cast<const float4*>(yp);
-          else { float t4[4] = {0, 0, 0, 0}; for (int r = 0; r < 4; ++r) if (yn + r < a.Cout) t4[r] = yp[r]; yv = make_float4(t4[0], t4[1], t4[2], t4[3]); }
-        }
-        yr[p] = yv;
+        const bool ok = row < BMc && m < m_hi && yn < a.Cout;
+        const int bc = min(b, a.B - 1);
+        const int oy = py * a.ostep + a.ooy, ox = px * a.ostep + a.oox;
+        yr[p] = *reinterpret_cast<const float4*>(a.dy + (((size_t)bc * a.Hout + oy) * a.Wout + ox) * a.Cout + yn_v);
+        ymask |= (ok ? 1u : 0u) << p;
         px += YRS;                                     // advance the pixel by the row stride without dividing
         while (px >= a.Wp) { px -= a.Wp; if (++py >= a.Hp) { py = 0; ++b; } }
       }
     }
     {
       int b, rr, py, px;
-      fdivmod(m0 + xrow0, HW, a.inv_hw, b, rr);
+      fdivmod(min(m0 + xrow0, M - 1), HW, a.inv_hw, b, rr);
       fdivmod(rr, a.Wp, a.inv_w, py, px);
       xmask = 0;
 #pragma unroll
       for (int p = 0; p < XP; ++p) {
         const int m = m0 + xrow0 + p * XRS;
-        float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kvalid && m < m_hi) {
-          const int iy = py * a.stride + iy_off, ix = px * a.stride + ix_off;
-          if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
-            xv = *reinterpret_cast<const float4*>(src + (((size_t)b * a.Hin + iy) * a.Win + ix) * cs + cl);
-            xmask |= 1u << p;      // transformed (affine + activation) in sstore, once the MFMAs of this chunk are issued
-          }
-        }
-        xr[p] = xv;
+        const int iy = py * a.stride + iy_off, ix = px * a.stride + ix_off;
+        const bool ok = kvalid && m < m_hi && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int iyc = min(max(iy, 0), a.Hin - 1), ixc = min(max(ix, 0), a.Win - 1), bc = min(b, a.B - 1);
+        xr[p] = *reinterpret_cast<const float4*>(src_v + (((size_t)bc * a.Hin + iyc) * a.Win + ixc) * cs_v + cl_v);
+        xmask |= (ok ? 1u : 0u) << p;      // transformed (affine + activation) in sstore, once the MFMAs of this chunk are issued
         px += XRS;
         while (px >= a.Wp) { px -= a.Wp; if (++py >= a.Hp) { py = 0; ++b; } }
       }
@@ -132,12 +133,13 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
 #pragma unroll
     for (int p = 0; p < YP; ++p) {
       const int row = yrow0 + p * YRS;
-      if (row < BMc) *reinterpret_cast<float4*>(&Ys[row * LDY + yc]) = yr[p];
+      if (row < BMc) *reinterpret_cast<float4*>(&Ys[row * LDY + yc]) = ((ymask >> p) & 1u) ? yr[p] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int p = 0; p < XP; ++p) {
-      float4 xv = xr[p];
+      float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
       if ((xmask >> p) & 1u) {
+        xv = xr[p];
         if (aff) { xv.x = xv.x * s4.x + h4.x; xv.y = xv.y * s4.y + h4.y; xv.z = xv.z * s4.z + h4.z; xv.w = xv.w * s4.w + h4.w; }
         float v4[4] = {xv.x, xv.y, xv.z, xv.w};
         apply_act4(v4, a.pro_act, 0.f);
@@ -161,6 +163,8 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
     const bool more = m0 + BMc < m_hi;
 #endif
     if (more) gload(m0 + BMc);
+    __builtin_amdgcn_sched_barrier(0);   // keep the loads' consumers (transform + LDS store) behind the MFMA block:
+                                         // the scheduler otherwise hoists them, and their vmcnt(0), in front of it
 #ifndef WG_NOMFMA
 #pragma unroll
     for (int ks = 0; ks < BMc / 4; ++ks) {
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(av[i], bv[j], acc[i][j]);
     }
 #endif
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     if (more) sstore();
     __syncthreads();
@@ -490,6 +495,7 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
   a.co_lim = co_lim < a.Cout ? co_lim : a.Cout; a.ci_lim = ci_lim < cin ? ci_lim : cin;
   const long Ml = (long)a.B * a.Hp * a.Wp;
   DPMN_REQUIRE(Ml > 0 && Ml < (1L << 24), "conv2d_wgrad: pixel count must be below 2^24");
+  DPMN_REQUIRE(a.Cout % 4 == 0, "conv2d_wgrad: dy must carry a multiple of 4 channels (pad the output gradient)");
   const int M = (int)Ml;
   a.inv_hw = 1.0f / (float)(a.Hp * a.Wp); a.inv_w = 1.0f / (float)a.Wp;
   const int bn = a.Cout <= 16 ? 16 : (a.Cout <= 64 ? 64 : 128);
