@@ -1,0 +1,92 @@
+"""Parameter / buffer holders for the PSN's spatial-transformer front end (``model/stn_head.py::STNHead`` 26-106 and
+``model/tps_spatial_transformer.py::TPSSpatialTransformer`` 54-95).
+
+The reference trains and tests with ``--STN`` (README.md:34,42), so released PSN checkpoints carry ``tps.*`` and
+``stn_head.*`` entries -- but the branch only executes under ``self.training`` (tsrn.py:62, tatt.py:75-78, tbsrn.py:215)
+and DPMN keeps the PSN in ``.eval()`` (super_resolution.py:56-59).  These classes therefore reproduce the state_dict
+layout and the constructors' values (so that checkpoints load and fresh models save identically) and have no forward.
+"""
+import itertools
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def _conv3x3_block(cin, cout):
+    return nn.Sequential(nn.Conv2d(cin, cout, 3, 1, 1), nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class STNHead(nn.Module):
+    def __init__(self, in_planes, num_ctrlpoints, activation='none', input_size=(16, 64)):
+        super().__init__()
+        self.in_planes, self.num_ctrlpoints, self.activation = in_planes, num_ctrlpoints, activation
+        self.stn_convnet = nn.Sequential(
+            _conv3x3_block(in_planes, 32), nn.MaxPool2d(2, 2), _conv3x3_block(32, 64), nn.MaxPool2d(2, 2),
+            _conv3x3_block(64, 128), nn.MaxPool2d(2, 2), _conv3x3_block(128, 256), nn.MaxPool2d(2, 2),
+            _conv3x3_block(256, 256), nn.MaxPool2d((1, 2), (1, 2)), _conv3x3_block(256, 256))
+        self.stn_fc1 = nn.Sequential(nn.Linear(512, 512), nn.BatchNorm1d(512), nn.ReLU(inplace=True))
+        self.stn_fc2 = nn.Linear(512, num_ctrlpoints * 2)
+        with torch.no_grad():
+            for seq in (self.stn_convnet, self.stn_fc1):          # stn_head.py:57-69
+                for m in seq.modules():
+                    if isinstance(m, nn.Conv2d):
+                        m.weight.normal_(0, math.sqrt(2. / (m.kernel_size[0] * m.kernel_size[1] * m.out_channels)))
+                        m.bias.zero_()
+                    elif isinstance(m, nn.BatchNorm2d):
+                        m.weight.fill_(1)
+                        m.bias.zero_()
+                    elif isinstance(m, nn.Linear):
+                        m.weight.normal_(0, 0.001)
+                        m.bias.zero_()
+            # stn_head.py:71-90: the last layer starts as the identity warp (control points on the top / bottom edges)
+            margin, half = 0.01, num_ctrlpoints // 2
+            xs = np.linspace(margin, 1. - margin, half)
+            pts = np.concatenate([np.stack([xs, np.full(half, margin)], 1), np.stack([xs, np.full(half, 1 - margin)], 1)], 0)
+            pts = pts.astype(np.float32)
+            if activation == 'sigmoid':
+                pts = -np.log(1. / pts - 1.)
+            self.stn_fc2.weight.zero_()
+            self.stn_fc2.bias.copy_(torch.from_numpy(pts).reshape(-1))
+
+    def forward(self, x):
+        raise NotImplementedError("dpmn_amd STNHead: the spatial transformer only runs in PSN train mode, which DPMN never "
+                                  "enters (super_resolution.py:56-59)")
+
+
+def _partial_repr(points, ctrl):
+    """phi(r) = r^2 log r written as 0.5 * d2 * log(d2) with 0 log 0 := 0 (tps_spatial_transformer.py:22-34)."""
+    d = points[:, None, :] - ctrl[None, :, :]
+    d2 = d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]
+    r = 0.5 * d2 * torch.log(d2)
+    return torch.where(torch.isnan(r), torch.zeros_like(r), r)
+
+
+class TPSSpatialTransformer(nn.Module):
+    def __init__(self, output_image_size=None, num_control_points=None, margins=None):
+        super().__init__()
+        self.output_image_size, self.num_control_points, self.margins = output_image_size, num_control_points, margins
+        H, W = output_image_size
+        half = num_control_points // 2
+        xs = np.linspace(margins[0], 1.0 - margins[0], half)
+        pts = np.concatenate([np.stack([xs, np.full(half, margins[1])], 1),
+                              np.stack([xs, np.full(half, 1.0 - margins[1])], 1)], 0)
+        ctrl = torch.Tensor(pts)
+        N = num_control_points
+        fk = torch.zeros(N + 3, N + 3)
+        fk[:N, :N] = _partial_repr(ctrl, ctrl)
+        fk[:N, -3] = 1
+        fk[-3, :N] = 1
+        fk[:N, -2:] = ctrl
+        fk[-2:, :N] = ctrl.t()
+        coord = torch.Tensor(list(itertools.product(range(H), range(W))))       # (y, x)
+        Y, X = coord[:, :1] / (H - 1), coord[:, 1:] / (W - 1)
+        tc = torch.cat([X, Y], 1)
+        self.register_buffer('inverse_kernel', torch.inverse(fk))
+        self.register_buffer('padding_matrix', torch.zeros(3, 2))
+        self.register_buffer('target_coordinate_repr', torch.cat([_partial_repr(tc, ctrl), torch.ones(H * W, 1), tc], 1))
+        self.register_buffer('target_control_points', ctrl)
+
+    def forward(self, input, source_control_points):
+        raise NotImplementedError("dpmn_amd TPSSpatialTransformer: train-mode PSN only (never entered by DPMN)")

@@ -80,9 +80,8 @@ class TBSRN(_PSNBase):
 
     def __init__(self, scale_factor=2, width=128, height=32, STN=False, srb_nums=5, mask=True, hidden_units=32, input_channel=3):
         super().__init__()
-        if STN:
-            raise NotImplementedError("dpmn_amd TBSRN: the STN/TPS head only runs in PSN train mode, which DPMN never "
-                                      "enters (super_resolution.py:59); construct with STN=False")
+        self.stn = bool(STN)       # held for checkpoint compatibility only (model/stn.py)
+        self._stn_hw = (height // scale_factor, width // scale_factor)
         if hidden_units != 32 or (height, width) != (32, 128) or scale_factor != 2:
             raise NotImplementedError("dpmn_amd TBSRN: FeatureEnhancer is hard-wired to 64 channels on a 16x64 map "
                                       "(tbsrn.py:66-83): hidden_units=32, 32x128 output, scale 2")

@@ -67,9 +67,8 @@ class _PSNBase(nn.Module):
     """Shared conv/GRU trunk of TSRN and TATT."""
 
     def _build_trunk(self, scale_factor, width, height, STN, srb_nums, mask, hidden_units, text_ch):
-        if STN:
-            raise NotImplementedError("dpmn_amd PSN: the STN/TPS head only runs in PSN train mode, which DPMN never "
-                                      "enters (super_resolution.py:59); construct with STN=False")
+        self.stn = bool(STN)      # parameters are held for checkpoint compatibility (model/stn.py); eval never runs them
+        self._stn_hw = (height // scale_factor, width // scale_factor)
         assert math.log(scale_factor, 2) % 1 == 0 and scale_factor == 2, "built for scale_factor=2"
         self.in_planes = 4 if mask else 3
         self.srb_nums = srb_nums
@@ -83,6 +82,10 @@ class _PSNBase(nn.Module):
         ch = self.ch
         setattr(self, "block%d" % (srb_nums + 2), nn.Sequential(nn.Conv2d(ch, ch, 3, padding=1), nn.BatchNorm2d(ch)))
         setattr(self, "block%d" % (srb_nums + 3), nn.Sequential(_Upsample(ch, 2), nn.Conv2d(ch, self.in_planes, 9, padding=4)))
+        if getattr(self, "stn", False):   # tsrn.py:44-56 / tatt.py:57-72 / tbsrn.py:199-212: registered after the blocks
+            from .stn import STNHead, TPSSpatialTransformer
+            self.tps = TPSSpatialTransformer(output_image_size=tuple(self._stn_hw), num_control_points=20, margins=(0.05, 0.05))
+            self.stn_head = STNHead(in_planes=self.in_planes, num_ctrlpoints=20, activation='none')
 
     # ------------------------------------------------------------------ packing (cached)
     def _trunk_pack(self):

@@ -143,3 +143,21 @@ def test_tbsrn_module_vs_reference_golden_and_oracle(dev):
     with torch.no_grad():
         out = m(xb.to(dev))
     assert_close(out, ot.tbsrn_forward(sd, xb), 2e-4, 2e-4, "TBSRN B=5 vs oracle")
+
+
+def test_psn_with_stn_entries_runs_like_without(dev):
+    """--STN models (the README's configuration) carry the tps.* / stn_head.* entries but never execute them in eval:
+    same output as the STN=False model on the same trunk weights."""
+    from dpmn_amd.model.tatt import TSRN_TL_TRANS
+    kw = dict(scale_factor=2, width=128, height=32, mask=True, srb_nums=5, hidden_units=32)
+    a = TSRN_TL_TRANS(STN=True, **kw).eval()
+    b = TSRN_TL_TRANS(STN=False, **kw).eval()
+    sd = a.state_dict()
+    synth.synth_fill_(sd, 45)
+    a.load_state_dict(sd)
+    b.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("tps.", "stn_head."))})
+    bt = synth.synth_batch(3, seed=6)
+    with torch.no_grad():
+        oa, _ = a.to(dev)(bt["images_lr"].to(dev), bt["label_vecs"].to(dev))
+        ob, _ = b.to(dev)(bt["images_lr"].to(dev), bt["label_vecs"].to(dev))
+    assert torch.equal(oa, ob)

@@ -37,3 +37,25 @@ def test_tbsrn_matches_reference():
     r = ot.bn_eval(F.conv2d(r, sd[pre + "conv2.weight"], sd[pre + "conv2.bias"], padding=1), sd, pre + "bn2.")
     fe = ot.feature_enhancer(r.reshape(2, 64, 1024), sd, pre + "feature_enhancer.")
     assert_close(fe[:, ::8], t(g["fe_block2"]), 2e-5, 1e-5, "tbsrn feature enhancer")
+
+
+def test_stn_front_end_layout_matches_reference():
+    """a15: the reference is trained / tested with --STN (README.md:34,42), so PSN checkpoints carry tps.* / stn_head.* entries.
+    The branch itself only runs under self.training, which DPMN never enters; the mirror must reproduce the state_dict
+    layout and the constructor-computed TPS matrices exactly."""
+    import torch
+    from dpmn_amd.model.tatt import TSRN_TL_TRANS
+    from dpmn_amd.model.tsrn import TSRN
+    from dpmn_amd.model.tbsrn import TBSRN
+    g = load_golden("stn_layout")
+    kw = dict(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+    sd = TSRN_TL_TRANS(**kw).state_dict()
+    assert ["%s|%s" % (k, ",".join(map(str, v.shape))) for k, v in sd.items()] == \
+           ["|".join(str(r).split("|")[:2]) for r in g["manifest"]]
+    assert torch.equal(sd["tps.inverse_kernel"], t(g["inverse_kernel"]))
+    assert torch.equal(sd["tps.target_control_points"], t(g["target_control_points"]))
+    assert torch.equal(sd["tps.target_coordinate_repr"][::37], t(g["target_coordinate_repr"]))
+    assert torch.equal(sd["stn_head.stn_fc2.bias"], t(g["fc2_bias"])) and float(sd["stn_head.stn_fc2.weight"].abs().max()) == 0.0
+    for cls in (TSRN, TBSRN):          # same 55 trailing entries
+        keys = list(cls(**kw).state_dict().keys())
+        assert keys[-55:] == list(sd.keys())[-55:] and keys[-56] == "block8.1.bias"

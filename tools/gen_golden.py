@@ -195,6 +195,16 @@ def gen_tbsrn(x):
         torch.Tensor.cuda = orig
 
 
+def gen_stn_layout():
+    """state_dict layout + constructor values of the --STN front end (the README's train/test commands pass --STN)."""
+    from model import tatt
+    m = tatt.TSRN_TL_TRANS(scale_factor=2, width=128, height=32, STN=True, mask=True, srb_nums=5, hidden_units=32)
+    sd = m.state_dict()
+    save("stn_layout", manifest=manifest(sd), inverse_kernel=sd["tps.inverse_kernel"], target_control_points=sd["tps.target_control_points"],
+         target_coordinate_repr=sd["tps.target_coordinate_repr"][::37].contiguous(), fc2_bias=sd["stn_head.stn_fc2.bias"],
+         fc2_weight_absmax=sd["stn_head.stn_fc2.weight"].abs().max())
+
+
 def gen_psn():
     """PSN backbones in eval mode (frozen in DPMN, super_resolution.py:56-59): TSRN and TATT."""
     from model import tsrn, tatt
@@ -252,7 +262,7 @@ def gen_stack():
          psnr=ssim_psnr.calculate_psnr(out, batch["images_hr"]), ssim=ssim_psnr.SSIM()(out, batch["images_hr"]))
 
 
-GENS = {"stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate}
+GENS = {"stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout}
 
 
 if __name__ == "__main__":
