@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
                     help="fwd: BASELINE.json configs[1] (headline metric); train: configs[2] step (loss, backward, clip+Adam, RCCL all-reduce)")
+    ap.add_argument("--drop", type=float, default=0.0,
+                    help="train mode: Dropout = attn_drop = DropPath rate (the reference README trains with 0.1; default 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
     return ap.parse_args()
@@ -139,7 +141,7 @@ def main():
         else:
             dist.init_process_group(backend)
     from dpmn_amd import workload
-    sr, models, psn, inp = workload.build(args.workload, batch=args.batch)
+    sr, models, psn, inp = workload.build(args.workload, batch=args.batch, drop=args.drop if args.mode == "train" else 0)
     B = inp["images_lr"].shape[0]
     arch, b1, b2, _ = workload.CONFIGS[args.workload]
 
@@ -194,7 +196,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s PSN + %d+%d PGRM (embed 96, windows 2/4/8) + CMM, %s" % (
                 args.workload, arch.upper(), b1, b2,
-                "forward-only" if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"),
+                "forward-only" if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"
+                + (", dropout/attn_drop/drop_path %g" % args.drop if args.drop else "")),
                 "per_gpu_batch": B, "global_batch": B * world,
                 "parallelism": ("dp%d (independent batch shards, no forward collective)" % world) if args.mode == "fwd" else
                                ("dp%d (per-model flat gradient buckets, RCCL all-reduce overlapped with backward)" % world)},

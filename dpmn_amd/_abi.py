@@ -49,7 +49,7 @@ class ConvDesc(C.Structure):
         ("stats", fp), ("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t), ("nphase", C.c_int), ("w_phase_stride", C.c_long)]
 
 
-_i, _f, _sz, _l = C.c_int, C.c_float, C.c_size_t, C.c_long
+_i, _f, _sz, _l, _u64 = C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_ulonglong
 _PP = C.POINTER(fp)
 _IP = C.POINTER(C.c_int)
 
@@ -120,6 +120,9 @@ SIGNATURES = {
     "dpmn_adam_clip_f32": (_i, [fp, fp, fp, fp, fp, _f, _f, _f, _f, _f, _i, fp, C.c_long, fp]),
     "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
+    "dpmn_window_attn_drop_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, _f, _u64, fp]),
+    "dpmn_window_attn_drop_bwd_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _i, _i, _i, _i, _f, _u64, fp]),
+    "dpmn_dropout_f32": (_i, [fp, fp, fp, _l, _l, _f, _u64, _f, _u64, fp]),
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_gelu_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_f32": (_i, [fp, fp, fp, fp, fp, _PP, _PP, _i, fp, fp, _i, _i, _i, _i, _i, _i, fp]),

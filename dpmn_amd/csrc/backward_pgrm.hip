@@ -10,11 +10,14 @@ namespace {
 // Pass 2 (lane = key row):  dK, dV and the relative-position-bias table gradient (LDS atomics, then global atomics).
 // All gathers/scatters use the forward's roll + window-major token map (quirk Q1); every token belongs to exactly
 // one window per group, so dq / dkv are plain stores.
-template <int WS, int D>
+// DROP: attn_drop (pgrm.py:248) -- P is multiplied by the regenerated mask M (0 or 1/(1-p)) before P.V, so dV = (P o M)^T dO,
+// dP = (dO V^T) o M, and delta = dO . O is unchanged in form (O is the dropped output).
+template <int WS, int D, bool DROP>
 __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict__ q, const float* __restrict__ kv,
                                                           const float* __restrict__ bias_table, const float* __restrict__ dout,
                                                           float* __restrict__ dq, float* __restrict__ dkv,
-                                                          float* __restrict__ dtable, int B, int H, int W, int C, int g, int shift) {
+                                                          float* __restrict__ dtable, int B, int H, int W, int C, int g, int shift,
+                                                          float p_drop, unsigned long long seed) {
   constexpr int N = WS * WS, CG = 2 * D, ROWS = 64, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
   static_assert(N <= 64, "windows larger than 64 tokens are not built yet");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -66,6 +69,9 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
   const int il = nl / WS, jl = nl % WS;
   const int my_reg = active ? reg_s[lane] : 0;
   float* smax = stat + head * 3 * ROWS, *sinv = smax + ROWS, *sdel = sinv + ROWS;
+  // mask element index = ((((b*G + g)*2 + head)*L + window-major query token)*N + key row in window)   (G = C / CG)
+  const unsigned long long mrow0 = ((unsigned long long)((size_t)b * (C / CG) + g) * 2 + head) * L;
+  const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
 
   if (active) {
     // ---------------- pass 1: lane = query
@@ -93,6 +99,7 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
       if (shift > 0 && reg_s[krow0 + m] != my_reg) a += -100.0f;
       const float p = expf(a - mx);
       den += p;
+      if (DROP) dp *= drop_scale(seed, (mrow0 + t0 + lane) * N + m, p_drop, inv_keep);
       dlt += p * dp;                                    // sum_m P dP = dO . O
     }
     const float inv = 1.0f / den;
@@ -109,6 +116,7 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
       for (int d = 0; d < D; ++d) { a += qv[d] * kr[d]; dp += go[d] * vr[d]; }
       a += tbl[((il - m / WS + WS - 1) * (2 * WS - 1) + (jl - m % WS + WS - 1)) * 2 + head];
       if (shift > 0 && reg_s[krow0 + m] != my_reg) a += -100.0f;
+      if (DROP) dp *= drop_scale(seed, (mrow0 + t0 + lane) * N + m, p_drop, inv_keep);
       const float ds = expf(a - mx) * inv * (dp - dlt);
 #pragma unroll
       for (int d = 0; d < D; ++d) dqa[d] += ds * kr[d];
@@ -135,9 +143,11 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
       a += tbl[tix];
       if (shift > 0 && reg_s[krow0 + n] != my_reg) a += -100.0f;
       const float p = expf(a - smax[krow0 + n]) * sinv[krow0 + n];
-      const float ds = p * (dp - sdel[krow0 + n]);
+      const float mk = DROP ? drop_scale(seed, (mrow0 + t0 + krow0 + n) * N + nl, p_drop, inv_keep) : 1.0f;
+      const float ds = p * (dp * mk - sdel[krow0 + n]);
+      const float pv = p * mk;
 #pragma unroll
-      for (int d = 0; d < D; ++d) { dv[d] += p * gr[d]; dk[d] += ds * scale * qr[d]; }
+      for (int d = 0; d < D; ++d) { dv[d] += pv * gr[d]; dk[d] += ds * scale * qr[d]; }
       atomicAdd(dtb + tix, ds);
     }
     float* dkp = dkv + src_tok * 2 * C + g * CG + head * D;
@@ -152,19 +162,19 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
   for (int i = threadIdx.x; i < TBL * 2; i += 256) atomicAdd(dtable + i, dtb[i]);
 }
 
-template <int WS, int D>
+template <int WS, int D, bool DROP>
 int launch_wattn_bwd(const float* q, const float* kv, const float* tbl, const float* dout, float* dq, float* dkv, float* dtable,
-                     int B, int H, int W, int C, int g, int shift, hipStream_t st) {
+                     int B, int H, int W, int C, int g, int shift, float p_drop, unsigned long long seed, hipStream_t st) {
   constexpr int CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
   const size_t smem = (size_t)(2 * ((TBL * 2 + 3) & ~3) + 2 * (4 * 64 * LDR + 6 * 64)) * 4 + 2 * 64 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn_bwd<WS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn_bwd<WS, D, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const long slabs = (long)B * (H * W / 64);
-  hipLaunchKernelGGL((k_window_attn_bwd<WS, D>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, tbl, dout, dq, dkv,
-                     dtable, B, H, W, C, g, shift);
+  hipLaunchKernelGGL((k_window_attn_bwd<WS, D, DROP>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, tbl, dout, dq, dkv,
+                     dtable, B, H, W, C, g, shift, p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -340,6 +350,31 @@ __global__ void k_act_fwd(const float* __restrict__ x, float* __restrict__ y, in
   float v[4] = {p.x, p.y, p.z, p.w};
   apply_act4(v, act, slope);
   reinterpret_cast<float4*>(y)[i] = make_float4(v[0], v[1], v[2], v[3]);
+}
+// y = res + x * m_elem(i) * m_row(i / row_len): nn.Dropout (p_elem) and/or timm DropPath (p_row, one draw per batch sample,
+// row_len = elements per sample) with the residual add of SwinTransformerBlock.forward (pgrm.py:329-330) folded in.
+// The backward is the same kernel on the gradient with res = NULL.  In place (y == x) is fine.
+__global__ void k_dropout(const float* __restrict__ x, const float* __restrict__ res, float* __restrict__ y, long n4, long row_len,
+                          float p_elem, unsigned long long seed_elem, float p_row, unsigned long long seed_row) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(x)[i];
+  float o[4] = {v.x, v.y, v.z, v.w};
+  if (p_elem > 0.f) {
+    const float ik = 1.0f / (1.0f - p_elem);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] *= drop_scale(seed_elem, (unsigned long long)(i * 4 + r), p_elem, ik);
+  }
+  if (p_row > 0.f) {
+    const float m = drop_scale(seed_row, (unsigned long long)((i * 4) / row_len), p_row, 1.0f / (1.0f - p_row));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] *= m;
+  }
+  if (res) {
+    const float4 rr = reinterpret_cast<const float4*>(res)[i];
+    o[0] += rr.x; o[1] += rr.y; o[2] += rr.z; o[3] += rr.w;
+  }
+  reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
 }
 // y = LayerNorm(x) (E = C), one row per 32 threads
 template <int C>
@@ -591,7 +626,16 @@ extern "C" {
 int dpmn_window_attn_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
                              const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
                              float* const* dtables, int B, int H, int W, int C, dpmn_stream_t stream) {
+  return dpmn_window_attn_drop_bwd_f32(q, kv, bias_tables, windows, shifts, n_groups, heads_per_group, dout, dq, dkv, dtables, B,
+                                       H, W, C, 0.f, 0ull, stream);
+}
+
+int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                                  const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
+                                  float* const* dtables, int B, int H, int W, int C, float p_drop, unsigned long long seed,
+                                  dpmn_stream_t stream) {
   DPMN_REQUIRE(q && kv && bias_tables && windows && shifts && dout && dq && dkv && dtables, "window_attn_bwd: null pointer");
+  DPMN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "window_attn_bwd: attn_drop must be in [0, 1)");
   DPMN_REQUIRE(heads_per_group == 2 && C % n_groups == 0 && (H * W) % 64 == 0, "window_attn_bwd: unsupported geometry");
   const int D = C / n_groups / heads_per_group;
   hipStream_t st = as_stream(stream);
@@ -599,7 +643,9 @@ int dpmn_window_attn_bwd_f32(const float* q, const float* kv, const float* const
     const int ws = windows[g], sh = shifts[g];
     DPMN_REQUIRE(H % ws == 0 && W % ws == 0 && sh >= 0 && sh < ws, "window_attn_bwd: bad window / shift");
     int rc = DPMN_ERR_ARG;
-#define WB_CASE(WSV, DV) if (ws == WSV && D == DV) rc = launch_wattn_bwd<WSV, DV>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, st); else
+#define WB_CASE(WSV, DV) if (ws == WSV && D == DV) rc = p_drop > 0.f \
+      ? launch_wattn_bwd<WSV, DV, true>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, p_drop, seed, st) \
+      : launch_wattn_bwd<WSV, DV, false>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, 0.f, 0ull, st); else
     WB_CASE(2, 16) WB_CASE(4, 16) WB_CASE(8, 16) WB_CASE(4, 32) WB_CASE(8, 32)
     return dpmn_set_error(DPMN_ERR_ARG, "window_attn_bwd: unsupported (window, head_dim)");
 #undef WB_CASE
@@ -660,6 +706,17 @@ int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, floa
 int dpmn_act_fwd_f32(const float* x, float* y, int act, float slope, long n, dpmn_stream_t stream) {
   DPMN_REQUIRE(x && y && n > 0 && n % 4 == 0, "act_fwd: bad arguments");
   hipLaunchKernelGGL(k_act_fwd, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, as_stream(stream), x, y, act, slope, n / 4);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_dropout_f32(const float* x, const float* res, float* y, long n, long row_len, float p_elem,
+                     unsigned long long seed_elem, float p_row, unsigned long long seed_row, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && y && n > 0 && n % 4 == 0, "dropout: n must be a positive multiple of 4");
+  DPMN_REQUIRE(p_elem >= 0.f && p_elem < 1.f && p_row >= 0.f && p_row < 1.f, "dropout: probabilities must be in [0, 1)");
+  DPMN_REQUIRE(p_row == 0.f || (row_len > 0 && row_len % 4 == 0 && n % row_len == 0), "dropout: row_len must divide n (multiple of 4)");
+  hipLaunchKernelGGL(k_dropout, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, as_stream(stream), x, res, y, n / 4,
+                     row_len > 0 ? row_len : n, p_elem, seed_elem, p_row, seed_row);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

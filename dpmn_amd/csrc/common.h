@@ -99,5 +99,18 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// Train-mode Dropout / DropPath masks (nn.Dropout pgrm.py:24,180,494; timm DropPath pgrm.py:310).  The reference draws them
+// from torch's Philox stream, which no other implementation can replay; here a mask element is a pure function of
+// (seed, element index) -- splitmix64 finaliser, top 24 bits as a uniform in [0,1) -- so forward, backward and the CPU
+// oracle (oracle/pgrm.py drop_mask) regenerate identical masks without storing them.  Returns 0 or 1/(1-p).
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  unsigned long long z = idx * 0x9E3779B97F4A7C15ull + seed;
+  z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 27; z *= 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(unsigned)(z >> 40) * 5.9604644775390625e-8f;   // 2^-24
+  return u >= p ? inv_keep : 0.0f;
+}
+
 static inline hipStream_t as_stream(dpmn_stream_t s) { return (hipStream_t)s; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

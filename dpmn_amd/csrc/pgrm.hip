@@ -109,10 +109,13 @@ __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict_
 // K/V (and Q, for coalescing) of the slab's windows are staged in LDS: rows of CG floats; every lane
 // of a window reads the same K/V row at a time (LDS broadcast).  Softmax is online over 16-key chunks.
 // HBM-bound: 4*L*C*4 bytes per image per block against 11 MFLOP.
-template <int WS, int D>   // D = head dim; channels per group CG = 2*D (two heads per group)
+// DROP (training only): attn_drop (pgrm.py:248) multiplies the normalised probabilities by a regenerated mask
+// (common.h drop_scale) before P.V; the softmax denominator is over the undropped row.
+template <int WS, int D, bool DROP>   // D = head dim; channels per group CG = 2*D (two heads per group)
 __global__ __launch_bounds__(256) void k_window_attn(const float* __restrict__ q, const float* __restrict__ kv,
                                                       const float* __restrict__ bias_table, float* __restrict__ out, int B,
-                                                      int H, int W, int C, int g, int shift) {
+                                                      int H, int W, int C, int g, int shift, float p_drop,
+                                                      unsigned long long seed) {
   constexpr int N = WS * WS;
   constexpr int CG = 2 * D;
   constexpr int QROWS = 64;                     // queries per slab
@@ -195,6 +198,8 @@ __global__ __launch_bounds__(256) void k_window_attn(const float* __restrict__ q
 #pragma unroll
   for (int d = 0; d < D; ++d) o[d] = 0.f;
   float mx = -INFINITY, den = 0.f;
+  const unsigned long long mrow = (((unsigned long long)((size_t)b * (C / CG) + g) * 2 + head) * L + tq) * N;
+  const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
   constexpr int CH = (N < 16) ? N : 16;
   for (int m0 = 0; m0 < N; m0 += CH) {
     float sc[CH];
@@ -222,8 +227,9 @@ __global__ __launch_bounds__(256) void k_window_attn(const float* __restrict__ q
     for (int d = 0; d < D; ++d) o[d] *= resc;
 #pragma unroll
     for (int mm = 0; mm < CH; ++mm) {
-      const float p = expf(sc[mm] - nmx);
+      float p = expf(sc[mm] - nmx);
       den += p;
+      if (DROP) p *= drop_scale(seed, mrow + m0 + mm, p_drop, inv_keep);
       const float* vr = Vs + (krow0 + m0 + mm) * LDR + head * D;
 #pragma unroll
       for (int d = 0; d < D; d += 4) {
@@ -240,20 +246,20 @@ __global__ __launch_bounds__(256) void k_window_attn(const float* __restrict__ q
     *reinterpret_cast<float4*>(dst + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
 }
 
-template <int WS, int D>
+template <int WS, int D, bool DROP>
 int launch_window_attn(const float* q, const float* kv, const float* table, float* out, int B, int H, int W, int C, int g,
-                       int shift, hipStream_t st) {
+                       int shift, float p_drop, unsigned long long seed, hipStream_t st) {
   constexpr int N = WS * WS, CG = 2 * D, KROWS = (N > 64) ? N : 64, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
   const size_t smem = N > 64 ? (size_t)(((TBL * 2 + 3) & ~3) + 2 * KROWS * LDR) * 4 + KROWS * 4
                              : (size_t)(((TBL * 2 + 3) & ~3) + 2 * (64 + 2 * KROWS) * LDR) * 4 + 2 * KROWS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn<WS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn<WS, D, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const long slabs = (long)B * (H * W / 64);
-  hipLaunchKernelGGL((k_window_attn<WS, D>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, table, out, B, H, W,
-                     C, g, shift);
+  hipLaunchKernelGGL((k_window_attn<WS, D, DROP>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, table, out, B, H, W,
+                     C, g, shift, p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -459,7 +465,14 @@ int dpmn_patch_embed_ln_f32(const float* img, int cin, const float* pf_w, const 
 int dpmn_window_attn_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
                          const int* shifts, int n_groups, int heads_per_group, float* out, int B, int H, int W, int C,
                          dpmn_stream_t stream) {
+  return dpmn_window_attn_drop_f32(q, kv, bias_tables, windows, shifts, n_groups, heads_per_group, out, B, H, W, C, 0.f, 0ull, stream);
+}
+
+int dpmn_window_attn_drop_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                              const int* shifts, int n_groups, int heads_per_group, float* out, int B, int H, int W, int C,
+                              float p_drop, unsigned long long seed, dpmn_stream_t stream) {
   DPMN_REQUIRE(q && kv && bias_tables && windows && shifts && out, "window_attn: null pointer");
+  DPMN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "window_attn: attn_drop must be in [0, 1)");
   DPMN_REQUIRE(heads_per_group == 2, "window_attn: two heads per group (num_heads = 2 * n_groups)");
   DPMN_REQUIRE(C % n_groups == 0, "window_attn: C must divide into groups");
   const int D = C / n_groups / heads_per_group;
@@ -470,7 +483,9 @@ int dpmn_window_attn_f32(const float* q, const float* kv, const float* const* bi
     DPMN_REQUIRE(H % ws == 0 && W % ws == 0, "window_attn: padding path (H or W not divisible by window) would crash the reference (quirk Q1)");
     DPMN_REQUIRE(sh >= 0 && sh < ws, "window_attn: shift must be in [0, window)");
     int rc = DPMN_ERR_ARG;
-#define WA_CASE(WSV, DV) if (ws == WSV && D == DV) rc = launch_window_attn<WSV, DV>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st); else
+#define WA_CASE(WSV, DV) if (ws == WSV && D == DV) rc = p_drop > 0.f \
+      ? launch_window_attn<WSV, DV, true>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, p_drop, seed, st) \
+      : launch_window_attn<WSV, DV, false>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, 0.f, 0ull, st); else
     WA_CASE(2, 16) WA_CASE(4, 16) WA_CASE(8, 16) WA_CASE(4, 32) WA_CASE(8, 32) WA_CASE(16, 32)
     return dpmn_set_error(DPMN_ERR_ARG, "window_attn: unsupported (window, head_dim); built: {2,4,8}x16, {4,8,16}x32");
 #undef WA_CASE

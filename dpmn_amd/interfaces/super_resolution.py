@@ -183,6 +183,11 @@ class TextSR(base.TextBase):
         if torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
             raise RuntimeError("dpmn_amd: graphed_train_step is single-process; multi-GPU runs use train_step")
         assert text_priors is not None, "graph capture needs the text priors as inputs"
+        for m in models:
+            dp = getattr(m, "drop_probs", None)
+            if dp is not None and (dp[0] > 0 or dp[1] > 0 or max(dp[2]) > 0):
+                raise RuntimeError("dpmn_amd: graphed_train_step would freeze the Dropout / DropPath seeds (kernel arguments) into "
+                                   "the captured graph and replay the same masks every step; train with train_step, or zero rates")
         trainer.device_step_counter()
         st = dict(lr=images_lr.clone(), hr=images_hr.clone(), lv=None if label_vecs is None else label_vecs.clone(),
                   tp=[t.clone() for t in text_priors])

@@ -132,10 +132,9 @@ class BasicLayer(_Layer):
 
     def __init__(self, dim, input_resolution, depth=2, num_heads=6, window_size=(2, 4, 8), mlp_ratio=4., qkv_bias=True,
                  qk_scale=None, drop=0., attn_drop=0., drop_path=0., norm_layer=None, downsample=None, use_checkpoint=False):
-        if depth != 2 or drop or attn_drop or downsample is not None or not qkv_bias or qk_scale is not None:
-            raise NotImplementedError("dpmn_amd BasicLayer: depth 2, no dropout, no downsample (what PGRM constructs, pgrm.py:500-512)")
-        if isinstance(drop_path, (list, tuple)) and any(drop_path) or (not isinstance(drop_path, (list, tuple)) and drop_path):
-            raise NotImplementedError("dpmn_amd BasicLayer: DropPath kernels are not built (the trainer's config has 0)")
+        if depth != 2 or downsample is not None or not qkv_bias or qk_scale is not None:
+            raise NotImplementedError("dpmn_amd BasicLayer: depth 2, no downsample (what PGRM constructs, pgrm.py:500-512)")
+        # drop / attn_drop / drop_path only act in training, which runs through PGRM (train/pgrm_train.py); eval ignores them
         super().__init__(dim, list(window_size), num_heads, tuple(input_resolution), mlp_ratio)
         self.dim, self.input_resolution, self.num_heads = dim, tuple(input_resolution), num_heads
         self.window_size, self.mlp_ratio = list(window_size), mlp_ratio
@@ -195,7 +194,10 @@ class PGRM(nn.Module):
         self.num_heads = num_heads[iter][0]
         self.mlp_ratio = mlp_ratio[iter]
         self.hidden_size = hidden_size
-        self.drop_probs = (drop_rate[iter], attn_drop_rate[iter], drop_path_rate[iter])
+        # stochastic depth decay rule (pgrm.py:499,512): 2 blocks per PGRM out of sum(depths)*2 along a linspace
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate[iter], sum(depths) * 2)]
+        first = sum(depths[:iter]) * 2
+        self.drop_probs = (float(drop_rate[iter]), float(attn_drop_rate[iter]), (dpr[first], dpr[first + 1]))
         H, W = img_size[0] // self.patch, img_size[1] // self.patch
         self.patches_resolution = [H, W]
         if not mode:
@@ -253,10 +255,8 @@ class PGRM(nn.Module):
         return w
 
     def forward(self, x_q, x_kv, residual_list):
-        if self.training and any(p > 0 for p in self.drop_probs):
-            raise NotImplementedError("dpmn_amd PGRM: train-mode dropout/DropPath kernels are not built yet; "
-                                      "use .eval() or zero drop rates")
-        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or x_kv.requires_grad):
+        dropping = self.training and (self.drop_probs[0] > 0 or self.drop_probs[1] > 0 or max(self.drop_probs[2]) > 0)
+        if dropping or (torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or x_kv.requires_grad)):
             from ..train import pgrm_train           # explicit HIP forward + backward behind torch.autograd
             return pgrm_train.apply(self, x_q, x_kv, list(residual_list))
         B = x_kv.shape[0]

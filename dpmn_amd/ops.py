@@ -56,12 +56,22 @@ def patch_embed_ln(img, pe_w, pe_b, ln_w, ln_b, patch, pf_w=None, pf_b=None):
     return tok
 
 
-def window_attn(q, kv, tables, windows, shifts, heads_per_group, H, W):
+def window_attn(q, kv, tables, windows, shifts, heads_per_group, H, W, p_drop=0.0, seed=0):
+    """p_drop > 0: train-mode attn_drop (pgrm.py:248) with the mask regenerated from `seed` (include/dpmn_hip.h)."""
     B, L, Cd = q.shape
     out = torch.empty_like(q)
-    check(lib.dpmn_window_attn_f32(dptr(q), dptr(kv), _abi.ptr_array(tables), _abi.int_array(windows),
-                                   _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), B, H, W, Cd, stream()))
+    check(lib.dpmn_window_attn_drop_f32(dptr(q), dptr(kv), _abi.ptr_array(tables), _abi.int_array(windows),
+                                        _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), B, H, W, Cd,
+                                        float(p_drop), int(seed), stream()))
     return out
+
+
+def dropout(x, p_elem=0.0, seed_elem=0, p_row=0.0, seed_row=0, row_len=0, res=None, out=None):
+    """out = res + x * dropout_mask(p_elem) * droppath_mask(p_row per row_len elements); in place on x unless `out` is given."""
+    y = x if out is None else out
+    check(lib.dpmn_dropout_f32(dptr(x), dptr(res, True), dptr(y), x.numel(), int(row_len), float(p_elem), int(seed_elem),
+                               float(p_row), int(seed_row), stream()))
+    return y
 
 
 def sk_fuse(cat, shortcut, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, head_w, head_b, groups):

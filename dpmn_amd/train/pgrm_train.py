@@ -3,7 +3,12 @@ composed from libdpmn_hip.so kernels.  Replaces autograd through model/pgrm.py (
 interfaces/super_resolution.py:270) for PGRM.forward (pgrm.py:546-565).
 
 The forward here is the unfused variant of csrc/pgrm_forward.hip (LayerNorm, GELU kept as separate kernels so that
-pre-activations are available); dropout / DropPath must be zero (the train-mode RNG kernels are not built).
+pre-activations are available).
+
+Train-mode Dropout / attn_drop / DropPath (pgrm.py:32,40,248,329-330,554-555): masks are counter-based (a pure function of
+a 64-bit seed and the element index, include/dpmn_hip.h), regenerated in the backward instead of stored.  The seeds of one
+PGRM call are drawn from torch's CPU generator (draw_seeds), so torch.manual_seed makes a run reproducible; the reference's
+Philox masks themselves cannot be replayed by any other implementation, parity there is distributional.
 """
 import ctypes as C
 
@@ -135,8 +140,23 @@ class ConvSpec:
         return ops.conv2d([dy], wt, None, self.cin, self.k, pad=self.pad)
 
 
-def forward(m, x_q, x_kv, residuals):
-    """Returns (out, saved).  m: dpmn_amd.model.pgrm.PGRM."""
+N_SEEDS = 12     # [0] pos_drop(x_q) [1] pos_drop(x_kv); block bi at 2+5*bi: attn_drop, DropPath(attn), Mlp drop 1, Mlp drop 2, DropPath(mlp)
+
+
+def draw_seeds():
+    return torch.randint(0, 2 ** 62, (N_SEEDS,), dtype=torch.int64).tolist()
+
+
+def drop_config(m):
+    """None in eval / all-zero rates, else dict(p, pa, dp=(block0, block1), seeds)."""
+    p, pa, dp = m.drop_probs
+    if not m.training or (p <= 0 and pa <= 0 and max(dp) <= 0):
+        return None
+    return dict(p=p, pa=pa, dp=tuple(dp), seeds=draw_seeds())
+
+
+def forward(m, x_q, x_kv, residuals, drop=None):
+    """Returns (out, saved).  m: dpmn_amd.model.pgrm.PGRM; drop: drop_config(m)."""
     B = x_kv.shape[0]
     H, Wd = m.patches_resolution
     L, Cd = H * Wd, m.embed_dim
@@ -147,7 +167,13 @@ def forward(m, x_q, x_kv, residuals):
     pf = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
     tq = ops.patch_embed_ln(x_q, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch, *pf).reshape(M, Cd)
     tkv = ops.patch_embed_ln(x_kv, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch).reshape(M, Cd)
-    sv = dict(x_q=x_q, x_kv=x_kv, tq=tq, residuals=list(residuals), blocks=[])
+    pd = drop["p"] if drop else 0.0
+    pa = drop["pa"] if drop else 0.0
+    sd = drop["seeds"] if drop else [0] * N_SEEDS
+    if pd > 0:
+        ops.dropout(tq, pd, sd[0])
+        ops.dropout(tkv, pd, sd[1])
+    sv = dict(x_q=x_q, x_kv=x_kv, tq=tq, residuals=list(residuals), blocks=[], drop=drop)
     parts = (L + 31) // 32
     for bi, blk in enumerate(m.layers[0].blocks):
         a, sk, mlp = blk.attn, blk.attn.sknet, blk.mlp
@@ -159,7 +185,10 @@ def forward(m, x_q, x_kv, residuals):
         s["nkv"] = layernorm(tkv, blk.norm1_kv.weight, blk.norm1_kv.bias)
         s["q"] = ops.linear(s["nq"], a.q.weight, a.q.bias)
         s["kv"] = ops.linear(s["nkv"], a.kv.weight, a.kv.bias)
-        s["cat"] = ops.window_attn(s["q"].reshape(B, L, Cd), s["kv"].reshape(B, L, 2 * Cd), tables, win, shift, hpg, H, Wd).reshape(M, Cd)
+        dpb = drop["dp"][bi] if drop else 0.0
+        sb = sd[2 + 5 * bi:7 + 5 * bi]
+        s["cat"] = ops.window_attn(s["q"].reshape(B, L, Cd), s["kv"].reshape(B, L, 2 * Cd), tables, win, shift, hpg, H, Wd,
+                                   p_drop=pa, seed=sb[0]).reshape(M, Cd)
         s["feats"] = _e(M, Cd, like=tkv)
         s["partial"] = _e(B * parts, Cd, like=tkv)
         check(lib.dpmn_sk_proj_f32(dptr(s["cat"]), dptr(sk.proj.weight), dptr(sk.proj.bias), dptr(s["feats"]), dptr(s["partial"]), M, Cd, stream()))
@@ -168,16 +197,26 @@ def forward(m, x_q, x_kv, residuals):
                                    dptr(sk.fc2.bias), dptr(s["avec"]), B, Cd, G, sk.fc1.weight.shape[0], stream()))
         s["V"] = _e(M, Cd // G, like=tkv)
         check(lib.dpmn_sk_select_only_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(s["V"]), M, L, Cd, G, stream()))
-        s["x1"] = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"], res2=tkv)
+        if dpb > 0:      # x1 = shortcut + DropPath(attention branch)
+            branch = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"])
+            s["x1"] = ops.dropout(branch, p_row=dpb, seed_row=sb[1], row_len=L * Cd, res=tkv)
+        else:
+            s["x1"] = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"], res2=tkv)
         s["n2"] = layernorm(s["x1"], blk.norm2.weight, blk.norm2.bias)
         s["ypre"] = ops.linear(s["n2"], mlp.fc1.weight, mlp.fc1.bias)
         s["y"] = act_fwd(s["ypre"])
+        if pd > 0:
+            ops.dropout(s["y"], pd, sb[2])
         r = int(round(L ** 0.5))
         s["gpre"] = _e(M, Ch, like=tkv)
         check(lib.dpmn_dwconv3x3_f32(dptr(s["y"]), dptr(mlp.depthwise_conv.weight), dptr(mlp.depthwise_conv.bias), dptr(s["gpre"]), B, Ch, r, stream()))
         s["g"] = act_fwd(s["gpre"])
         s["z"] = ops.pointwise(s["g"].reshape(B, L, Ch), mlp.pointwise_conv.weight.reshape(Ch, Ch), mlp.pointwise_conv.bias).reshape(M, Ch)
-        tkv = ops.linear(s["z"], mlp.fc2.weight, mlp.fc2.bias, res1=s["x1"])
+        if pd > 0 or dpb > 0:      # x_kv = x1 + DropPath(Dropout(fc2(z)))
+            branch = ops.linear(s["z"], mlp.fc2.weight, mlp.fc2.bias)
+            tkv = ops.dropout(branch, pd, sb[3], dpb, sb[4], row_len=L * Cd, res=s["x1"])
+        else:
+            tkv = ops.linear(s["z"], mlp.fc2.weight, mlp.fc2.bias, res1=s["x1"])
         sv["blocks"].append(s)
     sv["tkv_out"] = tkv
     c0s, c1s = ConvSpec(m.conv_before_upsample[0].weight, m.conv_before_upsample[0].bias), ConvSpec(m.conv_before_upsample[1].weight, m.conv_before_upsample[1].bias)
@@ -214,13 +253,20 @@ def backward(m, sv, dout, need_dx_kv=True):
     dc0 = ConvSpec(c1m.weight, c1m.bias).backward(sv["c0"], dc1, gr[c1m.weight], gr[c1m.bias])
     dtkv = ConvSpec(c0m.weight, c0m.bias).backward(sv["tkv_out"].reshape(B, H, Wd, Cd), dc0, gr[c0m.weight], gr[c0m.bias]).reshape(M, Cd)
     dtq = torch.zeros(M, Cd, device=dout.device)
+    drop = sv.get("drop")
+    pd = drop["p"] if drop else 0.0
+    pa = drop["pa"] if drop else 0.0
+    sd = drop["seeds"] if drop else [0] * N_SEEDS
     for bi in (1, 0):
         blk = m.layers[0].blocks[bi]
         a, sk, mlp = blk.attn, blk.attn.sknet, blk.mlp
         s = sv["blocks"][bi]
+        dpb = drop["dp"][bi] if drop else 0.0
+        sb = sd[2 + 5 * bi:7 + 5 * bi]
         dx2 = dtkv
-        # fc2 (+ residual x1)
-        dz = linear_bwd(dx2, s["z"], mlp.fc2.weight, gr[mlp.fc2.weight], gr[mlp.fc2.bias])
+        # fc2 (+ residual x1); with dropout the branch gradient is dx2 under the same masks
+        dbr = ops.dropout(dx2, pd, sb[3], dpb, sb[4], row_len=L * Cd, out=torch.empty_like(dx2)) if (pd > 0 or dpb > 0) else dx2
+        dz = linear_bwd(dbr, s["z"], mlp.fc2.weight, gr[mlp.fc2.weight], gr[mlp.fc2.bias])
         # pointwise conv on the raw (B, Ch, L) views
         wp = mlp.pointwise_conv.weight.reshape(Ch, Ch)
         dg = ops.pointwise(dz.reshape(B, L, Ch), wp.t().contiguous(), torch.zeros(Ch, device=dz.device)).reshape(M, Ch)
@@ -231,12 +277,15 @@ def backward(m, sv, dout, need_dx_kv=True):
         r = int(round(L ** 0.5))
         check(lib.dpmn_dwconv3x3_bwd_f32(dptr(s["y"]), dptr(dgpre), dptr(mlp.depthwise_conv.weight), dptr(dy),
                                          dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]), B, Ch, r, stream()))
+        if pd > 0:
+            ops.dropout(dy, pd, sb[2])
         dypre = act_bwd(dy, s["ypre"])
         dn2 = linear_bwd(dypre, s["n2"], mlp.fc1.weight, gr[mlp.fc1.weight], gr[mlp.fc1.bias])
         dx1 = dx2.clone()
         layernorm_bwd(s["x1"], dn2, blk.norm2.weight, dx1, True, gr[blk.norm2.weight], gr[blk.norm2.bias])
-        # x1 = tkv_in + feats + V Wh^T + bh
-        dV = linear_bwd(dx1, s["V"], sk.proj_head.weight, gr[sk.proj_head.weight], gr[sk.proj_head.bias])
+        # x1 = tkv_in + DropPath(feats + V Wh^T + bh)
+        dat = ops.dropout(dx1, p_row=dpb, seed_row=sb[1], row_len=L * Cd, out=torch.empty_like(dx1)) if dpb > 0 else dx1
+        dV = linear_bwd(dat, s["V"], sk.proj_head.weight, gr[sk.proj_head.weight], gr[sk.proj_head.bias])
         dcat = torch.zeros(M, Cd, device=dout.device)
         dA = torch.zeros(B, G, Cd // G, device=dout.device)
         check(lib.dpmn_sk_select_bwd_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(dV), dptr(dcat), dptr(dA), B, L, Cd, G, stream()))
@@ -245,21 +294,24 @@ def backward(m, sv, dout, need_dx_kv=True):
                                        dptr(s["avec"]), dptr(dA), dptr(dS), dptr(gr[sk.fc1.weight]), dptr(gr[sk.fc1.bias]),
                                        dptr(gr[sk.fc2.weight]), dptr(gr[sk.fc2.bias]), B, Cd, G, sk.fc1.weight.shape[0], stream()))
         dfeats = torch.empty(M, Cd, device=dout.device)
-        check(lib.dpmn_sk_feats_grad_f32(dptr(dx1), dptr(s["feats"]), dptr(dS), dptr(dfeats), M, L, Cd, stream()))
+        check(lib.dpmn_sk_feats_grad_f32(dptr(dat), dptr(s["feats"]), dptr(dS), dptr(dfeats), M, L, Cd, stream()))
         gemm_tn(dfeats, s["cat"], gr[sk.proj.weight], gr[sk.proj.bias])
         dcat = ops.linear(dfeats, sk.proj.weight.t().contiguous(), None, res1=dcat)
         # window attention
         dq = torch.empty(M, Cd, device=dout.device)
         dkv = torch.empty(M, 2 * Cd, device=dout.device)
         dtab = [gr[t] for t in s["tables"]]
-        check(lib.dpmn_window_attn_bwd_f32(dptr(s["q"]), dptr(s["kv"]), _abi.ptr_array(s["tables"]), _abi.int_array(s["win"]),
-                                           _abi.int_array(s["shift"]), G, hpg, dptr(dcat), dptr(dq), dptr(dkv), _abi.ptr_array(dtab),
-                                           B, H, Wd, Cd, stream()))
+        check(lib.dpmn_window_attn_drop_bwd_f32(dptr(s["q"]), dptr(s["kv"]), _abi.ptr_array(s["tables"]), _abi.int_array(s["win"]),
+                                                _abi.int_array(s["shift"]), G, hpg, dptr(dcat), dptr(dq), dptr(dkv),
+                                                _abi.ptr_array(dtab), B, H, Wd, Cd, float(pa), int(sb[0]), stream()))
         dnq = linear_bwd(dq, s["nq"], a.q.weight, gr[a.q.weight], gr[a.q.bias])
         layernorm_bwd(sv["tq"], dnq, blk.norm1_q.weight, dtq, True, gr[blk.norm1_q.weight], gr[blk.norm1_q.bias])
         dnkv = linear_bwd(dkv, s["nkv"], a.kv.weight, gr[a.kv.weight], gr[a.kv.bias])
         layernorm_bwd(s["tkv_in"], dnkv, blk.norm1_kv.weight, dx1, True, gr[blk.norm1_kv.weight], gr[blk.norm1_kv.bias])
         dtkv = dx1
+    if pd > 0:       # pos_drop on both token streams (pgrm.py:554-555)
+        ops.dropout(dtq, pd, sd[0])
+        ops.dropout(dtkv, pd, sd[1])
     # patch embeddings (shared weights): kv path gives the image gradient, q path the prior_fusion gradients
     pe = m.patch_embed
     dx_kv = None
@@ -294,7 +346,8 @@ class PGRMFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, x_q, x_kv, n_res, *rest):
         residuals = list(rest[:n_res])
-        out, sv = forward(m, x_q.contiguous().float(), x_kv.contiguous().float(), [r.contiguous().float() for r in residuals])
+        out, sv = forward(m, x_q.contiguous().float(), x_kv.contiguous().float(), [r.contiguous().float() for r in residuals],
+                          drop=drop_config(m))
         ctx.m, ctx.sv, ctx.n_res = m, sv, n_res
         ctx.need_kv = x_kv.requires_grad
         return out

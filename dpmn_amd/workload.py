@@ -16,13 +16,15 @@ CONFIGS = {
 }
 
 
-def make_args(arch, b1, b2, batch):
+def make_args(arch, b1, b2, batch, drop=0):
+    """drop: one rate for --drop_rate / --attn_drop_rate / --drop_path_rate (the reference README's training command uses
+    0.1 for all three; 0 = the deterministic configuration the parity tests and the headline bench run)."""
     n = b1 + b2
     rep = lambda v: ",".join([str(v)] * n) + ","
     return SimpleNamespace(
         arch=arch, test=False, test_data_dir=None, batch_size=batch, resume=None, vis_dir=None, rec="aster", mask=True,
         gradient=True, hd_u=32, srb=5, STN=False, patch_size=rep(2), embed_dim=rep(96), window_size=rep("2,4,8"),
-        depths=rep(1), num_heads=rep(6), mlp_ratio=rep(4), drop_rate=rep(0), attn_drop_rate=rep(0), drop_path_rate=rep(0),
+        depths=rep(1), num_heads=rep(6), mlp_ratio=rep(4), drop_rate=rep(drop), attn_drop_rate=rep(drop), drop_path_rate=rep(drop),
         rotate_train=0.0, rotate_test=0.0, stu_iter_b1=b1, stu_iter_b2=b2, tpg="visionlan", rec_path=None, font_path=None,
         sr_share=False, alpha=0.5, window_num=3)
 
@@ -34,13 +36,13 @@ def make_config(batch):
     return SimpleNamespace(TRAIN=train)
 
 
-def build(name, batch=None, seed=100, device=None):
+def build(name, batch=None, seed=100, device=None, drop=0):
     """Returns (sr: TextSR, models, psn, inputs dict) with name-seeded synthetic weights (module i -> seed+i in the
     order [PSN, PGRM_0.., CMM], identical to tools/gen_golden.py::gen_stack for cfg0)."""
     from .interfaces.super_resolution import TextSR
     arch, b1, b2, B = CONFIGS[name]
     B = batch or B
-    sr = TextSR(make_config(B), make_args(arch, b1, b2, B))
+    sr = TextSR(make_config(B), make_args(arch, b1, b2, B, drop))
     models, psn = sr.build_models()
     for i, m in enumerate([psn] + models):
         sd = m.state_dict()

@@ -221,6 +221,21 @@ int dpmn_image_loss_bwd_f32(const float* out, long out_stride, const float* tgt,
 int dpmn_window_attn_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
                              const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq,
                              float* dkv, float* const* dtables, int B, int H, int W, int C, dpmn_stream_t stream);
+/* Train-mode stochastic regularisers of PGRM (nn.Dropout pgrm.py:24,32,40,494,554-555; attn_drop pgrm.py:180,248; timm DropPath
+ * pgrm.py:310,329-330).  torch's Philox stream cannot be replayed outside torch, so a mask element is a pure function of
+ * (seed, element index): splitmix64 finaliser of idx*0x9E3779B97F4A7C15 + seed, top 24 bits / 2^24 = u, keep iff u >= p, kept
+ * values scaled by 1/(1-p).  Forward and backward regenerate the mask from the seed; nothing is stored.
+ *   y = res + x * m_elem(i) * m_row(i / row_len)      res may be NULL; p_elem / p_row = 0 disables that factor; y may alias x.
+ * window attention: mask index ((((b*n_groups + g)*2 + head)*L + window-major query token)*N + key row in window). */
+int dpmn_dropout_f32(const float* x, const float* res, float* y, long n, long row_len, float p_elem,
+                     unsigned long long seed_elem, float p_row, unsigned long long seed_row, dpmn_stream_t stream);
+int dpmn_window_attn_drop_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                              const int* shifts, int n_groups, int heads_per_group, float* out, int B, int H, int W, int C,
+                              float p_drop, unsigned long long seed, dpmn_stream_t stream);
+int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                                  const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq,
+                                  float* dkv, float* const* dtables, int B, int H, int W, int C, float p_drop,
+                                  unsigned long long seed, dpmn_stream_t stream);
 /* SKConv backward pieces (pgrm.py:79-96) */
 int dpmn_sk_select_only_f32(const float* cat, const float* attn_vec, float* V, long M, int L, int C, int G, dpmn_stream_t stream);
 int dpmn_sk_select_bwd_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA, int B, int L,

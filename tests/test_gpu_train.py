@@ -95,6 +95,74 @@ def test_pgrm_backward_vs_oracle_autograd(dev, it, mode):
     print("worst param grad", worst)
 
 
+def test_dropout_kernel_masks_equal_oracle_hash(dev):
+    """dpmn_dropout_f32 (elementwise + per-sample DropPath + residual) vs the numpy restatement of the mask hash: the kept set
+    is bit-identical, values equal to fp32 round-off of the single multiply."""
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    x, r = u("dx", (4, 256, 96), -1, 1), u("dr", (4, 256, 96), -1, 1)
+    seed_e, seed_r = 0x1234567890ABCDE, 0x0FEDCBA987654321
+    y = ops.dropout(x.to(dev), 0.1, seed_e, 0.5, seed_r, row_len=256 * 96, res=r.to(dev), out=torch.empty_like(x, device=dev))
+    ref = r + o.drop_path(o.dropout(x, 0.1, seed_e), 0.5, seed_r)
+    assert_close(y, ref, 1e-6, 1e-6, "dropout + droppath + residual")
+    kept = (ops.dropout(torch.ones(4, 256, 96, device=dev), 0.1, seed_e) != 0).cpu()
+    assert torch.equal(kept, o.dropout(torch.ones(4, 256, 96), 0.1, seed_e) != 0)
+    assert abs(float(kept.float().mean()) - 0.9) < 0.01
+
+
+@pytest.mark.parametrize("rates", [(0.1, 0.0, 0.0), (0.0, 0.1, 0.0), (0.0, 0.0, 0.9), (0.1, 0.1, 0.6)])
+def test_pgrm_train_dropout_vs_oracle_same_masks(dev, rates):
+    """Train-mode Dropout / attn_drop / DropPath (the reference README's training flags use 0.1 for all three): forward and
+    every gradient vs torch autograd through the oracle applying the SAME counter-based masks at the reference's sites."""
+    from dpmn_amd.model.pgrm import PGRM
+    from dpmn_amd.train import pgrm_train
+    from oracle import pgrm as o
+    B, it = 4, 2
+    pd, pa, pp = rates
+    args = _pgrm_args()
+    args.update(drop_rate=[pd] * 6, attn_drop_rate=[pa] * 6, drop_path_rate=[pp] * 6)
+    m = PGRM(iter=it, mode=True, hidden_size=3, **args)
+    dpr = [x.item() for x in torch.linspace(0, pp, 12)]
+    assert m.drop_probs == (pd, pa, (dpr[4], dpr[5]))            # pgrm.py:499,512
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 95)
+    m.load_state_dict(sd)
+    x_q = (u("xq", (B, 1, 32, 128), 0, 1) > 0.5).float().repeat(1, 3, 1, 1)
+    x_kv = u("xkv", (B, 3, 32, 128), 0, 1)
+    res = [u("r%d" % i, (B, 3, 32, 128), 0, 1) for i in range(it)]
+    cot = u("cot", (B, 3, 32, 128), -1, 1)
+    torch.manual_seed(4242)
+    seeds = pgrm_train.draw_seeds()
+    drop = dict(p=pd, pa=pa, dp=(dpr[4], dpr[5]), seeds=seeds)
+    sd_ref = {k: v.clone().requires_grad_(torch.is_floating_point(v) and "index" not in k and "mask" not in k) for k, v in sd.items()}
+    xkv_ref = x_kv.clone().requires_grad_(True)
+    out_ref = o.pgrm_forward(sd_ref, x_q, xkv_ref, res, drop=drop)
+    (out_ref * cot).sum().backward()
+    out_eval = o.pgrm_forward(sd, x_q, x_kv, res)
+    assert float((out_ref.detach() - out_eval).abs().max()) > 1e-3, "the masks must actually change the output"
+    m = m.to(dev).train()
+    xkv_d = x_kv.to(dev).requires_grad_(True)
+    torch.manual_seed(4242)                                       # the module draws the same seeds from the CPU generator
+    out = m(x_q.to(dev), xkv_d, [r.to(dev) for r in res])
+    assert_close(out, out_ref.detach(), 3e-4, 3e-4, "train-mode forward with dropout")
+    (out * cot.to(dev)).sum().backward()
+    assert rel_err(xkv_d.grad, xkv_ref.grad) < 2e-3, "dx_kv"
+    for name, p in m.named_parameters():
+        g_ref = sd_ref[name].grad
+        if g_ref is None:
+            assert float(p.grad.abs().max()) == 0.0, name
+            continue
+        e = rel_err(p.grad, g_ref)
+        assert e < 3e-3, "grad %s rel err %.2e (|ref|max %.3e)" % (name, e, float(g_ref.abs().max()))
+    # eval ignores every rate; a second training call draws new seeds
+    m.eval()
+    with torch.no_grad():
+        assert_close(m(x_q.to(dev), x_kv.to(dev), [r.to(dev) for r in res]), out_eval, 3e-4, 3e-4, "eval forward")
+        m.train()
+        out2 = m(x_q.to(dev), x_kv.to(dev), [r.to(dev) for r in res])
+    assert float((out2 - out.detach()).abs().max()) > 1e-4, "fresh masks per call"
+
+
 @pytest.mark.parametrize("cnum", [8, 16])
 def test_cmm_train_forward_backward_vs_oracle_autograd(dev, cnum):
     from dpmn_amd.model.cmm import ComplementationModulationModule
