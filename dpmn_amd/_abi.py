@@ -123,6 +123,9 @@ SIGNATURES = {
     "dpmn_window_attn_drop_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_window_attn_drop_bwd_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_dropout_f32": (_i, [fp, fp, fp, _l, _l, _f, _u64, _f, _u64, fp]),
+    "dpmn_maxpool_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "dpmn_stn_fc_f32": (_i, [fp, fp, fp, _i, fp, fp, fp, fp, fp, fp, _i, _f, _f, fp, fp, fp, fp, _i, _i, fp]),
+    "dpmn_tps_sample_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_gelu_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_f32": (_i, [fp, fp, fp, fp, fp, _PP, _PP, _i, fp, fp, _i, _i, _i, _i, _i, _i, fp]),

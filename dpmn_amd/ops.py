@@ -66,6 +66,37 @@ def window_attn(q, kv, tables, windows, shifts, heads_per_group, H, W, p_drop=0.
     return out
 
 
+def maxpool(x, kh, kw, scale=None, shift=None):
+    """nn.MaxPool2d((kh,kw), stride (kh,kw)) over NHWC; scale/shift: the producer's BatchNorm affine + ReLU applied on load."""
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, H // kh, W // kw, Cc, device=x.device)
+    check(lib.dpmn_maxpool_f32(dptr(x), dptr(scale, True), dptr(shift, True), dptr(y), B, H, W, Cc, kh, kw, stream()))
+    return y
+
+
+def stn_fc(x, in_affine, w1t, b1, bn, training, w2, b2):
+    """STNHead tail (stn_head.py:94-100) -> (img_feat (B,512), ctrl (B, n_out)).  x: (B,1,W2,C) NHWC, bn: nn.BatchNorm1d holder."""
+    B, _, W2, _ = x.shape
+    feat = torch.empty(B, 512, device=x.device)
+    ctrl = torch.empty(B, w2.shape[0], device=x.device)
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    check(lib.dpmn_stn_fc_f32(dptr(x), dptr(sc, True), dptr(sh, True), W2, dptr(w1t), dptr(b1), dptr(bn.weight), dptr(bn.bias),
+                              dptr(bn.running_mean), dptr(bn.running_var), int(training), float(bn.momentum), float(bn.eps),
+                              dptr(w2), dptr(b2), dptr(feat), dptr(ctrl), B, w2.shape[0], stream()))
+    return feat, ctrl
+
+
+def tps_sample(img, ctrl, inverse_kernel, coord_repr, out_hw):
+    """TPSSpatialTransformer.forward (tps_spatial_transformer.py:97-112) -> (warped (B,C,H,W), source_coordinate (B,H*W,2))."""
+    B, Cc, Hin, Win = img.shape
+    H, W = out_hw
+    out = torch.empty(B, Cc, H, W, device=img.device)
+    src = torch.empty(B, H * W, 2, device=img.device)
+    check(lib.dpmn_tps_sample_f32(dptr(img), dptr(ctrl), dptr(inverse_kernel), dptr(coord_repr), dptr(out), dptr(src), B, Cc,
+                                  Hin, Win, H, W, ctrl.shape[1], stream()))
+    return out, src
+
+
 def dropout(x, p_elem=0.0, seed_elem=0, p_row=0.0, seed_row=0, row_len=0, res=None, out=None):
     """out = res + x * dropout_mask(p_elem) * droppath_mask(p_row per row_len elements); in place on x unless `out` is given."""
     y = x if out is None else out

@@ -236,6 +236,25 @@ int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* 
                                   const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq,
                                   float* dkv, float* const* dtables, int B, int H, int W, int C, float p_drop,
                                   unsigned long long seed, dpmn_stream_t stream);
+/* Row a15 -- the PSNs' spatial-transformer front end (reached only in PSN train mode: tatt.py / tbsrn.py `if self.stn and
+ * self.training`).
+ *   maxpool : nn.MaxPool2d(k, stride k) over NHWC (stn_head.py:36-46); scale/shift != NULL applies the producing
+ *             conv3x3_block's BatchNorm affine + ReLU on load (train mode: batch statistics from dpmn_bn_finalize_f32).
+ *   stn_fc  : STNHead.forward after the conv stack (stn_head.py:94-100): x = last block's raw NHWC output (B,1,W2,512/W2)
+ *             (+ affine/ReLU on load), NCHW flatten, stn_fc1 = Linear(512,512) [w1t = weight transposed, (in,out)] +
+ *             BatchNorm1d (training != 0: batch statistics and running-stat update, needs B > 1) + ReLU -> img_feat (B,512);
+ *             ctrl (B,n_out) = stn_fc2(0.1 * img_feat).
+ *   tps_sample : TPSSpatialTransformer.forward (tps_spatial_transformer.py:97-112) incl. F.grid_sample(bilinear, zeros,
+ *             align_corners=False): img (B,C,Hin,Win) NCHW, ctrl (B,N,2), inverse_kernel (N+3,N+3), coord_repr (Hout*Wout,N+3)
+ *             -> out (B,C,Hout,Wout), src_coord (B,Hout*Wout,2) (the unclamped source coordinates the reference also returns). */
+int dpmn_maxpool_f32(const float* x, const float* scale, const float* shift, float* y, int B, int H, int W, int C, int kh,
+                     int kw, dpmn_stream_t stream);
+int dpmn_stn_fc_f32(const float* x, const float* in_scale, const float* in_shift, int W2, const float* w1t, const float* b1,
+                    const float* bn_gamma, const float* bn_beta, float* running_mean, float* running_var, int training,
+                    float momentum, float eps, const float* w2, const float* b2, float* img_feat, float* ctrl, int B,
+                    int n_out, dpmn_stream_t stream);
+int dpmn_tps_sample_f32(const float* img, const float* ctrl, const float* inverse_kernel, const float* coord_repr, float* out,
+                        float* src_coord, int B, int C, int Hin, int Win, int Hout, int Wout, int N, dpmn_stream_t stream);
 /* SKConv backward pieces (pgrm.py:79-96) */
 int dpmn_sk_select_only_f32(const float* cat, const float* attn_vec, float* V, long M, int L, int C, int G, dpmn_stream_t stream);
 int dpmn_sk_select_bwd_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA, int B, int L,

@@ -205,6 +205,34 @@ def gen_stn_layout():
          fc2_weight_absmax=sd["stn_head.stn_fc2.weight"].abs().max())
 
 
+def gen_stn_fwd():
+    """Row a15 forward: the imported STNHead (train and eval mode) and TPSSpatialTransformer on synthetic weights."""
+    from model import stn_head, tps_spatial_transformer as tps
+    B = 6
+    x = synth.uniform("stn_x", (B, 4, 16, 64), 0, 1, 51)
+    out = {}
+    for mode in ("train", "eval"):
+        m = stn_head.STNHead(in_planes=4, num_ctrlpoints=20, activation='none')
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=52)
+        sd = {k: v.clone() for k, v in sd.items()}
+        m.load_state_dict(sd)
+        m.train(mode == "train")
+        feat, ctrl = m(x)
+        out[mode + "_feat"], out[mode + "_ctrl"] = feat, ctrl
+        if mode == "train":
+            sd2 = m.state_dict()
+            for k in sd2:
+                if "running" in k or "num_batches" in k:
+                    out["after." + k] = sd2[k].clone()
+    t = tps.TPSSpatialTransformer(output_image_size=(16, 64), num_control_points=20, margins=(0.05, 0.05))
+    # control points around the identity layout, pushed far enough that some source coordinates leave [0, 1] (clamp path)
+    ctrl = t.target_control_points[None] + synth.uniform("stn_ctrl", (B, 20, 2), -0.12, 0.12, 53)
+    warped, src = t(x, ctrl)
+    save("stn_fwd", manifest=manifest(sd), checksum=checksum(sd), tps_out=warped, tps_src=src[:, ::7].contiguous(),
+         tps_src_minmax=np.array([float(src.min()), float(src.max())]), **out)
+
+
 def gen_psn():
     """PSN backbones in eval mode (frozen in DPMN, super_resolution.py:56-59): TSRN and TATT."""
     from model import tsrn, tatt
@@ -262,7 +290,7 @@ def gen_stack():
          psnr=ssim_psnr.calculate_psnr(out, batch["images_hr"]), ssim=ssim_psnr.SSIM()(out, batch["images_hr"]))
 
 
-GENS = {"stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout}
+GENS = {"stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
 
 
 if __name__ == "__main__":

@@ -36,11 +36,12 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 by = collections.Counter()
 tm = collections.Counter()
 for ev in prof.events():
-    if ev.device_time_total <= 0 or not ev.name.startswith("aten::") or ev.cpu_parent is not None and ev.cpu_parent.name.startswith("aten::"):
+    # leaf attribution: the op that launched the kernel / memcpy itself (aten::copy_ under aten::to, ...)
+    if getattr(ev, "self_device_time_total", 0) <= 0 or not ev.name.startswith("aten::"):
         continue
     st = [s for s in (ev.stack or []) if "dpmn_amd" in s or "bench" in s]
     key = (ev.name, st[0].strip()[-90:] if st else "?")
     by[key] += 1
-    tm[key] += ev.device_time_total
+    tm[key] += ev.self_device_time_total
 for key, us in tm.most_common(45):
     print("%7.1f us %4d  %-22s %s" % (us, by[key], key[0], key[1]))
