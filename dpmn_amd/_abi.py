@@ -122,6 +122,8 @@ SIGNATURES = {
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_drop_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_window_attn_drop_bwd_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _i, _i, _i, _i, _f, _u64, fp]),
+    "dpmn_pointwise_profile_begin": (_i, [_i]),
+    "dpmn_pointwise_profile_end": (_i, [C.POINTER(C.c_float)]),
     "dpmn_dropout_f32": (_i, [fp, fp, fp, _l, _l, _f, _u64, _f, _u64, fp]),
     "dpmn_maxpool_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
     "dpmn_stn_fc_f32": (_i, [fp, fp, fp, _i, fp, fp, fp, fp, fp, fp, _i, _f, _f, fp, fp, fp, fp, _i, _i, fp]),

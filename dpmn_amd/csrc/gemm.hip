@@ -374,8 +374,8 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
 // Block 256 threads, tile 128 (s) x BC (co), BK = 16; waves 2(s) x 2(co): 64 x BC/2 each.  BC = 192 when Ch is a multiple
 // of 192 (Ch = 384: 8 x 2 x 48 = 768 tiles = exactly 3 per CU at 3 resident blocks, and 96 MFMAs per barrier), else 128.
 template <int BC>
-__global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, const float* __restrict__ w,
-                                                  const float* __restrict__ bias, float* __restrict__ z, int Ch, int L) {
+__global__ __launch_bounds__(256, 2) void k_gemm_pw(const float* __restrict__ g, const float* __restrict__ w,
+                                                     const float* __restrict__ bias, float* __restrict__ z, int Ch, int L) {
   constexpr int BS = 128, BK = 16, LDS_G = BS + 4, LDS_W = BK + PAD, NJ = BC / 32, WP = BC / 64;
   __shared__ __attribute__((aligned(16))) float Gs[2][BK * LDS_G];
   __shared__ __attribute__((aligned(16))) float Wsm[2][BC * LDS_W];
@@ -385,25 +385,29 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
   const float* gb = g + (size_t)b * Ch * L;
   float* zb = z + (size_t)b * Ch * L;
 
-  // loaders: G chunk = 16 rows(k) x 128 s = 512 float4 -> 2 per thread ; W chunk = BC rows x 16 k = 4*BC float4 -> WP per thread
+  // loaders: G chunk = 16 rows(k) x 128 s = 512 float4 -> 2 per thread ; W chunk = BC rows x 16 k = 4*BC float4 -> WP per thread.
+  // Two named register sets (a, b) hold the k-steps kt+1 and kt+2: a step's loads are issued two steps before they are
+  // stored to LDS, so their latency hides behind two steps of MFMA work (tools/ubench/pw_steps.hip: 116.9 -> 121.5 TFLOP/s;
+  // __launch_bounds__(256, 2) keeps the wave at 2 per SIMD with the accumulators in VGPRs).  Indexed arrays here end up in
+  // scratch, hence the token-pasted names; w2 only exists for BC = 192.
   const int grow = tid >> 5, gcol = (tid & 31) * 4;   // rows 0..7 (+8)
   const int wrow = tid >> 2, wcol = (tid & 3) * 4;    // rows 0..63 (+64)
-  float4 g0, g1, w0, w1, w2;      // named registers (an indexed array here ends up in scratch); w2 only for BC = 192
-#define PW_GLOAD(k0)                                                                                   \
+  float4 ag0, ag1, aw0, aw1, aw2, bg0, bg1, bw0, bw1, bw2;
+#define PW_GLOAD(P, k0)                                                                                \
   do {                                                                                                 \
-    g0 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + grow) * L + s_blk + gcol);              \
-    g1 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + grow + 8) * L + s_blk + gcol);          \
-    w0 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow) * Ch + (k0) + wcol);              \
-    w1 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 64) * Ch + (k0) + wcol);         \
-    if (WP == 3) w2 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 128) * Ch + (k0) + wcol); \
+    P##g0 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + grow) * L + s_blk + gcol);           \
+    P##g1 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + grow + 8) * L + s_blk + gcol);       \
+    P##w0 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow) * Ch + (k0) + wcol);           \
+    P##w1 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 64) * Ch + (k0) + wcol);      \
+    if (WP == 3) P##w2 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 128) * Ch + (k0) + wcol); \
   } while (0)
-#define PW_SSTORE(buf)                                                                                 \
+#define PW_SSTORE(P, buf)                                                                              \
   do {                                                                                                 \
-    *reinterpret_cast<float4*>(&Gs[buf][grow * LDS_G + gcol]) = g0;                                    \
-    *reinterpret_cast<float4*>(&Gs[buf][(grow + 8) * LDS_G + gcol]) = g1;                              \
-    *reinterpret_cast<float4*>(&Wsm[buf][wrow * LDS_W + wcol]) = w0;                                   \
-    *reinterpret_cast<float4*>(&Wsm[buf][(wrow + 64) * LDS_W + wcol]) = w1;                            \
-    if (WP == 3) *reinterpret_cast<float4*>(&Wsm[buf][(wrow + 128) * LDS_W + wcol]) = w2;              \
+    *reinterpret_cast<float4*>(&Gs[buf][grow * LDS_G + gcol]) = P##g0;                                 \
+    *reinterpret_cast<float4*>(&Gs[buf][(grow + 8) * LDS_G + gcol]) = P##g1;                           \
+    *reinterpret_cast<float4*>(&Wsm[buf][wrow * LDS_W + wcol]) = P##w0;                                \
+    *reinterpret_cast<float4*>(&Wsm[buf][(wrow + 64) * LDS_W + wcol]) = P##w1;                         \
+    if (WP == 3) *reinterpret_cast<float4*>(&Wsm[buf][(wrow + 128) * LDS_W + wcol]) = P##w2;           \
   } while (0)
 
   const int ws_ = wave & 1, wc_ = wave >> 1;
@@ -414,34 +418,44 @@ __global__ __launch_bounds__(256) void k_gemm_pw(const float* __restrict__ g, co
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  PW_GLOAD(0);
-  PW_SSTORE(0);
+#define PW_MMA(buf)                                                                                    \
+  do {                                                                                                 \
+    f32x4 wf[NJ];                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                     \
+      wf[j] = *reinterpret_cast<const f32x4*>(&Wsm[buf][(wc_ * (BC / 2) + j * 16 + lr) * LDS_W + kq * 4]); \
+    const float* gp = &Gs[buf][(kq * 4) * LDS_G + ws_ * 64 + lr];                                      \
+    _Pragma("unroll") for (int st = 0; st < 4; ++st) {                                                 \
+      const float a0 = gp[st * LDS_G], a1 = gp[st * LDS_G + 16], a2 = gp[st * LDS_G + 32], a3 = gp[st * LDS_G + 48]; \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                 \
+        const float bv = wf[j][st];                                                                    \
+        acc[0][j] = mfma16(a0, bv, acc[0][j]);                                                         \
+        acc[1][j] = mfma16(a1, bv, acc[1][j]);                                                         \
+        acc[2][j] = mfma16(a2, bv, acc[2][j]);                                                         \
+        acc[3][j] = mfma16(a3, bv, acc[3][j]);                                                         \
+      }                                                                                                \
+    }                                                                                                  \
+  } while (0)
+
+  const int nk = Ch / BK;      // even: Ch is a multiple of 128
+  PW_GLOAD(a, 0);
+  PW_GLOAD(b, BK);
+  PW_SSTORE(a, 0);
   __syncthreads();
-  const int nk = Ch / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) PW_GLOAD((kt + 1) * BK);
-    f32x4 wf[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) wf[j] = *reinterpret_cast<const f32x4*>(&Wsm[buf][(wc_ * (BC / 2) + j * 16 + lr) * LDS_W + kq * 4]);
-    const float* gp = &Gs[buf][(kq * 4) * LDS_G + ws_ * 64 + lr];
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-      float a0 = gp[st * LDS_G], a1 = gp[st * LDS_G + 16], a2 = gp[st * LDS_G + 32], a3 = gp[st * LDS_G + 48];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const float bv = wf[j][st];
-        acc[0][j] = mfma16(a0, bv, acc[0][j]);
-        acc[1][j] = mfma16(a1, bv, acc[1][j]);
-        acc[2][j] = mfma16(a2, bv, acc[2][j]);
-        acc[3][j] = mfma16(a3, bv, acc[3][j]);
-      }
-    }
-    if (kt + 1 < nk) PW_SSTORE(buf ^ 1);
+  for (int kt = 0; kt < nk; kt += 2) {
+    // even step: multiply k-step kt (buffer 0); set b holds kt+1; set a is refilled with kt+2
+    if (kt + 2 < nk) PW_GLOAD(a, (kt + 2) * BK);
+    PW_MMA(0);
+    PW_SSTORE(b, 1);
+    __syncthreads();
+    // odd step: multiply kt+1 (buffer 1); set a holds kt+2; set b is refilled with kt+3
+    if (kt + 3 < nk) PW_GLOAD(b, (kt + 3) * BK);
+    PW_MMA(1);
+    if (kt + 2 < nk) PW_SSTORE(a, 0);
     __syncthreads();
   }
 #undef PW_GLOAD
 #undef PW_SSTORE
+#undef PW_MMA
   // lane holds z[co = c0 + j*16 + (l&15)][s = s0 + i*16 + (l>>4)*4 + r]
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -578,14 +592,56 @@ int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, 
   return DPMN_OK;
 }
 
+// In-pipeline timing of the pointwise GEMM (bench.py's roofline object): while armed, every dpmn_pointwise_f32 launch is
+// bracketed by a pair of HIP events on the stream it is launched on, so the kernel is timed where it runs -- inside the
+// whole step, at the clocks and cache state of the timed region -- instead of in a separate cold loop.
+namespace {
+struct PwProfile {
+  int armed = 0, count = 0, cap = 0;
+  hipEvent_t* ev = nullptr;
+} g_pwprof;
+}  // namespace
+
+int dpmn_pointwise_profile_begin(int max_launches) {
+  DPMN_REQUIRE(max_launches > 0 && max_launches <= (1 << 16), "pointwise_profile_begin: 1..65536 launches");
+  if (g_pwprof.cap < max_launches) {
+    for (int i = 0; i < 2 * g_pwprof.cap; ++i) (void)hipEventDestroy(g_pwprof.ev[i]);
+    delete[] g_pwprof.ev;
+    g_pwprof.ev = new hipEvent_t[2 * (size_t)max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i)
+      if (hipEventCreate(&g_pwprof.ev[i]) != hipSuccess) return dpmn_set_error(DPMN_ERR_LAUNCH, "pointwise_profile_begin: hipEventCreate failed");
+    g_pwprof.cap = max_launches;
+  }
+  g_pwprof.count = 0;
+  g_pwprof.armed = max_launches;
+  return DPMN_OK;
+}
+
+/* Disarms; call after the stream has been synchronised.  Returns the number of launches timed, their mean in *mean_ms. */
+int dpmn_pointwise_profile_end(float* mean_ms) {
+  g_pwprof.armed = 0;
+  double tot = 0.0;
+  for (int i = 0; i < g_pwprof.count; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_pwprof.ev[2 * i], g_pwprof.ev[2 * i + 1]) != hipSuccess)
+      return dpmn_set_error(DPMN_ERR_LAUNCH, "pointwise_profile_end: events not complete (synchronise the stream first)");
+    tot += ms;
+  }
+  if (mean_ms) *mean_ms = g_pwprof.count ? (float)(tot / g_pwprof.count) : 0.f;
+  return g_pwprof.count;
+}
+
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream) {
   DPMN_REQUIRE(g && w && bias && z && Ch % 128 == 0 && L % 128 == 0, "pointwise: Ch and L must be multiples of 128");
   static const int pw_bc = getenv("DPMN_PW_BC") ? atoi(getenv("DPMN_PW_BC")) : 192;
+  const bool timed = g_pwprof.armed && g_pwprof.count < g_pwprof.armed;
+  if (timed) (void)hipEventRecord(g_pwprof.ev[2 * g_pwprof.count], as_stream(stream));
   if (Ch % 192 == 0 && pw_bc == 192)
     hipLaunchKernelGGL((k_gemm_pw<192>), dim3(L / 128, Ch / 192, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
   else
     hipLaunchKernelGGL((k_gemm_pw<128>), dim3(L / 128, Ch / 128, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
+  if (timed) (void)hipEventRecord(g_pwprof.ev[2 * g_pwprof.count++ + 1], as_stream(stream));
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

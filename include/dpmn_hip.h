@@ -59,6 +59,11 @@ int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_h
 /* z[b] = w (Ch,Ch) . g[b] (Ch,L) + bias : Mlp.pointwise_conv on the raw (B,Ch,r,r) view (pgrm.py:34,37) */
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream);
+/* Measurement hook for bench.py's roofline object: while armed, each dpmn_pointwise_f32 launch (direct or from inside
+ * dpmn_pgrm_forward_f32) is bracketed by HIP events on its own stream, up to max_launches.  _end disarms and returns the
+ * number of launches timed and their mean duration; synchronise the stream before calling it.  Not thread-safe. */
+int dpmn_pointwise_profile_begin(int max_launches);
+int dpmn_pointwise_profile_end(float* mean_ms);
 
 /* ------------------------------------------------------------------ NHWC implicit-GEMM conv (conv.hip) */
 /* One descriptor drives nn.Conv2d / nn.ConvTranspose2d call sites of cmm.py:44-71,86-118 and
