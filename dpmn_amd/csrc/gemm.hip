@@ -443,14 +443,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_pw(const float* __restrict__ g,
   __syncthreads();
   for (int kt = 0; kt < nk; kt += 2) {
     // even step: multiply k-step kt (buffer 0); set b holds kt+1; set a is refilled with kt+2
-    if (kt + 2 < nk) PW_GLOAD(a, (kt + 2) * BK);
+    // (the refills past the end re-read the last k-step instead of being skipped: a conditional load makes hipcc drain
+    // vmcnt(0) at the join, which would also wait for the loads issued a moment ago)
+    PW_GLOAD(a, min(kt + 2, nk - 1) * BK);
     PW_MMA(0);
     PW_SSTORE(b, 1);
     __syncthreads();
     // odd step: multiply kt+1 (buffer 1); set a holds kt+2; set b is refilled with kt+3
-    if (kt + 3 < nk) PW_GLOAD(b, (kt + 3) * BK);
+    PW_GLOAD(b, min(kt + 3, nk - 1) * BK);
     PW_MMA(1);
-    if (kt + 2 < nk) PW_SSTORE(a, 0);
+    PW_SSTORE(a, 0);
     __syncthreads();
   }
 #undef PW_GLOAD
