@@ -274,20 +274,31 @@ __global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image
   float* Z = sm + C;        // [dmid]
   float* A = Z + dmid;      // [C]
   const int b = blockIdx.x;
+  // latency-bound (one block per image): keep several independent loads in flight instead of one dependent chain
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float s = 0.f;
-    for (int p = 0; p < parts_per_image; ++p) s += partial[((size_t)b * parts_per_image + p) * C + c];
-    S[c] = s / (float)L;
+    const float* pp = partial + (size_t)b * parts_per_image * C + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int p = 0;
+    for (; p + 4 <= parts_per_image; p += 4) {
+      s0 += pp[(size_t)p * C]; s1 += pp[(size_t)(p + 1) * C]; s2 += pp[(size_t)(p + 2) * C]; s3 += pp[(size_t)(p + 3) * C];
+    }
+    for (; p < parts_per_image; ++p) s0 += pp[(size_t)p * C];
+    S[c] = ((s0 + s1) + (s2 + s3)) / (float)L;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < dmid; j += blockDim.x) {
-    float a = fc1_b[j];
-    for (int c = 0; c < C; ++c) a += fc1_w[j * C + c] * S[c];
-    Z[j] = gelu_erf(a);
+  // fc1: 8 lanes per output, each sums an eighth of the C products, then a 3-step shuffle reduction
+  for (int j0 = 0; j0 < dmid; j0 += blockDim.x / 8) {
+    const int j = j0 + threadIdx.x / 8, part = threadIdx.x & 7;
+    float a = 0.f;
+    if (j < dmid)
+      for (int c = part; c < C; c += 8) a += fc1_w[j * C + c] * S[c];
+    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    if (j < dmid && part == 0) Z[j] = gelu_erf(a + fc1_b[j]);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float a = fc2_b[c];
+#pragma unroll 8
     for (int j = 0; j < dmid; ++j) a += fc2_w[c * dmid + j] * Z[j];
     A[c] = a;
   }
