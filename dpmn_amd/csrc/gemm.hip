@@ -299,29 +299,32 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
   const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
   // loader mapping: 8 float4 per row
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;   // rows 0..31 (+32 per pass)
-  float4 xr[2], wr[3];
-
-  auto gload = [&](int k0) {
-    int kk = k0;
-    size_t xoff = 0, woff = 0;
-    if (kb_len > 0) { const int kb = k0 / kb_len; kk = k0 - kb * kb_len; xoff = (size_t)kb * x_bstride; woff = (size_t)kb * w_bstride; }
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      const int m = m_blk + lrow + p * 32;
-      xr[p] = (m < M) ? *reinterpret_cast<const float4*>(x + xoff + (size_t)m * ldx + kk + lcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      const int n = n_blk + lrow + p * 32;
-      wr[p] = (n < N) ? *reinterpret_cast<const float4*>(w + woff + (size_t)n * ldw + kk + lcol) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto sstore = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * 32) * LDK + lcol]) = xr[p];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * 32) * LDK + lcol]) = wr[p];
-  };
+  // Two named register sets (a, b), same scheme as k_gemm_pw: the loads of k-step kt+2 are issued at the end of step kt and
+  // stored to LDS at the end of step kt+1, so they are in flight for a whole step of MFMA work and the waits are partial
+  // vmcnt.  Every load is unconditional: rows past M / N are clamped to the last row (their accumulator rows are never
+  // stored) and refills past the last k-step re-read it -- a predicated load is a branch, and hipcc drains vmcnt(0) at joins.
+  float4 ax0, ax1, aw0, aw1, aw2, bx0, bx1, bw0, bw1, bw2;
+  const int xm0 = min(m_blk + lrow, M - 1), xm1 = min(m_blk + lrow + 32, M - 1);
+  const int wn0 = min(n_blk + lrow, N - 1), wn1 = min(n_blk + lrow + 32, N - 1), wn2 = min(n_blk + lrow + 64, N - 1);
+#define KL_GLOAD(P, k0_)                                                                               \
+  do {                                                                                                 \
+    int kk = (k0_);                                                                                    \
+    size_t xoff = 0, woff = 0;                                                                         \
+    if (kb_len > 0) { const int kb = kk / kb_len; kk -= kb * kb_len; xoff = (size_t)kb * x_bstride; woff = (size_t)kb * w_bstride; } \
+    P##x0 = *reinterpret_cast<const float4*>(x + xoff + (size_t)xm0 * ldx + kk + lcol);                \
+    P##x1 = *reinterpret_cast<const float4*>(x + xoff + (size_t)xm1 * ldx + kk + lcol);                \
+    P##w0 = *reinterpret_cast<const float4*>(w + woff + (size_t)wn0 * ldw + kk + lcol);                \
+    P##w1 = *reinterpret_cast<const float4*>(w + woff + (size_t)wn1 * ldw + kk + lcol);                \
+    P##w2 = *reinterpret_cast<const float4*>(w + woff + (size_t)wn2 * ldw + kk + lcol);                \
+  } while (0)
+#define KL_SSTORE(P, buf)                                                                              \
+  do {                                                                                                 \
+    *reinterpret_cast<float4*>(&Xs[buf][lrow * LDK + lcol]) = P##x0;                                   \
+    *reinterpret_cast<float4*>(&Xs[buf][(lrow + 32) * LDK + lcol]) = P##x1;                            \
+    *reinterpret_cast<float4*>(&Ws[buf][lrow * LDK + lcol]) = P##w0;                                   \
+    *reinterpret_cast<float4*>(&Ws[buf][(lrow + 32) * LDK + lcol]) = P##w1;                            \
+    *reinterpret_cast<float4*>(&Ws[buf][(lrow + 64) * LDK + lcol]) = P##w2;                            \
+  } while (0)
 
   const int wm = wave & 1, wn = wave >> 1;
   const int lr = lane & 15, kq = lane >> 4;
@@ -330,40 +333,49 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define KL_MMA(buf)                                                                                    \
+  do {                                                                                                 \
+    const float* xa = &Xs[buf][(wm * 32 + lr) * LDK + kq * 4];                                         \
+    const float* wa = &Ws[buf][(wn * 48 + lr) * LDK + kq * 4];                                         \
+    _Pragma("unroll") for (int kc = 0; kc < BK; kc += 16) {                                            \
+      float4 xf[2], wf[3];                                                                             \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const float4*>(xa + j * 16 * LDK + kc); \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const float4*>(wa + i * 16 * LDK + kc); \
+      _Pragma("unroll") for (int i = 0; i < 3; ++i)                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                \
+          acc[i][j] = mfma16(wf[i].x, xf[j].x, acc[i][j]);                                             \
+          acc[i][j] = mfma16(wf[i].y, xf[j].y, acc[i][j]);                                             \
+          acc[i][j] = mfma16(wf[i].z, xf[j].z, acc[i][j]);                                             \
+          acc[i][j] = mfma16(wf[i].w, xf[j].w, acc[i][j]);                                             \
+        }                                                                                              \
+    }                                                                                                  \
+  } while (0)
 
   const int nk_all = K / BK;
   const int cps = (nk_all + gridDim.z - 1) / gridDim.z;      // K chunks per split (grid.z > 1 only with e.atomic)
   const int kt0 = blockIdx.z * cps;
   const int nk = min(nk_all, kt0 + cps);
   if (kt0 >= nk) return;
-  gload(kt0 * BK);
-  sstore(0);
+  KL_GLOAD(a, kt0 * BK);
+  KL_GLOAD(b, min(kt0 + 1, nk - 1) * BK);
+  KL_SSTORE(a, 0);
   __syncthreads();
-  for (int kt = kt0; kt < nk; ++kt) {
-    const int buf = (kt - kt0) & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
-    const float* xa = &Xs[buf][(wm * 32 + lr) * LDK + kq * 4];
-    const float* wa = &Ws[buf][(wn * 48 + lr) * LDK + kq * 4];
-#pragma unroll
-    for (int kc = 0; kc < BK; kc += 16) {
-      float4 xf[2], wf[3];
-#pragma unroll
-      for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const float4*>(xa + j * 16 * LDK + kc);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) wf[i] = *reinterpret_cast<const float4*>(wa + i * 16 * LDK + kc);
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          acc[i][j] = mfma16(wf[i].x, xf[j].x, acc[i][j]);
-          acc[i][j] = mfma16(wf[i].y, xf[j].y, acc[i][j]);
-          acc[i][j] = mfma16(wf[i].z, xf[j].z, acc[i][j]);
-          acc[i][j] = mfma16(wf[i].w, xf[j].w, acc[i][j]);
-        }
-    }
-    if (kt + 1 < nk) sstore(buf ^ 1);
+  for (int kt = kt0; kt < nk; kt += 2) {
+    // even step: multiply k-step kt (buffer 0); set b holds kt+1; set a is refilled with kt+2
+    KL_GLOAD(a, min(kt + 2, nk - 1) * BK);
+    KL_MMA(0);
+    KL_SSTORE(b, 1);
+    __syncthreads();
+    if (kt + 1 >= nk) break;          // odd number of k-steps (uniform)
+    // odd step: multiply kt+1 (buffer 1); set a holds kt+2; set b is refilled with kt+3
+    KL_GLOAD(b, min(kt + 3, nk - 1) * BK);
+    KL_MMA(1);
+    KL_SSTORE(a, 0);
     __syncthreads();
   }
+#undef KL_GLOAD
+#undef KL_SSTORE
+#undef KL_MMA
   epilogue<3, 2>(acc, m_blk + wm * 32, n_blk + wn * 48, M, N, ldy, y, e, nullptr, BN, n_blk);
 }
 
