@@ -48,7 +48,10 @@ enum { PRO_NONE = 0, PRO_LN = 1, PRO_SKSEL = 2, PRO_ADD = 3, PRO_CAT2 = 4 };
 
 // ---------------------------------------------------------------------------------- epilogue
 // tile (nt, mt): lane holds y[m = m_base + (l&15)][n = n_base + (l>>4)*4 + r]
-template <int NT, int MT>
+// FULL: the caller guarantees that the whole tile lies inside (M, N) -- no edge predicates, i.e. no per-row / per-column
+// branches around the stores (with branches hipcc cannot count its memory operations and drains vmcnt(0), which on gfx9
+// also waits for the stores of the previous tile).
+template <int NT, int MT, bool FULL = false>
 __device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, int M, int N, int ldy, float* y,
                                          const EpiArgs& e, float* red /*LDS >= 4*BN floats or null*/, int bn_cols,
                                          int n_block0) {
@@ -58,7 +61,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, i
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + nt * 16 + lq * 4;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool nfull = (n + 3 < N);
+    const bool nfull = FULL || (n + 3 < N);
     if (e.bias) {
       if (nfull) b4 = *reinterpret_cast<const float4*>(e.bias + n);
       else {
@@ -72,10 +75,11 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, i
     for (int mt = 0; mt < MT; ++mt) {
       const int m = m0 + mt * 16 + lm;
       float v[4] = {acc[nt][mt][0] + b4.x, acc[nt][mt][1] + b4.y, acc[nt][mt][2] + b4.z, acc[nt][mt][3] + b4.w};
-      if (m < M && e.atomic) {
+      const bool min_ = FULL || m < M;
+      if (min_ && e.atomic) {
         for (int r = 0; r < 4; ++r)
           if (n + r < N) atomicAdd(y + (size_t)m * ldy + n + r, acc[nt][mt][r]);
-      } else if (m < M) {
+      } else if (min_) {
         if (e.colsum) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) cs[r] += gelu_erf(v[r]);
@@ -125,7 +129,28 @@ constexpr int WS_BM = 32, WS_BN = 96;
 #define WSTAT_NBUF 1   // single X buffer + second barrier: 51 KB LDS at K = 96 -> 3 blocks per CU (measured 5-8 % faster than 2 x 64 KB)
 #endif
 
-template <int K, int PRO, int TH>   // TH threads: BM = TH/8 token rows per tile (32 or 64), waves (BM/16)(m) x 2(n)
+// EPI (with FULL): 0 = the generic epilogue above (every option a run-time branch); 1 = bias only, 2 = bias + GELU as
+// straight-line code: three unconditional float4 stores per lane.  With no branch between a tile's loads, its stores and
+// the next tile's loads, hipcc counts its vmcnt waits instead of draining to 0 at the top of every tile -- on gfx9 stores
+// count on vmcnt too, so the drain also waited for the previous tile's stores to reach memory.
+template <int EPI>
+__device__ __forceinline__ void epilogue_fast(f32x4 (&acc)[3][1], int m0, int n0, int ldy, float* y, const float4 (&bias4)[3]) {
+  const int lane = threadIdx.x & 63;
+  const int lm = lane & 15, lq = lane >> 4;
+  float* row = y + (size_t)(m0 + lm) * ldy + n0 + lq * 4;
+#pragma unroll
+  for (int nt = 0; nt < 3; ++nt) {
+    const float4 b4 = bias4[nt];      // the lane's 12 bias values, loaded once per block
+    float v[4] = {acc[nt][0][0] + b4.x, acc[nt][0][1] + b4.y, acc[nt][0][2] + b4.z, acc[nt][0][3] + b4.w};
+    if (EPI == 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    }
+    *reinterpret_cast<float4*>(row + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+template <int K, int PRO, int TH, bool FULL = false, int EPI = 0>   // TH threads: BM = TH/8 token rows per tile (32 or 64), waves (BM/16)(m) x 2(n)
 __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                     float* __restrict__ y, int ldy, int M, int N, ProArgs p, EpiArgs e) {
   constexpr int BM = TH / 8, BN = WS_BN, LDK = K + PAD;
@@ -158,7 +183,7 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
 
   auto issue = [&](float4 (&raw)[NRAW][VPT], int tile) {
     const int m = tile * BM + srow;
-    const bool ok = m < M;
+    const bool ok = FULL || m < M;
 #pragma unroll
     for (int v = 0; v < VPT; ++v) {
       if (PRO == PRO_SKSEL) {
@@ -224,13 +249,28 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
 
   const int wm = wave % WMN, wn = wave / WMN;
   const int lr = lane & 15, kq = lane >> 4;
+  float4 bias4[3] = {};
+  if constexpr (EPI != 0) {
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) bias4[nt] = *reinterpret_cast<const float4*>(e.bias + n_blk + wn * 48 + nt * 16 + kq * 4);
+  }
   const int stride = gridDim.x;
   int tile = blockIdx.x;
-  if (tile < tiles) issue(rawA, tile);
-  if (tile + stride < tiles) issue(rawB, tile + stride);
+  if (FULL) {                            // (grid.x <= tiles, so `tile` itself is valid)
+    issue(rawA, tile);
+    issue(rawB, min(tile + stride, tiles - 1));
+  } else {
+    if (tile < tiles) issue(rawA, tile);
+    if (tile + stride < tiles) issue(rawB, tile + stride);
+  }
   __syncthreads();                       // Ws / lng visible
-  if (tile < tiles) commit(rawA, tile, 0);
-  if (tile + 2 * stride < tiles) issue(rawA, tile + 2 * stride);
+  if (FULL) {
+    commit(rawA, tile, 0);
+    issue(rawA, min(tile + 2 * stride, tiles - 1));
+  } else {
+    if (tile < tiles) commit(rawA, tile, 0);
+    if (tile + 2 * stride < tiles) issue(rawA, tile + 2 * stride);
+  }
   int buf = 0;
   // one pipeline step: MFMA on Xs[buf] (tile), commit tile+stride from RAWN into Xs[buf^1], refill RAWN with tile+3*stride
 // experiment hooks (tools/variants): -DWSTAT_NOMFMA runs one k-chunk only, -DWSTAT_NOEPI skips the epilogue
@@ -261,10 +301,19 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
     /* commit BEFORE the epilogue's stores: vmcnt retires in order, waiting for loads issued after stores   \
        would also wait for those stores */                                                                   \
     if (WSTAT_NBUF == 1) __syncthreads(); /* single X buffer: everyone is done reading it */                 \
-    if (tile + stride < tiles) commit(RAWN, tile + stride, buf ^ 1);                                         \
-    if (tile + 3 * stride < tiles) issue(RAWN, tile + 3 * stride);                                           \
-    WSTAT_EPI_GUARD epilogue<3, 1>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk); \
-    if (e.colsum) {                                                                                          \
+    if constexpr (FULL) { /* unconditional (tile index clamped): a branch here costs the counted vmcnt waits */ \
+      commit(RAWN, min(tile + stride, tiles - 1), buf ^ 1);                                                  \
+      issue(RAWN, min(tile + 3 * stride, tiles - 1));                                                        \
+    } else {                                                                                                 \
+      if (tile + stride < tiles) commit(RAWN, tile + stride, buf ^ 1);                                       \
+      if (tile + 3 * stride < tiles) issue(RAWN, tile + 3 * stride);                                         \
+    }                                                                                                        \
+    if constexpr (EPI != 0) {                                                                                \
+      WSTAT_EPI_GUARD epilogue_fast<EPI>(acc, tile * BM + wm * 16, n_blk + wn * 48, ldy, y, bias4);          \
+    } else {                                                                                                 \
+      WSTAT_EPI_GUARD epilogue<3, 1, FULL>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk); \
+    }                                                                                                        \
+    if (EPI == 0 && e.colsum) {                                                                              \
       __syncthreads();                                                                                       \
       for (int c = tid; c < BN; c += TH) {                                                                   \
         const int wn_c = c / 48;                                                                             \
@@ -484,14 +533,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_pw(const float* __restrict__ g,
   }
 }
 
-template <int K, int PRO, int TH>
+template <int K, int PRO, int TH, bool FULL = false, int EPI = 0>
 int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
                      const EpiArgs& e, hipStream_t st, int target_blocks) {
   constexpr int BM = TH / 8;
   const size_t smem = (size_t)((WS_BN + WSTAT_NBUF * BM) * (K + PAD) + 4 * WS_BN + 2 * K) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstat<K, PRO, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstat<K, PRO, TH, FULL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const int tiles = cdiv(M, BM), ny = cdiv(N, WS_BN);
@@ -499,7 +548,7 @@ int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy,
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
   dim3 grid(gx, ny);
-  hipLaunchKernelGGL((k_gemm_wstat<K, PRO, TH>), grid, dim3(TH), smem, st, x, ldx, w, y, ldy, M, N, p, e);
+  hipLaunchKernelGGL((k_gemm_wstat<K, PRO, TH, FULL, EPI>), grid, dim3(TH), smem, st, x, ldx, w, y, ldy, M, N, p, e);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -512,7 +561,15 @@ int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, in
   // column-sum epilogue (SKConv GAP partials)
   static const int big = getenv("DPMN_WSTAT_TH") ? atoi(getenv("DPMN_WSTAT_TH")) : 512;
   if constexpr (K <= 128) {
-    if (big == 512 && !e.colsum && M >= 4096) return launch_wholeK_th<K, PRO, 512>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
+    if (big == 512 && !e.colsum && M >= 4096) {
+      if (M % 64 == 0 && N % WS_BN == 0 && !e.atomic) {    // every tile interior: the predicate-free instantiations
+        const bool plain = e.bias && !e.res1 && !e.res2 && ldy % 4 == 0;
+        if (plain && e.act == ACT_NONE) return launch_wholeK_th<K, PRO, 512, true, 1>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
+        if (plain && e.act == ACT_GELU) return launch_wholeK_th<K, PRO, 512, true, 2>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
+        return launch_wholeK_th<K, PRO, 512, true>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
+      }
+      return launch_wholeK_th<K, PRO, 512>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
+    }
   }
   return launch_wholeK_th<K, PRO, 256>(x, ldx, w, y, ldy, M, N, p, e, st, WSTAT_NBUF == 1 ? 768 : 512);
 }
