@@ -129,7 +129,7 @@ constexpr int WS_BM = 32, WS_BN = 96;
 #define WSTAT_NBUF 1   // single X buffer + second barrier: 51 KB LDS at K = 96 -> 3 blocks per CU (measured 5-8 % faster than 2 x 64 KB)
 #endif
 
-// EPI (with FULL): 0 = the generic epilogue above (every option a run-time branch); 1 = bias only, 2 = bias + GELU as
+// EPI (with FULL): 0 = the generic epilogue above (every option a run-time branch); 1 = (bias), 2 = (bias) + GELU as
 // straight-line code: three unconditional float4 stores per lane.  With no branch between a tile's loads, its stores and
 // the next tile's loads, hipcc counts its vmcnt waits instead of draining to 0 at the top of every tile -- on gfx9 stores
 // count on vmcnt too, so the drain also waited for the previous tile's stores to reach memory.
@@ -252,7 +252,8 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
   float4 bias4[3] = {};
   if constexpr (EPI != 0) {
 #pragma unroll
-    for (int nt = 0; nt < 3; ++nt) bias4[nt] = *reinterpret_cast<const float4*>(e.bias + n_blk + wn * 48 + nt * 16 + kq * 4);
+    for (int nt = 0; nt < 3; ++nt)
+      if (e.bias) bias4[nt] = *reinterpret_cast<const float4*>(e.bias + n_blk + wn * 48 + nt * 16 + kq * 4);
   }
   const int stride = gridDim.x;
   int tile = blockIdx.x;
@@ -563,7 +564,7 @@ int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, in
   if constexpr (K <= 128) {
     if (big == 512 && !e.colsum && M >= 4096) {
       if (M % 64 == 0 && N % WS_BN == 0 && !e.atomic) {    // every tile interior: the predicate-free instantiations
-        const bool plain = e.bias && !e.res1 && !e.res2 && ldy % 4 == 0;
+        const bool plain = !e.res1 && !e.res2 && ldy % 4 == 0;      // bias optional (data-gradient GEMMs have none)
         if (plain && e.act == ACT_NONE) return launch_wholeK_th<K, PRO, 512, true, 1>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
         if (plain && e.act == ACT_GELU) return launch_wholeK_th<K, PRO, 512, true, 2>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
         return launch_wholeK_th<K, PRO, 512, true>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
