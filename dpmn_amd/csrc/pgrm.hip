@@ -8,6 +8,7 @@
 // Reference lines: PatchEmbed 419-426 (+prior_fusion 548), WindowAttention.forward 197-266,
 // SKConv gate 86-91, Mlp depthwise 34-36, tail 559-565, SwinTransformerBlock.forward 315-331,
 // PGRM.forward 546-565.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -244,6 +245,149 @@ __global__ __launch_bounds__(256) void k_window_attn(const float* __restrict__ q
 #pragma unroll
   for (int d = 0; d < D; d += 4)
     *reinterpret_cast<float4*>(dst + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+}
+
+// ---------------------------------------------------------------------------------- window attention on the matrix cores
+// 8x8 windows, head dim 16 (the group that carries 76 % of the attention FLOPs): same block / slab /
+// LDS staging as k_window_attn (block = 2 windows x 2 heads, one wave per (window, head)), but QK^T and PV run as
+// v_mfma_f32_16x16x4_f32 instead of 64 x 64 x 16 scalar FMAs per lane:
+//   S^T tile (16 keys x 16 queries) = K (A operand: rows = keys) . Q^T (B operand: columns = queries); the reduction index of
+//   one MFMA is d = 4*kq + s, so one ds_read_b128 per operand tile feeds the 4 k-steps.  Lane (lr, kq) then holds
+//   S^T[key = 16t + 4kq + r][query = 16qt + lr]: a query's 64 logits sit in the 16 accumulator values of 4 lanes, and the
+//   softmax reduction over keys is a 16-value scan plus two xor-shuffles (16, 32).
+//   O^T (16 d x 16 queries) = V^T (A: rows = d) . P (B).  The B operand of reduction step (t, r) is the key 16t + 4kq + r --
+//   exactly the accumulator element the lane already holds, so P never leaves its registers (no LDS transpose); V^T comes
+//   from the staged V rows with one ds_read_b32 per step, shared by the 4 query tiles.
+// The result lands as O[query][d = 4kq + r]: one float4 store per lane and query tile.
+__global__ __launch_bounds__(256) void k_window_attn8_mfma(const float* __restrict__ q, const float* __restrict__ kv,
+                                                            const float* __restrict__ bias_table, float* __restrict__ out,
+                                                            int B, int H, int W, int C, int g, int shift) {
+  constexpr int WS = 8, D = 16, N = 64, CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tbl = smem;                            // [TBL][2]
+  float* base = smem + ((TBL * 2 + 3) & ~3);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int slab_in_blk = wave >> 1, head = wave & 1;
+  float* Qs = base + slab_in_blk * 3 * N * LDR;
+  float* Ks = Qs + N * LDR;
+  float* Vs = Ks + N * LDR;
+  int* reg_s = reinterpret_cast<int*>(base + 2 * 3 * N * LDR) + slab_in_blk * N;
+
+  const int L = H * W;
+  const int slabs_per_img = L / N;
+  const long slab = (long)blockIdx.x * 2 + slab_in_blk;
+  const int b = slab / slabs_per_img;
+  const int t0 = (slab % slabs_per_img) * N;         // first window-major token of the window
+  const int nWc = W / WS;
+  const bool active = b < B;
+
+  for (int i = threadIdx.x; i < TBL * 2; i += 256) tbl[i] = bias_table[i];
+  if (active) {
+    const int tl = threadIdx.x & 127;
+    constexpr int V4 = CG / 4;
+    for (int i = tl; i < N * V4; i += 128) {
+      const int r = i / V4, c4 = (i % V4) * 4;
+      const int t = t0 + r;
+      const int win = t / N, n = t % N;
+      const int hr = (win / nWc) * WS + n / WS, wcol = (win % nWc) * WS + n % WS;       // rolled-frame coordinates
+      const size_t src = (size_t)b * L + ((hr + shift) % H) * W + (wcol + shift) % W;  // source token (roll by -shift)
+      *reinterpret_cast<float4*>(Ks + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + src * 2 * C + g * CG + c4);
+      *reinterpret_cast<float4*>(Vs + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + src * 2 * C + C + g * CG + c4);
+      *reinterpret_cast<float4*>(Qs + r * LDR + c4) = *reinterpret_cast<const float4*>(q + src * C + g * CG + c4);
+      if (c4 == 0) {
+        const int rh = hr < H - WS ? 0 : (hr < H - shift ? 1 : 2), rw = wcol < W - WS ? 0 : (wcol < W - shift ? 1 : 2);
+        reg_s[r] = 3 * rh + rw;
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+
+  const int lr = lane & 15, kq = lane >> 4;
+  const float scale = 0.25f;                       // 16^-0.5
+  // ---- S^T = K . Q^T
+  f32x4 kf[4], qf[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    kf[t] = *reinterpret_cast<const f32x4*>(Ks + (16 * t + lr) * LDR + head * D + 4 * kq);
+    qf[t] = *reinterpret_cast<const f32x4*>(Qs + (16 * t + lr) * LDR + head * D + 4 * kq);
+    qf[t] *= scale;
+  }
+  f32x4 sacc[4][4];       // [key tile][query tile]
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) a = mfma16(kf[t][s4], qf[qt][s4], a);
+      sacc[t][qt] = a;
+    }
+  // ---- + relative position bias, shift mask; softmax over the keys of each query column
+  float inv[4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int nq = 16 * qt + lr, iq = nq / WS, jq = nq % WS;
+    const int my_reg = reg_s[nq];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = 16 * t + 4 * kq + r, im = m / WS, jm = m % WS;
+        float a = sacc[t][qt][r] + tbl[((iq - im + WS - 1) * (2 * WS - 1) + (jq - jm + WS - 1)) * 2 + head];
+        if (shift > 0 && reg_s[m] != my_reg) a += -100.0f;
+        sacc[t][qt][r] = a;
+        mx = fmaxf(mx, a);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = expf(sacc[t][qt][r] - mx);
+        sacc[t][qt][r] = p;
+        den += p;
+      }
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    inv[qt] = 1.0f / den;
+  }
+  // ---- O^T = V^T . P
+  f32x4 oacc[4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) oacc[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float vt = Vs[(16 * t + 4 * kq + r) * LDR + head * D + lr];      // V^T[d = lr][key = 16t + 4kq + r]
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) oacc[qt] = mfma16(vt, sacc[t][qt][r], oacc[qt]);
+    }
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const int tq = t0 + 16 * qt + lr;
+    float* dst = out + ((size_t)b * L + tq) * C + g * CG + head * D + 4 * kq;
+    *reinterpret_cast<float4*>(dst) = make_float4(oacc[qt][0] * inv[qt], oacc[qt][1] * inv[qt], oacc[qt][2] * inv[qt], oacc[qt][3] * inv[qt]);
+  }
+}
+
+int launch_window_attn8_mfma(const float* q, const float* kv, const float* table, float* out, int B, int H, int W, int C, int g,
+                             int shift, hipStream_t st) {
+  constexpr int N = 64, LDR = 36, TBL = 15 * 15;
+  const size_t smem = (size_t)(((TBL * 2 + 3) & ~3) + 2 * 3 * N * LDR) * 4 + 2 * N * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn8_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const long slabs = (long)B * (H * W / 64);
+  hipLaunchKernelGGL(k_window_attn8_mfma, dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, table, out, B, H, W, C, g, shift);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
 }
 
 template <int WS, int D, bool DROP>
@@ -494,6 +638,12 @@ int dpmn_window_attn_drop_f32(const float* q, const float* kv, const float* cons
     DPMN_REQUIRE(H % ws == 0 && W % ws == 0, "window_attn: padding path (H or W not divisible by window) would crash the reference (quirk Q1)");
     DPMN_REQUIRE(sh >= 0 && sh < ws, "window_attn: shift must be in [0, window)");
     int rc = DPMN_ERR_ARG;
+    static const int wa_mfma = getenv("DPMN_WATTN_MFMA") ? atoi(getenv("DPMN_WATTN_MFMA")) : 1;
+    if (ws == 8 && D == 16 && p_drop == 0.f && wa_mfma) {
+      rc = launch_window_attn8_mfma(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st);
+      if (rc != DPMN_OK) return rc;
+      continue;
+    }
 #define WA_CASE(WSV, DV) if (ws == WSV && D == DV) rc = p_drop > 0.f \
       ? launch_window_attn<WSV, DV, true>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, p_drop, seed, st) \
       : launch_window_attn<WSV, DV, false>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, 0.f, 0ull, st); else
