@@ -83,6 +83,25 @@ def test_pointwise(dev):
     assert_close(got, ref, ATOL, RTOL, "pointwise")
 
 
+def test_pointwise_profile_hook_times_every_launch(dev):
+    """bench.py's roofline timing: while armed the library brackets each pointwise launch with HIP events on its stream."""
+    import ctypes
+    from dpmn_amd import _abi, ops
+    g, w, b = u("g", (2, 1024, 384)).to(dev), u("w", (384, 384), -0.1, 0.1).to(dev), u("b", (384,)).to(dev)
+    ops.pointwise(g, w, b)
+    _abi.check(_abi.lib.dpmn_pointwise_profile_begin(3))
+    for _ in range(5):                      # only the first 3 launches are timed
+        ops.pointwise(g, w, b)
+    torch.cuda.synchronize()
+    mean_ms = ctypes.c_float(0.0)
+    assert _abi.lib.dpmn_pointwise_profile_end(ctypes.byref(mean_ms)) == 3
+    assert 1e-3 < mean_ms.value < 5.0
+    ops.pointwise(g, w, b)                  # disarmed: nothing recorded
+    torch.cuda.synchronize()
+    assert _abi.lib.dpmn_pointwise_profile_end(ctypes.byref(mean_ms)) == 3
+    assert _abi.lib.dpmn_pointwise_profile_begin(0) != 0        # rejected loudly
+
+
 # ------------------------------------------------------------------------------ PGRM pieces
 def test_patch_embed(dev):
     from dpmn_amd import ops
