@@ -129,13 +129,13 @@ constexpr int WS_BM = 32, WS_BN = 96;
 #define WSTAT_NBUF 1   // single X buffer + second barrier: 51 KB LDS at K = 96 -> 3 blocks per CU (measured 5-8 % faster than 2 x 64 KB)
 #endif
 
-// EPI (with FULL): 0 = the generic epilogue above (every option a run-time branch); 1 = (bias), 2 = (bias) + GELU, 3 = (bias) + two residuals as
+// EPI (with FULL): 0 = the generic epilogue above (every option a run-time branch); 1 = (bias), 2 = (bias) + GELU, 3 = (bias) + two residuals, 4 = (bias) + GELU column sums as
 // straight-line code: three unconditional float4 stores per lane.  With no branch between a tile's loads, its stores and
 // the next tile's loads, hipcc counts its vmcnt waits instead of draining to 0 at the top of every tile -- on gfx9 stores
 // count on vmcnt too, so the drain also waited for the previous tile's stores to reach memory.
 template <int EPI>
 __device__ __forceinline__ void epilogue_fast(f32x4 (&acc)[3][1], int m0, int n0, int ldy, float* y, const float4 (&bias4)[3],
-                                              const float* res1, const float* res2) {
+                                              const float* res1, const float* res2, float* red, int bn_cols, int n_block0) {
   const int lane = threadIdx.x & 63;
   const int lm = lane & 15, lq = lane >> 4;
   const size_t off = (size_t)(m0 + lm) * ldy + n0 + lq * 4;
@@ -160,6 +160,15 @@ __device__ __forceinline__ void epilogue_fast(f32x4 (&acc)[3][1], int m0, int n0
       v[0] += r2[nt].x; v[1] += r2[nt].y; v[2] += r2[nt].z; v[3] += r2[nt].w;
     }
     *reinterpret_cast<float4*>(y + off + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);
+    if (EPI == 4) {                   // SKConv global-average-pool partials: column sums of GELU(y) over the tile's rows
+      const int wave = threadIdx.x >> 6;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float c = gelu_erf(v[r]);
+        c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 8, 64);
+        if (lm == 0) red[wave * bn_cols + (n0 - n_block0) + nt * 16 + lq * 4 + r] = c;
+      }
+    }
   }
 }
 
@@ -323,11 +332,11 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
       if (tile + 3 * stride < tiles) issue(RAWN, tile + 3 * stride);                                         \
     }                                                                                                        \
     if constexpr (EPI != 0) {                                                                                \
-      WSTAT_EPI_GUARD epilogue_fast<EPI>(acc, tile * BM + wm * 16, n_blk + wn * 48, ldy, y, bias4, e.res1, e.res2); \
+      WSTAT_EPI_GUARD epilogue_fast<EPI>(acc, tile * BM + wm * 16, n_blk + wn * 48, ldy, y, bias4, e.res1, e.res2, red, BN, n_blk); \
     } else {                                                                                                 \
       WSTAT_EPI_GUARD epilogue<3, 1, FULL>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk); \
     }                                                                                                        \
-    if (EPI == 0 && e.colsum) {                                                                              \
+    if ((EPI == 0 && e.colsum) || EPI == 4) {                                                                \
       __syncthreads();                                                                                       \
       for (int c = tid; c < BN; c += TH) {                                                                   \
         const int wn_c = c / 48;                                                                             \
@@ -588,6 +597,10 @@ int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, in
       }
       return launch_wholeK_th<K, PRO, 512>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
     }
+  }
+  if constexpr (PRO == PRO_NONE && K == 96) {      // SKConv projection + GAP partials, straight-line (pgrm.py:84-86)
+    if (e.colsum && M % 32 == 0 && N % WS_BN == 0 && !e.atomic && !e.res1 && !e.res2 && e.act == ACT_NONE && ldy % 4 == 0)
+      return launch_wholeK_th<K, PRO, 256, true, 4>(x, ldx, w, y, ldy, M, N, p, e, st, WSTAT_NBUF == 1 ? 768 : 512);
   }
   return launch_wholeK_th<K, PRO, 256>(x, ldx, w, y, ldy, M, N, p, e, st, WSTAT_NBUF == 1 ? 768 : 512);
 }
