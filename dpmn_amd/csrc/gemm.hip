@@ -129,7 +129,7 @@ constexpr int WS_BM = 32, WS_BN = 96;
 #define WSTAT_NBUF 1   // single X buffer + second barrier: 51 KB LDS at K = 96 -> 3 blocks per CU (measured 5-8 % faster than 2 x 64 KB)
 #endif
 
-// EPI (with FULL): 0 = the generic epilogue above (every option a run-time branch); 1 = (bias), 2 = (bias) + GELU, 3 = (bias) + two residuals, 4 = (bias) + GELU column sums as
+// EPI (with FULL): 0 = the generic epilogue above (every option a run-time branch); 1 = (bias), 2 = (bias) + GELU, 3 / 5 = (bias) + two / one residuals, 4 = (bias) + GELU column sums as
 // straight-line code: three unconditional float4 stores per lane.  With no branch between a tile's loads, its stores and
 // the next tile's loads, hipcc counts its vmcnt waits instead of draining to 0 at the top of every tile -- on gfx9 stores
 // count on vmcnt too, so the drain also waited for the previous tile's stores to reach memory.
@@ -140,11 +140,11 @@ __device__ __forceinline__ void epilogue_fast(f32x4 (&acc)[3][1], int m0, int n0
   const int lm = lane & 15, lq = lane >> 4;
   const size_t off = (size_t)(m0 + lm) * ldy + n0 + lq * 4;
   float4 r1[3], r2[3];
-  if (EPI == 3) {                     // both residuals (SwinTransformerBlock shortcut + SKConv feats, pgrm.py:96,329)
+  if (EPI == 3 || EPI == 5) {         // 3: both residuals (SwinTransformerBlock shortcut + SKConv feats, pgrm.py:96,329); 5: one
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       r1[nt] = *reinterpret_cast<const float4*>(res1 + off + nt * 16);
-      r2[nt] = *reinterpret_cast<const float4*>(res2 + off + nt * 16);
+      if (EPI == 3) r2[nt] = *reinterpret_cast<const float4*>(res2 + off + nt * 16);
     }
   }
 #pragma unroll
@@ -155,10 +155,8 @@ __device__ __forceinline__ void epilogue_fast(f32x4 (&acc)[3][1], int m0, int n0
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     }
-    if (EPI == 3) {
-      v[0] += r1[nt].x; v[1] += r1[nt].y; v[2] += r1[nt].z; v[3] += r1[nt].w;
-      v[0] += r2[nt].x; v[1] += r2[nt].y; v[2] += r2[nt].z; v[3] += r2[nt].w;
-    }
+    if (EPI == 3 || EPI == 5) { v[0] += r1[nt].x; v[1] += r1[nt].y; v[2] += r1[nt].z; v[3] += r1[nt].w; }
+    if (EPI == 3) { v[0] += r2[nt].x; v[1] += r2[nt].y; v[2] += r2[nt].z; v[3] += r2[nt].w; }
     *reinterpret_cast<float4*>(y + off + nt * 16) = make_float4(v[0], v[1], v[2], v[3]);
     if (EPI == 4) {                   // SKConv global-average-pool partials: column sums of GELU(y) over the tile's rows
       const int wave = threadIdx.x >> 6;
@@ -589,9 +587,13 @@ int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, in
         const bool plain = !e.res1 && !e.res2 && ldy % 4 == 0;      // bias optional (data-gradient GEMMs have none)
         if (plain && e.act == ACT_NONE) return launch_wholeK_th<K, PRO, 512, true, 1>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
         if (plain && e.act == ACT_GELU) return launch_wholeK_th<K, PRO, 512, true, 2>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
-        if constexpr (PRO == PRO_SKSEL) {
+        if constexpr (PRO == PRO_SKSEL || PRO == PRO_NONE) {
           if (e.res1 && e.res2 && e.act == ACT_NONE && ldy % 4 == 0)
             return launch_wholeK_th<K, PRO, 512, true, 3>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
+        }
+        if constexpr (PRO == PRO_NONE) {
+          if (e.res1 && !e.res2 && e.act == ACT_NONE && ldy % 4 == 0)
+            return launch_wholeK_th<K, PRO, 512, true, 5>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
         }
         return launch_wholeK_th<K, PRO, 512, true>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
       }
