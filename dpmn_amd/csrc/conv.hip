@@ -114,7 +114,11 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, floa
   }
 }
 
-template <int BM, int BN, int WM, int WN>
+// UNI: cin and every input segment are multiples of 32, so one 32-wide k-chunk lies in ONE segment and ONE tap for the whole
+// block.  The chunk is then decoded once, on scalars, and every tile load is a raw buffer load whose hardware range check
+// returns 0 for the lanes that fall outside the image (offset 0x80000000) or past Cout -- no predicated loads, i.e. no
+// branches whose joins make hipcc drain vmcnt(0) in front of the MFMA block.
+template <int BM, int BN, int WM, int WN, bool UNI = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
   constexpr int APASS = BM / 32, BPASS = (BN + 31) / 32;
@@ -187,6 +191,39 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  auto gload_uni = [&](int k0) {
+    const int tap = k0 / a.cin, c0 = k0 - tap * a.cin;          // wave-uniform
+    const int ky = tap / a.KW, kx = tap - ky * a.KW;
+    const int dy = ky * a.dil_y, dx = kx * a.dil_x;
+    const int seg = c0 >= c01 ? 2 : (c0 >= a.cseg[0] ? 1 : 0);
+    const int cl = c0 - (seg == 2 ? c01 : (seg == 1 ? a.cseg[0] : 0)) + lcol;
+    const float* src = a.in[seg];
+    const int cs = a.cseg[seg];
+    const float* sc = a.in_scale[seg];
+    const float* sh = a.in_shift[seg];
+    const bool tap_ok = tap < ktaps;
+    has_aff = sc != nullptr && tap_ok;
+    if (has_aff) { s4r = *reinterpret_cast<const float4*>(sc + cl); h4r = *reinterpret_cast<const float4*>(sh + cl); }
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, a.B * a.Hin * a.Win * cs * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ph.w), 0, a.Cout * a.Kp * 4, 0x00020000);
+    vmask = 0;
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const int iy = py[p] + dy, ix = px[p] + dx;
+      const bool ok = pb[p] >= 0 && tap_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      // branch-free: bit 31 set = beyond num_records (< 2^31, checked by the launcher) whatever the low bits are
+      const unsigned off = (unsigned)((((pb[p] * a.Hin + iy) * a.Win + ix) * cs + cl) * 4) | (ok ? 0u : 0x80000000u);
+      xr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0));
+      vmask |= (ok ? 1u : 0u) << p;
+    }
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) {
+      const int r = lrow + p * 32;
+      if (BN % 32 == 0 || r < BN)       // rows past Cout are beyond num_records: the range check returns 0
+        wr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, ((n_blk + r) * a.Kp + k0 + lcol) * 4, 0, 0));
+    }
+  };
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
@@ -217,11 +254,15 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   const int cps = (nk_all + a.ksplit - 1) / a.ksplit;          // chunks per split
   const int kt0 = zsplit * cps;
   const int nk = min(nk_all, kt0 + cps);
-  if (kt0 < nk) { gload(kt0 * BK); sstore(0); }
+  if (kt0 < nk) {
+    if (UNI) gload_uni(kt0 * BK); else gload(kt0 * BK);
+    sstore(0);
+  }
   __syncthreads();
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = (kt - kt0) & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
+    if (UNI) gload_uni(min(kt + 1, nk - 1) * BK);      // unconditional: the refill past the end re-reads the last chunk
+    else if (kt + 1 < nk) gload((kt + 1) * BK);
     const float* xa = &Xs[buf][(wm * (MT * 16) + lr) * LDK + kq * 4];
     const float* wa = &Ws[buf][(wn * (NT * 16) + lr) * LDK + kq * 4];
 #pragma unroll
@@ -238,7 +279,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[i][s], xf[j][s], acc[i][j]);
     }
-    if (kt + 1 < nk) sstore(buf ^ 1);
+    if (UNI || kt + 1 < nk) sstore(buf ^ 1);
     __syncthreads();
   }
 
@@ -726,7 +767,13 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   a.ksplit = S;
   a.partial = S > 1 ? ws : nullptr;
   dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN), S * nph);
-  hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+  // segment-uniform chunks (all channel counts multiples of 32) and 32-bit byte offsets: the buffer-load instantiation
+  static const int uni_on = getenv("DPMN_CONV_UNI") ? atoi(getenv("DPMN_CONV_UNI")) : 1;
+  bool uni = uni_on && a.cin % 32 == 0 && (size_t)a.Cout * a.Kp * 4 < (1ull << 31);
+  for (int i = 0; i < 3; ++i)
+    uni = uni && a.cseg[i] % 32 == 0 && (size_t)a.B * a.Hin * a.Win * a.cseg[i] * 4 < (1ull << 31);
+  if (uni) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
   DPMN_CHECK_LAUNCH();
   if (S > 1) {
     // rows per block: 64 amortises the BatchNorm-statistics atomics on big outputs; small outputs need the parallelism
