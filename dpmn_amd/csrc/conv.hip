@@ -442,9 +442,50 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
     }
     return val;
   };
+  // All of a thread's halo elements are fetched first, as raw buffer loads (the range check returns 0 for pixels outside the
+  // image: no predicated load, no branch, so the HVD loads are in flight together instead of one wait per element), then
+  // transformed and stored.  256 % 8 == 0: every element of a thread has the same channel quad, hence one affine pair.
+  constexpr int HVD = (NPX * 8 + 255) / 256;
+  constexpr bool HALO_BUF = TH == 4;      // (8-row tiles, 6-12 loads per thread: measured slower than the per-element loop)
   auto stage_halo_direct = [&](int chunk) {
-    for (int i = tid; i < NPX * 8; i += 256)
-      *reinterpret_cast<float4*>(halo + (i >> 3) * LDK + (i & 7) * 4) = halo_elem(chunk, i);
+    if constexpr (!HALO_BUF) {
+      for (int i = tid; i < NPX * 8; i += 256)
+        *reinterpret_cast<float4*>(halo + (i >> 3) * LDK + (i & 7) * 4) = halo_elem(chunk, i);
+      return;
+    }
+    const int c0 = chunk * BK;                                   // wave-uniform chunk decode
+    const int seg = c0 >= c01 ? 2 : (c0 >= a.cseg[0] ? 1 : 0);
+    const int cl = c0 - (seg == 2 ? c01 : (seg == 1 ? a.cseg[0] : 0)) + (tid & 7) * 4;
+    const float* src = a.in[seg];
+    const int cs = a.cseg[seg];
+    const float* sc = a.in_scale[seg];
+    const float* sh = a.in_shift[seg];
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, a.B * a.Hin * a.Win * cs * 4, 0x00020000);
+    float4 raw[HVD];
+    unsigned inb = 0;
+#pragma unroll
+    for (int v = 0; v < HVD; ++v) {
+      const int px = (tid >> 3) + v * 32;
+      const int iy = ty0 + px / HW_ - padk, ix = tx0 + px % HW_ - padk;
+      const bool ok = px < NPX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      const unsigned off = (unsigned)((((b * a.Hin + iy) * a.Win + ix) * cs + cl) * 4) | (ok ? 0u : 0x80000000u);
+      raw[v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0));
+      inb |= (ok ? 1u : 0u) << v;
+    }
+    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sc) { s4 = *reinterpret_cast<const float4*>(sc + cl); h4 = *reinterpret_cast<const float4*>(sh + cl); }
+#pragma unroll
+    for (int v = 0; v < HVD; ++v) {
+      const int px = (tid >> 3) + v * 32;
+      float4 val = raw[v];
+      if (sc) { val.x = val.x * s4.x + h4.x; val.y = val.y * s4.y + h4.y; val.z = val.z * s4.z + h4.z; val.w = val.w * s4.w + h4.w; }
+      if (a.pro_act != ACT_NONE) {
+        val.x = apply_act(val.x, a.pro_act, 0.f); val.y = apply_act(val.y, a.pro_act, 0.f);
+        val.z = apply_act(val.z, a.pro_act, 0.f); val.w = apply_act(val.w, a.pro_act, 0.f);
+      }
+      if (!((inb >> v) & 1u)) val = make_float4(0.f, 0.f, 0.f, 0.f);      // padding stays exactly 0 after the transform
+      if (HVD * 32 == NPX || px < NPX) *reinterpret_cast<float4*>(halo + px * LDK + (tid & 7) * 4) = val;
+    }
   };
   auto issue_halo = [&](int chunk) {
 #pragma unroll
@@ -843,7 +884,8 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   const bool halo_ok = a.stride == 1 && a.dil_y == 1 && a.dil_x == 1 && a.KH == a.KW && (a.KH == 3 || a.KH == 9) &&
                        a.pad_y == (a.KH - 1) / 2 && a.pad_x == a.pad_y && a.Hin % 8 == 0 && a.Win % 16 == 0 && a.ostep == 1 &&
                        a.Hp == a.Hin && a.Wp == a.Win && cin % 32 == 0 && a.cseg[0] % 32 == 0 && a.cseg[1] % 32 == 0 &&
-                       a.cseg[2] % 32 == 0 && M >= 1024;
+                       a.cseg[2] % 32 == 0 && M >= 1024 &&
+                       (size_t)a.B * a.Hin * a.Win * (size_t)cin * 4 < (1ull << 31);   // 32-bit buffer-load offsets
   // too few 8x16-pixel tiles to fill 256 CUs (deep decoder levels with 3-segment inputs): split-K implicit GEMM instead
   const bool halo_starved = (M / 128) * cdiv(a.Cout, 64) < 256 && a.Cout >= 128 && ws != nullptr;
   static const bool c4_on = !(getenv("DPMN_CONV_C4") && atoi(getenv("DPMN_CONV_C4")) == 0);
