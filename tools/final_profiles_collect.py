@@ -13,9 +13,9 @@ src, dst = os.path.join(root, "gpurun_out", "final"), os.path.join(root, "profil
 
 
 def one(pattern):
-    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True))
+    hits = sorted(glob.glob(os.path.join(src, pattern), recursive=True), key=os.path.getmtime)
     assert hits, pattern
-    return hits[0]
+    return hits[-1]          # gpurun merges into gpurun_out/: an earlier run's files may still be there
 
 
 shutil.copy(one("fwd/**/*kernel_stats.csv"), os.path.join(dst, tag + "_fwd_cfg1_kernel_stats.csv"))
