@@ -585,6 +585,13 @@ int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, in
     if (big == 512 && !e.colsum && M >= 4096) {
       if (M % 64 == 0 && N % WS_BN == 0 && !e.atomic) {    // every tile interior: the predicate-free instantiations
         const bool plain = !e.res1 && !e.res2 && ldy % 4 == 0;      // bias optional (data-gradient GEMMs have none)
+        if constexpr (K == 96 && (PRO == PRO_NONE || PRO == PRO_LN)) {
+          // one column block and a 64-row tile count that does not divide over 512 resident blocks (M = 49152: 768 tiles =
+          // 1.5 per block): 32-row tiles over 768 blocks (3 per CU) are balanced, 2 tiles each
+          const int tiles64 = M / 64;
+          if (N == WS_BN && plain && e.act == ACT_NONE && tiles64 % 512 != 0 && tiles64 < 2048 && (M / 32) % 768 == 0)
+            return launch_wholeK_th<K, PRO, 256, true, 1>(x, ldx, w, y, ldy, M, N, p, e, st, 768);
+        }
         if (plain && e.act == ACT_NONE) return launch_wholeK_th<K, PRO, 512, true, 1>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
         if (plain && e.act == ACT_GELU) return launch_wholeK_th<K, PRO, 512, true, 2>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
         if constexpr (PRO == PRO_SKSEL || PRO == PRO_NONE) {
