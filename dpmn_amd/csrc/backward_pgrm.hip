@@ -1,5 +1,6 @@
 // PGRM-specific backward kernels (autograd of model/pgrm.py in the reference): window attention, SKConv gate,
 // depthwise conv, elementwise helpers.  Linear / conv data- and weight-gradients use gemm.hip / conv*.hip / backward.hip.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -160,6 +161,210 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
   }
   __syncthreads();
   for (int i = threadIdx.x; i < TBL * 2; i += 256) atomicAdd(dtable + i, dtb[i]);
+}
+
+// ---------------------------------------------------------------------------------- 8x8 window attention backward on MFMA
+// One block = one window (64 tokens) x 2 heads, one wave per head.  Everything is a 64 x 64 x 16 product on
+// v_mfma_f32_16x16x4_f32; the trick of k_window_attn8_mfma (pgrm.hip) is used four times: a 16x16 accumulator tile holds
+// element [row = 4kq + r][col = lr] in lane (lr, kq), which is exactly the B-operand slot of reduction step (tile, r) --
+// so P^T / dS^T (pass A) and P / dS (pass B) feed the next product straight from their accumulator registers.
+//   pass A, keys x queries:  S^T = K Q^T, dP^T = V dO^T  ->  softmax statistics per query column, delta = sum_k P dP,
+//                            dS^T = P^T o (dP^T - delta);  dQ^T = K^T dS^T;  bias-table gradient (LDS atomics)
+//   pass B, queries x keys:  S = Q K^T, dP = dO V^T (recomputed in the transposed layout; the per-query statistics come
+//                            back through LDS)  ->  P, dS;  dV^T = dO^T P;  dK^T = Q^T dS
+// K^T / Q^T / dO^T operands (rows = head dims) are ds_read_b32 of the staged rows, shared by the 4 tiles of the other axis.
+__global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __restrict__ q, const float* __restrict__ kv,
+                                                                const float* __restrict__ bias_table, const float* __restrict__ dout,
+                                                                float* __restrict__ dq, float* __restrict__ dkv,
+                                                                float* __restrict__ dtable, int H, int W, int C, int g, int shift) {
+  constexpr int WS = 8, D = 16, N = 64, CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1), TB4 = (TBL * 2 + 3) & ~3;
+  __shared__ __attribute__((aligned(16))) float tbl[TB4];
+  __shared__ __attribute__((aligned(16))) float dtb[TB4];
+  __shared__ __attribute__((aligned(16))) float Qs[N * LDR], Ks[N * LDR], Vs[N * LDR], Gs[N * LDR];
+  __shared__ float stat[2][3][N];          // [head][max, 1/sum, delta][query]
+  __shared__ int reg_s[N];
+  __shared__ int src_s[N];                 // source token of slab row r (roll by -shift + window-major map, quirk Q1)
+  const int tid = threadIdx.x, lane = tid & 63, head = tid >> 6;
+  const int L = H * W, slabs_per_img = L / N;
+  const int b = blockIdx.x / slabs_per_img;
+  const int t0 = (blockIdx.x % slabs_per_img) * N;
+  const int nWc = W / WS;
+  for (int i = tid; i < TBL * 2; i += 128) { tbl[i] = bias_table[i]; dtb[i] = 0.f; }
+  {
+    constexpr int V4 = CG / 4;
+    for (int i = tid; i < N * V4; i += 128) {
+      const int r = i / V4, c4 = (i % V4) * 4;
+      const int t = t0 + r, win = t / N, n = t % N;
+      const int hr = (win / nWc) * WS + n / WS, wcol = (win % nWc) * WS + n % WS;
+      const int src = b * L + ((hr + shift) % H) * W + (wcol + shift) % W;
+      *reinterpret_cast<float4*>(Qs + r * LDR + c4) = *reinterpret_cast<const float4*>(q + (size_t)src * C + g * CG + c4);
+      *reinterpret_cast<float4*>(Ks + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + (size_t)src * 2 * C + g * CG + c4);
+      *reinterpret_cast<float4*>(Vs + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + (size_t)src * 2 * C + C + g * CG + c4);
+      *reinterpret_cast<float4*>(Gs + r * LDR + c4) = *reinterpret_cast<const float4*>(dout + ((size_t)b * L + t) * C + g * CG + c4);
+      if (c4 == 0) {
+        const int rh = hr < H - WS ? 0 : (hr < H - shift ? 1 : 2), rw = wcol < W - WS ? 0 : (wcol < W - shift ? 1 : 2);
+        reg_s[r] = 3 * rh + rw;
+        src_s[r] = src;
+      }
+    }
+  }
+  __syncthreads();
+  const int lr = lane & 15, kq = lane >> 4;
+  const float scale = 0.25f;
+  f32x4 kf[4], qf[4], vf[4], gf[4];        // row fragments: [row = 16t + lr][d = 4kq .. 4kq+3]
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int o = (16 * t + lr) * LDR + head * D + 4 * kq;
+    kf[t] = *reinterpret_cast<const f32x4*>(Ks + o);
+    qf[t] = *reinterpret_cast<const f32x4*>(Qs + o);
+    qf[t] *= scale;
+    vf[t] = *reinterpret_cast<const f32x4*>(Vs + o);
+    gf[t] = *reinterpret_cast<const f32x4*>(Gs + o);
+  }
+  float* smax = stat[head][0];
+  float* sinv = stat[head][1];
+  float* sdel = stat[head][2];
+  // ================= pass A: rows = keys (16t + 4kq + r), columns = queries (16qt + lr)
+  {
+    f32x4 ps[4][4], dp[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { a = mfma16(kf[t][s4], qf[qt][s4], a); c = mfma16(vf[t][s4], gf[qt][s4], c); }
+        ps[t][qt] = a; dp[t][qt] = c;
+      }
+    float tacc[7][4];
+#pragma unroll
+    for (int dl = 0; dl < 7; ++dl)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tacc[dl][r] = 0.f;
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      const int nq = 16 * qt + lr, iq = nq / WS, jq = nq % WS;
+      const int my_reg = reg_s[nq];
+      float mx = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * t + 4 * kq + r, im = m / WS, jm = m % WS;
+          float a = ps[t][qt][r] + tbl[((iq - im + WS - 1) * (2 * WS - 1) + (jq - jm + WS - 1)) * 2 + head];
+          if (shift > 0 && reg_s[m] != my_reg) a += -100.0f;
+          ps[t][qt][r] = a;
+          mx = fmaxf(mx, a);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float den = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float p = expf(ps[t][qt][r] - mx); ps[t][qt][r] = p; den += p; }
+      den += __shfl_xor(den, 16, 64);
+      den += __shfl_xor(den, 32, 64);
+      const float inv = 1.0f / den;
+      float dlt = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ps[t][qt][r] *= inv; dlt += ps[t][qt][r] * dp[t][qt][r]; }
+      dlt += __shfl_xor(dlt, 16, 64);
+      dlt += __shfl_xor(dlt, 32, 64);
+      if (kq == 0) { smax[nq] = mx; sinv[nq] = inv; sdel[nq] = dlt; }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float ds = ps[t][qt][r] * (dp[t][qt][r] - dlt);
+          dp[t][qt][r] = ds;                                     // dS^T
+          tacc[qt - t + 3][r] += ds;      // bias-table gradient: the entry depends on (qt - t, r) only for a given lane
+        }
+    }
+    {
+      // query (iq, jq) = (2qt + lr/8, lr%8), key (im, jm) = (2t + kq/2, 4(kq%2) + r): di = 2(qt - t) + lr/8 - kq/2,
+      // dj = lr%8 - 4(kq%2) - r -- 28 pre-summed LDS atomics per lane instead of 64
+      const int ci = (lr >> 3) - (kq >> 1) + WS - 1, cj = (lr & 7) - 4 * (kq & 1) + WS - 1;
+#pragma unroll
+      for (int dl = 0; dl < 7; ++dl)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          atomicAdd(dtb + head * TBL + (2 * (dl - 3) + ci) * (2 * WS - 1) + (cj - r), tacc[dl][r]);
+    }
+    // dQ^T (16 d x 16 queries per tile) = K^T . dS^T
+    f32x4 dqa[4];
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) dqa[qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float kt = Ks[(16 * t + 4 * kq + r) * LDR + head * D + lr];     // K^T[d = lr][key]
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) dqa[qt] = mfma16(kt, dp[t][qt][r], dqa[qt]);
+      }
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      float* dst = dq + (size_t)src_s[16 * qt + lr] * C + g * CG + head * D + 4 * kq;
+      *reinterpret_cast<float4*>(dst) = make_float4(dqa[qt][0] * scale, dqa[qt][1] * scale, dqa[qt][2] * scale, dqa[qt][3] * scale);
+    }
+  }
+  __syncthreads();          // statistics of both heads visible (each wave only needs its own, but keep the waves together)
+  // ================= pass B: rows = queries (16qt + 4kq + r), columns = keys (16t + lr)
+  {
+    f32x4 ps[4][4], dp[4][4];           // [qt][t]
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f}, c = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) { a = mfma16(qf[qt][s4], kf[t][s4], a); c = mfma16(gf[qt][s4], vf[t][s4], c); }
+        ps[qt][t] = a; dp[qt][t] = c;
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int m = 16 * t + lr, im = m / WS, jm = m % WS;
+      const int key_reg = reg_s[m];
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nq = 16 * qt + 4 * kq + r, iq = nq / WS, jq = nq % WS;
+          float a = ps[qt][t][r] + tbl[((iq - im + WS - 1) * (2 * WS - 1) + (jq - jm + WS - 1)) * 2 + head];
+          if (shift > 0 && reg_s[nq] != key_reg) a += -100.0f;
+          const float p = expf(a - smax[nq]) * sinv[nq];
+          ps[qt][t][r] = p;                                      // P
+          dp[qt][t][r] = p * (dp[qt][t][r] - sdel[nq]);           // dS
+        }
+    }
+    // dV^T = dO^T . P ; dK^T = Q^T . dS   (16 d x 16 keys per tile)
+    f32x4 dva[4], dka[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dva[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; dka[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (16 * qt + 4 * kq + r) * LDR + head * D + lr;
+        const float gt = Gs[row], qt_ = Qs[row];                 // dO^T[d = lr][query], Q^T[d = lr][query]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          dva[t] = mfma16(gt, ps[qt][t][r], dva[t]);
+          dka[t] = mfma16(qt_, dp[qt][t][r], dka[t]);
+        }
+      }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float* dkp = dkv + (size_t)src_s[16 * t + lr] * 2 * C + g * CG + head * D + 4 * kq;
+      *reinterpret_cast<float4*>(dkp) = make_float4(dka[t][0] * scale, dka[t][1] * scale, dka[t][2] * scale, dka[t][3] * scale);
+      *reinterpret_cast<float4*>(dkp + C) = make_float4(dva[t][0], dva[t][1], dva[t][2], dva[t][3]);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < TBL * 2; i += 128) atomicAdd(dtable + i, dtb[(i & 1) * TBL + (i >> 1)]);     // table layout is [entry][head]
 }
 
 template <int WS, int D, bool DROP>
@@ -643,6 +848,13 @@ int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* 
     const int ws = windows[g], sh = shifts[g];
     DPMN_REQUIRE(H % ws == 0 && W % ws == 0 && sh >= 0 && sh < ws, "window_attn_bwd: bad window / shift");
     int rc = DPMN_ERR_ARG;
+    static const int wb_mfma = getenv("DPMN_WATTN_MFMA") ? atoi(getenv("DPMN_WATTN_MFMA")) : 1;
+    if (ws == 8 && D == 16 && p_drop == 0.f && wb_mfma) {
+      hipLaunchKernelGGL(k_window_attn8_bwd_mfma, dim3((unsigned)(B * (H * W / 64))), dim3(128), 0, st, q, kv, bias_tables[g], dout, dq,
+                         dkv, dtables[g], H, W, C, g, sh);
+      DPMN_CHECK_LAUNCH();
+      continue;
+    }
 #define WB_CASE(WSV, DV) if (ws == WSV && D == DV) rc = p_drop > 0.f \
       ? launch_wattn_bwd<WSV, DV, true>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, p_drop, seed, st) \
       : launch_wattn_bwd<WSV, DV, false>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, 0.f, 0ull, st); else
