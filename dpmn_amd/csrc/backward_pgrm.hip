@@ -173,10 +173,12 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
 //   pass B, queries x keys:  S = Q K^T, dP = dO V^T (recomputed in the transposed layout; the per-query statistics come
 //                            back through LDS)  ->  P, dS;  dV^T = dO^T P;  dK^T = Q^T dS
 // K^T / Q^T / dO^T operands (rows = head dims) are ds_read_b32 of the staged rows, shared by the 4 tiles of the other axis.
+template <bool DROP>
 __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __restrict__ q, const float* __restrict__ kv,
                                                                 const float* __restrict__ bias_table, const float* __restrict__ dout,
                                                                 float* __restrict__ dq, float* __restrict__ dkv,
-                                                                float* __restrict__ dtable, int H, int W, int C, int g, int shift) {
+                                                                float* __restrict__ dtable, int H, int W, int C, int g, int shift,
+                                                                float p_drop, unsigned long long seed) {
   constexpr int WS = 8, D = 16, N = 64, CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1), TB4 = (TBL * 2 + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float tbl[TB4];
   __shared__ __attribute__((aligned(16))) float dtb[TB4];
@@ -211,6 +213,8 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
   __syncthreads();
   const int lr = lane & 15, kq = lane >> 4;
   const float scale = 0.25f;
+  const unsigned long long mrow0 = ((unsigned long long)((size_t)b * (C / CG) + g) * 2 + head) * L;   // mask index base (include/dpmn_hip.h)
+  const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
   f32x4 kf[4], qf[4], vf[4], gf[4];        // row fragments: [row = 16t + lr][d = 4kq .. 4kq+3]
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -266,6 +270,13 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
       den += __shfl_xor(den, 16, 64);
       den += __shfl_xor(den, 32, 64);
       const float inv = 1.0f / den;
+      if (DROP) {    // dP = (dO V^T) o M with the forward's mask (0 or 1/(1-p)); delta = sum_k P dP is unchanged in form
+        const unsigned long long mrow = (mrow0 + t0 + nq) * N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dp[t][qt][r] *= drop_scale(seed, mrow + 16 * t + 4 * kq + r, p_drop, inv_keep);
+      }
       float dlt = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -336,8 +347,9 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
           float a = ps[qt][t][r] + tbl[((iq - im + WS - 1) * (2 * WS - 1) + (jq - jm + WS - 1)) * 2 + head];
           if (shift > 0 && reg_s[nq] != key_reg) a += -100.0f;
           const float p = expf(a - smax[nq]) * sinv[nq];
-          ps[qt][t][r] = p;                                      // P
-          dp[qt][t][r] = p * (dp[qt][t][r] - sdel[nq]);           // dS
+          const float mk = DROP ? drop_scale(seed, (mrow0 + t0 + nq) * N + m, p_drop, inv_keep) : 1.0f;
+          ps[qt][t][r] = p * mk;                                 // P o M (what multiplies V in the forward)
+          dp[qt][t][r] = p * (dp[qt][t][r] * mk - sdel[nq]);      // dS
         }
     }
     // dV^T = dO^T . P ; dK^T = Q^T . dS   (16 d x 16 keys per tile)
@@ -849,9 +861,13 @@ int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* 
     DPMN_REQUIRE(H % ws == 0 && W % ws == 0 && sh >= 0 && sh < ws, "window_attn_bwd: bad window / shift");
     int rc = DPMN_ERR_ARG;
     static const int wb_mfma = getenv("DPMN_WATTN_MFMA") ? atoi(getenv("DPMN_WATTN_MFMA")) : 1;
-    if (ws == 8 && D == 16 && p_drop == 0.f && wb_mfma) {
-      hipLaunchKernelGGL(k_window_attn8_bwd_mfma, dim3((unsigned)(B * (H * W / 64))), dim3(128), 0, st, q, kv, bias_tables[g], dout, dq,
-                         dkv, dtables[g], H, W, C, g, sh);
+    if (ws == 8 && D == 16 && wb_mfma) {
+      if (p_drop > 0.f)
+        hipLaunchKernelGGL((k_window_attn8_bwd_mfma<true>), dim3((unsigned)(B * (H * W / 64))), dim3(128), 0, st, q, kv, bias_tables[g],
+                           dout, dq, dkv, dtables[g], H, W, C, g, sh, p_drop, seed);
+      else
+        hipLaunchKernelGGL((k_window_attn8_bwd_mfma<false>), dim3((unsigned)(B * (H * W / 64))), dim3(128), 0, st, q, kv, bias_tables[g],
+                           dout, dq, dkv, dtables[g], H, W, C, g, sh, 0.f, 0ull);
       DPMN_CHECK_LAUNCH();
       continue;
     }

@@ -259,9 +259,11 @@ __global__ __launch_bounds__(256) void k_window_attn(const float* __restrict__ q
 //   exactly the accumulator element the lane already holds, so P never leaves its registers (no LDS transpose); V^T comes
 //   from the staged V rows with one ds_read_b32 per step, shared by the 4 query tiles.
 // The result lands as O[query][d = 4kq + r]: one float4 store per lane and query tile.
+template <bool DROP>
 __global__ __launch_bounds__(256) void k_window_attn8_mfma(const float* __restrict__ q, const float* __restrict__ kv,
                                                             const float* __restrict__ bias_table, float* __restrict__ out,
-                                                            int B, int H, int W, int C, int g, int shift) {
+                                                            int B, int H, int W, int C, int g, int shift, float p_drop,
+                                                            unsigned long long seed) {
   constexpr int WS = 8, D = 16, N = 64, CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tbl = smem;                            // [TBL][2]
@@ -354,6 +356,14 @@ __global__ __launch_bounds__(256) void k_window_attn8_mfma(const float* __restri
     den += __shfl_xor(den, 16, 64);
     den += __shfl_xor(den, 32, 64);
     inv[qt] = 1.0f / den;
+    if (DROP) {      // attn_drop (pgrm.py:248): same mask index as k_window_attn -- query row base + key
+      const unsigned long long mrow = (((unsigned long long)((size_t)b * (C / CG) + g) * 2 + head) * L + t0 + nq) * N;
+      const float inv_keep = 1.0f / (1.0f - p_drop);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[t][qt][r] *= drop_scale(seed, mrow + 16 * t + 4 * kq + r, p_drop, inv_keep);
+    }
   }
   // ---- O^T = V^T . P
   f32x4 oacc[4];
@@ -375,17 +385,19 @@ __global__ __launch_bounds__(256) void k_window_attn8_mfma(const float* __restri
   }
 }
 
+template <bool DROP>
 int launch_window_attn8_mfma(const float* q, const float* kv, const float* table, float* out, int B, int H, int W, int C, int g,
-                             int shift, hipStream_t st) {
+                             int shift, float p_drop, unsigned long long seed, hipStream_t st) {
   constexpr int N = 64, LDR = 36, TBL = 15 * 15;
   const size_t smem = (size_t)(((TBL * 2 + 3) & ~3) + 2 * 3 * N * LDR) * 4 + 2 * N * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn8_mfma), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn8_mfma<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const long slabs = (long)B * (H * W / 64);
-  hipLaunchKernelGGL(k_window_attn8_mfma, dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, table, out, B, H, W, C, g, shift);
+  hipLaunchKernelGGL((k_window_attn8_mfma<DROP>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, table, out, B, H, W, C, g, shift,
+                     p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -639,8 +651,9 @@ int dpmn_window_attn_drop_f32(const float* q, const float* kv, const float* cons
     DPMN_REQUIRE(sh >= 0 && sh < ws, "window_attn: shift must be in [0, window)");
     int rc = DPMN_ERR_ARG;
     static const int wa_mfma = getenv("DPMN_WATTN_MFMA") ? atoi(getenv("DPMN_WATTN_MFMA")) : 1;
-    if (ws == 8 && D == 16 && p_drop == 0.f && wa_mfma) {
-      rc = launch_window_attn8_mfma(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st);
+    if (ws == 8 && D == 16 && wa_mfma) {
+      rc = p_drop > 0.f ? launch_window_attn8_mfma<true>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, p_drop, seed, st)
+                        : launch_window_attn8_mfma<false>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, 0.f, 0ull, st);
       if (rc != DPMN_OK) return rc;
       continue;
     }
