@@ -275,6 +275,118 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
   }
 }
 
+// LayerNorm backward, vector form: 8 threads per row (C/32 float4 each, the row reductions are 3 xor-shuffles), 32 rows per
+// block pass, R rows per thread group in flight; every load is unconditional (rows past M are clamped and masked), so the
+// loads of a pass are issued back to back instead of one `s_waitcnt vmcnt(0)` per predicated load.
+template <int C>
+__global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, const float* __restrict__ dy,
+                                                    const float* __restrict__ gamma, float eps, float* __restrict__ dx,
+                                                    int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long M) {
+  constexpr int V = C / 32;                 // float4 per thread
+  __shared__ float red_g[32][C + 4], red_b[32][C + 4];
+  const int sub = threadIdx.x >> 3, t = threadIdx.x & 7;      // 32 row groups per block, 8 threads per row
+  float4 gam[V], ag[V], ab[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    gam[i] = *reinterpret_cast<const float4*>(gamma + (t + 8 * i) * 4);
+    ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  constexpr int R = 2;
+  const long stride = (long)gridDim.x * 32;
+  for (long row0 = (long)blockIdx.x * 32 + sub; row0 < M; row0 += stride * R) {
+    float4 xv[R][V], dv[R][V], dxo[R][V];
+    float okf[R], s[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const long row = row0 + u * stride;
+      okf[u] = row < M ? 1.f : 0.f;
+      const long rc = row < M ? row : M - 1;
+      s[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const long o = rc * C + (t + 8 * i) * 4;
+        xv[u][i] = *reinterpret_cast<const float4*>(x + o);
+        dv[u][i] = *reinterpret_cast<const float4*>(dy + o);
+        if (accumulate_dx) dxo[u][i] = *reinterpret_cast<const float4*>(dx + o);
+        s[u] += (xv[u][i].x + xv[u][i].y) + (xv[u][i].z + xv[u][i].w);
+      }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < R; ++u) s[u] += __shfl_xor(s[u], o, 64);
+    float q[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      s[u] *= (1.0f / C);
+      q[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const float a = xv[u][i].x - s[u], b = xv[u][i].y - s[u], c = xv[u][i].z - s[u], d = xv[u][i].w - s[u];
+        q[u] += (a * a + b * b) + (c * c + d * d);
+      }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < R; ++u) q[u] += __shfl_xor(q[u], o, 64);
+    float s1[R], s2[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      q[u] = 1.0f / sqrtf(q[u] * (1.0f / C) + eps);
+      s1[u] = 0.f; s2[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float* xp = reinterpret_cast<float*>(&xv[u][i]);
+        float* dp = reinterpret_cast<float*>(&dv[u][i]);
+        const float* gp = reinterpret_cast<const float*>(&gam[i]);
+        float* agp = reinterpret_cast<float*>(&ag[i]);
+        float* abp = reinterpret_cast<float*>(&ab[i]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float xh = (xp[c] - s[u]) * q[u];
+          const float dvm = dp[c] * okf[u];          // rows past M contribute nothing
+          const float dgi = dvm * gp[c];
+          s1[u] += dgi; s2[u] += dgi * xh;
+          agp[c] += dvm * xh; abp[c] += dvm;
+          xp[c] = xh; dp[c] = dgi;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < R; ++u) { s1[u] += __shfl_xor(s1[u], o, 64); s2[u] += __shfl_xor(s2[u], o, 64); }
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+      const long row = row0 + u * stride;
+      if (row >= M) continue;
+      const float m1 = s1[u] * (1.0f / C), m2 = s2[u] * (1.0f / C);
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        float4 gq;
+        gq.x = q[u] * (dv[u][i].x - m1 - xv[u][i].x * m2); gq.y = q[u] * (dv[u][i].y - m1 - xv[u][i].y * m2);
+        gq.z = q[u] * (dv[u][i].z - m1 - xv[u][i].z * m2); gq.w = q[u] * (dv[u][i].w - m1 - xv[u][i].w * m2);
+        if (accumulate_dx) { gq.x += dxo[u][i].x; gq.y += dxo[u][i].y; gq.z += dxo[u][i].z; gq.w += dxo[u][i].w; }
+        *reinterpret_cast<float4*>(dx + row * C + (t + 8 * i) * 4) = gq;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    *reinterpret_cast<float4*>(&red_g[sub][(t + 8 * i) * 4]) = ag[i];
+    *reinterpret_cast<float4*>(&red_b[sub][(t + 8 * i) * 4]) = ab[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float g = 0.f, b = 0.f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) { g += red_g[r][c]; b += red_b[r][c]; }
+    atomicAdd(dgamma + c, g);
+    atomicAdd(dbeta + c, b);
+  }
+}
+
 // ---------------------------------------------------------------------------------- activation backward
 __device__ __forceinline__ float act_grad(float pre, int act, float slope) {
   switch (act) {
@@ -417,7 +529,14 @@ int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, 
   // 32-thread group).  In-pipeline sweep at M = 49152: 256 blocks 46.6 us, 512: 36.9, 1024: 41.9, 2048: 59.9
   static const long cap = getenv("DPMN_LNB_BLOCKS") ? atol(getenv("DPMN_LNB_BLOCKS")) : 512;
   const unsigned blocks = (unsigned)(M / 8 < cap ? (M + 7) / 8 : cap);
-  if (C == 96)
+  static const int v4 = getenv("DPMN_LNB_V4") ? atoi(getenv("DPMN_LNB_V4")) : 1;
+  if (C == 96 && v4) {
+    // in-pipeline sweep of the vector kernel at M = 49152: 256 blocks 20.2 us, 384: 21.2, 512: 24.3, 768: 27.6, 1024: 33.3
+    // (the scalar kernel it replaces: 36.8 us) -- one block per CU, the same-address dgamma / dbeta atomics set the slope
+    static const long cap4 = getenv("DPMN_LNB_BLOCKS") ? atol(getenv("DPMN_LNB_BLOCKS")) : 256;
+    const unsigned b4 = (unsigned)(M / 32 < cap4 ? (M + 31) / 32 : cap4);
+    hipLaunchKernelGGL((k_ln_bwd_v4<96>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
+  } else if (C == 96)
     hipLaunchKernelGGL((k_ln_bwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
   else if (C == 192)
     hipLaunchKernelGGL((k_ln_bwd<192>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
