@@ -312,7 +312,23 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (pl < PL) {
     const float4 mu = *reinterpret_cast<const float4*>(mean + cq * 4), rs = *reinterpret_cast<const float4*>(rstd + cq * 4);
-    for (long p = p0 + pl; p < p1; p += PL) {
+    // 4 pixels per thread in flight (8 independent float4 loads), then the tail
+    long p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {
+      float4 g[4], x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        g[u] = *reinterpret_cast<const float4*>(G + (p + u * PL) * C + cq * 4);
+        x[u] = *reinterpret_cast<const float4*>(r + (p + u * PL) * C + cq * 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s1[0] += g[u].x; s1[1] += g[u].y; s1[2] += g[u].z; s1[3] += g[u].w;
+        s2[0] += g[u].x * (x[u].x - mu.x) * rs.x; s2[1] += g[u].y * (x[u].y - mu.y) * rs.y;
+        s2[2] += g[u].z * (x[u].z - mu.z) * rs.z; s2[3] += g[u].w * (x[u].w - mu.w) * rs.w;
+      }
+    }
+    for (; p < p1; p += PL) {
       const float4 g = *reinterpret_cast<const float4*>(G + p * C + cq * 4);
       const float4 x = *reinterpret_cast<const float4*>(r + p * C + cq * 4);
       s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
@@ -338,12 +354,22 @@ __global__ void k_bn_bwd_apply(const float* __restrict__ G, const float* __restr
                                const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ sums,
                                float count, float* __restrict__ dr, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                long pixels, int C) {
+  // one float4 (4 channels of one pixel) per thread; C % 4 == 0
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx < C && dgamma) { atomicAdd(dgamma + idx, sums[C + idx]); atomicAdd(dbeta + idx, sums[idx]); }
-  if (idx >= pixels * C) return;
-  const int c = idx % C;
-  const float xh = (r[idx] - mean[c]) * rstd[c];
-  dr[idx] = gamma[c] * rstd[c] * (G[idx] - sums[c] / count - xh * sums[C + c] / count);
+  const long e = idx * 4;
+  if (e >= pixels * C) return;
+  const int c = (int)(e % C);
+  const float4 g4 = *reinterpret_cast<const float4*>(G + e), r4 = *reinterpret_cast<const float4*>(r + e);
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + c), mu = *reinterpret_cast<const float4*>(mean + c);
+  const float4 rs = *reinterpret_cast<const float4*>(rstd + c);
+  const float4 a0 = *reinterpret_cast<const float4*>(sums + c), a1 = *reinterpret_cast<const float4*>(sums + C + c);
+  float4 o;
+  o.x = ga.x * rs.x * (g4.x - a0.x / count - (r4.x - mu.x) * rs.x * a1.x / count);
+  o.y = ga.y * rs.y * (g4.y - a0.y / count - (r4.y - mu.y) * rs.y * a1.y / count);
+  o.z = ga.z * rs.z * (g4.z - a0.z / count - (r4.z - mu.z) * rs.z * a1.z / count);
+  o.w = ga.w * rs.w * (g4.w - a0.w / count - (r4.w - mu.w) * rs.w * a1.w / count);
+  *reinterpret_cast<float4*>(dr + e) = o;
 }
 
 // ---------------------------------------------------------------------------------- CMM channel gate backward
@@ -589,7 +615,8 @@ int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const fl
   hipLaunchKernelGGL(k_bn_bwd_reduce, dim3((unsigned)((pixels + ppb - 1) / ppb)), dim3(256), 0, as_stream(stream), G, r, mean, rstd,
                      sums_ws, pixels, C, ppb);
   DPMN_CHECK_LAUNCH();
-  const long total = pixels * C;
+  long total = pixels * C / 4;                 // one float4 per thread; at least C threads for the dgamma / dbeta adds
+  if (total < C) total = C;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), G, r, gamma, mean, rstd,
                      sums_ws, (float)pixels, dr, dgamma, dbeta, pixels, C);
   DPMN_CHECK_LAUNCH();
