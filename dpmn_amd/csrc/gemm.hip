@@ -607,6 +607,12 @@ int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, in
       return launch_wholeK_th<K, PRO, 512>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
     }
   }
+  if constexpr (K == 96 && PRO == PRO_LN) {        // experiment: 32-row tiles with the straight-line epilogues (DPMN_WSTAT_TH=256)
+    if (big == 256 && !e.colsum && M % 32 == 0 && N % WS_BN == 0 && !e.atomic && !e.res1 && !e.res2 && ldy % 4 == 0) {
+      if (e.act == ACT_NONE) return launch_wholeK_th<K, PRO, 256, true, 1>(x, ldx, w, y, ldy, M, N, p, e, st, 768);
+      if (e.act == ACT_GELU) return launch_wholeK_th<K, PRO, 256, true, 2>(x, ldx, w, y, ldy, M, N, p, e, st, 768);
+    }
+  }
   if constexpr (PRO == PRO_NONE && K == 96) {      // SKConv projection + GAP partials, straight-line (pgrm.py:84-86)
     if (e.colsum && M % 32 == 0 && N % WS_BN == 0 && !e.atomic && !e.res1 && !e.res2 && e.act == ACT_NONE && ldy % 4 == 0)
       return launch_wholeK_th<K, PRO, 256, true, 4>(x, ldx, w, y, ldy, M, N, p, e, st, WSTAT_NBUF == 1 ? 768 : 512);
