@@ -188,11 +188,28 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
   const int tiles = (M + BM - 1) / BM;
 
   constexpr int KV = K / 4;
-  for (int i = tid; i < BN * KV; i += TH) {
-    const int r = i / KV, c = (i % KV) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n_blk + r < N) v = *reinterpret_cast<const float4*>(w + (size_t)(n_blk + r) * K + c);
-    *reinterpret_cast<float4*>(Ws + r * LDK + c) = v;
+  if constexpr (FULL) {
+    // the W tile's float4s of a thread are loaded back to back (unconditional: every row is inside N) and stored afterwards,
+    // instead of one load -> wait -> LDS store round trip per element
+    constexpr int WL = (BN * KV + TH - 1) / TH;
+    float4 wv[WL];
+#pragma unroll
+    for (int u = 0; u < WL; ++u) {
+      const int i = min(tid + u * TH, BN * KV - 1);
+      wv[u] = *reinterpret_cast<const float4*>(w + (size_t)(n_blk + i / KV) * K + (i % KV) * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < WL; ++u) {
+      const int i = tid + u * TH;
+      if (i < BN * KV) *reinterpret_cast<float4*>(Ws + (i / KV) * LDK + (i % KV) * 4) = wv[u];
+    }
+  } else {
+    for (int i = tid; i < BN * KV; i += TH) {
+      const int r = i / KV, c = (i % KV) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n_blk + r < N) v = *reinterpret_cast<const float4*>(w + (size_t)(n_blk + r) * K + c);
+      *reinterpret_cast<float4*>(Ws + r * LDK + c) = v;
+    }
   }
   if (PRO == PRO_LN)
     for (int i = tid; i < K; i += TH) { lng[i] = p.ln_w[i]; lng[K + i] = p.ln_b[i]; }
