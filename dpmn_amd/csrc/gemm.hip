@@ -463,6 +463,27 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
 #undef KL_GLOAD
 #undef KL_SSTORE
 #undef KL_MMA
+  // interior tile, bias + one residual, no activation (Mlp.fc2 + shortcut, pgrm.py:39,330): the 6 residual loads are issued
+  // together and the stores follow -- the generic epilogue below does load -> wait -> store per 16 x 16 tile
+  if (e.bias && e.res1 && !e.res2 && !e.colsum && !e.atomic && e.act == ACT_NONE && m_blk + BM <= M && n_blk + BN <= N && (ldy & 3) == 0) {
+    const int lm = lane & 15, lq = lane >> 4;
+    float4 rr[3][2];
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        rr[nt][mt] = *reinterpret_cast<const float4*>(e.res1 + (size_t)(m_blk + wm * 32 + mt * 16 + lm) * ldy + n_blk + wn * 48 + nt * 16 + lq * 4);
+#pragma unroll
+    for (int nt = 0; nt < 3; ++nt) {
+      const float4 b4 = *reinterpret_cast<const float4*>(e.bias + n_blk + wn * 48 + nt * 16 + lq * 4);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        *reinterpret_cast<float4*>(y + (size_t)(m_blk + wm * 32 + mt * 16 + lm) * ldy + n_blk + wn * 48 + nt * 16 + lq * 4) =
+            make_float4(acc[nt][mt][0] + b4.x + rr[nt][mt].x, acc[nt][mt][1] + b4.y + rr[nt][mt].y,
+                        acc[nt][mt][2] + b4.z + rr[nt][mt].z, acc[nt][mt][3] + b4.w + rr[nt][mt].w);
+    }
+    return;
+  }
   epilogue<3, 2>(acc, m_blk + wm * 32, n_blk + wn * 48, M, N, ldy, y, e, nullptr, BN, n_blk);
 }
 
