@@ -57,6 +57,39 @@ def test_ln_linear(dev, K, N):
     assert_close(got, F.gelu(ref), ATOL, RTOL, "ln_linear gelu")
 
 
+@pytest.mark.parametrize("M", [4096, 4160, 6144, 12288])
+@pytest.mark.parametrize("K,N", [(96, 96), (96, 192), (96, 384), (32, 96), (64, 192), (128, 192), (96, 100)])
+def test_whole_k_gemm_dispatch_interior_and_edge_tiles(dev, M, K, N):
+    """Every epilogue instantiation of the whole-K GEMM (predicate-free interior tiles with straight-line bias / GELU / one or
+    two residuals vs the generic edge path: M not a multiple of 64, N not a multiple of 96) against torch on the same data."""
+    from dpmn_amd import ops
+    x, w, b = u("x", (M, K)), u("w", (N, K), -0.2, 0.2), u("b", (N,))
+    r1, r2 = u("r1", (M, N)), u("r2", (M, N))
+    xd, wd, bd, r1d, r2d = (t_.to(dev) for t_ in (x, w, b, r1, r2))
+    base = F.linear(x, w, b)
+    assert_close(ops.linear(xd, wd, bd), base, ATOL, RTOL, "bias")
+    assert_close(ops.linear(xd, wd), F.linear(x, w), ATOL, RTOL, "no bias")
+    assert_close(ops.linear(xd, wd, bd, act="gelu"), F.gelu(base), ATOL, RTOL, "bias + gelu")
+    assert_close(ops.linear(xd, wd, bd, r1d), base + r1, ATOL, RTOL, "bias + res1")
+    assert_close(ops.linear(xd, wd, bd, r1d, r2d), base + r1 + r2, ATOL, RTOL, "bias + res1 + res2")
+    assert_close(ops.linear(xd, wd, None, r1d), F.linear(x, w) + r1, ATOL, RTOL, "res1 only")
+    if K == 96:
+        g, be = u("g", (K,), 0.5, 1.5), u("be", (K,))
+        ref = F.linear(F.layer_norm(x, (K,), g, be), w, b)
+        assert_close(ops.ln_linear(xd, g.to(dev), be.to(dev), wd, bd), ref, ATOL, RTOL, "ln + linear")
+        assert_close(ops.ln_linear(xd, g.to(dev), be.to(dev), wd, bd, act="gelu"), F.gelu(ref), ATOL, RTOL, "ln + linear + gelu")
+
+
+@pytest.mark.parametrize("M,N,K", [(6144, 96, 384), (6200, 96, 384), (4096, 100, 192), (64, 96, 256)])
+def test_k_loop_gemm_residual_epilogues(dev, M, N, K):
+    from dpmn_amd import ops
+    x, w, b, r1 = u("x", (M, K)), u("w", (N, K), -0.2, 0.2), u("b", (N,)), u("r1", (M, N))
+    xd, wd, bd, r1d = (t_.to(dev) for t_ in (x, w, b, r1))
+    assert_close(ops.linear(xd, wd, bd, r1d), F.linear(x, w, b) + r1, ATOL, RTOL, "k-loop bias + res1")
+    assert_close(ops.linear(xd, wd, bd, act="gelu"), F.gelu(F.linear(x, w, b)), ATOL, RTOL, "k-loop bias + gelu")
+    assert_close(ops.linear(xd, wd), F.linear(x, w), ATOL, RTOL, "k-loop plain")
+
+
 def test_add_linear(dev):
     from dpmn_amd import ops
     x, a = u("x", (200, 64)), u("a", (200, 64))
