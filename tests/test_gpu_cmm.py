@@ -51,6 +51,36 @@ def test_conv2d_matches_torch(dev, cin, cout, k, stride, pad, dil, H, W):
     assert_close(got2, torch.tanh(ref), ATOL, RTOL, "conv nchw+tanh")
 
 
+@pytest.mark.parametrize("segs,cout,k,stride,pad,dil,H,W", [
+    ((32,), 40, 3, 1, 1, 1, 5, 7),            # odd plane, Cout not a multiple of 4*16: borders + the num_records row check
+    ((64, 32), 96, 4, 2, 1, 1, 6, 10),        # two segments, stride 2, even kernel
+    ((32, 32, 64), 132, 3, 1, 2, 2, 9, 12),   # three segments, dilation 2, padding wider than the kernel radius
+    ((96,), 64, 1, 1, 0, 1, 7, 9),            # 1x1
+    ((256, 256, 256), 128, 3, 1, 1, 1, 4, 16),  # deep decoder shape: split-K path (M = 192 pixels at B = 3)
+])
+def test_conv2d_buffer_load_instantiation_borders_segments_affine(dev, segs, cout, k, stride, pad, dil, H, W):
+    """Channel counts that are multiples of 32 take the raw-buffer-load implicit GEMM (hardware range check instead of
+    predicated loads): odd planes, strides, dilation, 1-3 input segments, affine + activation on load (padding must stay 0)."""
+    from dpmn_amd import ops
+    from dpmn_amd.model import packing
+    B = 3
+    xs = [u("s%d" % i, (B, c, H, W)) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    w = u("w", (cout, cin, k, k), -1, 1) * (1.0 / (cin * k * k) ** 0.5)
+    b = u("b", (cout,))
+    sc = [u("sc%d" % i, (c,), 0.5, 1.5) for i, c in enumerate(segs)]
+    sh = [u("sh%d" % i, (c,), -0.3, 0.3) for i, c in enumerate(segs)]
+    xa = torch.cat([x * s_[None, :, None, None] + h[None, :, None, None] for x, s_, h in zip(xs, sc, sh)], 1)
+    ref = F.conv2d(F.leaky_relu(xa, 0.2), w, b, stride=stride, padding=pad, dilation=dil)
+    wp, bp = packing.pack_conv(w.to(dev), b.to(dev))
+    got = ops.conv2d([nhwc(x).to(dev) for x in xs], wp, bp, cout, k, stride=stride, pad=pad, dil=dil, pro_act="leaky02",
+                     affine=[(s_.to(dev), h.to(dev)) for s_, h in zip(sc, sh)])
+    assert_close(got.permute(0, 3, 1, 2), ref, ATOL, RTOL, "affine + leaky on load, segs %s" % (segs,))
+    ref0 = F.conv2d(torch.cat(xs, 1), w, b, stride=stride, padding=pad, dilation=dil)
+    got0 = ops.conv2d([nhwc(x).to(dev) for x in xs], wp, bp, cout, k, stride=stride, pad=pad, dil=dil)
+    assert_close(got0.permute(0, 3, 1, 2), ref0, ATOL, RTOL, "plain, segs %s" % (segs,))
+
+
 def test_conv2d_bn_fold_segments_residual_and_pixelshuffle(dev):
     from dpmn_amd import ops
     from dpmn_amd.model import packing
