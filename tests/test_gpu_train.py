@@ -95,6 +95,24 @@ def test_pgrm_backward_vs_oracle_autograd(dev, it, mode):
     print("worst param grad", worst)
 
 
+@pytest.mark.parametrize("M", [49, 1000, 4096])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_layernorm_backward_ragged_rows_vs_torch(dev, M, accumulate):
+    """dpmn_layernorm_bwd_f32 (vector kernel: 32 rows per block pass, rows past M clamped and masked) vs torch autograd."""
+    from dpmn_amd.train import pgrm_train
+    C = 96
+    x = u("lnx", (M, C), -2, 3).requires_grad_(True)
+    g, b = u("lng", (C,), 0.5, 1.5).requires_grad_(True), u("lnb", (C,)).requires_grad_(True)
+    dy, dx0 = u("lndy", (M, C)), u("lndx0", (M, C))
+    torch.nn.functional.layer_norm(x, (C,), g, b).backward(dy)
+    dx = dx0.clone().to(dev) if accumulate else torch.full((M, C), float("nan"), device=dev)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    pgrm_train.layernorm_bwd(x.detach().to(dev), dy.to(dev), g.detach().to(dev), dx, accumulate, dg, db)
+    assert_close(dx, x.grad + (dx0 if accumulate else 0), 2e-4, 2e-4, "dx")
+    assert_close(dg, g.grad, 2e-3, 2e-4, "dgamma")
+    assert_close(db, b.grad, 2e-3, 2e-4, "dbeta")
+
+
 def test_dropout_kernel_masks_equal_oracle_hash(dev):
     """dpmn_dropout_f32 (elementwise + per-sample DropPath + residual) vs the numpy restatement of the mask hash: the kept set
     is bit-identical, values equal to fp32 round-off of the single multiply."""
