@@ -26,6 +26,20 @@ def timed(inputs, wp, bias, cout, k, *a, **kw):
 
 
 ops.conv2d = timed
+recT = []
+origT = ops.convT_s2k4
+
+
+def timedT(inputs, packs, cout, *a, **kw):
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    out = origT(inputs, packs, cout, *a, **kw)
+    e.record()
+    recT.append((s, e, [tuple(t.shape) for t in inputs], cout))
+    return out
+
+
+ops.convT_s2k4 = timedT
 import dpmn_amd.model.cmm as cmm_mod, dpmn_amd.model.pgrm as pgrm_mod, dpmn_amd.model.tsrn as tsrn_mod
 step()
 torch.cuda.synchronize()
@@ -47,3 +61,13 @@ for s, e, shp, cout, k, stride, phase, oshp, wn in rec:
         "+".join("%dx%dx%d" % (x[1], x[2], x[3]) for x in shp), cout, k, stride, phase or "", M, ms * 1e3, fl / ms / 1e9, wn * 4 / 1e6,
         wn * 4 / ms / 1e9))
 print("conv total %.2f ms in %d launches" % (tot, len(rec)))
+totT = 0.0
+for s, e, shp, cout in recT:      # ConvTranspose2d(4,2,1): 4 phases of a 2x2 conv, one launch
+    ms = s.elapsed_time(e)
+    totT += ms
+    cin = sum(x[3] for x in shp)
+    B, H, W = shp[0][:3]
+    fl = 2.0 * B * H * W * 4 * (4 * cin) * cout
+    print("convT in %-38s cout %4d  M/phase %6d K %5d  %7.1f us %6.1f TF" % ("+".join("%dx%dx%d" % (x[1], x[2], x[3]) for x in shp), cout,
+                                                                          B * H * W, 4 * cin, ms * 1e3, fl / ms / 1e9))
+print("convT total %.2f ms in %d launches" % (totT, len(recT)))
