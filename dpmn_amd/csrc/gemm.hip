@@ -181,7 +181,7 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
   float* Ws = smem;                       // [BN][LDK]
   float* Xs = Ws + BN * LDK;              // [2][BM][LDK]
   float* red = Xs + WSTAT_NBUF * BM * LDK;   // [4][BN] colsum scratch
-  float* lng = red + 4 * BN;              // [K] LayerNorm gamma, [K] beta
+  float* lng = red + (TH / 64) * BN;      // [K] LayerNorm gamma, [K] beta   (red: one row of BN column sums per wave)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_blk = blockIdx.y * BN;
@@ -353,10 +353,11 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
     }                                                                                                        \
     if ((EPI == 0 && e.colsum) || EPI == 4) {                                                                \
       __syncthreads();                                                                                       \
-      for (int c = tid; c < BN; c += TH) {                                                                   \
-        const int wn_c = c / 48;                                                                             \
-        const float s_ = red[(wn_c * 2 + 0) * BN + c] + red[(wn_c * 2 + 1) * BN + c];                        \
-        if (n_blk + c < N) e.colsum[(size_t)tile * N + n_blk + c] = s_;                                      \
+      /* one partial per 32 rows (the consumer's contract): BM/32 per tile, each summed over the 2 waves of its rows */ \
+      for (int c = tid; c < BN * (BM / 32); c += TH) {                                                       \
+        const int part = c / BN, col = c - part * BN, wn_c = col / 48;                                       \
+        const float s_ = red[(wn_c * WMN + 2 * part) * BN + col] + red[(wn_c * WMN + 2 * part + 1) * BN + col]; \
+        if (n_blk + col < N) e.colsum[((size_t)tile * (BM / 32) + part) * N + n_blk + col] = s_;             \
       }                                                                                                      \
     }                                                                                                        \
     buf ^= 1;                                                                                                \
@@ -596,7 +597,7 @@ template <int K, int PRO, int TH, bool FULL = false, int EPI = 0>
 int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
                      const EpiArgs& e, hipStream_t st, int target_blocks) {
   constexpr int BM = TH / 8;
-  const size_t smem = (size_t)((WS_BN + WSTAT_NBUF * BM) * (K + PAD) + 4 * WS_BN + 2 * K) * sizeof(float);
+  const size_t smem = (size_t)((WS_BN + WSTAT_NBUF * BM) * (K + PAD) + (TH / 64) * WS_BN + 2 * K) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstat<K, PRO, TH, FULL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -652,8 +653,12 @@ int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, in
     }
   }
   if constexpr (PRO == PRO_NONE && K == 96) {      // SKConv projection + GAP partials, straight-line (pgrm.py:84-86)
-    if (e.colsum && M % 32 == 0 && N % WS_BN == 0 && !e.atomic && !e.res1 && !e.res2 && e.act == ACT_NONE && ldy % 4 == 0)
+    if (e.colsum && M % 32 == 0 && N % WS_BN == 0 && !e.atomic && !e.res1 && !e.res2 && e.act == ACT_NONE && ldy % 4 == 0) {
+      static const int cs512 = getenv("DPMN_COLSUM_TH") ? atoi(getenv("DPMN_COLSUM_TH")) : 512;
+      if (cs512 == 512 && M % 64 == 0 && M >= 4096)     // 64-row tiles, two 32-row partials each: half the barriers
+        return launch_wholeK_th<K, PRO, 512, true, 4>(x, ldx, w, y, ldy, M, N, p, e, st, 512);
       return launch_wholeK_th<K, PRO, 256, true, 4>(x, ldx, w, y, ldy, M, N, p, e, st, WSTAT_NBUF == 1 ? 768 : 512);
+    }
   }
   return launch_wholeK_th<K, PRO, 256>(x, ldx, w, y, ldy, M, N, p, e, st, WSTAT_NBUF == 1 ? 768 : 512);
 }
