@@ -30,6 +30,9 @@ class TextBase(object):
         self.rec_path = getattr(args, "rec_path", None)
         self.resume = args.resume if getattr(args, "resume", None) is not None else config.TRAIN.resume
         self.batch_size = args.batch_size if args.batch_size is not None else self.config.TRAIN.batch_size
+        val = getattr(config.TRAIN, "VAL", None)     # base.py:56
+        self.vis_dir = args.vis_dir if getattr(args, "vis_dir", None) is not None else (getattr(val, "vis_dir", None) or "./vis")
+        self.voc_type = getattr(config.TRAIN, "voc_type", None)
         if not torch.cuda.is_available():
             raise RuntimeError("dpmn_amd: the DPMN hot path needs a MI355X (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device())
@@ -86,9 +89,11 @@ class TextBase(object):
         return {'model': model, 'crit': image_crit}
 
     def save_checkpoint(self, netG_list, epoch, iters, best_acc_dict, best_model_info, is_best, converge_list,
-                        recognizer=None, name=None):
-        """Same files and dict keys as base.py:328-358 (all models overwrite checkpoint.pth when not best)."""
-        ckpt_path = os.path.join(self.vis_dir if hasattr(self, "vis_dir") else ".", 'ckpt')
+                        recognizer=None, metric="sum"):
+        """Same files and dict keys as base.py:328-358: model_best_{metric}_{epoch}_{i}.pth when is_best, otherwise every
+        model overwrites checkpoint.pth (the reference's behaviour, line 358).  Recogniser files (base.py:360-373) are written
+        when a recogniser list is passed (none is built here: SURVEY.md section 2 rows 14-17)."""
+        ckpt_path = os.path.join(self.vis_dir, 'ckpt')
         os.makedirs(ckpt_path, exist_ok=True)
         for i, netG in enumerate(netG_list):
             # parameters may be views into the trainer's flat buckets: store compact, storage-independent copies
@@ -97,8 +102,14 @@ class TextBase(object):
                                   'voc_type': getattr(self, "voc_type", None), 'up_scale_factor': self.scale_factor},
                          'best_history_res': best_acc_dict, 'best_model_info': best_model_info,
                          'param_num': sum(p.numel() for p in netG.parameters()), 'converge': converge_list}
-            if is_best:
-                fname = 'model_best_' + (name + '_' if name else '') + str(epoch) + '_' + str(i) + '.pth'
-            else:
-                fname = 'checkpoint.pth'
+            fname = 'model_best_{}_{}_{}.pth'.format(metric, epoch, i) if is_best else 'checkpoint.pth'
             torch.save(save_dict, os.path.join(ckpt_path, fname))
+        if recognizer is not None:
+            recs = recognizer if isinstance(recognizer, list) else [recognizer]
+            for i, r in enumerate(recs):
+                if isinstance(recognizer, list):
+                    fname = ('recognizer_best_{}_{}_{}.pth' if is_best else 'recognizer_{}_{}_{}.pth').format(metric, epoch, i)
+                else:
+                    fname = 'recognizer_best.pth' if is_best else 'recognizer.pth'
+                torch.save(r.state_dict(), os.path.join(ckpt_path, fname))
+        return ckpt_path

@@ -7,6 +7,9 @@ blend with the PSN image.  Every tensor op runs in libdpmn_hip.so.  Text priors 
 glyph renderer that produce them in the reference are out of scope, so
 the synthetic source of dpmn_amd.utils.synth is the default.
 """
+import csv
+import os
+
 import torch
 
 from . import base
@@ -33,7 +36,18 @@ class TextSR(base.TextBase):
         for p in psn.parameters():
             p.requires_grad = False
         psn.eval()
-        models.append(ComplementationModulationModule().to(self.device))
+        cmm = ComplementationModulationModule().to(self.device)
+        if testing:
+            # super_resolution.py:570-582: test() evaluates the trained CMM, model_best_cmm.pth next to the PGRM files
+            if not (self.resume and os.path.isdir(self.resume)):
+                raise RuntimeError("dpmn_amd: test() needs --resume <dir> holding model_best_{k}.pth and model_best_cmm.pth")
+            path = os.path.join(self.resume, "model_best_cmm.pth")
+            if not os.path.isfile(path):
+                raise FileNotFoundError("dpmn_amd: %s is missing -- refusing to evaluate a randomly initialised CMM" % path)
+            print('loading pre-trained model from %s ' % path)
+            sd = torch.load(path, map_location=self.device)['state_dict_G']
+            cmm.load_state_dict({(k[7:] if k.startswith('module.') else k): v for k, v in sd.items()})
+        models.append(cmm)
         return models, psn
 
     @staticmethod
@@ -80,11 +94,16 @@ class TextSR(base.TextBase):
     @torch.no_grad()
     def eval(self, model_list, val_loader, index=0, rec=None, aster_info=None, rec_list=None, model_psn=None, crnn_psn=None,
              text_prior_fn=None):
-        """PSNR/SSIM part of super_resolution.py:340-513 (recognition accuracy needs the out-of-scope recognisers)."""
+        """super_resolution.py:340-513.  PSNR/SSIM always; recognition accuracy (lines 453-493) only when `rec` is a
+        callable images (B,3,H,W) -> list[str] and the loader yields label strings as a 4th item -- the reference's
+        ASTER / MORAN / CRNN recognisers are out of scope, so by default 'accuracy' is
+        None ("not computed"), never a fake 0.0."""
+        from ..utils.util import str_filt
         for m in model_list:
             m.eval()
         fn = text_prior_fn or self.synthetic_text_prior()
         psnr, ssim, n = [], [], 0
+        n_correct, n_labelled = 0, 0
         for data in val_loader:
             images_hr, images_lr = data[0].to(self.device), data[1].to(self.device)
             label_vecs = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
@@ -95,9 +114,14 @@ class TextSR(base.TextBase):
             psnr.append(p)
             ssim.append(s)
             n += images_lr.shape[0]
+            if callable(rec) and len(data) > 3 and data[3] is not None:
+                for pred, target in zip(rec(sr[:, :3]), data[3]):
+                    n_correct += int(pred == str_filt(target, 'lower'))
+                n_labelled += len(data[3])
         psnr_avg = float(torch.stack(psnr).mean().item())
         ssim_avg = float(torch.stack(ssim).mean().item())
-        return {'psnr': psnr, 'ssim': ssim, 'accuracy': 0.0, 'psnr_avg': round(psnr_avg, 6), 'ssim_avg': round(ssim_avg, 6)}
+        accuracy = round(n_correct / n_labelled, 4) if n_labelled else None
+        return {'psnr': psnr, 'ssim': ssim, 'accuracy': accuracy, 'psnr_avg': round(psnr_avg, 6), 'ssim_avg': round(ssim_avg, 6)}
 
     # ------------------------------------------------------------------ training (super_resolution.py:113-278)
     def build_training(self, world_size=1, group=None):
@@ -192,6 +216,11 @@ class TextSR(base.TextBase):
         st = dict(lr=images_lr.clone(), hr=images_hr.clone(), lv=None if label_vecs is None else label_vecs.clone(),
                   tp=[t.clone() for t in text_priors])
         call = lambda: self.train_step(models, psn, distill, crit, trainer, st["lr"], st["hr"], st["lv"], text_priors=st["tp"])
+        # the warm-up steps and the capture pass (which only records) must not train: snapshot everything a step mutates
+        # (parameters, Adam moments and step count, BatchNorm running statistics) and put it back afterwards
+        snap = trainer.state_snapshot()
+        bufs = [b for m in models + distill for b in m.buffers()]
+        buf_snap = [b.clone() for b in bufs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -201,6 +230,9 @@ class TextSR(base.TextBase):
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             loss = call()
+        trainer.state_restore(snap)
+        for b, s_ in zip(bufs, buf_snap):
+            b.copy_(s_)
 
         def run(images_lr, images_hr, label_vecs=None, text_priors=None):
             st["lr"].copy_(images_lr)
@@ -215,29 +247,64 @@ class TextSR(base.TextBase):
         run.graph = graph
         return run
 
-    def train(self, loader=None, steps=None):
-        """Training loop over a loader of (images_hr, images_lr, label_vecs) batches (the TextZoom LMDB reader and the
-        recogniser-driven text priors are out of scope: synthetic batches / priors by default)."""
-        world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    def train(self, loader=None, steps=None, val_loader=None, rec=None):
+        """Training loop (super_resolution.py:125-337) over a loader of (images_hr, images_lr, label_vecs) batches (the
+        TextZoom LMDB reader and the recogniser-driven text priors are out of scope: synthetic batches / priors by default).
+        Bookkeeping as in the reference: display every displayInterval, eval + best-model checkpoint every
+        VAL.valInterval when a val_loader is given (best = recognition accuracy when `rec` computes one, else PSNR --
+        the reference's criterion needs its out-of-scope recognisers), checkpoint.pth every saveInterval and at the end.
+        Rank 0 writes the files."""
+        dist = torch.distributed
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
         models, psn, distill, crit, trainer = self.build_training(world)
+        if getattr(self, "rank_seed", None) is not None:      # models are built (and broadcast): now diverge the per-rank RNG
+            from ..utils.util import set_seed
+            set_seed(self.rank_seed)
         fn = self.synthetic_text_prior()
         if loader is None:
             raise RuntimeError("dpmn_amd: pass a loader of (images_hr, images_lr, label_vecs) batches")
+        cfg = self.config.TRAIN
+        val_int = getattr(getattr(cfg, "VAL", None), "valInterval", None) or 80
+        log_path = os.path.join(getattr(cfg, "ckpt_dir", None) or ".", "log.csv")
+        best, best_info, converge = None, {}, []
         it = 0
         for data in loader:
             hr, lr = data[0].to(self.device), data[1].to(self.device)
             lv = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
             loss = self.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_prior_fn=fn)
             it += 1
-            if it % self.config.TRAIN.displayInterval == 0:
+            if it % cfg.displayInterval == 0 and rank == 0:
                 print('iter %d | Loss: %f' % (it, float(loss)))
+            if val_loader is not None and it % val_int == 0:
+                md = self.eval(models, val_loader() if callable(val_loader) else val_loader, 0, rec=rec, model_psn=psn, text_prior_fn=fn)
+                for m_ in models + distill:
+                    m_.train()
+                converge.append({'iterator': it, 'acc': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']})
+                score = md['accuracy'] if md['accuracy'] is not None else md['psnr_avg']
+                is_best = best is None or score > best
+                if is_best:
+                    best = score
+                    best_info = {'accuracy': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']}
+                if rank == 0:
+                    if is_best:
+                        self.save_checkpoint(models, 0, it, {'score': best}, best_info, True, converge, None)
+                    os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
+                    with open(log_path, "a+", newline="") as out:
+                        csv.writer(out).writerow([0, "val", md['accuracy'], md['psnr_avg'], md['ssim_avg'], "", "best_sum" if is_best else ""])
+            if it % cfg.saveInterval == 0 and rank == 0:
+                self.save_checkpoint(models, 0, it, {'score': best}, best_info, False, converge, None)
             if steps is not None and it >= steps:
                 break
+        if rank == 0 and it % cfg.saveInterval != 0:
+            self.save_checkpoint(models, 0, it, {'score': best}, best_info, False, converge, None)
         return models, distill
 
-    def test(self, loader=None):
-        models, psn = self.build_models(testing=bool(self.resume))
+    def test(self, loader=None, rec=None):
+        """super_resolution.py:515-775: PGRMs from model_best_{k}.pth, CMM from model_best_cmm.pth, PSN from model_{arch}.pth
+        under --resume (all required: there is no evaluation of untrained weights)."""
+        models, psn = self.build_models(testing=True)
         if loader is None:
             raise RuntimeError("dpmn_amd: TextZoom LMDB loading is out of scope (SURVEY.md section 2 row 18); pass a loader of "
                                "(images_hr, images_lr, label_vecs) batches, e.g. dpmn_amd.utils.synth.synth_batch")
-        return self.eval(models, loader, 0, model_psn=psn)
+        return self.eval(models, loader, 0, rec=rec, model_psn=psn)

@@ -251,4 +251,6 @@ class CMMFunction(torch.autograd.Function):
 
 
 def apply(m, x1, x2):
+    if getattr(m, "_dpmn_bucket", None) is not None:
+        m._dpmn_bucket.note_use()
     return CMMFunction.apply(m, x1, x2, *list(m.parameters()))

@@ -1,59 +1,113 @@
 """Optimizer + data-parallel gradient exchange of the DPMN training step (interfaces/super_resolution.py:272-278,
-base.py:200-223; DataParallel's reduce replaced per SURVEY.md section 5.8).
+base.py:200-223; nn.DataParallel's broadcast/reduce replaced per SURVEY.md section 5.8 and section 8(f)-2).
 
-Each model (PGRM_k, DistillModule_j, CMM) becomes ONE flat bucket: parameters and gradients are views into contiguous
-buffers, so
-  * clip_grad_norm_(model.parameters(), 0.25) is one sum-of-squares kernel,
-  * Adam(lr, betas=(beta1, 0.999)) is one fused kernel (clip coefficient applied on the fly, no host sync),
-  * the RCCL all-reduce is one collective per model, launched as soon as the model's last gradient lands -- CMM's
-    214 MB bucket goes first (its backward runs first) and overlaps with the PGRM backward.
+Storage: ONE parameter arena and ONE gradient arena for the whole trainer.  Each model (PGRM_k, DistillModule_j, CMM) is a
+`FlatBucket` = a contiguous range of both arenas (every parameter view 256-byte aligned), so
+  * zero_grad is one memset,
+  * clip_grad_norm_(model.parameters(), 0.25) is one sum-of-squares kernel per model (the clip stays PER MODEL, as in the
+    reference) and Adam(lr, betas=(beta1, 0.999)) one fused kernel (clip coefficient applied on the fly, no host sync).
+Buckets are packed into `CommGroup`s, the unit of the RCCL exchange: consecutive models (in the trainer's order, CMM first
+because its backward runs first) are coalesced until a group holds >= `group_mb` of gradients -- CMM's 214 MB is its own
+group, the 2.3 MB PGRMs and the 1 KB DistillModules share groups, so no latency-bound small collective is issued.
+A group's collective is launched the moment the LAST gradient of its LAST member has been accumulated in the current
+backward (async, on RCCL's stream, overlapping the rest of the backward) and is waited for right before its optimizer
+kernels.  Two exchange modes:
+  * zero1=False: all-reduce(AVG) of the group's gradient range; every rank runs the full clip+Adam.
+  * zero1=True (default for world > 1; ZeRO-1): reduce-scatter(AVG) -> every rank owns 1/world of the group's range
+    -> per-model ||g||^2 of the owned slices, one tiny all-reduce(SUM) of those scalars (the per-model clip needs the norm
+    of the WHOLE model gradient) -> clip+Adam on the owned slices only (exp_avg / exp_avg_sq exist only for the owned
+    1/world) -> async all-gather of the updated parameters, waited for by the first forward that uses a member model
+    (CMM's 214 MB all-gather hides behind the next step's PSN + PGRM forward).
+Gradient averaging over ranks = the single-device semantics of the reference (mean of per-shard means, SURVEY 5.8).
+Replicas start identical: rank 0's parameters and buffers (BatchNorm running statistics) are broadcast at construction,
+which is what nn.DataParallel's per-forward replicate() guarantees in the reference (base.py:160-162).
+
 PGRM and CMM (explicit backward kernels, train/pgrm_train.py, train/cmm_train.py) run in DIRECT mode: their backward
 accumulates straight into the bucket's gradient views and reports completion itself, so autograd never allocates,
-zero-fills or adds a per-parameter gradient tensor (that was ~1500 tiny launches per step).  Every other module keeps the
-ordinary post-accumulate-grad hooks.
-Gradient averaging over ranks = the single-device semantics of the reference (mean of per-shard means).
+zero-fills or adds a per-parameter gradient tensor.  A module invoked several times per step (--sr_share) reports once per
+call; the bucket is ready when as many backward calls have finished as forward calls were made.  Every other module
+keeps ordinary post-accumulate-grad hooks.
 """
 import torch
 import torch.distributed as dist
 
 from .._abi import lib, check, dptr, stream
 
+ALIGN = 64          # floats: every parameter / gradient view starts on a 256-byte boundary (float4 + atomics friendly)
+
+
+def _padded(n, a=ALIGN):
+    return (n + a - 1) // a * a
+
+
+def _sumsq(g, out, part):
+    """out[0] = sum(g^2) on the GPU (csrc/conv_bwd.hip k_sumsq_partial).  Module-level so the CPU gloo tests can
+    substitute a torch restatement for the two kernels below -- the product path has no CPU implementation."""
+    if not g.is_cuda:
+        raise RuntimeError("dpmn_amd: the optimizer kernels run on the GPU only")
+    check(lib.dpmn_sumsq_f32(dptr(g), dptr(out), dptr(part), g.numel(), stream()))
+
+
+def _adam_clip(p, g, m, v, normsq, max_norm, lr, beta1, beta2, eps, step, step_dev):
+    if not p.is_cuda:
+        raise RuntimeError("dpmn_amd: the optimizer kernels run on the GPU only")
+    check(lib.dpmn_adam_clip_f32(dptr(p), dptr(g), dptr(m), dptr(v), dptr(normsq), max_norm, lr, beta1, beta2, eps, step,
+                                 dptr(step_dev, True), p.numel(), stream()))
+
 
 class FlatBucket:
-    def __init__(self, module, name="", direct=False):
+    """One model's parameters / gradients as one contiguous range.  Stand-alone (`FlatBucket(module)`) it owns its storage;
+    inside a Trainer the storage is a slice of the trainer's arenas (`storage=(flat_p, flat_g)`)."""
+
+    def __init__(self, module, name="", direct=False, storage=None):
         self.name = name
         self.direct = direct
+        self.module = module
         self.params = [p for p in module.parameters()]
-        align = 64      # floats: every parameter / gradient view starts on a 256-byte boundary (float4 + atomics friendly)
-        n = sum((p.numel() + align - 1) // align * align for p in self.params)
+        n = self.size_of(module)
         dev = self.params[0].device
-        self.flat_p = torch.zeros(n, device=dev)
-        self.flat_g = torch.zeros(n, device=dev)
+        if storage is None:
+            self.flat_p = torch.zeros(n, device=dev)
+            self.flat_g = torch.zeros(n, device=dev)
+        else:
+            self.flat_p, self.flat_g = storage
+            assert self.flat_p.numel() == n and self.flat_g.numel() == n
         off = 0
         for p in self.params:
             k = p.numel()
             self.flat_p[off:off + k].copy_(p.data.reshape(-1))
             p.data = self.flat_p[off:off + k].view(p.shape)
             p.grad = self.flat_g[off:off + k].view(p.shape)
-            off += (k + align - 1) // align * align
+            off += _padded(k)
         if direct:
             for p in self.params:
                 p._dpmn_sink = p.grad
             module._dpmn_bucket = self
         self.n = n
-        self.m = torch.zeros(n, device=dev)
-        self.v = torch.zeros(n, device=dev)
         self.normsq = torch.zeros(1, device=dev)
         self.part = torch.empty(1024, device=dev)
-        self.work = None
+        self.m = self.v = None          # allocated on first stand-alone step(); a CommGroup owns them otherwise
+        self.group = None
+        self.uses = 0                   # direct mode: forward calls of the module in this step ...
+        self.done = 0                   # ... and backward calls that have finished
         self._pending = 0
+        self._expect = 0
+        self.ready = False
 
-    # ------------------------------------------------------------------ DP exchange
-    def install_hooks(self, world_size, group=None):
-        """all-reduce this bucket as soon as every parameter has accumulated its gradient in the current backward."""
-        self.world, self.group = world_size, group
+    @staticmethod
+    def size_of(module):
+        return sum(_padded(p.numel()) for p in module.parameters())
+
+    # ------------------------------------------------------------------ readiness (when may the exchange start?)
+    def install_hooks(self, world_size=1, group=None):
+        """Stand-alone use (tests, single bucket): wraps the bucket in its own CommGroup."""
+        if self.group is None:
+            CommGroup([self], world_size, group, zero1=False)
+        return self
+
+    def _install_ready_hooks(self):
         if self.direct:
-            return          # the module's backward calls grads_ready() itself
+            return          # the module's forward / backward call note_use() / grads_ready() themselves
         trainable = [p for p in self.params if p.requires_grad]
         self._expect = len(trainable)
 
@@ -61,62 +115,260 @@ class FlatBucket:
             self._pending += 1
             if self._pending == self._expect:
                 self._pending = 0
-                self.launch_allreduce()
+                self._mark_ready()
         for p in trainable:
             p.register_post_accumulate_grad_hook(hook)
 
+    def note_use(self):
+        """direct mode: the module's training forward ran once more in this step."""
+        self.uses += 1
+
     def grads_ready(self):
-        """direct mode: called by the module's backward once every gradient of this bucket has been accumulated."""
-        self.launch_allreduce()
+        """direct mode: one backward call of the module has accumulated all its gradients."""
+        self.done += 1
+        if self.done >= max(self.uses, 1):
+            self._mark_ready()
 
-    def launch_allreduce(self):
-        if getattr(self, "world", 1) > 1:
-            self.flat_g.div_(self.world)    # pre-scale: average (mean of per-shard means, SURVEY.md section 5.8)
-            self.work = dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+    def _mark_ready(self):
+        self.ready = True
+        if self.group is not None:
+            self.group.member_ready()
 
+    def reset_step(self):
+        self.uses = self.done = self._pending = 0
+        self.ready = False
+
+    # ------------------------------------------------------------------ stand-alone optimizer API
     def wait(self):
-        if self.work is not None:
-            self.work.wait()
-            self.work = None
+        if self.group is not None:
+            self.group.wait_grads()
 
-    # ------------------------------------------------------------------ optimizer
     def zero_grad(self):
         self.flat_g.zero_()
+        self.reset_step()
+        if self.group is not None:
+            self.group.launched = False
 
     def step(self, step, lr, beta1, beta2=0.999, eps=1e-8, max_norm=0.25, step_dev=None):
-        if self.flat_g.is_cuda:
-            check(lib.dpmn_sumsq_f32(dptr(self.flat_g), dptr(self.normsq), dptr(self.part), self.n, stream()))
-            check(lib.dpmn_adam_clip_f32(dptr(self.flat_p), dptr(self.flat_g), dptr(self.m), dptr(self.v), dptr(self.normsq),
-                                         max_norm, lr, beta1, beta2, eps, step, dptr(step_dev, True), self.n, stream()))
+        """clip + Adam over the whole bucket (single-process semantics)."""
+        if self.m is None:
+            self.m = torch.zeros_like(self.flat_p)
+            self.v = torch.zeros_like(self.flat_p)
+        _sumsq(self.flat_g, self.normsq, self.part)
+        _adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.normsq, max_norm, lr, beta1, beta2, eps, step, step_dev)
+
+
+class CommGroup:
+    """Several buckets adjacent in the arenas, exchanged with one collective."""
+
+    def __init__(self, buckets, world=1, pg=None, zero1=False, arena=None):
+        self.buckets = buckets
+        self.world, self.pg, self.zero1 = world, pg, bool(zero1) and world > 1
+        self.rank = dist.get_rank(pg) if world > 1 else 0
+        if arena is None:      # stand-alone bucket: its own storage is the group's range (no padding to `world` needed)
+            assert len(buckets) == 1 and not self.zero1
+            self.flat_p, self.flat_g = buckets[0].flat_p, buckets[0].flat_g
         else:
-            raise RuntimeError("dpmn_amd: the optimizer kernels run on the GPU only")
+            self.flat_p, self.flat_g = arena
+        self.n = self.flat_g.numel()
+        self.offsets = []
+        off = 0
+        for b in buckets:
+            self.offsets.append(off)
+            off += b.n
+            b.group = self
+            b._install_ready_hooks()
+        dev = self.flat_p.device
+        if self.zero1:
+            assert self.n % world == 0
+            self.shard_n = self.n // world
+            self.lo = self.rank * self.shard_n
+            self.g_shard = torch.zeros(self.shard_n, device=dev)      # reduce-scatter output (averaged gradients I own)
+        else:
+            self.shard_n, self.lo = self.n, 0
+            self.g_shard = self.flat_g
+        self.m = torch.zeros(self.shard_n, device=dev)
+        self.v = torch.zeros(self.shard_n, device=dev)
+        self.normsq = torch.zeros(len(buckets), device=dev)
+        self.part = torch.empty(1024, device=dev)
+        self.launched = False
+        self.grad_work = None
+        self.param_work = None
+        self._post_scale = None
+        if self.zero1:
+            for b in buckets:      # the all-gather of step t is awaited by the first forward of step t+1 that needs it
+                b.module.register_forward_pre_hook(lambda _m, _a: self.wait_params())
+
+    # ------------------------------------------------------------------ gradient exchange
+    def member_ready(self):
+        if not self.launched and all(b.ready for b in self.buckets):
+            self.launch()
+
+    def launch(self):
+        self.launched = True
+        if self.world <= 1:
+            return
+        avg = dist.ReduceOp.AVG
+        self._post_scale = None
+        if dist.get_backend(self.pg) != "nccl":        # test hook (gloo): no AVG / reduce-scatter guarantee on every build
+            avg = dist.ReduceOp.SUM
+            self._post_scale = 1.0 / self.world
+        if self.zero1:
+            try:
+                self.grad_work = dist.reduce_scatter_tensor(self.g_shard, self.flat_g, op=avg, group=self.pg, async_op=True)
+            except (RuntimeError, NotImplementedError):
+                if dist.get_backend(self.pg) == "nccl":
+                    raise
+                self.grad_work = dist.all_reduce(self.flat_g, op=avg, group=self.pg, async_op=True)
+                self._copy_shard = True
+        else:
+            self.grad_work = dist.all_reduce(self.flat_g, op=avg, group=self.pg, async_op=True)
+
+    def wait_grads(self):
+        if not self.launched:
+            self.launch()       # a member never reported (e.g. a parameter without gradient): exchange now, still correct
+        if self.grad_work is not None:
+            self.grad_work.wait()
+            self.grad_work = None
+            if getattr(self, "_copy_shard", False):
+                self.g_shard.copy_(self.flat_g[self.lo:self.lo + self.shard_n])
+                self._copy_shard = False
+            if self._post_scale is not None:
+                self.g_shard.mul_(self._post_scale)
+
+    def wait_params(self):
+        if self.param_work is not None:
+            self.param_work.wait()
+            self.param_work = None
+
+    # ------------------------------------------------------------------ optimizer
+    def _owned(self, i):
+        """intersection of bucket i with the range this rank owns, as (offset in the shard, length)."""
+        a = max(self.offsets[i], self.lo)
+        b = min(self.offsets[i] + self.buckets[i].n, self.lo + self.shard_n)
+        return (a - self.lo, b - a) if b > a else (0, 0)
+
+    def step(self, step, lr, beta1, beta2=0.999, eps=1e-8, max_norm=0.25, step_dev=None):
+        self.wait_grads()
+        self.wait_params()
+        owned = [self._owned(i) for i in range(len(self.buckets))]
+        if self.zero1:
+            self.normsq.zero_()
+        for i, (o, k) in enumerate(owned):
+            if k:
+                _sumsq(self.g_shard[o:o + k], self.normsq[i:i + 1], self.part)
+        if self.zero1:
+            dist.all_reduce(self.normsq, op=dist.ReduceOp.SUM, group=self.pg)     # len(buckets) floats
+        p_shard = self.flat_p[self.lo:self.lo + self.shard_n]
+        for i, (o, k) in enumerate(owned):
+            if k:
+                _adam_clip(p_shard[o:o + k], self.g_shard[o:o + k], self.m[o:o + k], self.v[o:o + k], self.normsq[i:i + 1],
+                           max_norm, lr, beta1, beta2, eps, step, step_dev)
+        if self.zero1:
+            self.param_work = dist.all_gather_into_tensor(self.flat_p, p_shard, group=self.pg, async_op=True)
+
+
+def broadcast_replicas(models, flat_p, pg=None):
+    """All ranks start from rank 0's parameters and buffers (the reference replicates one model, base.py:160-162)."""
+    dist.broadcast(flat_p, src=0, group=pg)
+    for m in models:
+        for buf in m.buffers():
+            if buf.numel():
+                dist.broadcast(buf, src=0, group=pg)
 
 
 class Trainer:
-    """zero_grad / backward hooks / clip+Adam over a list of models, in the reference's order."""
+    """zero_grad / gradient exchange / clip+Adam over a list of models, in the reference's order."""
 
-    def __init__(self, models, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=1, group=None):
-        self.buckets = [FlatBucket(m, "model%d" % i, direct=getattr(m, "direct_grad", False)) for i, m in enumerate(models)]
+    def __init__(self, models, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=1, group=None, zero1=None, group_mb=6.0):
         self.lr, self.beta1, self.max_norm = lr, beta1, max_norm
+        self.world = world_size
+        zero1 = (world_size > 1) if zero1 is None else (bool(zero1) and world_size > 1)
+        self.zero1 = zero1
         self.t = 0
         self.t_dev = None       # device-side step counter, see device_step_counter()
-        for b in self.buckets:
-            b.install_hooks(world_size, group)
+        dev = next(models[0].parameters()).device
+        # exchange order = expected backward order: the model list arrives as [PGRM_0.., CMM, Distill..] and the backward
+        # runs CMM first, then the distill modules, then the PGRMs last-to-first
+        sizes = [FlatBucket.size_of(m) for m in models]
+        order = self._backward_order(models)
+        plan, cur, cur_n = [], [], 0
+        for i in order:
+            cur.append(i)
+            cur_n += sizes[i]
+            if cur_n * 4 >= group_mb * 2 ** 20:
+                plan.append(cur)
+                cur, cur_n = [], 0
+        if cur:
+            if plan and sum(sizes[i] for i in cur) * 4 < 2 ** 20 and len(plan) > 1:
+                plan[-1].extend(cur)        # a sub-megabyte tail joins the previous small-model group
+            else:
+                plan.append(cur)
+        unit = ALIGN * max(world_size, 1)
+        gsize = [_padded(sum(sizes[i] for i in g), unit) for g in plan]
+        total = sum(gsize)
+        self.flat_p = torch.zeros(total, device=dev)
+        self.flat_g = torch.zeros(total, device=dev)
+        self.buckets = [None] * len(models)
+        self.groups = []
+        off = 0
+        for g, gs in zip(plan, gsize):
+            o = off
+            members = []
+            for i in g:
+                st = (self.flat_p[o:o + sizes[i]], self.flat_g[o:o + sizes[i]])
+                b = FlatBucket(models[i], "model%d" % i, direct=getattr(models[i], "direct_grad", False), storage=st)
+                self.buckets[i] = b
+                members.append(b)
+                o += sizes[i]
+            self.groups.append(CommGroup(members, world_size, group, zero1, arena=(self.flat_p[off:off + gs], self.flat_g[off:off + gs])))
+            off += gs
+        if world_size > 1:
+            broadcast_replicas(models, self.flat_p, group)
+
+    @staticmethod
+    def _backward_order(models):
+        idx = list(range(len(models)))
+        big = [i for i in idx if type(models[i]).__name__ == "ComplementationModulationModule"]
+        small = [i for i in idx if type(models[i]).__name__ == "DistillModule"]
+        rest = [i for i in idx if i not in big and i not in small]
+        return big + small + rest[::-1]
 
     def zero_grad(self):
+        self.flat_g.zero_()
         for b in self.buckets:
-            b.zero_grad()
+            b.reset_step()
+        for g in self.groups:
+            g.launched = False
 
     def device_step_counter(self):
         """Keep Adam's step count in device memory from now on, so that a hipGraph capture of the training step replays
         the right bias corrections (host scalars are frozen into a graph at capture time)."""
         if self.t_dev is None:
-            self.t_dev = torch.full((1,), float(self.t), device=self.buckets[0].flat_p.device)
+            self.t_dev = torch.full((1,), float(self.t), device=self.flat_p.device)
+
+    def sync_params(self):
+        """Wait for outstanding parameter all-gathers (ZeRO-1); call before reading parameters outside a forward."""
+        for g in self.groups:
+            g.wait_params()
+
+    def state_snapshot(self):
+        """Everything a step mutates in the optimizer (used to undo hipGraph warm-up steps)."""
+        return dict(p=self.flat_p.clone(), t=self.t, t_dev=None if self.t_dev is None else self.t_dev.clone(),
+                    mv=[(g.m.clone(), g.v.clone()) for g in self.groups])
+
+    def state_restore(self, snap):
+        self.flat_p.copy_(snap["p"])
+        self.t = snap["t"]
+        if self.t_dev is not None and snap["t_dev"] is not None:
+            self.t_dev.copy_(snap["t_dev"])
+        for g, (m, v) in zip(self.groups, snap["mv"]):
+            g.m.copy_(m)
+            g.v.copy_(v)
 
     def step(self):
         self.t += 1
         if self.t_dev is not None:
             self.t_dev.add_(1.0)
-        for b in self.buckets:
-            b.wait()
-            b.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
+        for g in self.groups:
+            g.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)

@@ -163,7 +163,9 @@ def forward(m, x_q, x_kv, residuals, drop=None):
     M, Ch, G = B * L, int(m.embed_dim * m.mlp_ratio), len(m.window_size)
     hpg = m.num_heads // G
     pe = m.patch_embed
-    fuse = not m.mode
+    fuse = x_q.shape[1] == 2          # pgrm.py:547-548: prior_fusion runs iff the prior has 2 channels, whatever `mode` is
+    if fuse and m.mode:
+        raise _abi.DpmnError("PGRM(mode=True) has no prior_fusion: x_q must have 3 channels (pgrm.py:470,547)")
     pf = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
     tq = ops.patch_embed_ln(x_q, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch, *pf).reshape(M, Cd)
     tkv = ops.patch_embed_ln(x_kv, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch).reshape(M, Cd)
@@ -316,7 +318,7 @@ def backward(m, sv, dout, need_dx_kv=True):
     pe = m.patch_embed
     dx_kv = None
     for which, img, dtok in (("kv", sv["x_kv"], dtkv), ("q", sv["x_q"], dtq)):
-        fuse = which == "q" and not m.mode
+        fuse = which == "q" and img.shape[1] == 2
         pfw, pfb = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
         dconv = torch.empty(M, Cd, device=dout.device)
         patches = torch.empty(M, 16, device=dout.device)
@@ -362,5 +364,7 @@ class PGRMFunction(torch.autograd.Function):
 
 
 def apply(m, x_q, x_kv, residual_list):
+    if getattr(m, "_dpmn_bucket", None) is not None and torch.is_grad_enabled():
+        m._dpmn_bucket.note_use()       # a shared module (--sr_share) reports ready after as many backward calls
     params = list(m.parameters())
     return PGRMFunction.apply(m, x_q, x_kv, len(residual_list), *residual_list, *params)

@@ -43,8 +43,12 @@ def main(config, args):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl")
     rank = dist.get_rank() if dist.is_initialized() else 0
-    set_seed(config.TRAIN.manualSeed + rank)
+    # same seed on every rank while the models are built (replicas must start identical, like nn.DataParallel's replicate of
+    # ONE model, base.py:160-162; the Trainer additionally broadcasts rank 0's parameters and buffers); the per-rank stream
+    # (data order, augmentation, dropout seeds) is re-seeded in TextSR.train after construction
+    set_seed(config.TRAIN.manualSeed)
     mission = TextSR(config, args)
+    mission.rank_seed = config.TRAIN.manualSeed + rank
     bs = args.batch_size or config.TRAIN.batch_size
     os.makedirs(config.TRAIN.ckpt_dir, exist_ok=True)
     if args.test:

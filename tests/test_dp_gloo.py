@@ -65,3 +65,142 @@ def test_bucketed_allreduce_world2_gloo():
         assert p.exitcode == 0
     for rank, err, scale in res:
         assert scale > 0 and err < 1e-6 * max(1.0, scale), (rank, err, scale)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Trainer level: arena + CommGroups, ZeRO-1 (reduce-scatter -> sharded per-model clip + Adam -> all-gather), replica
+# broadcast, and DIRECT-mode buckets (the path PGRM / CMM use) including a module invoked twice per step (--sr_share).
+# The two optimizer kernels are GPU-only in the product; here a torch restatement is injected so the exchange logic,
+# the shard arithmetic and the per-model clip can be checked on CPU.
+
+def _torch_sumsq(g, out, part):
+    out.copy_((g.double() ** 2).sum().float().reshape(1))
+
+
+def _torch_adam_clip(p, g, m, v, normsq, max_norm, lr, b1, b2, eps, step, step_dev):
+    coef = 1.0
+    if max_norm > 0:
+        coef = min(1.0, max_norm / (float(normsq[0]) ** 0.5 + 1e-6))
+    gi = g * coef
+    m.mul_(b1).add_(gi, alpha=1 - b1)
+    v.mul_(b2).addcmul_(gi, gi, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    p.sub_((lr / bc1) * m / (v.sqrt() / bc2 ** 0.5 + eps))
+
+
+class _DirectLinear(torch.nn.Module):
+    """y = x W^T with an explicit backward that accumulates straight into the bucket's gradient view and reports
+    completion itself -- the protocol of train/pgrm_train.py (grad_targets / finish_grads)."""
+    direct_grad = True
+
+    def __init__(self, i, o):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.randn(o, i) * 0.3)
+
+    def forward(self, x):
+        m = self
+
+        class F(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                ctx.save_for_backward(x)
+                return x @ w.t()
+
+            @staticmethod
+            def backward(ctx, dy):
+                (x,) = ctx.saved_tensors
+                dx = dy @ m.weight.detach()
+                if getattr(m, "_dpmn_bucket", None) is None:      # plain autograd (the single-process reference)
+                    return dx, dy.t() @ x
+                m.weight._dpmn_sink += dy.t() @ x
+                m._dpmn_bucket.grads_ready()
+                return dx, None
+        if getattr(self, "_dpmn_bucket", None) is not None:
+            self._dpmn_bucket.note_use()
+        return F.apply(x, self.weight)
+
+
+class ComplementationModulationModule(torch.nn.Module):     # same class NAME as the big model: scheduled first, own group
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(5, 700)
+        self.b = torch.nn.Linear(700, 3)
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def _build(seed):
+    torch.manual_seed(seed)
+    return [_DirectLinear(6, 5), _DirectLinear(5, 5), ComplementationModulationModule(), torch.nn.Linear(3, 2)]
+
+
+def _loss(models, x):
+    d0, d1, big, tail = models
+    h = d1(d1(d0(x)))                   # d1 is used twice in one step (shared module)
+    return tail(big(h)).pow(2).mean() * 50
+
+
+def _trainer_worker(rank, world, port, q, zero1):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpmn_amd.train import optim
+    optim._sumsq, optim._adam_clip = _torch_sumsq, _torch_adam_clip
+    models = _build(1000 + rank)          # DIFFERENT initial weights per rank: the trainer must broadcast rank 0's
+    tr = optim.Trainer(models, lr=1e-2, beta1=0.5, max_norm=0.25, world_size=world, zero1=zero1, group_mb=0.005)
+    assert len(tr.groups) >= 2 and tr.groups[0].buckets[0].module is models[2]
+    ref = _build(1000)                    # single-process reference = rank 0's weights, averaged gradients
+    for a, b in zip(models, ref):
+        for p, r in zip(a.parameters(), b.parameters()):
+            assert torch.equal(p.detach(), r.detach()), "replicas must start from rank 0's parameters"
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-2, betas=(0.5, 0.999)) for m in ref]
+    worst = 0.0
+    for step in range(3):
+        xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * step + r)) for r in range(world)]
+        tr.zero_grad()
+        _loss(models, xs[rank]).backward()
+        assert all(g.launched for g in tr.groups), "every group's exchange starts inside backward"
+        tr.step()
+        tr.sync_params()
+        for m in ref:
+            m.zero_grad()
+        for r in range(world):
+            (_loss(ref, xs[r]) / world).backward()          # mean of per-shard means
+        for m, o in zip(ref, opts):
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 0.25)    # per model, as super_resolution.py:272-277
+            o.step()
+        for a, b in zip(models, ref):
+            for p, r in zip(a.parameters(), b.parameters()):
+                worst = max(worst, float((p.detach() - r.detach()).abs().max()))
+    flat = tr.flat_p.clone()
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    same = all(torch.equal(other[0], o) for o in other)
+    q.put((rank, worst, same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_trainer(zero1):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_trainer_worker, args=(r, 2, port, q, zero1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, same in res:
+        assert same, "ranks diverged (rank %d)" % rank
+        assert worst < 2e-5, (rank, worst)
+
+
+def test_trainer_allreduce_direct_mode_world2_gloo():
+    _run_trainer(zero1=False)
+
+
+def test_trainer_zero1_sharded_adam_world2_gloo():
+    _run_trainer(zero1=True)

@@ -355,7 +355,7 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
             p.requires_grad = True
     Trainer(models)                      # parameters become views into padded flat buffers
     sr.vis_dir = str(tmp_path)
-    sr.save_checkpoint(models, epoch=3, iters=7, best_acc_dict={}, best_model_info={}, is_best=True, converge_list=[], name="sum")
+    sr.save_checkpoint(models, epoch=3, iters=7, best_acc_dict={}, best_model_info={}, is_best=True, converge_list=[], metric="sum")
     x_q, x_kv = inp["text_priors"][0], inp["images_hr"][:, :3].contiguous()
     with torch.no_grad():
         ref = models[0](x_q, x_kv, [])
@@ -391,11 +391,10 @@ def test_graphed_train_step_matches_eager(dev):
     batches = [synth.synth_batch(B, seed=20 + i) for i in range(2)]
     priors = [[torch.floor(synth.uniform("gtp%d_%d" % (i, k), (B, 2, 32, 128), 0, 256, 4)).to(dev) for k in range(b1)] for i in range(2)]
     warm = 2
-    # eager: `warm` steps on batch 0 (what the capture's warm-up does), then one step on each batch
+    # eager: one step on each batch from the fresh state (the capture's warm-up steps are undone: parameters, Adam state and
+    # BatchNorm running statistics are snapshotted before and restored after the capture)
     sr_, models, psn, distill, crit, trainer = fresh()
     lr0, hr0 = batches[0]["images_lr"].to(dev), batches[0]["images_hr"].to(dev)
-    for _ in range(warm):
-        sr_.train_step(models, psn, distill, crit, trainer, lr0, hr0, None, text_priors=priors[0])
     eager_losses = [float(sr_.train_step(models, psn, distill, crit, trainer, b["images_lr"].to(dev), b["images_hr"].to(dev), None,
                                          text_priors=priors[i])) for i, b in enumerate(batches)]
     eager_params = [p.detach().clone() for m in models for p in m.parameters()]
