@@ -3,29 +3,36 @@
 
 A "step" = one pass of the hot path over one synthetic batch already resident in HBM:
 frozen TATT PSN -> 3 text-prior PGRMs -> 3 mask-prior PGRMs (toMask on the GPU) -> CMM -> alpha blend,
-fp32, per-GPU batch 48 (BASELINE.json configs[1]).  With N > 1 every rank runs the same step on its own
-batch shard (weak scaling, no data-path collective in the forward path); the timed region is bracketed by
-barrier + synchronize and the MAX over ranks is reported.
+fp32, per-GPU batch 48 (BASELINE.json configs[1]).  `--gpus N` runs N ranks, one per GPU, over RCCL: launched by the
+driver under torch.distributed.run (WORLD_SIZE in the environment) or, when started as a plain `python bench.py --gpus N`,
+by re-executing itself under torch.distributed.run.  Every rank runs the same step on its own batch shard (weak
+scaling, no data-path collective in the forward path; `--mode train` adds the bucketed RCCL gradient exchange); the
+timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel (Mlp pointwise GEMM, csrc/gemm.hip::k_gemm_pw): algorithmic FLOPs per
-                  launch / mean launch duration measured live with HIP events on the launch stream, against
-                  the dense fp32-MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
-  cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+  roofline     -- the kernel family that takes the most time in the step (picked from an all-families profile of the last
+                  warm-up step, so it always names what the profile ranks first): algorithmic FLOPs (or bytes) of its
+                  launches / their summed duration, both taken from HIP events the library records around EVERY launch of
+                  that family inside the timed steps, on the stream it is launched on (include/dpmn_hip.h dpmn_profile_*).
+                  `traffic` is static: HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/), or null.
+  kernels      -- the same measurement for the top families (3 extra, untimed steps after the timed region with every
+                  family armed): launches/step, us/launch, TFLOP/s, GB/s, which roof bounds it and the fraction reached.
+  cpu_baseline -- the CPU oracle (oracle/, kind "port") timed on this box's host cores: B = 48, 2 warm-ups, median of 5.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
-FP32_MFMA_PEAK_TFLOPS = 157.3
+FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32), no TF32 on gfx950
+HBM_PEAK_GBS = 8000.0             # HBM3E spec (6.3 TB/s is the measured streaming ceiling)
+RIDGE = FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)   # FLOP per byte above which the MFMA roof bounds a kernel
 
 
 def parse():
@@ -34,87 +41,95 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="train mode, 1 GPU: replay the step from one hipGraph capture")
-    ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1", "cfg3"])
+    ap.add_argument("--workload", default="cfg1", choices=["cfg0", "cfg1", "cfg3", "cfg4"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--mode", default="fwd", choices=["fwd", "train"],
-                    help="fwd: BASELINE.json configs[1] (headline metric); train: configs[2] step (loss, backward, clip+Adam, RCCL all-reduce)")
+                    help="fwd: BASELINE.json configs[1] (headline metric); train: configs[2] step (loss, backward, clip+Adam, RCCL gradient exchange)")
     ap.add_argument("--drop", type=float, default=0.0,
                     help="train mode: Dropout = attn_drop = DropPath rate (the reference README trains with 0.1; default 0)")
+    ap.add_argument("--zero1", type=int, default=None, help="train mode, N > 1: 1 = reduce-scatter + sharded clip/Adam + all-gather (default), 0 = all-reduce")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="images in the CPU-baseline sample")
+    ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel event timing (roofline = null)")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="images in the CPU-baseline sample (default: the per-GPU batch)")
     return ap.parse_args()
 
 
-def roofline_pw(B, reps=30, live=None):
-    """The dominant kernel on the step's shapes: z[b] = Wp(384x384) . g[b](384x1024), b < B.
-    live = (launches, mean ms) from the HIP events the library recorded around every launch of the timed region; without
-    it (graph replay) the kernel is timed alone, after 200 back-to-back launches: the part needs ~20 ms of sustained load
-    to reach its clocks (139.7 us cold -> 123.5 us, measured with rocprofv3), which the timed steps have and a cold loop has not."""
-    from dpmn_amd import ops
-    from dpmn_amd.utils import synth
-    if live is not None:
-        n_timed, ms = live
-        source = "HIP events around each of the %d launches inside the timed steps" % n_timed
-    else:
-        dev = torch.device("cuda", torch.cuda.current_device())
-        g = synth.uniform("rf_g", (B, 1024, 384), -1, 1, 5).to(dev)
-        w = synth.uniform("rf_w", (384, 384), -0.1, 0.1, 5).to(dev)
-        b = synth.uniform("rf_b", (384,), -0.1, 0.1, 5).to(dev)
-        for _ in range(200):
-            ops.pointwise(g, w, b)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for s, e in evs:
-            s.record()
-            ops.pointwise(g, w, b)
-            e.record()
-        torch.cuda.synchronize()
-        ms = sum(s.elapsed_time(e) for s, e in evs) / reps
-        source = "HIP events, kernel alone after 200 warm-up launches"
-    flops = 2.0 * 384 * 384 * 1024 * B
-    achieved = flops / (ms * 1e-3) / 1e12
-    # HBM bytes per launch: PMC counters cannot be read from inside this process; they come from the separate
-    # rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over tools/roofline_kernel.py (same kernel, same shapes),
-    # committed under profiles/ with the gfx950 correction already applied.  null when no pass matches this batch.
-    traffic, src = None, None
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-execute under torch.distributed.run, one rank per GPU."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def kernel_row(r, steps):
+    """dict from one dpmn_profile row: which roof bounds the family (arithmetic intensity vs the ridge) and how close it is."""
+    s = r["total_ms"] * 1e-3
+    tf = r["flops"] / s / 1e12 if s > 0 else 0.0
+    gbs = r["bytes"] / s / 1e9 if s > 0 else 0.0
+    mfma = r["bytes"] <= 0 or r["flops"] / max(r["bytes"], 1.0) >= RIDGE
+    frac = tf / FP32_MFMA_PEAK_TFLOPS if mfma else gbs / HBM_PEAK_GBS
+    return {"kernel": r["kernel"], "launches_per_step": round(r["launches"] / steps, 2), "us_per_launch": round(r["total_ms"] * 1e3 / r["launches"], 2),
+            "ms_per_step": round(r["total_ms"] / steps, 4), "tflops": round(tf, 2), "gbs": round(gbs, 1), "bound": "mfma" if mfma else "hbm",
+            "frac": round(frac, 4)}
+
+
+def static_traffic(kernel, B):
+    """HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py writes
+    profiles/*_pmc_traffic.json; counters cannot be read from inside this process)."""
     import glob
-    for f in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_k_gemm_pw.json"))):
+    best = (None, None)
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
         try:
             rec = json.load(open(f))
-            if rec.get("workload", "").startswith("B=%d:" % B):
-                traffic, src = rec["hbm_bytes_per_launch"], os.path.basename(f)
+            if rec.get("per_gpu_batch") == B and kernel in rec.get("kernels", {}):
+                best = (rec["kernels"][kernel]["hbm_bytes_per_launch"], os.path.basename(f))
         except Exception:
             pass
-    return {"kernel": "k_gemm_pw (Mlp.pointwise_conv, pgrm.py:37)", "bound": "mfma", "achieved": round(achieved, 2),
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_source": src, "algorithmic_bytes": 4.0 * (2 * B * 384 * 1024 + 384 * 384 + 384),
-            "launch_ms": round(ms, 4), "flops_per_launch": flops, "timing": source}
+    return best
 
 
 def cpu_baseline_worker(workload_name, n_img, threads):
     """Runs in a child process (no GPU context): oracle forward on synthetic weights/inputs, prints JSON."""
+    import torch
     from dpmn_amd.utils import synth
     from oracle import dpmn as odpmn
-    from dpmn_amd.workload import cpu_state_dicts
+    from dpmn_amd.workload import cpu_state_dicts, cpu_priors
     torch.set_num_threads(threads)
     arch, b1, b2, sd_psn, sds = cpu_state_dicts(workload_name)
     batch = synth.synth_batch(n_img, seed=2)
-    priors = [torch.floor(synth.uniform("text_prior_%d" % k, (n_img, 2, 32, 128), 0.0, 256.0, 2)) for k in range(b1)]
+    priors = cpu_priors(workload_name, n_img)
     run = lambda: odpmn.refine(sd_psn, sds[:-1], sds[-1], arch, b1, b2, batch["images_lr"], batch["label_vecs"], priors, 0.5)
     with torch.no_grad():
-        run()  # warm-up
-        ts = []
         for _ in range(2):
+            run()  # warm-ups
+        ts = []
+        for _ in range(5):
             t0 = time.perf_counter()
             run()
             ts.append(time.perf_counter() - t0)
-    print(json.dumps({"seconds": sorted(ts)[0]}))
+    print(json.dumps({"seconds": sorted(ts)[len(ts) // 2], "all": ts}))
 
 
-def cpu_baseline(workload_name, n_img, budget_s=150):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload_name, n_img, budget_s=300):
     """Oracle (CPU restatement, test infrastructure) timed on the host cores in a child process with a hard time
     budget: a reported baseline, not the target.  Threads are capped at 32: torch's intra-op pool stops scaling
     (and can livelock) far below the 256 logical cores of the GPU box on these small tensors."""
-    import subprocess
+    import torch
     cores = min(os.cpu_count() or 1, 32)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", workload_name, str(n_img), str(cores)]
     env = dict(os.environ, OMP_NUM_THREADS=str(cores), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
@@ -122,25 +137,33 @@ def cpu_baseline(workload_name, n_img, budget_s=150):
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s, env=env, cwd=ROOT)
         t = json.loads(out.stdout.strip().splitlines()[-1])["seconds"]
         value = round(n_img / t, 3)
-        note = "best of 2 after 1 warm-up"
+        note = "median of 5 after 2 warm-ups"
     except Exception as e:  # timeout or failure: report it, never hang the bench
         value, note = None, "failed within %ds budget: %s" % (budget_s, type(e).__name__)
-    return {"value": value, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%s forward on %d synthetic images, %s, torch %s CPU fp32 oracle" % (workload_name, n_img, note,
-                                                                                          torch.__version__)}
+    return {"value": value, "unit": "images/s", "cores": cores, "kind": "port", "cpu": "%s (%d logical cores on the box)" % (cpu_model(), os.cpu_count() or 0),
+            "sample": "%s forward on one batch of %d synthetic images, %s, torch %s CPU fp32 oracle" % (workload_name, n_img, note, torch.__version__)}
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
         return cpu_baseline_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but the launcher started %d ranks; reporting n_gpus = %d" % (args.gpus, world, world), file=sys.stderr)
     # one process per GPU.  (Test hook: DPMN_DIST_BACKEND=gloo lets several ranks share one GPU to exercise the N > 1 code
     # path on a single-GPU box -- RCCL itself refuses two ranks on one device.)
     backend = os.environ.get("DPMN_DIST_BACKEND", "nccl")
-    local = local % max(1, torch.cuda.device_count()) if backend != "nccl" else local
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit("bench.py: %d ranks need %d GPUs, this node has %d" % (world, world, ndev))
+    local = local % max(1, ndev) if backend != "nccl" else local
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -148,22 +171,24 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    from dpmn_amd import workload
+    from dpmn_amd import workload, _abi
     sr, models, psn, inp = workload.build(args.workload, batch=args.batch, drop=args.drop if args.mode == "train" else 0)
     B = inp["images_lr"].shape[0]
-    arch, b1, b2, _ = workload.CONFIGS[args.workload]
+    spec = workload.describe(args.workload)
+    arch, b1, b2 = spec["arch"], spec["b1"], spec["b2"]
 
     if args.mode == "train":
         from dpmn_amd.loss.image_loss import ImageLoss
         from dpmn_amd.model.distill_module import DistillModule
         from dpmn_amd.train.optim import Trainer
+        torch.manual_seed(2)       # every rank builds the same DistillModules (the Trainer broadcasts rank 0's anyway)
         distill = [DistillModule().to(sr.device) for _ in range(b1 + b2 - 2)]
         crit = ImageLoss(gradient=True, loss_weight=[1, 1])
         for m in models + distill:
             m.train()
             for p in m.parameters():
                 p.requires_grad = True
-        trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=world)
+        trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=world, zero1=args.zero1)
 
         def step():
             return sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
@@ -178,18 +203,25 @@ def main():
         def step():
             return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
 
-    for _ in range(args.warmup):
-        step()
+    profiling = rank == 0 and not args.graph and not args.no_kernel_profile
+    dominant = None
+    for i in range(args.warmup):
+        if profiling and i == args.warmup - 1:      # all families armed on the last warm-up step: who is the dominant kernel?
+            torch.cuda.synchronize()
+            _abi.profile_begin(None)
+            step()
+            torch.cuda.synchronize()
+            rows = _abi.profile_end()
+            if rows:
+                dominant = max(rows, key=lambda r: r["total_ms"])["kernel"]
+        else:
+            step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # roofline kernel timed where it runs: every k_gemm_pw launch of the timed steps is bracketed by HIP events on its
-    # own stream inside libdpmn_hip.so (include/dpmn_hip.h dpmn_pointwise_profile_*); not under graph replay
-    from dpmn_amd import _abi
-    pw_timed = rank == 0 and not args.graph
-    if pw_timed:
-        _abi.check(_abi.lib.dpmn_pointwise_profile_begin(min(65536, args.steps * 4 * (b1 + b2) + 8)))
+    if profiling and dominant:
+        _abi.profile_begin([dominant])     # only this family is bracketed by events inside the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -198,33 +230,51 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    pw_live = None
-    if pw_timed:
-        import ctypes
-        mean_ms = ctypes.c_float(0.0)
-        n_pw = _abi.lib.dpmn_pointwise_profile_end(ctypes.byref(mean_ms))
-        if n_pw > 0:
-            pw_live = (n_pw, float(mean_ms.value))
+    live = _abi.profile_end() if (profiling and dominant) else []
     if world > 1:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    kernels = []
+    if profiling:
+        post = 3
+        _abi.profile_begin(None)
+        for _ in range(post):
+            step()
+        torch.cuda.synchronize()
+        kernels = sorted((kernel_row(r, post) for r in _abi.profile_end()), key=lambda k: -k["ms_per_step"])[:10]
     if rank == 0:
+        what = "forward" if args.mode == "fwd" else "training step"
         line = {
-            "metric": "SR images/sec (16x64->32x128, bs=%d per GPU, fp32 %s)" % (B, "forward" if args.mode == "fwd" else "training step"),
+            "metric": "SR images/sec (%s, bs=%d per GPU, fp32 %s)" % (spec["shape"], B, what),
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: %s PSN + %d+%d PGRM (embed 96, windows 2/4/8) + CMM, %s" % (
-                args.workload, arch.upper(), b1, b2,
+            "config": {"workload": "%s: %s, %s" % (
+                args.workload, spec["text"],
                 "forward-only" if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"
                 + (", dropout/attn_drop/drop_path %g" % args.drop if args.drop else "")),
-                "per_gpu_batch": B, "global_batch": B * world,
+                "per_gpu_batch": B, "global_batch": B * world, "ranks": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
                 "parallelism": ("dp%d (independent batch shards, no forward collective)" % world) if args.mode == "fwd" else
-                               ("dp%d (per-model flat gradient buckets, RCCL all-reduce overlapped with backward)" % world)},
+                               ("dp%d (coalesced gradient groups, RCCL %s overlapped with backward)" % (
+                                   world, "reduce-scatter + sharded clip/Adam + all-gather" if (world > 1 and trainer.zero1) else "all-reduce"))},
         }
-        line["roofline"] = roofline_pw(B, live=pw_live)
-        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(args.workload, args.cpu_sample)   # N=1 only
+        roof = None
+        if live:
+            r = kernel_row(live[0], args.steps)
+            traffic, src = static_traffic(r["kernel"], B)
+            roof = {"kernel": r["kernel"], "bound": r["bound"],
+                    "achieved": r["tflops"] if r["bound"] == "mfma" else r["gbs"],
+                    "peak": FP32_MFMA_PEAK_TFLOPS if r["bound"] == "mfma" else HBM_PEAK_GBS,
+                    "unit": "TFLOP/s" if r["bound"] == "mfma" else "GB/s", "frac": r["frac"],
+                    "traffic": traffic, "traffic_kind": None if traffic is None else "static: per-launch mean from the rocprofv3 --pmc passes in profiles/%s" % src,
+                    "algorithmic_bytes_per_launch": round(live[0]["bytes"] / live[0]["launches"]),
+                    "flops_per_launch": round(live[0]["flops"] / live[0]["launches"]),
+                    "launches_timed": live[0]["launches"], "us_per_launch": r["us_per_launch"], "ms_per_step": r["ms_per_step"],
+                    "timing": "HIP events around each of the %d launches of this family inside the timed steps, on the launch stream" % live[0]["launches"]}
+        line["roofline"] = roof
+        line["kernels"] = kernels
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.mode != "fwd") else cpu_baseline(args.workload, args.cpu_sample or B)   # N=1 only
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -122,8 +122,10 @@ SIGNATURES = {
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_drop_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_window_attn_drop_bwd_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _i, _i, _i, _i, _f, _u64, fp]),
-    "dpmn_pointwise_profile_begin": (_i, [_i]),
-    "dpmn_pointwise_profile_end": (_i, [C.POINTER(C.c_float)]),
+    "dpmn_profile_tag_count": (_i, []),
+    "dpmn_profile_tag_name": (C.c_char_p, [_i]),
+    "dpmn_profile_begin": (_i, [C.c_ulonglong, _i]),
+    "dpmn_profile_end": (_i, [C.c_void_p, _i]),
     "dpmn_dropout_f32": (_i, [fp, fp, fp, _l, _l, _f, _u64, _f, _u64, fp]),
     "dpmn_maxpool_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
     "dpmn_stn_fc_f32": (_i, [fp, fp, fp, _i, fp, fp, fp, fp, fp, fp, _i, _f, _f, fp, fp, fp, fp, _i, _i, fp]),
@@ -181,3 +183,33 @@ def int_array(vals):
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------ in-pipeline kernel profiler (dpmn_profile_*)
+class ProfileRow(C.Structure):
+    _fields_ = [("tag", C.c_int), ("launches", C.c_int), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
+def profile_tags():
+    return [lib.dpmn_profile_tag_name(i).decode() for i in range(lib.dpmn_profile_tag_count())]
+
+
+def profile_begin(tags=None, max_launches=1 << 16):
+    """Arm the library's launch timers for the named kernel families (None = all)."""
+    names = profile_tags()
+    mask = 0
+    for i, n in enumerate(names):
+        if tags is None or n in tags:
+            mask |= 1 << i
+    check(lib.dpmn_profile_begin(mask, max_launches))
+
+
+def profile_end():
+    """Disarm; returns [dict(kernel, launches, total_ms, flops, bytes)].  The stream must be synchronised."""
+    n_tags = lib.dpmn_profile_tag_count()
+    rows = (ProfileRow * n_tags)()
+    n = lib.dpmn_profile_end(C.cast(rows, C.c_void_p), n_tags)
+    if n < 0:
+        raise DpmnError(lib.dpmn_last_error().decode())
+    names = profile_tags()
+    return [dict(kernel=names[r.tag], launches=r.launches, total_ms=r.total_ms, flops=r.flops, bytes=r.bytes) for r in rows[:n]]

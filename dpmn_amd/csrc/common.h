@@ -113,4 +113,28 @@ __device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned lo
 }
 
 static inline hipStream_t as_stream(dpmn_stream_t s) { return (hipStream_t)s; }
+
+// In-pipeline kernel timing (include/dpmn_hip.h dpmn_profile_*; runtime.hip).  A ProfScope placed around ONE kernel launch
+// brackets it with a pair of HIP events on the launch stream while profiling is armed for its tag, and carries the launch's
+// algorithmic FLOPs and bytes (from the launch arguments), so bench.py can report achieved TFLOP/s / GB/s per kernel family
+// measured where the kernel runs -- inside the step, at the clocks and cache state of the timed region.  Disarmed cost: one
+// load and one branch.
+enum ProfTag { PT_CONV_IGEMM_128 = 0, PT_CONV_IGEMM_64, PT_CONV_IGEMM_NARROW, PT_CONV_SPLITK_REDUCE, PT_CONV_HALO, PT_CONV_HALO_C4,
+               PT_GEMM_PW, PT_GEMM_WSTAT, PT_GEMM_KLOOP, PT_DWCONV_GELU, PT_WATTN8, PT_WATTN_SCALAR, PT_ATTN_FUSED, PT_BIGRU,
+               PT_MHA32, PT_PATCH_EMBED, PT_SK_GATE, PT_TAIL, PT_DWPW_FUSED, PT_COUNT };
+extern unsigned long long g_dpmn_prof_mask;
+struct ProfScope {
+  int slot;
+  hipStream_t st;
+  ProfScope(int tag, hipStream_t s, double flops, double bytes);
+  ~ProfScope();
+};
+int dpmn_prof_open(int tag, hipStream_t st, double flops, double bytes);
+void dpmn_prof_close(int slot, hipStream_t st);
+inline ProfScope::ProfScope(int tag, hipStream_t s, double flops, double bytes) : slot(-1), st(s) {
+  if ((g_dpmn_prof_mask >> tag) & 1ull) slot = dpmn_prof_open(tag, s, flops, bytes);
+}
+inline ProfScope::~ProfScope() {
+  if (slot >= 0) dpmn_prof_close(slot, st);
+}
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

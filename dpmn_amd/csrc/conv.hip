@@ -747,6 +747,14 @@ __global__ __launch_bounds__(256) void k_conv_halo_c4(ConvArgs a) {
   }
 }
 
+static inline double conv_flops(const ConvArgs& a) {
+  return 2.0 * a.B * a.Hp * a.Wp * (a.nphase > 1 ? a.nphase : 1) * (double)a.Cout * a.KH * a.KW * a.cin;
+}
+static inline double conv_bytes(const ConvArgs& a) {
+  const double nph = a.nphase > 1 ? a.nphase : 1;
+  return 4.0 * ((double)a.B * a.Hin * a.Win * a.cin + nph * (double)a.Cout * a.KH * a.KW * a.cin + nph * a.B * a.Hp * a.Wp * (double)a.Cout);
+}
+
 template <int KS, int TH>
 int launch_halo_c4(const ConvArgs& a, hipStream_t st) {
   constexpr int NPX = (TH + KS - 1) * (16 + KS - 1);
@@ -757,6 +765,7 @@ int launch_halo_c4(const ConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(a.B * (a.Hin / TH) * cdiv(a.Win, 13));
+  ProfScope prof(PT_CONV_HALO_C4, st, conv_flops(a), conv_bytes(a));
   hipLaunchKernelGGL((k_conv_halo_c4<KS, TH>), grid, dim3(256), smem, st, a);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -772,6 +781,7 @@ int launch_halo_th(const ConvArgs& a, hipStream_t st) {
     attr_set = true;
   }
   dim3 grid(a.B * (a.Hin / TH) * (a.Win / 16), cdiv(a.Cout, BN));
+  ProfScope prof(PT_CONV_HALO, st, conv_flops(a), conv_bytes(a));
   hipLaunchKernelGGL((k_conv_halo<KS, BN, TH>), grid, dim3(256), smem, st, a);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -813,10 +823,15 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   bool uni = uni_on && a.cin % 32 == 0 && (size_t)a.Cout * a.Kp * 4 < (1ull << 31);
   for (int i = 0; i < 3; ++i)
     uni = uni && a.cseg[i] % 32 == 0 && (size_t)a.B * a.Hin * a.Win * a.cseg[i] * 4 < (1ull << 31);
-  if (uni) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+  {
+    // split-K launches additionally move S partial-sum slabs (written here, read by the reduce kernel): not algorithmic
+    ProfScope prof(BN == 128 ? PT_CONV_IGEMM_128 : (BN == 64 ? PT_CONV_IGEMM_64 : PT_CONV_IGEMM_NARROW), st, conv_flops(a), conv_bytes(a));
+    if (uni) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
+  }
   DPMN_CHECK_LAUNCH();
   if (S > 1) {
+    ProfScope prof(PT_CONV_SPLITK_REDUCE, st, 0.0, 4.0 * (double)(S + 1) * nph * M * a.npad);
     // rows per block: 64 amortises the BatchNorm-statistics atomics on big outputs; small outputs need the parallelism
     const int cb = cdiv(a.npad / 4, 64);
     const int rows = cb * cdiv(M, 64) >= 1024 ? 64 : (cb * cdiv(M, 16) >= 1024 ? 16 : 4);

@@ -608,6 +608,7 @@ int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy,
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
   dim3 grid(gx, ny);
+  ProfScope prof(PT_GEMM_WSTAT, st, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
   hipLaunchKernelGGL((k_gemm_wstat<K, PRO, TH, FULL, EPI>), grid, dim3(TH), smem, st, x, ldx, w, y, ldy, M, N, p, e);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -691,6 +692,7 @@ int dpmn_linear_f32(const float* x, const float* w, const float* bias, const flo
     return dispatch_wholeK<PRO_NONE>(K, x, K, w, y, N, M, N, p, e, as_stream(stream));
   DPMN_REQUIRE(K % 32 == 0, "linear: K must be a multiple of 32");
   dim3 grid(cdiv(M, 64), cdiv(N, 96));
+  ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N * (res1 ? 2 : 1) + (double)N * K));
   hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -752,56 +754,15 @@ int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, 
   return DPMN_OK;
 }
 
-// In-pipeline timing of the pointwise GEMM (bench.py's roofline object): while armed, every dpmn_pointwise_f32 launch is
-// bracketed by a pair of HIP events on the stream it is launched on, so the kernel is timed where it runs -- inside the
-// whole step, at the clocks and cache state of the timed region -- instead of in a separate cold loop.
-namespace {
-struct PwProfile {
-  int armed = 0, count = 0, cap = 0;
-  hipEvent_t* ev = nullptr;
-} g_pwprof;
-}  // namespace
-
-int dpmn_pointwise_profile_begin(int max_launches) {
-  DPMN_REQUIRE(max_launches > 0 && max_launches <= (1 << 16), "pointwise_profile_begin: 1..65536 launches");
-  if (g_pwprof.cap < max_launches) {
-    for (int i = 0; i < 2 * g_pwprof.cap; ++i) (void)hipEventDestroy(g_pwprof.ev[i]);
-    delete[] g_pwprof.ev;
-    g_pwprof.ev = new hipEvent_t[2 * (size_t)max_launches];
-    for (int i = 0; i < 2 * max_launches; ++i)
-      if (hipEventCreate(&g_pwprof.ev[i]) != hipSuccess) return dpmn_set_error(DPMN_ERR_LAUNCH, "pointwise_profile_begin: hipEventCreate failed");
-    g_pwprof.cap = max_launches;
-  }
-  g_pwprof.count = 0;
-  g_pwprof.armed = max_launches;
-  return DPMN_OK;
-}
-
-/* Disarms; call after the stream has been synchronised.  Returns the number of launches timed, their mean in *mean_ms. */
-int dpmn_pointwise_profile_end(float* mean_ms) {
-  g_pwprof.armed = 0;
-  double tot = 0.0;
-  for (int i = 0; i < g_pwprof.count; ++i) {
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, g_pwprof.ev[2 * i], g_pwprof.ev[2 * i + 1]) != hipSuccess)
-      return dpmn_set_error(DPMN_ERR_LAUNCH, "pointwise_profile_end: events not complete (synchronise the stream first)");
-    tot += ms;
-  }
-  if (mean_ms) *mean_ms = g_pwprof.count ? (float)(tot / g_pwprof.count) : 0.f;
-  return g_pwprof.count;
-}
-
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream) {
   DPMN_REQUIRE(g && w && bias && z && Ch % 128 == 0 && L % 128 == 0, "pointwise: Ch and L must be multiples of 128");
   static const int pw_bc = getenv("DPMN_PW_BC") ? atoi(getenv("DPMN_PW_BC")) : 192;
-  const bool timed = g_pwprof.armed && g_pwprof.count < g_pwprof.armed;
-  if (timed) (void)hipEventRecord(g_pwprof.ev[2 * g_pwprof.count], as_stream(stream));
+  ProfScope prof(PT_GEMM_PW, as_stream(stream), 2.0 * Ch * Ch * (double)L * B, 4.0 * (2.0 * B * Ch * (double)L + (double)Ch * Ch + Ch));
   if (Ch % 192 == 0 && pw_bc == 192)
     hipLaunchKernelGGL((k_gemm_pw<192>), dim3(L / 128, Ch / 192, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
   else
     hipLaunchKernelGGL((k_gemm_pw<128>), dim3(L / 128, Ch / 128, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
-  if (timed) (void)hipEventRecord(g_pwprof.ev[2 * g_pwprof.count++ + 1], as_stream(stream));
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -396,6 +396,8 @@ int launch_window_attn8_mfma(const float* q, const float* kv, const float* table
     attr_set = true;
   }
   const long slabs = (long)B * (H * W / 64);
+  // per (window, head): QK^T + PV = 4 * N^2 * d FLOPs; q, k, v read + out written for this group's 32 channels
+  ProfScope prof(PT_WATTN8, st, 4.0 * 64 * 16 * 2 * (double)B * H * W, 4.0 * 4 * 32 * (double)B * H * W);
   hipLaunchKernelGGL((k_window_attn8_mfma<DROP>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, table, out, B, H, W, C, g, shift,
                      p_drop, seed);
   DPMN_CHECK_LAUNCH();
@@ -414,6 +416,7 @@ int launch_window_attn(const float* q, const float* kv, const float* table, floa
     attr_set = true;
   }
   const long slabs = (long)B * (H * W / 64);
+  ProfScope prof(PT_WATTN_SCALAR, st, 4.0 * N * D * 2 * (double)B * H * W, 4.0 * 4 * CG * (double)B * H * W);
   hipLaunchKernelGGL((k_window_attn<WS, D, DROP>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, table, out, B, H, W,
                      C, g, shift, p_drop, seed);
   DPMN_CHECK_LAUNCH();
@@ -686,6 +689,7 @@ int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, f
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  ProfScope prof(PT_DWCONV_GELU, as_stream(stream), 18.0 * planes * r * r, 8.0 * planes * r * r);
   hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;

@@ -10,7 +10,69 @@ int dpmn_set_error(int code, const char* msg) {
   return code;
 }
 
+// ------------------------------------------------------------------ in-pipeline kernel profiler (common.h ProfScope)
+unsigned long long g_dpmn_prof_mask = 0ull;
+namespace {
+const char* const kTagNames[PT_COUNT] = {
+    "k_conv_igemm<128,128>", "k_conv_igemm<64,64>", "k_conv_igemm<128,16|32>", "k_conv_splitk_reduce", "k_conv_halo", "k_conv_halo_c4",
+    "k_gemm_pw", "k_gemm_wstat", "k_gemm_kloop", "k_dwconv_gelu", "k_window_attn8_mfma", "k_window_attn<2|4|16>", "k_ln_qkv_window_attn",
+    "k_bigru", "k_mha32", "k_patch_embed_ln", "k_sk_gate", "k_tail_conv2", "k_mlp_dw_pw"};
+struct Rec { int tag; double flops, bytes; };
+struct Prof {
+  int cap = 0, count = 0;
+  hipEvent_t* ev = nullptr;
+  Rec* rec = nullptr;
+} g_prof;
+}  // namespace
+
+int dpmn_prof_open(int tag, hipStream_t st, double flops, double bytes) {
+  if (g_prof.count >= g_prof.cap) return -1;
+  const int i = g_prof.count++;
+  g_prof.rec[i] = Rec{tag, flops, bytes};
+  (void)hipEventRecord(g_prof.ev[2 * i], st);
+  return i;
+}
+void dpmn_prof_close(int slot, hipStream_t st) { (void)hipEventRecord(g_prof.ev[2 * slot + 1], st); }
+
 extern "C" {
-int dpmn_abi_version(void) { return 1; }
+int dpmn_abi_version(void) { return 2; }
 const char* dpmn_last_error(void) { return g_err; }
+
+int dpmn_profile_tag_count(void) { return PT_COUNT; }
+const char* dpmn_profile_tag_name(int tag) { return tag >= 0 && tag < PT_COUNT ? kTagNames[tag] : ""; }
+
+int dpmn_profile_begin(unsigned long long tag_mask, int max_launches) {
+  DPMN_REQUIRE(max_launches > 0 && max_launches <= (1 << 18), "profile_begin: 1..262144 launches");
+  if (g_prof.cap < max_launches) {
+    for (int i = 0; i < 2 * g_prof.cap; ++i) (void)hipEventDestroy(g_prof.ev[i]);
+    delete[] g_prof.ev;
+    delete[] g_prof.rec;
+    g_prof.ev = new hipEvent_t[2 * (size_t)max_launches];
+    g_prof.rec = new Rec[(size_t)max_launches];
+    for (int i = 0; i < 2 * max_launches; ++i)
+      if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) return dpmn_set_error(DPMN_ERR_LAUNCH, "profile_begin: hipEventCreate failed");
+    g_prof.cap = max_launches;
+  }
+  g_prof.count = 0;
+  g_dpmn_prof_mask = tag_mask;
+  return DPMN_OK;
+}
+
+int dpmn_profile_end(dpmn_profile_row* rows, int max_rows) {
+  g_dpmn_prof_mask = 0ull;
+  dpmn_profile_row acc[PT_COUNT];
+  for (int t = 0; t < PT_COUNT; ++t) acc[t] = dpmn_profile_row{t, 0, 0.0, 0.0, 0.0};
+  for (int i = 0; i < g_prof.count; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+      return dpmn_set_error(DPMN_ERR_LAUNCH, "profile_end: events not complete (synchronise the stream first)");
+    dpmn_profile_row& r = acc[g_prof.rec[i].tag];
+    r.launches += 1; r.total_ms += ms; r.flops += g_prof.rec[i].flops; r.bytes += g_prof.rec[i].bytes;
+  }
+  int n = 0;
+  for (int t = 0; t < PT_COUNT && n < max_rows; ++t)
+    if (acc[t].launches > 0) rows[n++] = acc[t];
+  g_prof.count = 0;
+  return n;
+}
 }

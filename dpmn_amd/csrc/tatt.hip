@@ -321,6 +321,7 @@ int dpmn_bigru_f32(const float* gi, const float* w_hh, const float* b_hh, const 
                    int inner, long outer_stride, long inner_stride, long step_stride, int hidden, dpmn_stream_t stream) {
   DPMN_REQUIRE(gi && w_hh && b_hh && out && nseq > 0 && T > 0 && inner > 0, "bigru: bad arguments");
   DPMN_REQUIRE(hidden == 32, "bigru: built for hidden_units=32 per direction (hd_u default, main.py:47)");
+  ProfScope prof(PT_BIGRU, as_stream(stream), 2.0 * 2 * 3 * 32 * 32 * (double)nseq * T, 4.0 * (2 * 96 + 64 + 64) * (double)nseq * T);
   hipLaunchKernelGGL((k_bigru<32>), dim3((unsigned)((nseq + 3) / 4)), dim3(256), 0, as_stream(stream), gi, w_hh, b_hh, res, out,
                      nseq, T, inner, outer_stride, inner_stride, step_stride);
   DPMN_CHECK_LAUNCH();

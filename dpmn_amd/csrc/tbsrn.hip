@@ -121,6 +121,7 @@ extern "C" {
 
 int dpmn_mha32_f32(const float* qkv, float* out, int B, int L, int heads, float scale, dpmn_stream_t stream) {
   DPMN_REQUIRE(qkv && out && B > 0 && heads > 0 && L > 0 && L % 64 == 0, "mha32: L must be a multiple of 64 (d_k is 32)");
+  ProfScope prof(PT_MHA32, as_stream(stream), 4.0 * L * (double)L * 32 * heads * B, 4.0 * 4 * 32 * heads * (double)L * B);
   hipLaunchKernelGGL(k_mha32, dim3(L / 64, heads, B), dim3(256), 0, as_stream(stream), qkv, out, L, heads, scale);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;

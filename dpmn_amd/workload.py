@@ -16,6 +16,19 @@ CONFIGS = {
 }
 
 
+def describe(name):
+    """dict(arch, b1, b2, shape, text) for bench.py's JSON line."""
+    arch, b1, b2, _ = CONFIGS[name]
+    return dict(arch=arch, b1=b1, b2=b2, shape="16x64->32x128",
+                text="%s PSN + %d+%d PGRM (embed 96, windows 2/4/8) + CMM" % (arch.upper(), b1, b2))
+
+
+def cpu_priors(name, n_img):
+    """the same synthetic text priors build() uploads, on the CPU (bench.py's cpu_baseline child)."""
+    _, b1, _, _ = CONFIGS[name]
+    return [torch.floor(synth.uniform("text_prior_%d" % k, (n_img, 2, 32, 128), 0.0, 256.0, 2)) for k in range(b1)]
+
+
 def make_args(arch, b1, b2, batch, drop=0):
     """drop: one rate for --drop_rate / --attn_drop_rate / --drop_path_rate (the reference README's training command uses
     0.1 for all three; 0 = the deterministic configuration the parity tests and the headline bench run)."""

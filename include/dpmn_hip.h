@@ -59,11 +59,23 @@ int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_h
 /* z[b] = w (Ch,Ch) . g[b] (Ch,L) + bias : Mlp.pointwise_conv on the raw (B,Ch,r,r) view (pgrm.py:34,37) */
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream);
-/* Measurement hook for bench.py's roofline object: while armed, each dpmn_pointwise_f32 launch (direct or from inside
- * dpmn_pgrm_forward_f32) is bracketed by HIP events on its own stream, up to max_launches.  _end disarms and returns the
- * number of launches timed and their mean duration; synchronise the stream before calling it.  Not thread-safe. */
-int dpmn_pointwise_profile_begin(int max_launches);
-int dpmn_pointwise_profile_end(float* mean_ms);
+/* Measurement hooks for bench.py's roofline objects (no reference counterpart: the reference has no profiler, SURVEY.md
+ * section 5).  While armed, every launch of a kernel family whose tag bit is set in tag_mask -- issued directly or from
+ * inside a module driver such as dpmn_pgrm_forward_f32 -- is bracketed by HIP events on the stream it is launched on, up to
+ * max_launches.  dpmn_profile_end disarms and aggregates per tag: launches, summed duration, summed ALGORITHMIC FLOPs and
+ * bytes of those launches (computed from the launch arguments; DESIGN.md (d) states the formulas).  Synchronise the
+ * stream before calling it.  Returns the number of rows written (<= max_rows) or a negative error.  Not thread-safe. */
+typedef struct {
+  int tag;          /* index for dpmn_profile_tag_name */
+  int launches;
+  double total_ms;  /* sum of event-to-event durations */
+  double flops;     /* sum over the timed launches */
+  double bytes;     /* compulsory HBM bytes (inputs read once + outputs written once) */
+} dpmn_profile_row;
+int dpmn_profile_tag_count(void);
+const char* dpmn_profile_tag_name(int tag);
+int dpmn_profile_begin(unsigned long long tag_mask, int max_launches);
+int dpmn_profile_end(dpmn_profile_row* rows, int max_rows);
 
 /* ------------------------------------------------------------------ NHWC implicit-GEMM conv (conv.hip) */
 /* One descriptor drives nn.Conv2d / nn.ConvTranspose2d call sites of cmm.py:44-71,86-118 and

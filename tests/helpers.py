@@ -46,3 +46,64 @@ def assert_close(a, b, atol, rtol=0.0, what=""):
     bad = err > tol
     assert not bad.any(), "%s max err %.3e (tol %.1e) at %d/%d elems, ref max %.3e" % (
         what, err.max().item(), atol, int(bad.sum()), a.numel(), b.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Gradient fixtures: a gradient tensor is stored in full up to 4096 elements; larger ones as a digest -- float64 norm and
+# sum, 64 evenly strided samples, and one projection onto a seeded probe vector (tools/gen_golden.py gen_grads/gen_step).
+def grad_digest(name, g):
+    g = g.detach().double().reshape(-1)
+    n = g.numel()
+    if n <= 4096:
+        return {"full": g.float().numpy()}
+    probe = synth.uniform("probe::" + name, (n,), -1.0, 1.0, 77).double()
+    step = n // 64
+    return {"norm": np.array(float(g.norm())), "sum": np.array(float(g.sum())), "samples": g[::step][:64].float().numpy(),
+            "proj": np.array(float((g * probe).sum())), "absmax": np.array(float(g.abs().max()))}
+
+
+def fixture_grad_names(npz, prefix=""):
+    names = []
+    for k in npz.files:
+        if "::" in k and k.startswith(prefix):
+            n = k[len(prefix):].split("::")[0]
+            if n not in names:
+                names.append(n)
+    return names
+
+
+def grad_error_vs_fixture(npz, key, g):
+    """relative error of gradient tensor g against the fixture entry `key` (= prefix + name): full tensors by relative L2;
+    digests by the worst of |norm| ratio, the 64 samples (relative to the tensor's max) and the seeded projection
+    (relative to norm * |probe| / sqrt(n), the scale of a projected random error)."""
+    g = torch.as_tensor(g).detach().cpu().double().reshape(-1)
+    if key + "::full" in npz.files:
+        ref = torch.from_numpy(npz[key + "::full"]).double()
+        return float((g - ref).norm() / (ref.norm() + 1e-30)), float(ref.abs().max())
+    d = grad_digest(key.split("/", 1)[-1], g)
+    norm, amax = float(npz[key + "::norm"]), float(npz[key + "::absmax"])
+    e_norm = abs(float(d["norm"]) - norm) / (norm + 1e-30)
+    e_smp = float(np.abs(d["samples"].astype(np.float64) - npz[key + "::samples"].astype(np.float64)).max()) / (amax + 1e-30)
+    n = g.numel()
+    e_proj = abs(float(d["proj"]) - float(npz[key + "::proj"])) / (norm * (n / 3.0) ** 0.5 / n ** 0.5 + 1e-30)
+    return max(e_norm, e_smp, e_proj), amax
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity-error record: GPU tests call record(test, metric, value, tol); conftest.py dumps everything at session end to
+# gpurun_out/parity_errors.json (copied to profiles/ by hand after a gpurun call), so achieved errors are data, not prints.
+RECORD = []
+
+
+def record(test, metric, value, tol=None):
+    RECORD.append({"test": test, "metric": metric, "value": float(value), "tol": None if tol is None else float(tol)})
+    return value
+
+
+def max_abs_err(a, b):
+    return float((torch.as_tensor(a).float().cpu() - torch.as_tensor(b).float().cpu()).abs().max())
+
+
+def l2_rel(a, b):
+    a, b = torch.as_tensor(a).float().cpu().double(), torch.as_tensor(b).float().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))

@@ -1,0 +1,165 @@
+"""GPU parity AT THE SHAPES bench.py TIMES: the conv dispatcher picks other instantiations and split-K
+factors at B = 48 / cnum = 64 than at the small batches of the other tests, so the benchmarked configuration is checked
+as it runs: (a) config 1 whole stack, B = 48, every intermediate vs the oracle + PSNR/SSIM to 1e-3; (b) CMM cnum = 64 in
+train mode, forward + backward vs oracle autograd at B = 8; (c) the config-2 training step on the TATT 3+3 stack (B = 4).
+Achieved errors are recorded (helpers.record -> gpurun_out/parity_errors.json), tolerances = measured x ~3."""
+import pytest
+import torch
+
+from dpmn_amd.utils import synth
+from helpers import assert_close, record, max_abs_err, l2_rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def test_cfg1_whole_stack_at_bench_batch_vs_oracle(dev):
+    """workload.build('cfg1') exactly as bench.py runs it (TATT + 3+3 PGRM + CMM cnum 64, B = 48).  The branch-2 mask
+    priors are discrete: the oracle is driven stage by stage and given the GPU's masks (toMask itself is pinned bit-exactly
+    on identical inputs elsewhere); the fraction of pixels where its own masks would differ is recorded and bounded."""
+    from dpmn_amd import workload, ops
+    from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn
+    name = "cfg1_B48"
+    sr, models, psn, inp = workload.build("cfg1")
+    B = inp["images_lr"].shape[0]
+    assert B == 48
+    out, mid = sr.refine(models, psn, inp["images_lr"], inp["label_vecs"], text_priors=inp["text_priors"], return_all=True)
+    torch.cuda.synchronize()
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [x.cpu() for x in v]) for k, v in inp.items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        r_psn, _ = otsrn.tatt_forward(sd_psn, cpu["images_lr"], cpu["label_vecs"])
+        assert_close(mid["psn"], r_psn, 2e-4, 2e-4, "TATT PSN B=48")
+        record(name, "psn max|err|", max_abs_err(mid["psn"], r_psn), 2e-4)
+        casc, l1 = r_psn, []
+        for k in range(3):
+            o = opgrm.pgrm_forward(sds[k], cpu["text_priors"][k], casc[:, :3], l1[:k]); l1.append(o); casc = o
+            e = record(name, "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 5e-4)
+            assert_close(mid["branch1"][k], o, 5e-4, 5e-4, "branch1[%d]" % k)
+        casc_gpu, casc, l2 = mid["psn"], r_psn, []
+        flips = 0
+        for k in range(3, 6):
+            m_gpu = ops.to_mask(casc_gpu).cpu()
+            flips += int((m_gpu != ocmm.to_mask(casc[:, :3])).sum()) // 3
+            o = opgrm.pgrm_forward(sds[k], m_gpu, casc[:, :3], l2[:(k - 3)]); l2.append(o); casc = o
+            casc_gpu = mid["branch2"][k - 3]
+            record(name, "branch2[%d] max|err|" % (k - 3), max_abs_err(casc_gpu, o), 5e-4)
+            assert_close(casc_gpu, o, 5e-4, 5e-4, "branch2[%d]" % (k - 3))
+        record(name, "mask pixels flipped (of %d)" % (3 * B * 32 * 128), flips, 3 * B * 32 * 128 * 2e-4)
+        assert flips <= 3 * B * 32 * 128 * 2e-4
+        fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
+        record(name, "cmm max|err|", max_abs_err(mid["cmm"], fused), 1e-3)
+        assert_close(mid["cmm"], fused, 1e-3, 1e-3, "CMM cnum 64 at B=48")
+        ref = 0.5 * fused + 0.5 * r_psn[:, :3]
+    assert_close(out, ref, 1e-3, 1e-3, "cfg1 B=48 output")
+    record(name, "output max|err|", max_abs_err(out, ref), 1e-3)
+    p, s = ops.psnr_ssim(out, inp["images_hr"])
+    dp = abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"])))
+    ds = abs(float(s) - float(ocmm.ssim(ref, cpu["images_hr"])))
+    record(name, "|dPSNR|", dp, 1e-3)
+    record(name, "|dSSIM|", ds, 1e-3)
+    assert dp < 1e-3 and ds < 1e-3
+
+
+def test_cmm_cnum64_train_fwd_bwd_at_b8_vs_oracle_autograd(dev):
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    from oracle import cmm as ocmm
+    name = "cmm64_train_B8"
+    B = 8
+    u = lambda n, shape, lo, hi: synth.uniform(n, shape, lo, hi, 81)
+    m = ComplementationModulationModule(cnum=64)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 96)
+    m.load_state_dict(sd)
+    x1, x2 = u("x1", (B, 3, 32, 128), 0, 1), u("x2", (B, 3, 32, 128), 0, 1)
+    cot = u("cot", (B, 3, 32, 128), -1, 1)
+    sd_ref = {k: v.clone().requires_grad_(torch.is_floating_point(v) and "running" not in k) for k, v in sd.items()}
+    x1r, x2r = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    out_ref = ocmm.cmm_forward(sd_ref, x1r, x2r, True)
+    (out_ref * cot).sum().backward()
+    m = m.to(dev).train()
+    x1d, x2d = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
+    out = m(x1d, x2d)
+    record(name, "forward max|err|", max_abs_err(out, out_ref.detach()), 5e-4)
+    assert_close(out, out_ref.detach(), 5e-4, 5e-4, "CMM cnum 64 train-mode forward")
+    (out * cot.to(dev)).sum().backward()
+    e1, e2 = l2_rel(x1d.grad, x1r.grad), l2_rel(x2d.grad, x2r.grad)
+    record(name, "dx1 rel L2", e1, 1e-2)
+    record(name, "dx2 rel L2", e2, 1e-2)
+    assert e1 < 1e-2 and e2 < 1e-2
+    worst = ("", 0.0)
+    for n_, p in m.named_parameters():
+        g_ref = sd_ref[n_].grad
+        if float(g_ref.abs().max()) < 2e-3:
+            assert float(p.grad.abs().max()) < 5e-3, n_
+            continue
+        e = l2_rel(p.grad, g_ref)
+        worst = max(worst, (n_, e), key=lambda t_: t_[1])
+        assert e < 1e-2, "grad %s rel L2 %.2e" % (n_, e)
+    record(name, "worst parameter-gradient rel L2 (%s)" % worst[0], worst[1], 1e-2)
+
+
+def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev):
+    """BASELINE.json configs[2]'s step on its own stack -- TATT PSN (frozen) + 3+3 PGRM + 4 DistillModules + CMM -- at B = 4:
+    loss, and every model's gradient (whole-model relative L2, what the per-model clip sees) vs autograd through the oracle."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn
+    name = "cfg2_step_tatt3p3_B4"
+    B, b1, b2 = 4, 3, 3
+    sr_ = TextSR(workload.make_config(B), workload.make_args("tatt", b1, b2, B))
+    models, psn, distill, crit, trainer = sr_.build_training()
+    for i, m in enumerate([psn] + models + distill):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, 700 + i)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                v.copy_(sd[k])
+    psn.eval()
+    sd0 = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in [psn] + models + distill]
+    batch = synth.synth_batch(B, seed=6)
+    priors = [torch.floor(synth.uniform("tq%d" % k, (B, 2, 32, 128), 0, 256, 6)) for k in range(b1)]
+    loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev),
+                          batch["label_vecs"].to(dev), text_priors=[p.to(dev) for p in priors])
+    ref = [{k: v.clone().requires_grad_(torch.is_floating_point(v) and "running" not in k and "index" not in k and "mask" not in k)
+            for k, v in sd.items()} for sd in sd0]
+    with torch.no_grad():
+        lr_psn, _ = otsrn.tatt_forward(sd0[0], batch["images_lr"], batch["label_vecs"])
+    hr3 = batch["images_hr"][:, :3]
+    tot, casc, l1, l2 = 0, lr_psn, [], []
+    for k in range(b1):
+        o = opgrm.pgrm_forward(ref[1 + k], priors[k], casc[:, :3], l1[:k]); l1.append(o); casc = o
+        tot = tot + ocmm.image_loss(o, hr3, True) * 100
+    casc = lr_psn
+    for k in range(b1, b1 + b2):
+        o = opgrm.pgrm_forward(ref[1 + k], ocmm.to_mask(casc.detach()[:, :3]), casc[:, :3], l2[:k - b2]); l2.append(o); casc = o
+        tot = tot + ocmm.image_loss(o, hr3, True) * 100
+    nm = 1 + b1 + b2 + 1
+    feat = l1[-1]
+    for k in range(b1 - 1, 0, -1):
+        ld, feat = ocmm.distill_forward(ref[nm + k - 1], feat, l1[k - 1], True); tot = tot + ld * 100
+    feat = l2[-1]
+    for k in range(b2 - 1, 0, -1):
+        ld, feat = ocmm.distill_forward(ref[nm + k + b1 - 2], feat, l2[k - 1], True); tot = tot + ld * 100
+    o = ocmm.cmm_forward(ref[1 + b1 + b2], l1[-1], l2[-1], True)
+    tot = (tot + ocmm.image_loss(o, hr3, True) * 100) / (b1 + b2 + 1)
+    tot.backward()
+    le = abs(float(loss) - float(tot)) / abs(float(tot))
+    record(name, "loss rel err", le, 2e-4)
+    assert le < 2e-4, (float(loss), float(tot))
+    for i, m in enumerate(models + distill):
+        rsd = ref[1 + i]
+        num = den = 0.0
+        for n_, p_ in m.named_parameters():
+            g_ref = rsd[n_].grad if rsd[n_].grad is not None else torch.zeros_like(rsd[n_])
+            d = p_.grad.detach().cpu().double() - g_ref.double()
+            num += float((d * d).sum()); den += float((g_ref.double() ** 2).sum())
+        e = (num / max(den, 1e-30)) ** 0.5
+        record(name, "model %d whole-gradient rel L2" % i, e, 2e-2)
+        assert e < 2e-2, "model %d gradient differs from oracle autograd: %.3e" % (i, e)

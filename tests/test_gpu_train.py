@@ -340,7 +340,8 @@ def test_full_train_step_vs_oracle_autograd(dev):
                 e = float(d.norm() / g_ref.double().norm())
                 worst = max(worst, (n, e), key=lambda t_: t_[1])
         tot_err = (num / max(den, 1e-30)) ** 0.5
-        print("model %d: whole-gradient L2 err %.2e, worst tensor %s %.2e" % (i, tot_err, worst[0], worst[1]))
+        from helpers import record
+        record("full_train_step_tsrn2p2_B2", "model %d whole-gradient rel L2 (worst tensor %s %.2e)" % (i, worst[0], worst[1]), tot_err, 2e-2)
         assert tot_err < 2e-2, "model %d gradient differs from oracle autograd: %.3e (%s %.3e)" % (i, tot_err, worst[0], worst[1])
 
 
@@ -428,3 +429,133 @@ def test_adam_device_step_counter_equals_host_step(dev):
         bb.step(0, 1e-3, 0.5, step_dev=t_dev)
         for p, q in zip(a.parameters(), b.parameters()):
             assert_close(p.detach(), q.detach(), 1e-7, 1e-6, "adam device step %d" % step)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HIP backward vs gradients captured from the IMPORTED reference itself (tests/golden/grads_*.npz, step_tsrn_2p2.npz;
+# tools/gen_golden.py gen_grads / gen_step) -- not only vs autograd through the oracle.
+def _fixture_check(test, g, named, prefix="", tol=3e-3):
+    from helpers import fixture_grad_names, grad_error_vs_fixture, record
+    worst = ("", 0.0)
+    for n in fixture_grad_names(g, prefix):
+        err, amax = grad_error_vs_fixture(g, prefix + n, named[n])
+        if amax < 2e-3:      # exactly-zero true gradients: both sides hold round-off
+            assert float(torch.as_tensor(named[n]).abs().max()) < 5e-3, n
+            continue
+        worst = max(worst, (n, err), key=lambda x: x[1])
+        assert err < tol, "gradient %s%s differs from the reference's own by %.2e" % (prefix, n, err)
+    record(test, "worst gradient error vs reference fixture (%s%s)" % (prefix, worst[0]), worst[1], tol)
+
+
+@pytest.mark.parametrize("tag,it,mode", [("mode0_iter0", 0, False), ("mode1_iter2", 2, True)])
+def test_pgrm_backward_vs_reference_gradient_fixture(dev, tag, it, mode):
+    from dpmn_amd.model.pgrm import PGRM
+    from helpers import load_golden, t
+    B = 2
+    g = load_golden("grads_pgrm_" + tag)
+    m = PGRM(iter=it, mode=mode, hidden_size=3, **_pgrm_args())
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 11 + it)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    if mode:
+        x_q = (synth.uniform("x_q", (B, 1, 32, 128), 0, 1, 5) > 0.5).float().repeat(1, 3, 1, 1)
+    else:
+        x_q = torch.floor(synth.uniform("x_q", (B, 2, 32, 128), 0, 256, 5))
+    x_kv = synth.uniform("x_kv", (B, 3, 32, 128), 0, 1, 5).to(dev).requires_grad_(True)
+    res = [synth.uniform("res%d" % i, (B, 3, 32, 128), 0, 1, 5).to(dev).requires_grad_(True) for i in range(it)]
+    cot = synth.uniform("cot", (B, 3, 32, 128), -1, 1, 5).to(dev)
+    out = m(x_q.to(dev), x_kv, res)
+    assert_close(out, t(g["out"]), 3e-4, 3e-4, "train-mode forward vs the reference's")
+    (out * cot).sum().backward()
+    named = {"x_kv": x_kv.grad}
+    named.update({"res%d" % i: r.grad for i, r in enumerate(res) if r.grad is not None})
+    named.update({n: p.grad for n, p in m.named_parameters()})
+    _fixture_check("pgrm_grads_" + tag, g, named)
+
+
+@pytest.mark.parametrize("cnum", [8, 64])
+def test_cmm_backward_vs_reference_gradient_fixture(dev, cnum):
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    from helpers import load_golden, t
+    B = 2
+    g = load_golden("grads_cmm_cnum%d" % cnum)
+    m = ComplementationModulationModule(cnum=cnum)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 31)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    x1 = synth.uniform("cmm_x1", (B, 3, 32, 128), 0, 1, 7).to(dev).requires_grad_(True)
+    x2 = synth.uniform("cmm_x2", (B, 3, 32, 128), 0, 1, 7).to(dev).requires_grad_(True)
+    cot = synth.uniform("cmm_cot", (B, 3, 32, 128), -1, 1, 7).to(dev)
+    out = m(x1, x2)
+    assert_close(out, t(g["out"]), 5e-4, 5e-4, "CMM train forward vs the reference's")
+    (out * cot).sum().backward()
+    named = {"x1": x1.grad, "x2": x2.grad}
+    named.update({n: p.grad for n, p in m.named_parameters()})
+    _fixture_check("cmm_grads_cnum%d" % cnum, g, named, tol=2e-2)      # B = 2: 8-sample BatchNorm statistics at the bottleneck
+
+
+def test_training_step_vs_reference_step_fixture(dev):
+    """The a19 'step' fixture: loss, cascade images and per-model clip norms / gradients of one step of
+    super_resolution.py:140-278 run on the imported reference modules (same seeds as the oracle-autograd test above)."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    from helpers import load_golden, t, record
+    g = load_golden("step_tsrn_2p2")
+    B, b1, b2 = 2, 2, 2
+    sr_ = TextSR(workload.make_config(B), workload.make_args("tsrn", b1, b2, B))
+    models, psn, distill, crit, trainer = sr_.build_training()
+    for i, m in enumerate([psn] + models + distill):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, 300 + i)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                v.copy_(sd[k])
+    psn.eval()
+    batch = synth.synth_batch(B, seed=4)
+    priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)).to(dev) for k in range(b1)]
+    loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev), None,
+                          text_priors=priors)
+    le = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
+    record("step_fixture", "loss rel err vs reference", le, 2e-4)
+    assert le < 2e-4
+    for i, m in enumerate(models + distill):
+        named = {n: p.grad for n, p in m.named_parameters()}
+        norm = float(torch.sqrt(sum((v.double() ** 2).sum() for v in named.values())))
+        ne = abs(norm - float(g["grad_norms"][i])) / float(g["grad_norms"][i])
+        record("step_fixture", "model %d clip-norm rel err" % i, ne, 5e-3)
+        assert ne < 5e-3, "model %d: the norm clip_grad_norm_ sees differs from the reference's by %.2e" % (i, ne)
+        _fixture_check("step_fixture", g, named, "m%d/" % i, tol=3e-2)
+
+
+def test_test_mode_loads_every_checkpoint_including_cmm(dev, tmp_path):
+    """TextSR.test() (super_resolution.py:515-775): PGRMs from model_best_{k}.pth, CMM from model_best_cmm.pth (570-582), PSN
+    from model_{arch}.pth -- written by save_checkpoint's format, evaluated through test(), equal to refine() on the
+    original models; a missing CMM file is an error, never a silently random CMM."""
+    import types
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    sr, models, psn, inp = workload.build("cfg0")
+    ref = sr.refine(models, psn, inp["images_lr"], None, text_priors=inp["text_priors"])
+    d = str(tmp_path)
+    pack = lambda m: {"state_dict_G": {k: v.detach().clone() for k, v in m.state_dict().items()}}
+    torch.save(pack(psn), os.path.join(d, "model_tsrn.pth"))
+    for k, m in enumerate(models[:-1]):
+        torch.save(pack(m), os.path.join(d, "model_best_%d.pth" % k))
+    args = workload.make_args("tsrn", 1, 1, 4)
+    args.resume = d
+    sr2 = TextSR(workload.make_config(4), args)
+    loader = [(inp["images_hr"], inp["images_lr"], None)]
+    with pytest.raises(FileNotFoundError, match="model_best_cmm.pth"):
+        sr2.test(loader)
+    torch.save({"state_dict_G": {"module." + k: v.detach().clone() for k, v in models[-1].state_dict().items()}},
+               os.path.join(d, "model_best_cmm.pth"))           # the ngpu > 1 key style is accepted too
+    got = {}
+    orig = sr2.refine
+    sr2.refine = types.MethodType(lambda self, *a, **kw: got.setdefault("out", orig(*a, **kw)), sr2)
+    res = sr2.test(loader)
+    assert res["accuracy"] is None and res["psnr_avg"] > 0
+    fn = sr2.synthetic_text_prior()
+    ref2 = sr.refine(models, psn, inp["images_lr"], None, text_prior_fn=fn)
+    assert torch.equal(got["out"], ref2)

@@ -290,7 +290,125 @@ def gen_stack():
          psnr=ssim_psnr.calculate_psnr(out, batch["images_hr"]), ssim=ssim_psnr.SSIM()(out, batch["images_hr"]))
 
 
-GENS = {"stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
+# ------------------------------------------------------------------------------------ gradients of the reference itself
+def grad_arrays(prefix, named_grads):
+    """npz entries for a set of gradients: helpers.grad_digest (full tensor up to 4096 elements, otherwise norm / sum /
+    64 strided samples / one seeded projection) -- the reference's own autograd results, SURVEY.md section 8c."""
+    from tests.helpers import grad_digest
+    out = {}
+    for name, g in named_grads:
+        for k, v in grad_digest(name, g).items():
+            out["%s%s::%s" % (prefix, name, k)] = v
+    return out
+
+
+def gen_grads():
+    """d(out . r)/d(inputs, params) for a fixed seeded cotangent r through the IMPORTED reference modules (train mode,
+    drop rates 0): PGRM (both fixture variants), CMM (cnum 8 and 64, batch-statistics BatchNorm), DistillModule."""
+    from model import pgrm, cmm, distill_module
+    with torch.enable_grad():
+        B = 2
+        for tag, it, mode in (("mode0_iter0", 0, False), ("mode1_iter2", 2, True)):
+            m = pgrm.PGRM(iter=it, mode=mode, hidden_size=3, **pgrm_args()).train()
+            sd = m.state_dict()
+            synth.synth_fill_(sd, seed=11 + it)
+            m.load_state_dict(sd)
+            if mode:
+                x_q = (synth.uniform("x_q", (B, 1, 32, 128), 0, 1, 5) > 0.5).float().repeat(1, 3, 1, 1)
+            else:
+                x_q = torch.floor(synth.uniform("x_q", (B, 2, 32, 128), 0, 256, 5))
+            x_kv = synth.uniform("x_kv", (B, 3, 32, 128), 0, 1, 5).requires_grad_(True)
+            res = [synth.uniform("res%d" % i, (B, 3, 32, 128), 0, 1, 5).requires_grad_(True) for i in range(it)]
+            cot = synth.uniform("cot", (B, 3, 32, 128), -1, 1, 5)
+            out = m(x_q, x_kv, res)
+            (out * cot).sum().backward()
+            named = [("x_kv", x_kv.grad)] + [("res%d" % i, r.grad) for i, r in enumerate(res) if r.grad is not None]
+            named += [(n, p.grad) for n, p in m.named_parameters() if p.grad is not None]
+            save("grads_pgrm_" + tag, out=out.detach(), **grad_arrays("", named))
+        x1 = synth.uniform("cmm_x1", (B, 3, 32, 128), 0, 1, 7).requires_grad_(True)
+        x2 = synth.uniform("cmm_x2", (B, 3, 32, 128), 0, 1, 7).requires_grad_(True)
+        cot = synth.uniform("cmm_cot", (B, 3, 32, 128), -1, 1, 7)
+        for cnum in (8, 64):
+            m = cmm.ComplementationModulationModule(cnum=cnum).train()
+            sd = m.state_dict()
+            synth.synth_fill_(sd, seed=31)
+            m.load_state_dict({k: v.clone() for k, v in sd.items()})
+            x1.grad = x2.grad = None
+            out = m(x1, x2)
+            (out * cot).sum().backward()
+            named = [("x1", x1.grad), ("x2", x2.grad)] + [(n, p.grad) for n, p in m.named_parameters()]
+            save("grads_cmm_cnum%d" % cnum, out=out.detach(), **grad_arrays("", named))
+        xd = synth.uniform("dist_deep", (B, 3, 32, 128), 0, 1, 8).requires_grad_(True)
+        xs = synth.uniform("dist_shallow", (B, 3, 32, 128), 0, 1, 8).requires_grad_(True)
+        cot = synth.uniform("dist_cot", (B, 3, 32, 128), -0.01, 0.01, 8)
+        m = distill_module.DistillModule().train()
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=32)
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+        loss, feat = m(xd, xs)
+        (loss.sum() * 100 + (feat * cot).sum()).backward()
+        named = [("xd", xd.grad), ("xs", xs.grad)] + [(n, p.grad) for n, p in m.named_parameters()]
+        save("grads_distill", loss=loss.detach(), **grad_arrays("", named))
+
+
+def gen_step():
+    """One optimisation step of interfaces/super_resolution.py:140-278 re-stated around the IMPORTED reference modules
+    (TSRN PSN frozen in eval, 2+2 PGRM, 2 DistillModules, CMM, B=2, drop rates 0; text priors are inputs, toMask is the
+    PIL-pinned restatement): the loss, every cascade image, and per model the gradient norm that clip_grad_norm_(0.25)
+    sees plus digests of the pre-clip gradients.  Same seeds as tests/test_gpu_train.py::test_full_train_step_*."""
+    from model import tsrn, pgrm, cmm, distill_module
+    from loss import image_loss
+    from oracle import cmm as ocmm
+    B, b1, b2 = 2, 2, 2
+    with torch.enable_grad():
+        psn = tsrn.TSRN(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32).eval()
+        mods = [pgrm.PGRM(iter=k, mode=False, hidden_size=3, **pgrm_args(4)).train() for k in range(b1)]
+        mods += [pgrm.PGRM(iter=k, mode=True, hidden_size=3, **pgrm_args(4)).train() for k in range(b1, b1 + b2)]
+        mods.append(cmm.ComplementationModulationModule().train())
+        distill = [distill_module.DistillModule().train() for _ in range(b1 + b2 - 2)]
+        for i, m in enumerate([psn] + mods + distill):
+            sd = m.state_dict()
+            synth.synth_fill_(sd, seed=300 + i)
+            m.load_state_dict({k: v.clone() for k, v in sd.items()})
+        crit = image_loss.ImageLoss(gradient=True, loss_weight=[1, 1])
+        batch = synth.synth_batch(B, seed=4)
+        priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)) for k in range(b1)]
+        hr = batch["images_hr"]
+        with torch.no_grad():
+            lr_psn = psn(batch["images_lr"])
+        loss = 0
+        casc, l1 = lr_psn, []
+        for k in range(b1):
+            sr = mods[k](priors[k], casc[:, :3, :], l1[:k]); l1.append(sr); casc = sr
+            loss = loss + crit(sr, hr[:, :3, :]).mean() * 100
+        casc, l2 = lr_psn, []
+        for k in range(b1, b1 + b2):
+            sr = mods[k](ocmm.to_mask(casc.detach()[:, :3]), casc[:, :3, :], l2[:(k - b2)]); l2.append(sr); casc = sr
+            loss = loss + crit(sr, hr[:, :3, :]).mean() * 100
+        feat = l1[-1]
+        for k in range(b1 - 1, 0, -1):
+            ld, feat = distill[k - 1](feat, l1[k - 1]); loss = loss + ld.sum() * 100
+        feat = l2[-1]
+        for k in range(b2 - 1, 0, -1):
+            ld, feat = distill[k + b1 - 2](feat, l2[k - 1]); loss = loss + ld.sum() * 100
+        out = mods[-1](l1[-1], l2[-1])
+        loss = (loss + crit(out, hr[:, :3, :]).mean() * 100) / (b1 + b2 + 1)
+        loss.backward()
+        arrs = dict(loss=loss.detach(), psn=lr_psn, cmm_out=out.detach())
+        for k in range(b1):
+            arrs["branch1_%d" % k] = l1[k].detach()
+        for k in range(b2):
+            arrs["branch2_%d" % k] = l2[k].detach()
+        norms = []
+        for i, m in enumerate(mods + distill):
+            named = [(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()]
+            norms.append(float(torch.sqrt(sum((g.double() ** 2).sum() for _, g in named))))
+            arrs.update(grad_arrays("m%d/" % i, named))
+        arrs["grad_norms"] = np.array(norms)
+        save("step_tsrn_2p2", **arrs)
+
+
+GENS = {"grads": gen_grads, "step": gen_step, "stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
 
 
 if __name__ == "__main__":
