@@ -608,7 +608,7 @@ int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy,
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
   dim3 grid(gx, ny);
-  ProfScope prof(PT_GEMM_WSTAT, st, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
+  ProfScope prof(PRO == PRO_LN ? PT_GEMM_WSTAT_LN : PT_GEMM_WSTAT, st, 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N + (double)N * K));
   hipLaunchKernelGGL((k_gemm_wstat<K, PRO, TH, FULL, EPI>), grid, dim3(TH), smem, st, x, ldx, w, y, ldy, M, N, p, e);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;

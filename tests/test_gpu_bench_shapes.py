@@ -35,13 +35,13 @@ def test_cfg1_whole_stack_at_bench_batch_vs_oracle(dev):
     torch.set_num_threads(min(32, torch.get_num_threads()))
     with torch.no_grad():
         r_psn, _ = otsrn.tatt_forward(sd_psn, cpu["images_lr"], cpu["label_vecs"])
-        assert_close(mid["psn"], r_psn, 2e-4, 2e-4, "TATT PSN B=48")
-        record(name, "psn max|err|", max_abs_err(mid["psn"], r_psn), 2e-4)
+        assert_close(mid["psn"], r_psn, 2e-5, 2e-5, "TATT PSN B=48")
+        record(name, "psn max|err|", max_abs_err(mid["psn"], r_psn), 2e-5)
         casc, l1 = r_psn, []
         for k in range(3):
             o = opgrm.pgrm_forward(sds[k], cpu["text_priors"][k], casc[:, :3], l1[:k]); l1.append(o); casc = o
-            e = record(name, "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 5e-4)
-            assert_close(mid["branch1"][k], o, 5e-4, 5e-4, "branch1[%d]" % k)
+            e = record(name, "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 1e-4)
+            assert_close(mid["branch1"][k], o, 1e-4, 1e-4, "branch1[%d]" % k)
         casc_gpu, casc, l2 = mid["psn"], r_psn, []
         flips = 0
         for k in range(3, 6):
@@ -49,16 +49,16 @@ def test_cfg1_whole_stack_at_bench_batch_vs_oracle(dev):
             flips += int((m_gpu != ocmm.to_mask(casc[:, :3])).sum()) // 3
             o = opgrm.pgrm_forward(sds[k], m_gpu, casc[:, :3], l2[:(k - 3)]); l2.append(o); casc = o
             casc_gpu = mid["branch2"][k - 3]
-            record(name, "branch2[%d] max|err|" % (k - 3), max_abs_err(casc_gpu, o), 5e-4)
-            assert_close(casc_gpu, o, 5e-4, 5e-4, "branch2[%d]" % (k - 3))
-        record(name, "mask pixels flipped (of %d)" % (3 * B * 32 * 128), flips, 3 * B * 32 * 128 * 2e-4)
-        assert flips <= 3 * B * 32 * 128 * 2e-4
+            record(name, "branch2[%d] max|err|" % (k - 3), max_abs_err(casc_gpu, o), 1e-4)
+            assert_close(casc_gpu, o, 1e-4, 1e-4, "branch2[%d]" % (k - 3))
+        record(name, "mask pixels flipped (of %d)" % (3 * B * 32 * 128), flips, 3 * B * 32 * 128 * 2e-5)
+        assert flips <= 3 * B * 32 * 128 * 2e-5
         fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
-        record(name, "cmm max|err|", max_abs_err(mid["cmm"], fused), 1e-3)
-        assert_close(mid["cmm"], fused, 1e-3, 1e-3, "CMM cnum 64 at B=48")
+        record(name, "cmm max|err|", max_abs_err(mid["cmm"], fused), 3e-4)
+        assert_close(mid["cmm"], fused, 3e-4, 3e-4, "CMM cnum 64 at B=48")
         ref = 0.5 * fused + 0.5 * r_psn[:, :3]
-    assert_close(out, ref, 1e-3, 1e-3, "cfg1 B=48 output")
-    record(name, "output max|err|", max_abs_err(out, ref), 1e-3)
+    assert_close(out, ref, 2e-4, 2e-4, "cfg1 B=48 output")
+    record(name, "output max|err|", max_abs_err(out, ref), 2e-4)
     p, s = ops.psnr_ssim(out, inp["images_hr"])
     dp = abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"])))
     ds = abs(float(s) - float(ocmm.ssim(ref, cpu["images_hr"])))
@@ -86,23 +86,28 @@ def test_cmm_cnum64_train_fwd_bwd_at_b8_vs_oracle_autograd(dev):
     m = m.to(dev).train()
     x1d, x2d = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
     out = m(x1d, x2d)
-    record(name, "forward max|err|", max_abs_err(out, out_ref.detach()), 5e-4)
-    assert_close(out, out_ref.detach(), 5e-4, 5e-4, "CMM cnum 64 train-mode forward")
+    record(name, "forward max|err|", max_abs_err(out, out_ref.detach()), 2e-4)
+    assert_close(out, out_ref.detach(), 2e-4, 2e-4, "CMM cnum 64 train-mode forward")
     (out * cot.to(dev)).sum().backward()
     e1, e2 = l2_rel(x1d.grad, x1r.grad), l2_rel(x2d.grad, x2r.grad)
     record(name, "dx1 rel L2", e1, 1e-2)
     record(name, "dx2 rel L2", e2, 1e-2)
     assert e1 < 1e-2 and e2 < 1e-2
-    worst = ("", 0.0)
+    worst, num, den = ("", 0.0), 0.0, 0.0
     for n_, p in m.named_parameters():
         g_ref = sd_ref[n_].grad
+        d = p.grad.detach().cpu().double() - g_ref.double()
+        num += float((d * d).sum()); den += float((g_ref.double() ** 2).sum())
         if float(g_ref.abs().max()) < 2e-3:
             assert float(p.grad.abs().max()) < 5e-3, n_
             continue
-        e = l2_rel(p.grad, g_ref)
-        worst = max(worst, (n_, e), key=lambda t_: t_[1])
-        assert e < 1e-2, "grad %s rel L2 %.2e" % (n_, e)
-    record(name, "worst parameter-gradient rel L2 (%s)" % worst[0], worst[1], 1e-2)
+        worst = max(worst, (n_, l2_rel(p.grad, g_ref)), key=lambda t_: t_[1])
+    # per tensor: the deepest levels (en_6 / de_6: 1x4 maps, 32 samples per BatchNorm channel at B = 8) are fp32-conditioned
+    # -- two torch CPU evaluations of the same CMM already differ by 3e-3 .. 1.2e-2 there (tests/test_oracle_grads.py)
+    record(name, "worst parameter-gradient rel L2 (%s)" % worst[0], worst[1], 3e-2)
+    record(name, "whole-gradient rel L2", (num / den) ** 0.5, 1e-2)
+    assert worst[1] < 3e-2, worst
+    assert (num / den) ** 0.5 < 1e-2
 
 
 def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev):
@@ -151,8 +156,8 @@ def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev):
     tot = (tot + ocmm.image_loss(o, hr3, True) * 100) / (b1 + b2 + 1)
     tot.backward()
     le = abs(float(loss) - float(tot)) / abs(float(tot))
-    record(name, "loss rel err", le, 2e-4)
-    assert le < 2e-4, (float(loss), float(tot))
+    record(name, "loss rel err", le, 1e-5)
+    assert le < 1e-5, (float(loss), float(tot))
     for i, m in enumerate(models + distill):
         rsd = ref[1 + i]
         num = den = 0.0
@@ -161,5 +166,5 @@ def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev):
             d = p_.grad.detach().cpu().double() - g_ref.double()
             num += float((d * d).sum()); den += float((g_ref.double() ** 2).sum())
         e = (num / max(den, 1e-30)) ** 0.5
-        record(name, "model %d whole-gradient rel L2" % i, e, 2e-2)
-        assert e < 2e-2, "model %d gradient differs from oracle autograd: %.3e" % (i, e)
+        record(name, "model %d whole-gradient rel L2" % i, e, 3e-3)
+        assert e < 3e-3, "model %d gradient differs from oracle autograd: %.3e" % (i, e)

@@ -116,23 +116,33 @@ def test_pointwise(dev):
     assert_close(got, ref, ATOL, RTOL, "pointwise")
 
 
-def test_pointwise_profile_hook_times_every_launch(dev):
-    """bench.py's roofline timing: while armed the library brackets each pointwise launch with HIP events on its stream."""
-    import ctypes
+def test_kernel_profile_hooks_time_tagged_launches(dev):
+    """bench.py's roofline timing (include/dpmn_hip.h dpmn_profile_*): while armed, the library brackets each launch of an
+    armed kernel family with HIP events on its stream and reports launches, time and the algorithmic FLOPs / bytes."""
     from dpmn_amd import _abi, ops
     g, w, b = u("g", (2, 1024, 384)).to(dev), u("w", (384, 384), -0.1, 0.1).to(dev), u("b", (384,)).to(dev)
+    x, wl = u("x", (2048, 96)).to(dev), u("wl", (96, 96), -0.1, 0.1).to(dev)
     ops.pointwise(g, w, b)
-    _abi.check(_abi.lib.dpmn_pointwise_profile_begin(3))
-    for _ in range(5):                      # only the first 3 launches are timed
+    assert "k_gemm_pw" in _abi.profile_tags() and "k_conv_igemm<128,128>" in _abi.profile_tags()
+    _abi.profile_begin(["k_gemm_pw"], max_launches=3)
+    for _ in range(5):                      # only the first 3 launches fit the record
         ops.pointwise(g, w, b)
+    ops.linear(x, wl)                       # another family: not armed, not recorded
     torch.cuda.synchronize()
-    mean_ms = ctypes.c_float(0.0)
-    assert _abi.lib.dpmn_pointwise_profile_end(ctypes.byref(mean_ms)) == 3
-    assert 1e-3 < mean_ms.value < 5.0
+    rows = _abi.profile_end()
+    assert len(rows) == 1 and rows[0]["kernel"] == "k_gemm_pw" and rows[0]["launches"] == 3
+    assert 3e-3 < rows[0]["total_ms"] < 15.0
+    assert rows[0]["flops"] == 3 * 2.0 * 384 * 384 * 1024 * 2
+    assert rows[0]["bytes"] == 3 * 4.0 * (2 * 2 * 384 * 1024 + 384 * 384 + 384)
     ops.pointwise(g, w, b)                  # disarmed: nothing recorded
     torch.cuda.synchronize()
-    assert _abi.lib.dpmn_pointwise_profile_end(ctypes.byref(mean_ms)) == 3
-    assert _abi.lib.dpmn_pointwise_profile_begin(0) != 0        # rejected loudly
+    assert _abi.profile_end() == []
+    _abi.profile_begin(None)                # every family
+    ops.pointwise(g, w, b)
+    ops.linear(x, wl)
+    torch.cuda.synchronize()
+    assert {r["kernel"] for r in _abi.profile_end()} == {"k_gemm_pw", "k_gemm_wstat"}
+    assert _abi.lib.dpmn_profile_begin(1, 0) != 0        # rejected loudly
 
 
 # ------------------------------------------------------------------------------ PGRM pieces

