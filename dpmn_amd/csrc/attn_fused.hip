@@ -1,0 +1,432 @@
+// Fused LayerNorm + q/kv projection + multi-size window attention (SURVEY.md K3 + K4 + K5):
+//   norm1_q / norm1_kv (pgrm.py:322-323)  ->  q = Linear(96,96), kv = Linear(96,192) (pgrm.py:188,194)
+//   -> per channel group g (window 2 / 4 / 8): roll, window partition, 2 heads x 16, q*scale, QK^T + relative position
+//      bias (+ shift mask), softmax, P.V, window-major write without un-roll (pgrm.py:197-266, quirk Q1).
+// q and kv never exist in HBM: the unfused path wrote and re-read 3 x (B, L, 96) floats per block (56 MB at B = 48).
+//
+// Work unit = (group g, 64 consecutive window-major tokens of one image) = one 256-thread block; wave w owns the unit's
+// token tile [16w, 16w+16).  Everything GEMM-shaped runs on v_mfma_f32_16x16x4_f32 and chains through the accumulator
+// registers -- the MFMA D layout (lane (j = l&15, kq = l>>4) holds D[feature 4kq+r][token j]) is at once
+//   * the B-operand layout of the next product's "token" side, and
+//   * the A-operand layout of a [token][feature] matrix,
+// so with the output-feature axis on A and the token axis on B:
+//   1. X rows (gathered through the roll / window permutation of THIS group) go straight from global memory into the
+//      B-operand registers: lane (j, kq) loads x[token j][16c + 4kq .. +3], c = 0..5 -- the reduction index is permuted
+//      (k-step (c, s) <-> k = 16c + 4kq + s) identically on both operands.  LayerNorm = 24 in-lane values + two
+//      xor-shuffles (16, 32); no LDS staging of activations at all.
+//   2. projection: A = the group's 96 weight rows (q: 32, k: 32, v: 32) from an LDS copy shared by the 4 waves;
+//      result lane (j, kq) holds q|k|v[token j][head h, d = 4kq+r].
+//   3. S^T = K . Q^T: A = K[key][d], B = Q^T[d][query] -- both ARE the projection accumulators (own tile); the 8x8 group
+//      needs the other waves' keys, exchanged through 9 KB of LDS.  4x4 windows = exactly one 16x16 tile per head,
+//      2x2 windows = four windows on the tile's block diagonal (off-diagonal logits = -inf).
+//   4. softmax over keys = in-lane values + xor-shuffles 16, 32; P stays in the accumulator registers.
+//   5. O^T = V^T . P: B = P (registers), A = V^T read column-wise from the LDS copy of V (the only transpose).
+// Algorithmic work per unit: projections 2*64*96*96 = 1.18 MFLOP + attention 4*N*16 FLOP per (token, head); bytes: the unit's
+// 128 input rows (49 KB) + 8 KB of output -- the kernel is MFMA-bound (AI ~57 FLOP/B).
+#include <cstdlib>
+#include "common.h"
+
+#ifndef FA_SKIP
+#define FA_SKIP 0      // timing ablations only (tools/variants): 1 no LayerNorm, 2 no projection MFMAs, 4 no attention, 8 no barrier, 16 no row loads
+#endif
+
+namespace {
+
+constexpr float QSCALE = 0.25f * 1.44269504088896340736f;      // head_dim ** -0.5 * log2(e)
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr int FC = 96, FCG = 32, FD = 16, LDW = FC + 4, LDK = FCG + 4, TBLMAX = 15 * 15 * 2;
+
+struct FusedAttnArgs {
+  const float *tq, *tkv, *lnq_w, *lnq_b, *lnkv_w, *lnkv_b, *wq, *bq, *wkv, *bkv;
+  const float* table[3];
+  int ws[3], shift[3], gid[3];      // processing slot s (expensive windows first) -> group gid[s]
+  int cost[3];                      // relative MFMA cost of one unit of slot s (36 + N/4), for the static load balance
+  float* out;
+  int B, H, W;
+  int lgW, lgS;                     // H, W (hence S = H*W/64 and every W / ws) are powers of two: index math is shifts and masks
+  float eps;
+};
+
+// source row of window-major token t of image b through the roll (pgrm.py:209-213); also the token's rolled-frame coordinates
+template <int WS>
+__device__ __forceinline__ unsigned source_row(int t, int H, int W, int lgW, int shift, int& hr, int& wcol) {
+  constexpr int N = WS * WS, LGWS = WS == 8 ? 3 : (WS == 4 ? 2 : 1);
+  const int lgnWc = lgW - LGWS;            // windows per row = W / WS
+  const int win = t / N, n = t % N;
+  hr = ((win >> lgnWc) << LGWS) + n / WS;
+  wcol = ((win & ((1 << lgnWc) - 1)) << LGWS) + n % WS;
+  return (unsigned)((((hr + shift) & (H - 1)) << lgW) + ((wcol + shift) & (W - 1)));   // token index inside the image
+}
+
+// mean and 1/sqrt(var + eps) of the 96-value row this lane shares with its 3 kq partners (two-pass, like nn.LayerNorm)
+__device__ __forceinline__ void row_stats(const f32x4 (&x)[6], float eps, float& mean, float& rstd) {
+  float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) { s0 += x[c][0] + x[c][1]; s1 += x[c][2] + x[c][3]; }
+  float s = s0 + s1;
+  s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+  mean = s * (1.0f / FC);
+  float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;      // four independent chains
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const float d0 = x[c][0] - mean, d1 = x[c][1] - mean, d2 = x[c][2] - mean, d3 = x[c][3] - mean;
+    q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
+  }
+  float q = (q0 + q1) + (q2 + q3);
+  q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+  rstd = 1.0f / sqrtf(q * (1.0f / FC) + eps);
+}
+
+template <int WS>
+__device__ __forceinline__ void load_rows(const FusedAttnArgs& a, int xcd, int i, int shift, int wave, int lr, int kq, f32x4 (&xq)[6],
+                                          f32x4 (&xkv)[6]) {
+  const int b = xcd + 8 * (i >> a.lgS), t = ((i & ((1 << a.lgS) - 1)) << 6) + 16 * wave + lr;
+  int hr, wc;
+  const size_t src = (size_t)b * a.H * a.W + source_row<WS>(t, a.H, a.W, a.lgW, shift, hr, wc);
+  const float* pq = a.tq + src * FC + 4 * kq;
+  const float* pk = a.tkv + src * FC + 4 * kq;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) xq[c] = *reinterpret_cast<const f32x4*>(pq + 16 * c);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) xkv[c] = *reinterpret_cast<const f32x4*>(pk + 16 * c);
+}
+
+// Units [first, last) of ONE slot (window size WS), decoded as unit i -> image xcd + 8 * (i / S), slab i % S.
+// Software pipeline (vmcnt retires in order, so the ONLY global loads inside the loop are the row prefetches):
+//   top: x = rows of unit i (arrived) -> LayerNorm -> projections (x dead) -> issue the loads of unit i+1 into the same
+//   registers -> attention of unit i + stores.
+template <int WS>
+__device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int xcd, int first, int last, float* smem) {
+  constexpr int N = WS * WS, TBL = (2 * WS - 1) * (2 * WS - 1);
+  constexpr int KT = (WS == 8) ? 4 : 1;    // key tiles per query tile
+  float* Wsm = smem;                       // [96][LDW]: rows 0-31 Wq, 32-63 Wk, 64-95 Wv of this group
+  float* KVs = Wsm + FC * LDW;             // 2 x { K [64][LDK], V [64][LDK] }: double-buffered across units (one barrier per unit)
+  float* tbl = KVs + 4 * 64 * LDK;         // [TBL][2]
+  int* reg_all = reinterpret_cast<int*>(tbl + TBLMAX);   // 2 x [64] shift-mask region of each token of the unit
+  float* lnp = reinterpret_cast<float*>(reg_all + 128);  // [4][96] LayerNorm q weight, q bias, kv weight, kv bias
+  float* pbias = lnp + 4 * FC;             // [2][96]: folded biases b' of this group's q (32), k (32), v (32) rows, then rowsum(W')
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+  const int H = a.H, W = a.W, L = H * W, S = L / 64;
+  const int g = a.gid[slot], shift = a.shift[slot];
+  const float* __restrict__ table = a.table[slot];
+
+  __syncthreads();                         // the previous slot's readers of the staged tables are done
+  // LayerNorm affine folded into the projection (y = W (g * xhat + beta) + b = (W diag g) xhat + (W beta + b)), and the
+  // normalisation moved behind the MFMAs by linearity: W' xhat = rstd * (W' x - mean * rowsum(W')).  So the MFMAs eat RAW
+  // rows (they need not wait for the statistics) and the per-element LayerNorm arithmetic disappears; what remains per unit
+  // is the two-pass row statistics and a 3-op fix-up of the 24 accumulator values.
+  for (int i = tid; i < 4 * FC; i += 256) {
+    const int which = i / FC, c = i % FC;
+    lnp[i] = which == 0 ? a.lnq_w[c] : (which == 1 ? a.lnq_b[c] : (which == 2 ? a.lnkv_w[c] : a.lnkv_b[c]));
+  }
+  for (int i = tid; i < TBL * 2; i += 256) tbl[i] = table[i] * LOG2E;      // logits are kept in log2 units
+  {
+    f32x4 wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {          // all nine loads in flight before the first use
+      const int i = tid + 256 * k, r = i / (FC / 4), c4 = (i % (FC / 4)) * 4;
+      const float* srcw = r < 32 ? a.wq + (size_t)(FCG * g + r) * FC
+                                 : (r < 64 ? a.wkv + (size_t)(FCG * g + r - 32) * FC : a.wkv + (size_t)(FC + FCG * g + r - 64) * FC);
+      wv[k] = *reinterpret_cast<const f32x4*>(srcw + c4);
+    }
+    __syncthreads();                       // lnp visible
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      const int i = tid + 256 * k, r = i / (FC / 4), c4 = (i % (FC / 4)) * 4;
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(lnp + (r < 32 ? 0 : 2 * FC) + c4);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(lnp + (r < 32 ? FC : 3 * FC) + c4);
+      const f32x4 wg = wv[k] * gm, wb = wv[k] * bt;
+      *reinterpret_cast<f32x4*>(Wsm + r * LDW + c4) = wg;
+      // per-row partial sums (24 four-column pieces per row) for rowsum(W') and W beta, reduced in a fixed order below
+      KVs[(r * 24 + c4 / 4) * 2] = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+      KVs[(r * 24 + c4 / 4) * 2 + 1] = (wb[0] + wb[1]) + (wb[2] + wb[3]);
+    }
+  }
+  __syncthreads();
+  if (tid < FC) {
+    const int r = tid;
+    float cw = 0.f, bb = r < 32 ? a.bq[FCG * g + r] : (r < 64 ? a.bkv[FCG * g + r - 32] : a.bkv[FC + FCG * g + r - 64]);
+    for (int k = 0; k < 24; ++k) {
+      cw += KVs[(r * 24 + k) * 2];
+      bb += KVs[(r * 24 + k) * 2 + 1];
+    }
+    pbias[r] = r < 32 ? bb * QSCALE : bb;        // b' = b + W beta
+    pbias[FC + r] = r < 32 ? cw * QSCALE : cw;   // rowsum(W diag g)   (q rows: times head_dim ** -0.5 * log2(e))
+  }
+  __syncthreads();
+  f32x4 xq[6], xkv[6];
+  load_rows<WS>(a, xcd, first, shift, wave, lr, kq, xq, xkv);
+  // relative position bias of (my query, my keys): the same in every window, hence in every unit (pgrm.py:234-238).
+  // 4x4 / 2x2: 8 values, kept in registers.  8x8: 32 values -- their table index is linear in the key tile
+  // (idx(kt, r) = idx(3, r) + 60 (3 - kt)), so four base pointers + immediate offsets replace them.
+  constexpr int RBN = (WS == 8) ? 1 : 4;
+  float rb[RBN][2];
+  const float* tb_r[4];
+  {
+    const int n = (16 * wave + lr) % N, iq = n / WS, jq = n % WS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int krow = (WS == 8 ? 48 : 16 * wave) + 4 * kq + r;
+      const int nk = krow % N, ik = nk / WS, jk = nk % WS;
+      const int idx = ((iq - ik + WS - 1) * (2 * WS - 1) + (jq - jk + WS - 1)) * 2;
+      tb_r[r] = tbl + idx;
+      if (WS != 8) {
+        rb[r % RBN][0] = tbl[idx];
+        rb[r % RBN][1] = tbl[idx + 1];
+        if (WS == 2 && kq != (lr >> 2)) { rb[r % RBN][0] = -INFINITY; rb[r % RBN][1] = -INFINITY; }   // another 2x2 window of the tile
+      }
+    }
+  }
+
+  for (int i = first; i < last; ++i) {
+    const int b = xcd + 8 * (i >> a.lgS), t = ((i & (S - 1)) << 6) + 16 * wave + lr;
+    float* Ks = KVs + (i & 1) * 2 * 64 * LDK;
+    float* Vs = Ks + 64 * LDK;
+    int* reg_s = reg_all + (i & 1) * 64;
+    if (shift > 0 && kq == 0) {
+      int hr_, wc_;
+      (void)source_row<WS>(t, H, W, a.lgW, shift, hr_, wc_);
+      const int rh = hr_ < H - WS ? 0 : (hr_ < H - shift ? 1 : 2), rw = wc_ < W - WS ? 0 : (wc_ < W - shift ? 1 : 2);
+      reg_s[16 * wave + lr] = 3 * rh + rw;
+    }
+    float mq = 0.f, rq = 1.f, mk = 0.f, rk = 1.f;
+    if (!(FA_SKIP & 1)) {
+      row_stats(xq, a.eps, mq, rq);
+      row_stats(xkv, a.eps, mk, rk);
+    }
+    const float rqs = rq * QSCALE, nmq = -mq * rq, nmk = -mk * rk;     // (b' and rowsum(W') of the q rows are pre-scaled)
+
+    // ---- projections: six independent accumulator tiles (q, k, v x 2 heads) interleaved over the 24 k-steps
+    f32x4 qa[2], ka[2], va[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { qa[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; ka[h] = qa[h]; va[h] = qa[h]; }
+    if (FA_SKIP & 2) { qa[0] = xq[0] + xq[2]; qa[1] = xq[1] + xq[3]; ka[0] = xkv[0] + xq[4]; ka[1] = xkv[1] + xq[5]; va[0] = xkv[2] + xkv[4]; va[1] = xkv[3] + xkv[5]; }
+    else
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      f32x4 wf[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) wf[j] = *reinterpret_cast<const f32x4*>(Wsm + (16 * j + lr) * LDW + 16 * c + 4 * kq);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        qa[0] = mfma16(wf[0][s], xq[c][s], qa[0]);
+        qa[1] = mfma16(wf[1][s], xq[c][s], qa[1]);
+        ka[0] = mfma16(wf[2][s], xkv[c][s], ka[0]);
+        ka[1] = mfma16(wf[3][s], xkv[c][s], ka[1]);
+        va[0] = mfma16(wf[4][s], xkv[c][s], va[0]);
+        va[1] = mfma16(wf[5][s], xkv[c][s], va[1]);
+      }
+    }
+    // y = rstd * acc - (rstd * mean) * rowsum(W') + b'   (two fma per value; the q rows of b' / rowsum(W') / rstd carry
+    // head_dim ** -0.5 (pgrm.py:230-231) times log2(e): the softmax below is exp2(s - max)).  v, k, q in turn: short live ranges.
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = 16 * h + 4 * kq;
+      const f32x4 cv = *reinterpret_cast<const f32x4*>(pbias + FC + 64 + f), bv4 = *reinterpret_cast<const f32x4*>(pbias + 64 + f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) va[h][e] = fmaf(va[h][e], rk, fmaf(nmk, cv[e], bv4[e]));
+      *reinterpret_cast<f32x4*>(Vs + (16 * wave + lr) * LDK + f) = va[h];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = 16 * h + 4 * kq;
+      const f32x4 ck = *reinterpret_cast<const f32x4*>(pbias + FC + 32 + f), bk4 = *reinterpret_cast<const f32x4*>(pbias + 32 + f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ka[h][e] = fmaf(ka[h][e], rk, fmaf(nmk, ck[e], bk4[e]));
+      if (WS == 8) *reinterpret_cast<f32x4*>(Ks + (16 * wave + lr) * LDK + f) = ka[h];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int f = 16 * h + 4 * kq;
+      const f32x4 cq = *reinterpret_cast<const f32x4*>(pbias + FC + f), bq4 = *reinterpret_cast<const f32x4*>(pbias + f);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qa[h][e] = fmaf(qa[h][e], rqs, fmaf(nmq, cq[e], bq4[e]));
+    }
+    // ---- the row registers are dead: send for unit i+1 now, the loads fly during this unit's attention (and the partner
+    // wave's projection).  The index is clamped, not predicated: a load inside a branch makes hipcc drain vmcnt(0) at the join.
+    if (!(FA_SKIP & 16)) load_rows<WS>(a, xcd, i + 1 < last ? i + 1 : i, shift, wave, lr, kq, xq, xkv);
+    if (!(FA_SKIP & 8)) __syncthreads();
+    if (FA_SKIP & 4) {
+      float* dst = a.out + ((size_t)b * L + t) * FC + FCG * g + 4 * kq;
+      *reinterpret_cast<f32x4*>(dst) = qa[0] + ka[0] + va[0];
+      *reinterpret_cast<f32x4*>(dst + 16) = qa[1] + ka[1] + va[1];
+      continue;
+    }
+
+    unsigned masked = 0u;                  // bit (4 kt + r): key in another shift-mask region than my query (pgrm.py:240-243)
+    if (shift > 0) {
+      const int my_reg = reg_s[16 * wave + lr];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          masked |= (reg_s[(WS == 8 ? 16 * kt : 16 * wave) + 4 * kq + r] != my_reg ? 1u : 0u) << (4 * kt + r);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      f32x4 sacc[KT];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        f32x4 kf = ka[h];
+        if (WS == 8) kf = *reinterpret_cast<const f32x4*>(Ks + (16 * kt + lr) * LDK + 16 * h + 4 * kq);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma16(kf[s], qa[h][s], acc);
+        sacc[kt] = acc;
+      }
+      // + relative position bias, shift mask; softmax over the keys of query column lr
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = sacc[kt][r] + (WS == 8 ? tb_r[r][60 * (3 - kt) + h] : rb[r % RBN][h]);
+          if ((masked >> (4 * kt + r)) & 1u) v += -100.0f * LOG2E;
+          sacc[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float den = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(sacc[kt][r] - mx);
+          sacc[kt][r] = p;
+          den += p;
+        }
+      den += __shfl_xor(den, 16, 64);
+      den += __shfl_xor(den, 32, 64);
+      const float inv = 1.0f / den;
+      // O^T = V^T . P: two accumulator chains
+      f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int s = 0; s < 4; s += 2) {
+          const int krow = (WS == 8 ? 16 * kt : 16 * wave) + 4 * kq + s;
+          o0 = mfma16(Vs[krow * LDK + 16 * h + lr], sacc[kt][s], o0);
+          o1 = mfma16(Vs[(krow + 1) * LDK + 16 * h + lr], sacc[kt][s + 1], o1);
+        }
+      o0 += o1;
+      float* dst = a.out + ((size_t)b * L + t) * FC + FCG * g + 16 * h + 4 * kq;
+      *reinterpret_cast<float4*>(dst) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+    }
+  }
+}
+
+// units of this XCD's list whose cumulative start cost is < c
+__device__ __forceinline__ int units_before(long c, int per, const int (&cs)[3]) {
+  long base = 0;
+  int n = 0;
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    const long rem = c - base;
+    long k = rem <= 0 ? 0 : (rem + cs[s] - 1) / cs[s];
+    if (k > per) k = per;
+    n += (int)k;
+    base += (long)per * cs[s];
+  }
+  return n;
+}
+
+// Persistent: 2 blocks per CU, each walks a contiguous, cost-balanced range of the unit list of "its" XCD (blocks are
+// dealt to XCDs round-robin -- observed placement, used for speed only): images b with b % 8 == xcd, ordered slot-major, so
+//   * the three groups' gathers of an image's rows (each row is needed once per group) meet in one XCD's L2,
+//   * the group's weight slice is staged once per block and slot (<= 3 times), not once per unit,
+//   * the next unit's rows are loaded while the current unit computes, and workgroup dispatch cost is paid 512 times, not 2304.
+__global__ __launch_bounds__(256, 2) void k_ln_qkv_window_attn(FusedAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+  const int S = 1 << a.lgS;
+  const int ni = xcd < a.B ? (a.B - xcd + 7) / 8 : 0;
+  const int per = ni * S;                  // units per slot on this XCD
+  if (per == 0) return;
+  const int cs[3] = {a.cost[0], a.cost[1], a.cost[2]};
+  const long ctot = (long)per * (cs[0] + cs[1] + cs[2]);
+  const int u0 = units_before(ctot * j / nbx, per, cs);
+  const int u1 = j + 1 == nbx ? 3 * per : units_before(ctot * (j + 1) / nbx, per, cs);
+  for (int slot = 0; slot < 3; ++slot) {
+    const int lo = u0 > slot * per ? u0 - slot * per : 0;
+    const int hi = (u1 < (slot + 1) * per ? u1 : (slot + 1) * per) - slot * per;
+    if (lo >= hi) continue;                // block-uniform
+    const int ws = a.ws[slot];
+    if (ws == 8) run_units<8>(a, slot, xcd, lo, hi, smem);
+    else if (ws == 4) run_units<4>(a, slot, xcd, lo, hi, smem);
+    else run_units<2>(a, slot, xcd, lo, hi, smem);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dpmn_ln_qkv_window_attn_supported(int C, int n_groups, int heads_per_group, const int* windows, int H, int W) {
+  if (C != FC || n_groups != 3 || heads_per_group != 2 || !windows || (H * W) % 64 != 0) return 0;
+  if ((H & (H - 1)) || (W & (W - 1)) || H < 8 || W < 8) return 0;      // index math uses shifts / masks (16x64 and 32x128 token grids)
+  static const int off = getenv("DPMN_ATTN_FUSED") && atoi(getenv("DPMN_ATTN_FUSED")) == 0;
+  if (off) return 0;
+  for (int g = 0; g < 3; ++g) {
+    const int ws = windows[g];
+    if (!(ws == 2 || ws == 4 || ws == 8) || H % ws || W % ws) return 0;
+  }
+  return 1;
+}
+
+int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                                const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                                const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                                int n_groups, int heads_per_group, float* out, int B, int H, int W, int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(tq && tkv && lnq_w && lnq_b && lnkv_w && lnkv_b && wq && bq && wkv && bkv && bias_tables && windows && shifts && out,
+               "ln_qkv_window_attn: null pointer");
+  DPMN_REQUIRE(B > 0, "ln_qkv_window_attn: empty batch");
+  DPMN_REQUIRE(!(H & (H - 1)) && !(W & (W - 1)) && H >= 8 && W >= 8, "ln_qkv_window_attn: token grid sides must be powers of two >= 8");
+  DPMN_REQUIRE(C == FC && n_groups == 3 && heads_per_group == 2 && (H * W) % 64 == 0,
+               "ln_qkv_window_attn: built for dim 96 = 3 groups x 2 heads x 16 (config 1/2/3); other shapes use the unfused kernels");
+  FusedAttnArgs a{};
+  a.tq = tq; a.tkv = tkv; a.lnq_w = lnq_w; a.lnq_b = lnq_b; a.lnkv_w = lnkv_w; a.lnkv_b = lnkv_b;
+  a.wq = wq; a.bq = bq; a.wkv = wkv; a.bkv = bkv; a.out = out; a.B = B; a.H = H; a.W = W; a.eps = eps;
+  for (a.lgW = 0; (1 << a.lgW) < W; ++a.lgW) {}
+  for (a.lgS = 0; (64 << a.lgS) < H * W; ++a.lgS) {}
+  int order[3] = {0, 1, 2};      // largest windows first: their units carry 30 % more MFMA work, the short ones fill the tail
+  for (int i = 0; i < 3; ++i)
+    for (int j = i + 1; j < 3; ++j)
+      if (windows[order[j]] > windows[order[i]]) { const int t_ = order[i]; order[i] = order[j]; order[j] = t_; }
+  for (int s = 0; s < 3; ++s) {
+    const int g = order[s], ws = windows[g];
+    DPMN_REQUIRE((ws == 2 || ws == 4 || ws == 8) && H % ws == 0 && W % ws == 0 && shifts[g] >= 0 && shifts[g] < ws,
+                 "ln_qkv_window_attn: windows must be 2, 4 or 8 and divide the token grid (padding path of pgrm.py:200-207 not built)");
+    DPMN_REQUIRE(bias_tables[g], "ln_qkv_window_attn: null bias table");
+    a.gid[s] = g; a.ws[s] = ws; a.shift[s] = shifts[g]; a.table[s] = bias_tables[g];
+    a.cost[s] = 36 + ws * ws / 4;         // (576 projection + 4 N attention MFMAs per unit) / 16
+  }
+  const size_t smem = (size_t)(FC * LDW + 4 * 64 * LDK + TBLMAX + 2 * 64 + 6 * FC) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const long slabs = (long)B * (H * W / 64);
+  const double tokens = (double)B * H * W;
+  double attn = 0.0;
+  for (int g = 0; g < 3; ++g) attn += 4.0 * windows[g] * windows[g] * FD * 2 * tokens;
+  hipStream_t st = as_stream(stream);
+  ProfScope prof(PT_ATTN_FUSED, st, 2.0 * tokens * FC * (3 * FC) + attn, 4.0 * (3.0 * tokens * FC + 3.0 * FC * FC));
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return dpmn_set_error(DPMN_ERR_LAUNCH, "ln_qkv_window_attn: device query failed");
+    n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
+  }
+  static const int bpc = getenv("DPMN_FA_BPC") ? atoi(getenv("DPMN_FA_BPC")) : 2;
+  long blocks = (long)bpc * n_cu;          // 2 resident blocks per CU (78 KB of LDS each); a multiple of 8
+  const long need = ((3 * slabs + 7) / 8) * 8;
+  if (blocks > need) blocks = need;
+  hipLaunchKernelGGL(k_ln_qkv_window_attn, dim3((unsigned)blocks), dim3(256), smem, st, a);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+}  // extern "C"

@@ -74,9 +74,15 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
       shift[g] = blk == 0 ? 0 : w->window[g] / 2;          // pgrm.py:362
       if ((H < Wd ? H : Wd) <= win[g]) { win[g] = H < Wd ? H : Wd; shift[g] = 0; }  // pgrm.py:147-150
     }
-    RUN(dpmn_ln_linear_f32(s.tq, p.norm1_q_w, p.norm1_q_b, 1e-5f, p.q_w, p.q_b, s.q, M, C, C, DPMN_ACT_NONE, stream));
-    RUN(dpmn_ln_linear_f32(s.tkv, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, p.kv_w, p.kv_b, s.kv, M, 2 * C, C, DPMN_ACT_NONE, stream));
-    RUN(dpmn_window_attn_f32(s.q, s.kv, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat, B, H, Wd, C, stream));
+    if (dpmn_ln_qkv_window_attn_supported(C, w->n_groups, w->heads_per_group, win, H, Wd)) {
+      // LayerNorm + q / kv projection + window attention in one kernel: q and kv never reach HBM (attn_fused.hip)
+      RUN(dpmn_ln_qkv_window_attn_f32(s.tq, s.tkv, p.norm1_q_w, p.norm1_q_b, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, p.q_w, p.q_b, p.kv_w,
+                                      p.kv_b, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat, B, H, Wd, C, stream));
+    } else {
+      RUN(dpmn_ln_linear_f32(s.tq, p.norm1_q_w, p.norm1_q_b, 1e-5f, p.q_w, p.q_b, s.q, M, C, C, DPMN_ACT_NONE, stream));
+      RUN(dpmn_ln_linear_f32(s.tkv, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, p.kv_w, p.kv_b, s.kv, M, 2 * C, C, DPMN_ACT_NONE, stream));
+      RUN(dpmn_window_attn_f32(s.q, s.kv, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat, B, H, Wd, C, stream));
+    }
     RUN(dpmn_sk_proj_f32(s.cat, p.sk_proj_w, p.sk_proj_b, s.feats, s.partial, M, C, stream));
     const int cg = C / w->n_groups;
     RUN(dpmn_sk_gate_f32(s.partial, (L + 31) / 32, L, p.sk_fc1_w, p.sk_fc1_b, p.sk_fc2_w, p.sk_fc2_b, s.avec, B, C,

@@ -66,6 +66,22 @@ def window_attn(q, kv, tables, windows, shifts, heads_per_group, H, W, p_drop=0.
     return out
 
 
+def ln_qkv_window_attn_supported(Cd, windows, heads_per_group, H, W):
+    return bool(lib.dpmn_ln_qkv_window_attn_supported(Cd, len(windows), heads_per_group, _abi.int_array(windows), H, W))
+
+
+def ln_qkv_window_attn(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, tables, windows, shifts, heads_per_group, H, W,
+                       eps=1e-5):
+    """norm1_q / norm1_kv + q / kv Linear + multi-size window attention in ONE kernel (pgrm.py:322-323, 188-266); tq / tkv
+    (B, L, C) are the token streams before the LayerNorms; returns the window-major `cat` tensor (B, L, C)."""
+    B, L, Cd = tq.shape
+    out = torch.empty_like(tq)
+    check(lib.dpmn_ln_qkv_window_attn_f32(dptr(tq), dptr(tkv), dptr(lnq_w), dptr(lnq_b), dptr(lnkv_w), dptr(lnkv_b), float(eps),
+                                          dptr(wq), dptr(bq), dptr(wkv), dptr(bkv), _abi.ptr_array(tables), _abi.int_array(windows),
+                                          _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), B, H, W, Cd, stream()))
+    return out
+
+
 def maxpool(x, kh, kw, scale=None, shift=None):
     """nn.MaxPool2d((kh,kw), stride (kh,kw)) over NHWC; scale/shift: the producer's BatchNorm affine + ReLU applied on load."""
     B, H, W, Cc = x.shape

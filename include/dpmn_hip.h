@@ -59,6 +59,18 @@ int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_h
 /* z[b] = w (Ch,Ch) . g[b] (Ch,L) + bias : Mlp.pointwise_conv on the raw (B,Ch,r,r) view (pgrm.py:34,37) */
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream);
+/* Fused norm1_q / norm1_kv + q / kv projections + multi-size window attention of one SwinTransformerBlock
+ * (pgrm.py:322-323 LayerNorms, 188/194 Linear q / kv, 197-266 per-group roll + window partition + 2 heads x 16 + relative
+ * position bias + shift mask + softmax + P.V, written window-major without un-roll, quirk Q1).  tq / tkv: (B, H*W, C) token
+ * streams BEFORE the LayerNorms; out: (B, H*W, C) = the `cat` tensor fed to SKConv.  q and kv never reach HBM.
+ * Built for C = 96 = 3 groups x 2 heads x 16 with windows in {2, 4, 8} (configs 1-3); _supported() says whether a shape
+ * qualifies (0: use dpmn_ln_linear_f32 x2 + dpmn_window_attn_f32).  Eval path only (no attn_drop). */
+int dpmn_ln_qkv_window_attn_supported(int C, int n_groups, int heads_per_group, const int* windows, int H, int W);
+int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                                const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                                const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                                int n_groups, int heads_per_group, float* out, int B, int H, int W, int C, dpmn_stream_t stream);
+
 /* Measurement hooks for bench.py's roofline objects (no reference counterpart: the reference has no profiler, SURVEY.md
  * section 5).  While armed, every launch of a kernel family whose tag bit is set in tag_mask -- issued directly or from
  * inside a module driver such as dpmn_pgrm_forward_f32 -- is bracketed by HIP events on the stream it is launched on, up to
