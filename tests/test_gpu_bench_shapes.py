@@ -94,12 +94,15 @@ def test_cmm_cnum64_train_fwd_bwd_at_b8_vs_oracle_autograd(dev):
     record(name, "dx2 rel L2", e2, 1e-2)
     assert e1 < 1e-2 and e2 < 1e-2
     worst, num, den = ("", 0.0), 0.0, 0.0
+    gmax = max(float(sd_ref[n_].grad.abs().max()) for n_, _ in m.named_parameters())
     for n_, p in m.named_parameters():
         g_ref = sd_ref[n_].grad
         d = p.grad.detach().cpu().double() - g_ref.double()
         num += float((d * d).sum()); den += float((g_ref.double() ** 2).sum())
-        if float(g_ref.abs().max()) < 2e-3:
-            assert float(p.grad.abs().max()) < 5e-3, n_
+        if float(g_ref.abs().max()) < max(2e-3, 1e-4 * gmax):
+            # conv biases in front of a batch-statistics BatchNorm: the true gradient is exactly zero (the batch mean removes
+            # the bias); torch holds only the round-off of a sum over B*H*W terms there, which grows with the map size
+            assert float(p.grad.abs().max()) < max(5e-3, 3e-4 * gmax), n_
             continue
         worst = max(worst, (n_, l2_rel(p.grad, g_ref)), key=lambda t_: t_[1])
     # per tensor: the deepest levels (en_6 / de_6: 1x4 maps, 32 samples per BatchNorm channel at B = 8) are fp32-conditioned
