@@ -192,28 +192,51 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     }
   };
   typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  // UNI path: everything that does not depend on the chunk is hoisted -- per pass the pixel's linear index and a row/column
+  // pair in which rows beyond M are parked far outside the image (their range test then fails like an out-of-image tap);
+  // per chunk the tap / segment decode runs on scalars, and a pass costs two adds, two unsigned compares, one 24-bit
+  // multiply-add and the buffer load (the matrix pipe shares its issue port with the vector ALU: address arithmetic in
+  // the loop is paid in MFMA time).
+  int pix[APASS];
+#pragma unroll
+  for (int p = 0; p < APASS; ++p) {
+    pix[p] = pb[p] >= 0 ? (pb[p] * a.Hin + py[p]) * a.Win + px[p] : 0;
+    if (pb[p] < 0) { py[p] = -(1 << 20); px[p] = -(1 << 20); }
+  }
+  // chunk decode state (scalars): advanced by one 32-channel chunk per call instead of two integer divisions per chunk
+  int u_tap = 0, u_c0 = 0, u_ky = 0, u_kx = 0, u_k0 = -1;
+  int wofs[BPASS];
+#pragma unroll
+  for (int p = 0; p < BPASS; ++p) wofs[p] = ((n_blk + lrow + p * 32) * a.Kp + lcol) * 4;      // + k0 * 4 through the scalar offset
   auto gload_uni = [&](int k0) {
-    const int tap = k0 / a.cin, c0 = k0 - tap * a.cin;          // wave-uniform
-    const int ky = tap / a.KW, kx = tap - ky * a.KW;
-    const int dy = ky * a.dil_y, dx = kx * a.dil_x;
+    if (k0 == u_k0 + BK) {                 // the next chunk (the common case)
+      u_c0 += BK;
+      if (u_c0 >= a.cin) { u_c0 = 0; ++u_tap; if (++u_kx == a.KW) { u_kx = 0; ++u_ky; } }
+    } else if (k0 != u_k0) {               // first chunk of a split (or the clamped re-read of the last one: unchanged)
+      u_tap = k0 / a.cin; u_c0 = k0 - u_tap * a.cin;
+      u_ky = u_tap / a.KW; u_kx = u_tap - u_ky * a.KW;
+    }
+    u_k0 = k0;
+    const int tap = u_tap, c0 = u_c0, ky = u_ky, kx = u_kx;      // wave-uniform
+    const bool tap_ok = tap < ktaps;
+    const int dy = tap_ok ? ky * a.dil_y : (1 << 21), dx = kx * a.dil_x;      // K-padding chunk: every range test fails
     const int seg = c0 >= c01 ? 2 : (c0 >= a.cseg[0] ? 1 : 0);
     const int cl = c0 - (seg == 2 ? c01 : (seg == 1 ? a.cseg[0] : 0)) + lcol;
     const float* src = a.in[seg];
     const int cs = a.cseg[seg];
     const float* sc = a.in_scale[seg];
     const float* sh = a.in_shift[seg];
-    const bool tap_ok = tap < ktaps;
     has_aff = sc != nullptr && tap_ok;
     if (has_aff) { s4r = *reinterpret_cast<const float4*>(sc + cl); h4r = *reinterpret_cast<const float4*>(sh + cl); }
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, a.B * a.Hin * a.Win * cs * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ph.w), 0, a.Cout * a.Kp * 4, 0x00020000);
+    const int tapoff = dy * a.Win + dx;                          // scalar
     vmask = 0;
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
-      const int iy = py[p] + dy, ix = px[p] + dx;
-      const bool ok = pb[p] >= 0 && tap_ok && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      const bool ok = (unsigned)(py[p] + dy) < (unsigned)a.Hin && (unsigned)(px[p] + dx) < (unsigned)a.Win;
       // branch-free: bit 31 set = beyond num_records (< 2^31, checked by the launcher) whatever the low bits are
-      const unsigned off = (unsigned)((((pb[p] * a.Hin + iy) * a.Win + ix) * cs + cl) * 4) | (ok ? 0u : 0x80000000u);
+      const unsigned off = (unsigned)((__mul24(pix[p] + tapoff, cs) + cl) * 4) | (ok ? 0u : 0x80000000u);
       xr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)off, 0, 0));
       vmask |= (ok ? 1u : 0u) << p;
     }
@@ -221,14 +244,19 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     for (int p = 0; p < BPASS; ++p) {
       const int r = lrow + p * 32;
       if (BN % 32 == 0 || r < BN)       // rows past Cout are beyond num_records: the range check returns 0
-        wr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, ((n_blk + r) * a.Kp + k0 + lcol) * 4, 0, 0));
+        wr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wofs[p], k0 * 4, 0));
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
       float4 v = xr[p];
-      if ((vmask >> p) & 1u) {
+      if (!has_aff && (a.pro_act == ACT_LEAKY02 || a.pro_act == ACT_RELU)) {
+        // the usual case (eval: BatchNorm folded into the producer): out-of-image lanes already hold 0 and act(0) = 0, so no
+        // mask; LeakyReLU(0.2) = max(x, 0.2 x), ReLU = max(x, 0)
+        const float sl = a.pro_act == ACT_LEAKY02 ? 0.2f : 0.0f;
+        v.x = fmaxf(v.x, sl * v.x); v.y = fmaxf(v.y, sl * v.y); v.z = fmaxf(v.z, sl * v.z); v.w = fmaxf(v.w, sl * v.w);
+      } else if ((vmask >> p) & 1u) {
         if (has_aff) { v.x = v.x * s4r.x + h4r.x; v.y = v.y * s4r.y + h4r.y; v.z = v.z * s4r.z + h4r.z; v.w = v.w * s4r.w + h4r.w; }
         if (a.pro_act != ACT_NONE) {
           v.x = apply_act(v.x, a.pro_act, 0.f); v.y = apply_act(v.y, a.pro_act, 0.f);
@@ -805,8 +833,10 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN) * nph;
   const int nk = a.Kp / BK;
   int S = 1;
+  static const int force_s = getenv("DPMN_CONV_S") ? atoi(getenv("DPMN_CONV_S")) : 0;      // experiment knob: fixed split count
+  static const int target = getenv("DPMN_CONV_TARGET") ? atoi(getenv("DPMN_CONV_TARGET")) : 768;
   if (ws && tiles < 384 && nk >= 16) {
-    S = cdiv(768, tiles);
+    S = force_s > 0 ? force_s : cdiv(target, tiles);
     if (S > nk / 8) S = nk / 8;
     if (S > 64) S = 64;
     static const size_t cap_mb = getenv("DPMN_SPLITK_CAP_MB") ? (size_t)atoi(getenv("DPMN_SPLITK_CAP_MB")) : 32;
@@ -914,6 +944,8 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   if (a.Cout <= 32) return launch_conv<128, 32, 4, 1>(a, ws, wsb, st);
   // 128x128 tiles halve the L2->LDS bytes per FLOP of the 64x64 tile (which is L2-bound); small-M convs regain
   // parallelism through split-K (deep CMM levels: K = 2304..13824)
+  static const int force_tile = getenv("DPMN_CONV_TILE") ? atoi(getenv("DPMN_CONV_TILE")) : 0;          // experiment knob
+  if (force_tile == 64) return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
   if (a.Cout >= 128 && M >= 128) return launch_conv<128, 128, 2, 2>(a, ws, wsb, st);
   return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
 }
