@@ -529,8 +529,24 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
       if (i < NPX * 8) *reinterpret_cast<float4*>(halo + (size_t)buf * NPX * LDK + (i >> 3) * LDK + (i & 7) * 4) = hraw[v];
     }
   };
+  // weight slice of one (chunk, tap): raw buffer loads -- per-thread byte offsets are loop invariants, the (chunk, tap) part
+  // travels in the scalar offset, rows past Cout fall beyond num_records and read 0: no address arithmetic and no predicated
+  // load (whose join would make hipcc drain vmcnt(0) in front of the MFMA block) inside the tap loop
+  int wofs_h[WV];
+#pragma unroll
+  for (int v = 0; v < WV; ++v) {
+    const int i = tid + v * 256;
+    wofs_h[v] = (i < BN * 8) ? ((n_blk + (i >> 3)) * a.Kp + (i & 7) * 4) * 4 : (int)0x80000000;
+  }
+  const bool w_buf_ok = (size_t)a.Cout * a.Kp * 4 < (1ull << 31);
+  const __amdgpu_buffer_rsrc_t wrs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_buf_ok ? a.Cout * a.Kp * 4 : 0, 0x00020000);
   auto issue_w = [&](int chunk, int tap) {
     const size_t k0 = (size_t)tap * a.cin + chunk * BK;
+    if (w_buf_ok) {
+#pragma unroll
+      for (int v = 0; v < WV; ++v) wraw[v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs_h, wofs_h[v], (int)k0 * 4, 0));
+      return;
+    }
 #pragma unroll
     for (int v = 0; v < WV; ++v) {
       const int i = tid + v * 256;
