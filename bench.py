@@ -101,9 +101,11 @@ def cpu_baseline_worker(workload_name, n_img, threads):
     from dpmn_amd.workload import cpu_state_dicts, cpu_priors
     torch.set_num_threads(threads)
     arch, b1, b2, sd_psn, sds = cpu_state_dicts(workload_name)
-    batch = synth.synth_batch(n_img, seed=2)
+    from dpmn_amd.workload import geom
+    _, win, h, w = geom(workload_name)
+    batch = synth.synth_batch(n_img, seed=2, h_lr=h // 2, w_lr=w // 2)
     priors = cpu_priors(workload_name, n_img)
-    run = lambda: odpmn.refine(sd_psn, sds[:-1], sds[-1], arch, b1, b2, batch["images_lr"], batch["label_vecs"], priors, 0.5)
+    run = lambda: odpmn.refine(sd_psn, sds[:-1], sds[-1], arch, b1, b2, batch["images_lr"], batch["label_vecs"], priors, 0.5, windows=win)
     with torch.no_grad():
         for _ in range(2):
             run()  # warm-ups

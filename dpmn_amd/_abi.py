@@ -37,7 +37,7 @@ class PgrmWeights(C.Structure):
         "n_weight_list")] + [("window", C.c_int * 4)] + [(n, fp) for n in (
             "prior_fusion_w", "prior_fusion_b", "pe_w", "pe_b", "pe_norm_w", "pe_norm_b")] + [
         ("blocks", PgrmBlock * 2)] + [(n, fp) for n in ("tail0_w", "tail0_b", "tail1_w", "tail1_b")] + [
-        ("weight_list", fp * 8)]
+        ("weight_list", fp * 16)]
 
 
 class ConvDesc(C.Structure):

@@ -50,7 +50,7 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
   DPMN_REQUIRE(w && x_q && x_kv && out && workspace, "pgrm_forward: null pointer");
   DPMN_REQUIRE(B >= 1, "pgrm_forward: empty batch");
   DPMN_REQUIRE(w->n_groups >= 1 && w->n_groups <= 4, "pgrm_forward: 1..4 window groups");
-  DPMN_REQUIRE(n_residuals <= w->n_weight_list, "pgrm_forward: more residuals than weight_list entries (iter)");
+  DPMN_REQUIRE(n_residuals <= w->n_weight_list && w->n_weight_list <= 16, "pgrm_forward: more residuals than weight_list entries (iter), or iter > 15");
   DPMN_REQUIRE((x_q_channels == 2) == (w->prior_fusion_w != nullptr) || x_q_channels == 3,
                "pgrm_forward: a 2-channel text prior needs prior_fusion weights (mode=False)");
   const int H = w->img_h / w->patch, Wd = w->img_w / w->patch, L = H * Wd, C = w->dim, Ch = w->mlp_hidden;

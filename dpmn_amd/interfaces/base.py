@@ -71,7 +71,11 @@ class TextBase(object):
         elif psn:
             raise NotImplementedError("dpmn_amd: PSN arch %r is not built (built: tsrn, tg, tatt, tbsrn)" % self.args.arch)
         else:
-            model = pgrm.PGRM(patch_size=self.patch_size, embed_dim=self.embed_dim, depths=self.depths,
+            # base.py:151 never passes img_size, so the reference PGRM is hard-wired to 32x128 outputs (weight_list_i is
+            # (1, hidden, 32, 128), pgrm.py:497, quirk Q7).  Here the size follows the config (height x width), which is the
+            # identical call for the 32x128 recipe and lets the 64x256 stress configuration run at all.
+            model = pgrm.PGRM(img_size=[cfg.height, cfg.width],
+                              patch_size=self.patch_size, embed_dim=self.embed_dim, depths=self.depths,
                               num_heads=self.num_heads, window_size=self.window_size, mlp_ratio=self.mlp_ratio,
                               drop_rate=self.drop_rate, attn_drop_rate=self.attn_drop_rate,
                               drop_path_rate=self.drop_path_rate, iter=iter, mode=mode, hidden_size=hidden_size)

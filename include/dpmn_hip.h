@@ -376,7 +376,7 @@ typedef struct {
   const float *pe_w, *pe_b, *pe_norm_w, *pe_norm_b;
   dpmn_pgrm_block blocks[2];
   const float *tail0_w, *tail0_b, *tail1_w, *tail1_b;
-  const float* weight_list[8];
+  const float* weight_list[16];   /* weight_list_0 .. weight_list_iter (iter <= 11 in the 6+6 stress stack) */
 } dpmn_pgrm_weights;
 
 size_t dpmn_pgrm_workspace_bytes(const dpmn_pgrm_weights* w, int B);

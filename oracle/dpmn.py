@@ -9,7 +9,8 @@ from . import pgrm as opgrm
 from . import tsrn as otsrn
 
 
-def refine(sd_psn, sd_pgrms, sd_cmm, arch, b1, b2, images_lr, label_vecs, text_priors, alpha=0.5, return_all=False):
+def refine(sd_psn, sd_pgrms, sd_cmm, arch, b1, b2, images_lr, label_vecs, text_priors, alpha=0.5, return_all=False,
+           windows=(2, 4, 8)):
     if arch == "tatt":
         psn, _ = otsrn.tatt_forward(sd_psn, images_lr, label_vecs)
     elif arch == "tbsrn":
@@ -18,12 +19,12 @@ def refine(sd_psn, sd_pgrms, sd_cmm, arch, b1, b2, images_lr, label_vecs, text_p
         psn = otsrn.tsrn_forward(sd_psn, images_lr)
     cascade, br1 = psn, []
     for k in range(b1):
-        sr = opgrm.pgrm_forward(sd_pgrms[k], text_priors[k], cascade[:, :3], br1[:k])
+        sr = opgrm.pgrm_forward(sd_pgrms[k], text_priors[k], cascade[:, :3], br1[:k], windows=windows)
         br1.append(sr)
         cascade = sr
     cascade, br2 = psn, []
     for k in range(b1, b1 + b2):
-        sr = opgrm.pgrm_forward(sd_pgrms[k], ocmm.to_mask(cascade[:, :3]), cascade[:, :3], br2[:(k - b2)])
+        sr = opgrm.pgrm_forward(sd_pgrms[k], ocmm.to_mask(cascade[:, :3]), cascade[:, :3], br2[:(k - b2)], windows=windows)
         br2.append(sr)
         cascade = sr
     fused = ocmm.cmm_forward(sd_cmm, br1[-1], br2[-1], False)

@@ -137,3 +137,41 @@ def test_error_behaviour_through_the_c_abi():
     with pytest.raises(DpmnError, match="mha32"):
         ops.mha32(torch.zeros(100, 384, device=dev), 1, 100, 4, 1.0)
     assert lib.dpmn_abi_version() >= 1
+
+
+def test_stack_cfg4_stress_vs_oracle_small_batch():
+    """BASELINE.json configs[4] as a runnable stack: TSRN PSN on 32x128 inputs + 6+6 PGRM (embed 192, windows 4/8/16, 64x256
+    outputs, weight_list sized from the image: the reference itself cannot build this, quirk Q7) + CMM, against the oracle
+    (which can) at B = 2.  The mask priors of branch 2 are taken from the GPU (discrete, pinned separately)."""
+    from dpmn_amd import workload, ops
+    from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn
+    from helpers import record, max_abs_err
+    B = 2
+    sr, models, psn, inp = workload.build("cfg4", batch=B)
+    assert models[0].img_size == [64, 256] and models[0].embed_dim == 192 and models[-2].iter == 11
+    out, mid = sr.refine(models, psn, inp["images_lr"], None, text_priors=inp["text_priors"], return_all=True)
+    assert out.shape == (B, 3, 64, 256)
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [x.cpu() for x in v]) for k, v in inp.items()}
+    win = (4, 8, 16)
+    with torch.no_grad():
+        r_psn = otsrn.tsrn_forward(sd_psn, cpu["images_lr"])
+        assert_close(mid["psn"], r_psn, 2e-4, 2e-4, "TSRN at 32x128 -> 64x256")
+        casc, l1 = r_psn, []
+        for k in range(6):
+            o = opgrm.pgrm_forward(sds[k], cpu["text_priors"][k], casc[:, :3], l1[:k], windows=win); l1.append(o); casc = o
+            record("cfg4_B2", "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 1e-3)
+            assert_close(mid["branch1"][k], o, 1e-3, 1e-3, "cfg4 branch1[%d]" % k)
+        casc_gpu, casc, l2 = mid["psn"], r_psn, []
+        for k in range(6, 12):
+            o = opgrm.pgrm_forward(sds[k], ops.to_mask(casc_gpu).cpu(), casc[:, :3], l2[:(k - 6)], windows=win); l2.append(o); casc = o
+            casc_gpu = mid["branch2"][k - 6]
+            record("cfg4_B2", "branch2[%d] max|err|" % (k - 6), max_abs_err(casc_gpu, o), 1e-3)
+            assert_close(casc_gpu, o, 1e-3, 1e-3, "cfg4 branch2[%d]" % (k - 6))
+        fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
+        ref = 0.5 * fused + 0.5 * r_psn[:, :3]
+    record("cfg4_B2", "output max|err|", max_abs_err(out, ref), 2e-3)
+    assert_close(out, ref, 2e-3, 2e-3, "cfg4 output")
+    p, s = ops.psnr_ssim(out, inp["images_hr"])
+    assert abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"]))) < 1e-3
+    assert abs(float(s) - float(ocmm.ssim(ref, cpu["images_hr"]))) < 1e-3
