@@ -1,0 +1,32 @@
+#!/bin/bash
+# Evidence run on the MI355X box (gpurun):  bash tools/collect_profiles.sh [quick]
+#   kernel-trace summaries of the forward and training benches, three PMC passes over the forward bench (FETCH_SIZE, WRITE_SIZE,
+#   MFMA utilisation -- separate runs, --pmc never combined with other trace domains), and the bench JSON lines.
+# Everything lands in gpurun_out/prof/; tools/collect_profiles.py <tag> copies the summaries into profiles/.
+set -u
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --no-cpu-baseline --no-kernel-profile"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fwd -- $B --steps 10 --warmup 3 > $OUT/fwd.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- $B --mode train --steps 5 --warmup 2 > $OUT/train.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 3 --warmup 2 > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --steps 3 --warmup 2 > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- $B --steps 3 --warmup 2 > $OUT/pmc_mfma.log 2>&1
+cd $R
+timeout 900 python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
+timeout 600 python bench.py --mode train 2>/dev/null | tail -1 > $OUT/bench_train.json
+if [ "${1:-}" != "quick" ]; then
+  timeout 600 python bench.py --mode train --drop 0.1 2>/dev/null | tail -1 > $OUT/bench_train_drop.json
+  timeout 600 python bench.py --workload cfg3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg3.json
+  timeout 900 python bench.py --workload cfg4 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg4.json
+fi
+# keep the merge-back small: the per-dispatch traces are reduced on the box, only summaries travel
+python tools/collect_profiles.py --reduce $OUT > $OUT/reduce.log 2>&1
+find $OUT -name "*.db" -delete 2>/dev/null
+find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null
+find $OUT -name "*counter_collection.csv" -delete 2>/dev/null
+find $OUT -type f -size +8M -delete 2>/dev/null
+du -sh $OUT; cat $OUT/reduce.log | tail -5
+head -c 400 $OUT/bench_default.json
