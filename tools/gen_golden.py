@@ -408,7 +408,56 @@ def gen_step():
         save("step_tsrn_2p2", **arrs)
 
 
-GENS = {"grads": gen_grads, "step": gen_step, "stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
+def gen_visionlan():
+    """VisionLAN (the branch-1 text-prior recogniser) in eval mode through the imported reference: per-step logits captured at
+    Prediction, the flattened (output, out_length) pair MLM_VRM returns, a digest of the backbone feature map and the strings
+    cha_encdec.decode (restated: the dict file is read there, utils.py:13-16) produces.  B = 3 images of 64x256."""
+    from model.VisionLAN.VisionLAN import VisionLAN
+    B = 3
+    m = VisionLAN(strides=[(1, 1), (2, 2), (2, 2), (2, 2), (1, 1), (1, 1)], input_shape=[3, 64, 256]).eval()
+    pos_tab = m.MLM_VRM.SequenceModeling.position_enc.pos_table[0, ::5, ::7].clone()      # the constructor's sinusoid table
+    sd = m.state_dict()
+    synth.synth_fill_(sd, seed=61)
+    sd = {k: v.clone() for k, v in sd.items()}
+    m.load_state_dict(sd)
+    x = synth.uniform("vl_img", (B, 3, 64, 256), 0, 1, 62)
+    grab = {}
+    m.MLM_VRM.Prediction.register_forward_hook(lambda mod, i, o: grab.__setitem__("logits", o.clone()))
+    m.backbone.register_forward_hook(lambda mod, i, o: grab.__setitem__("feat", o[-1].clone()))
+    m.MLM_VRM.SequenceModeling.register_forward_hook(lambda mod, i, o: grab.__setitem__("enc", o[0].clone()))
+    output, out_length = m(x, None, '', False)
+    dic = [l.replace("\n", "") for l in open(os.path.join(ref_shims.REF_ROOT, "dic_36.txt")).readlines()]
+    prob = torch.softmax(output, 1)
+    texts, start = [], 0
+    for i in range(B):
+        n = int(out_length[i])
+        idx = prob[start:start + n].topk(1)[1][:, 0].tolist()
+        texts.append("".join(dic[c - 1] if 0 < c <= len(dic) else "" for c in idx))
+        start += n
+    # the decode loop (VisionLAN.py:107-135) on logits with EOS in the middle / at step 0 / never: Prediction replaced by a stub
+    # returning crafted logits, everything after it is the reference's own code
+    grab = dict(grab)                                    # (the hooks fire again below)
+    m.backbone._forward_hooks.clear(); m.MLM_VRM.SequenceModeling._forward_hooks.clear(); m.MLM_VRM.Prediction._forward_hooks.clear()
+    crafted = synth.uniform("vl_crafted", (4, 26, 37), -1, 1, 64)
+    crafted[:, :, 0] -= 3.0
+    crafted[0, 6, 0] = 5.0; crafted[0, 9, 0] = 5.0      # first EOS at step 6 -> length 7
+    crafted[1, 0, 0] = 5.0                               # EOS at step 0 -> length 1, empty string
+    crafted[3, 24, 0] = 5.0                              # EOS at the last step -> length 25
+    m.MLM_VRM.Prediction.forward = lambda *a, **k: crafted.clone()
+    d_out, d_len = m(synth.uniform("vl_img4", (4, 3, 64, 256), 0, 1, 62), None, '', False)
+    d_prob = torch.softmax(d_out, 1)
+    d_texts, start = [], 0
+    for i in range(4):
+        n = int(d_len[i])
+        idx = d_prob[start:start + n].topk(1)[1][:, 0].tolist()
+        d_texts.append("".join(dic[c - 1] if 0 < c <= len(dic) else "" for c in idx))
+        start += n
+    save("visionlan", pos_table_sample=pos_tab, decode_output=d_out, decode_length=d_len, decode_texts=np.array(d_texts), logits=grab["logits"], output=output, out_length=out_length, feat_sample=grab["feat"][:, ::16, :, ::4].contiguous(),
+         enc_sample=grab["enc"][:, ::8, ::8].contiguous(), texts=np.array(texts), dict36=np.array("".join(dic)),
+         manifest=manifest(sd), checksum=checksum(sd))
+
+
+GENS = {"visionlan": gen_visionlan, "grads": gen_grads, "step": gen_step, "stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
 
 
 if __name__ == "__main__":
