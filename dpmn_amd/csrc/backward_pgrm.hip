@@ -956,7 +956,8 @@ int dpmn_layernorm_f32(const float* x, const float* gamma, const float* beta, fl
   if (C == 96) hipLaunchKernelGGL((k_ln_fwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, y, M);
   else if (C == 192) hipLaunchKernelGGL((k_ln_fwd<192>), dim3(blocks), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, y, M);
   else if (C == 64) hipLaunchKernelGGL((k_ln_fwd<64>), dim3(blocks), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, y, M);
-  else return dpmn_set_error(DPMN_ERR_ARG, "layernorm: C must be 64, 96 or 192");
+  else if (C == 512) hipLaunchKernelGGL((k_ln_fwd<512>), dim3(blocks), dim3(256), 0, as_stream(stream), x, gamma, beta, eps, y, M);
+  else return dpmn_set_error(DPMN_ERR_ARG, "layernorm: C must be 64, 96, 192 or 512");
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

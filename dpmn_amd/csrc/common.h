@@ -50,7 +50,7 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 
 // activation codes shared by GEMM / conv epilogues and conv prologues
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_LEAKY02 = 3, ACT_LEAKY001 = 4, ACT_MISH = 5, ACT_PRELU = 6,
-       ACT_TANH = 7, ACT_SIGMOID = 8 };
+       ACT_TANH = 7, ACT_SIGMOID = 8, ACT_RELU_POST_RES = 9 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {

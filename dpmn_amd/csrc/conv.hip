@@ -83,12 +83,14 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, floa
     for (int r = 0; r < 4; ++r) { ssum[r] += v[r]; ssq[r] += v[r] * v[r]; }
   }
   apply_act4(v, a.epi_act, a.slope);
+  const bool post = a.epi_act == ACT_RELU_POST_RES;      // ReLU after the residual add (apply_act4 leaves this code alone)
   if (a.out_nchw) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (n + r < a.Cout) {
         const size_t o = (((size_t)b * a.Cout + n + r) * a.Hout + oy) * a.Wout + ox;
-        a.out[o] = v[r] + (a.res ? a.res[o] : 0.f);
+        const float t = v[r] + (a.res ? a.res[o] : 0.f);
+        a.out[o] = post ? fmaxf(t, 0.f) : t;
       }
   } else if (a.pixel_shuffle) {
     // out[b, 2*oy+dy, 2*ox+dx, c] = conv[b, oy, ox, c*4 + dy*2 + dx]; the lane's 4 channels are one c
@@ -106,10 +108,14 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, floa
         const float4 rs = *reinterpret_cast<const float4*>(a.res + o);
         q.x += rs.x; q.y += rs.y; q.z += rs.z; q.w += rs.w;
       }
+      if (post) { q.x = fmaxf(q.x, 0.f); q.y = fmaxf(q.y, 0.f); q.z = fmaxf(q.z, 0.f); q.w = fmaxf(q.w, 0.f); }
       *reinterpret_cast<float4*>(a.out + o) = q;
     } else {
       for (int r = 0; r < 4; ++r)
-        if (n + r < a.Cout) a.out[o + r] = v[r] + (a.res ? a.res[o + r] : 0.f);
+        if (n + r < a.Cout) {
+          const float t = v[r] + (a.res ? a.res[o + r] : 0.f);
+          a.out[o + r] = post ? fmaxf(t, 0.f) : t;
+        }
     }
   }
 }

@@ -12,34 +12,37 @@ namespace {
 //   S^T  = K Q^T    : A = K rows (key), B = Q rows (query)  -> lane (lr,kq) holds S[query lr][keys 16 kt + 4 kq + r]
 //   O^T += V^T P^T  : A = V^T rows (d), B = P -- the D layout of S^T is exactly the B-operand layout (k = key), no shuffle
 // Online softmax per query column: running max / sum live replicated in the 4 kq lanes of a query.
-__global__ __launch_bounds__(256) void k_mha32(const float* __restrict__ qkv, float* __restrict__ out, int L, int H, float scale) {
-  constexpr int LDKs = 36, LDV = 68;
+template <int D>      // head dim: 32 (TBSRN FeatureEnhancer) or 64 (VisionLAN encoder, modules.py:43-81)
+__global__ __launch_bounds__(256) void k_mha(const float* __restrict__ qkv, float* __restrict__ out, int L, int H, float scale) {
+  constexpr int LDKs = D + 4, LDV = 68, DC = D / 16;
   __shared__ __attribute__((aligned(16))) float Ks[64 * LDKs];
-  __shared__ __attribute__((aligned(16))) float Vt[32 * LDV];
+  __shared__ __attribute__((aligned(16))) float Vt[D * LDV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, kq = lane >> 4;
   const int h = blockIdx.y, b = blockIdx.z;
-  const int ld = 3 * H * 32;
+  const int ld = 3 * H * D;
   const float* base = qkv + (size_t)b * L * ld;
   const int qrow = blockIdx.x * 64 + wave * 16 + lr;
-  f32x4 qf[2];
+  f32x4 qf[DC];
 #pragma unroll
-  for (int c = 0; c < 2; ++c) {
-    qf[c] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + h * 32 + c * 16 + kq * 4);
+  for (int c = 0; c < DC; ++c) {
+    qf[c] = *reinterpret_cast<const f32x4*>(base + (size_t)qrow * ld + h * D + c * 16 + kq * 4);
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[c][s] *= scale;
   }
   float m_run = -1e30f, l_run = 0.f;
-  f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  f32x4 o[DC];
+#pragma unroll
+  for (int c = 0; c < DC; ++c) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
   for (int k0 = 0; k0 < L; k0 += 64) {
     __syncthreads();
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
+    for (int p = 0; p < D / 16; ++p) {
       const int idx = tid + p * 256;
-      const int key = idx >> 3, c4 = (idx & 7) * 4;
-      const float* row = base + (size_t)(k0 + key) * ld + h * 32 + c4;
-      const float4 kv = *reinterpret_cast<const float4*>(row + H * 32);
-      const float4 vv = *reinterpret_cast<const float4*>(row + 2 * H * 32);
+      const int key = idx / (D / 4), c4 = (idx % (D / 4)) * 4;
+      const float* row = base + (size_t)(k0 + key) * ld + h * D + c4;
+      const float4 kv = *reinterpret_cast<const float4*>(row + H * D);
+      const float4 vv = *reinterpret_cast<const float4*>(row + 2 * H * D);
       *reinterpret_cast<float4*>(&Ks[key * LDKs + c4]) = kv;
       Vt[(c4 + 0) * LDV + key] = vv.x; Vt[(c4 + 1) * LDV + key] = vv.y;
       Vt[(c4 + 2) * LDV + key] = vv.z; Vt[(c4 + 3) * LDV + key] = vv.w;
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256) void k_mha32(const float* __restrict__ qkv, fl
     for (int kt = 0; kt < 4; ++kt) {
       s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < DC; ++c) {
         const f32x4 kf = *reinterpret_cast<const f32x4*>(&Ks[(kt * 16 + lr) * LDKs + c * 16 + kq * 4]);
 #pragma unroll
         for (int st = 0; st < 4; ++st) s[kt] = mfma16(kf[st], qf[c][st], s[kt]);
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256) void k_mha32(const float* __restrict__ qkv, fl
     l_run = l_run * corr + psum;
     m_run = m_new;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
+    for (int dt = 0; dt < DC; ++dt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[dt][r] *= corr;
 #pragma unroll
@@ -87,9 +90,9 @@ __global__ __launch_bounds__(256) void k_mha32(const float* __restrict__ qkv, fl
     }
   }
   const float inv = 1.0f / l_run;
-  float* orow = out + ((size_t)b * L + qrow) * (H * 32) + h * 32 + kq * 4;
+  float* orow = out + ((size_t)b * L + qrow) * (H * D) + h * D + kq * 4;
 #pragma unroll
-  for (int dt = 0; dt < 2; ++dt)
+  for (int dt = 0; dt < DC; ++dt)
     *reinterpret_cast<float4*>(orow + dt * 16) = make_float4(o[dt][0] * inv, o[dt][1] * inv, o[dt][2] * inv, o[dt][3] * inv);
 }
 
@@ -119,10 +122,18 @@ __global__ __launch_bounds__(256) void k_ln_std(const float* __restrict__ x, con
 
 extern "C" {
 
+int dpmn_mha64_f32(const float* qkv, float* out, int B, int L, int heads, float scale, dpmn_stream_t stream) {
+  DPMN_REQUIRE(qkv && out && B > 0 && heads > 0 && L > 0 && L % 64 == 0, "mha64: L must be a multiple of 64 (d_k is 64)");
+  ProfScope prof(PT_MHA32, as_stream(stream), 4.0 * L * (double)L * 64 * heads * B, 4.0 * 4 * 64 * heads * (double)L * B);
+  hipLaunchKernelGGL((k_mha<64>), dim3(L / 64, heads, B), dim3(256), 0, as_stream(stream), qkv, out, L, heads, scale);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
 int dpmn_mha32_f32(const float* qkv, float* out, int B, int L, int heads, float scale, dpmn_stream_t stream) {
   DPMN_REQUIRE(qkv && out && B > 0 && heads > 0 && L > 0 && L % 64 == 0, "mha32: L must be a multiple of 64 (d_k is 32)");
   ProfScope prof(PT_MHA32, as_stream(stream), 4.0 * L * (double)L * 32 * heads * B, 4.0 * 4 * 32 * heads * (double)L * B);
-  hipLaunchKernelGGL(k_mha32, dim3(L / 64, heads, B), dim3(256), 0, as_stream(stream), qkv, out, L, heads, scale);
+  hipLaunchKernelGGL((k_mha<32>), dim3(L / 64, heads, B), dim3(256), 0, as_stream(stream), qkv, out, L, heads, scale);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

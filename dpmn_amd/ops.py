@@ -9,7 +9,8 @@ import torch
 from . import _abi
 from ._abi import dptr, lib, check, stream
 
-ACT = {"none": 0, "gelu": 1, "relu": 2, "leaky02": 3, "leaky001": 4, "mish": 5, "prelu": 6, "tanh": 7, "sigmoid": 8}
+ACT = {"none": 0, "gelu": 1, "relu": 2, "leaky02": 3, "leaky001": 4, "mish": 5, "prelu": 6, "tanh": 7, "sigmoid": 8,
+       "relu_post_res": 9}      # conv epilogue only: ReLU after the residual add
 
 
 def linear(x, w, bias=None, res1=None, res2=None, act="none", slope=0.0):
@@ -397,3 +398,70 @@ def psnr_ssim(x, y):
     out = torch.empty(2, device=x.device)
     check(lib.dpmn_psnr_ssim_f32(px, sx, py, sy, dptr(out), ws.data_ptr(), B, 3, H, W, stream()))
     return out[0], out[1]
+
+
+# ------------------------------------------------------------------ in-loop text prior (csrc/visionlan.hip)
+def mha64(qkv, B, L, heads, scale):
+    """VisionLAN MultiHeadAttention core (modules.py:43-81): qkv (B*L, 3*heads*64) rows [q|k|v] -> (B*L, heads*64)."""
+    out = torch.empty(B * L, heads * 64, device=qkv.device)
+    check(lib.dpmn_mha64_f32(dptr(qkv), dptr(out), B, L, heads, float(scale), stream()))
+    return out
+
+
+def layernorm(x, w, b, eps=1e-5):
+    """nn.LayerNorm over the last axis of (M, C), C in {64, 96, 192, 512}."""
+    y = torch.empty_like(x)
+    check(lib.dpmn_layernorm_f32(dptr(x), dptr(w), dptr(b), float(eps), dptr(y), x.shape[0], x.shape[1], stream()))
+    return y
+
+
+def act(x, kind):
+    y = torch.empty_like(x)
+    check(lib.dpmn_act_fwd_f32(dptr(x), dptr(y), ACT[kind], 0.0, x.numel(), stream()))
+    return y
+
+
+def vl_resize(img, out_h=64, out_w=256):
+    """parse_visionlan_data (base.py:473-478) for a batch: (B, >=3, H, W) -> NHWC (B, out_h, out_w, 4), channel 3 zero."""
+    B, _, H, W = img.shape
+    v, ptr, stride = _nchw_view(img)
+    out = torch.empty(B, out_h, out_w, 4, device=img.device)
+    check(lib.dpmn_vl_resize_f32(ptr, stride, dptr(out), B, H, W, out_h, out_w, stream()))
+    return out
+
+
+def vl_tokens(feat, pos_table):
+    B, Hf, Wf, Cc = feat.shape
+    tok = torch.empty(B, Hf * Wf, Cc, device=feat.device)
+    check(lib.dpmn_vl_tokens_f32(dptr(feat), dptr(pos_table), dptr(tok), B, Hf, Wf, Cc, stream()))
+    return tok
+
+
+def vl_pp_pool(scores, enc, w_vrm, b_vrm, n_steps):
+    B, L, Cc = enc.shape
+    n_class = w_vrm.shape[0]
+    logits = torch.empty(B, n_steps, n_class, device=enc.device)
+    check(lib.dpmn_vl_pp_pool_f32(dptr(scores), scores.shape[1], dptr(enc), dptr(w_vrm), dptr(b_vrm), dptr(logits), B, L, Cc, n_steps,
+                                  n_class, stream()))
+    return logits
+
+
+def vl_decode(logits, max_len=25):
+    B, n_steps, n_class = logits.shape
+    cls = torch.empty(B, max_len, dtype=torch.int32, device=logits.device)
+    length = torch.empty(B, dtype=torch.int32, device=logits.device)
+    check(lib.dpmn_vl_decode_i32(dptr(logits), cls.data_ptr(), length.data_ptr(), B, n_steps, n_class, max_len, stream()))
+    return cls, length
+
+
+def text_prior_compose(cls, length, atlas, advance, out_h, out_w):
+    """cls (B, max_len) int32, length (B) int32, atlas (2, n_glyph, GH, GW) float 0..255, advance (2, n_glyph) int32."""
+    B, max_len = cls.shape
+    _, n_glyph, GH, GW = atlas.shape
+    out = torch.empty(B, 2, out_h, out_w, device=atlas.device)
+    for t_ in (cls, length, advance):
+        if not (t_.is_cuda and t_.dtype == torch.int32 and t_.is_contiguous()):
+            raise _abi.DpmnError("dpmn_amd: text_prior_compose expects contiguous int32 CUDA index tensors")
+    check(lib.dpmn_text_prior_compose_f32(cls.data_ptr(), length.data_ptr(), dptr(atlas), advance.data_ptr(), dptr(out), B, max_len,
+                                          n_glyph, GH, GW, out_h, out_w, stream()))
+    return out

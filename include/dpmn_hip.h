@@ -27,7 +27,8 @@ enum { DPMN_OK = 0, DPMN_ERR_ARG = -1, DPMN_ERR_LAUNCH = -2, DPMN_ERR_WORKSPACE 
 
 /* activation codes (epilogues / conv prologues) */
 enum { DPMN_ACT_NONE = 0, DPMN_ACT_GELU = 1, DPMN_ACT_RELU = 2, DPMN_ACT_LEAKY02 = 3, DPMN_ACT_LEAKY001 = 4,
-       DPMN_ACT_MISH = 5, DPMN_ACT_PRELU = 6, DPMN_ACT_TANH = 7, DPMN_ACT_SIGMOID = 8 };
+       DPMN_ACT_MISH = 5, DPMN_ACT_PRELU = 6, DPMN_ACT_TANH = 7, DPMN_ACT_SIGMOID = 8,
+       DPMN_ACT_RELU_POST_RES = 9 /* conv epilogue only: ReLU applied AFTER the residual add (ResNet BasicBlock, VisionLAN resnet.py:34-36) */ };
 
 int dpmn_abi_version(void);
 const char* dpmn_last_error(void);
@@ -199,6 +200,27 @@ int dpmn_to_mask_f32(const float* img, long img_stride, float* out, int B, int H
  * fused into one GEMM by the caller), out (B*L, heads*32) = softmax(q k^T * scale) v per head over the L positions of an
  * image; L % 64 == 0.  layernorm_std: tbsrn.py:23-36, a2 * (x - mean) / (unbiased std + eps) + b2, C in {64,128,256}. */
 int dpmn_mha32_f32(const float* qkv, float* out, int B, int L, int heads, float scale, dpmn_stream_t stream);
+/* the same core with d_k = 64: VisionLAN's MultiHeadAttention (model/VisionLAN/modules/modules.py:43-81, 8 heads x 64, L = 256) */
+int dpmn_mha64_f32(const float* qkv, float* out, int B, int L, int heads, float scale, dpmn_stream_t stream);
+
+/* ------------------------------------------------------------------ in-loop text prior (visionlan.hip), SURVEY.md section 8(f)-1:
+ * replaces the per-image host loop of interfaces/super_resolution.py:174-199.
+ * vl_resize:   parse_visionlan_data (interfaces/base.py:473-478): img (B, >=3, H, W) planes with batch stride img_stride ->
+ *              uint8 quantisation, bilinear (half-pixel centres, edge clamp) to Ho x Wo, /255, stored NHWC with 4 channels (ch 3 = 0).
+ * vl_tokens:   MLM_VRM.forward (VisionLAN.py:70-75) + PositionalEncoding: NHWC features (B,Hf,Wf,C) -> (B, Wf*Hf, C), token w*Hf+h, + table.
+ * vl_pp_pool:  PP_layer.forward (modules.py:168-171) from the position scores on + Prediction.w_vrm (199-202):
+ *              scores (B*256, ld) [column n = step n], enc (B,256,512) -> logits (B, n_steps, n_class).
+ * vl_decode:   MLM_VRM.forward 107-126: cls (B, max_len) = first arg-max per step, length = first EOS (class 0) step + 1, else max_len.
+ * text_prior_compose: replaces utils/render_standard_text.py (pygame + cv2): the decoded string is laid out from a glyph atlas
+ *              (2 cases, n_glyph classes, GH x GW cells, per-glyph advance) and stretched bilinearly to (B, 2, Ho, Wo), values
+ *              rounded to integers 0..255 (quirk Q6).  Specification: oracle/visionlan.py compose_text_prior. */
+int dpmn_vl_resize_f32(const float* img, long img_stride, float* out_nhwc4, int B, int H, int W, int Ho, int Wo, dpmn_stream_t stream);
+int dpmn_vl_tokens_f32(const float* feat_nhwc, const float* pos_table, float* tokens, int B, int Hf, int Wf, int C, dpmn_stream_t stream);
+int dpmn_vl_pp_pool_f32(const float* scores, int ld_scores, const float* enc, const float* w_vrm, const float* b_vrm, float* logits,
+                        int B, int L, int C, int n_steps, int n_class, dpmn_stream_t stream);
+int dpmn_vl_decode_i32(const float* logits, int* cls, int* length, int B, int n_steps, int n_class, int max_len, dpmn_stream_t stream);
+int dpmn_text_prior_compose_f32(const int* cls, const int* length, const float* atlas, const int* advance, float* out, int B, int max_len,
+                                int n_glyph, int GH, int GW, int Ho, int Wo, dpmn_stream_t stream);
 int dpmn_layernorm_std_f32(const float* x, const float* a2, const float* b2, float eps, float* y, long M, int C,
                            dpmn_stream_t stream);
 /* rotation augmentation of the trainer (utils/util.py:37-58 torch_rotate_img; super_resolution.py:144-151, 358-365):
