@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--drop", type=float, default=0.0,
                     help="train mode: Dropout = attn_drop = DropPath rate (the reference README trains with 0.1; default 0)")
     ap.add_argument("--zero1", type=int, default=None, help="train mode, N > 1: 1 = reduce-scatter + sharded clip/Adam + all-gather (default), 0 = all-reduce")
+    ap.add_argument("--prior", default="synthetic", choices=["synthetic", "visionlan"],
+                    help="branch-1 text priors: precomputed synthetic tensors (default) or the in-loop batched VisionLAN + glyph-atlas "
+                         "pipeline inside the timed step (BASELINE.json configs[3]: 'VisionLAN text-prior branch enabled')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="images in the CPU-baseline sample (default: the per-GPU batch)")
@@ -201,6 +204,11 @@ def main():
 
             def step():   # noqa: F811  (same batch every step, like the eager path of this bench)
                 return run(inp["images_lr"], inp["images_hr"], inp.get("label_vecs"), inp["text_priors"])
+    elif args.prior == "visionlan":
+        prior_fn = workload.build_text_prior(sr, b1)
+
+        def step():
+            return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_prior_fn=prior_fn)
     else:
         def step():
             return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
@@ -254,7 +262,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s: %s, %s" % (
                 args.workload, spec["text"],
-                "forward-only" if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"
+                ("forward-only" + (", in-loop VisionLAN + glyph-atlas text priors" if args.prior == "visionlan" else "")) if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"
                 + (", dropout/attn_drop/drop_path %g" % args.drop if args.drop else "")),
                 "per_gpu_batch": B, "global_batch": B * world, "ranks": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
                 "parallelism": ("dp%d (independent batch shards, no forward collective)" % world) if args.mode == "fwd" else
@@ -276,7 +284,7 @@ def main():
                     "timing": "HIP events around each of the %d launches of this family inside the timed steps, on the launch stream" % live[0]["launches"]}
         line["roofline"] = roof
         line["kernels"] = kernels
-        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.mode != "fwd") else cpu_baseline(args.workload, args.cpu_sample or B)   # N=1 only
+        line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.mode != "fwd") else cpu_baseline(args.workload, args.cpu_sample or B) if args.prior == "synthetic" else None   # N=1 only
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

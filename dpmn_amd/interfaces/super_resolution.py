@@ -50,6 +50,21 @@ class TextSR(base.TextBase):
         models.append(cmm)
         return models, psn
 
+    def recogniser_text_prior(self, n=None, path=None):
+        """The reference's branch-1 prior source (super_resolution.py:100-111, 174-199): one VisionLAN per stage, driving the
+        batched GPU pipeline of interfaces/text_prior.py.  path: visionlan.pth-style checkpoint (--rec_path); None leaves the
+        constructor's initialisation, like VisionLAN_init with init_state_dict None (base.py:452-471)."""
+        from .text_prior import VisionLANTextPrior, build_recognizers
+        n = self.args.stu_iter_b1 if n is None else n
+        recs = build_recognizers(n, self.device, path if path is not None else self.rec_path)
+        return VisionLANTextPrior(recs, self.device, font_path=getattr(self.args, "font_path", None))
+
+    def default_text_prior(self):
+        """--synthetic_prior (ours): seeded uint8-valued noise priors; otherwise the recogniser-driven prior (--tpg visionlan)."""
+        if getattr(self.args, "synthetic_prior", True) or getattr(self.args, "tpg", "visionlan") != "visionlan":
+            return self.synthetic_text_prior()
+        return self.recogniser_text_prior()
+
     @staticmethod
     def synthetic_text_prior(seed=2):
         def fn(cascade, k):
@@ -101,7 +116,7 @@ class TextSR(base.TextBase):
         from ..utils.util import str_filt
         for m in model_list:
             m.eval()
-        fn = text_prior_fn or self.synthetic_text_prior()
+        fn = text_prior_fn or self.default_text_prior()
         psnr, ssim, n = [], [], 0
         n_correct, n_labelled = 0, 0
         for data in val_loader:
@@ -261,7 +276,7 @@ class TextSR(base.TextBase):
         if getattr(self, "rank_seed", None) is not None:      # models are built (and broadcast): now diverge the per-rank RNG
             from ..utils.util import set_seed
             set_seed(self.rank_seed)
-        fn = self.synthetic_text_prior()
+        fn = self.default_text_prior()
         if loader is None:
             raise RuntimeError("dpmn_amd: pass a loader of (images_hr, images_lr, label_vecs) batches")
         cfg = self.config.TRAIN

@@ -49,7 +49,7 @@ def make_args(arch, b1, b2, batch, drop=0, dim=96, windows=(2, 4, 8)):
         arch=arch, test=False, test_data_dir=None, batch_size=batch, resume=None, vis_dir=None, rec="aster", mask=True,
         gradient=True, hd_u=32, srb=5, STN=False, patch_size=rep(2), embed_dim=rep(dim), window_size=rep(",".join(map(str, windows))),
         depths=rep(1), num_heads=rep(6), mlp_ratio=rep(4), drop_rate=rep(drop), attn_drop_rate=rep(drop), drop_path_rate=rep(drop),
-        rotate_train=0.0, rotate_test=0.0, stu_iter_b1=b1, stu_iter_b2=b2, tpg="visionlan", rec_path=None, font_path=None,
+        rotate_train=0.0, rotate_test=0.0, stu_iter_b1=b1, stu_iter_b2=b2, tpg="visionlan", rec_path=None, font_path=None, synthetic_prior=True,
         sr_share=False, alpha=0.5, window_num=3)
 
 
@@ -82,6 +82,18 @@ def build(name, batch=None, seed=100, device=None, drop=0):
     inputs["text_priors"] = [torch.floor(synth.uniform("text_prior_%d" % k, (B, 2, h, w), 0.0, 256.0, 2)).to(dev)
                              for k in range(b1)]
     return sr, models, psn, inputs
+
+
+def build_text_prior(sr, b1, seed=400):
+    """The in-loop recogniser-driven text prior (config 3: "VisionLAN text-prior branch enabled") with synthetic recogniser
+    weights: b1 VisionLAN mirrors + the glyph atlas -> callable(cascade, k)."""
+    from .interfaces.text_prior import VisionLANTextPrior, build_recognizers
+    recs = build_recognizers(b1, sr.device)
+    for i, r in enumerate(recs):
+        sd = r.state_dict()
+        synth.synth_fill_(sd, seed=seed + i)
+        r.load_state_dict(sd)
+    return VisionLANTextPrior(recs, sr.device)
 
 
 def state_dicts_cpu(models, psn):

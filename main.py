@@ -102,6 +102,8 @@ if __name__ == '__main__':
     parser.add_argument('--sr_share', action='store_true', default=False)
     parser.add_argument('--alpha', type=float, default=0.5)
     parser.add_argument('--window_num', type=int, default=3)
+    parser.add_argument('--synthetic_prior', action='store_true', default=False,
+                        help='seeded noise text priors instead of the VisionLAN + glyph-atlas prior of --tpg visionlan')
     parser.add_argument('--synthetic_steps', type=int, default=20, help='number of synthetic batches to run (no dataset reader here)')
     args = parser.parse_args()
     config_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'config', 'super_resolution.yaml')
