@@ -58,6 +58,30 @@ class TextBase(object):
         self.attn_drop_rate = parse_list(self.args.attn_drop_rate)
         self.drop_path_rate = parse_list(self.args.drop_path_rate)
 
+    # ------------------------------------------------------------------ data (base.py:85-125)
+    def _loader(self, dirs, test, shuffle, drop_last):
+        from ..dataset import textzoom as tz
+        cfg = self.config.TRAIN
+        sets = [tz.lmdbDataset_real(root=d, voc_type=cfg.voc_type, max_len=cfg.max_len, test=test) for d in dirs]
+        ds = torch.utils.data.ConcatDataset(sets)
+        loader = torch.utils.data.DataLoader(
+            ds, batch_size=self.batch_size, shuffle=shuffle, num_workers=int(cfg.workers), pin_memory=True, drop_last=drop_last,
+            collate_fn=tz.alignCollate_realWTLAMask(imgH=cfg.height, imgW=cfg.width, down_sample_scale=cfg.down_sample_scale, mask=self.mask))
+        return ds, loader
+
+    def get_train_data(self):
+        cfg = self.config.TRAIN
+        if not isinstance(cfg.train_data_dir, list):
+            raise TypeError('check trainRoot')
+        return self._loader(cfg.train_data_dir, False, True, True)
+
+    def get_val_data(self):
+        pairs = [self.get_test_data(d) for d in self.config.TRAIN.VAL.val_data_dir]
+        return [p[0] for p in pairs], [p[1] for p in pairs]
+
+    def get_test_data(self, dir_):
+        return self._loader([dir_], True, True, False)
+
     def generator_init(self, iter=0, mode=True, psn=False, hidden_size=64, testing=False):
         cfg = self.config.TRAIN
         kw = dict(scale_factor=self.scale_factor, width=cfg.width, height=cfg.height, STN=self.args.STN, mask=self.mask,

@@ -56,7 +56,12 @@ def main(config, args):
         if rank == 0 and not os.path.exists(result_path):
             with open(result_path, "w+") as out:
                 csv.writer(out).writerow(["recognizer", "subset", "accuracy", "psnr", "ssim"])
-        res = mission.test(synthetic_loader(bs, args.synthetic_steps, 1000 + rank))
+        if args.test_data_dir and os.path.isdir(args.test_data_dir):       # a TextZoom LMDB directory (needs the lmdb package)
+            from dpmn_amd.dataset.textzoom import sr_batches
+            loader = sr_batches(mission.get_test_data(args.test_data_dir)[1])
+        else:
+            loader = synthetic_loader(bs, args.synthetic_steps, 1000 + rank)
+        res = mission.test(loader)
         if rank == 0:
             with open(result_path, "a") as out:
                 csv.writer(out).writerow([args.rec, "synthetic", res["accuracy"], res["psnr_avg"], res["ssim_avg"]])
@@ -66,7 +71,13 @@ def main(config, args):
         if rank == 0 and not os.path.exists(log_path):
             with open(log_path, "w+") as out:
                 csv.writer(out).writerow(["epoch", "dataset", "accuracy", "psnr_avg", "ssim_avg", "best", "best_sum"])
-        mission.train(synthetic_loader(bs, args.synthetic_steps, 2000 + rank))
+        dirs = config.TRAIN.train_data_dir or []
+        if dirs and all(os.path.isdir(d) for d in dirs):                   # TextZoom LMDBs from the config, like base.py:85-103
+            from dpmn_amd.dataset.textzoom import sr_batches
+            loader = sr_batches(mission.get_train_data()[1])
+        else:
+            loader = synthetic_loader(bs, args.synthetic_steps, 2000 + rank)
+        mission.train(loader, steps=args.synthetic_steps if not dirs else None)
 
 
 if __name__ == '__main__':
