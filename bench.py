@@ -170,7 +170,8 @@ def main():
         raise SystemExit("bench.py: %d ranks need %d GPUs, this node has %d" % (world, world, ndev))
     local = local % max(1, ndev) if backend != "nccl" else local
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dist = os.environ.get("DPMN_FORCE_DIST") == "1"      # exercise the RCCL code path on one GPU (world size 1)
+    if world > 1 or (force_dist and "RANK" in os.environ):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -193,7 +194,8 @@ def main():
             m.train()
             for p in m.parameters():
                 p.requires_grad = True
-        trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=world, zero1=args.zero1)
+        trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=world, zero1=args.zero1,
+                          force_collectives=force_dist and dist.is_initialized())
 
         def step():
             return sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
@@ -227,7 +229,7 @@ def main():
         else:
             step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     if profiling and dominant:
@@ -236,12 +238,12 @@ def main():
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     live = _abi.profile_end() if (profiling and dominant) else []
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -286,7 +288,7 @@ def main():
         line["kernels"] = kernels
         line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.mode != "fwd") else cpu_baseline(args.workload, args.cpu_sample or B) if args.prior == "synthetic" else None   # N=1 only
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

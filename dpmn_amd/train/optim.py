@@ -161,10 +161,11 @@ class FlatBucket:
 class CommGroup:
     """Several buckets adjacent in the arenas, exchanged with one collective."""
 
-    def __init__(self, buckets, world=1, pg=None, zero1=False, arena=None):
+    def __init__(self, buckets, world=1, pg=None, zero1=False, arena=None, force=False):
         self.buckets = buckets
-        self.world, self.pg, self.zero1 = world, pg, bool(zero1) and world > 1
-        self.rank = dist.get_rank(pg) if world > 1 else 0
+        self.multi = world > 1 or force          # force: issue the collectives even at world size 1
+        self.world, self.pg, self.zero1 = world, pg, bool(zero1) and self.multi
+        self.rank = dist.get_rank(pg) if self.multi else 0
         if arena is None:      # stand-alone bucket: its own storage is the group's range (no padding to `world` needed)
             assert len(buckets) == 1 and not self.zero1
             self.flat_p, self.flat_g = buckets[0].flat_p, buckets[0].flat_g
@@ -206,7 +207,7 @@ class CommGroup:
 
     def launch(self):
         self.launched = True
-        if self.world <= 1:
+        if not self.multi:
             return
         avg = dist.ReduceOp.AVG
         self._post_scale = None
@@ -280,10 +281,12 @@ def broadcast_replicas(models, flat_p, pg=None):
 class Trainer:
     """zero_grad / gradient exchange / clip+Adam over a list of models, in the reference's order."""
 
-    def __init__(self, models, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=1, group=None, zero1=None, group_mb=6.0):
+    def __init__(self, models, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=1, group=None, zero1=None, group_mb=6.0,
+                 force_collectives=False):
         self.lr, self.beta1, self.max_norm = lr, beta1, max_norm
         self.world = world_size
-        zero1 = (world_size > 1) if zero1 is None else (bool(zero1) and world_size > 1)
+        multi = world_size > 1 or force_collectives      # force_collectives: run the RCCL calls at world size 1 (1-GPU box check)
+        zero1 = multi if zero1 is None else (bool(zero1) and multi)
         self.zero1 = zero1
         self.t = 0
         self.t_dev = None       # device-side step counter, see device_step_counter()
@@ -321,9 +324,10 @@ class Trainer:
                 self.buckets[i] = b
                 members.append(b)
                 o += sizes[i]
-            self.groups.append(CommGroup(members, world_size, group, zero1, arena=(self.flat_p[off:off + gs], self.flat_g[off:off + gs])))
+            self.groups.append(CommGroup(members, world_size, group, zero1, arena=(self.flat_p[off:off + gs], self.flat_g[off:off + gs]),
+                                         force=force_collectives))
             off += gs
-        if world_size > 1:
+        if multi:
             broadcast_replicas(models, self.flat_p, group)
 
     @staticmethod
