@@ -124,10 +124,14 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, floa
 // block.  The chunk is then decoded once, on scalars, and every tile load is a raw buffer load whose hardware range check
 // returns 0 for the lanes that fall outside the image (offset 0x80000000) or past Cout -- no predicated loads, i.e. no
 // branches whose joins make hipcc drain vmcnt(0) in front of the MFMA block.
-template <int BM, int BN, int WM, int WN, bool UNI = false>
+// BKT = k-chunk: 32, or 16 for the 128x128 tile (36.9 KB of LDS instead of 73.7: three resident blocks per CU instead of two, the
+// same trade the pointwise GEMM makes -- fewer MFMAs per barrier, but a third block to run while two wait)
+template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
-  constexpr int APASS = BM / 32, BPASS = (BN + 31) / 32;
+  constexpr int TPR = BKT / 4, RPP = 256 / TPR;          // threads per tile row, tile rows per pass
+  constexpr int APASS = BM / RPP, BPASS = (BN + RPP - 1) / RPP;
+  constexpr int BK = BKT, LDK = BKT + PAD;
   __shared__ __attribute__((aligned(16))) float Xs[2][BM * LDK];
   __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
 
@@ -136,13 +140,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   const PhaseSel ph = conv_select_phase(a, blockIdx.z);
   const int zsplit = ph.zsplit;
   const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
-  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  const int lrow = tid / TPR, lcol = (tid % TPR) * 4;
 
   // per-thread pixel rows of the A tile
   int pb[APASS], py[APASS], px[APASS];
 #pragma unroll
   for (int p = 0; p < APASS; ++p) {
-    const int m = m_blk + lrow + p * 32;
+    const int m = m_blk + lrow + p * RPP;
     if (m < M) {
       const int b = m / (a.Hp * a.Wp), r = m % (a.Hp * a.Wp);
       pb[p] = b;
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     }
 #pragma unroll
     for (int p = 0; p < BPASS; ++p) {
-      const int r = lrow + p * 32;
+      const int r = lrow + p * RPP;
       const int n = n_blk + r;
       wr[p] = (r < BN && n < a.Cout) ? *reinterpret_cast<const float4*>(ph.w + (size_t)n * a.Kp + k0 + lcol)
                                      : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   int u_tap = 0, u_c0 = 0, u_ky = 0, u_kx = 0, u_k0 = -1;
   int wofs[BPASS];
 #pragma unroll
-  for (int p = 0; p < BPASS; ++p) wofs[p] = ((n_blk + lrow + p * 32) * a.Kp + lcol) * 4;      // + k0 * 4 through the scalar offset
+  for (int p = 0; p < BPASS; ++p) wofs[p] = ((n_blk + lrow + p * RPP) * a.Kp + lcol) * 4;      // + k0 * 4 through the scalar offset
   auto gload_uni = [&](int k0) {
     if (k0 == u_k0 + BK) {                 // the next chunk (the common case)
       u_c0 += BK;
@@ -248,8 +252,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     }
 #pragma unroll
     for (int p = 0; p < BPASS; ++p) {
-      const int r = lrow + p * 32;
-      if (BN % 32 == 0 || r < BN)       // rows past Cout are beyond num_records: the range check returns 0
+      const int r = lrow + p * RPP;
+      if (BN % RPP == 0 || r < BN)       // rows past Cout are beyond num_records: the range check returns 0
         wr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wofs[p], k0 * 4, 0));
     }
   };
@@ -269,11 +273,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
           v.z = apply_act(v.z, a.pro_act, 0.f); v.w = apply_act(v.w, a.pro_act, 0.f);
         }
       }
-      *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * 32) * LDK + lcol]) = v;
+      *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * RPP) * LDK + lcol]) = v;
     }
 #pragma unroll
     for (int p = 0; p < BPASS; ++p)
-      if (lrow + p * 32 < BN) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * 32) * LDK + lcol]) = wr[p];
+      if (lrow + p * RPP < BN) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * RPP) * LDK + lcol]) = wr[p];
   };
 
   const int wm = wave % WM, wn = wave / WM;
@@ -878,7 +882,9 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   {
     // split-K launches additionally move S partial-sum slabs (written here, read by the reduce kernel): not algorithmic
     ProfScope prof(BN == 128 ? PT_CONV_IGEMM_128 : (BN == 64 ? PT_CONV_IGEMM_64 : PT_CONV_IGEMM_NARROW), st, conv_flops(a), conv_bytes(a));
-    if (uni) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
+    static const int bk16 = getenv("DPMN_CONV_BK16") ? atoi(getenv("DPMN_CONV_BK16")) : 0;
+  if (uni && BM == 128 && BN == 128 && bk16) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 16>), grid, dim3(256), 0, st, a);
+  else if (uni) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
   }
   DPMN_CHECK_LAUNCH();
