@@ -133,17 +133,12 @@ constexpr int WS_BM = 32, WS_BN = 96;
 // straight-line code: three unconditional float4 stores per lane.  With no branch between a tile's loads, its stores and
 // the next tile's loads, hipcc counts its vmcnt waits instead of draining to 0 at the top of every tile -- on gfx9 stores
 // count on vmcnt too, so the drain also waited for the previous tile's stores to reach memory.
-// LNF: the LayerNorm prologue folded behind the MFMAs (see k_gemm_wstat): acc = W' x_raw; y = rstd * acc - rstd * mean * rowsum(W') + b'
-// with (mean, rstd) of the lane's token row read from `stat`, cw4 = the lane's rowsum(W') values, bias4 = b'.
-template <int EPI, bool LNF = false>
+template <int EPI>
 __device__ __forceinline__ void epilogue_fast(f32x4 (&acc)[3][1], int m0, int n0, int ldy, float* y, const float4 (&bias4)[3],
-                                              const float* res1, const float* res2, float* red, int bn_cols, int n_block0,
-                                              const float4* cw4 = nullptr, const float* stat = nullptr) {
+                                              const float* res1, const float* res2, float* red, int bn_cols, int n_block0) {
   const int lane = threadIdx.x & 63;
   const int lm = lane & 15, lq = lane >> 4;
   const size_t off = (size_t)(m0 + lm) * ldy + n0 + lq * 4;
-  float ln_r = 1.f, ln_nm = 0.f;
-  if (LNF) { const float2 st2 = *reinterpret_cast<const float2*>(stat + 2 * lm); ln_r = st2.y; ln_nm = -st2.x * st2.y; }
   float4 r1[3], r2[3];
   if (EPI == 3 || EPI == 5) {         // 3: both residuals (SwinTransformerBlock shortcut + SKConv feats, pgrm.py:96,329); 5: one
 #pragma unroll
@@ -156,11 +151,6 @@ __device__ __forceinline__ void epilogue_fast(f32x4 (&acc)[3][1], int m0, int n0
   for (int nt = 0; nt < 3; ++nt) {
     const float4 b4 = bias4[nt];      // the lane's 12 bias values, loaded once per block
     float v[4] = {acc[nt][0][0] + b4.x, acc[nt][0][1] + b4.y, acc[nt][0][2] + b4.z, acc[nt][0][3] + b4.w};
-    if (LNF) {
-      const float4 c4 = cw4[nt];
-      v[0] = fmaf(acc[nt][0][0], ln_r, fmaf(ln_nm, c4.x, b4.x)); v[1] = fmaf(acc[nt][0][1], ln_r, fmaf(ln_nm, c4.y, b4.y));
-      v[2] = fmaf(acc[nt][0][2], ln_r, fmaf(ln_nm, c4.z, b4.z)); v[3] = fmaf(acc[nt][0][3], ln_r, fmaf(ln_nm, c4.w, b4.w));
-    }
     if (EPI == 2) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
@@ -192,13 +182,6 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
   float* Xs = Ws + BN * LDK;              // [2][BM][LDK]
   float* red = Xs + WSTAT_NBUF * BM * LDK;   // [4][BN] colsum scratch
   float* lng = red + (TH / 64) * BN;      // [K] LayerNorm gamma, [K] beta   (red: one row of BN column sums per wave)
-  // LayerNorm folded behind the MFMAs (interior tiles with the straight-line bias / bias + GELU epilogues): gamma goes into the
-  // staged weights (W' = W diag(gamma), b' = b + W beta), the tiles are staged RAW with only their row statistics computed, and
-  // the epilogue applies y = rstd * (W' x) - rstd * mean * rowsum(W') + b'.  Per element this replaces the normalise-and-affine
-  // arithmetic and two LDS reads of the prologue by nothing; the vector ALU shares its issue with the fp32 matrix pipe.
-  constexpr bool LNFOLD = PRO == PRO_LN && FULL && (EPI == 1 || EPI == 2);
-  float* lnstat = lng + 2 * K;            // [2][BM][2] (mean, rstd) of the rows of the tile in Xs, by step parity
-  float* lncw = lnstat + 4 * BM;          // [BN] rowsum(W'), [BN] b'
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_blk = blockIdx.y * BN;
@@ -293,12 +276,8 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
       for (int i = 0; i < VPT * 4; ++i) { const float d = vals[i] - mean; q += d * d; }
       q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
       const float rstd = 1.0f / sqrtf(q * (1.0f / K) + p.eps);
-      if constexpr (LNFOLD) {
-        if (spart == 0) *reinterpret_cast<float2*>(lnstat + (buf & 1) * 2 * BM + 2 * srow) = make_float2(mean, rstd);
-      } else {
 #pragma unroll
-        for (int i = 0; i < VPT * 4; ++i) vals[i] = (vals[i] - mean) * rstd * lng[scol + i] + lng[K + scol + i];
-      }
+      for (int i = 0; i < VPT * 4; ++i) vals[i] = (vals[i] - mean) * rstd * lng[scol + i] + lng[K + scol + i];
     }
 #pragma unroll
     for (int v = 0; v < VPT; ++v)
@@ -323,28 +302,6 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
     if (tile + stride < tiles) issue(rawB, tile + stride);
   }
   __syncthreads();                       // Ws / lng visible
-  float4 cw4[3] = {};
-  if constexpr (LNFOLD) {
-    if (tid < BN) {
-      float* wrow = Ws + tid * LDK;
-      float cw = 0.f, bf = e.bias ? e.bias[n_blk + tid] : 0.f;
-      for (int k = 0; k < K; ++k) {
-        const float wv_ = wrow[k];
-        bf = fmaf(wv_, lng[K + k], bf);
-        const float wg = wv_ * lng[k];
-        cw += wg;
-        wrow[k] = wg;
-      }
-      lncw[tid] = cw;
-      lncw[BN + tid] = bf;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < 3; ++nt) {
-      cw4[nt] = *reinterpret_cast<const float4*>(lncw + wn * 48 + nt * 16 + kq * 4);
-      bias4[nt] = *reinterpret_cast<const float4*>(lncw + BN + wn * 48 + nt * 16 + kq * 4);
-    }
-  }
   if (FULL) {
     commit(rawA, tile, 0);
     issue(rawA, min(tile + 2 * stride, tiles - 1));
@@ -390,8 +347,7 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
       if (tile + 3 * stride < tiles) issue(RAWN, tile + 3 * stride);                                         \
     }                                                                                                        \
     if constexpr (EPI != 0) {                                                                                \
-      WSTAT_EPI_GUARD epilogue_fast<EPI, LNFOLD>(acc, tile * BM + wm * 16, n_blk + wn * 48, ldy, y, bias4, e.res1, e.res2, red, BN, n_blk, \
-                                                 cw4, lnstat + (buf & 1) * 2 * BM + 2 * (wm * 16)); \
+      WSTAT_EPI_GUARD epilogue_fast<EPI>(acc, tile * BM + wm * 16, n_blk + wn * 48, ldy, y, bias4, e.res1, e.res2, red, BN, n_blk); \
     } else {                                                                                                 \
       WSTAT_EPI_GUARD epilogue<3, 1, FULL>(acc, tile * BM + wm * 16, n_blk + wn * 48, M, N, ldy, y, e, red, BN, n_blk); \
     }                                                                                                        \
@@ -641,7 +597,7 @@ template <int K, int PRO, int TH, bool FULL = false, int EPI = 0>
 int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
                      const EpiArgs& e, hipStream_t st, int target_blocks) {
   constexpr int BM = TH / 8;
-  const size_t smem = (size_t)((WS_BN + WSTAT_NBUF * BM) * (K + PAD) + (TH / 64) * WS_BN + 2 * K + 4 * BM + 2 * WS_BN) * sizeof(float);
+  const size_t smem = (size_t)((WS_BN + WSTAT_NBUF * BM) * (K + PAD) + (TH / 64) * WS_BN + 2 * K) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_wstat<K, PRO, TH, FULL, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
