@@ -257,6 +257,40 @@ __global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wp,
   wp[idx] = v;
 }
 
+// All weight packs of a training step in ONE launch: block b finds its descriptor by binary search in the block prefix and packs
+// 1024 elements of it.  (The step re-packs ~135 weights -- forward, data-gradient and transposed variants -- because the
+// parameters changed; one launch each was 1.0 ms of 7 us launches.)
+struct PackDesc {
+  const float* w;
+  float* wp;
+  long s_co, s_ci, s_ky, s_kx, base, n_elems;
+  int Cout, Kp, K, cin, KW, co_lim, ci_lim, pad_;
+};
+__global__ __launch_bounds__(256) void k_conv_pack_multi(const PackDesc* __restrict__ descs, const int* __restrict__ block_prefix, int n_desc) {
+  int lo = 0, hi = n_desc - 1;                       // largest d with block_prefix[d] <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  const unsigned base_idx = (unsigned)(blockIdx.x - block_prefix[lo]) * 1024u;      // a pack has < 2^31 elements
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const unsigned idx = base_idx + u * 256 + threadIdx.x;
+    if (idx >= (unsigned)d.n_elems) return;
+    const int co = (int)(idx / (unsigned)d.Kp), k = (int)(idx - (unsigned)co * (unsigned)d.Kp);
+    float v = 0.f;
+    if (k < d.K && co < d.co_lim) {
+      const int tp = k / d.cin, ci = k - tp * d.cin;
+      if (ci < d.ci_lim) {
+        const int ty = tp / d.KW, tx = tp - ty * d.KW;
+        v = d.w[d.base + co * d.s_co + ci * d.s_ci + ty * d.s_ky + tx * d.s_kx];
+      }
+    }
+    d.wp[idx] = v;
+  }
+}
+
 // ---------------------------------------------------------------------------------- train-mode BatchNorm
 // stats (32,2,C) = slotted (sum, sumsq) over `count` values per channel (accumulated by the conv epilogue)
 __global__ void k_bn_finalize(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -564,6 +598,14 @@ int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int
   const long total = (long)Cout * Kp;
   hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, wp, Cout, Kp, K, cin, KW,
                      co_lim < Cout ? co_lim : Cout, ci_lim < cin ? ci_lim : cin, s_co, s_ci, s_ky, s_kx, base);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_conv_pack_multi_f32(const void* descs, const int* block_prefix, int n_desc, int n_blocks, dpmn_stream_t stream) {
+  DPMN_REQUIRE(descs && block_prefix && n_desc > 0 && n_blocks > 0, "conv_pack_multi: bad arguments");
+  hipLaunchKernelGGL(k_conv_pack_multi, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const PackDesc*>(descs),
+                     block_prefix, n_desc);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -95,19 +95,101 @@ def pack_bwd_data_generic(weight):
 # variants alike.  These build the same (Cout_p, Kp) packs as the functions above with ONE dpmn_conv_pack_f32 launch
 # each, reading the parameter's own storage through (s_co, s_ci, s_ky, s_kx, base) strides.  `c0`/`cs` select an
 # input-channel segment (concat inputs get one data-gradient conv per segment).
+class PackCache:
+    """Every pack a Trainer's step asks for, refreshed by ONE dpmn_conv_pack_multi_f32 launch per step.
+    The first request for a (weight, geometry) pair packs it with its own launch and registers it; from then on the first
+    request of a new step (Trainer.zero_grad -> new_step) re-packs ALL registered entries at once -- the parameters are final
+    for the whole step at that point (Adam ran at the end of the previous one) -- and later requests are dictionary hits.
+    Entries keep their output tensors, so a hipGraph capture of the step replays on stable addresses."""
+
+    def __init__(self, arena=None):
+        # only tensors that live in the trainer's parameter arena are cached: their address identifies the parameter for the
+        # whole run; a temporary (e.g. DistillModule's channel-padded weight copy) gets a new address every step
+        self.base = None if arena is None else arena.untyped_storage().data_ptr()
+        self.entries = {}          # key -> [out, weight, desc tuple]
+        self.order = []
+        self.epoch = 0             # current step
+        self.fresh = -1            # step whose parameters the packs hold
+        self.table = None          # (device descs, device prefix, n_blocks) or None when stale
+
+    def new_step(self):
+        self.epoch += 1
+
+    def _refresh(self):
+        import struct
+        from .._abi import lib, check, stream
+        if self.table is None:
+            raw, prefix, nb = bytearray(), [], 0
+            for key in self.order:
+                out, w, (cout_p, cin_p, kh, kw, co_lim, ci_lim, st) = self.entries[key]
+                K = kh * kw * cin_p
+                kp = out.shape[1]
+                raw += struct.pack("<2Q6q8i", w.data_ptr(), out.data_ptr(), st[0], st[1], st[2], st[3], st[4], cout_p * kp, cout_p, kp, K, cin_p,
+                                   kw, min(co_lim, cout_p), min(ci_lim, cin_p), 0)
+                prefix.append(nb)
+                nb += (cout_p * kp + 1023) // 1024
+            dev = self.entries[self.order[0]][0].device
+            descs = torch.frombuffer(raw, dtype=torch.uint8).to(dev)
+            self.table = (descs, torch.tensor(prefix, dtype=torch.int32, device=dev), nb)
+        descs, prefix, nb = self.table
+        check(lib.dpmn_conv_pack_multi_f32(descs.data_ptr(), prefix.data_ptr(), len(self.order), nb, stream()))
+        self.fresh = self.epoch
+
+    def get(self, key, w, geom, out):
+        from .._abi import lib, check, dptr, stream
+        e = self.entries.get(key)
+        if e is not None:
+            if self.fresh != self.epoch:
+                self._refresh()
+            return e[0]
+        cout_p, cin_p, kh, kw, co_lim, ci_lim, st = geom
+        kp = (kh * kw * cin_p + 31) // 32 * 32
+        wp = torch.empty(cout_p, kp, device=w.device) if out is None else out
+        check(lib.dpmn_conv_pack_f32(dptr(w), dptr(wp), cout_p, cin_p, kh, kw, co_lim, ci_lim, *st, stream()))
+        self.entries[key] = [wp, w, geom]
+        self.order.append(key)
+        self.table = None
+        return wp
+
+
+ACTIVE = None      # the PackCache of the Trainer whose step is running (train/optim.py), or None: pack per request
+
+
 def _gpu_pack(w, cout_p, cin_p, kh, kw, co_lim, ci_lim, st, out=None):
     from .._abi import lib, check, dptr, stream
     assert w.is_contiguous() and w.is_cuda
+    if ACTIVE is not None and w.untyped_storage().data_ptr() == ACTIVE.base:
+        key = (w.data_ptr(), cout_p, cin_p, kh, kw, co_lim, ci_lim, tuple(st))
+        return ACTIVE.get(key, w, (cout_p, cin_p, kh, kw, co_lim, ci_lim, tuple(st)), out)
     kp = (kh * kw * cin_p + 31) // 32 * 32
     wp = torch.empty(cout_p, kp, device=w.device) if out is None else out
     check(lib.dpmn_conv_pack_f32(dptr(w), dptr(wp), cout_p, cin_p, kh, kw, co_lim, ci_lim, *st, stream()))
     return wp
 
 
+def transposed(w):
+    """w (N, K) -> contiguous (K, N) for the data-gradient GEMMs (dx = dy . W): a pack with swapped strides, so that under a
+    PackCache all of a step's weight transposes ride in the step's single pack launch.  N must be a multiple of 32."""
+    n, k = w.shape
+    if ACTIVE is None or n % 32 != 0 or w.untyped_storage().data_ptr() != ACTIVE.base:
+        return w.t().contiguous()
+    return _gpu_pack(w, k, n, 1, 1, k, n, (1, k, 0, 0, 0))
+
+
 def _gpu_pack_phases(w, cout_p, cin_p, st_of_phase):
     """(4, Cout_p, Kp) phase-major pack for the fused ConvTranspose2d(4,2,1) launch (ops.convT_s2k4)."""
     kp = (4 * cin_p + 31) // 32 * 32
-    wp4 = torch.empty(4, cout_p, kp, device=w.device)
+    wp4 = None
+    cached = ACTIVE is not None and w.untyped_storage().data_ptr() == ACTIVE.base
+    if cached:      # the four phase packs are views of one cached tensor
+        wp4 = ACTIVE.entries.get((w.data_ptr(), "phases", cout_p, cin_p, st_of_phase(0, 0), st_of_phase(1, 1)))
+        if wp4 is not None:
+            wp4 = wp4[0]
+    fresh_alloc = wp4 is None
+    if fresh_alloc:
+        wp4 = torch.empty(4, cout_p, kp, device=w.device)
+        if cached:
+            ACTIVE.entries[(w.data_ptr(), "phases", cout_p, cin_p, st_of_phase(0, 0), st_of_phase(1, 1))] = [wp4, w, None]
     for py in range(2):
         for px in range(2):
             _gpu_pack(w, cout_p, cin_p, 2, 2, cout_p, cin_p, st_of_phase(py, px), out=wp4[2 * py + px])

@@ -312,6 +312,8 @@ class Trainer:
         total = sum(gsize)
         self.flat_p = torch.zeros(total, device=dev)
         self.flat_g = torch.zeros(total, device=dev)
+        from ..model.packing import PackCache
+        self.pack_cache = PackCache(self.flat_p)
         self.buckets = [None] * len(models)
         self.groups = []
         off = 0
@@ -339,11 +341,15 @@ class Trainer:
         return big + small + rest[::-1]
 
     def zero_grad(self):
+        from ..model import packing
         self.flat_g.zero_()
         for b in self.buckets:
             b.reset_step()
         for g in self.groups:
             g.launched = False
+        # weight packs / transposes of this step: one multi-descriptor launch at their first use (model/packing.py PackCache)
+        self.pack_cache.new_step()
+        packing.ACTIVE = self.pack_cache
 
     def device_step_counter(self):
         """Keep Adam's step count in device memory from now on, so that a hipGraph capture of the training step replays
@@ -371,8 +377,10 @@ class Trainer:
             g.v.copy_(v)
 
     def step(self):
+        from ..model import packing
         self.t += 1
         if self.t_dev is not None:
             self.t_dev.add_(1.0)
         for g in self.groups:
             g.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
+        packing.ACTIVE = None       # the packs are stale from here on

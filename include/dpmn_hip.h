@@ -349,6 +349,11 @@ int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp,
  * covers nn.Conv2d, flipped nn.ConvTranspose2d, the ConvTranspose2d(4,2,1) phases and every data-gradient re-pack */
 int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co, long s_ci,
                        long s_ky, long s_kx, long base, dpmn_stream_t stream);
+/* every pack of a training step in one launch: descs = device array of
+ *   { const float* w; float* wp; long s_co, s_ci, s_ky, s_kx, base, n_elems; int Cout, Kp, K, cin, KW, co_lim, ci_lim, pad; }
+ * (the arguments of dpmn_conv_pack_f32, n_elems = Cout * Kp), block_prefix[d] = first 1024-element block of descriptor d,
+ * n_blocks = total.  Built and cached by dpmn_amd/model/packing.py (PackCache). */
+int dpmn_conv_pack_multi_f32(const void* descs, const int* block_prefix, int n_desc, int n_blocks, dpmn_stream_t stream);
 /* packed (Cout,Kp) gradient -> += into the parameter layout (same stride convention as below); clear != 0 zeroes the
  * packed buffer afterwards so that a persistent workspace needs no memset before its next dpmn_conv2d_wgrad_f32 */
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
