@@ -126,8 +126,27 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, floa
 // branches whose joins make hipcc drain vmcnt(0) in front of the MFMA block.
 // BKT = k-chunk: 32, or 16 for the 128x128 tile (36.9 KB of LDS instead of 73.7: three resident blocks per CU instead of two, the
 // same trade the pointwise GEMM makes -- fewer MFMAs per barrier, but a third block to run while two wait)
-template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32>
+__device__ __forceinline__ float vmax_raw(float x, float y) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
+// SIMPLE (implies UNI): additionally no input affine on any segment, input activation in {none, ReLU, LeakyReLU(0.2)} and
+// at most 31 taps.  The in-image test of a (pixel row, tap) pair is then precomputed ONCE per block into a per-row tap
+// bitmask, the per-chunk address of a row is `voff[row] | bit31-if-outside` (2 vector instructions) with the tap / channel
+// part of the address in the buffer load's scalar offset, and the store to LDS needs no validity mask (act(0) = 0).
+template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  static_assert(!SIMPLE || UNI, "SIMPLE is a refinement of the UNI path");
+#ifndef DPMN_IGEMM_FENCE
+#define DPMN_IGEMM_FENCE 1
+#endif
+  constexpr bool SCHED_FENCE = DPMN_IGEMM_FENCE;
+#ifndef DPMN_IGEMM_ABLATE
+#define DPMN_IGEMM_ABLATE 0      // timing experiments only (tools/build_variants.sh): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no LDS reads
+#endif
+  constexpr int ABL = SIMPLE ? DPMN_IGEMM_ABLATE : 0;
   constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
   constexpr int TPR = BKT / 4, RPP = 256 / TPR;          // threads per tile row, tile rows per pass
   constexpr int APASS = BM / RPP, BPASS = (BN + RPP - 1) / RPP;
@@ -257,6 +276,87 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         wr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wofs[p], k0 * 4, 0));
     }
   };
+  // ---- SIMPLE path state
+  unsigned nok[APASS];       // bit t: tap t of this pixel row reads outside the image (or the row is beyond M)
+  int voff[APASS];           // byte offset of (pixel row, channel lcol) from the pad-shifted base, for the current segment
+  int s_seg = -1, s_segstart = 0;
+  __amdgpu_buffer_rsrc_t s_xrs;
+  // address = base + (pix + tapoff) * cs * 4 is split into a per-row vector part (pix + padoff >= 0) and a per-chunk scalar
+  // part (tapoff - minoff >= 0; minoff < 0 for the reversed taps, dil -1, of the transposed-conv phases) over a base
+  // shifted down by (padoff - minoff) pixels -- never dereferenced there, valid lanes land inside the tensor
+  const int padoff = ph.pad_y * a.Win + ph.pad_x;
+  const int minoff = (a.dil_y < 0 ? (a.KH - 1) * a.dil_y : 0) * a.Win + (a.dil_x < 0 ? (a.KW - 1) * a.dil_x : 0);
+  const int baseshift = padoff - minoff;
+  if (SIMPLE) {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      unsigned colm = 0, okb = 0;
+      for (int kx = 0; kx < a.KW; ++kx) colm |= ((unsigned)(px[p] + kx * a.dil_x) < (unsigned)a.Win ? 1u : 0u) << kx;
+      for (int ky = 0; ky < a.KH; ++ky)
+        if ((unsigned)(py[p] + ky * a.dil_y) < (unsigned)a.Hin) okb |= colm << (ky * a.KW);
+      nok[p] = ~okb;                                          // parked rows fail every test; bits >= KH*KW stay set
+    }
+  }
+  const __amdgpu_buffer_rsrc_t s_wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ph.w), 0, a.Cout * a.Kp * 4, 0x00020000);
+  auto gload_simple = [&](int k0) {
+    if (k0 == u_k0 + BK) {
+      u_c0 += BK;
+      if (u_c0 >= a.cin) { u_c0 = 0; ++u_tap; if (++u_kx == a.KW) { u_kx = 0; ++u_ky; } }
+    } else if (k0 != u_k0) {
+      u_tap = k0 / a.cin; u_c0 = k0 - u_tap * a.cin;
+      u_ky = u_tap / a.KW; u_kx = u_tap - u_ky * a.KW;
+    }
+    u_k0 = k0;
+    const int seg = u_c0 >= c01 ? 2 : (u_c0 >= a.cseg[0] ? 1 : 0);
+    const int cs = seg == 2 ? a.cseg[2] : (seg == 1 ? a.cseg[1] : a.cseg[0]);
+    if (seg != s_seg) {                                       // wave-uniform, once per segment change
+      s_seg = seg;
+      s_segstart = seg == 2 ? c01 : (seg == 1 ? a.cseg[0] : 0);
+      const float* src = seg == 2 ? a.in[2] : (seg == 1 ? a.in[1] : a.in[0]);
+      s_xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) - (ptrdiff_t)baseshift * cs, 0,
+                                                (a.B * a.Hin * a.Win + baseshift) * cs * 4, 0x00020000);
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) voff[p] = (__mul24(pix[p] + padoff, cs) + lcol) * 4;
+    }
+    // scalar, >= 0 (readfirstlane: keeps it in an SGPR -- a VGPR soffset makes hipcc emit a waterfall loop around every load)
+    const int soff = __builtin_amdgcn_readfirstlane(((u_ky * a.dil_y * a.Win + u_kx * a.dil_x - minoff) * cs + u_c0 - s_segstart) * 4);
+    const int sh = 31 - min(u_tap, 31);
+    if (ABL & 1) {
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) xr[p] = make_float4(1.f, 1.f, 1.f, (float)(soff + sh));
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p) wr[p] = make_float4(1.f, 1.f, 1.f, 1.f);
+      return;
+    }
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const unsigned off = ((nok[p] << sh) & 0x80000000u) | (unsigned)voff[p];
+      xr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_xrs, (int)off, soff, 0));
+    }
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) {
+      const int r = lrow + p * RPP;
+      if (BN % RPP == 0 || r < BN)
+        wr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_wrs, wofs[p], k0 * 4, 0));
+    }
+  };
+  auto sstore_simple = [&](int buf) {
+    // one v_max per element (fmaxf would first canonicalise both operands); ReLU = slope 0, none = skipped
+    if (a.pro_act != ACT_NONE) {
+      const float sl = a.pro_act == ACT_LEAKY02 ? 0.2f : 0.0f;
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) {
+        xr[p].x = vmax_raw(xr[p].x, sl * xr[p].x); xr[p].y = vmax_raw(xr[p].y, sl * xr[p].y);
+        xr[p].z = vmax_raw(xr[p].z, sl * xr[p].z); xr[p].w = vmax_raw(xr[p].w, sl * xr[p].w);
+      }
+    }
+    if ((ABL & 2) && xr[0].w != 12345.f) return;
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * RPP) * LDK + lcol]) = xr[p];
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p)
+      if (BN % RPP == 0 || lrow + p * RPP < BN) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * RPP) * LDK + lcol]) = wr[p];
+  };
   auto sstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
@@ -293,23 +393,32 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   const int kt0 = zsplit * cps;
   const int nk = min(nk_all, kt0 + cps);
   if (kt0 < nk) {
-    if (UNI) gload_uni(kt0 * BK); else gload(kt0 * BK);
-    sstore(0);
+    if (SIMPLE) { gload_simple(kt0 * BK); sstore_simple(0); }
+    else {
+      if (UNI) gload_uni(kt0 * BK); else gload(kt0 * BK);
+      sstore(0);
+    }
   }
   __syncthreads();
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = (kt - kt0) & 1;
-    if (UNI) gload_uni(min(kt + 1, nk - 1) * BK);      // unconditional: the refill past the end re-reads the last chunk
+    if (SIMPLE) gload_simple(min(kt + 1, nk - 1) * BK);
+    else if (UNI) gload_uni(min(kt + 1, nk - 1) * BK);      // unconditional: the refill past the end re-reads the last chunk
     else if (kt + 1 < nk) gload((kt + 1) * BK);
+    // hipcc otherwise sinks the buffer loads deep into the MFMA block (the last ones ~100 MFMAs down): they must be in
+    // flight for the WHOLE block to cover HBM / L2 latency before sstore waits for them
+    if (UNI && SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
     const float* xa = &Xs[buf][(wm * (MT * 16) + lr) * LDK + kq * 4];
     const float* wa = &Ws[buf][(wn * (NT * 16) + lr) * LDK + kq * 4];
 #pragma unroll
     for (int kc = 0; kc < BK; kc += 16) {
       f32x4 xf[MT], wf[NT];
 #pragma unroll
-      for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xa + j * 16 * LDK + kc);
+      for (int j = 0; j < MT; ++j)
+        if (ABL & 8) xf[j] = (f32x4){1.f, (float)kt, 1.f, 1.f}; else xf[j] = *reinterpret_cast<const f32x4*>(xa + j * 16 * LDK + kc);
 #pragma unroll
-      for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 16 * LDK + kc);
+      for (int i = 0; i < NT; ++i)
+        if (ABL & 8) wf[i] = (f32x4){1.f, (float)kt, 1.f, 1.f}; else wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 16 * LDK + kc);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -317,8 +426,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[i][s], xf[j][s], acc[i][j]);
     }
-    if (UNI || kt + 1 < nk) sstore(buf ^ 1);
-    __syncthreads();
+    if (SIMPLE) sstore_simple(buf ^ 1);
+    else if (UNI || kt + 1 < nk) sstore(buf ^ 1);
+    if (!(ABL & 4)) __syncthreads();
   }
 
   // ---- epilogue: lane holds out[pixel m = .. + (l&15)][co = .. + (l>>4)*4 + r]
@@ -594,13 +704,20 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
       stage_halo_direct(chunk);     // all reads of the previous chunk finished at the last barrier
       __syncthreads();
     }
+    // 3x3: the nine taps fully unrolled -- (ky, kx), the halo offsets of the B-operand reads and the weight-buffer parity become
+    // immediates instead of per-tap scalar / vector arithmetic (81 VALU + 81 SALU per 64-MFMA tap before; the vector ALU shares
+    // its issue with the fp32 matrix pipe).  T = 9 is odd, so the buffer parity of tap t is (chunk + t) & 1.
+    const float* hp0 = halo + (size_t)hb * NPX * LDK + ((MR * wave) * HW_ + lr) * LDK + kq * 4;
+    const float* wp0 = Wt + lr * LDK + kq * 4;
+    constexpr int TAP_UNROLL = KS == 3 ? 9 : 1;
+#pragma unroll TAP_UNROLL
     for (int tap = 0; tap < T; ++tap) {
       const bool lastt = tap == T - 1;
       if (!lastt) issue_w(chunk, tap + 1);
       else if (more) issue_w(chunk + 1, 0);
       const int ky = tap / KS, kx = tap % KS;
-      const float* hp = halo + (size_t)hb * NPX * LDK + ((MR * wave + ky) * HW_ + lr + kx) * LDK + kq * 4;
-      const float* wp = Wt + (size_t)wb * BN * LDK + lr * LDK + kq * 4;
+      const float* hp = hp0 + (ky * HW_ + kx) * LDK;
+      const float* wp = wp0 + (size_t)wb * BN * LDK;
 #pragma unroll
       for (int kc = 0; kc < BK; kc += 16) {
         f32x4 xf[MR];
@@ -883,7 +1000,13 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     // split-K launches additionally move S partial-sum slabs (written here, read by the reduce kernel): not algorithmic
     ProfScope prof(BN == 128 ? PT_CONV_IGEMM_128 : (BN == 64 ? PT_CONV_IGEMM_64 : PT_CONV_IGEMM_NARROW), st, conv_flops(a), conv_bytes(a));
     static const int bk16 = getenv("DPMN_CONV_BK16") ? atoi(getenv("DPMN_CONV_BK16")) : 0;
+    static const int simple_on = getenv("DPMN_CONV_SIMPLE") ? atoi(getenv("DPMN_CONV_SIMPLE")) : 1;
+    bool simple = simple_on && uni && a.KH * a.KW <= 31 && (a.pro_act == ACT_NONE || a.pro_act == ACT_RELU || a.pro_act == ACT_LEAKY02);
+    for (int i = 0; i < 3; ++i)      // + the pad shift of the buffer base must keep the byte range below 2^31
+      simple = simple && a.in_scale[i] == nullptr &&
+               ((size_t)a.B * a.Hin * a.Win + (size_t)(abs(a.pad_y) + a.KH * abs(a.dil_y) + 2) * a.Win) * a.cseg[i] * 4 < (1ull << 31);
   if (uni && BM == 128 && BN == 128 && bk16) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 16>), grid, dim3(256), 0, st, a);
+  else if (simple) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true>), grid, dim3(256), 0, st, a);
   else if (uni) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
   }
