@@ -123,6 +123,7 @@ SIGNATURES = {
     "dpmn_window_attn_drop_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_window_attn_drop_bwd_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_conv_pack_multi_f32": (_i, [fp, fp, _i, _i, fp]),
+    "dpmn_conv_pack_tile_shape": (_i, [_i, _i, _i, _l, _l, fp]),
     "dpmn_mha64_f32": (_i, [fp, fp, _i, _i, _i, _f, fp]),
     "dpmn_vl_resize_f32": (_i, [fp, _l, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_vl_tokens_f32": (_i, [fp, fp, fp, _i, _i, _i, _i, fp]),

@@ -220,75 +220,124 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
   }
 }
 
-// packed (Cout, Kp) gradient -> += into the parameter's layout, and clear the packed workspace for its next use
-__global__ void k_wgrad_unpack(float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Kp, int K, int cin, int KW, int co_lim,
-                               int ci_lim, long s_co, long s_ci, long s_ky, long s_kx, long base, int clear, int nslots) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long n = (long)Cout * Kp;
-  if (idx >= n) return;
-  const int co = (int)(idx / Kp), k = (int)(idx - (long)co * Kp);
-  float v = 0.f;
-  for (int s = 0; s < nslots; ++s) {
-    v += dwp[s * n + idx];
-    if (clear) dwp[s * n + idx] = 0.f;
-  }
-  if (k >= K || co >= co_lim) return;
-  const int tp = k / cin, ci = k - tp * cin;
-  if (ci >= ci_lim) return;
-  const int ty = tp / KW, tx = tp - ty * KW;
-  dw[base + co * s_co + ci * s_ci + ty * s_ky + tx * s_kx] += v;
-}
-
-// parameter layout -> packed (Cout_p, Kp), zero filled outside (co_lim, ci_lim, K): the inverse gather of k_wgrad_unpack.
-// One launch per conv per step replaces the permute / flip / cat / contiguous chain of the host-side packers.
-__global__ void k_conv_pack(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Kp, int K, int cin, int KW, int co_lim,
-                            int ci_lim, long s_co, long s_ci, long s_ky, long s_kx, long base) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)Cout * Kp) return;
-  const int co = (int)(idx / Kp), k = (int)(idx - (long)co * Kp);
-  float v = 0.f;
-  if (k < K && co < co_lim) {
-    const int tp = k / cin, ci = k - tp * cin;
-    if (ci < ci_lim) {
-      const int ty = tp / KW, tx = tp - ty * KW;
-      v = w[base + co * s_co + ci * s_ci + ty * s_ky + tx * s_kx];
-    }
-  }
-  wp[idx] = v;
-}
-
-// All weight packs of a training step in ONE launch: block b finds its descriptor by binary search in the block prefix and packs
-// 1024 elements of it.  (The step re-packs ~135 weights -- forward, data-gradient and transposed variants -- because the
-// parameters changed; one launch each was 1.0 ms of 7 us launches.)
+// ---------------------------------------------------------------------------------- parameter layout <-> packed (Cout, Kp)
+// Both directions are a transpose between the parameter's strided layout (w[base + co*s_co + ci*s_ci + ky*s_ky + kx*s_kx]) and
+// the packed rows wp[co][(ky*KW+kx)*cin + ci]: whichever side a thread-per-element kernel walks contiguously, the other side is
+// a 36..64-byte-strided gather / scatter (measured: 0.9 ms for one step's 240 MB of packs).  Here a block moves one
+// (co_t x ci_t x taps) tile through LDS: it walks the STRIDED side in that side's own memory order (order 0: tap fastest, then
+// ci, then co = nn.Conv2d; order 1: tap, then co, then ci = nn.ConvTranspose2d and the (N,K)->(K,N) transposes) and the packed
+// side ci-fastest, so both sides move in contiguous runs.
+constexpr int PK_LDS = 4608;      // floats: co_t * taps * (ci_t + 1) <= PK_LDS
 struct PackDesc {
   const float* w;
   float* wp;
   long s_co, s_ci, s_ky, s_kx, base, n_elems;
-  int Cout, Kp, K, cin, KW, co_lim, ci_lim, pad_;
+  int Cout, Kp, K, cin, KW, co_lim, ci_lim, co_t, ci_t, order, nci, pad_;
 };
+static_assert(sizeof(PackDesc) == 112, "PackDesc is mirrored by dpmn_amd/model/packing.py (struct format <2Q6q12i)");
+
+// tile shape for a (Cout, cin, taps) pack; shared by the host launchers and (through dpmn_conv_pack_tile_shape) by PackCache
+static void pack_tile_shape(int Cout, int cin, int taps, long s_co, long s_ci, int* co_t, int* ci_t, int* order) {
+  const long aco = s_co < 0 ? -s_co : s_co, aci = s_ci < 0 ? -s_ci : s_ci;
+  if (aco < aci) {            // co is the faster axis of the strided side
+    *order = 1;
+    int ct = cin < 32 ? cin : 32;
+    while (taps * (ct + 1) > PK_LDS && ct > 1) --ct;
+    int co = PK_LDS / (taps * (ct + 1));
+    co = co > 64 ? 64 : (co < 1 ? 1 : co);
+    *ci_t = ct; *co_t = co < Cout ? co : Cout;
+  } else {
+    *order = 0;
+    int ct = cin < 128 ? cin : 128;
+    while (taps * (ct + 1) > PK_LDS && ct > 1) --ct;
+    int co = (PK_LDS / 2) / (taps * (ct + 1));
+    co = co < 1 ? 1 : co;
+    *ci_t = ct; *co_t = co < Cout ? co : Cout;
+  }
+  // small weights: a full-size tile would leave a handful of blocks (a 96 -> 384 linear: 17), and the slotted unpack reads
+  // up to 32 copies per element -- trade tile size for blocks until the chip has work
+  auto blocks = [&]() { return ((Cout + *co_t - 1) / *co_t) * ((cin + *ci_t - 1) / *ci_t); };
+  while (blocks() < 512 && *co_t > 1) *co_t = (*co_t + 1) / 2;
+  while (blocks() < 512 && *ci_t > 32) *ci_t = (*ci_t + 1) / 2;
+}
+static int pack_tile_blocks(const PackDesc& d) { return ((d.Cout + d.co_t - 1) / d.co_t) * d.nci; }
+
+__device__ __forceinline__ int pk_div(int e, float rd) { return (int)(((float)e + 0.5f) * rd); }     // exact for e, e/d < 2^12
+
+// UNPACK = false: strided -> packed (zero fill outside co_lim / ci_lim / K).  UNPACK = true: sum of `nslots` packed copies
+// -> += into the strided layout, optionally clearing the packed copies.
+template <bool UNPACK>
+__device__ __forceinline__ void pack_tile(const PackDesc& d, int blk, float* lds, int nslots, int clear) {
+  const int co_blk = blk / d.nci, ci_blk = blk - co_blk * d.nci;
+  const int co0 = co_blk * d.co_t, ci0 = ci_blk * d.ci_t;
+  const int cot = min(d.co_t, d.Cout - co0), cit = min(d.ci_t, d.cin - ci0);
+  const int taps = d.K / d.cin;
+  const int n = cot * cit * taps, ldc = d.ci_t + 1;
+  const float r_taps = 1.0f / (float)taps, r_cit = 1.0f / (float)cit, r_cot = 1.0f / (float)cot, r_kw = 1.0f / (float)d.KW;
+  float* wp = d.wp;
+  auto strided_side = [&](int e, bool store) {
+    const int q = pk_div(e, r_taps), tap = e - q * taps;
+    int co_l, ci_l;
+    if (d.order == 0) { co_l = pk_div(q, r_cit); ci_l = q - co_l * cit; }
+    else { ci_l = pk_div(q, r_cot); co_l = q - ci_l * cot; }
+    const int co = co0 + co_l, ci = ci0 + ci_l;
+    const int ty = pk_div(tap, r_kw), tx = tap - ty * d.KW;
+    const bool in = co < d.co_lim && ci < d.ci_lim;
+    const long addr = d.base + co * d.s_co + ci * d.s_ci + ty * d.s_ky + tx * d.s_kx;
+    float* cell = lds + (co_l * taps + tap) * ldc + ci_l;
+    if (!store) *cell = in ? d.w[addr] : 0.f;
+    else if (in) const_cast<float*>(d.w)[addr] += *cell;
+  };
+  auto packed_side = [&](int e, bool store) {
+    const int q = pk_div(e, r_cit), ci_l = e - q * cit;
+    const int co_l = pk_div(q, r_taps), tap = q - co_l * taps;
+    const long idx = (long)(co0 + co_l) * d.Kp + tap * d.cin + ci0 + ci_l;
+    float* cell = lds + (co_l * taps + tap) * ldc + ci_l;
+    if (store) wp[idx] = *cell;
+    else {
+      float v = 0.f;
+      for (int sl = 0; sl < nslots; ++sl) {
+        v += wp[sl * d.n_elems + idx];
+        if (clear) wp[sl * d.n_elems + idx] = 0.f;
+      }
+      *cell = v;
+    }
+  };
+  for (int e = threadIdx.x; e < n; e += blockDim.x) { if (UNPACK) packed_side(e, false); else strided_side(e, false); }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += blockDim.x) { if (UNPACK) strided_side(e, true); else packed_side(e, true); }
+  const int tail = d.Kp - d.K;      // K padding of the packed rows: zero (pack) / cleared (unpack)
+  if (ci_blk == 0 && tail > 0 && (!UNPACK || clear)) {
+    const float r_tail = 1.0f / (float)tail;
+    for (int e = threadIdx.x; e < cot * tail; e += blockDim.x) {
+      const int r = pk_div(e, r_tail), c = e - r * tail;
+      for (int sl = 0; sl < (UNPACK ? nslots : 1); ++sl) wp[sl * d.n_elems + (long)(co0 + r) * d.Kp + d.K + c] = 0.f;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_unpack(PackDesc d, int clear, int nslots) {
+  __shared__ float lds[PK_LDS];
+  pack_tile<true>(d, blockIdx.x, lds, nslots, clear);
+}
+
+__global__ __launch_bounds__(256) void k_conv_pack(PackDesc d) {
+  __shared__ float lds[PK_LDS];
+  pack_tile<false>(d, blockIdx.x, lds, 1, 0);
+}
+
+// All weight packs of a training step in ONE launch: block b finds its descriptor by binary search in the block prefix and moves
+// one tile of it.  (The step re-packs ~135 weights -- forward, data-gradient and transposed variants -- because the parameters
+// changed; one launch each was 1.0 ms of 7 us launches.)
 __global__ __launch_bounds__(256) void k_conv_pack_multi(const PackDesc* __restrict__ descs, const int* __restrict__ block_prefix, int n_desc) {
+  __shared__ float lds[PK_LDS];
   int lo = 0, hi = n_desc - 1;                       // largest d with block_prefix[d] <= blockIdx.x
   while (lo < hi) {
     const int mid = (lo + hi + 1) >> 1;
     if (block_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const PackDesc d = descs[lo];
-  const unsigned base_idx = (unsigned)(blockIdx.x - block_prefix[lo]) * 1024u;      // a pack has < 2^31 elements
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const unsigned idx = base_idx + u * 256 + threadIdx.x;
-    if (idx >= (unsigned)d.n_elems) return;
-    const int co = (int)(idx / (unsigned)d.Kp), k = (int)(idx - (unsigned)co * (unsigned)d.Kp);
-    float v = 0.f;
-    if (k < d.K && co < d.co_lim) {
-      const int tp = k / d.cin, ci = k - tp * d.cin;
-      if (ci < d.ci_lim) {
-        const int ty = tp / d.KW, tx = tp - ty * d.KW;
-        v = d.w[d.base + co * d.s_co + ci * d.s_ci + ty * d.s_ky + tx * d.s_kx];
-      }
-    }
-    d.wp[idx] = v;
-  }
+  pack_tile<false>(d, (int)blockIdx.x - block_prefix[lo], lds, 1, 0);
 }
 
 // ---------------------------------------------------------------------------------- train-mode BatchNorm
@@ -591,14 +640,29 @@ int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, 
   return launch_wgrad(d, dy, dwp, d->Cout, cin, Kp, 1, (long)d->KW * cin, cin, 0, nslots, (long)d->Cout * Kp, stream);
 }
 
+static PackDesc make_pack_desc(const float* w, float* wp, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co, long s_ci,
+                               long s_ky, long s_kx, long base) {
+  PackDesc d{};
+  d.w = w; d.wp = wp; d.s_co = s_co; d.s_ci = s_ci; d.s_ky = s_ky; d.s_kx = s_kx; d.base = base;
+  d.K = KH * KW * cin; d.Kp = (d.K + 31) / 32 * 32; d.n_elems = (long)Cout * d.Kp;
+  d.Cout = Cout; d.cin = cin; d.KW = KW; d.co_lim = co_lim < Cout ? co_lim : Cout; d.ci_lim = ci_lim < cin ? ci_lim : cin;
+  pack_tile_shape(Cout, cin, KH * KW, s_co, s_ci, &d.co_t, &d.ci_t, &d.order);
+  d.nci = (cin + d.ci_t - 1) / d.ci_t;
+  return d;
+}
+
 int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co, long s_ci,
                        long s_ky, long s_kx, long base, dpmn_stream_t stream) {
-  DPMN_REQUIRE(w && wp && Cout > 0 && cin > 0 && KH > 0 && KW > 0, "conv_pack: bad arguments");
-  const int K = KH * KW * cin, Kp = (K + 31) / 32 * 32;
-  const long total = (long)Cout * Kp;
-  hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), w, wp, Cout, Kp, K, cin, KW,
-                     co_lim < Cout ? co_lim : Cout, ci_lim < cin ? ci_lim : cin, s_co, s_ci, s_ky, s_kx, base);
+  DPMN_REQUIRE(w && wp && Cout > 0 && cin > 0 && KH > 0 && KW > 0 && KH * KW <= 2304, "conv_pack: bad arguments");
+  const PackDesc d = make_pack_desc(w, wp, Cout, cin, KH, KW, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base);
+  hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)pack_tile_blocks(d)), dim3(256), 0, as_stream(stream), d);
   DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_conv_pack_tile_shape(int Cout, int cin, int taps, long s_co, long s_ci, int* shape3) {
+  DPMN_REQUIRE(shape3 && Cout > 0 && cin > 0 && taps > 0 && taps <= 2304, "conv_pack_tile_shape: bad arguments");
+  pack_tile_shape(Cout, cin, taps, s_co, s_ci, &shape3[0], &shape3[1], &shape3[2]);
   return DPMN_OK;
 }
 
@@ -612,12 +676,9 @@ int dpmn_conv_pack_multi_f32(const void* descs, const int* block_prefix, int n_d
 
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
                                  long s_ci, long s_ky, long s_kx, long base, int clear, int nslots, dpmn_stream_t stream) {
-  DPMN_REQUIRE(dwp && dw && Cout > 0 && cin > 0 && KH > 0 && KW > 0, "conv2d_wgrad_unpack: bad arguments");
-  const int K = KH * KW * cin, Kp = (K + 31) / 32 * 32;
-  const long total = (long)Cout * Kp;
-  hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), dwp, dw, Cout, Kp, K, cin,
-                     KW, co_lim < Cout ? co_lim : Cout, ci_lim < cin ? ci_lim : cin, s_co, s_ci, s_ky, s_kx, base, clear,
-                     nslots > 1 ? nslots : 1);
+  DPMN_REQUIRE(dwp && dw && Cout > 0 && cin > 0 && KH > 0 && KW > 0 && KH * KW <= 2304, "conv2d_wgrad_unpack: bad arguments");
+  const PackDesc d = make_pack_desc(dw, dwp, Cout, cin, KH, KW, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base);
+  hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)pack_tile_blocks(d)), dim3(256), 0, as_stream(stream), d, clear, nslots > 1 ? nslots : 1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -116,18 +116,23 @@ class PackCache:
         self.epoch += 1
 
     def _refresh(self):
+        import ctypes
         import struct
         from .._abi import lib, check, stream
         if self.table is None:
             raw, prefix, nb = bytearray(), [], 0
+            shape = (ctypes.c_int * 3)()
             for key in self.order:
                 out, w, (cout_p, cin_p, kh, kw, co_lim, ci_lim, st) = self.entries[key]
                 K = kh * kw * cin_p
                 kp = out.shape[1]
-                raw += struct.pack("<2Q6q8i", w.data_ptr(), out.data_ptr(), st[0], st[1], st[2], st[3], st[4], cout_p * kp, cout_p, kp, K, cin_p,
-                                   kw, min(co_lim, cout_p), min(ci_lim, cin_p), 0)
+                check(lib.dpmn_conv_pack_tile_shape(cout_p, cin_p, kh * kw, st[0], st[1], ctypes.cast(shape, ctypes.c_void_p)))
+                co_t, ci_t, order = shape[0], shape[1], shape[2]
+                nci = (cin_p + ci_t - 1) // ci_t
+                raw += struct.pack("<2Q6q12i", w.data_ptr(), out.data_ptr(), st[0], st[1], st[2], st[3], st[4], cout_p * kp, cout_p, kp, K, cin_p,
+                                   kw, min(co_lim, cout_p), min(ci_lim, cin_p), co_t, ci_t, order, nci, 0)
                 prefix.append(nb)
-                nb += (cout_p * kp + 1023) // 1024
+                nb += (cout_p + co_t - 1) // co_t * nci
             dev = self.entries[self.order[0]][0].device
             descs = torch.frombuffer(raw, dtype=torch.uint8).to(dev)
             self.table = (descs, torch.tensor(prefix, dtype=torch.int32, device=dev), nb)

@@ -350,10 +350,15 @@ int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp,
 int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co, long s_ci,
                        long s_ky, long s_kx, long base, dpmn_stream_t stream);
 /* every pack of a training step in one launch: descs = device array of
- *   { const float* w; float* wp; long s_co, s_ci, s_ky, s_kx, base, n_elems; int Cout, Kp, K, cin, KW, co_lim, ci_lim, pad; }
- * (the arguments of dpmn_conv_pack_f32, n_elems = Cout * Kp), block_prefix[d] = first 1024-element block of descriptor d,
+ *   { const float* w; float* wp; long s_co, s_ci, s_ky, s_kx, base, n_elems; int Cout, Kp, K, cin, KW, co_lim, ci_lim,
+ *     co_t, ci_t, order, nci, pad; }                                                       (112 bytes)
+ * (the arguments of dpmn_conv_pack_f32, n_elems = Cout * Kp; (co_t, ci_t, order) from dpmn_conv_pack_tile_shape,
+ * nci = ceil(cin / ci_t)); a descriptor owns ceil(Cout / co_t) * nci blocks, block_prefix[d] = its first block,
  * n_blocks = total.  Built and cached by dpmn_amd/model/packing.py (PackCache). */
 int dpmn_conv_pack_multi_f32(const void* descs, const int* block_prefix, int n_desc, int n_blocks, dpmn_stream_t stream);
+/* LDS tile of the pack / unpack kernels for one weight: shape3 = {co_t, ci_t, order} (order 1: co is the faster axis of the
+ * parameter layout, i.e. |s_co| < |s_ci|) */
+int dpmn_conv_pack_tile_shape(int Cout, int cin, int taps, long s_co, long s_ci, int* shape3);
 /* packed (Cout,Kp) gradient -> += into the parameter layout (same stride convention as below); clear != 0 zeroes the
  * packed buffer afterwards so that a persistent workspace needs no memset before its next dpmn_conv2d_wgrad_f32 */
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
