@@ -132,13 +132,15 @@ __device__ __forceinline__ float vmax_raw(float x, float y) {
   return r;
 }
 
-// SIMPLE (implies UNI): additionally no input affine on any segment, input activation in {none, ReLU, LeakyReLU(0.2)} and
+// SIMPLE (implies UNI): additionally the input affine on none (AFF = false) or on all (AFF = true: the training forward,
+// BatchNorm applied on load) of the segments, input activation in {none, ReLU, LeakyReLU(0.2)} and
 // at most 31 taps.  The in-image test of a (pixel row, tap) pair is then precomputed ONCE per block into a per-row tap
 // bitmask, the per-chunk address of a row is `voff[row] | bit31-if-outside` (2 vector instructions) with the tap / channel
 // part of the address in the buffer load's scalar offset, and the store to LDS needs no validity mask (act(0) = 0).
-template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false>
+template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   static_assert(!SIMPLE || UNI, "SIMPLE is a refinement of the UNI path");
+  static_assert(!AFF || SIMPLE, "AFF is a variant of the SIMPLE path");
 #ifndef DPMN_IGEMM_FENCE
 #define DPMN_IGEMM_FENCE 1
 #endif
@@ -280,7 +282,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   unsigned nok[APASS];       // bit t: tap t of this pixel row reads outside the image (or the row is beyond M)
   int voff[APASS];           // byte offset of (pixel row, channel lcol) from the pad-shifted base, for the current segment
   int s_seg = -1, s_segstart = 0;
-  __amdgpu_buffer_rsrc_t s_xrs;
+  __amdgpu_buffer_rsrc_t s_xrs, s_scrs, s_shrs;
+  unsigned inv[APASS];       // AFF: bit 31 set = this chunk's tap is outside the image for the row (the affine must leave 0 there)
   // address = base + (pix + tapoff) * cs * 4 is split into a per-row vector part (pix + padoff >= 0) and a per-chunk scalar
   // part (tapoff - minoff >= 0; minoff < 0 for the reversed taps, dil -1, of the transposed-conv phases) over a base
   // shifted down by (padoff - minoff) pixels -- never dereferenced there, valid lanes land inside the tensor
@@ -317,6 +320,12 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
                                                 (a.B * a.Hin * a.Win + baseshift) * cs * 4, 0x00020000);
 #pragma unroll
       for (int p = 0; p < APASS; ++p) voff[p] = (__mul24(pix[p] + padoff, cs) + lcol) * 4;
+      if (AFF) {
+        const float* sc = seg == 2 ? a.in_scale[2] : (seg == 1 ? a.in_scale[1] : a.in_scale[0]);
+        const float* sf = seg == 2 ? a.in_shift[2] : (seg == 1 ? a.in_shift[1] : a.in_shift[0]);
+        s_scrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc), 0, cs * 4, 0x00020000);
+        s_shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sf), 0, cs * 4, 0x00020000);
+      }
     }
     // scalar, >= 0 (readfirstlane: keeps it in an SGPR -- a VGPR soffset makes hipcc emit a waterfall loop around every load)
     const int soff = __builtin_amdgcn_readfirstlane(((u_ky * a.dil_y * a.Win + u_kx * a.dil_x - minoff) * cs + u_c0 - s_segstart) * 4);
@@ -330,8 +339,14 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     }
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
-      const unsigned off = ((nok[p] << sh) & 0x80000000u) | (unsigned)voff[p];
-      xr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_xrs, (int)off, soff, 0));
+      const unsigned oob = (nok[p] << sh) & 0x80000000u;
+      if (AFF) inv[p] = oob;
+      xr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_xrs, (int)(oob | (unsigned)voff[p]), soff, 0));
+    }
+    if (AFF) {
+      const int coff = __builtin_amdgcn_readfirstlane((u_c0 - s_segstart) * 4);
+      s4r = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_scrs, lcol * 4, coff, 0));
+      h4r = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_shrs, lcol * 4, coff, 0));
     }
 #pragma unroll
     for (int p = 0; p < BPASS; ++p) {
@@ -341,6 +356,13 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     }
   };
   auto sstore_simple = [&](int buf) {
+    if (AFF) {          // same expression as the general path (mul, then add: -ffp-contract=off)
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) {
+        xr[p].x = xr[p].x * s4r.x + h4r.x; xr[p].y = xr[p].y * s4r.y + h4r.y;
+        xr[p].z = xr[p].z * s4r.z + h4r.z; xr[p].w = xr[p].w * s4r.w + h4r.w;
+      }
+    }
     // one v_max per element (fmaxf would first canonicalise both operands); ReLU = slope 0, none = skipped
     if (a.pro_act != ACT_NONE) {
       const float sl = a.pro_act == ACT_LEAKY02 ? 0.2f : 0.0f;
@@ -351,6 +373,11 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
       }
     }
     if ((ABL & 2) && xr[0].w != 12345.f) return;
+    if (AFF) {          // act(shift) is not 0: out-of-image taps are zeroed explicitly
+#pragma unroll
+      for (int p = 0; p < APASS; ++p)
+        if (inv[p]) xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int p = 0; p < APASS; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * RPP) * LDK + lcol]) = xr[p];
 #pragma unroll
@@ -1002,10 +1029,15 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     static const int bk16 = getenv("DPMN_CONV_BK16") ? atoi(getenv("DPMN_CONV_BK16")) : 0;
     static const int simple_on = getenv("DPMN_CONV_SIMPLE") ? atoi(getenv("DPMN_CONV_SIMPLE")) : 1;
     bool simple = simple_on && uni && a.KH * a.KW <= 31 && (a.pro_act == ACT_NONE || a.pro_act == ACT_RELU || a.pro_act == ACT_LEAKY02);
-    for (int i = 0; i < 3; ++i)      // + the pad shift of the buffer base must keep the byte range below 2^31
-      simple = simple && a.in_scale[i] == nullptr &&
+    int n_seg = 0, n_aff = 0;
+    for (int i = 0; i < 3; ++i) {    // + the shift of the buffer base must keep the byte range below 2^31
+      if (a.cseg[i] > 0) { ++n_seg; n_aff += a.in_scale[i] != nullptr; }
+      simple = simple &&
                ((size_t)a.B * a.Hin * a.Win + (size_t)(abs(a.pad_y) + a.KH * abs(a.dil_y) + 2) * a.Win) * a.cseg[i] * 4 < (1ull << 31);
+    }
+    simple = simple && (n_aff == 0 || n_aff == n_seg);       // mixed segments: the general UNI path
   if (uni && BM == 128 && BN == 128 && bk16) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 16>), grid, dim3(256), 0, st, a);
+  else if (simple && n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true>), grid, dim3(256), 0, st, a);
   else if (simple) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true>), grid, dim3(256), 0, st, a);
   else if (uni) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN>), grid, dim3(256), 0, st, a);
