@@ -342,14 +342,20 @@ __global__ __launch_bounds__(256) void k_conv_pack_multi(const PackDesc* __restr
 
 // ---------------------------------------------------------------------------------- train-mode BatchNorm
 // stats (32,2,C) = slotted (sum, sumsq) over `count` values per channel (accumulated by the conv epilogue)
-__global__ void k_bn_finalize(const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+// clear: zero the slots after reading them (a persistent statistics buffer then needs no memset per conv); nbt: the module's
+// num_batches_tracked counter, incremented here instead of by a separate one-element kernel
+__global__ void k_bn_finalize(float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
                               float count, float eps, float momentum, float* __restrict__ scale, float* __restrict__ shift,
                               float* __restrict__ mean_out, float* __restrict__ rstd_out, float* __restrict__ running_mean,
-                              float* __restrict__ running_var, int C) {
+                              float* __restrict__ running_var, int C, long long* __restrict__ nbt, int clear) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
   float s1 = 0.f, s2 = 0.f;
-  for (int slot = 0; slot < 32; ++slot) { s1 += stats[(size_t)slot * 2 * C + c]; s2 += stats[(size_t)slot * 2 * C + C + c]; }   // STAT_SLOTS
+  for (int slot = 0; slot < 32; ++slot) {   // STAT_SLOTS
+    s1 += stats[(size_t)slot * 2 * C + c]; s2 += stats[(size_t)slot * 2 * C + C + c];
+    if (clear) { stats[(size_t)slot * 2 * C + c] = 0.f; stats[(size_t)slot * 2 * C + C + c] = 0.f; }
+  }
   const float mean = s1 / count;
   float var = s2 / count - mean * mean;   // biased variance used for normalisation
   var = var > 0.f ? var : 0.f;
@@ -688,12 +694,12 @@ int dpmn_conv2d_wgrad_strided_f32(const dpmn_conv_desc* d, const float* dy, floa
   return launch_wgrad(d, dy, dw, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base, 1, 0, stream);
 }
 
-int dpmn_bn_finalize_f32(const float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,
+int dpmn_bn_finalize_f32(float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,
                          float* scale, float* shift, float* mean, float* rstd, float* running_mean, float* running_var, int C,
-                         dpmn_stream_t stream) {
+                         long long* num_batches_tracked, int clear_stats, dpmn_stream_t stream) {
   DPMN_REQUIRE(stats && gamma && beta && scale && shift && mean && rstd && C > 0 && count > 1.f, "bn_finalize: bad arguments");
   hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 128)), dim3(128), 0, as_stream(stream), stats, gamma, beta, count, eps, momentum,
-                     scale, shift, mean, rstd, running_mean, running_var, C);
+                     scale, shift, mean, rstd, running_mean, running_var, C, num_batches_tracked, clear_stats);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -35,7 +35,7 @@ int dpmn_prof_open(int tag, hipStream_t st, double flops, double bytes) {
 void dpmn_prof_close(int slot, hipStream_t st) { (void)hipEventRecord(g_prof.ev[2 * slot + 1], st); }
 
 extern "C" {
-int dpmn_abi_version(void) { return 2; }
+int dpmn_abi_version(void) { return 3; }
 const char* dpmn_last_error(void) { return g_err; }
 
 int dpmn_profile_tag_count(void) { return PT_COUNT; }

@@ -56,7 +56,7 @@ class STNHead(nn.Module):
         """(B, in_planes, 16, 64) -> (img_feat (B,512), ctrl_points (B, num_ctrlpoints, 2))   (stn_head.py:92-106)"""
         from .. import ops
         from . import packing
-        from ..train.cmm_train import _bn_finalize
+        from ..train.cmm_train import _bn_finalize, stats_buffer
         if self.activation != 'none':
             raise NotImplementedError("dpmn_amd STNHead: activation 'none' is what every PSN constructs (tatt.py:66-70)")
         B, cin, H, W = x.shape
@@ -70,7 +70,7 @@ class STNHead(nn.Module):
             conv, bn = self.stn_convnet[2 * bi][0], self.stn_convnet[2 * bi][1]
             cout = conv.out_channels
             if self.training:       # batch statistics from the conv epilogue; affine + ReLU applied by the consumer on load
-                stats = torch.zeros(32, 2, cout, device=cur.device)
+                stats = stats_buffer(cout, cur.device)
                 r = ops.conv2d([cur], packing.tpack_conv(conv.weight, cin_pad=cur.shape[3]), conv.bias, cout, 3, pad=1, stats=stats)
                 aff = _bn_finalize(stats, bn, r.shape[0] * r.shape[1] * r.shape[2])[:2]
             else:                   # running statistics folded into the conv, ReLU in its epilogue

@@ -35,14 +35,27 @@ class T:
         return self.G
 
 
+_STATS = {}
+
+
+def stats_buffer(cout, device):
+    """(32, 2, cout) zeroed BatchNorm-statistics slots for ONE convolution.  A single persistent buffer per device: the conv that
+    fills it and the _bn_finalize that reads it are stream-ordered, and the finalize kernel zeroes what it read, so the next
+    convolution gets the same memory back clean (33 memsets per step otherwise)."""
+    buf = _STATS.get(device)
+    if buf is None or buf.numel() < 64 * cout:
+        buf = _STATS[device] = torch.zeros(64 * max(cout, 1024), device=device)
+    return buf[:64 * cout].view(32, 2, cout)
+
+
 def _bn_finalize(stats, bn, count):
     Cc = bn.weight.shape[0]
     dev = stats.device
-    scale, shift, mean, rstd = (torch.empty(Cc, device=dev) for _ in range(4))
+    scale, shift, mean, rstd = torch.empty(4, Cc, device=dev).unbind(0)
+    nbt = bn.num_batches_tracked
     check(lib.dpmn_bn_finalize_f32(dptr(stats), dptr(bn.weight), dptr(bn.bias), float(count), float(bn.eps), float(bn.momentum),
                                    dptr(scale), dptr(shift), dptr(mean), dptr(rstd), dptr(bn.running_mean), dptr(bn.running_var),
-                                   Cc, stream()))
-    bn.num_batches_tracked += 1
+                                   Cc, nbt.data_ptr() if nbt is not None and nbt.is_cuda else None, 1, stream()))
     return scale, shift, mean, rstd
 
 
@@ -72,7 +85,7 @@ class Unit:
         aff = [t.aff for t in self.inputs]
         transposed = self.kind in ("convT3", "convT4s2")
         cout = w.shape[1] if transposed else w.shape[0]
-        stats = torch.zeros(32, 2, cout, device=w.device) if self.bn is not None else None
+        stats = stats_buffer(cout, w.device) if self.bn is not None else None
         if self.kind == "convT4s2":
             r = ops.convT_s2k4(xs, (packing.tpack_convT_s2k4(w), b), cout, pro_act=self.pro_act, affine=aff, stats=stats)
         else:

@@ -366,9 +366,11 @@ int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int K
                                  dpmn_stream_t stream);
 int dpmn_conv2d_wgrad_strided_f32(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co,
                                   long s_ci, long s_ky, long s_kx, long base, dpmn_stream_t stream);
-int dpmn_bn_finalize_f32(const float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,
+/* num_batches_tracked (int64, may be NULL) is incremented by one; clear_stats != 0 zeroes the (32,2,C) slots after they are
+ * read, so that a persistent statistics buffer serves the next convolution without a memset */
+int dpmn_bn_finalize_f32(float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,
                          float* scale, float* shift, float* mean, float* rstd, float* running_mean, float* running_var,
-                         int C, dpmn_stream_t stream);
+                         int C, long long* num_batches_tracked, int clear_stats, dpmn_stream_t stream);
 int dpmn_affine_act_bwd_f32(const float* dA, const float* r, const float* scale, const float* shift, int act, float* G,
                             int accumulate, long pixels, int C, dpmn_stream_t stream);
 int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const float* mean, const float* rstd, float* sums_ws,

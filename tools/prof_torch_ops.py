@@ -39,7 +39,12 @@ for ev in prof.events():
     # leaf attribution: the op that launched the kernel / memcpy itself (aten::copy_ under aten::to, ...)
     if getattr(ev, "self_device_time_total", 0) <= 0 or not ev.name.startswith("aten::"):
         continue
-    st = [s for s in (ev.stack or []) if "dpmn_amd" in s or "bench" in s]
+    st = [s for s in (ev.stack or []) if ("dpmn_amd" in s or "bench" in s) and "prof_torch_ops" not in s]
+    if not st:          # ops issued from the autograd thread carry no Python frames of ours: name the enclosing backward node
+        par = ev.cpu_parent
+        while par is not None and not ("Backward" in par.name or "autograd" in par.name):
+            par = par.cpu_parent
+        st = ["<" + par.name + ">"] if par is not None else [str((ev.stack or ["?"])[:1])]
     key = (ev.name, st[0].strip()[-90:] if st else "?")
     by[key] += 1
     tm[key] += ev.self_device_time_total
