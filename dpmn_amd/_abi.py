@@ -107,6 +107,8 @@ SIGNATURES = {
     "dpmn_prior_fusion_wgrad_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), fp, fp, _i, fp]),
     "dpmn_conv_pack_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, fp]),
+    "dpmn_conv2d_wgrad_excl_slots": (_i, [C.POINTER(ConvDesc), fp]),
+    "dpmn_conv2d_wgrad_excl_f32": (_i, [C.POINTER(ConvDesc), fp, fp, _i, fp]),
     "dpmn_conv2d_wgrad_unpack_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, _i, _i, fp]),
     "dpmn_conv2d_wgrad_strided_f32": (_i, [C.POINTER(ConvDesc), fp, fp, _i, _i, _l, _l, _l, _l, _l, fp]),
     "dpmn_bn_finalize_f32": (_i, [fp, fp, fp, _f, _f, _f, fp, fp, fp, fp, fp, fp, _i, fp, _i, fp]),

@@ -27,6 +27,7 @@ struct WgArgs {
   int gx, gy, gz;       // logical grid (co tiles, k tiles, pixel splits)
   int nslots;           // > 1: split z accumulates into copy (z % nslots) of dw, copies slot_stride floats apart
   long slot_stride;
+  int excl;             // packed destination with one slot PER split: plain stores, no atomics, slots need no zero-init
   float inv_hw, inv_w;
 };
 
@@ -196,6 +197,26 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
     if (more) sstore();
     __syncthreads();
   }
+  if (a.excl) {
+    // the block owns tile (n_blk, k_blk) of slot bz: a lane's NJ consecutive k values go out as one vector store, 16 lanes
+    // cover a contiguous 16*NJ-float run of one co row.  k in [K, Kp) holds zeros (the X loader zero-fills k >= K).
+    float* slotp = a.dw + (long)bz * a.slot_stride;
+    const int k0 = k_blk + wave * (NJ * 16) + lr * NJ;
+    if (k0 < (int)a.s_co) {
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ii = kq * 4 + r;
+          const int n = n_blk + (NI == 1 ? ii : (i >> 2) * 64 + ii * 4 + (i & 3));
+          if (n >= a.Cout) continue;
+          float* dst = slotp + (long)n * a.s_co + k0;
+          if constexpr (NJ == 4) *reinterpret_cast<float4*>(dst) = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+          else *reinterpret_cast<float2*>(dst) = make_float2(acc[i][0][r], acc[i][1][r]);
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int k = k_blk + wave * (NJ * 16) + lr * NJ + j;
@@ -296,6 +317,7 @@ __device__ __forceinline__ void pack_tile(const PackDesc& d, int blk, float* lds
     if (store) wp[idx] = *cell;
     else {
       float v = 0.f;
+#pragma unroll 8
       for (int sl = 0; sl < nslots; ++sl) {
         v += wp[sl * d.n_elems + idx];
         if (clear) wp[sl * d.n_elems + idx] = 0.f;
@@ -303,7 +325,35 @@ __device__ __forceinline__ void pack_tile(const PackDesc& d, int blk, float* lds
       *cell = v;
     }
   };
-  for (int e = threadIdx.x; e < n; e += blockDim.x) { if (UNPACK) packed_side(e, false); else strided_side(e, false); }
+  // many copies of a small tile (the exclusive-slot weight gradients of huge-M convs: up to 256 copies, tiles shrunk to a few
+  // dozen elements for parallelism): SG threads per element each sum every SG-th copy -- the chain of dependent loads per
+  // thread is what bounds this kernel -- and the partial sums meet in LDS
+  int SG = 1;
+  if (UNPACK && !clear && cot * taps * ldc <= PK_LDS - 256)
+    while (SG < 16 && SG * 2 * n <= (int)blockDim.x && SG * 2 <= nslots) SG *= 2;
+  if (UNPACK && SG > 1) {
+    float* part = lds + PK_LDS - 256;            // [SG][n], SG * n <= 256; the tile cells live below (n <= 128 here)
+    const int e = threadIdx.x % n, g = threadIdx.x / n;
+    if (g < SG) {
+      const int q = pk_div(e, r_cit), ci_l = e - q * cit;
+      const int co_l = pk_div(q, r_taps), tap = q - co_l * taps;
+      const long idx = (long)(co0 + co_l) * d.Kp + tap * d.cin + ci0 + ci_l;
+      float v = 0.f;
+#pragma unroll 8
+      for (int sl = g; sl < nslots; sl += SG) v += wp[sl * d.n_elems + idx];
+      part[g * n + e] = v;
+    }
+    __syncthreads();
+    if (g == 0) {
+      const int q = pk_div(e, r_cit), ci_l = e - q * cit;
+      const int co_l = pk_div(q, r_taps), tap = q - co_l * taps;
+      float v = 0.f;
+      for (int h = 0; h < SG; ++h) v += part[h * n + e];
+      lds[(co_l * taps + tap) * ldc + ci_l] = v;
+    }
+  } else {
+    for (int e = threadIdx.x; e < n; e += blockDim.x) { if (UNPACK) packed_side(e, false); else strided_side(e, false); }
+  }
   __syncthreads();
   for (int e = threadIdx.x; e < n; e += blockDim.x) { if (UNPACK) strided_side(e, true); else packed_side(e, true); }
   const int tail = d.Kp - d.K;      // K padding of the packed rows: zero (pack) / cleared (unpack)
@@ -590,9 +640,12 @@ __global__ void k_adam_clip(float* __restrict__ p, const float* __restrict__ g, 
 
 extern "C" {
 
+// excl_slots: 0 = atomic accumulation (nslots copies); > 0 = exclusive mode, must equal the split count of the plan;
+// plan_only != nullptr: only report the split count exclusive mode would use
 static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co, long s_ci,
-                        long s_ky, long s_kx, long base, int nslots, long slot_stride, dpmn_stream_t stream) {
-  DPMN_REQUIRE(d && d->in[0] && dy && dw, "conv2d_wgrad: null pointer");
+                        long s_ky, long s_kx, long base, int nslots, long slot_stride, dpmn_stream_t stream, int excl_slots = 0,
+                        int* plan_only = nullptr) {
+  DPMN_REQUIRE(d && d->in[0] && (plan_only || (dy && dw)), "conv2d_wgrad: null pointer");
   WgArgs a{};
   int cin = 0;
   for (int s = 0; s < 3; ++s) {
@@ -628,6 +681,26 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
   int ppb = cdiv(cdiv(M, splits), 32) * 32;
   if (ppb < min_ppb) ppb = min_ppb;
   splits = cdiv(M, ppb);
+  if (excl_slots > 0 || plan_only) {
+    // no atomic epilogue to amortise: split for parallelism (~768 blocks), bounded by the slot round trip (every split writes
+    // and the unpack reads one Cout x Kp slot: <= 32 MB in flight, but never fewer than 2 splits of a large M)
+    static const int want_blocks = getenv("DPMN_WG_BLOCKS") ? atoi(getenv("DPMN_WG_BLOCKS")) : 768;
+    static const long cap_bytes = (long)(getenv("DPMN_WG_CAP_MB") ? atoi(getenv("DPMN_WG_CAP_MB")) : 32) << 20;
+    const long slot_bytes = (long)a.Cout * s_co * 4;
+    long sp = cdiv(want_blocks, tiles);
+    const long by_cap = cap_bytes / slot_bytes < 2 ? 2 : cap_bytes / slot_bytes;
+    if (sp > by_cap) sp = by_cap;
+    if (sp > M / 64) sp = M / 64;
+    if (sp > 256) sp = 256;          // the unpack sums the copies: 256 is what its slot-parallel reduction is sized for
+    if (sp < 1) sp = 1;
+    ppb = cdiv(cdiv(M, (int)sp), 32) * 32;
+    splits = cdiv(M, ppb);
+    // a few hundred gradient values over 10^5 pixels (the 4-channel DistillModule convs): the MFMA tile is mostly padding and
+    // the launch is latency-bound either way; 32 slotted atomic copies measured faster there (60 vs 95 us) -> report 0
+    if (plan_only) { *plan_only = (bn == 16 && a.K <= 128) ? 0 : splits; return DPMN_OK; }
+    DPMN_REQUIRE(excl_slots == splits, "conv2d_wgrad_excl: slots must be the count dpmn_conv2d_wgrad_excl_slots reports");
+    a.excl = 1; a.nslots = splits;
+  }
   a.pix_per_block = ppb; a.gz = splits;
   const dim3 grid((unsigned)(tiles * splits));
   if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256>), grid, dim3(256), 0, as_stream(stream), a);
@@ -644,6 +717,22 @@ int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, 
   for (int s = 0; s < 3; ++s) cin += d->in[s] ? d->cseg[s] : 0;
   const long Kp = ((long)(d->KH * d->KW * cin + 31) / 32) * 32;
   return launch_wgrad(d, dy, dwp, d->Cout, cin, Kp, 1, (long)d->KW * cin, cin, 0, nslots, (long)d->Cout * Kp, stream);
+}
+
+int dpmn_conv2d_wgrad_excl_slots(const dpmn_conv_desc* d, int* slots) {
+  DPMN_REQUIRE(d && slots, "conv2d_wgrad_excl_slots: null pointer");
+  int cin = 0;
+  for (int s = 0; s < 3; ++s) cin += d->in[s] ? d->cseg[s] : 0;
+  const long Kp = ((long)(d->KH * d->KW * cin + 31) / 32) * 32;
+  return launch_wgrad(d, nullptr, nullptr, d->Cout, cin, Kp, 1, (long)d->KW * cin, cin, 0, 1, (long)d->Cout * Kp, nullptr, 0, slots);
+}
+
+int dpmn_conv2d_wgrad_excl_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, int slots, dpmn_stream_t stream) {
+  DPMN_REQUIRE(d && slots > 0, "conv2d_wgrad_excl: bad arguments");
+  int cin = 0;
+  for (int s = 0; s < 3; ++s) cin += d->in[s] ? d->cseg[s] : 0;
+  const long Kp = ((long)(d->KH * d->KW * cin + 31) / 32) * 32;
+  return launch_wgrad(d, dy, dwp, d->Cout, cin, Kp, 1, (long)d->KW * cin, cin, 0, slots, (long)d->Cout * Kp, stream, slots);
 }
 
 static PackDesc make_pack_desc(const float* w, float* wp, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co, long s_ci,

@@ -112,19 +112,34 @@ def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
     else:
         ci, co = dweight.shape[:2]
         st = (16, co * 16, 8, 2, (1 - phase[0]) * 4 + (1 - phase[1]))
-    # coalesced atomics into a persistent packed (Cout, Kp) workspace, then one unpack kernel that also re-zeroes it
-    # (scattering the atomics straight into the parameter layout, dpmn_conv2d_wgrad_strided_f32, measured 3x slower)
+    # Every pixel split STORES its partial (Cout, Kp) tile set into its own copy of a persistent packed workspace (no atomics:
+    # deterministic, and no zero-init), then one unpack kernel sums the copies into the parameter layout.
+    # (Measured alternatives: atomics into one packed copy + re-zeroing unpack, ~51 TF on the CMM convs; atomics straight into
+    # the parameter layout, dpmn_conv2d_wgrad_strided_f32, 3x slower than that.)
     cin_d = sum(d.cseg[i] for i in range(3) if d.inp[i])
     kp = (d.KH * d.KW * cin_d + 31) // 32 * 32
-    nslots = 32 if d.Cout * kp <= 12288 else 1     # small gradients: spread the pixel splits' atomics over 32 copies
-    key = (dy.device, d.Cout, kp, nslots)
-    ws = _WGRAD_WS.get(key)
-    if ws is None:
-        ws = _WGRAD_WS[key] = torch.zeros(nslots, d.Cout, kp, device=dy.device)
-    check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dy), dptr(ws), nslots, stream()))
-    check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 1, nslots, stream()))
+    slots = C.c_int(0)
+    if WGRAD_MODE != "atomic":
+        check(lib.dpmn_conv2d_wgrad_excl_slots(C.byref(d), C.cast(C.pointer(slots), C.c_void_p)))
+    if slots.value == 0:      # (the library advises the slotted-atomic path for tiny gradients over many pixels)
+        nslots = 32 if d.Cout * kp <= 12288 else 1     # small gradients: spread the pixel splits' atomics over 32 copies
+        key = (dy.device, d.Cout, kp, nslots)
+        ws = _WGRAD_WS.get(key)
+        if ws is None:
+            ws = _WGRAD_WS[key] = torch.zeros(nslots, d.Cout, kp, device=dy.device)
+        check(lib.dpmn_conv2d_wgrad_f32(C.byref(d), dptr(dy), dptr(ws), nslots, stream()))
+        check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 1, nslots, stream()))
+        return
+    n = slots.value * d.Cout * kp
+    ws = _WGRAD_WS.get(dy.device)
+    if ws is None or ws.numel() < n:       # one workspace per device: wgrad -> unpack pairs are stream-ordered
+        ws = _WGRAD_WS[dy.device] = torch.empty(max(n, 16 << 20), device=dy.device)
+    check(lib.dpmn_conv2d_wgrad_excl_f32(C.byref(d), dptr(dy), dptr(ws), slots.value, stream()))
+    check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 0, slots.value, stream()))
 
 
+import os as _os
+WGRAD_MODE = _os.environ.get("DPMN_WGRAD", "excl")      # "atomic": the previous accumulate-by-atomics path (A/B switch)
 _WGRAD_WS = {}
 
 

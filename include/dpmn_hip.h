@@ -359,6 +359,12 @@ int dpmn_conv_pack_multi_f32(const void* descs, const int* block_prefix, int n_d
 /* LDS tile of the pack / unpack kernels for one weight: shape3 = {co_t, ci_t, order} (order 1: co is the faster axis of the
  * parameter layout, i.e. |s_co| < |s_ci|) */
 int dpmn_conv_pack_tile_shape(int Cout, int cin, int taps, long s_co, long s_ci, int* shape3);
+/* the same gradient without atomics: the pixel range is cut into `slots` splits (dpmn_conv2d_wgrad_excl_slots reports the
+ * count for a descriptor; 0 = tiny gradient over very many pixels, use dpmn_conv2d_wgrad_f32 with 32 slotted copies) and
+ * every (tile, split) block STORES its partial tile into copy `split` of dwp (slots, Cout, Kp):
+ * deterministic, the copies need no zero-init; sum them with dpmn_conv2d_wgrad_unpack_f32(clear = 0, nslots = slots) */
+int dpmn_conv2d_wgrad_excl_slots(const dpmn_conv_desc* d, int* slots);
+int dpmn_conv2d_wgrad_excl_f32(const dpmn_conv_desc* d, const float* dy, float* dwp, int slots, dpmn_stream_t stream);
 /* packed (Cout,Kp) gradient -> += into the parameter layout (same stride convention as below); clear != 0 zeroes the
  * packed buffer afterwards so that a persistent workspace needs no memset before its next dpmn_conv2d_wgrad_f32 */
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
