@@ -49,7 +49,11 @@ struct ConvArgs {
   int npad;                   // Cout rounded up to 4
   int nphase;                 // 4: the phases of ConvTranspose2d(4,2,1) in one launch (gridDim.z = nphase * ksplit):
   long wps;                   //    phase p = 2*py + px uses w + p*wps, pad = -(py,px), output offset (py,px)
+  int groups;                 // 2: the batch holds two independent halves (the CMM's twin encoder branches, cmm.py:86-99): pixels
+  int m_per_group;            //    m >= m_per_group use w + wgs and bias + Cout -- one launch, twice the tiles, half the split-K
+  long wgs;
 };
+__device__ __forceinline__ int conv_group_of(const ConvArgs& a, int m) { return (a.groups > 1 && m >= a.m_per_group) ? 1 : 0; }
 
 // phase-fused launch: the phase-dependent arguments of this workgroup (the kernel argument struct itself stays
 // read-only -- writing to it would spill it to scratch)
@@ -58,13 +62,13 @@ struct PhaseSel {
   const float* w;
   float* partial;
 };
-__device__ __forceinline__ PhaseSel conv_select_phase(const ConvArgs& a, int z) {
-  PhaseSel s{a.pad_y, a.pad_x, a.ooy, a.oox, z, a.w, a.partial};
+__device__ __forceinline__ PhaseSel conv_select_phase(const ConvArgs& a, int z, int m_first = 0) {
+  PhaseSel s{a.pad_y, a.pad_x, a.ooy, a.oox, z, a.w + (conv_group_of(a, m_first) ? a.wgs : 0L), a.partial};
   if (a.nphase > 1) {
     const int ph = z / a.ksplit;
     const int phy = ph >> 1, phx = ph & 1;
     s.pad_y = -phy; s.pad_x = -phx; s.ooy = phy; s.oox = phx;
-    s.w = a.w + (size_t)ph * a.wps;
+    s.w += (size_t)ph * a.wps;
     if (a.partial) s.partial = a.partial + (size_t)ph * a.ksplit * a.B * a.Hp * a.Wp * a.npad;
     s.zsplit = z - ph * a.ksplit;
   }
@@ -76,8 +80,9 @@ __device__ __forceinline__ void conv_store(const ConvArgs& a, int m, int n, floa
                                            int oox) {
   const int b = m / (a.Hp * a.Wp), rr = m % (a.Hp * a.Wp);
   const int oy = (rr / a.Wp) * a.ostep + ooy, ox = (rr % a.Wp) * a.ostep + oox;
+  const float* bias = a.bias ? a.bias + (conv_group_of(a, m) ? a.Cout : 0) : nullptr;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] += ((a.bias && n + r < a.Cout) ? a.bias[n + r] : 0.f);
+  for (int r = 0; r < 4; ++r) v[r] += ((bias && n + r < a.Cout) ? bias[n + r] : 0.f);
   if (a.stats) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { ssum[r] += v[r]; ssq[r] += v[r] * v[r]; }
@@ -158,9 +163,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.B * a.Hp * a.Wp;
-  const PhaseSel ph = conv_select_phase(a, blockIdx.z);
-  const int zsplit = ph.zsplit;
   const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  const PhaseSel ph = conv_select_phase(a, blockIdx.z, m_blk);      // (a tile never straddles the two groups: checked at launch)
+  const int zsplit = ph.zsplit;
   const int lrow = tid / TPR, lcol = (tid % TPR) * 4;
 
   // per-thread pixel rows of the A tile
@@ -686,7 +691,8 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
     wofs_h[v] = (i < BN * 8) ? ((n_blk + (i >> 3)) * a.Kp + (i & 7) * 4) * 4 : (int)0x80000000;
   }
   const bool w_buf_ok = (size_t)a.Cout * a.Kp * 4 < (1ull << 31);
-  const __amdgpu_buffer_rsrc_t wrs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, w_buf_ok ? a.Cout * a.Kp * 4 : 0, 0x00020000);
+  const float* wg = a.w + (conv_group_of(a, (b * a.Hin + ty0) * a.Win + tx0) ? a.wgs : 0L);       // the tile's image decides the group
+  const __amdgpu_buffer_rsrc_t wrs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, w_buf_ok ? a.Cout * a.Kp * 4 : 0, 0x00020000);
   auto issue_w = [&](int chunk, int tap) {
     const size_t k0 = (size_t)tap * a.cin + chunk * BK;
     if (w_buf_ok) {
@@ -698,7 +704,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
     for (int v = 0; v < WV; ++v) {
       const int i = tid + v * 256;
       const int r = i >> 3, c4 = (i & 7) * 4;
-      wraw[v] = (i < BN * 8 && n_blk + r < a.Cout) ? *reinterpret_cast<const float4*>(a.w + (size_t)(n_blk + r) * a.Kp + k0 + c4)
+      wraw[v] = (i < BN * 8 && n_blk + r < a.Cout) ? *reinterpret_cast<const float4*>(wg + (size_t)(n_blk + r) * a.Kp + k0 + c4)
                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
@@ -950,7 +956,8 @@ static inline double conv_flops(const ConvArgs& a) {
 }
 static inline double conv_bytes(const ConvArgs& a) {
   const double nph = a.nphase > 1 ? a.nphase : 1;
-  return 4.0 * ((double)a.B * a.Hin * a.Win * a.cin + nph * (double)a.Cout * a.KH * a.KW * a.cin + nph * a.B * a.Hp * a.Wp * (double)a.Cout);
+  const double ng = a.groups > 1 ? a.groups : 1;
+  return 4.0 * ((double)a.B * a.Hin * a.Win * a.cin + ng * nph * (double)a.Cout * a.KH * a.KW * a.cin + nph * a.B * a.Hp * a.Wp * (double)a.Cout);
 }
 
 template <int KS, int TH>
@@ -998,6 +1005,8 @@ int launch_halo(const ConvArgs& a, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
+  if (a.groups == 2 && a.m_per_group % BM != 0)
+    return dpmn_set_error(DPMN_ERR_ARG, "conv2d: groups = 2 needs the pixels of one half to fill whole row tiles (B/2*Hp*Wp % 128 == 0)");
   const int M = a.B * a.Hp * a.Wp;
   const int nph = a.nphase > 1 ? a.nphase : 1;
   const int tiles = cdiv(M, BM) * cdiv(a.Cout, BN) * nph;
@@ -1096,6 +1105,9 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   a.out_nchw = d->out_nchw; a.pixel_shuffle = d->pixel_shuffle; a.stats = d->stats;
   a.Kp = ((d->KH * d->KW * cin + 31) / 32) * 32;
   a.nphase = d->nphase == 4 ? 4 : 1; a.wps = d->w_phase_stride;
+  a.groups = d->groups == 2 ? 2 : 1; a.wgs = d->w_group_stride; a.m_per_group = a.groups == 2 ? d->B / 2 * d->Hp * d->Wp : 0;
+  DPMN_REQUIRE(d->groups == 0 || d->groups == 1 || (d->groups == 2 && d->B % 2 == 0 && d->w_group_stride > 0 && !d->stats),
+               "conv2d: groups = 2 splits an even batch into halves with their own weights (w_group_stride) and bias (+Cout)");
   DPMN_REQUIRE(d->nphase == 0 || d->nphase == 1 || (d->nphase == 4 && d->KH == 2 && d->KW == 2 && d->dil_y == -1 && d->dil_x == -1 &&
                                                     d->ostep == 2 && d->w_phase_stride >= (long)d->Cout * a.Kp),
                "conv2d: nphase = 4 is the fused ConvTranspose2d(4,2,1) launch (k 2, dil -1, ostep 2, 4 packed phase weights)");
@@ -1117,7 +1129,7 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   // too few 8x16-pixel tiles to fill 256 CUs (deep decoder levels with 3-segment inputs): split-K implicit GEMM instead
   const bool halo_starved = (M / 128) * cdiv(a.Cout, 64) < 256 && a.Cout >= 128 && ws != nullptr;
   static const bool c4_on = !(getenv("DPMN_CONV_C4") && atoi(getenv("DPMN_CONV_C4")) == 0);
-  if (halo_ok && a.Cout <= 4 && c4_on && !a.pixel_shuffle && !a.res)
+  if (halo_ok && a.Cout <= 4 && c4_on && !a.pixel_shuffle && !a.res && a.groups == 1)
     return a.KH == 3 ? launch_halo_c4<3, 8>(a, st) : launch_halo_c4<9, 8>(a, st);   // (3x3: 4- and 16-row tiles measured no better)
   if (halo_ok && !halo_starved) {
     if (a.KH == 3) return a.Cout <= 16 ? launch_halo<3, 16>(a, st) : launch_halo<3, 64>(a, st);

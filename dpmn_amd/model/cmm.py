@@ -76,6 +76,12 @@ class ComplementationModulationModule(nn.Module):
                     P["en_%d_%s.b" % (lvl, br)] = packing.pack_conv(seq[4].weight, seq[4].bias, self._bn(seq[5]))
                 e6 = getattr(self, "en_6_" + br)[1]
                 P["en_6_" + br] = packing.pack_conv(e6.weight, e6.bias)
+            # the twin encoder branches (cmm.py:86-99: same shapes, own weights) run as ONE grouped launch per level over the
+            # batch-concatenated inputs: stacked (2, Cout, Kp) weights / (2, Cout) biases
+            for name in ["en_1"] + ["en_%d.%s" % (lvl, ab) for lvl in (2, 3, 4, 5) for ab in "ab"] + ["en_6"]:
+                k1, k2 = (name.replace(".", "_1."), name.replace(".", "_2.")) if "." in name else (name + "_1", name + "_2")
+                P[name] = (torch.stack([P[k1][0], P[k2][0]]).contiguous(), torch.stack([P[k1][1], P[k2][1]]).contiguous())
+                del P[k1], P[k2]
             P["de_6"] = ops.stack_phase_packs(packing.pack_convT_s2k4(self.de_6[1].weight, self.de_6[1].bias, self._bn(self.de_6[2])))
             for lvl in (5, 4, 3, 2):
                 seq = getattr(self, "de_%d" % lvl).decode
@@ -96,18 +102,16 @@ class ComplementationModulationModule(nn.Module):
             raise NotImplementedError("dpmn_amd CMM: gradients in eval mode (running-stat BatchNorm) are not built; use .train()")
         P = self._packed()
         c = self.cnum
-        enc = []
-        for br, x in (("1", x1), ("2", x2)):
-            xin = ops.nchw_to_nhwc(x.contiguous().float(), 4)
-            o = [ops.conv2d([xin], *P["en_1_" + br], c, 3, pad=1)]
-            chans = {2: (c, 2 * c), 3: (2 * c, 4 * c), 4: (4 * c, 8 * c), 5: (8 * c, 8 * c)}
-            for lvl in (2, 3, 4, 5):
-                ci, co = chans[lvl]
-                t = ops.conv2d([o[-1]], *P["en_%d_%s.a" % (lvl, br)], ci, 4, stride=2, pad=3, dil=2, pro_act="leaky02")
-                o.append(ops.conv2d([t], *P["en_%d_%s.b" % (lvl, br)], co, 3, pad=1, pro_act="leaky02"))
-            o.append(ops.conv2d([o[-1]], *P["en_6_" + br], 8 * c, 4, stride=2, pad=1, pro_act="leaky02"))
-            enc.append(o)
-        a, b = enc
+        Bn = x1.shape[0]
+        xin = torch.cat([ops.nchw_to_nhwc(x1.contiguous().float(), 4), ops.nchw_to_nhwc(x2.contiguous().float(), 4)], 0)
+        o = [ops.conv2d([xin], *P["en_1"], c, 3, pad=1, groups=2)]
+        chans = {2: (c, 2 * c), 3: (2 * c, 4 * c), 4: (4 * c, 8 * c), 5: (8 * c, 8 * c)}
+        for lvl in (2, 3, 4, 5):
+            ci, co = chans[lvl]
+            t = ops.conv2d([o[-1]], *P["en_%d.a" % lvl], ci, 4, stride=2, pad=3, dil=2, pro_act="leaky02", groups=2)
+            o.append(ops.conv2d([t], *P["en_%d.b" % lvl], co, 3, pad=1, pro_act="leaky02", groups=2))
+        o.append(ops.conv2d([o[-1]], *P["en_6"], 8 * c, 4, stride=2, pad=1, pro_act="leaky02", groups=2))
+        a, b = [t[:Bn] for t in o], [t[Bn:] for t in o]          # batch halves: contiguous views
         bott = torch.cat([a[5], b[5]], dim=3)  # (B,1,4,16c) tiny concat feeding the gate (device memory plumbing)
         gated = ops.se_gate(bott, self.fc_1.weight, self.fc_1.bias, self.fc_2.weight, self.fc_2.bias)
         d = ops.convT_s2k4([gated], P["de_6"], 8 * c, pro_act="relu")

@@ -221,11 +221,26 @@ def conv_desc(inputs, k, stride=1, pad=0, dil=1, cout=0, pro_act="none", affine=
 
 
 def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", epi_act="none", slope=0.0, res=None,
-           affine=None, out=None, out_nchw=False, pixel_shuffle=False, stats=None, phase=None, geom=None, out_coff=None):
+           affine=None, out=None, out_nchw=False, pixel_shuffle=False, stats=None, phase=None, geom=None, out_coff=None, groups=1):
     """inputs: list of 1..3 NHWC tensors (channel-concatenated on the fly).  k: int or (KH, KW).
     phase=(py, px): one output phase of ConvTranspose2d(4,2,1) (k=2, dil=-1, pad=-phase).
-    affine: optional list of (scale, shift) per input segment."""
+    affine: optional list of (scale, shift) per input segment.
+    groups=2: wp (2, Cout, Kp) / bias (2, Cout) -- images [B/2, B) are convolved with the second weight set (the CMM's twin
+    encoder branches in one launch); falls back to two launches over the batch halves when a half does not fill whole
+    128-pixel row tiles."""
+    if groups == 2:
+        B0, h = inputs[0].shape[0], inputs[0].shape[0] // 2
+        d0 = conv_desc(inputs, k, stride, pad, dil, cout, pro_act, affine, phase, geom)
+        if B0 % 2 or (h * d0.Hp * d0.Wp) % 128 or stats is not None or res is not None or out_nchw or pixel_shuffle:
+            assert out is None and out_coff is None and B0 % 2 == 0
+            outs = [conv2d([t[g * h:(g + 1) * h] for t in inputs], wp[g], None if bias is None else bias[g], cout, k, stride, pad, dil,
+                           pro_act, epi_act, slope, None if res is None else res[g * h:(g + 1) * h], affine, None, out_nchw,
+                           pixel_shuffle, stats, phase, geom) for g in range(2)]
+            return torch.cat(outs, 0)
     d = conv_desc(inputs, k, stride, pad, dil, cout, pro_act, affine, phase, geom)
+    if groups == 2:
+        assert wp.dim() == 3 and wp.is_contiguous() and (bias is None or (bias.dim() == 2 and bias.is_contiguous()))
+        d.groups, d.w_group_stride = 2, wp.shape[1] * wp.shape[2]
     B = d.B
     Ho, Wo = d.Hout, d.Wout
     d.epi_act, d.slope = ACT[epi_act], float(slope)

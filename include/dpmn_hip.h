@@ -123,6 +123,10 @@ typedef struct {
                               * phase p = 2*py+px reads w + p*w_phase_stride, pad = -(py,px), writes output pixels
                               * (2y+py, 2x+px); pad_y/pad_x/ooy/oox of the descriptor are ignored */
   long w_phase_stride;       /* floats between consecutive packed phase weights */
+  int groups;                /* 0/1: one weight set.  2: images [B/2, B) use w + w_group_stride and bias + Cout -- the twin
+                              * encoder branches of the CMM (cmm.py:86-99: same shapes, own weights) in one launch; needs an
+                              * even B, no stats, and (implicit-GEMM path) B/2*Hp*Wp % 128 == 0 */
+  long w_group_stride;
 } dpmn_conv_desc;
 int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream);
 /* layout plumbing at the module boundary: NCHW images <-> NHWC (channels zero-padded to Cpad) */
