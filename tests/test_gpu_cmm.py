@@ -180,3 +180,28 @@ def test_cmm_module_batch48_vs_oracle(dev):
     with torch.no_grad():
         out = m(x1.to(dev), x2.to(dev))
     assert_close(out, ref, 2e-4, 2e-4, "CMM B=48 vs oracle")
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,B,H,W", [
+    (64, 64, 4, 2, 3, 2, 4, 32, 128),     # grouped implicit GEMM, 64x64 tiles (EncodeBlock first conv, cmm.py:44)
+    (128, 128, 4, 2, 3, 2, 8, 16, 64),    # grouped 128x128 tiles
+    (64, 128, 3, 1, 1, 1, 4, 16, 64),     # grouped halo kernel (the tile's image picks the weights)
+    (256, 512, 4, 2, 1, 1, 16, 8, 32),    # grouped split-K (M = 1024 pixels, K = 4096)
+    (4, 64, 3, 1, 1, 1, 2, 32, 128),      # en_1: 4 padded input channels (generic loader)
+    (512, 512, 4, 2, 1, 1, 6, 2, 8),      # half a batch = 12 pixels: not whole row tiles -> two launches over the halves
+])
+def test_conv2d_two_groups_equals_two_convs(dev, cin, cout, k, stride, pad, dil, B, H, W):
+    """groups = 2 (the twin encoder branches of cmm.py:86-99 in one launch): images [B/2, B) use the second weight set."""
+    from dpmn_amd import ops
+    from dpmn_amd.model import packing
+    x = u("gx", (B, cin, H, W))
+    ws = [u("gw%d" % g, (cout, cin, k, k), -1, 1) * (1.0 / (cin * k * k) ** 0.5) for g in range(2)]
+    bs = [u("gb%d" % g, (cout,)) for g in range(2)]
+    h = B // 2
+    ref = torch.cat([F.conv2d(F.leaky_relu(x[g * h:(g + 1) * h], 0.2), ws[g], bs[g], stride=stride, padding=pad, dilation=dil)
+                     for g in range(2)], 0)
+    packs = [packing.pack_conv(ws[g].to(dev), bs[g].to(dev)) for g in range(2)]
+    wp = torch.stack([p[0] for p in packs]).contiguous()
+    bp = torch.stack([p[1] for p in packs]).contiguous()
+    got = ops.conv2d([nhwc(x).to(dev)], wp, bp, cout, k, stride=stride, pad=pad, dil=dil, pro_act="leaky02", groups=2)
+    assert_close(got.permute(0, 3, 1, 2), ref, ATOL, RTOL, "grouped conv %s" % ((cin, cout, k, stride, pad, dil),))
