@@ -52,6 +52,7 @@ struct ConvArgs {
   int groups;                 // 2: the batch holds two independent halves (the CMM's twin encoder branches, cmm.py:86-99): pixels
   int m_per_group;            //    m >= m_per_group use w + wgs and bias + Cout -- one launch, twice the tiles, half the split-K
   long wgs;
+  int wlocal;                 // implicit GEMM: 1 = blocks that share a weight slice (same n tile, same k split) are dealt to ONE XCD
 };
 __device__ __forceinline__ int conv_group_of(const ConvArgs& a, int m) { return (a.groups > 1 && m >= a.m_per_group) ? 1 : 0; }
 
@@ -163,8 +164,24 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.B * a.Hp * a.Wp;
-  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
-  const PhaseSel ph = conv_select_phase(a, blockIdx.z, m_blk);      // (a tile never straddles the two groups: checked at launch)
+  // Workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD with its own L2.  With the natural order the row tiles
+  // that share one (n tile, k split) weight slice land on 8 different XCDs and every one of them pulls the slice from HBM: the
+  // deep CMM levels (12-48 row tiles against 17-28 MB of weights) fetched 4x their compulsory bytes.  wlocal: XCD c owns the
+  // slices nz = c, c + 8, ... and walks their row tiles back to back.  nz counts the k split FASTEST (nz = z + Z n): the n tiles
+  // of one k split read the same input slice, and with Z a multiple of 8 they all sit on one XCD (in general on
+  // min(n tiles, 8 / gcd(Z, 8)) of them).
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.wlocal) {
+    const int L = bx + gridDim.x * (by + gridDim.y * bz);
+    const int c = L & 7, j = L >> 3;
+    const int jm = j / (int)gridDim.x;
+    bx = j - jm * (int)gridDim.x;
+    const int nz = c + 8 * jm;
+    by = nz / (int)gridDim.z;
+    bz = nz - by * (int)gridDim.z;
+  }
+  const int m_blk = bx * BM, n_blk = by * BN;
+  const PhaseSel ph = conv_select_phase(a, bz, m_blk);      // (a tile never straddles the two groups: checked at launch)
   const int zsplit = ph.zsplit;
   const int lrow = tid / TPR, lcol = (tid % TPR) * 4;
 
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     if (pb[p] < 0) { py[p] = -(1 << 20); px[p] = -(1 << 20); }
   }
   // chunk decode state (scalars): advanced by one 32-channel chunk per call instead of two integer divisions per chunk
-  int u_tap = 0, u_c0 = 0, u_ky = 0, u_kx = 0, u_k0 = -1;
+  int u_tap = 0, u_c0 = 0, u_ky = 0, u_kx = 0, u_k0 = -2;      // (-2: the first call always decodes)
   int wofs[BPASS];
 #pragma unroll
   for (int p = 0; p < BPASS; ++p) wofs[p] = ((n_blk + lrow + p * RPP) * a.Kp + lcol) * 4;      // + k0 * 4 through the scalar offset
@@ -306,15 +323,23 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     }
   }
   const __amdgpu_buffer_rsrc_t s_wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ph.w), 0, a.Cout * a.Kp * 4, 0x00020000);
-  auto gload_simple = [&](int k0) {
-    if (k0 == u_k0 + BK) {
-      u_c0 += BK;
-      if (u_c0 >= a.cin) { u_c0 = 0; ++u_tap; if (++u_kx == a.KW) { u_kx = 0; ++u_ky; } }
-    } else if (k0 != u_k0) {
-      u_tap = k0 / a.cin; u_c0 = k0 - u_tap * a.cin;
+  // The chunks are VISITED channel-chunk-major, tap-minor (step kt = cchunk * taps + tap; the packed layout stays tap-major, the
+  // weight column of a step is k0 = tap * cin + cchunk * 32): the taps of one 32-channel chunk re-read the same pixels a few
+  // steps apart, while they are still in L2.  In tap-major order a block swept ALL channels of a tap (393 KB per block on the
+  // 768-channel decoder convs, x 64 resident blocks per XCD against 4 MB of L2) before coming back to the same pixels for the
+  // next tap, and the input went over the fabric once per tap.  A k split is a contiguous range of steps = a channel range.
+  auto gload_simple = [&](int kt_) {
+    if (kt_ == u_k0 + 1) {
+      ++u_tap;
+      if (++u_kx == a.KW) { u_kx = 0; ++u_ky; }
+      if (u_tap == ktaps) { u_tap = 0; u_ky = 0; u_c0 += BK; }
+    } else if (kt_ != u_k0) {
+      const int cch = kt_ / ktaps;
+      u_tap = kt_ - cch * ktaps; u_c0 = cch * BK;
       u_ky = u_tap / a.KW; u_kx = u_tap - u_ky * a.KW;
     }
-    u_k0 = k0;
+    u_k0 = kt_;
+    const int k0 = u_tap * a.cin + u_c0;
     const int seg = u_c0 >= c01 ? 2 : (u_c0 >= a.cseg[0] ? 1 : 0);
     const int cs = seg == 2 ? a.cseg[2] : (seg == 1 ? a.cseg[1] : a.cseg[0]);
     if (seg != s_seg) {                                       // wave-uniform, once per segment change
@@ -425,7 +450,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   const int kt0 = zsplit * cps;
   const int nk = min(nk_all, kt0 + cps);
   if (kt0 < nk) {
-    if (SIMPLE) { gload_simple(kt0 * BK); sstore_simple(0); }
+    if (SIMPLE) { gload_simple(kt0); sstore_simple(0); }
     else {
       if (UNI) gload_uni(kt0 * BK); else gload(kt0 * BK);
       sstore(0);
@@ -434,7 +459,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   __syncthreads();
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = (kt - kt0) & 1;
-    if (SIMPLE) gload_simple(min(kt + 1, nk - 1) * BK);
+    if (SIMPLE) gload_simple(min(kt + 1, nk - 1));
     else if (UNI) gload_uni(min(kt + 1, nk - 1) * BK);      // unconditional: the refill past the end re-reads the last chunk
     else if (kt + 1 < nk) gload((kt + 1) * BK);
     // hipcc otherwise sinks the buffer loads deep into the MFMA block (the last ones ~100 MFMAs down): they must be in
@@ -506,7 +531,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
         q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
         if (lr == 0 && n + r < a.Cout) {
-          float* st = a.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;   // slotted: spreads same-address atomics
+          float* st = a.stats + (size_t)(bx % STAT_SLOTS) * 2 * a.Cout;   // slotted: spreads same-address atomics
           atomicAdd(st + n + r, s);
           atomicAdd(st + a.Cout + n + r, q);
         }
@@ -1027,6 +1052,13 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   a.ksplit = S;
   a.partial = S > 1 ? ws : nullptr;
   dim3 grid(cdiv(M, BM), cdiv(a.Cout, BN), S * nph);
+  {
+    // weight-local XCD mapping when re-reading the weights per row tile costs more than re-reading the input per column tile
+    static const int wlocal_on = getenv("DPMN_CONV_WLOCAL") ? atoi(getenv("DPMN_CONV_WLOCAL")) : 1;
+    const double w_reread = (double)a.Cout * a.Kp * nph * (a.groups > 1 ? 2 : 1) * (grid.x > 8 ? 8 : grid.x);
+    const double x_reread = (double)a.B * a.Hin * a.Win * a.cin * (grid.y > 8 ? 8 : grid.y);
+    a.wlocal = wlocal_on && ((grid.y * grid.z) % 8 == 0) && grid.x > 1 && w_reread > x_reread;
+  }
   // segment-uniform chunks (all channel counts multiples of 32) and 32-bit byte offsets: the buffer-load instantiation
   static const int uni_on = getenv("DPMN_CONV_UNI") ? atoi(getenv("DPMN_CONV_UNI")) : 1;
   bool uni = uni_on && a.cin % 32 == 0 && (size_t)a.Cout * a.Kp * 4 < (1ull << 31);
