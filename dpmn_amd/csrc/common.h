@@ -30,10 +30,12 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e. fp32 round-off class) -- branch-free, ~12 VALU ops
 // instead of libm erff's ~50; exact GELU (nn.GELU default, not the tanh approximation) to 2e-7 * |x|.
 __device__ __forceinline__ float erf_as(float x) {
+  // (v_rcp_f32, 1 ulp, instead of the ~10-instruction IEEE division, and explicit fmas under -ffp-contract=off: both far inside
+  // the 1.5e-7 of the approximation itself; the GELU epilogue of the K = 96 GEMMs is paid in MFMA issue time)
   const float ax = fabsf(x);
-  const float t = 1.0f / (1.0f + 0.3275911f * ax);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float r = 1.0f - poly * __expf(-ax * ax);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float r = fmaf(-poly, __expf(-ax * ax), 1.0f);
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
