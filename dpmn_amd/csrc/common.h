@@ -49,6 +49,9 @@ __device__ __forceinline__ float mish_f(float x) {
   return x * (n / (n + 2.0f));
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+// hardware-transcendental forms for latency chains (the GRU recurrence): v_exp_f32 + v_rcp_f32, abs error ~1e-7
+__device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) { return fmaf(2.0f, __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)), -1.0f); }
 
 // activation codes shared by GEMM / conv epilogues and conv prologues
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_LEAKY02 = 3, ACT_LEAKY001 = 4, ACT_MISH = 5, ACT_PRELU = 6,

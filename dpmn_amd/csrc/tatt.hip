@@ -62,17 +62,19 @@ __global__ __launch_bounds__(256) void k_bigru(const float* __restrict__ gi, con
     for (int k = 0; k < HID; k += 8) {
       const float4 h0 = *reinterpret_cast<const float4*>(hp + k);
       const float4 h1 = *reinterpret_cast<const float4*>(hp + k + 4);
-      ar0 += wr[k] * h0.x + wr[k + 1] * h0.y + wr[k + 2] * h0.z + wr[k + 3] * h0.w;
-      az0 += wz[k] * h0.x + wz[k + 1] * h0.y + wz[k + 2] * h0.z + wz[k + 3] * h0.w;
-      an0 += wn[k] * h0.x + wn[k + 1] * h0.y + wn[k + 2] * h0.z + wn[k + 3] * h0.w;
-      ar1 += wr[k + 4] * h1.x + wr[k + 5] * h1.y + wr[k + 6] * h1.z + wr[k + 7] * h1.w;
-      az1 += wz[k + 4] * h1.x + wz[k + 5] * h1.y + wz[k + 6] * h1.z + wz[k + 7] * h1.w;
-      an1 += wn[k + 4] * h1.x + wn[k + 5] * h1.y + wn[k + 6] * h1.z + wn[k + 7] * h1.w;
+      // explicit fmas (the file is built with -ffp-contract=off): 96 instead of 192 vector instructions on the step's critical path
+      ar0 = fmaf(wr[k + 3], h0.w, fmaf(wr[k + 2], h0.z, fmaf(wr[k + 1], h0.y, fmaf(wr[k], h0.x, ar0))));
+      az0 = fmaf(wz[k + 3], h0.w, fmaf(wz[k + 2], h0.z, fmaf(wz[k + 1], h0.y, fmaf(wz[k], h0.x, az0))));
+      an0 = fmaf(wn[k + 3], h0.w, fmaf(wn[k + 2], h0.z, fmaf(wn[k + 1], h0.y, fmaf(wn[k], h0.x, an0))));
+      ar1 = fmaf(wr[k + 7], h1.w, fmaf(wr[k + 6], h1.z, fmaf(wr[k + 5], h1.y, fmaf(wr[k + 4], h1.x, ar1))));
+      az1 = fmaf(wz[k + 7], h1.w, fmaf(wz[k + 6], h1.z, fmaf(wz[k + 5], h1.y, fmaf(wz[k + 4], h1.x, az1))));
+      an1 = fmaf(wn[k + 7], h1.w, fmaf(wn[k + 6], h1.z, fmaf(wn[k + 5], h1.y, fmaf(wn[k + 4], h1.x, an1))));
     }
     __builtin_amdgcn_wave_barrier();
-    const float r = sigmoid_f(g4[0] + ar0 + ar1);
-    const float z = sigmoid_f(g4[1] + az0 + az1);
-    const float n = tanhf(g4[2] + r * (an0 + an1));
+    // v_exp / v_rcp gates: libm expf / tanhf and the IEEE divisions were ~100 dependent instructions per step of a pure latency chain
+    const float r = sigmoid_fast(g4[0] + ar0 + ar1);
+    const float z = sigmoid_fast(g4[1] + az0 + az1);
+    const float n = tanh_fast(g4[2] + r * (an0 + an1));
     h = (1.f - z) * n + z * h;
     if (active) {
       const long pix = base + (long)(dir ? T - 1 - t : t) * step_stride;
