@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
       for (int d = 0; d < D; ++d) { a += qv[d] * kr[d]; dp += go[d] * vr[d]; }
       a += tbl[((il - m / WS + WS - 1) * (2 * WS - 1) + (jl - m % WS + WS - 1)) * 2 + head];
       if (shift > 0 && reg_s[krow0 + m] != my_reg) a += -100.0f;
-      const float p = expf(a - mx);
+      const float p = __expf(a - mx);
       den += p;
       if (DROP) dp *= drop_scale(seed, (mrow0 + t0 + lane) * N + m, p_drop, inv_keep);
       dlt += p * dp;                                    // sum_m P dP = dO . O
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
       a += tbl[((il - m / WS + WS - 1) * (2 * WS - 1) + (jl - m % WS + WS - 1)) * 2 + head];
       if (shift > 0 && reg_s[krow0 + m] != my_reg) a += -100.0f;
       if (DROP) dp *= drop_scale(seed, (mrow0 + t0 + lane) * N + m, p_drop, inv_keep);
-      const float ds = expf(a - mx) * inv * (dp - dlt);
+      const float ds = __expf(a - mx) * inv * (dp - dlt);
 #pragma unroll
       for (int d = 0; d < D; ++d) dqa[d] += ds * kr[d];
     }
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
       const int tix = ((n / WS - il + WS - 1) * (2 * WS - 1) + (n % WS - jl + WS - 1)) * 2 + head;
       a += tbl[tix];
       if (shift > 0 && reg_s[krow0 + n] != my_reg) a += -100.0f;
-      const float p = expf(a - smax[krow0 + n]) * sinv[krow0 + n];
+      const float p = __expf(a - smax[krow0 + n]) * sinv[krow0 + n];
       const float mk = DROP ? drop_scale(seed, (mrow0 + t0 + krow0 + n) * N + nl, p_drop, inv_keep) : 1.0f;
       const float ds = p * (dp * mk - sdel[krow0 + n]);
       const float pv = p * mk;
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float p = expf(ps[t][qt][r] - mx); ps[t][qt][r] = p; den += p; }
+        for (int r = 0; r < 4; ++r) { const float p = __expf(ps[t][qt][r] - mx); ps[t][qt][r] = p; den += p; }
       den += __shfl_xor(den, 16, 64);
       den += __shfl_xor(den, 32, 64);
       const float inv = 1.0f / den;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
           const int nq = 16 * qt + 4 * kq + r, iq = nq / WS, jq = nq % WS;
           float a = ps[qt][t][r] + tbl[((iq - im + WS - 1) * (2 * WS - 1) + (jq - jm + WS - 1)) * 2 + head];
           if (shift > 0 && reg_s[nq] != key_reg) a += -100.0f;
-          const float p = expf(a - smax[nq]) * sinv[nq];
+          const float p = __expf(a - smax[nq]) * sinv[nq];
           const float mk = DROP ? drop_scale(seed, (mrow0 + t0 + nq) * N + m, p_drop, inv_keep) : 1.0f;
           ps[qt][t][r] = p * mk;                                 // P o M (what multiplies V in the forward)
           dp[qt][t][r] = p * (dp[qt][t][r] * mk - sdel[nq]);      // dS

@@ -222,13 +222,13 @@ __global__ __launch_bounds__(256) void k_window_attn(const float* __restrict__ q
       cmax = fmaxf(cmax, a);
     }
     const float nmx = fmaxf(mx, cmax);
-    const float resc = expf(mx - nmx);   // exp(-inf) = 0 on the first chunk
+    const float resc = __expf(mx - nmx);   // exp(-inf) = 0 on the first chunk
     den *= resc;
 #pragma unroll
     for (int d = 0; d < D; ++d) o[d] *= resc;
 #pragma unroll
     for (int mm = 0; mm < CH; ++mm) {
-      float p = expf(sc[mm] - nmx);
+      float p = __expf(sc[mm] - nmx);
       den += p;
       if (DROP) p *= drop_scale(seed, mrow + m0 + mm, p_drop, inv_keep);
       const float* vr = Vs + (krow0 + m0 + mm) * LDR + head * D;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_window_attn8_mfma(const float* __restri
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = expf(sacc[t][qt][r] - mx);
+        const float p = __expf(sacc[t][qt][r] - mx);
         sacc[t][qt][r] = p;
         den += p;
       }
