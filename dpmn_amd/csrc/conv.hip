@@ -976,6 +976,101 @@ __global__ __launch_bounds__(256) void k_conv_halo_c4(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------- direct conv for <= 16 x <= 16 channels
+// The DistillModule convs (4/8 -> 4 channels over 196608 pixels, distill_module.py:9-12), their data gradients and the
+// 12 -> 12 tail convs of the PGRM: a few hundred MACs per pixel.  On the MFMA tiles these are 1-6 % utilised and latency /
+// atomic bound (25 us each; 95 us with BatchNorm statistics: 1536 blocks x 4 waves of same-address atomics).  Here one thread
+// owns one output pixel and all its channels; the weights are wave-uniform, so hipcc reads them with scalar loads and feeds
+// them to the FMAs as SGPR operands -- no LDS, no MFMA.  Prologue (affine + activation, zero outside the image) and epilogue
+// (conv_store) are the implicit-GEMM path's; the statistics are reduced over the block before ONE atomic per channel.
+template <int NG>      // channel quads of the output (Cout <= 4 NG)
+__global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
+  __shared__ float red[4][NG * 8];
+  const int M = a.B * a.Hp * a.Wp;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  const bool live = m < M;
+  const int mm = live ? m : M - 1;
+  const int b = mm / (a.Hp * a.Wp), rr = mm - b * (a.Hp * a.Wp);
+  const int py = rr / a.Wp, px = rr - py * a.Wp;
+  const int iy0 = py * a.stride - a.pad_y, ix0 = px * a.stride - a.pad_x;
+  float acc[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[g][r] = 0.f;
+  int cbase = 0;
+  for (int seg = 0; seg < 3; ++seg) {
+    const int cs = a.cseg[seg];
+    if (cs == 0) continue;
+    const float* src = a.in[seg];
+    const float* sc = a.in_scale[seg];
+    const float* sh = a.in_shift[seg];
+    for (int ky = 0; ky < a.KH; ++ky) {
+      const int iy = iy0 + ky * a.dil_y;
+      for (int kx = 0; kx < a.KW; ++kx) {
+        const int ix = ix0 + kx * a.dil_x;
+        const bool ok = live && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+        const int iyc = min(max(iy, 0), a.Hin - 1), ixc = min(max(ix, 0), a.Win - 1);
+        const float* xp = src + ((size_t)(b * a.Hin + iyc) * a.Win + ixc) * cs;
+        const int k0 = (ky * a.KW + kx) * a.cin + cbase;
+        for (int c4 = 0; c4 < cs; c4 += 4) {
+          float4 x = *reinterpret_cast<const float4*>(xp + c4);
+          if (sc) {
+            const float4 s4 = *reinterpret_cast<const float4*>(sc + c4), h4 = *reinterpret_cast<const float4*>(sh + c4);
+            x.x = x.x * s4.x + h4.x; x.y = x.y * s4.y + h4.y; x.z = x.z * s4.z + h4.z; x.w = x.w * s4.w + h4.w;
+          }
+          if (a.pro_act != ACT_NONE) {
+            float v4[4] = {x.x, x.y, x.z, x.w};
+            apply_act4(v4, a.pro_act, 0.f);
+            x = make_float4(v4[0], v4[1], v4[2], v4[3]);
+          }
+          if (!ok) x = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = min(g * 4 + r, a.Cout - 1);                                   // (uniform: scalar loads)
+              const float4 w4 = *reinterpret_cast<const float4*>(a.w + (size_t)co * a.Kp + k0 + c4);
+              acc[g][r] += x.x * w4.x + x.y * w4.y + x.z * w4.z + x.w * w4.w;
+            }
+        }
+      }
+    }
+    cbase += cs;
+  }
+  float ssum[NG][4], ssq[NG][4];
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { ssum[g][r] = 0.f; ssq[g][r] = 0.f; }
+  if (live) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+      if (g * 4 < a.Cout) conv_store(a, m, g * 4, acc[g], ssum[g], ssq[g], a.ooy, a.oox);
+  }
+  if (a.stats) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s_ = ssum[g][r], q = ssq[g][r];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { s_ += __shfl_xor(s_, o, 64); q += __shfl_xor(q, o, 64); }
+        if (lane == 0) { red[wave][g * 8 + r] = s_; red[wave][g * 8 + 4 + r] = q; }
+      }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < NG * 8) {
+      const int g = t >> 3, r = t & 3, sq = (t >> 2) & 1, n = g * 4 + r;
+      if (n < a.Cout) {
+        float* st = a.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
+        atomicAdd(st + (sq ? a.Cout : 0) + n, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+      }
+    }
+  }
+}
+
 static inline double conv_flops(const ConvArgs& a) {
   return 2.0 * a.B * a.Hp * a.Wp * (a.nphase > 1 ? a.nphase : 1) * (double)a.Cout * a.KH * a.KW * a.cin;
 }
@@ -1160,6 +1255,19 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
                        (size_t)a.B * a.Hin * a.Win * (size_t)cin * 4 < (1ull << 31);   // 32-bit buffer-load offsets
   // too few 8x16-pixel tiles to fill 256 CUs (deep decoder levels with 3-segment inputs): split-K implicit GEMM instead
   const bool halo_starved = (M / 128) * cdiv(a.Cout, 64) < 256 && a.Cout >= 128 && ws != nullptr;
+  static const bool direct_on = !(getenv("DPMN_CONV_DIRECT") && atoi(getenv("DPMN_CONV_DIRECT")) == 0);
+  // (measured: 8 -> 4 with statistics 95 -> 20 us, 4 -> 4 25 -> 12 us; 12 -> 12 over 49152 pixels 22 -> 37 us -- too few,
+  //  too heavy threads -- so the rule is cin * Cout <= 64)
+  if (direct_on && cin <= 16 && a.Cout <= 16 && cin * a.Cout <= 64 && a.nphase == 1 && a.groups == 1 && !a.pixel_shuffle && M >= 4096) {
+    ProfScope prof(PT_CONV_IGEMM_NARROW, st, conv_flops(a), conv_bytes(a));
+    const dim3 grid(cdiv(M, 256));
+    if (a.Cout <= 4) hipLaunchKernelGGL(k_conv_direct<1>, grid, dim3(256), 0, st, a);
+    else if (a.Cout <= 8) hipLaunchKernelGGL(k_conv_direct<2>, grid, dim3(256), 0, st, a);
+    else if (a.Cout <= 12) hipLaunchKernelGGL(k_conv_direct<3>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_conv_direct<4>, grid, dim3(256), 0, st, a);
+    DPMN_CHECK_LAUNCH();
+    return DPMN_OK;
+  }
   static const bool c4_on = !(getenv("DPMN_CONV_C4") && atoi(getenv("DPMN_CONV_C4")) == 0);
   if (halo_ok && a.Cout <= 4 && c4_on && !a.pixel_shuffle && !a.res && a.groups == 1)
     return a.KH == 3 ? launch_halo_c4<3, 8>(a, st) : launch_halo_c4<9, 8>(a, st);   // (3x3: 4- and 16-row tiles measured no better)

@@ -205,3 +205,37 @@ def test_conv2d_two_groups_equals_two_convs(dev, cin, cout, k, stride, pad, dil,
     bp = torch.stack([p[1] for p in packs]).contiguous()
     got = ops.conv2d([nhwc(x).to(dev)], wp, bp, cout, k, stride=stride, pad=pad, dil=dil, pro_act="leaky02", groups=2)
     assert_close(got.permute(0, 3, 1, 2), ref, ATOL, RTOL, "grouped conv %s" % ((cin, cout, k, stride, pad, dil),))
+
+
+@pytest.mark.parametrize("segs,cout,act,affine,stats,B,H,W", [
+    ((4, 4), 4, "leaky02", True, True, 2, 32, 128),     # DistillModule conv on cat(deep, shallow) (distill_module.py:9) + BN statistics
+    ((4,), 4, "none", False, True, 2, 32, 128),
+    ((4,), 12, "relu", False, False, 3, 16, 64),        # three output quads
+    ((8, 4, 4), 4, "none", True, False, 2, 16, 64),     # three segments, 16 input channels
+    ((4,), 16, "none", False, True, 2, 16, 64),         # four output quads + statistics
+    ((8,), 8, "leaky02", False, False, 2, 16, 64),      # two output quads
+    ((4,), 3, "none", False, False, 2, 32, 128),        # Cout not a multiple of 4
+    ((12,), 12, "relu", False, False, 3, 16, 64),       # PGRM 12 -> 12 tail conv: cin * Cout > 64 stays on the MFMA tiles
+])
+def test_conv2d_direct_small_channels(dev, segs, cout, act, affine, stats, B, H, W):
+    """k_conv_direct (cin * Cout <= 64, one thread per pixel): prologue affine + activation with exact-zero padding,
+    conv_store epilogue, block-reduced BatchNorm statistics."""
+    from dpmn_amd import ops
+    from dpmn_amd.model import packing
+    cin = sum(segs)
+    xs = [u("dx%d" % i, (B, c, H, W)) for i, c in enumerate(segs)]
+    aff = [(u("ds%d" % i, (c,), 0.5, 1.5), u("dh%d" % i, (c,), -0.5, 0.5)) for i, c in enumerate(segs)] if affine else None
+    w = u("dw", (cout, cin, 3, 3), -1, 1) * (1.0 / (cin * 9) ** 0.5)
+    b = u("db", (cout,))
+    pre = torch.cat([x * aff[i][0][None, :, None, None] + aff[i][1][None, :, None, None] if affine else x for i, x in enumerate(xs)], 1)
+    pre = {"none": lambda t_: t_, "relu": F.relu, "leaky02": lambda t_: F.leaky_relu(t_, 0.2)}[act](pre)
+    ref = F.conv2d(pre, w, b, padding=1)
+    wp, bp = packing.pack_conv(w.to(dev), b.to(dev))
+    st = torch.zeros(32, 2, cout, device=dev) if stats else None
+    got = ops.conv2d([nhwc(x).to(dev) for x in xs], wp, bp, cout, 3, pad=1, pro_act=act,
+                     affine=None if not affine else [(s.to(dev), h.to(dev)) for s, h in aff], stats=st)
+    assert_close(got.permute(0, 3, 1, 2), ref, ATOL, RTOL, "direct conv %s" % (segs,))
+    if stats:
+        s12 = st.sum(0).cpu()
+        assert_close(s12[0], ref.sum((0, 2, 3)), 2e-2, 1e-4, "stats sum")
+        assert_close(s12[1], (ref * ref).sum((0, 2, 3)), 2e-2, 1e-4, "stats sumsq")
