@@ -186,15 +186,24 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   const int lrow = tid / TPR, lcol = (tid % TPR) * 4;
 
   // per-thread pixel rows of the A tile
+  // (m -> image, row, column through one float multiply and a +-1 fix-up each, exact below 2^24 pixels -- checked at launch:
+  //  eight 32-bit integer divisions per thread were a third of the block prologue, paid by every short split-K block)
   int pb[APASS], py[APASS], px[APASS];
+  const int HWp = a.Hp * a.Wp;
+  const float inv_hw = 1.0f / (float)HWp, inv_w = 1.0f / (float)a.Wp;
 #pragma unroll
   for (int p = 0; p < APASS; ++p) {
     const int m = m_blk + lrow + p * RPP;
     if (m < M) {
-      const int b = m / (a.Hp * a.Wp), r = m % (a.Hp * a.Wp);
+      int b = (int)((float)m * inv_hw), r = m - b * HWp;
+      if (r < 0) { --b; r += HWp; }
+      if (r >= HWp) { ++b; r -= HWp; }
+      int y = (int)((float)r * inv_w), x = r - y * a.Wp;
+      if (x < 0) { --y; x += a.Wp; }
+      if (x >= a.Wp) { ++y; x -= a.Wp; }
       pb[p] = b;
-      py[p] = (r / a.Wp) * a.stride - ph.pad_y;
-      px[p] = (r % a.Wp) * a.stride - ph.pad_x;
+      py[p] = y * a.stride - ph.pad_y;
+      px[p] = x * a.stride - ph.pad_x;
     } else {
       pb[p] = -1; py[p] = 0; px[p] = 0;
     }
@@ -1125,6 +1134,8 @@ int launch_halo(const ConvArgs& a, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
+  if ((long)a.B * a.Hp * a.Wp >= (1L << 24))
+    return dpmn_set_error(DPMN_ERR_ARG, "conv2d: the implicit-GEMM path decodes pixel indices in fp32 (B*Hp*Wp must be below 2^24)");
   if (a.groups == 2 && a.m_per_group % BM != 0)
     return dpmn_set_error(DPMN_ERR_ARG, "conv2d: groups = 2 needs the pixels of one half to fill whole row tiles (B/2*Hp*Wp % 128 == 0)");
   const int M = a.B * a.Hp * a.Wp;

@@ -604,6 +604,8 @@ int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy,
     attr_set = true;
   }
   const int tiles = cdiv(M, BM), ny = cdiv(N, WS_BN);
+  static const int force_blocks = getenv("DPMN_WSTAT_BLOCKS") ? atoi(getenv("DPMN_WSTAT_BLOCKS")) : 0;      // experiment knob
+  if (force_blocks > 0) target_blocks = force_blocks;
   int gx = target_blocks / ny;
   if (gx < 1) gx = 1;
   if (gx > tiles) gx = tiles;
