@@ -1283,6 +1283,10 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   if (halo_ok && a.Cout <= 4 && c4_on && !a.pixel_shuffle && !a.res && a.groups == 1)
     return a.KH == 3 ? launch_halo_c4<3, 8>(a, st) : launch_halo_c4<9, 8>(a, st);   // (3x3: 4- and 16-row tiles measured no better)
   if (halo_ok && !halo_starved) {
+    // (128 output channels per block -- one halo staging instead of two, 64 MFMAs per tap and barrier -- measured 212-220 us
+    //  against 143-148 us on the 64 -> 128 / 64 -> 256 convs: rejected, switch kept for the record)
+    static const int bn128 = getenv("DPMN_HALO_BN128") ? atoi(getenv("DPMN_HALO_BN128")) : 0;
+    if (a.KH == 3 && bn128 && a.Cout % 128 == 0) return launch_halo<3, 128>(a, st);
     if (a.KH == 3) return a.Cout <= 16 ? launch_halo<3, 16>(a, st) : launch_halo<3, 64>(a, st);
     return a.Cout <= 16 ? launch_halo<9, 16>(a, st) : launch_halo<9, 64>(a, st);
   }
