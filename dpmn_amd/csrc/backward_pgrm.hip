@@ -495,9 +495,18 @@ __global__ void k_sk_feats_grad(const float* __restrict__ dout, const float* __r
 
 // ---------------------------------------------------------------------------------- depthwise 3x3 backward
 // per plane (b, c'): dP = full-correlation of dg with the kernel, dW[c'] += sum dg * shifted P, db[c'] += sum dg
+// Fused activation backward / forward around it (the Mlp chain fc1 -> GELU -> dwconv -> GELU -> pointwise, pgrm.py:31-37):
+//   gpre != NULL : dg is the gradient of GELU(conv output); it is multiplied by GELU'(gpre) on the way into the LDS tile
+//   in_gelu      : P is fc1's pre-activation, GELU is applied on load (the forward input of the conv)
+//   out_gelu_bwd : dP is multiplied by GELU'(P raw) before the store (the gradient of fc1's pre-activation); needs in_gelu
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
+  return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
 __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P, const float* __restrict__ dg,
                                                      const float* __restrict__ w, float* __restrict__ dP, float* __restrict__ dw,
-                                                     float* __restrict__ db, int Ch, int r, long planes) {
+                                                     float* __restrict__ db, int Ch, int r, long planes,
+                                                     const float* __restrict__ gpre = nullptr, int in_gelu = 0, int out_gelu_bwd = 0) {
   // per wave: P tile and dg tile, (r+2) rows x LD = r+8 floats, plane starting at column 4 (16-byte aligned rows, r % 4 == 0)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -512,8 +521,14 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P,
     const float* gs = dg + plane * r * r;
     for (int i = lane; i < r * r4; i += 64) {
       const int yy = i / r4, x4 = (i - yy * r4) * 4;
-      *reinterpret_cast<float4*>(tp + (yy + 1) * LD + 4 + x4) = *reinterpret_cast<const float4*>(ps + yy * r + x4);
-      *reinterpret_cast<float4*>(tg + (yy + 1) * LD + 4 + x4) = *reinterpret_cast<const float4*>(gs + yy * r + x4);
+      float4 pv = *reinterpret_cast<const float4*>(ps + yy * r + x4), gv = *reinterpret_cast<const float4*>(gs + yy * r + x4);
+      if (in_gelu) { pv.x = gelu_erf(pv.x); pv.y = gelu_erf(pv.y); pv.z = gelu_erf(pv.z); pv.w = gelu_erf(pv.w); }
+      if (gpre) {
+        const float4 q = *reinterpret_cast<const float4*>(gpre + plane * r * r + yy * r + x4);
+        gv.x *= gelu_grad(q.x); gv.y *= gelu_grad(q.y); gv.z *= gelu_grad(q.z); gv.w *= gelu_grad(q.w);
+      }
+      *reinterpret_cast<float4*>(tp + (yy + 1) * LD + 4 + x4) = pv;
+      *reinterpret_cast<float4*>(tg + (yy + 1) * LD + 4 + x4) = gv;
     }
     for (int i = lane; i < LD; i += 64) { tp[i] = 0.f; tp[(r + 1) * LD + i] = 0.f; tg[i] = 0.f; tg[(r + 1) * LD + i] = 0.f; }
     for (int i = lane; i < r; i += 64) {
@@ -551,6 +566,10 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P,
       aw[ky * 3 + 2] += gc.x * pm.y + gc.y * pm.z + gc.z * pm.w + gc.w * pr;
     }
     ab += (gc.x + gc.y) + (gc.z + gc.w);
+    if (out_gelu_bwd) {
+      const float4 q = *reinterpret_cast<const float4*>(P + plane * r * r + yy * r + x4);
+      a[0] *= gelu_grad(q.x); a[1] *= gelu_grad(q.y); a[2] *= gelu_grad(q.z); a[3] *= gelu_grad(q.w);
+    }
     *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
   }
 #pragma unroll
@@ -927,6 +946,19 @@ int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, floa
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_dwconv3x3_bwd_fused_f32(const float* P, const float* dg, const float* gpre, const float* w, float* dP, float* dw, float* db,
+                                 int in_gelu, int out_gelu_bwd, int B, int Ch, int r, dpmn_stream_t stream) {
+  DPMN_REQUIRE(P && dg && w && dP && dw && db && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_bwd_fused: plane side must be a multiple of 4 in [4, 64]");
+  DPMN_REQUIRE(!out_gelu_bwd || in_gelu, "dwconv_bwd_fused: out_gelu_bwd needs P to be the pre-activation (in_gelu)");
+  const long planes = (long)B * Ch;
+  const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+                     planes, gpre, in_gelu, out_gelu_bwd);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -474,9 +474,12 @@ __global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image
 
 // ---------------------------------------------------------------------------------- depthwise 3x3 + GELU
 // planes of r x r (raw reinterpretation of the (B, L, Ch) fc1 output, quirk Q2); one block per 4 planes
+// apply_gelu: 0 = g holds the conv output, 1 = g holds GELU(conv), 2 = g holds the conv output AND g2 holds GELU(conv) (the
+// training forward keeps the pre-activation for the backward: one pass instead of conv + a separate activation kernel);
+// in_gelu: the input is a pre-activation, GELU is applied on the way into the LDS tile (fc1's GELU, pgrm.py:33)
 __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ g, int Ch, int r,
-                                                      long planes, int apply_gelu) {
+                                                      long planes, int apply_gelu, float* __restrict__ g2 = nullptr, int in_gelu = 0) {
   // per wave: one r x r plane in an LDS tile of (r+2) rows x LD = r+8 floats; the plane starts at column 4 so that rows are
   // 16-byte aligned for float4 traffic (global loads / stores and the centre taps); r % 4 == 0
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -490,7 +493,9 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
     const float* src = y + plane * r * r;
     for (int i = lane; i < r * r4; i += 64) {
       const int yy = i / r4, x4 = (i - yy * r4) * 4;
-      *reinterpret_cast<float4*>(t + (yy + 1) * LD + 4 + x4) = *reinterpret_cast<const float4*>(src + yy * r + x4);
+      float4 v = *reinterpret_cast<const float4*>(src + yy * r + x4);
+      if (in_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+      *reinterpret_cast<float4*>(t + (yy + 1) * LD + 4 + x4) = v;
     }
     for (int i = lane; i < LD; i += 64) { t[i] = 0.f; t[(r + 1) * LD + i] = 0.f; }       // top / bottom halo rows
     for (int i = lane; i < r; i += 64) { t[(i + 1) * LD + 3] = 0.f; t[(i + 1) * LD + 4 + r] = 0.f; }   // left / right halo columns
@@ -515,6 +520,11 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
       a[1] += k0 * m.x + k1 * m.y + k2 * m.z;
       a[2] += k0 * m.y + k1 * m.z + k2 * m.w;
       a[3] += k0 * m.z + k1 * m.w + k2 * rr;
+    }
+    if (apply_gelu == 2) {
+      *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
+      *reinterpret_cast<float4*>(g2 + plane * r * r + yy * r + x4) = make_float4(gelu_erf(a[0]), gelu_erf(a[1]), gelu_erf(a[2]), gelu_erf(a[3]));
+      continue;
     }
     if (apply_gelu) {
 #pragma unroll
@@ -701,6 +711,18 @@ int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float*
   const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_dwconv3x3_train_f32(const float* y, const float* w, const float* bias, float* gpre, float* g, int in_gelu, int B, int Ch, int r,
+                             dpmn_stream_t stream) {
+  DPMN_REQUIRE(y && w && bias && gpre && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_train: plane side must be a multiple of 4 in [4, 64]");
+  const long planes = (long)B * Ch;
+  const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, gpre, Ch, r, planes, 2, g,
+                     in_gelu);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
