@@ -100,8 +100,8 @@ SIGNATURES = {
     "dpmn_sk_feats_grad_f32": (_i, [fp, fp, fp, fp, C.c_long, _i, _i, fp]),
     "dpmn_dwconv3x3_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, fp]),
-    "dpmn_dwconv3x3_train_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
-    "dpmn_dwconv3x3_bwd_fused_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_dwconv3x3_train_f32": (_i, [fp, fp, fp, fp, fp, _i, _f, _u64, _i, _i, _i, fp]),
+    "dpmn_dwconv3x3_bwd_fused_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _f, _u64, _i, _i, _i, fp]),
     "dpmn_pointwise_wgrad_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_elem_f32": (_i, [fp, _PP, _PP, _i, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_elem_bwd_f32": (_i, [fp, fp, _PP, _PP, _PP, _PP, _i, fp, _i, _i, _i, fp]),

@@ -506,7 +506,10 @@ __device__ __forceinline__ float gelu_grad(float x) {
 __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P, const float* __restrict__ dg,
                                                      const float* __restrict__ w, float* __restrict__ dP, float* __restrict__ dw,
                                                      float* __restrict__ db, int Ch, int r, long planes,
-                                                     const float* __restrict__ gpre = nullptr, int in_gelu = 0, int out_gelu_bwd = 0) {
+                                                     const float* __restrict__ gpre = nullptr, int in_gelu = 0, int out_gelu_bwd = 0,
+                                                     float p_drop = 0.f, unsigned long long seed = 0ull) {
+  // p_drop > 0: the forward input was dropout(GELU(P)) -- the same mask on load, and again on dP before GELU'
+  const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   // per wave: P tile and dg tile, (r+2) rows x LD = r+8 floats, plane starting at column 4 (16-byte aligned rows, r % 4 == 0)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -523,6 +526,11 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P,
       const int yy = i / r4, x4 = (i - yy * r4) * 4;
       float4 pv = *reinterpret_cast<const float4*>(ps + yy * r + x4), gv = *reinterpret_cast<const float4*>(gs + yy * r + x4);
       if (in_gelu) { pv.x = gelu_erf(pv.x); pv.y = gelu_erf(pv.y); pv.z = gelu_erf(pv.z); pv.w = gelu_erf(pv.w); }
+      if (p_drop > 0.f) {
+        const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
+        pv.x *= drop_scale(seed, e0, p_drop, inv_keep); pv.y *= drop_scale(seed, e0 + 1, p_drop, inv_keep);
+        pv.z *= drop_scale(seed, e0 + 2, p_drop, inv_keep); pv.w *= drop_scale(seed, e0 + 3, p_drop, inv_keep);
+      }
       if (gpre) {
         const float4 q = *reinterpret_cast<const float4*>(gpre + plane * r * r + yy * r + x4);
         gv.x *= gelu_grad(q.x); gv.y *= gelu_grad(q.y); gv.z *= gelu_grad(q.z); gv.w *= gelu_grad(q.w);
@@ -566,6 +574,11 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P,
       aw[ky * 3 + 2] += gc.x * pm.y + gc.y * pm.z + gc.z * pm.w + gc.w * pr;
     }
     ab += (gc.x + gc.y) + (gc.z + gc.w);
+    if (p_drop > 0.f) {
+      const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) a[q] *= drop_scale(seed, e0 + q, p_drop, inv_keep);
+    }
     if (out_gelu_bwd) {
       const float4 q = *reinterpret_cast<const float4*>(P + plane * r * r + yy * r + x4);
       a[0] *= gelu_grad(q.x); a[1] *= gelu_grad(q.y); a[2] *= gelu_grad(q.z); a[3] *= gelu_grad(q.w);
@@ -951,14 +964,15 @@ int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, floa
 }
 
 int dpmn_dwconv3x3_bwd_fused_f32(const float* P, const float* dg, const float* gpre, const float* w, float* dP, float* dw, float* db,
-                                 int in_gelu, int out_gelu_bwd, int B, int Ch, int r, dpmn_stream_t stream) {
+                                 int in_gelu, int out_gelu_bwd, float p_drop, unsigned long long seed, int B, int Ch, int r,
+                                 dpmn_stream_t stream) {
   DPMN_REQUIRE(P && dg && w && dP && dw && db && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_bwd_fused: plane side must be a multiple of 4 in [4, 64]");
   DPMN_REQUIRE(!out_gelu_bwd || in_gelu, "dwconv_bwd_fused: out_gelu_bwd needs P to be the pre-activation (in_gelu)");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
-                     planes, gpre, in_gelu, out_gelu_bwd);
+                     planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -479,7 +479,11 @@ __global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image
 // in_gelu: the input is a pre-activation, GELU is applied on the way into the LDS tile (fc1's GELU, pgrm.py:33)
 __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ g, int Ch, int r,
-                                                      long planes, int apply_gelu, float* __restrict__ g2 = nullptr, int in_gelu = 0) {
+                                                      long planes, int apply_gelu, float* __restrict__ g2 = nullptr, int in_gelu = 0,
+                                                      float p_drop = 0.f, unsigned long long seed = 0ull) {
+  // p_drop > 0 (with in_gelu): nn.Dropout between fc1's GELU and the conv (pgrm.py:34) -- the mask is a pure function of
+  // (seed, element index), so it is applied on load instead of through a materialised activated tensor
+  const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   // per wave: one r x r plane in an LDS tile of (r+2) rows x LD = r+8 floats; the plane starts at column 4 so that rows are
   // 16-byte aligned for float4 traffic (global loads / stores and the centre taps); r % 4 == 0
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -495,6 +499,11 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
       const int yy = i / r4, x4 = (i - yy * r4) * 4;
       float4 v = *reinterpret_cast<const float4*>(src + yy * r + x4);
       if (in_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+      if (p_drop > 0.f) {
+        const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
+        v.x *= drop_scale(seed, e0, p_drop, inv_keep); v.y *= drop_scale(seed, e0 + 1, p_drop, inv_keep);
+        v.z *= drop_scale(seed, e0 + 2, p_drop, inv_keep); v.w *= drop_scale(seed, e0 + 3, p_drop, inv_keep);
+      }
       *reinterpret_cast<float4*>(t + (yy + 1) * LD + 4 + x4) = v;
     }
     for (int i = lane; i < LD; i += 64) { t[i] = 0.f; t[(r + 1) * LD + i] = 0.f; }       // top / bottom halo rows
@@ -715,14 +724,14 @@ int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float*
   return DPMN_OK;
 }
 
-int dpmn_dwconv3x3_train_f32(const float* y, const float* w, const float* bias, float* gpre, float* g, int in_gelu, int B, int Ch, int r,
-                             dpmn_stream_t stream) {
+int dpmn_dwconv3x3_train_f32(const float* y, const float* w, const float* bias, float* gpre, float* g, int in_gelu, float p_drop,
+                             unsigned long long seed, int B, int Ch, int r, dpmn_stream_t stream) {
   DPMN_REQUIRE(y && w && bias && gpre && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_train: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, gpre, Ch, r, planes, 2, g,
-                     in_gelu);
+                     in_gelu, p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

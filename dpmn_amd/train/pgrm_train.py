@@ -232,15 +232,11 @@ def forward(m, x_q, x_kv, residuals, drop=None):
             s["x1"] = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"], res2=tkv)
         s["n2"] = layernorm(s["x1"], blk.norm2.weight, blk.norm2.bias)
         s["ypre"] = ops.linear(s["n2"], mlp.fc1.weight, mlp.fc1.bias)
-        # the two GELUs ride in the depthwise conv (on load / second output); with element dropout between fc1's GELU and the conv
-        # the activated tensor is materialised for the mask
-        if pd > 0:
-            s["y"] = act_fwd(s["ypre"])
-            ops.dropout(s["y"], pd, sb[2])
+        # the two GELUs and the element dropout between fc1's GELU and the conv ride in the depthwise conv (on load / second output)
         r = int(round(L ** 0.5))
         s["gpre"], s["g"] = _e(M, Ch, like=tkv), _e(M, Ch, like=tkv)
-        check(lib.dpmn_dwconv3x3_train_f32(dptr(s["y"] if pd > 0 else s["ypre"]), dptr(mlp.depthwise_conv.weight), dptr(mlp.depthwise_conv.bias),
-                                           dptr(s["gpre"]), dptr(s["g"]), 0 if pd > 0 else 1, B, Ch, r, stream()))
+        check(lib.dpmn_dwconv3x3_train_f32(dptr(s["ypre"]), dptr(mlp.depthwise_conv.weight), dptr(mlp.depthwise_conv.bias),
+                                           dptr(s["gpre"]), dptr(s["g"]), 1, float(pd), int(sb[2]), B, Ch, r, stream()))
         s["z"] = ops.pointwise(s["g"].reshape(B, L, Ch), mlp.pointwise_conv.weight.reshape(Ch, Ch), mlp.pointwise_conv.bias).reshape(M, Ch)
         if pd > 0 or dpb > 0:      # x_kv = x1 + DropPath(Dropout(fc2(z)))
             branch = ops.linear(s["z"], mlp.fc2.weight, mlp.fc2.bias)
@@ -315,17 +311,12 @@ def backward(m, sv, dout, need_dx_kv=True):
         dg = ops.pointwise(dz.reshape(B, L, Ch), packing.transposed(wp), _zero_bias(Ch, dz.device)).reshape(M, Ch)
         check(lib.dpmn_pointwise_wgrad_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, stream()))
         check(lib.dpmn_rowsum_mod_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, stream()))
-        # GELU'(gpre) on the way in; without element dropout also GELU on the forward input and GELU'(ypre) on the way out
-        dy = torch.empty_like(dg)
+        # GELU'(gpre) on the way in, GELU (+ the dropout mask) on the forward input, mask and GELU'(ypre) on the way out
+        dypre = torch.empty_like(dg)
         r = int(round(L ** 0.5))
-        check(lib.dpmn_dwconv3x3_bwd_fused_f32(dptr(s["y"] if pd > 0 else s["ypre"]), dptr(dg), dptr(s["gpre"]), dptr(mlp.depthwise_conv.weight),
-                                               dptr(dy), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
-                                               0 if pd > 0 else 1, 0 if pd > 0 else 1, B, Ch, r, stream()))
-        if pd > 0:
-            ops.dropout(dy, pd, sb[2])
-            dypre = act_bwd(dy, s["ypre"])
-        else:
-            dypre = dy
+        check(lib.dpmn_dwconv3x3_bwd_fused_f32(dptr(s["ypre"]), dptr(dg), dptr(s["gpre"]), dptr(mlp.depthwise_conv.weight),
+                                               dptr(dypre), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
+                                               1, 1, float(pd), int(sb[2]), B, Ch, r, stream()))
         dn2 = linear_bwd(dypre, s["n2"], mlp.fc1.weight, gr[mlp.fc1.weight], gr[mlp.fc1.bias])
         dx1 = dx2.clone()
         layernorm_bwd(s["x1"], dn2, blk.norm2.weight, dx1, True, gr[blk.norm2.weight], gr[blk.norm2.bias])

@@ -325,11 +325,14 @@ int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float*
 /* the same two kernels with the GELUs of the Mlp chain (pgrm.py:31-37: fc1 -> GELU -> dwconv -> GELU -> pointwise) fused in:
  *   _train : gpre = dwconv(in_gelu ? GELU(y) : y) and g = GELU(gpre) in one pass (the backward needs both)
  *   _bwd_fused : dg is multiplied by GELU'(gpre) on load (gpre may be NULL), P is GELU'd on load when in_gelu (then it is fc1's
- *                pre-activation), and dP is multiplied by GELU'(P) before the store when out_gelu_bwd */
-int dpmn_dwconv3x3_train_f32(const float* y, const float* w, const float* bias, float* gpre, float* g, int in_gelu, int B, int Ch, int r,
-                             dpmn_stream_t stream);
+ *                pre-activation), and dP is multiplied by GELU'(P) before the store when out_gelu_bwd
+ *   p_drop > 0 : nn.Dropout(p_drop) between fc1's GELU and the conv (pgrm.py:34), mask = f(seed, element index) as in
+ *                dpmn_dropout_f32, applied on load (forward input) and on dP (before GELU') */
+int dpmn_dwconv3x3_train_f32(const float* y, const float* w, const float* bias, float* gpre, float* g, int in_gelu, float p_drop,
+                             unsigned long long seed, int B, int Ch, int r, dpmn_stream_t stream);
 int dpmn_dwconv3x3_bwd_fused_f32(const float* P, const float* dg, const float* gpre, const float* w, float* dP, float* dw, float* db,
-                                 int in_gelu, int out_gelu_bwd, int B, int Ch, int r, dpmn_stream_t stream);
+                                 int in_gelu, int out_gelu_bwd, float p_drop, unsigned long long seed, int B, int Ch, int r,
+                                 dpmn_stream_t stream);
 int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, float* dP, float* dw, float* db, int B, int Ch,
                            int r, dpmn_stream_t stream);
 int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, int Ch, int L, dpmn_stream_t stream);
