@@ -171,11 +171,21 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, in
   const long m_lo = (long)blockIdx.x * rows_per_block;
   const long m_hi = m_lo + rows_per_block < M ? m_lo + rows_per_block : M;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (rl < lanes && cg * 4 < N && cols4 <= 256)
-    for (long m = m_lo + rl; m < m_hi; m += lanes) {
+  if (rl < lanes && cg * 4 < N && cols4 <= 256) {
+    long m = m_lo + rl;
+    for (; m + 3L * lanes < m_hi; m += 4L * lanes) {      // four rows in flight per thread: the loop was one load latency per row
+      const float4 v0 = *reinterpret_cast<const float4*>(dy + m * ldy + cg * 4);
+      const float4 v1 = *reinterpret_cast<const float4*>(dy + (m + lanes) * ldy + cg * 4);
+      const float4 v2 = *reinterpret_cast<const float4*>(dy + (m + 2L * lanes) * ldy + cg * 4);
+      const float4 v3 = *reinterpret_cast<const float4*>(dy + (m + 3L * lanes) * ldy + cg * 4);
+      s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+      s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; m < m_hi; m += lanes) {
       const float4 v = *reinterpret_cast<const float4*>(dy + m * ldy + cg * 4);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (rl == 0 && cg * 4 < N) {

@@ -663,7 +663,15 @@ __global__ __launch_bounds__(256) void k_rowsum_mod(const float* __restrict__ x,
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   float s = 0.f;
-  for (int c = lane; c < cols; c += 64) s += x[row * cols + c];
+  if ((cols & 3) == 0) {          // float4 loads, all of a row's loads of a lane issued before the adds
+    const float4* xr = reinterpret_cast<const float4*>(x + row * cols);
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int c = lane; c < (cols >> 2); c += 64) { const float4 v = xr[c]; a4.x += v.x; a4.y += v.y; a4.z += v.z; a4.w += v.w; }
+    s = (a4.x + a4.y) + (a4.z + a4.w);
+  } else {
+    for (int c = lane; c < cols; c += 64) s += x[row * cols + c];
+  }
   s = wave_sum(s);
   if (lane == 0) atomicAdd(out + row % mod, s);
 }
