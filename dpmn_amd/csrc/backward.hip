@@ -505,7 +505,8 @@ int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int 
                      dpmn_stream_t stream) {
   DPMN_REQUIRE(dy && x && dw && M > 0 && N % 4 == 0 && K % 4 == 0, "gemm_tn: bad arguments (N, K multiples of 4)");
   const int tiles = cdiv(N, 96) * cdiv(K, 96);
-  int splits = cdiv(256, tiles);
+  static const int want = getenv("DPMN_TN_BLOCKS") ? atoi(getenv("DPMN_TN_BLOCKS")) : 256;       // experiment knob
+  int splits = cdiv(want, tiles);
   int rows = cdiv(cdiv(M, splits), 32) * 32;
   if (rows < 32) rows = 32;
   splits = cdiv(M, rows);
