@@ -125,16 +125,27 @@ __global__ __launch_bounds__(256) void k_encoder_layer(const float* __restrict__
     s2[l][e] = v;
   }
   __syncthreads();
-  for (int i = tid; i < L * E; i += 256) {
-    const int l = i / E, e = i % E;
-    float aq = w.in_b[e], ak = w.in_b[E + e], av = w.in_b[2 * E + e];
-    for (int k = 0; k < E; ++k) {
-      const float sv = s2[l][k], qv = sv + pos[l * E + k];   // q = k = src + pos, v = src (transformer_v2.py:462-465)
-      aq += qv * w.in_w[e * E + k];
-      ak += qv * w.in_w[(E + e) * E + k];
-      av += sv * w.in_w[(2 * E + e) * E + k];
+  // Every E x E weight matrix goes through LDS transposed (Wt[k][e], in the score buffer P, which is idle whenever a projection
+  // runs): lanes own consecutive e, so the global rows w[e][:] they used to read were 256 bytes apart -- 64 cache lines per
+  // wave and k step.  (88 -> see DESIGN; the weights stay in the nn.Module layouts at the ABI.)
+  float* Wt = &P[0][0][0];
+  static_assert(NH * LMAX * LMAX >= E * E, "the score buffer doubles as the weight stage");
+  auto stage = [&](const float* W) {
+    __syncthreads();
+    for (int i = tid; i < E * E; i += 256) Wt[(i % E) * E + i / E] = W[i];
+    __syncthreads();
+  };
+  // q = k = src + pos, v = src (transformer_v2.py:462-465): O holds src + pos for the q / k projections
+  for (int i = tid; i < L * E; i += 256) O[i / E][i % E] = s2[i / E][i % E] + pos[i];
+  for (int which = 0; which < 3; ++which) {
+    stage(w.in_w + (size_t)which * E * E);
+    for (int i = tid; i < L * E; i += 256) {
+      const int l = i / E, e = i % E;
+      float a = w.in_b[which * E + e];
+      const float* in = which == 2 ? &s2[l][0] : &O[l][0];
+      for (int k = 0; k < E; ++k) a += in[k] * Wt[k * E + e];
+      (which == 0 ? Q : (which == 1 ? Kk : V))[l][e] = a;
     }
-    Q[l][e] = aq; Kk[l][e] = ak; V[l][e] = av;
   }
   __syncthreads();
   const float scale = 1.0f / sqrtf((float)D);
@@ -163,10 +174,11 @@ __global__ __launch_bounds__(256) void k_encoder_layer(const float* __restrict__
   }
   __syncthreads();
   // out_proj + residual -> Q (reuse) ; then LayerNorm1 -> s2
+  stage(w.out_w);
   for (int i = tid; i < L * E; i += 256) {
     const int l = i / E, e = i % E;
     float a = w.out_b[e];
-    for (int k = 0; k < E; ++k) a += O[l][k] * w.out_w[e * E + k];
+    for (int k = 0; k < E; ++k) a += O[l][k] * Wt[k * E + e];
     Q[l][e] = s2[l][e] + a;
   }
   __syncthreads();
@@ -182,17 +194,18 @@ __global__ __launch_bounds__(256) void k_encoder_layer(const float* __restrict__
   };
   layer_norm_rows(Q, s2, w.n1_w, w.n1_b);
   __syncthreads();
+  stage(w.l1_w);
   for (int i = tid; i < L * E; i += 256) {
     const int l = i / E, e = i % E;
     float a = w.l1_b[e];
-    for (int k = 0; k < E; ++k) a += s2[l][k] * w.l1_w[e * E + k];
+    for (int k = 0; k < E; ++k) a += s2[l][k] * Wt[k * E + e];
     O[l][e] = a > 0.f ? a : 0.f;
   }
-  __syncthreads();
+  stage(w.l2_w);
   for (int i = tid; i < L * E; i += 256) {
     const int l = i / E, e = i % E;
     float a = w.l2_b[e];
-    for (int k = 0; k < E; ++k) a += O[l][k] * w.l2_w[e * E + k];
+    for (int k = 0; k < E; ++k) a += O[l][k] * Wt[k * E + e];
     Q[l][e] = s2[l][e] + a;
   }
   __syncthreads();
