@@ -199,6 +199,9 @@ def test_fused_ln_qkv_window_attention_vs_oracle(dev, B, shifts):
     lnq_w, lnq_b = u("lnq_w", (C,), 0.5, 1.5), u("lnq_b", (C,), -0.5, 0.5)
     lnk_w, lnk_b = u("lnk_w", (C,), 0.5, 1.5), u("lnk_b", (C,), -0.5, 0.5)
     tq, tkv = u("f_tq%d" % B, (B, H * W, C), -2, 3), u("f_tkv%d" % B, (B, H * W, C), -3, 2)
+    import os
+    if os.environ.get("DPMN_ATTN_FUSED") == "0":
+        pytest.skip("the fused kernel is switched off (DPMN_ATTN_FUSED=0)")
     assert ops.ln_qkv_window_attn_supported(C, [2, 4, 8], 2, H, W)
     q = F.linear(F.layer_norm(tq, (C,), lnq_w, lnq_b), sd["q.weight"], sd["q.bias"])
     kv = F.linear(F.layer_norm(tkv, (C,), lnk_w, lnk_b), sd["kv.weight"], sd["kv.bias"])
