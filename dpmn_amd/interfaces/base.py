@@ -59,21 +59,35 @@ class TextBase(object):
         self.drop_path_rate = parse_list(self.args.drop_path_rate)
 
     # ------------------------------------------------------------------ data (base.py:85-125)
-    def _loader(self, dirs, test, shuffle, drop_last):
+    def _loader(self, dirs, test, shuffle, drop_last, shard=False):
+        """shard=True (training under torch.distributed): every rank walks its own 1/world of a per-epoch permutation
+        (DistributedSampler, call `self.train_sampler.set_epoch(epoch)`) with batch_size // world samples per step, so the
+        GLOBAL batch stays config.TRAIN.batch_size at the configured learning rate -- nn.DataParallel's scatter of one batch
+        over the GPUs (base.py:160-162), not world x batch_size."""
         from ..dataset import textzoom as tz
         cfg = self.config.TRAIN
         sets = [tz.lmdbDataset_real(root=d, voc_type=cfg.voc_type, max_len=cfg.max_len, test=test) for d in dirs]
         ds = torch.utils.data.ConcatDataset(sets)
+        dist = torch.distributed
+        world = dist.get_world_size() if (shard and dist.is_initialized()) else 1
+        sampler, bs = None, self.batch_size
+        if world > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(ds, num_replicas=world, rank=dist.get_rank(), shuffle=shuffle,
+                                                                      drop_last=drop_last)
+            bs = max(self.batch_size // world, 2)       # B_local = 1 changes SKConv's squeeze() semantics (quirk Q3)
         loader = torch.utils.data.DataLoader(
-            ds, batch_size=self.batch_size, shuffle=shuffle, num_workers=int(cfg.workers), pin_memory=True, drop_last=drop_last,
+            ds, batch_size=bs, shuffle=shuffle and sampler is None, sampler=sampler, num_workers=int(cfg.workers), pin_memory=True,
+            drop_last=drop_last,
             collate_fn=tz.alignCollate_realWTLAMask(imgH=cfg.height, imgW=cfg.width, down_sample_scale=cfg.down_sample_scale, mask=self.mask))
+        if shard:
+            self.train_sampler = sampler
         return ds, loader
 
     def get_train_data(self):
         cfg = self.config.TRAIN
         if not isinstance(cfg.train_data_dir, list):
             raise TypeError('check trainRoot')
-        return self._loader(cfg.train_data_dir, False, True, True)
+        return self._loader(cfg.train_data_dir, False, True, True, shard=True)
 
     def get_val_data(self):
         pairs = [self.get_test_data(d) for d in self.config.TRAIN.VAL.val_data_dir]
@@ -117,10 +131,14 @@ class TextBase(object):
         return {'model': model, 'crit': image_crit}
 
     def save_checkpoint(self, netG_list, epoch, iters, best_acc_dict, best_model_info, is_best, converge_list,
-                        recognizer=None, metric="sum"):
+                        recognizer=None, metric="sum", trainer=None):
         """Same files and dict keys as base.py:328-358: model_best_{metric}_{epoch}_{i}.pth when is_best, otherwise every
         model overwrites checkpoint.pth (the reference's behaviour, line 358).  Recogniser files (base.py:360-373) are written
-        when a recogniser list is passed (none is built here: SURVEY.md section 2 rows 14-17)."""
+        when a recogniser list is passed.  trainer (ours): the train/optim.py Trainer that owns the parameters -- its pending
+        ZeRO-1 parameter all-gathers are awaited before any state_dict is cloned (they write the flat parameter arena from
+        RCCL's stream; a clone racing them would store step t-1 values for the shards other ranks own)."""
+        if trainer is not None:
+            trainer.sync_params()
         ckpt_path = os.path.join(self.vis_dir, 'ckpt')
         os.makedirs(ckpt_path, exist_ok=True)
         for i, netG in enumerate(netG_list):

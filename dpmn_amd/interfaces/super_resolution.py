@@ -50,13 +50,13 @@ class TextSR(base.TextBase):
         models.append(cmm)
         return models, psn
 
-    def recogniser_text_prior(self, n=None, path=None):
+    def recogniser_text_prior(self, n=None, path=None, allow_random=False):
         """The reference's branch-1 prior source (super_resolution.py:100-111, 174-199): one VisionLAN per stage, driving the
-        batched GPU pipeline of interfaces/text_prior.py.  path: visionlan.pth-style checkpoint (--rec_path); None leaves the
-        constructor's initialisation, like VisionLAN_init with init_state_dict None (base.py:452-471)."""
+        batched GPU pipeline of interfaces/text_prior.py.  path: the reference's --rec_path directory (recognizer_best_{i}.pth
+        per stage) or one visionlan.pth-style file; without one this raises unless allow_random (tests / synthetic benches)."""
         from .text_prior import VisionLANTextPrior, build_recognizers
         n = self.args.stu_iter_b1 if n is None else n
-        recs = build_recognizers(n, self.device, path if path is not None else self.rec_path)
+        recs = build_recognizers(n, self.device, path if path is not None else self.rec_path, allow_random=allow_random)
         return VisionLANTextPrior(recs, self.device, font_path=getattr(self.args, "font_path", None))
 
     def default_text_prior(self):
@@ -262,13 +262,16 @@ class TextSR(base.TextBase):
         run.graph = graph
         return run
 
-    def train(self, loader=None, steps=None, val_loader=None, rec=None):
-        """Training loop (super_resolution.py:125-337) over a loader of (images_hr, images_lr, label_vecs) batches (the
-        TextZoom LMDB reader and the recogniser-driven text priors are out of scope: synthetic batches / priors by default).
-        Bookkeeping as in the reference: display every displayInterval, eval + best-model checkpoint every
-        VAL.valInterval when a val_loader is given (best = recognition accuracy when `rec` computes one, else PSNR --
-        the reference's criterion needs its out-of-scope recognisers), checkpoint.pth every saveInterval and at the end.
-        Rank 0 writes the files."""
+    def train(self, loader=None, steps=None, val_loader=None, rec=None, epochs=None, sampler=None):
+        """Training loop (super_resolution.py:125-337) over (images_hr, images_lr, label_vecs) batches.
+        loader: a callable `loader(epoch) -> iterable` (a fresh pass per epoch), a re-iterable (list, DataLoader-like: walked
+        once per epoch for `epochs` / config.TRAIN.epochs epochs, `for epoch in range(cfg.epochs)` of the reference), or a
+        one-shot iterator (a single epoch).  sampler: a DistributedSampler whose set_epoch is called per epoch.
+        Bookkeeping as in the reference: iters = len(loader) * epoch + j + 1 counted globally, display every displayInterval,
+        eval + best-model checkpoint every VAL.valInterval when a val_loader is given (best = recognition accuracy when `rec`
+        computes one, else PSNR), checkpoint.pth every saveInterval and at the end, epoch written to checkpoints and log.csv.
+        Rank 0 writes the files; under ZeRO-1 every save waits for the step's parameter all-gather first (trainer.sync_params:
+        the gather runs asynchronously on RCCL's stream, a state_dict clone before it lands would tear the checkpoint)."""
         dist = torch.distributed
         world = dist.get_world_size() if dist.is_initialized() else 1
         rank = dist.get_rank() if dist.is_initialized() else 0
@@ -283,37 +286,71 @@ class TextSR(base.TextBase):
         val_int = getattr(getattr(cfg, "VAL", None), "valInterval", None) or 80
         log_path = os.path.join(getattr(cfg, "ckpt_dir", None) or ".", "log.csv")
         best, best_info, converge = None, {}, []
-        it = 0
-        for data in loader:
-            hr, lr = data[0].to(self.device), data[1].to(self.device)
-            lv = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
-            loss = self.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_prior_fn=fn)
-            it += 1
-            if it % cfg.displayInterval == 0 and rank == 0:
-                print('iter %d | Loss: %f' % (it, float(loss)))
-            if val_loader is not None and it % val_int == 0:
-                md = self.eval(models, val_loader() if callable(val_loader) else val_loader, 0, rec=rec, model_psn=psn, text_prior_fn=fn)
-                for m_ in models + distill:
-                    m_.train()
-                converge.append({'iterator': it, 'acc': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']})
-                score = md['accuracy'] if md['accuracy'] is not None else md['psnr_avg']
-                is_best = best is None or score > best
-                if is_best:
-                    best = score
-                    best_info = {'accuracy': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']}
-                if rank == 0:
+        if callable(loader):
+            passes = loader
+            n_epochs = epochs if epochs is not None else int(getattr(cfg, "epochs", 1) or 1)
+        elif hasattr(loader, "__next__"):      # a generator can be walked once
+            passes = lambda _e: loader
+            n_epochs = 1
+        else:
+            passes = lambda _e: loader
+            n_epochs = epochs if epochs is not None else int(getattr(cfg, "epochs", 1) or 1)
+
+        def save(epoch, it, is_best):
+            if rank == 0:
+                self.save_checkpoint(models, epoch, it, {'score': best}, best_info, is_best, converge, None, trainer=trainer)
+
+        it, epoch, saved_at = 0, 0, -1
+        for epoch in range(n_epochs):
+            if sampler is not None and hasattr(sampler, "set_epoch"):
+                sampler.set_epoch(epoch)
+            for data in passes(epoch):
+                hr, lr = data[0].to(self.device), data[1].to(self.device)
+                lv = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
+                if lv is None and self.args.arch == 'tatt':
+                    lv = self.label_vecs_from_crnn(lr)
+                loss = self.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_prior_fn=fn)
+                it += 1
+                if it % cfg.displayInterval == 0 and rank == 0:
+                    print('Epoch: [%d] iter %d | Loss: %f' % (epoch, it, float(loss)))
+                if val_loader is not None and it % val_int == 0:
+                    trainer.sync_params()
+                    md = self.eval(models, val_loader() if callable(val_loader) else val_loader, epoch, rec=rec, model_psn=psn, text_prior_fn=fn)
+                    for m_ in models + distill:
+                        m_.train()
+                    converge.append({'iterator': it, 'acc': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']})
+                    score = md['accuracy'] if md['accuracy'] is not None else md['psnr_avg']
+                    is_best = best is None or score > best
                     if is_best:
-                        self.save_checkpoint(models, 0, it, {'score': best}, best_info, True, converge, None)
-                    os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
-                    with open(log_path, "a+", newline="") as out:
-                        csv.writer(out).writerow([0, "val", md['accuracy'], md['psnr_avg'], md['ssim_avg'], "", "best_sum" if is_best else ""])
-            if it % cfg.saveInterval == 0 and rank == 0:
-                self.save_checkpoint(models, 0, it, {'score': best}, best_info, False, converge, None)
+                        best = score
+                        best_info = {'accuracy': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']}
+                        save(epoch, it, True)
+                    if rank == 0:
+                        os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
+                        with open(log_path, "a+", newline="") as out:
+                            csv.writer(out).writerow([epoch, "val", md['accuracy'], md['psnr_avg'], md['ssim_avg'], "", "best_sum" if is_best else ""])
+                if it % cfg.saveInterval == 0:
+                    save(epoch, it, False)
+                    saved_at = it
+                if steps is not None and it >= steps:
+                    break
             if steps is not None and it >= steps:
                 break
-        if rank == 0 and it % cfg.saveInterval != 0:
-            self.save_checkpoint(models, 0, it, {'score': best}, best_info, False, converge, None)
+        if saved_at != it:
+            save(epoch, it, False)
+        trainer.sync_params()
+        self.trainer = trainer
         return models, distill
+
+    def label_vecs_from_crnn(self, images_lr):
+        """--arch tatt on real data (super_resolution.py:165-169): label_vecs = softmax of the frozen CRNN's logits on the LR
+        image, reshaped (T, B, 37) -> (B, 37, 1, T).  The CRNN is loaded from <resume>/recognizer_best_crnn.pth (line 92)."""
+        crnn = getattr(self, "_crnn_psn", None)
+        if crnn is None:
+            from ..model.crnn import load_crnn
+            path = os.path.join(self.resume, "recognizer_best_crnn.pth") if self.resume and os.path.isdir(self.resume) else None
+            crnn = self._crnn_psn = load_crnn(path, self.device)
+        return crnn.label_vecs(images_lr[:, :3])
 
     def test(self, loader=None, rec=None):
         """super_resolution.py:515-775: PGRMs from model_best_{k}.pth, CMM from model_best_cmm.pth, PSN from model_{arch}.pth

@@ -33,17 +33,34 @@ class VisionLANTextPrior:
         return decode_strings(*self.last) if self.last is not None else []
 
 
-def build_recognizers(n, device, path=None):
-    """VisionLAN_init (interfaces/base.py:452-471): n recognisers, optionally initialised from a checkpoint whose keys may carry
-    the 'module.' prefix of nn.DataParallel."""
+def _load_visionlan(m, path, device):
+    """VisionLAN_init's key handling (interfaces/base.py:452-471): DataParallel 'module.' prefixes dropped, only keys the
+    model owns are taken."""
+    sd = torch.load(path, map_location=device)
+    sd = {(k[7:] if k.startswith("module.") else k).replace("features.module.", "features."): v for k, v in sd.items()}
+    own = m.state_dict()
+    own.update({k: v for k, v in sd.items() if k in own})
+    m.load_state_dict(own)
+
+
+def build_recognizers(n, device, path=None, allow_random=False):
+    """The student recognisers of super_resolution.py:100-111: stage i is loaded from
+    os.path.join(rec_path, 'recognizer_best_%d.pth' % i) when `path` is a directory (the reference's --rec_path), from the
+    single file for every stage when `path` is a file (VisionLAN_init(path)).  No checkpoint: the reference cannot run at all
+    (rec_path None -> os.path.join raises), so a randomly initialised recogniser silently driving the text prior is refused
+    unless the caller asks for it (tests, benchmarks on synthetic weights)."""
+    import os
+    if not path and not allow_random:
+        raise RuntimeError("dpmn_amd: --tpg visionlan needs --rec_path (a directory holding recognizer_best_{i}.pth per stage, or "
+                           "one visionlan .pth file); pass --synthetic_prior to train / evaluate on seeded noise priors instead")
     recs = []
-    for _ in range(n):
+    for i in range(n):
         m = VisionLAN().to(device)
         if path:
-            sd = torch.load(path, map_location=device)
-            sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
-            own = m.state_dict()
-            own.update({k: v for k, v in sd.items() if k in own})
-            m.load_state_dict(own)
+            f = os.path.join(path, "recognizer_best_%d.pth" % i) if os.path.isdir(path) else path
+            if not os.path.isfile(f):
+                raise FileNotFoundError("dpmn_amd: recogniser checkpoint %s is missing" % f)
+            print('load pre_trained VisionLAN model from %s' % f)
+            _load_visionlan(m, f, device)
         recs.append(m.eval())
     return recs

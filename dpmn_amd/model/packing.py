@@ -111,6 +111,7 @@ class PackCache:
         self.epoch = 0             # current step
         self.fresh = -1            # step whose parameters the packs hold
         self.table = None          # (device descs, device prefix, n_blocks) or None when stale
+        self.before_refresh = None # Trainer.sync_params under ZeRO-1: every parameter all-gather must have landed before packing
 
     def new_step(self):
         self.epoch += 1
@@ -119,7 +120,15 @@ class PackCache:
         import ctypes
         import struct
         from .._abi import lib, check, stream
+        if self.before_refresh is not None:
+            # the multi-pack reads EVERY registered parameter (CMM's included) at the first pack request of the step, when only
+            # the first module's forward pre-hook has waited for its own group's all-gather: wait for all of them explicitly
+            # instead of relying on the groups sharing one in-order RCCL stream
+            self.before_refresh()
         if self.table is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("dpmn_amd PackCache: the descriptor table must be built before hipGraph capture (it uploads from "
+                                   "the host); run at least two eager steps first (graphed_train_step warmup >= 2)")
             raw, prefix, nb = bytearray(), [], 0
             shape = (ctypes.c_int * 3)()
             for key in self.order:

@@ -180,6 +180,9 @@ class Unit:
 def build(m, x1, x2):
     """Forward in training mode; returns (out NCHW, graph) where graph lists the units in execution order."""
     units = []
+    # a train-mode forward moves the BatchNorm running statistics through raw pointers (no torch _version bump), so the
+    # eval-mode pack of model/cmm.py (folded BatchNorm) is stale from here on
+    m._pack = None
 
     def run(kind, conv, bn, inputs, act, cin_pad=None):
         u = Unit(kind, conv, bn, inputs, act, cin_pad)

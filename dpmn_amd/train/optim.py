@@ -314,6 +314,8 @@ class Trainer:
         self.flat_g = torch.zeros(total, device=dev)
         from ..model.packing import PackCache
         self.pack_cache = PackCache(self.flat_p)
+        if zero1:
+            self.pack_cache.before_refresh = self.sync_params
         self.buckets = [None] * len(models)
         self.groups = []
         off = 0
@@ -358,9 +360,17 @@ class Trainer:
             self.t_dev = torch.full((1,), float(self.t), device=self.flat_p.device)
 
     def sync_params(self):
-        """Wait for outstanding parameter all-gathers (ZeRO-1); call before reading parameters outside a forward."""
+        """Wait for outstanding parameter all-gathers (ZeRO-1); call before reading parameters outside a forward
+        (checkpoints, state_dict clones) -- the gather runs on RCCL's stream and writes flat_p behind torch's back."""
         for g in self.groups:
             g.wait_params()
+
+    def invalidate_packs(self):
+        """The optimizer kernels write parameters through raw pointers, so torch's `_version` counters never move: every
+        module that caches eval-mode weight packs keyed on them (model/cmm.py `_pack`) must drop the cache explicitly."""
+        for b in self.buckets:
+            if getattr(b.module, "_pack", None) is not None:
+                b.module._pack = None
 
     def state_snapshot(self):
         """Everything a step mutates in the optimizer (used to undo hipGraph warm-up steps)."""
@@ -375,6 +385,7 @@ class Trainer:
         for g, (m, v) in zip(self.groups, snap["mv"]):
             g.m.copy_(m)
             g.v.copy_(v)
+        self.invalidate_packs()
 
     def step(self):
         from ..model import packing
@@ -384,3 +395,4 @@ class Trainer:
         for g in self.groups:
             g.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
         packing.ACTIVE = None       # the packs are stale from here on
+        self.invalidate_packs()

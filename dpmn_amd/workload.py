@@ -88,7 +88,7 @@ def build_text_prior(sr, b1, seed=400):
     """The in-loop recogniser-driven text prior (config 3: "VisionLAN text-prior branch enabled") with synthetic recogniser
     weights: b1 VisionLAN mirrors + the glyph atlas -> callable(cascade, k)."""
     from .interfaces.text_prior import VisionLANTextPrior, build_recognizers
-    recs = build_recognizers(b1, sr.device)
+    recs = build_recognizers(b1, sr.device, allow_random=True)       # filled with synthetic weights right below
     for i, r in enumerate(recs):
         sd = r.state_dict()
         synth.synth_fill_(sd, seed=seed + i)

@@ -74,10 +74,10 @@ def main(config, args):
         dirs = config.TRAIN.train_data_dir or []
         if dirs and all(os.path.isdir(d) for d in dirs):                   # TextZoom LMDBs from the config, like base.py:85-103
             from dpmn_amd.dataset.textzoom import sr_batches
-            loader = sr_batches(mission.get_train_data()[1])
+            dl = mission.get_train_data()[1]           # per-rank shard of a per-epoch permutation (DistributedSampler)
+            mission.train(lambda epoch: sr_batches(dl), epochs=config.TRAIN.epochs, sampler=getattr(mission, "train_sampler", None))
         else:
-            loader = synthetic_loader(bs, args.synthetic_steps, 2000 + rank)
-        mission.train(loader, steps=args.synthetic_steps if not dirs else None)
+            mission.train(synthetic_loader(bs, args.synthetic_steps, 2000 + rank), steps=args.synthetic_steps)
 
 
 if __name__ == '__main__':

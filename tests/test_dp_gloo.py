@@ -204,3 +204,72 @@ def test_trainer_allreduce_direct_mode_world2_gloo():
 
 def test_trainer_zero1_sharded_adam_world2_gloo():
     _run_trainer(zero1=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ZeRO-1 + checkpoint: the parameter all-gather of a step is asynchronous; save_checkpoint(trainer=...) must wait for it, so
+# a checkpoint written right after trainer.step() holds step-t values for EVERY shard, on every rank.
+
+def _ckpt_worker(rank, world, port, q, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from dpmn_amd.train import optim
+    from dpmn_amd.interfaces.base import TextBase
+    optim._sumsq, optim._adam_clip = _torch_sumsq, _torch_adam_clip
+    models = _build(1000)
+    tr = optim.Trainer(models, lr=1e-2, beta1=0.5, max_norm=0.25, world_size=world, zero1=True, group_mb=0.005)
+    ref = _build(1000)
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-2, betas=(0.5, 0.999)) for m in ref]
+    fake = SimpleNamespace(vis_dir=os.path.join(tmp, "rank%d" % rank), args=SimpleNamespace(arch="tsrn"), batch_size=4, scale_factor=2,
+                           voc_type="all")
+    worst = 0.0
+    for step in range(4):
+        xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * step + r)) for r in range(world)]
+        tr.zero_grad()
+        _loss(models, xs[rank]).backward()
+        tr.step()
+        # NO explicit sync_params here: the save itself must wait for the all-gather
+        d = TextBase.save_checkpoint(fake, models, 0, step + 1, {}, {}, False, [], None, trainer=tr)
+        for m in ref:
+            m.zero_grad()
+        for r in range(world):
+            (_loss(ref, xs[r]) / world).backward()
+        for m, o in zip(ref, opts):
+            torch.nn.utils.clip_grad_norm_(m.parameters(), 0.25)
+            o.step()
+        # checkpoint.pth is overwritten by every model (base.py:358): the file holds the LAST model of the list
+        sd = torch.load(os.path.join(d, "checkpoint.pth"))["state_dict_G"]
+        for k, v in ref[-1].state_dict().items():
+            worst = max(worst, float((sd[k] - v).abs().max()))
+    # a best-model save writes one file per model: compare all of them with the reference and across ranks
+    d = TextBase.save_checkpoint(fake, models, 0, 4, {}, {}, True, [], None, trainer=tr)
+    vec = []
+    for i, m in enumerate(ref):
+        sd = torch.load(os.path.join(d, "model_best_sum_0_%d.pth" % i))["state_dict_G"]
+        for k, v in m.state_dict().items():
+            worst = max(worst, float((sd[k] - v).abs().max()))
+            vec.append(sd[k].reshape(-1))
+    flat = torch.cat(vec)
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    q.put((rank, worst, all(torch.equal(other[0], o) for o in other)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero1_checkpoint_right_after_step_world2_gloo(tmp_path):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ckpt_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, same in res:
+        assert same, "checkpoints differ between ranks (rank %d)" % rank
+        assert worst < 2e-5, (rank, worst)

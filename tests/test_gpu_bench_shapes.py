@@ -113,14 +113,23 @@ def test_cmm_cnum64_train_fwd_bwd_at_b8_vs_oracle_autograd(dev):
     assert (num / den) ** 0.5 < 1e-2
 
 
-def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev):
-    """BASELINE.json configs[2]'s step on its own stack -- TATT PSN (frozen) + 3+3 PGRM + 4 DistillModules + CMM -- at B = 4:
+# tolerances of the step test = ~3x the errors recorded in profiles/ (r02f at B = 4, r03 at B = 48), floor 1e-5
+CFG2_TOL = {4: dict(loss=1e-6, pgrm=3e-4, pgrm_b2=2.5e-3, cmm=2e-3, distill=1e-5),
+            48: dict(loss=1e-6, pgrm=3e-4, pgrm_b2=2.5e-3, cmm=2e-3, distill=1e-5)}
+
+
+@pytest.mark.parametrize("B", [4, 48])
+def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev, B):
+    """BASELINE.json configs[2]'s step on its own stack -- TATT PSN (frozen) + 3+3 PGRM + 4 DistillModules + CMM -- at B = 4 and
+    at the batch bench.py times (B = 48: other split factors, block counts and workspace sizes than B = 4):
     loss, and every model's gradient (whole-model relative L2, what the per-model clip sees) vs autograd through the oracle."""
     from dpmn_amd import workload
     from dpmn_amd.interfaces.super_resolution import TextSR
     from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn
-    name = "cfg2_step_tatt3p3_B4"
-    B, b1, b2 = 4, 3, 3
+    name = "cfg2_step_tatt3p3_B%d" % B
+    b1, b2 = 3, 3
+    tols = CFG2_TOL[B]
+    torch.set_num_threads(min(32, torch.get_num_threads()))
     sr_ = TextSR(workload.make_config(B), workload.make_args("tatt", b1, b2, B))
     models, psn, distill, crit, trainer = sr_.build_training()
     for i, m in enumerate([psn] + models + distill):
@@ -159,8 +168,8 @@ def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev):
     tot = (tot + ocmm.image_loss(o, hr3, True) * 100) / (b1 + b2 + 1)
     tot.backward()
     le = abs(float(loss) - float(tot)) / abs(float(tot))
-    record(name, "loss rel err", le, 1e-5)
-    assert le < 1e-5, (float(loss), float(tot))
+    record(name, "loss rel err", le, tols["loss"])
+    assert le < tols["loss"], (float(loss), float(tot))
     for i, m in enumerate(models + distill):
         rsd = ref[1 + i]
         num = den = 0.0
@@ -169,5 +178,257 @@ def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev):
             d = p_.grad.detach().cpu().double() - g_ref.double()
             num += float((d * d).sum()); den += float((g_ref.double() ** 2).sum())
         e = (num / max(den, 1e-30)) ** 0.5
-        record(name, "model %d whole-gradient rel L2" % i, e, 3e-3)
-        assert e < 3e-3, "model %d gradient differs from oracle autograd: %.3e" % (i, e)
+        tol = tols["pgrm"] if i < b1 else tols["pgrm_b2"] if i < b1 + b2 else tols["cmm"] if i == b1 + b2 else tols["distill"]
+        record(name, "model %d whole-gradient rel L2" % i, e, tol)
+        assert e < tol, "model %d gradient differs from oracle autograd: %.3e (tol %.1e)" % (i, e, tol)
+
+
+def test_cfg3_as_named_inloop_visionlan_prior_b64_vs_oracle(dev):
+    """BASELINE.json configs[3] exactly as `bench.py --workload cfg3 --prior visionlan` runs it: TBSRN PSN + 3+3 PGRM + CMM at
+    B = 64 with the batched VisionLAN recogniser + glyph-atlas composer INSIDE the loop.  The oracle is driven stage by stage.
+    Two discrete hand-offs are fed from the GPU the way the cfg1 test feeds the masks: the recogniser's uint8-quantised input
+    image (resize of the GPU's cascade image; pixels where the oracle's own cascade would quantise differently are counted
+    and bounded) and the decoded classes / lengths (arg-max ties; mismatches vs the oracle's decode counted and bounded).
+    Asserted: per-stage logits vs oracle/visionlan.py, the composed prior vs the composer's specification on the GPU's
+    classes, every cascade image, the CMM output, the blend and PSNR / SSIM."""
+    from dpmn_amd import workload, ops
+    from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn, visionlan as ov
+    name = "cfg3_inloop_B64"
+    sr, models, psn, inp = workload.build("cfg3")
+    B = inp["images_lr"].shape[0]
+    assert B == 64
+    fn = workload.build_text_prior(sr, 3)
+    seen = []
+
+    def wrapped(cascade, k):
+        pr = fn(cascade, k)
+        seen.append((cascade, pr, fn.last))
+        return pr
+    out, mid = sr.refine(models, psn, inp["images_lr"], None, text_prior_fn=wrapped, return_all=True)
+    torch.cuda.synchronize()
+    assert len(seen) == 3
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    rec_sds = [{k: v.detach().cpu() for k, v in r.state_dict().items()} for r in fn.recognizers]
+    atlas, adv = fn.atlas.cpu(), fn.advance.cpu()
+    cpu = {k: (v.cpu() if torch.is_tensor(v) else [x.cpu() for x in v]) for k, v in inp.items()}
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        r_psn = otsrn.tbsrn_forward(sd_psn, cpu["images_lr"])
+        record(name, "psn max|err|", max_abs_err(mid["psn"], r_psn), 6e-5)
+        assert_close(mid["psn"], r_psn, 6e-5, 6e-5, "TBSRN PSN B=64")
+        casc, l1 = r_psn, []
+        for k in range(3):
+            casc_gpu, prior_gpu, (cls_gpu, len_gpu) = seen[k]
+            assert casc_gpu.data_ptr() == (mid["psn"] if k == 0 else mid["branch1"][k - 1]).data_ptr()
+            img_gpu = ov.resize_for_visionlan(casc_gpu[:, :3].cpu())
+            flips = int((img_gpu != ov.resize_for_visionlan(casc[:, :3])).sum())
+            record(name, "stage %d recogniser-input pixels quantised differently (of %d)" % (k, img_gpu.numel()), flips, img_gpu.numel() * 2e-3)
+            assert flips <= img_gpu.numel() * 2e-3
+            lg_ref = ov.logits(rec_sds[k], img_gpu)
+            lg_gpu, cls2, len2 = fn.recognizers[k].recognise(casc_gpu[:, :3])
+            assert torch.equal(cls2, cls_gpu) and torch.equal(len2, len_gpu), "recognise() is deterministic"
+            record(name, "stage %d logits max|err|" % k, max_abs_err(lg_gpu, lg_ref), 3e-5)
+            assert_close(lg_gpu, lg_ref, 3e-5, 3e-5, "VisionLAN logits, stage %d, B=64" % k)
+            rc, rl, _ = ov.decode(lg_ref)
+            n_len = int((rl != len_gpu.cpu().long()).sum())
+            live = torch.arange(25)[None, :] < rl[:, None]
+            n_cls = int(((rc != cls_gpu.cpu().long()) & live).sum())
+            record(name, "stage %d decoded classes differing from the oracle's arg-max (of %d)" % (k, int(live.sum())), n_cls, 2)
+            record(name, "stage %d lengths differing" % k, n_len, 1)
+            assert n_cls <= 2 and n_len <= 1
+            spec = ov.compose_text_prior(cls_gpu.cpu().long(), len_gpu.cpu().long(), atlas, adv.long())
+            d = (prior_gpu.cpu() - spec).abs()
+            record(name, "stage %d composed prior: pixels off by one grey level (fraction)" % k, float((d > 0).float().mean()), 2e-3)
+            assert float(d.max()) <= 1.0 and float((d > 0).float().mean()) < 2e-3
+            o = opgrm.pgrm_forward(sds[k], prior_gpu.cpu(), casc[:, :3], l1[:k]); l1.append(o); casc = o
+            record(name, "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 1e-4)
+            assert_close(mid["branch1"][k], o, 1e-4, 1e-4, "cfg3 branch1[%d]" % k)
+        casc_gpu, casc, l2 = mid["psn"], r_psn, []
+        flips = 0
+        for k in range(3, 6):
+            m_gpu = ops.to_mask(casc_gpu).cpu()
+            flips += int((m_gpu != ocmm.to_mask(casc[:, :3])).sum()) // 3
+            o = opgrm.pgrm_forward(sds[k], m_gpu, casc[:, :3], l2[:(k - 3)]); l2.append(o); casc = o
+            casc_gpu = mid["branch2"][k - 3]
+            record(name, "branch2[%d] max|err|" % (k - 3), max_abs_err(casc_gpu, o), 1e-4)
+            assert_close(casc_gpu, o, 1e-4, 1e-4, "cfg3 branch2[%d]" % (k - 3))
+        record(name, "mask pixels flipped (of %d)" % (3 * B * 32 * 128), flips, 3 * B * 32 * 128 * 2e-5)
+        assert flips <= 3 * B * 32 * 128 * 2e-5
+        fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
+        record(name, "cmm max|err|", max_abs_err(mid["cmm"], fused), 3e-4)
+        assert_close(mid["cmm"], fused, 3e-4, 3e-4, "CMM at B=64")
+        ref = 0.5 * fused + 0.5 * r_psn[:, :3]
+    record(name, "output max|err|", max_abs_err(out, ref), 2e-4)
+    assert_close(out, ref, 2e-4, 2e-4, "cfg3 B=64 output")
+    p, s_ = ops.psnr_ssim(out, inp["images_hr"])
+    dp = abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"])))
+    ds = abs(float(s_) - float(ocmm.ssim(ref, cpu["images_hr"])))
+    record(name, "|dPSNR|", dp, 1e-3)
+    record(name, "|dSSIM|", ds, 1e-3)
+    assert dp < 1e-3 and ds < 1e-3
+
+
+def test_cfg4_stress_at_bench_batch_rows_vs_small_batch_and_oracle(dev):
+    """BASELINE.json configs[4] at the batch bench.py times (B = 96, 64x256, dim 192, 6+6 PGRM): every stage of the B = 96 call,
+    restricted to two rows, equals a B = 2 call on those rows (samples are independent: only dispatch, split factors and
+    block counts differ), and those rows equal the oracle (driven stage by stage with the GPU's masks)."""
+    from dpmn_amd import workload, ops
+    from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn
+    name = "cfg4_B96"
+    sr, models, psn, inp = workload.build("cfg4")
+    B = inp["images_lr"].shape[0]
+    assert B == 96
+    out, mid = sr.refine(models, psn, inp["images_lr"], None, text_priors=inp["text_priors"], return_all=True)
+    r0 = 57
+    rows = slice(r0, r0 + 2)
+    out2, mid2 = sr.refine(models, psn, inp["images_lr"][rows].contiguous(), None,
+                           text_priors=[t_[rows].contiguous() for t_ in inp["text_priors"]], return_all=True)
+    torch.cuda.synchronize()
+    worst = max_abs_err(mid["psn"][rows], mid2["psn"])
+    for a, b in zip(mid["branch1"] + mid["branch2"] + [mid["cmm"], out], mid2["branch1"] + mid2["branch2"] + [mid2["cmm"], out2]):
+        worst = max(worst, max_abs_err(a[rows], b))
+    record(name, "rows %d..%d of the B=96 call vs a B=2 call, worst stage max|err|" % (r0, r0 + 1), worst, 2e-4)
+    assert worst < 2e-4
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    lr2 = inp["images_lr"][rows].cpu()
+    pri2 = [t_[rows].cpu() for t_ in inp["text_priors"]]
+    win = (4, 8, 16)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    with torch.no_grad():
+        r_psn = otsrn.tsrn_forward(sd_psn, lr2)
+        assert_close(mid["psn"][rows], r_psn, 5e-5, 5e-5, "cfg4 TSRN rows of B=96")
+        casc, l1 = r_psn, []
+        for k in range(6):
+            o = opgrm.pgrm_forward(sds[k], pri2[k], casc[:, :3], l1[:k], windows=win); l1.append(o); casc = o
+            record(name, "branch1[%d] rows max|err|" % k, max_abs_err(mid["branch1"][k][rows], o), 4.5e-4)
+            assert_close(mid["branch1"][k][rows], o, 4.5e-4, 4.5e-4, "cfg4 B=96 branch1[%d]" % k)
+        casc_gpu, casc, l2 = mid["psn"][rows], r_psn, []
+        for k in range(6, 12):
+            m_gpu = ops.to_mask(casc_gpu.contiguous()).cpu()
+            o = opgrm.pgrm_forward(sds[k], m_gpu, casc[:, :3], l2[:(k - 6)], windows=win); l2.append(o); casc = o
+            casc_gpu = mid["branch2"][k - 6][rows]
+            record(name, "branch2[%d] rows max|err|" % (k - 6), max_abs_err(casc_gpu, o), 4.5e-4)
+            assert_close(casc_gpu, o, 4.5e-4, 4.5e-4, "cfg4 B=96 branch2[%d]" % (k - 6))
+        fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
+        ref = 0.5 * fused + 0.5 * r_psn[:, :3]
+    record(name, "output rows max|err|", max_abs_err(out[rows], ref), 8e-4)
+    assert_close(out[rows], ref, 8e-4, 8e-4, "cfg4 B=96 output rows")
+
+
+def _share_setup(dev, B):
+    """--sr_share (super_resolution.py:38-76, 204-208, 232-236): model_list = [PGRM(iter 0, mode False), PGRM(iter b1, mode True),
+    CMM]; stage k of BOTH branches runs model_list[0] -- fed the 2-channel text prior through prior_fusion in branch 1 and
+    the 3-channel mask directly in branch 2 (pgrm.py:547).  The reference can only run it with b1, b2 <= 2: a longer
+    residual list needs weight_list_1, which PGRM(iter = 0) does not own (pgrm.py:563-564)."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    args = workload.make_args("tsrn", 2, 2, B)
+    args.sr_share = True
+    return TextSR(workload.make_config(B), args)
+
+
+def test_sr_share_real_modules_eval_and_train_step_vs_oracle(dev):
+    from oracle import dpmn as odpmn, pgrm as opgrm, cmm as ocmm, tsrn as otsrn
+    name = "sr_share_tsrn2p2_B4"
+    B, b1, b2 = 4, 2, 2
+    sr_ = _share_setup(dev, B)
+    models, psn, distill, crit, trainer = sr_.build_training()
+    assert len(models) == 3 and not models[0].mode and models[1].mode, "shared list = [mode-False PGRM, mode-True PGRM, CMM]"
+    for i, m in enumerate([psn] + models + distill):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, 500 + i)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                v.copy_(sd[k])
+    psn.eval()
+    sd0 = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in [psn] + models + distill]
+    batch = synth.synth_batch(B, seed=8)
+    priors = [torch.floor(synth.uniform("sq%d" % k, (B, 2, 32, 128), 0, 256, 8)) for k in range(b1)]
+    lr_d, hr_d = batch["images_lr"].to(dev), batch["images_hr"].to(dev)
+    # ---- eval: the shared mode-False PGRM in all four stages
+    for m in models:
+        m.eval()
+    out = sr_.refine(models, psn, lr_d, None, text_priors=[p.to(dev) for p in priors])
+    ref = odpmn.refine(sd0[0], [sd0[1]] * 4, sd0[3], "tsrn", b1, b2, batch["images_lr"], None, priors, 0.5)
+    record(name, "eval output max|err|", max_abs_err(out, ref), 1e-4)
+    assert_close(out, ref, 1e-4, 1e-4, "sr_share eval vs oracle")
+    # ---- one training step: model 0 is used four times, model 1 never
+    for m in models + distill:
+        m.train()
+    loss = sr_.train_step(models, psn, distill, crit, trainer, lr_d, hr_d, None, text_priors=[p.to(dev) for p in priors])
+    mk = lambda sd: {k: v.clone().requires_grad_(torch.is_floating_point(v) and "running" not in k and "index" not in k and "mask" not in k)
+                     for k, v in sd.items()}
+    shared, rcmm, rdist = mk(sd0[1]), mk(sd0[3]), [mk(sd0[4]), mk(sd0[5])]
+    with torch.no_grad():
+        lr_psn = otsrn.tsrn_forward(sd0[0], batch["images_lr"])
+    hr3 = batch["images_hr"][:, :3]
+    tot, casc, l1, l2 = 0, lr_psn, [], []
+    for k in range(b1):
+        o = opgrm.pgrm_forward(shared, priors[k], casc[:, :3], l1[:k]); l1.append(o); casc = o
+        tot = tot + ocmm.image_loss(o, hr3, True) * 100
+    casc = lr_psn
+    for k in range(b1, b1 + b2):
+        o = opgrm.pgrm_forward(shared, ocmm.to_mask(casc.detach()[:, :3]), casc[:, :3], l2[:k - b2]); l2.append(o); casc = o
+        tot = tot + ocmm.image_loss(o, hr3, True) * 100
+    ld, _ = ocmm.distill_forward(rdist[0], l1[-1], l1[0], True); tot = tot + ld * 100
+    ld, _ = ocmm.distill_forward(rdist[1], l2[-1], l2[0], True); tot = tot + ld * 100
+    o = ocmm.cmm_forward(rcmm, l1[-1], l2[-1], True)
+    tot = (tot + ocmm.image_loss(o, hr3, True) * 100) / (b1 + b2 + 1)
+    tot.backward()
+    le = abs(float(loss) - float(tot)) / abs(float(tot))
+    record(name, "train loss rel err", le, 1e-6)
+    assert le < 1e-6, (float(loss), float(tot))
+    for tag, m, rsd, tol in (("shared PGRM (4 uses)", models[0], shared, 6e-4), ("CMM", models[2], rcmm, 2e-3),
+                             ("distill 0", distill[0], rdist[0], 1e-5), ("distill 1", distill[1], rdist[1], 1e-5)):
+        num = den = 0.0
+        for n_, p_ in m.named_parameters():
+            g_ref = rsd[n_].grad if rsd[n_].grad is not None else torch.zeros_like(rsd[n_])
+            d = p_.grad.detach().cpu().double() - g_ref.double()
+            num += float((d * d).sum()); den += float((g_ref.double() ** 2).sum())
+        e = (num / max(den, 1e-30)) ** 0.5
+        record(name, "%s whole-gradient rel L2" % tag, e, tol)
+        assert e < tol, (tag, e)
+    unused = models[1]
+    assert all(float(p_.grad.abs().max()) == 0.0 for p_ in unused.parameters()), "the mode-True PGRM is never called under --sr_share"
+    for (n_, p_) in unused.named_parameters():
+        assert torch.equal(p_.detach().cpu(), sd0[2][n_]), "zero gradient -> Adam leaves %s unchanged" % n_
+
+
+def test_cmm_eval_after_training_uses_the_updated_weights(dev):
+    """the eval-mode CMM pack (BatchNorm folded) is cached; Adam and the BatchNorm running statistics are
+    updated through raw pointers, so the cache must be dropped explicitly.  eval -> two train steps -> eval, each eval
+    against the oracle on the weights / running statistics of that moment."""
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    from dpmn_amd.train.optim import Trainer
+    from oracle import cmm as ocmm
+    name = "cmm_eval_train_eval"
+    B = 4
+    u = lambda n, shape, lo, hi: synth.uniform(n, shape, lo, hi, 83)
+    m = ComplementationModulationModule(cnum=16)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 97)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x1, x2 = u("x1", (B, 3, 32, 128), 0, 1).to(dev), u("x2", (B, 3, 32, 128), 0, 1).to(dev)
+    cpu_sd = lambda: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m.eval()
+    with torch.no_grad():
+        e0 = m(x1, x2)
+        r0 = ocmm.cmm_forward(cpu_sd(), x1.cpu(), x2.cpu(), False)
+    assert_close(e0, r0, 1e-4, 1e-4, "eval before training")
+    tr = Trainer([m], lr=1e-2, beta1=0.5, max_norm=0.25)
+    m.train()
+    for p in m.parameters():
+        p.requires_grad = True
+    for _ in range(2):
+        tr.zero_grad()
+        (m(x1, x2) ** 2).mean().mul(100).backward()
+        tr.step()
+    m.eval()
+    with torch.no_grad():
+        e1 = m(x1, x2)
+        r1 = ocmm.cmm_forward(cpu_sd(), x1.cpu(), x2.cpu(), False)
+    moved = max_abs_err(r1, r0)
+    assert moved > 1e-2, "two Adam steps at lr 1e-2 + new running statistics must move the eval output (moved %.2e)" % moved
+    record(name, "eval after 2 train steps max|err| vs oracle on the updated weights", max_abs_err(e1, r1), 1e-4)
+    assert_close(e1, r1, 1e-4, 1e-4, "eval after training must use the updated weights and running statistics")
