@@ -52,6 +52,8 @@ def parse():
                     help="branch-1 text priors: precomputed synthetic tensors (default) or the in-loop batched VisionLAN + glyph-atlas "
                          "pipeline inside the timed step (BASELINE.json configs[3]: 'VisionLAN text-prior branch enabled')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="fwd mode: skip the `train` object (configs[2] step timed after the forward region)")
+    ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the `train` object")
     ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="images in the CPU-baseline sample (default: the per-GPU batch)")
     return ap.parse_args()
@@ -149,6 +151,126 @@ def cpu_baseline(workload_name, n_img, budget_s=300):
             "sample": "%s forward on one batch of %d synthetic images, %s, torch %s CPU fp32 oracle" % (workload_name, n_img, note, torch.__version__)}
 
 
+def timed_leg(step, steps, warmup, profiling, torch, dist, _abi, post=3):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks.
+    Returns (seconds, rows of the dominant family event-timed inside the timed steps, per-family rows of `post` extra steps)."""
+    dominant = None
+    n_pick = min(2, warmup)                        # all families armed on the last warm-up steps: who is the dominant kernel?
+    for i in range(warmup):                         # (two steps: the top two families of the forward are within 5 % of each other)
+        if profiling and i == warmup - n_pick:
+            torch.cuda.synchronize()
+            _abi.profile_begin(None)
+        step()
+        if profiling and i == warmup - 1:
+            torch.cuda.synchronize()
+            rows = _abi.profile_end()
+            if rows:
+                dominant = max(rows, key=lambda r: r["total_ms"])["kernel"]
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    if profiling and dominant:
+        _abi.profile_begin([dominant])     # only this family is bracketed by events inside the timed region
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    live = _abi.profile_end() if (profiling and dominant) else []
+    if dist.is_initialized():
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernels = []
+    if profiling and post:
+        _abi.profile_begin(None)
+        for _ in range(post):
+            step()
+        torch.cuda.synchronize()
+        kernels = sorted((kernel_row(r, post) for r in _abi.profile_end()), key=lambda k: -k["ms_per_step"])[:10]
+    return elapsed, live, kernels
+
+
+def roofline_of(live, steps, B):
+    if not live:
+        return None
+    r = kernel_row(live[0], steps)
+    traffic, src = static_traffic(r["kernel"], B)
+    return {"kernel": r["kernel"], "bound": r["bound"],
+            "achieved": r["tflops"] if r["bound"] == "mfma" else r["gbs"],
+            "peak": FP32_MFMA_PEAK_TFLOPS if r["bound"] == "mfma" else HBM_PEAK_GBS,
+            "unit": "TFLOP/s" if r["bound"] == "mfma" else "GB/s", "frac": r["frac"],
+            "traffic": traffic, "traffic_kind": None if traffic is None else "static: per-launch mean from the rocprofv3 --pmc passes in profiles/%s" % src,
+            "algorithmic_bytes_per_launch": round(live[0]["bytes"] / live[0]["launches"]),
+            "flops_per_launch": round(live[0]["flops"] / live[0]["launches"]),
+            "launches_timed": live[0]["launches"], "us_per_launch": r["us_per_launch"], "ms_per_step": r["ms_per_step"],
+            "timing": "HIP events around each of the %d launches of this family inside the timed steps, on the launch stream" % live[0]["launches"]}
+
+
+TRAIN_GFLOP_PER_IMAGE = 36.0      # SURVEY.md 8(d): 3 x (6 PGRM 6.81 + CMM 4.46) + PSN forward, config 1 / 2 stack
+
+
+def build_train_step(args, workload, world, force_dist, dist, torch, drop):
+    """BASELINE.json configs[2]: the training step of the workload's stack (own models: the forward leg's stay in eval)."""
+    from dpmn_amd.loss.image_loss import ImageLoss
+    from dpmn_amd.model.distill_module import DistillModule
+    from dpmn_amd.train.optim import Trainer
+    sr, models, psn, inp = workload.build(args.workload, batch=args.batch, drop=drop)
+    spec = workload.describe(args.workload)
+    b1, b2 = spec["b1"], spec["b2"]
+    torch.manual_seed(2)       # every rank builds the same DistillModules (the Trainer broadcasts rank 0's anyway)
+    distill = [DistillModule().to(sr.device) for _ in range(b1 + b2 - 2)]
+    crit = ImageLoss(gradient=True, loss_weight=[1, 1])
+    for m in models + distill:
+        m.train()
+        for p in m.parameters():
+            p.requires_grad = True
+    trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=world, zero1=args.zero1,
+                      force_collectives=force_dist and dist.is_initialized())
+
+    def step():
+        return sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
+                             text_priors=inp["text_priors"])
+    if args.graph and world == 1:
+        run = sr.graphed_train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"],
+                                    inp.get("label_vecs"), inp["text_priors"])
+
+        def step():   # noqa: F811  (same batch every step, like the eager path of this bench)
+            return run(inp["images_lr"], inp["images_hr"], inp.get("label_vecs"), inp["text_priors"])
+    return step, trainer, inp["images_lr"].shape[0]
+
+
+def train_object(args, workload, world, rank, force_dist, dist, torch, _abi):
+    """The `train` object of the default line: the configs[2] training step timed in the same process after the forward
+    region, without dropout (with the dominant family's live roofline) and with Dropout = attn_drop = DropPath = 0.1."""
+    out = {}
+    profiling = rank == 0 and not args.no_kernel_profile
+    for drop in (0.0, 0.1):
+        step, trainer, B = build_train_step(args, workload, world, force_dist, dist, torch, drop)
+        steps, warmup = args.train_steps, max(2, min(args.warmup, 3))
+        elapsed, live, kernels = timed_leg(step, steps, warmup, profiling and drop == 0.0, torch, dist, _abi, post=2 if drop == 0.0 else 0)
+        ms = elapsed / steps * 1e3
+        rec = {"ms_per_step": round(ms, 3), "images_per_s": round(world * B * steps / elapsed, 2), "steps": steps, "warmup": warmup,
+               "timed_seconds": round(elapsed, 4)}
+        if drop == 0.0:
+            out.update(rec)
+            out["what"] = "config 2 step on the same stack: forward, ImageLoss + distill, backward, per-model clip 0.25, Adam%s" % (
+                "" if world == 1 else ", RCCL gradient exchange (%s)" % ("reduce-scatter + sharded clip/Adam + all-gather" if trainer.zero1 else "all-reduce"))
+            out["algorithmic_gflop_per_image"] = TRAIN_GFLOP_PER_IMAGE
+            out["whole_step_frac_of_fp32_mfma_peak"] = round(TRAIN_GFLOP_PER_IMAGE * 1e9 * B / (ms * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4)
+            out["roofline"] = roofline_of(live, steps, B)
+            out["kernels"] = kernels[:6]
+        else:
+            out["with_dropout_0.1"] = rec
+        del step, trainer
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
         return cpu_baseline_worker(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
@@ -178,34 +300,15 @@ def main():
         else:
             dist.init_process_group(backend)
     from dpmn_amd import workload, _abi
-    sr, models, psn, inp = workload.build(args.workload, batch=args.batch, drop=args.drop if args.mode == "train" else 0)
-    B = inp["images_lr"].shape[0]
     spec = workload.describe(args.workload)
     arch, b1, b2 = spec["arch"], spec["b1"], spec["b2"]
-
     if args.mode == "train":
-        from dpmn_amd.loss.image_loss import ImageLoss
-        from dpmn_amd.model.distill_module import DistillModule
-        from dpmn_amd.train.optim import Trainer
-        torch.manual_seed(2)       # every rank builds the same DistillModules (the Trainer broadcasts rank 0's anyway)
-        distill = [DistillModule().to(sr.device) for _ in range(b1 + b2 - 2)]
-        crit = ImageLoss(gradient=True, loss_weight=[1, 1])
-        for m in models + distill:
-            m.train()
-            for p in m.parameters():
-                p.requires_grad = True
-        trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=world, zero1=args.zero1,
-                          force_collectives=force_dist and dist.is_initialized())
-
-        def step():
-            return sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
-                                 text_priors=inp["text_priors"])
-        if args.graph and world == 1:
-            run = sr.graphed_train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"],
-                                        inp.get("label_vecs"), inp["text_priors"])
-
-            def step():   # noqa: F811  (same batch every step, like the eager path of this bench)
-                return run(inp["images_lr"], inp["images_hr"], inp.get("label_vecs"), inp["text_priors"])
+        step, trainer, B = build_train_step(args, workload, world, force_dist, dist, torch, args.drop)
+    else:
+        sr, models, psn, inp = workload.build(args.workload, batch=args.batch)
+        B = inp["images_lr"].shape[0]
+    if args.mode == "train":
+        pass
     elif args.prior == "visionlan":
         prior_fn = workload.build_text_prior(sr, b1)
 
@@ -216,45 +319,7 @@ def main():
             return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
 
     profiling = rank == 0 and not args.graph and not args.no_kernel_profile
-    dominant = None
-    n_pick = min(2, args.warmup)                   # all families armed on the last warm-up steps: who is the dominant kernel?
-    for i in range(args.warmup):                    # (two steps: the top two families of the forward are within 5 % of each other)
-        if profiling and i == args.warmup - n_pick:
-            torch.cuda.synchronize()
-            _abi.profile_begin(None)
-        step()
-        if profiling and i == args.warmup - 1:
-            torch.cuda.synchronize()
-            rows = _abi.profile_end()
-            if rows:
-                dominant = max(rows, key=lambda r: r["total_ms"])["kernel"]
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    if profiling and dominant:
-        _abi.profile_begin([dominant])     # only this family is bracketed by events inside the timed region
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist.is_initialized():
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    live = _abi.profile_end() if (profiling and dominant) else []
-    if dist.is_initialized():
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kernels = []
-    if profiling:
-        post = 3
-        _abi.profile_begin(None)
-        for _ in range(post):
-            step()
-        torch.cuda.synchronize()
-        kernels = sorted((kernel_row(r, post) for r in _abi.profile_end()), key=lambda k: -k["ms_per_step"])[:10]
+    elapsed, live, kernels = timed_leg(step, args.steps, args.warmup, profiling, torch, dist, _abi)
     if rank == 0:
         what = "forward" if args.mode == "fwd" else "training step"
         line = {
@@ -271,21 +336,17 @@ def main():
                                ("dp%d (coalesced gradient groups, RCCL %s overlapped with backward)" % (
                                    world, "reduce-scatter + sharded clip/Adam + all-gather" if (world > 1 and trainer.zero1) else "all-reduce"))},
         }
-        roof = None
-        if live:
-            r = kernel_row(live[0], args.steps)
-            traffic, src = static_traffic(r["kernel"], B)
-            roof = {"kernel": r["kernel"], "bound": r["bound"],
-                    "achieved": r["tflops"] if r["bound"] == "mfma" else r["gbs"],
-                    "peak": FP32_MFMA_PEAK_TFLOPS if r["bound"] == "mfma" else HBM_PEAK_GBS,
-                    "unit": "TFLOP/s" if r["bound"] == "mfma" else "GB/s", "frac": r["frac"],
-                    "traffic": traffic, "traffic_kind": None if traffic is None else "static: per-launch mean from the rocprofv3 --pmc passes in profiles/%s" % src,
-                    "algorithmic_bytes_per_launch": round(live[0]["bytes"] / live[0]["launches"]),
-                    "flops_per_launch": round(live[0]["flops"] / live[0]["launches"]),
-                    "launches_timed": live[0]["launches"], "us_per_launch": r["us_per_launch"], "ms_per_step": r["ms_per_step"],
-                    "timing": "HIP events around each of the %d launches of this family inside the timed steps, on the launch stream" % live[0]["launches"]}
+        roof = roofline_of(live, args.steps, B)
         line["roofline"] = roof
         line["kernels"] = kernels
+    # the configs[2] training step, timed after the forward region in the same process (every rank takes part: the step holds
+    # the RCCL gradient exchange when N > 1); headline `value` stays the forward
+    train = None
+    if args.mode == "fwd" and args.workload == "cfg1" and args.prior == "synthetic" and not args.no_train and not args.graph:
+        del step
+        train = train_object(args, workload, world, rank, force_dist, dist, torch, _abi)
+    if rank == 0:
+        line["train"] = train
         line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.mode != "fwd") else cpu_baseline(args.workload, args.cpu_sample or B) if args.prior == "synthetic" else None   # N=1 only
         print(json.dumps(line))
     if dist.is_initialized():

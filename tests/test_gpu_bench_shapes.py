@@ -2,7 +2,8 @@
 factors at B = 48 / cnum = 64 than at the small batches of the other tests, so the benchmarked configuration is checked
 as it runs: (a) config 1 whole stack, B = 48, every intermediate vs the oracle + PSNR/SSIM to 1e-3; (b) CMM cnum = 64 in
 train mode, forward + backward vs oracle autograd at B = 8; (c) the config-2 training step on the TATT 3+3 stack (B = 4).
-Achieved errors are recorded (helpers.record -> gpurun_out/parity_errors.json), tolerances = measured x ~3."""
+Achieved errors are recorded (helpers.record -> gpurun_out/parity_errors.json, copied to profiles/); tolerances = measured x ~3
+(profiles/r03*_parity_errors.json), never below 1e-5 relative (fp32 reduction-order noise between boxes)."""
 import pytest
 import torch
 
@@ -35,13 +36,13 @@ def test_cfg1_whole_stack_at_bench_batch_vs_oracle(dev):
     torch.set_num_threads(min(32, torch.get_num_threads()))
     with torch.no_grad():
         r_psn, _ = otsrn.tatt_forward(sd_psn, cpu["images_lr"], cpu["label_vecs"])
-        assert_close(mid["psn"], r_psn, 2e-5, 2e-5, "TATT PSN B=48")
-        record(name, "psn max|err|", max_abs_err(mid["psn"], r_psn), 2e-5)
+        assert_close(mid["psn"], r_psn, 1e-5, 1e-5, "TATT PSN B=48")
+        record(name, "psn max|err|", max_abs_err(mid["psn"], r_psn), 1e-5)
         casc, l1 = r_psn, []
         for k in range(3):
             o = opgrm.pgrm_forward(sds[k], cpu["text_priors"][k], casc[:, :3], l1[:k]); l1.append(o); casc = o
-            e = record(name, "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 1e-4)
-            assert_close(mid["branch1"][k], o, 1e-4, 1e-4, "branch1[%d]" % k)
+            e = record(name, "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 8e-5)
+            assert_close(mid["branch1"][k], o, 8e-5, 8e-5, "branch1[%d]" % k)
         casc_gpu, casc, l2 = mid["psn"], r_psn, []
         flips = 0
         for k in range(3, 6):
@@ -49,16 +50,16 @@ def test_cfg1_whole_stack_at_bench_batch_vs_oracle(dev):
             flips += int((m_gpu != ocmm.to_mask(casc[:, :3])).sum()) // 3
             o = opgrm.pgrm_forward(sds[k], m_gpu, casc[:, :3], l2[:(k - 3)]); l2.append(o); casc = o
             casc_gpu = mid["branch2"][k - 3]
-            record(name, "branch2[%d] max|err|" % (k - 3), max_abs_err(casc_gpu, o), 1e-4)
-            assert_close(casc_gpu, o, 1e-4, 1e-4, "branch2[%d]" % (k - 3))
+            record(name, "branch2[%d] max|err|" % (k - 3), max_abs_err(casc_gpu, o), 5e-5)
+            assert_close(casc_gpu, o, 5e-5, 5e-5, "branch2[%d]" % (k - 3))
         record(name, "mask pixels flipped (of %d)" % (3 * B * 32 * 128), flips, 3 * B * 32 * 128 * 2e-5)
         assert flips <= 3 * B * 32 * 128 * 2e-5
         fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
-        record(name, "cmm max|err|", max_abs_err(mid["cmm"], fused), 3e-4)
-        assert_close(mid["cmm"], fused, 3e-4, 3e-4, "CMM cnum 64 at B=48")
+        record(name, "cmm max|err|", max_abs_err(mid["cmm"], fused), 2.5e-4)
+        assert_close(mid["cmm"], fused, 2.5e-4, 2.5e-4, "CMM cnum 64 at B=48")
         ref = 0.5 * fused + 0.5 * r_psn[:, :3]
-    assert_close(out, ref, 2e-4, 2e-4, "cfg1 B=48 output")
-    record(name, "output max|err|", max_abs_err(out, ref), 2e-4)
+    assert_close(out, ref, 1.3e-4, 1.3e-4, "cfg1 B=48 output")
+    record(name, "output max|err|", max_abs_err(out, ref), 1.3e-4)
     p, s = ops.psnr_ssim(out, inp["images_hr"])
     dp = abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"])))
     ds = abs(float(s) - float(ocmm.ssim(ref, cpu["images_hr"])))
@@ -86,8 +87,8 @@ def test_cmm_cnum64_train_fwd_bwd_at_b8_vs_oracle_autograd(dev):
     m = m.to(dev).train()
     x1d, x2d = x1.to(dev).requires_grad_(True), x2.to(dev).requires_grad_(True)
     out = m(x1d, x2d)
-    record(name, "forward max|err|", max_abs_err(out, out_ref.detach()), 2e-4)
-    assert_close(out, out_ref.detach(), 2e-4, 2e-4, "CMM cnum 64 train-mode forward")
+    record(name, "forward max|err|", max_abs_err(out, out_ref.detach()), 1.2e-4)
+    assert_close(out, out_ref.detach(), 1.2e-4, 1.2e-4, "CMM cnum 64 train-mode forward")
     (out * cot.to(dev)).sum().backward()
     e1, e2 = l2_rel(x1d.grad, x1r.grad), l2_rel(x2d.grad, x2r.grad)
     record(name, "dx1 rel L2", e1, 1e-2)
@@ -107,15 +108,15 @@ def test_cmm_cnum64_train_fwd_bwd_at_b8_vs_oracle_autograd(dev):
         worst = max(worst, (n_, l2_rel(p.grad, g_ref)), key=lambda t_: t_[1])
     # per tensor: the deepest levels (en_6 / de_6: 1x4 maps, 32 samples per BatchNorm channel at B = 8) are fp32-conditioned
     # -- two torch CPU evaluations of the same CMM already differ by 3e-3 .. 1.2e-2 there (tests/test_oracle_grads.py)
-    record(name, "worst parameter-gradient rel L2 (%s)" % worst[0], worst[1], 3e-2)
+    record(name, "worst parameter-gradient rel L2 (%s)" % worst[0], worst[1], 2e-2)
     record(name, "whole-gradient rel L2", (num / den) ** 0.5, 1e-2)
-    assert worst[1] < 3e-2, worst
+    assert worst[1] < 2e-2, worst
     assert (num / den) ** 0.5 < 1e-2
 
 
 # tolerances of the step test = ~3x the errors recorded in profiles/ (r02f at B = 4, r03 at B = 48), floor 1e-5
-CFG2_TOL = {4: dict(loss=1e-6, pgrm=3e-4, pgrm_b2=2.5e-3, cmm=2e-3, distill=1e-5),
-            48: dict(loss=1e-6, pgrm=3e-4, pgrm_b2=2.5e-3, cmm=2e-3, distill=1e-5)}
+CFG2_TOL = {4: dict(loss=1e-6, pgrm=3e-4, pgrm_b2=2.5e-3, cmm=2e-3, distill=2e-3),
+            48: dict(loss=2e-6, pgrm=5e-4, pgrm_b2=3e-3, cmm=3.6e-3, distill=4.5e-4)}
 
 
 @pytest.mark.parametrize("B", [4, 48])
@@ -214,21 +215,21 @@ def test_cfg3_as_named_inloop_visionlan_prior_b64_vs_oracle(dev):
     torch.set_num_threads(min(32, torch.get_num_threads()))
     with torch.no_grad():
         r_psn = otsrn.tbsrn_forward(sd_psn, cpu["images_lr"])
-        record(name, "psn max|err|", max_abs_err(mid["psn"], r_psn), 6e-5)
-        assert_close(mid["psn"], r_psn, 6e-5, 6e-5, "TBSRN PSN B=64")
+        record(name, "psn max|err|", max_abs_err(mid["psn"], r_psn), 3.5e-5)
+        assert_close(mid["psn"], r_psn, 3.5e-5, 3.5e-5, "TBSRN PSN B=64")
         casc, l1 = r_psn, []
         for k in range(3):
             casc_gpu, prior_gpu, (cls_gpu, len_gpu) = seen[k]
             assert casc_gpu.data_ptr() == (mid["psn"] if k == 0 else mid["branch1"][k - 1]).data_ptr()
             img_gpu = ov.resize_for_visionlan(casc_gpu[:, :3].cpu())
             flips = int((img_gpu != ov.resize_for_visionlan(casc[:, :3])).sum())
-            record(name, "stage %d recogniser-input pixels quantised differently (of %d)" % (k, img_gpu.numel()), flips, img_gpu.numel() * 2e-3)
-            assert flips <= img_gpu.numel() * 2e-3
+            record(name, "stage %d recogniser-input pixels quantised differently (of %d)" % (k, img_gpu.numel()), flips, img_gpu.numel() * 5e-4)
+            assert flips <= img_gpu.numel() * 5e-4
             lg_ref = ov.logits(rec_sds[k], img_gpu)
             lg_gpu, cls2, len2 = fn.recognizers[k].recognise(casc_gpu[:, :3])
             assert torch.equal(cls2, cls_gpu) and torch.equal(len2, len_gpu), "recognise() is deterministic"
-            record(name, "stage %d logits max|err|" % k, max_abs_err(lg_gpu, lg_ref), 3e-5)
-            assert_close(lg_gpu, lg_ref, 3e-5, 3e-5, "VisionLAN logits, stage %d, B=64" % k)
+            record(name, "stage %d logits max|err|" % k, max_abs_err(lg_gpu, lg_ref), 2e-5)
+            assert_close(lg_gpu, lg_ref, 2e-5, 2e-5, "VisionLAN logits, stage %d, B=64" % k)
             rc, rl, _ = ov.decode(lg_ref)
             n_len = int((rl != len_gpu.cpu().long()).sum())
             live = torch.arange(25)[None, :] < rl[:, None]
@@ -241,8 +242,8 @@ def test_cfg3_as_named_inloop_visionlan_prior_b64_vs_oracle(dev):
             record(name, "stage %d composed prior: pixels off by one grey level (fraction)" % k, float((d > 0).float().mean()), 2e-3)
             assert float(d.max()) <= 1.0 and float((d > 0).float().mean()) < 2e-3
             o = opgrm.pgrm_forward(sds[k], prior_gpu.cpu(), casc[:, :3], l1[:k]); l1.append(o); casc = o
-            record(name, "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 1e-4)
-            assert_close(mid["branch1"][k], o, 1e-4, 1e-4, "cfg3 branch1[%d]" % k)
+            record(name, "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 8e-5)
+            assert_close(mid["branch1"][k], o, 8e-5, 8e-5, "cfg3 branch1[%d]" % k)
         casc_gpu, casc, l2 = mid["psn"], r_psn, []
         flips = 0
         for k in range(3, 6):
@@ -250,16 +251,16 @@ def test_cfg3_as_named_inloop_visionlan_prior_b64_vs_oracle(dev):
             flips += int((m_gpu != ocmm.to_mask(casc[:, :3])).sum()) // 3
             o = opgrm.pgrm_forward(sds[k], m_gpu, casc[:, :3], l2[:(k - 3)]); l2.append(o); casc = o
             casc_gpu = mid["branch2"][k - 3]
-            record(name, "branch2[%d] max|err|" % (k - 3), max_abs_err(casc_gpu, o), 1e-4)
-            assert_close(casc_gpu, o, 1e-4, 1e-4, "cfg3 branch2[%d]" % (k - 3))
+            record(name, "branch2[%d] max|err|" % (k - 3), max_abs_err(casc_gpu, o), 6.5e-5)
+            assert_close(casc_gpu, o, 6.5e-5, 6.5e-5, "cfg3 branch2[%d]" % (k - 3))
         record(name, "mask pixels flipped (of %d)" % (3 * B * 32 * 128), flips, 3 * B * 32 * 128 * 2e-5)
         assert flips <= 3 * B * 32 * 128 * 2e-5
         fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
-        record(name, "cmm max|err|", max_abs_err(mid["cmm"], fused), 3e-4)
-        assert_close(mid["cmm"], fused, 3e-4, 3e-4, "CMM at B=64")
+        record(name, "cmm max|err|", max_abs_err(mid["cmm"], fused), 2.7e-4)
+        assert_close(mid["cmm"], fused, 2.7e-4, 2.7e-4, "CMM at B=64")
         ref = 0.5 * fused + 0.5 * r_psn[:, :3]
-    record(name, "output max|err|", max_abs_err(out, ref), 2e-4)
-    assert_close(out, ref, 2e-4, 2e-4, "cfg3 B=64 output")
+    record(name, "output max|err|", max_abs_err(out, ref), 1.4e-4)
+    assert_close(out, ref, 1.4e-4, 1.4e-4, "cfg3 B=64 output")
     p, s_ = ops.psnr_ssim(out, inp["images_hr"])
     dp = abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"])))
     ds = abs(float(s_) - float(ocmm.ssim(ref, cpu["images_hr"])))
@@ -350,8 +351,8 @@ def test_sr_share_real_modules_eval_and_train_step_vs_oracle(dev):
         m.eval()
     out = sr_.refine(models, psn, lr_d, None, text_priors=[p.to(dev) for p in priors])
     ref = odpmn.refine(sd0[0], [sd0[1]] * 4, sd0[3], "tsrn", b1, b2, batch["images_lr"], None, priors, 0.5)
-    record(name, "eval output max|err|", max_abs_err(out, ref), 1e-4)
-    assert_close(out, ref, 1e-4, 1e-4, "sr_share eval vs oracle")
+    record(name, "eval output max|err|", max_abs_err(out, ref), 6e-5)
+    assert_close(out, ref, 6e-5, 6e-5, "sr_share eval vs oracle")
     # ---- one training step: model 0 is used four times, model 1 never
     for m in models + distill:
         m.train()
@@ -378,7 +379,7 @@ def test_sr_share_real_modules_eval_and_train_step_vs_oracle(dev):
     le = abs(float(loss) - float(tot)) / abs(float(tot))
     record(name, "train loss rel err", le, 1e-6)
     assert le < 1e-6, (float(loss), float(tot))
-    for tag, m, rsd, tol in (("shared PGRM (4 uses)", models[0], shared, 6e-4), ("CMM", models[2], rcmm, 2e-3),
+    for tag, m, rsd, tol in (("shared PGRM (4 uses)", models[0], shared, 1e-3), ("CMM", models[2], rcmm, 7e-3),
                              ("distill 0", distill[0], rdist[0], 1e-5), ("distill 1", distill[1], rdist[1], 1e-5)):
         num = den = 0.0
         for n_, p_ in m.named_parameters():
@@ -430,5 +431,5 @@ def test_cmm_eval_after_training_uses_the_updated_weights(dev):
         r1 = ocmm.cmm_forward(cpu_sd(), x1.cpu(), x2.cpu(), False)
     moved = max_abs_err(r1, r0)
     assert moved > 1e-2, "two Adam steps at lr 1e-2 + new running statistics must move the eval output (moved %.2e)" % moved
-    record(name, "eval after 2 train steps max|err| vs oracle on the updated weights", max_abs_err(e1, r1), 1e-4)
-    assert_close(e1, r1, 1e-4, 1e-4, "eval after training must use the updated weights and running statistics")
+    record(name, "eval after 2 train steps max|err| vs oracle on the updated weights", max_abs_err(e1, r1), 5e-5)
+    assert_close(e1, r1, 5e-5, 5e-5, "eval after training must use the updated weights and running statistics")
