@@ -331,10 +331,10 @@ def main():
                 args.workload, spec["text"],
                 ("forward-only" + (", in-loop VisionLAN + glyph-atlas text priors" if args.prior == "visionlan" else "")) if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"
                 + (", dropout/attn_drop/drop_path %g" % args.drop if args.drop else "")),
-                "per_gpu_batch": B, "global_batch": B * world, "ranks": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else "")) if world > 1 else None,
+                "per_gpu_batch": B, "global_batch": B * world, "ranks": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else "") + (", collectives forced at world size 1 (DPMN_FORCE_DIST)" if world == 1 else "")) if dist.is_initialized() else None,
                 "parallelism": ("dp%d (independent batch shards, no forward collective)" % world) if args.mode == "fwd" else
                                ("dp%d (coalesced gradient groups, RCCL %s overlapped with backward)" % (
-                                   world, "reduce-scatter + sharded clip/Adam + all-gather" if (world > 1 and trainer.zero1) else "all-reduce"))},
+                                   world, "reduce-scatter + sharded clip/Adam + all-gather" if trainer.zero1 else "all-reduce"))},
         }
         roof = roofline_of(live, args.steps, B)
         line["roofline"] = roof

@@ -27,7 +27,10 @@
 #include "common.h"
 
 #ifndef FA_SKIP
-#define FA_SKIP 0      // timing ablations only (tools/variants): 1 no LayerNorm, 2 no projection MFMAs, 4 no attention, 8 no barrier, 16 no row loads
+#define FA_SKIP 0
+#endif
+#ifndef FA_SCHED
+#define FA_SCHED 2      // timing ablations only (tools/variants): 1 no LayerNorm, 2 no projection MFMAs, 4 no attention, 8 no barrier, 16 no row loads
 #endif
 
 namespace {
@@ -217,6 +220,19 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
         va[1] = mfma16(wf[5][s], xkv[c][s], va[1]);
       }
     }
+#if FA_SCHED
+    // issue order of the block above: the row statistics (vector ALU, independent of the MFMAs: they eat RAW rows) are
+    // dealt into the shadows of the 144 projection MFMAs, two vector instructions behind each
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int m = 0; m < 24; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, FA_SCHED, 0);
+      }
+    }
+#endif
     // y = rstd * acc - (rstd * mean) * rowsum(W') + b'   (two fma per value; the q rows of b' / rowsum(W') / rstd carry
     // head_dim ** -0.5 (pgrm.py:230-231) times log2(e): the softmax below is exp2(s - max)).  v, k, q in turn: short live ranges.
 #pragma unroll
