@@ -24,6 +24,9 @@
 // Algorithmic work per unit: projections 2*64*96*96 = 1.18 MFLOP + attention 4*N*16 FLOP per (token, head); bytes: the unit's
 // 128 input rows (49 KB) + 8 KB of output -- the kernel is MFMA-bound (AI ~57 FLOP/B).
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <utility>
 #include "common.h"
 
 #ifndef FA_SKIP
@@ -33,17 +36,30 @@
 #define FA_SCHED 2      // timing ablations only (tools/variants): 1 no LayerNorm, 2 no projection MFMAs, 4 no attention, 8 no barrier, 16 no row loads
 #endif
 
+#ifndef FA_TIMING
+#define FA_TIMING 0    // tools/fa_timeline.py: s_memtime stamps of the loop phases of wave 0 of the first 64 blocks
+#endif
+#if FA_TIMING
+__device__ unsigned long long g_fa_t[512][9][8];
+#define FA_STAMP(u, k) do { if (blockIdx.x < 512 && threadIdx.x == 0 && (u) < 9) g_fa_t[blockIdx.x][(u)][(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FA_STAMP(u, k) do {} while (0)
+#endif
+
 namespace {
 
 constexpr float QSCALE = 0.25f * 1.44269504088896340736f;      // head_dim ** -0.5 * log2(e)
 constexpr float LOG2E = 1.44269504088896340736f;
-constexpr int FC = 96, FCG = 32, FD = 16, LDW = FC + 4, LDK = FCG + 4, TBLMAX = 15 * 15 * 2;
+constexpr int FC = 96, FCG = 32, FD = 16, LDW = FC + 4, LDK = FCG + 4, TBLMAX = 15 * 15 * 2, TBLPAD = 452;
+constexpr int FOLD_STRIDE = FC * LDW + 2 * FC + TBLPAD;     // floats per group in the folded-weight workspace (a multiple of 4)
 
 struct FusedAttnArgs {
   const float *tq, *tkv, *lnq_w, *lnq_b, *lnkv_w, *lnkv_b, *wq, *bq, *wkv, *bkv;
   const float* table[3];
+  float* folded;                    // [3 groups][FOLD_STRIDE]: k_attn_fold's output, indexed by GROUP (not slot)
   int ws[3], shift[3], gid[3];      // processing slot s (expensive windows first) -> group gid[s]
-  int cost[3];                      // relative MFMA cost of one unit of slot s (36 + N/4), for the static load balance
+  int cost[3];                      // measured cost of one unit of slot s (hundreds of cycles), for the static load balance
+  int nblk[2][3];                   // blocks per slot on an XCD holding ceil(B/8) ([0]) / floor(B/8) ([1]) images; nblk[.][0] = 0: contiguous ranges
   float* out;
   int B, H, W;
   int lgW, lgS;                     // H, W (hence S = H*W/64 and every W / ws) are powers of two: index math is shifts and masks
@@ -94,6 +110,46 @@ __device__ __forceinline__ void load_rows(const FusedAttnArgs& a, int xcd, int i
   for (int c = 0; c < 6; ++c) xkv[c] = *reinterpret_cast<const f32x4*>(pk + 16 * c);
 }
 
+// Folded projection weights, once per call (they used to be rebuilt by every block at every slot change: 15 k cycles of a
+// 120 k-cycle kernel).  LayerNorm's affine goes into the projection, y = W (gamma * xhat + beta) + b = (W diag gamma) xhat +
+// (W beta + b), and the normalisation moves behind the MFMAs by linearity, W' xhat = rstd * (W' x - mean * rowsum(W')): the
+// MFMAs eat RAW rows, the per-element LayerNorm arithmetic becomes a 2-fma fix-up of the accumulators.
+// Output per group g: [96][LDW] W' (rows q 32 | k 32 | v 32) | b' [96] | rowsum(W') [96] | bias table * log2(e) [TBLPAD];
+// the q rows of b' / rowsum carry head_dim ** -0.5 * log2(e).  grid (97, 3) x 64 threads: block (r, g) = row r, block 96 = table.
+__global__ __launch_bounds__(64) void k_attn_fold(FusedAttnArgs a) {
+  const int g = blockIdx.y, r = blockIdx.x, tid = threadIdx.x;
+  float* dst = a.folded + (size_t)g * FOLD_STRIDE;
+  if (r == FC) {
+    int slot = 0;
+    for (int s_ = 1; s_ < 3; ++s_) if (a.gid[s_] == g) slot = s_;
+    const int n = (2 * a.ws[slot] - 1) * (2 * a.ws[slot] - 1) * 2;
+    for (int i = tid; i < TBLPAD; i += 64) dst[FC * LDW + 2 * FC + i] = i < n ? a.table[slot][i] * LOG2E : 0.f;
+    return;
+  }
+  __shared__ float part[24][2];
+  const float* srcw = r < 32 ? a.wq + (size_t)(FCG * g + r) * FC
+                             : (r < 64 ? a.wkv + (size_t)(FCG * g + r - 32) * FC : a.wkv + (size_t)(FC + FCG * g + r - 64) * FC);
+  const float* gam = r < 32 ? a.lnq_w : a.lnkv_w;
+  const float* bet = r < 32 ? a.lnq_b : a.lnkv_b;
+  if (tid < 24) {
+    const int c4 = 4 * tid;
+    const f32x4 wv = *reinterpret_cast<const f32x4*>(srcw + c4);
+    const f32x4 wg = wv * *reinterpret_cast<const f32x4*>(gam + c4), wb = wv * *reinterpret_cast<const f32x4*>(bet + c4);
+    *reinterpret_cast<f32x4*>(dst + r * LDW + c4) = wg;
+    part[tid][0] = (wg[0] + wg[1]) + (wg[2] + wg[3]);
+    part[tid][1] = (wb[0] + wb[1]) + (wb[2] + wb[3]);
+  } else if (tid == 24) {
+    *reinterpret_cast<f32x4*>(dst + r * LDW + FC) = (f32x4){0.f, 0.f, 0.f, 0.f};      // row padding
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float cw = 0.f, bb = r < 32 ? a.bq[FCG * g + r] : (r < 64 ? a.bkv[FCG * g + r - 32] : a.bkv[FC + FCG * g + r - 64]);
+    for (int k = 0; k < 24; ++k) { cw += part[k][0]; bb += part[k][1]; }      // fixed order
+    dst[FC * LDW + r] = r < 32 ? bb * QSCALE : bb;             // b' = b + W beta
+    dst[FC * LDW + FC + r] = r < 32 ? cw * QSCALE : cw;        // rowsum(W diag gamma)
+  }
+}
+
 // Units [first, last) of ONE slot (window size WS), decoded as unit i -> image xcd + 8 * (i / S), slab i % S.
 // Software pipeline (vmcnt retires in order, so the ONLY global loads inside the loop are the row prefetches):
 //   top: x = rows of unit i (arrived) -> LayerNorm -> projections (x dead) -> issue the loads of unit i+1 into the same
@@ -102,63 +158,41 @@ template <int WS>
 __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int xcd, int first, int last, float* smem) {
   constexpr int N = WS * WS, TBL = (2 * WS - 1) * (2 * WS - 1);
   constexpr int KT = (WS == 8) ? 4 : 1;    // key tiles per query tile
-  float* Wsm = smem;                       // [96][LDW]: rows 0-31 Wq, 32-63 Wk, 64-95 Wv of this group
-  float* KVs = Wsm + FC * LDW;             // 2 x { K [64][LDK], V [64][LDK] }: double-buffered across units (one barrier per unit)
-  float* tbl = KVs + 4 * 64 * LDK;         // [TBL][2]
-  int* reg_all = reinterpret_cast<int*>(tbl + TBLMAX);   // 2 x [64] shift-mask region of each token of the unit
-  float* lnp = reinterpret_cast<float*>(reg_all + 128);  // [4][96] LayerNorm q weight, q bias, kv weight, kv bias
-  float* pbias = lnp + 4 * FC;             // [2][96]: folded biases b' of this group's q (32), k (32), v (32) rows, then rowsum(W')
+  // LDS: [ Wsm [96][LDW] | pbias [2][96] | tbl [TBLPAD] ] = one contiguous copy of this group's block of the folded-weight
+  // workspace (k_attn_fold below), then the K / V exchange buffers and the shift-mask regions
+  float* Wsm = smem;                       // [96][LDW]: rows 0-31 W'q, 32-63 W'k, 64-95 W'v of this group (LayerNorm gamma folded in)
+  float* pbias = Wsm + FC * LDW;           // [2][96]: folded biases b' of the q / k / v rows, then rowsum(W')
+  float* tbl = pbias + 2 * FC;             // [TBL][2] relative position bias table, times log2(e)
+  float* KVs = tbl + TBLPAD;               // 2 x { K [64][LDK], V [64][LDK] }: double-buffered across units (one barrier per unit)
+  int* reg_all = reinterpret_cast<int*>(KVs + 4 * 64 * LDK);   // 2 x [64] shift-mask region of each token of the unit
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
   const int H = a.H, W = a.W, L = H * W, S = L / 64;
   const int g = a.gid[slot], shift = a.shift[slot];
-  const float* __restrict__ table = a.table[slot];
 
-  __syncthreads();                         // the previous slot's readers of the staged tables are done
-  // LayerNorm affine folded into the projection (y = W (g * xhat + beta) + b = (W diag g) xhat + (W beta + b)), and the
-  // normalisation moved behind the MFMAs by linearity: W' xhat = rstd * (W' x - mean * rowsum(W')).  So the MFMAs eat RAW
-  // rows (they need not wait for the statistics) and the per-element LayerNorm arithmetic disappears; what remains per unit
-  // is the two-pass row statistics and a 3-op fix-up of the 24 accumulator values.
-  for (int i = tid; i < 4 * FC; i += 256) {
-    const int which = i / FC, c = i % FC;
-    lnp[i] = which == 0 ? a.lnq_w[c] : (which == 1 ? a.lnq_b[c] : (which == 2 ? a.lnkv_w[c] : a.lnkv_b[c]));
-  }
-  for (int i = tid; i < TBL * 2; i += 256) tbl[i] = table[i] * LOG2E;      // logits are kept in log2 units
-  {
-    f32x4 wv[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {          // all nine loads in flight before the first use
-      const int i = tid + 256 * k, r = i / (FC / 4), c4 = (i % (FC / 4)) * 4;
-      const float* srcw = r < 32 ? a.wq + (size_t)(FCG * g + r) * FC
-                                 : (r < 64 ? a.wkv + (size_t)(FCG * g + r - 32) * FC : a.wkv + (size_t)(FC + FCG * g + r - 64) * FC);
-      wv[k] = *reinterpret_cast<const f32x4*>(srcw + c4);
-    }
-    __syncthreads();                       // lnp visible
-#pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      const int i = tid + 256 * k, r = i / (FC / 4), c4 = (i % (FC / 4)) * 4;
-      const f32x4 gm = *reinterpret_cast<const f32x4*>(lnp + (r < 32 ? 0 : 2 * FC) + c4);
-      const f32x4 bt = *reinterpret_cast<const f32x4*>(lnp + (r < 32 ? FC : 3 * FC) + c4);
-      const f32x4 wg = wv[k] * gm, wb = wv[k] * bt;
-      *reinterpret_cast<f32x4*>(Wsm + r * LDW + c4) = wg;
-      // per-row partial sums (24 four-column pieces per row) for rowsum(W') and W beta, reduced in a fixed order below
-      KVs[(r * 24 + c4 / 4) * 2] = (wg[0] + wg[1]) + (wg[2] + wg[3]);
-      KVs[(r * 24 + c4 / 4) * 2 + 1] = (wb[0] + wb[1]) + (wb[2] + wb[3]);
-    }
-  }
-  __syncthreads();
-  if (tid < FC) {
-    const int r = tid;
-    float cw = 0.f, bb = r < 32 ? a.bq[FCG * g + r] : (r < 64 ? a.bkv[FCG * g + r - 32] : a.bkv[FC + FCG * g + r - 64]);
-    for (int k = 0; k < 24; ++k) {
-      cw += KVs[(r * 24 + k) * 2];
-      bb += KVs[(r * 24 + k) * 2 + 1];
-    }
-    pbias[r] = r < 32 ? bb * QSCALE : bb;        // b' = b + W beta
-    pbias[FC + r] = r < 32 ? cw * QSCALE : cw;   // rowsum(W diag g)   (q rows: times head_dim ** -0.5 * log2(e))
-  }
-  __syncthreads();
+  // global loads in the order they are consumed (vmcnt retires in order): this group's folded weights, then the first unit's
+  // rows, which fly while the weights go to LDS
+  FA_STAMP(8, slot * 2);
   f32x4 xq[6], xkv[6];
-  load_rows<WS>(a, xcd, first, shift, wave, lr, kq, xq, xkv);
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.folded + (size_t)g * FOLD_STRIDE);
+    f32x4* dst = reinterpret_cast<f32x4*>(smem);
+    constexpr int NV4 = FOLD_STRIDE / 4, NIT = (NV4 + 255) / 256;
+    f32x4 wv[NIT];
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {        // the tail index is clamped, not predicated
+      const int i = tid + 256 * k;
+      wv[k] = src[i < NV4 ? i : NV4 - 1];
+    }
+    load_rows<WS>(a, xcd, first, shift, wave, lr, kq, xq, xkv);
+    __syncthreads();                       // the previous slot's readers of the staged tables are done
+#pragma unroll
+    for (int k = 0; k < NIT; ++k) {
+      const int i = tid + 256 * k;
+      if (i < NV4) dst[i] = wv[k];
+    }
+  }
+  __syncthreads();
+  FA_STAMP(8, slot * 2 + 1);
   // relative position bias of (my query, my keys): the same in every window, hence in every unit (pgrm.py:234-238).
   // 4x4 / 2x2: 8 values, kept in registers.  8x8: 32 values -- their table index is linear in the key tile
   // (idx(kt, r) = idx(3, r) + 60 (3 - kt)), so four base pointers + immediate offsets replace them.
@@ -192,6 +226,7 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
       const int rh = hr_ < H - WS ? 0 : (hr_ < H - shift ? 1 : 2), rw = wc_ < W - WS ? 0 : (wc_ < W - shift ? 1 : 2);
       reg_s[16 * wave + lr] = 3 * rh + rw;
     }
+    FA_STAMP(i - first, 0);
     float mq = 0.f, rq = 1.f, mk = 0.f, rk = 1.f;
     if (!(FA_SKIP & 1)) {
       row_stats(xq, a.eps, mq, rq);
@@ -199,6 +234,7 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
     }
     const float rqs = rq * QSCALE, nmq = -mq * rq, nmk = -mk * rk;     // (b' and rowsum(W') of the q rows are pre-scaled)
 
+    FA_STAMP(i - first, 1);
     // ---- projections: six independent accumulator tiles (q, k, v x 2 heads) interleaved over the 24 k-steps
     f32x4 qa[2], ka[2], va[2];
 #pragma unroll
@@ -220,6 +256,7 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
         va[1] = mfma16(wf[5][s], xkv[c][s], va[1]);
       }
     }
+    FA_STAMP(i - first, 2);
 #if FA_SCHED
     // issue order of the block above: the row statistics (vector ALU, independent of the MFMAs: they eat RAW rows) are
     // dealt into the shadows of the 144 projection MFMAs, two vector instructions behind each
@@ -261,7 +298,9 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
     // ---- the row registers are dead: send for unit i+1 now, the loads fly during this unit's attention (and the partner
     // wave's projection).  The index is clamped, not predicated: a load inside a branch makes hipcc drain vmcnt(0) at the join.
     if (!(FA_SKIP & 16)) load_rows<WS>(a, xcd, i + 1 < last ? i + 1 : i, shift, wave, lr, kq, xq, xkv);
+    FA_STAMP(i - first, 3);
     if (!(FA_SKIP & 8)) __syncthreads();
+    FA_STAMP(i - first, 4);
     if (FA_SKIP & 4) {
       float* dst = a.out + ((size_t)b * L + t) * FC + FCG * g + 4 * kq;
       *reinterpret_cast<f32x4*>(dst) = qa[0] + ka[0] + va[0];
@@ -328,8 +367,10 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
       o0 += o1;
       float* dst = a.out + ((size_t)b * L + t) * FC + FCG * g + 16 * h + 4 * kq;
       *reinterpret_cast<float4*>(dst) = make_float4(o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv);
+      FA_STAMP(i - first, 5 + h);
     }
   }
+  FA_STAMP(8, 6 + (slot == 2 ? 1 : 0));
 }
 
 // units of this XCD's list whose cumulative start cost is < c
@@ -359,6 +400,21 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_window_attn(FusedAttnArgs a) 
   const int ni = xcd < a.B ? (a.B - xcd + 7) / 8 : 0;
   const int per = ni * S;                  // units per slot on this XCD
   if (per == 0) return;
+  if (FA_SKIP & 64) return;
+  const int* nb = a.nblk[ni == (a.B + 7) / 8 ? 0 : 1];
+  if (nb[0] > 0) {
+    // one slot per block: a block never changes the staged weights, and the units of a slot are dealt evenly (+-1) to its
+    // blocks; the block counts per slot come from the host (minimum of the predicted finish time of the slowest block)
+    const int slot = j < nb[0] ? 0 : (j < nb[0] + nb[1] ? 1 : 2);
+    const int jj = j - (slot == 0 ? 0 : (slot == 1 ? nb[0] : nb[0] + nb[1])), ns = nb[slot];
+    const int lo = (int)((long)per * jj / ns), hi = (int)((long)per * (jj + 1) / ns);
+    if (lo >= hi) return;
+    const int ws = a.ws[slot];
+    if (ws == 8) run_units<8>(a, slot, xcd, lo, hi, smem);
+    else if (ws == 4) run_units<4>(a, slot, xcd, lo, hi, smem);
+    else run_units<2>(a, slot, xcd, lo, hi, smem);
+    return;
+  }
   const int cs[3] = {a.cost[0], a.cost[1], a.cost[2]};
   const long ctot = (long)per * (cs[0] + cs[1] + cs[2]);
   const int u0 = units_before(ctot * j / nbx, per, cs);
@@ -375,6 +431,22 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_window_attn(FusedAttnArgs a) 
 }
 
 }  // namespace
+
+// One folded-weight buffer per (device, stream): a call's fold kernel and main kernel are stream-ordered, calls on
+// different streams must not share the buffer.  Allocated on first use (never during a hipGraph capture of a warmed-up step).
+static float* fold_buffer(hipStream_t st) {
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, float*> bufs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = bufs.find({dev, st});
+  if (it != bufs.end()) return it->second;
+  float* p = nullptr;
+  if (hipMalloc(&p, sizeof(float) * 3 * FOLD_STRIDE) != hipSuccess) return nullptr;
+  bufs[{dev, st}] = p;
+  return p;
+}
 
 extern "C" {
 
@@ -415,9 +487,9 @@ int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* 
                  "ln_qkv_window_attn: windows must be 2, 4 or 8 and divide the token grid (padding path of pgrm.py:200-207 not built)");
     DPMN_REQUIRE(bias_tables[g], "ln_qkv_window_attn: null bias table");
     a.gid[s] = g; a.ws[s] = ws; a.shift[s] = shifts[g]; a.table[s] = bias_tables[g];
-    a.cost[s] = 36 + ws * ws / 4;         // (576 projection + 4 N attention MFMAs per unit) / 16
+    a.cost[s] = ws == 8 ? 183 : (ws == 4 ? 151 : 146);   // cycles / 100 per unit at B = 48 (tools/fa_timeline.py, round 3)
   }
-  const size_t smem = (size_t)(FC * LDW + 4 * 64 * LDK + TBLMAX + 2 * 64 + 6 * FC) * sizeof(float);
+  const size_t smem = (size_t)(FOLD_STRIDE + 4 * 64 * LDK + 2 * 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -428,6 +500,9 @@ int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* 
   double attn = 0.0;
   for (int g = 0; g < 3; ++g) attn += 4.0 * windows[g] * windows[g] * FD * 2 * tokens;
   hipStream_t st = as_stream(stream);
+  a.folded = fold_buffer(st);
+  if (!a.folded) return dpmn_set_error(DPMN_ERR_LAUNCH, "ln_qkv_window_attn: folded-weight workspace allocation failed");
+  hipLaunchKernelGGL(k_attn_fold, dim3(FC + 1, 3), dim3(64), 0, st, a);
   ProfScope prof(PT_ATTN_FUSED, st, 2.0 * tokens * FC * (3 * FC) + attn, 4.0 * (3.0 * tokens * FC + 3.0 * FC * FC));
   static int n_cu = 0;
   if (!n_cu) {
@@ -440,9 +515,42 @@ int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* 
   long blocks = (long)bpc * n_cu;          // 2 resident blocks per CU (78 KB of LDS each); a multiple of 8
   const long need = ((3 * slabs + 7) / 8) * 8;
   if (blocks > need) blocks = need;
+  {
+    const int nbx = (int)(blocks / 8), S = H * W / 64, PRE = 50;
+    for (int w = 0; w < 2; ++w) {
+      const int ni = w == 0 ? (B + 7) / 8 : B / 8, per = ni * S;
+      a.nblk[w][0] = 0;
+      if (per == 0 || nbx < 3) continue;
+      long best = -1;
+      for (int n0 = 1; n0 <= nbx - 2; ++n0)
+        for (int n1 = 1; n0 + n1 <= nbx - 1; ++n1) {
+          const int n[3] = {n0, n1, nbx - n0 - n1};
+          long worst = 0, sum = 0;
+          for (int s_ = 0; s_ < 3; ++s_) {
+            const long t_ = PRE + (long)((per + n[s_] - 1) / n[s_]) * a.cost[s_];
+            worst = t_ > worst ? t_ : worst;
+            sum += t_ * n[s_];
+          }
+          const long key = worst * 1000000 + sum / nbx;
+          if (best < 0 || key < best) { best = key; a.nblk[w][0] = n0; a.nblk[w][1] = n1; a.nblk[w][2] = n[2]; }
+        }
+    }
+    static const int contiguous = getenv("DPMN_FA_CONTIG") ? atoi(getenv("DPMN_FA_CONTIG")) : 0;
+    if (contiguous) a.nblk[0][0] = a.nblk[1][0] = 0;
+  }
   hipLaunchKernelGGL(k_ln_qkv_window_attn, dim3((unsigned)blocks), dim3(256), smem, st, a);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
+
+#if FA_TIMING
+int dpmn_fa_timing_dump(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fa_t), sizeof(unsigned long long) * 512 * 9 * 8);
+}
+int dpmn_fa_timing_clear() {
+  static unsigned long long z[512 * 9 * 8];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fa_t), z, sizeof(z));
+}
+#endif
 
 }  // extern "C"
