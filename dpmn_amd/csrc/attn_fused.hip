@@ -24,9 +24,6 @@
 // Algorithmic work per unit: projections 2*64*96*96 = 1.18 MFLOP + attention 4*N*16 FLOP per (token, head); bytes: the unit's
 // 128 input rows (49 KB) + 8 KB of output -- the kernel is MFMA-bound (AI ~57 FLOP/B).
 #include <cstdlib>
-#include <map>
-#include <mutex>
-#include <utility>
 #include "common.h"
 
 #ifndef FA_SKIP
@@ -56,6 +53,9 @@ constexpr int FOLD_STRIDE = FC * LDW + 2 * FC + TBLPAD;     // floats per group 
 struct FusedAttnArgs {
   const float *tq, *tkv, *lnq_w, *lnq_b, *lnkv_w, *lnkv_b, *wq, *bq, *wkv, *bkv;
   const float* table[3];
+  float *q_out, *kv_out;            // TRAIN: the projections, (B L, 96) and (B L, 192) in raster token order, saved for the backward
+  float p_drop, inv_keep;           // TRAIN: attn_drop (pgrm.py:248), counter-based masks (common.h drop_scale)
+  unsigned long long seed;
   float* folded;                    // [3 groups][FOLD_STRIDE]: k_attn_fold's output, indexed by GROUP (not slot)
   int ws[3], shift[3], gid[3];      // processing slot s (expensive windows first) -> group gid[s]
   int cost[3];                      // measured cost of one unit of slot s (hundreds of cycles), for the static load balance
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64) void k_attn_fold(FusedAttnArgs a) {
 // Software pipeline (vmcnt retires in order, so the ONLY global loads inside the loop are the row prefetches):
 //   top: x = rows of unit i (arrived) -> LayerNorm -> projections (x dead) -> issue the loads of unit i+1 into the same
 //   registers -> attention of unit i + stores.
-template <int WS>
+template <int WS, bool TRAIN>
 __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int xcd, int first, int last, float* smem) {
   constexpr int N = WS * WS, TBL = (2 * WS - 1) * (2 * WS - 1);
   constexpr int KT = (WS == 8) ? 4 : 1;    // key tiles per query tile
@@ -295,6 +295,20 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
 #pragma unroll
       for (int e = 0; e < 4; ++e) qa[h][e] = fmaf(qa[h][e], rqs, fmaf(nmq, cq[e], bq4[e]));
     }
+    if (TRAIN) {
+      // training forward: q / k / v of this (token, group) go to HBM in raster token order, exactly the tensors the unfused
+      // q / kv Linear layers produce (pgrm.py:188,194) -- the backward kernels read them; q without the folded softmax scale
+      int hr_, wc_;
+      const size_t src = (size_t)b * L + source_row<WS>(t, H, W, a.lgW, shift, hr_, wc_);
+      constexpr float UNSCALE = 1.0f / QSCALE;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int f = FCG * g + 16 * h + 4 * kq;
+        *reinterpret_cast<f32x4*>(a.q_out + src * FC + f) = qa[h] * UNSCALE;
+        *reinterpret_cast<f32x4*>(a.kv_out + src * (2 * FC) + f) = ka[h];
+        *reinterpret_cast<f32x4*>(a.kv_out + src * (2 * FC) + FC + f) = va[h];
+      }
+    }
     // ---- the row registers are dead: send for unit i+1 now, the loads fly during this unit's attention (and the partner
     // wave's projection).  The index is clamped, not predicated: a load inside a branch makes hipcc drain vmcnt(0) at the join.
     if (!(FA_SKIP & 16)) load_rows<WS>(a, xcd, i + 1 < last ? i + 1 : i, shift, wave, lr, kq, xq, xkv);
@@ -354,6 +368,20 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
       den += __shfl_xor(den, 16, 64);
       den += __shfl_xor(den, 32, 64);
       const float inv = 1.0f / den;
+      if (TRAIN) {
+        // attn_drop on the probabilities (the denominator is over the undropped row); element index of (b, g, h, query t, key m)
+        // as documented for dpmn_window_attn_f32: ((((b G + g) heads + h) L + t) N + m)
+        if (a.p_drop > 0.f) {
+          const unsigned long long e0 = ((((unsigned long long)b * 3 + g) * 2 + h) * L + t) * N;
+#pragma unroll
+          for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int mkey = WS == 8 ? 16 * kt + 4 * kq + r : (WS == 4 ? 4 * kq + r : r);
+              sacc[kt][r] *= drop_scale(a.seed, e0 + mkey, a.p_drop, a.inv_keep);
+            }
+        }
+      }
       // O^T = V^T . P: two accumulator chains
       f32x4 o0 = (f32x4){0.f, 0.f, 0.f, 0.f}, o1 = o0;
 #pragma unroll
@@ -393,6 +421,7 @@ __device__ __forceinline__ int units_before(long c, int per, const int (&cs)[3])
 //   * the three groups' gathers of an image's rows (each row is needed once per group) meet in one XCD's L2,
 //   * the group's weight slice is staged once per block and slot (<= 3 times), not once per unit,
 //   * the next unit's rows are loaded while the current unit computes, and workgroup dispatch cost is paid 512 times, not 2304.
+template <bool TRAIN>
 __global__ __launch_bounds__(256, 2) void k_ln_qkv_window_attn(FusedAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, nbx = gridDim.x >> 3;
@@ -410,9 +439,9 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_window_attn(FusedAttnArgs a) 
     const int lo = (int)((long)per * jj / ns), hi = (int)((long)per * (jj + 1) / ns);
     if (lo >= hi) return;
     const int ws = a.ws[slot];
-    if (ws == 8) run_units<8>(a, slot, xcd, lo, hi, smem);
-    else if (ws == 4) run_units<4>(a, slot, xcd, lo, hi, smem);
-    else run_units<2>(a, slot, xcd, lo, hi, smem);
+    if (ws == 8) run_units<8, TRAIN>(a, slot, xcd, lo, hi, smem);
+    else if (ws == 4) run_units<4, TRAIN>(a, slot, xcd, lo, hi, smem);
+    else run_units<2, TRAIN>(a, slot, xcd, lo, hi, smem);
     return;
   }
   const int cs[3] = {a.cost[0], a.cost[1], a.cost[2]};
@@ -424,29 +453,13 @@ __global__ __launch_bounds__(256, 2) void k_ln_qkv_window_attn(FusedAttnArgs a) 
     const int hi = (u1 < (slot + 1) * per ? u1 : (slot + 1) * per) - slot * per;
     if (lo >= hi) continue;                // block-uniform
     const int ws = a.ws[slot];
-    if (ws == 8) run_units<8>(a, slot, xcd, lo, hi, smem);
-    else if (ws == 4) run_units<4>(a, slot, xcd, lo, hi, smem);
-    else run_units<2>(a, slot, xcd, lo, hi, smem);
+    if (ws == 8) run_units<8, TRAIN>(a, slot, xcd, lo, hi, smem);
+    else if (ws == 4) run_units<4, TRAIN>(a, slot, xcd, lo, hi, smem);
+    else run_units<2, TRAIN>(a, slot, xcd, lo, hi, smem);
   }
 }
 
 }  // namespace
-
-// One folded-weight buffer per (device, stream): a call's fold kernel and main kernel are stream-ordered, calls on
-// different streams must not share the buffer.  Allocated on first use (never during a hipGraph capture of a warmed-up step).
-static float* fold_buffer(hipStream_t st) {
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, float*> bufs;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  auto it = bufs.find({dev, st});
-  if (it != bufs.end()) return it->second;
-  float* p = nullptr;
-  if (hipMalloc(&p, sizeof(float) * 3 * FOLD_STRIDE) != hipSuccess) return nullptr;
-  bufs[{dev, st}] = p;
-  return p;
-}
 
 extern "C" {
 
@@ -462,17 +475,20 @@ int dpmn_ln_qkv_window_attn_supported(int C, int n_groups, int heads_per_group, 
   return 1;
 }
 
-int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
-                                const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
-                                const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
-                                int n_groups, int heads_per_group, float* out, int B, int H, int W, int C, dpmn_stream_t stream) {
+static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                             const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                             const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                             int n_groups, int heads_per_group, float* out, int B, int H, int W, int C, dpmn_stream_t stream,
+                             void* workspace, bool train, float* q_out, float* kv_out, float p_drop, unsigned long long seed) {
   DPMN_REQUIRE(tq && tkv && lnq_w && lnq_b && lnkv_w && lnkv_b && wq && bq && wkv && bkv && bias_tables && windows && shifts && out,
                "ln_qkv_window_attn: null pointer");
   DPMN_REQUIRE(B > 0, "ln_qkv_window_attn: empty batch");
   DPMN_REQUIRE(!(H & (H - 1)) && !(W & (W - 1)) && H >= 8 && W >= 8, "ln_qkv_window_attn: token grid sides must be powers of two >= 8");
   DPMN_REQUIRE(C == FC && n_groups == 3 && heads_per_group == 2 && (H * W) % 64 == 0,
                "ln_qkv_window_attn: built for dim 96 = 3 groups x 2 heads x 16 (config 1/2/3); other shapes use the unfused kernels");
+  DPMN_REQUIRE(!train || (q_out && kv_out && p_drop >= 0.f && p_drop < 1.f), "ln_qkv_window_attn_train: q_out / kv_out missing or p_drop outside [0, 1)");
   FusedAttnArgs a{};
+  a.q_out = q_out; a.kv_out = kv_out; a.p_drop = p_drop; a.inv_keep = train ? 1.0f / (1.0f - p_drop) : 1.0f; a.seed = seed;
   a.tq = tq; a.tkv = tkv; a.lnq_w = lnq_w; a.lnq_b = lnq_b; a.lnkv_w = lnkv_w; a.lnkv_b = lnkv_b;
   a.wq = wq; a.bq = bq; a.wkv = wkv; a.bkv = bkv; a.out = out; a.B = B; a.H = H; a.W = W; a.eps = eps;
   for (a.lgW = 0; (1 << a.lgW) < W; ++a.lgW) {}
@@ -492,7 +508,8 @@ int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* 
   const size_t smem = (size_t)(FOLD_STRIDE + 4 * 64 * LDK + 2 * 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const long slabs = (long)B * (H * W / 64);
@@ -500,8 +517,8 @@ int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* 
   double attn = 0.0;
   for (int g = 0; g < 3; ++g) attn += 4.0 * windows[g] * windows[g] * FD * 2 * tokens;
   hipStream_t st = as_stream(stream);
-  a.folded = fold_buffer(st);
-  if (!a.folded) return dpmn_set_error(DPMN_ERR_LAUNCH, "ln_qkv_window_attn: folded-weight workspace allocation failed");
+  DPMN_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0, "ln_qkv_window_attn: workspace (dpmn_ln_qkv_window_attn_workspace_bytes, 16-byte aligned) missing");
+  a.folded = static_cast<float*>(workspace);
   hipLaunchKernelGGL(k_attn_fold, dim3(FC + 1, 3), dim3(64), 0, st, a);
   ProfScope prof(PT_ATTN_FUSED, st, 2.0 * tokens * FC * (3 * FC) + attn, 4.0 * (3.0 * tokens * FC + 3.0 * FC * FC));
   static int n_cu = 0;
@@ -538,9 +555,30 @@ int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* 
     static const int contiguous = getenv("DPMN_FA_CONTIG") ? atoi(getenv("DPMN_FA_CONTIG")) : 0;
     if (contiguous) a.nblk[0][0] = a.nblk[1][0] = 0;
   }
-  hipLaunchKernelGGL(k_ln_qkv_window_attn, dim3((unsigned)blocks), dim3(256), smem, st, a);
+  if (train) hipLaunchKernelGGL(k_ln_qkv_window_attn<true>, dim3((unsigned)blocks), dim3(256), smem, st, a);
+  else hipLaunchKernelGGL(k_ln_qkv_window_attn<false>, dim3((unsigned)blocks), dim3(256), smem, st, a);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
+}
+
+int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                                const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                                const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                                int n_groups, int heads_per_group, float* out, void* workspace, int B, int H, int W, int C,
+                                dpmn_stream_t stream) {
+  return fused_attn_launch(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, eps, wq, bq, wkv, bkv, bias_tables, windows, shifts, n_groups,
+                           heads_per_group, out, B, H, W, C, stream, workspace, false, nullptr, nullptr, 0.f, 0ull);
+}
+
+size_t dpmn_ln_qkv_window_attn_workspace_bytes(void) { return sizeof(float) * 3 * FOLD_STRIDE; }
+
+int dpmn_ln_qkv_window_attn_train_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                                      const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                                      const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                                      int n_groups, int heads_per_group, float* out, float* q_out, float* kv_out, float p_drop,
+                                      unsigned long long seed, void* workspace, int B, int H, int W, int C, dpmn_stream_t stream) {
+  return fused_attn_launch(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, eps, wq, bq, wkv, bkv, bias_tables, windows, shifts, n_groups,
+                           heads_per_group, out, B, H, W, C, stream, workspace, true, q_out, kv_out, p_drop, seed);
 }
 
 #if FA_TIMING

@@ -77,10 +77,26 @@ def ln_qkv_window_attn(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, 
     (B, L, C) are the token streams before the LayerNorms; returns the window-major `cat` tensor (B, L, C)."""
     B, L, Cd = tq.shape
     out = torch.empty_like(tq)
+    ws = torch.empty(lib.dpmn_ln_qkv_window_attn_workspace_bytes() // 4, device=tq.device)      # folded weights of this call
     check(lib.dpmn_ln_qkv_window_attn_f32(dptr(tq), dptr(tkv), dptr(lnq_w), dptr(lnq_b), dptr(lnkv_w), dptr(lnkv_b), float(eps),
                                           dptr(wq), dptr(bq), dptr(wkv), dptr(bkv), _abi.ptr_array(tables), _abi.int_array(windows),
-                                          _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), B, H, W, Cd, stream()))
+                                          _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), dptr(ws), B, H, W, Cd, stream()))
     return out
+
+
+def ln_qkv_window_attn_train(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, tables, windows, shifts, heads_per_group, H, W,
+                             p_drop=0.0, seed=0, eps=1e-5):
+    """Training forward of ln_qkv_window_attn: returns (cat, q, kv) -- q (B, L, C) and kv (B, L, 2C) are what the backward reads."""
+    B, L, Cd = tq.shape
+    out = torch.empty_like(tq)
+    q = torch.empty_like(tq)
+    kv = torch.empty(B, L, 2 * Cd, device=tq.device)
+    ws = torch.empty(lib.dpmn_ln_qkv_window_attn_workspace_bytes() // 4, device=tq.device)
+    check(lib.dpmn_ln_qkv_window_attn_train_f32(dptr(tq), dptr(tkv), dptr(lnq_w), dptr(lnq_b), dptr(lnkv_w), dptr(lnkv_b), float(eps),
+                                                dptr(wq), dptr(bq), dptr(wkv), dptr(bkv), _abi.ptr_array(tables), _abi.int_array(windows),
+                                                _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), dptr(q), dptr(kv),
+                                                float(p_drop), int(seed), dptr(ws), B, H, W, Cd, stream()))
+    return out, q, kv
 
 
 def maxpool(x, kh, kw, scale=None, shift=None):

@@ -11,6 +11,7 @@ PGRM call are drawn from torch's CPU generator (draw_seeds), so torch.manual_see
 Philox masks themselves cannot be replayed by any other implementation, parity there is distributional.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -166,6 +167,8 @@ class ConvSpec:
         return ops.conv2d([dy], wt, None, self.cin, self.k, pad=self.pad)
 
 
+FUSED_ATTN = os.environ.get("DPMN_ATTN_FUSED_TRAIN", "1") != "0"      # 0: LayerNorm / q / kv / window-attention as separate launches
+
 N_SEEDS = 12     # [0] pos_drop(x_q) [1] pos_drop(x_kv); block bi at 2+5*bi: attn_drop, DropPath(attn), Mlp drop 1, Mlp drop 2, DropPath(mlp)
 
 
@@ -209,14 +212,24 @@ def forward(m, x_q, x_kv, residuals, drop=None):
         shift = [0 if (bi == 0 or min(H, Wd) <= w) else w // 2 for w in m.window_size]
         tables = [getattr(a, "relative_position_bias_table_%d" % g) for g in range(G)]
         s = dict(tkv_in=tkv, win=win, shift=shift, tables=tables)
-        s["nq"] = layernorm(tq, blk.norm1_q.weight, blk.norm1_q.bias)
-        s["nkv"] = layernorm(tkv, blk.norm1_kv.weight, blk.norm1_kv.bias)
-        s["q"] = ops.linear(s["nq"], a.q.weight, a.q.bias)
-        s["kv"] = ops.linear(s["nkv"], a.kv.weight, a.kv.bias)
         dpb = drop["dp"][bi] if drop else 0.0
         sb = sd[2 + 5 * bi:7 + 5 * bi]
-        s["cat"] = ops.window_attn(s["q"].reshape(B, L, Cd), s["kv"].reshape(B, L, 2 * Cd), tables, win, shift, hpg, H, Wd,
-                                   p_drop=pa, seed=sb[0]).reshape(M, Cd)
+        if FUSED_ATTN and ops.ln_qkv_window_attn_supported(Cd, win, hpg, H, Wd):
+            # norm1_q / norm1_kv + q / kv Linear + the three window sizes (+ attn_drop) in one launch; q and kv come back for the
+            # backward, the normalised tokens are NOT kept (the backward recomputes them: two LayerNorm launches there instead of
+            # two LayerNorm + two GEMM + three attention launches and 2 x 19 MB of saved activations here)
+            cat, q_, kv_ = ops.ln_qkv_window_attn_train(tq.reshape(B, L, Cd), tkv.reshape(B, L, Cd), blk.norm1_q.weight, blk.norm1_q.bias,
+                                                        blk.norm1_kv.weight, blk.norm1_kv.bias, a.q.weight, a.q.bias, a.kv.weight, a.kv.bias,
+                                                        tables, win, shift, hpg, H, Wd, p_drop=pa, seed=sb[0])
+            s["q"], s["kv"], s["cat"] = q_.reshape(M, Cd), kv_.reshape(M, 2 * Cd), cat.reshape(M, Cd)
+            s["nq"] = s["nkv"] = None
+        else:
+            s["nq"] = layernorm(tq, blk.norm1_q.weight, blk.norm1_q.bias)
+            s["nkv"] = layernorm(tkv, blk.norm1_kv.weight, blk.norm1_kv.bias)
+            s["q"] = ops.linear(s["nq"], a.q.weight, a.q.bias)
+            s["kv"] = ops.linear(s["nkv"], a.kv.weight, a.kv.bias)
+            s["cat"] = ops.window_attn(s["q"].reshape(B, L, Cd), s["kv"].reshape(B, L, 2 * Cd), tables, win, shift, hpg, H, Wd,
+                                       p_drop=pa, seed=sb[0]).reshape(M, Cd)
         s["feats"] = _e(M, Cd, like=tkv)
         s["partial"] = _e(B * parts, Cd, like=tkv)
         check(lib.dpmn_sk_proj_f32(dptr(s["cat"]), dptr(sk.proj.weight), dptr(sk.proj.bias), dptr(s["feats"]), dptr(s["partial"]), M, Cd, stream()))
@@ -341,9 +354,13 @@ def backward(m, sv, dout, need_dx_kv=True):
         check(lib.dpmn_window_attn_drop_bwd_f32(dptr(s["q"]), dptr(s["kv"]), _abi.ptr_array(s["tables"]), _abi.int_array(s["win"]),
                                                 _abi.int_array(s["shift"]), G, hpg, dptr(dcat), dptr(dq), dptr(dkv),
                                                 _abi.ptr_array(dtab), B, H, Wd, Cd, float(pa), int(sb[0]), stream()))
-        dnq = linear_bwd(dq, s["nq"], a.q.weight, gr[a.q.weight], gr[a.q.bias])
+        nq = s["nq"] if s["nq"] is not None else layernorm(sv["tq"], blk.norm1_q.weight, blk.norm1_q.bias)
+        dnq = linear_bwd(dq, nq, a.q.weight, gr[a.q.weight], gr[a.q.bias])
+        del nq
         layernorm_bwd(sv["tq"], dnq, blk.norm1_q.weight, dtq, True, gr[blk.norm1_q.weight], gr[blk.norm1_q.bias])
-        dnkv = linear_bwd(dkv, s["nkv"], a.kv.weight, gr[a.kv.weight], gr[a.kv.bias])
+        nkv = s["nkv"] if s["nkv"] is not None else layernorm(s["tkv_in"], blk.norm1_kv.weight, blk.norm1_kv.bias)
+        dnkv = linear_bwd(dkv, nkv, a.kv.weight, gr[a.kv.weight], gr[a.kv.bias])
+        del nkv
         layernorm_bwd(s["tkv_in"], dnkv, blk.norm1_kv.weight, dx1, True, gr[blk.norm1_kv.weight], gr[blk.norm1_kv.bias])
         dtkv = dx1
     if pd > 0:       # pos_drop on both token streams (pgrm.py:554-555)

@@ -65,12 +65,25 @@ int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float*
  * position bias + shift mask + softmax + P.V, written window-major without un-roll, quirk Q1).  tq / tkv: (B, H*W, C) token
  * streams BEFORE the LayerNorms; out: (B, H*W, C) = the `cat` tensor fed to SKConv.  q and kv never reach HBM.
  * Built for C = 96 = 3 groups x 2 heads x 16 with windows in {2, 4, 8} (configs 1-3); _supported() says whether a shape
- * qualifies (0: use dpmn_ln_linear_f32 x2 + dpmn_window_attn_f32).  Eval path only (no attn_drop). */
+ * qualifies (0: use dpmn_ln_linear_f32 x2 + dpmn_window_attn_f32). */
 int dpmn_ln_qkv_window_attn_supported(int C, int n_groups, int heads_per_group, const int* windows, int H, int W);
 int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
                                 const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
                                 const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
-                                int n_groups, int heads_per_group, float* out, int B, int H, int W, int C, dpmn_stream_t stream);
+                                int n_groups, int heads_per_group, float* out, void* workspace, int B, int H, int W, int C,
+                                dpmn_stream_t stream);
+/* workspace: dpmn_ln_qkv_window_attn_workspace_bytes() bytes of device memory, 16-byte aligned, private to the call's stream until
+ * the call has run -- it receives the projection weights with the LayerNorm affine folded in (one tiny kernel per call). */
+size_t dpmn_ln_qkv_window_attn_workspace_bytes(void);
+/* Training forward of the same fused kernel (interfaces/super_resolution.py:140-278 runs the PGRMs in .train()): also writes
+ * the projections q_out (B L, C) and kv_out (B L, 2 C) in raster token order -- the tensors a.q(norm1_q(x_q)) and
+ * a.kv(norm1_kv(x_kv)) of pgrm.py:188,194, which the backward kernels read -- and applies attn_drop (pgrm.py:248) with the
+ * counter-based masks of dpmn_window_attn_f32 (same element index, same seed => same masks as the unfused kernels). */
+int dpmn_ln_qkv_window_attn_train_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                                      const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                                      const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                                      int n_groups, int heads_per_group, float* out, float* q_out, float* kv_out, float p_drop,
+                                      unsigned long long seed, void* workspace, int B, int H, int W, int C, dpmn_stream_t stream);
 
 /* Measurement hooks for bench.py's roofline objects (no reference counterpart: the reference has no profiler, SURVEY.md
  * section 5).  While armed, every launch of a kernel family whose tag bit is set in tag_mask -- issued directly or from

@@ -362,3 +362,39 @@ def test_basiclayer_stress_dims_vs_reference_golden_and_oracle(dev):
     with torch.no_grad():
         _, o3 = m(xq3.to(dev), xkv3.to(dev))
     assert_close(o3, ref, 3e-4, 3e-4, "BasicLayer stress B=3 vs oracle")
+
+
+@pytest.mark.parametrize("B,shifts,p", [(3, [1, 2, 4], 0.0), (5, [0, 0, 0], 0.1), (48, [1, 2, 4], 0.1)])
+def test_fused_attention_training_variant_vs_oracle_and_unfused(dev, B, shifts, p):
+    """Training forward of the fused kernel (dpmn_ln_qkv_window_attn_train_f32): the saved q / kv equal Linear(LayerNorm(x)) of
+    pgrm.py:188,194, and `cat` under attn_drop equals the oracle with the SAME counter-based masks (and the unfused DROP kernels)."""
+    import os
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    from helpers import record, max_abs_err
+    if os.environ.get("DPMN_ATTN_FUSED") == "0":
+        pytest.skip("the fused kernel is switched off (DPMN_ATTN_FUSED=0)")
+    H, W, C = 16, 64, 96
+    g = load_golden("wattn_shift0" if shifts[0] == 0 else "wattn_shifted")
+    sd = sd_from_manifest(g["manifest"], 21)
+    lnq_w, lnq_b = u("tlnq_w", (C,), 0.5, 1.5), u("tlnq_b", (C,), -0.5, 0.5)
+    lnk_w, lnk_b = u("tlnk_w", (C,), 0.5, 1.5), u("tlnk_b", (C,), -0.5, 0.5)
+    tq, tkv = u("t_tq%d" % B, (B, H * W, C), -2, 3), u("t_tkv%d" % B, (B, H * W, C), -3, 2)
+    seed = 0x1234567 + B
+    q = F.linear(F.layer_norm(tq, (C,), lnq_w, lnq_b), sd["q.weight"], sd["q.bias"])
+    kv = F.linear(F.layer_norm(tkv, (C,), lnk_w, lnk_b), sd["kv.weight"], sd["kv.bias"])
+    ref = o.window_attention_core(q, kv[..., :C], kv[..., C:], sd, "", H, W, [2, 4, 8], shifts, 2, p_attn=p, seed=seed)
+    d = cu(sd, dev)
+    tables = [d["relative_position_bias_table_%d" % i] for i in range(3)]
+    cat, q_d, kv_d = ops.ln_qkv_window_attn_train(tq.to(dev), tkv.to(dev), lnq_w.to(dev), lnq_b.to(dev), lnk_w.to(dev), lnk_b.to(dev),
+                                                  d["q.weight"], d["q.bias"], d["kv.weight"], d["kv.bias"], tables, [2, 4, 8], shifts, 2, H, W,
+                                                  p_drop=p, seed=seed)
+    tag = "fused_train_B%d_p%g" % (B, p)
+    record(tag, "q max|err| vs oracle", max_abs_err(q_d, q), 1e-5)
+    record(tag, "kv max|err| vs oracle", max_abs_err(kv_d, kv), 1e-5)
+    record(tag, "cat max|err| vs oracle (same masks)", max_abs_err(cat, ref), 2e-5)
+    assert_close(q_d, q, 1e-5, 1e-5, "saved q")
+    assert_close(kv_d, kv, 1e-5, 1e-5, "saved kv")
+    assert_close(cat, ref, 2e-5, 2e-5, "fused training forward, attn_drop %g" % p)
+    unf = ops.window_attn(q_d, kv_d, tables, [2, 4, 8], shifts, 2, H, W, p_drop=p, seed=seed)
+    assert_close(cat, unf, 2e-5, 2e-5, "fused vs unfused DROP kernels on the saved q / kv")
