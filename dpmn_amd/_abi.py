@@ -37,7 +37,7 @@ class PgrmWeights(C.Structure):
         "n_weight_list")] + [("window", C.c_int * 4)] + [(n, fp) for n in (
             "prior_fusion_w", "prior_fusion_b", "pe_w", "pe_b", "pe_norm_w", "pe_norm_b")] + [
         ("blocks", PgrmBlock * 2)] + [(n, fp) for n in ("tail0_w", "tail0_b", "tail1_w", "tail1_b")] + [
-        ("weight_list", fp * 16)]
+        ("weight_list", fp * 16), ("reuse_folded", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -136,7 +136,7 @@ SIGNATURES = {
     "dpmn_vl_decode_i32": (_i, [fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_text_prior_compose_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_supported": (_i, [_i, _i, _i, _IP, _i, _i]),
-    "dpmn_ln_qkv_window_attn_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_ln_qkv_window_attn_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_train_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _f, _u64, fp, _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_workspace_bytes": (_sz, []),
     "dpmn_profile_tag_count": (_i, []),

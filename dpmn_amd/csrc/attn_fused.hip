@@ -479,7 +479,7 @@ static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq
                              const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
                              const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
                              int n_groups, int heads_per_group, float* out, int B, int H, int W, int C, dpmn_stream_t stream,
-                             void* workspace, bool train, float* q_out, float* kv_out, float p_drop, unsigned long long seed) {
+                             void* workspace, int refold, bool train, float* q_out, float* kv_out, float p_drop, unsigned long long seed) {
   DPMN_REQUIRE(tq && tkv && lnq_w && lnq_b && lnkv_w && lnkv_b && wq && bq && wkv && bkv && bias_tables && windows && shifts && out,
                "ln_qkv_window_attn: null pointer");
   DPMN_REQUIRE(B > 0, "ln_qkv_window_attn: empty batch");
@@ -519,7 +519,7 @@ static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq
   hipStream_t st = as_stream(stream);
   DPMN_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0, "ln_qkv_window_attn: workspace (dpmn_ln_qkv_window_attn_workspace_bytes, 16-byte aligned) missing");
   a.folded = static_cast<float*>(workspace);
-  hipLaunchKernelGGL(k_attn_fold, dim3(FC + 1, 3), dim3(64), 0, st, a);
+  if (refold) hipLaunchKernelGGL(k_attn_fold, dim3(FC + 1, 3), dim3(64), 0, st, a);
   ProfScope prof(PT_ATTN_FUSED, st, 2.0 * tokens * FC * (3 * FC) + attn, 4.0 * (3.0 * tokens * FC + 3.0 * FC * FC));
   static int n_cu = 0;
   if (!n_cu) {
@@ -564,10 +564,10 @@ static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq
 int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
                                 const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
                                 const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
-                                int n_groups, int heads_per_group, float* out, void* workspace, int B, int H, int W, int C,
-                                dpmn_stream_t stream) {
+                                int n_groups, int heads_per_group, float* out, void* workspace, int refold, int B, int H, int W,
+                                int C, dpmn_stream_t stream) {
   return fused_attn_launch(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, eps, wq, bq, wkv, bkv, bias_tables, windows, shifts, n_groups,
-                           heads_per_group, out, B, H, W, C, stream, workspace, false, nullptr, nullptr, 0.f, 0ull);
+                           heads_per_group, out, B, H, W, C, stream, workspace, refold, false, nullptr, nullptr, 0.f, 0ull);
 }
 
 size_t dpmn_ln_qkv_window_attn_workspace_bytes(void) { return sizeof(float) * 3 * FOLD_STRIDE; }
@@ -578,7 +578,7 @@ int dpmn_ln_qkv_window_attn_train_f32(const float* tq, const float* tkv, const f
                                       int n_groups, int heads_per_group, float* out, float* q_out, float* kv_out, float p_drop,
                                       unsigned long long seed, void* workspace, int B, int H, int W, int C, dpmn_stream_t stream) {
   return fused_attn_launch(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, eps, wq, bq, wkv, bkv, bias_tables, windows, shifts, n_groups,
-                           heads_per_group, out, B, H, W, C, stream, workspace, true, q_out, kv_out, p_drop, seed);
+                           heads_per_group, out, B, H, W, C, stream, workspace, 1, true, q_out, kv_out, p_drop, seed);
 }
 
 #if FA_TIMING

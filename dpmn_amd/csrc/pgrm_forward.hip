@@ -6,7 +6,7 @@
 
 namespace {
 struct Ws {
-  float *tq, *tkv, *q, *kv, *cat, *feats, *x1, *y, *g, *partial, *avec, *mid;
+  float *tq, *tkv, *q, *kv, *cat, *feats, *x1, *y, *g, *partial, *avec, *mid, *fold;
   size_t total;
 };
 
@@ -32,6 +32,7 @@ Ws carve(const dpmn_pgrm_weights* w, int B, char* base) {
   s.partial = take((size_t)B * ((L + 31) / 32) * C);
   s.avec = take((size_t)B * C);
   s.mid = take(B * L * (size_t)w->hidden_size * w->patch * w->patch + (size_t)16 * (9 * C + 32));
+  s.fold = take(2 * dpmn_ln_qkv_window_attn_workspace_bytes() / sizeof(float));     // folded attention weights of the two blocks
   s.total = off;
   return s;
 }
@@ -75,11 +76,12 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
       if ((H < Wd ? H : Wd) <= win[g]) { win[g] = H < Wd ? H : Wd; shift[g] = 0; }  // pgrm.py:147-150
     }
     if (dpmn_ln_qkv_window_attn_supported(C, w->n_groups, w->heads_per_group, win, H, Wd)) {
-      // LayerNorm + q / kv projection + window attention in one kernel: q and kv never reach HBM (attn_fused.hip); the unused
-      // q buffer holds the call's folded projection weights
-      DPMN_REQUIRE((size_t)M * C * sizeof(float) >= dpmn_ln_qkv_window_attn_workspace_bytes(), "pgrm_forward: q buffer smaller than the fused attention workspace");
+      // LayerNorm + q / kv projection + window attention in one kernel: q and kv never reach HBM (attn_fused.hip).  The folded
+      // projection weights of block blk live at the end of the workspace and survive between calls (reuse_folded)
       RUN(dpmn_ln_qkv_window_attn_f32(s.tq, s.tkv, p.norm1_q_w, p.norm1_q_b, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, p.q_w, p.q_b, p.kv_w,
-                                      p.kv_b, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat, s.q, B, H, Wd, C, stream));
+                                      p.kv_b, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat,
+                                      s.fold + blk * (dpmn_ln_qkv_window_attn_workspace_bytes() / sizeof(float)), w->reuse_folded ? 0 : 1,
+                                      B, H, Wd, C, stream));
     } else {
       RUN(dpmn_ln_linear_f32(s.tq, p.norm1_q_w, p.norm1_q_b, 1e-5f, p.q_w, p.q_b, s.q, M, C, C, DPMN_ACT_NONE, stream));
       RUN(dpmn_ln_linear_f32(s.tkv, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, p.kv_w, p.kv_b, s.kv, M, 2 * C, C, DPMN_ACT_NONE, stream));

@@ -211,6 +211,8 @@ class PGRM(nn.Module):
                                                    _Affine((pp, pp, 3, 3), kind="conv")])
         self._packed = None
         self._ws = None
+        self._fold_key = None      # (workspace pointer, B, parameter versions) the workspace holds folded attention weights for
+        self._pack = None          # train/optim.py Trainer.invalidate_packs() resets this after every optimizer step (raw-pointer updates)
 
     # ------------------------------------------------------------------ C-ABI weight table
     def _weights(self):
@@ -270,6 +272,11 @@ class PGRM(nn.Module):
         if self._ws is None or self._ws.numel() < need or self._ws.device != x_kv.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x_kv.device)
         out = torch.empty(B, self.hidden_size, self.img_size[0], self.img_size[1], device=x_kv.device)
+        # the LayerNorm-folded attention weights in the workspace stay valid while nothing touched the parameters: torch-side
+        # writes bump _version, the optimizer kernels (raw pointers) reset self._pack through Trainer.invalidate_packs()
+        fkey = (self._ws.data_ptr(), B, tuple(p._version for p in self.layers[0].parameters()))
+        w.reuse_folded = int(self._fold_key == fkey and self._pack is not None)
+        self._fold_key, self._pack = fkey, True
         _abi.check(_abi.lib.dpmn_pgrm_forward_f32(C.byref(w), _abi.dptr(x_q), x_q.shape[1], _abi.dptr(x_kv),
                                                   _abi.ptr_array(res), len(res), _abi.dptr(out), self._ws.data_ptr(),
                                                   self._ws.numel(), B, _abi.stream()))

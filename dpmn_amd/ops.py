@@ -80,7 +80,7 @@ def ln_qkv_window_attn(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, 
     ws = torch.empty(lib.dpmn_ln_qkv_window_attn_workspace_bytes() // 4, device=tq.device)      # folded weights of this call
     check(lib.dpmn_ln_qkv_window_attn_f32(dptr(tq), dptr(tkv), dptr(lnq_w), dptr(lnq_b), dptr(lnkv_w), dptr(lnkv_b), float(eps),
                                           dptr(wq), dptr(bq), dptr(wkv), dptr(bkv), _abi.ptr_array(tables), _abi.int_array(windows),
-                                          _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), dptr(ws), B, H, W, Cd, stream()))
+                                          _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), dptr(ws), 1, B, H, W, Cd, stream()))
     return out
 
 

@@ -369,7 +369,7 @@ class Trainer:
         """The optimizer kernels write parameters through raw pointers, so torch's `_version` counters never move: every
         module that caches eval-mode weight packs keyed on them (model/cmm.py `_pack`) must drop the cache explicitly."""
         for b in self.buckets:
-            if getattr(b.module, "_pack", None) is not None:
+            if getattr(b.module, "_pack", None) is not None:      # CMM: eval packs; PGRM: "the workspace holds the folded weights"
                 b.module._pack = None
 
     def state_snapshot(self):

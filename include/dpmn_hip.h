@@ -70,10 +70,12 @@ int dpmn_ln_qkv_window_attn_supported(int C, int n_groups, int heads_per_group, 
 int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
                                 const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
                                 const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
-                                int n_groups, int heads_per_group, float* out, void* workspace, int B, int H, int W, int C,
-                                dpmn_stream_t stream);
+                                int n_groups, int heads_per_group, float* out, void* workspace, int refold, int B, int H, int W,
+                                int C, dpmn_stream_t stream);
 /* workspace: dpmn_ln_qkv_window_attn_workspace_bytes() bytes of device memory, 16-byte aligned, private to the call's stream until
- * the call has run -- it receives the projection weights with the LayerNorm affine folded in (one tiny kernel per call). */
+ * the call has run -- it receives the projection weights with the LayerNorm affine folded in (one tiny kernel, when refold != 0).
+ * refold = 0: the caller vouches that the workspace still holds the fold of THESE weights and bias tables (frozen weights in
+ * evaluation: the fold kernel then runs once per module, not once per call). */
 size_t dpmn_ln_qkv_window_attn_workspace_bytes(void);
 /* Training forward of the same fused kernel (interfaces/super_resolution.py:140-278 runs the PGRMs in .train()): also writes
  * the projections q_out (B L, C) and kv_out (B L, 2 C) in raster token order -- the tensors a.q(norm1_q(x_q)) and
@@ -445,6 +447,8 @@ typedef struct {
   dpmn_pgrm_block blocks[2];
   const float *tail0_w, *tail0_b, *tail1_w, *tail1_b;
   const float* weight_list[16];   /* weight_list_0 .. weight_list_iter (iter <= 11 in the 6+6 stress stack) */
+  int reuse_folded;               /* != 0: the workspace (same pointer, same B) still holds the folded attention weights of a previous
+                                   * dpmn_pgrm_forward_f32 call with these weights -- skip the two fold kernels (frozen weights) */
 } dpmn_pgrm_weights;
 
 size_t dpmn_pgrm_workspace_bytes(const dpmn_pgrm_weights* w, int B);

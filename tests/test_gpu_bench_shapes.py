@@ -433,3 +433,46 @@ def test_cmm_eval_after_training_uses_the_updated_weights(dev):
     assert moved > 1e-2, "two Adam steps at lr 1e-2 + new running statistics must move the eval output (moved %.2e)" % moved
     record(name, "eval after 2 train steps max|err| vs oracle on the updated weights", max_abs_err(e1, r1), 5e-5)
     assert_close(e1, r1, 5e-5, 5e-5, "eval after training must use the updated weights and running statistics")
+
+
+def test_pgrm_eval_after_training_refolds_the_attention_weights(dev):
+    """The eval driver keeps the LayerNorm-folded attention weights in its workspace between calls (reuse_folded); an optimizer
+    step writes the parameters through raw pointers, so the cache must be dropped: eval -> eval (cached) -> train steps -> eval,
+    each against the oracle on the weights of that moment."""
+    from dpmn_amd.model.pgrm import PGRM
+    from dpmn_amd.train.optim import Trainer
+    from oracle import pgrm as opgrm
+    n = 6
+    args = dict(patch_size=[2] * n, embed_dim=[96] * n, depths=[1] * n, num_heads=[[6]] * n, window_size=[[2, 4, 8]] * n,
+                mlp_ratio=[4.] * n, drop_rate=[0.] * n, attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
+    m = PGRM(iter=0, mode=True, hidden_size=3, **args)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 98)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    B = 4
+    xq = (synth.uniform("fq", (B, 3, 32, 128), 0, 1, 84) > 0.5).float().to(dev)
+    xkv = synth.uniform("fkv", (B, 3, 32, 128), 0, 1, 84).to(dev)
+    cpu_sd = lambda: {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    m.eval()
+    with torch.no_grad():
+        e0 = m(xq, xkv, [])
+        e0b = m(xq, xkv, [])          # second call: folded weights reused
+        r0 = opgrm.pgrm_forward(cpu_sd(), xq.cpu(), xkv.cpu(), [])
+    assert torch.equal(e0, e0b)
+    assert_close(e0, r0, 1e-4, 1e-4, "eval before training")
+    tr = Trainer([m], lr=1e-2, beta1=0.5, max_norm=0.25)
+    m.train()
+    for p in m.parameters():
+        p.requires_grad = True
+    for _ in range(2):
+        tr.zero_grad()
+        (m(xq, xkv, []) ** 2).mean().mul(100).backward()
+        tr.step()
+    m.eval()
+    with torch.no_grad():
+        e1 = m(xq, xkv, [])
+        r1 = opgrm.pgrm_forward(cpu_sd(), xq.cpu(), xkv.cpu(), [])
+    assert max_abs_err(r1, r0) > 1e-3, "the training steps must move the output"
+    record("pgrm_eval_train_eval", "eval after 2 train steps max|err| vs oracle on the updated weights", max_abs_err(e1, r1), 1e-4)
+    assert_close(e1, r1, 1e-4, 1e-4, "eval after training must refold the attention weights")

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-cpu-baseline --no-kernel-profile"
+B="python $R/bench.py --no-cpu-baseline --no-kernel-profile --no-train"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fwd -- $B --steps 10 --warmup 3 > $OUT/fwd.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -- $B --mode train --steps 5 --warmup 2 > $OUT/train.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 3 --warmup 2 > $OUT/pmc_fetch.log 2>&1

@@ -460,9 +460,79 @@ def gen_visionlan():
 GENS = {"visionlan": gen_visionlan, "grads": gen_grads, "step": gen_step, "stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
 
 
+
+def gen_collate():
+    """Data path: the reference's own `resizeNormalize` and `alignCollate_realWTLAMask.__call__`
+    (dataset/dataset.py:1266-1319, 1966-2076) and `str_filt` (utils/util.py) run on five synthetic RGB images of ragged sizes
+    (the generator of tests/test_dataset.py::_fake_env, RandomState(7)) and labels that exercise every branch of the label
+    spreading (1 char, empty, 2..25 chars, >= 26 chars, out-of-alphabet characters).
+    Import-time shims beyond tools/ref_shims.py (none of them executed except ToTensor): lmdb, imgaug.augmenters (constructed by
+    alignCollate_syn.__init__, never applied by this class), cv2, torchvision.utils.  torchvision.transforms.ToTensor IS executed
+    and is stood in for by its definition for uint8 PIL images (HWC uint8 -> CHW float32 / 255): torchvision is absent."""
+    import types
+    from PIL import Image
+
+    class _Any:
+        def __getattr__(self, k):
+            return _Any()
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+    class ToTensor:
+        def __call__(self, img):
+            a = np.asarray(img, dtype=np.uint8)
+            if a.ndim == 2:
+                a = a[:, :, None]
+            return torch.from_numpy(np.ascontiguousarray(a.transpose(2, 0, 1))).float().div(255)
+
+    tvt = sys.modules["torchvision.transforms"]
+    tvt.ToTensor = ToTensor
+    tvt.ToPILImage = _Any
+    sys.modules["torchvision"].utils = types.ModuleType("torchvision.utils")
+    sys.modules["torchvision.utils"] = sys.modules["torchvision"].utils
+    sys.modules["torchvision.utils"].make_grid = None
+    sys.modules["torchvision"].transforms = tvt
+    for name in ("lmdb", "imgaug"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["imgaug.augmenters"] = _Any()
+    sys.modules["imgaug"].augmenters = sys.modules["imgaug.augmenters"]
+    import scipy
+    scipy.finfo = np.finfo      # version skew: dataset.py builds an (unused here) blur kernel at import through scipy.finfo (removed in scipy 1.x)
+    from dataset import dataset as rds       # /root/reference/dataset/dataset.py
+    from utils import str_filt as ref_str_filt
+
+    rng = np.random.RandomState(7)
+    words = ["Hello", "a", "", "SuperResolution-2023!", "abcdefghijklmnopqrstuvwxyz0123"]
+    batch = []
+    for i in range(1, 6):
+        hr = rng.randint(0, 256, (40 + 3 * i, 150 + 7 * i, 3)).astype(np.uint8)
+        lr = rng.randint(0, 256, (18 + i, 70 + 3 * i, 3)).astype(np.uint8)
+        ph, pl = Image.fromarray(hr), Image.fromarray(lr)
+        batch.append((ph, pl, ph, pl, ref_str_filt(words[i - 1], "all")))
+    out = {}
+    for mask in (True, False):
+        col = rds.alignCollate_realWTLAMask(imgH=32, imgW=128, down_sample_scale=2, mask=mask)
+        r = col(batch)
+        tag = "mask" if mask else "nomask"
+        out["hr_" + tag] = r[0].numpy()
+        out["lr_" + tag] = r[2].numpy()
+        if mask:
+            out["label_vecs"] = r[6].numpy()
+            out["weighted_masks"] = r[7].numpy()
+            out["weighted_tics"] = r[8].numpy()
+            out["label_strs"] = np.array(list(r[5]))
+    filt_in = ["Hello, World!", "abc DEF 123", "", "!!", "MiXed-Case_09"]
+    for voc in ("lower", "upper", "all", "digit"):
+        out["str_filt_" + voc] = np.array([ref_str_filt(w, voc) for w in filt_in])
+    out["str_filt_in"] = np.array(filt_in)
+    save("collate", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["all"]
+    GENS["collate"] = gen_collate      # last: it installs extra import shims (lmdb, imgaug, torchvision.utils)
     for name, fn in GENS.items():
         if "all" in which or name in which:
             fn()

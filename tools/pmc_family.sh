@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT; tag=$1; shift
 OUT=$R/gpurun_out/pmc_$tag; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do export "$v"; done
-B="python $R/bench.py --no-cpu-baseline --no-kernel-profile --steps 3 --warmup 2"
+B="python $R/bench.py --no-cpu-baseline --no-kernel-profile --no-train --steps 3 --warmup 2"
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
 cd $R
