@@ -139,6 +139,7 @@ SIGNATURES = {
     "dpmn_ln_qkv_window_attn_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_train_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _f, _u64, fp, _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_workspace_bytes": (_sz, []),
+    "dpmn_collate_u8_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_profile_tag_count": (_i, []),
     "dpmn_profile_tag_name": (C.c_char_p, [_i]),
     "dpmn_profile_begin": (_i, [C.c_ulonglong, _i]),

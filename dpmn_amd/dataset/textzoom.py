@@ -89,19 +89,45 @@ class resizeNormalize(object):
         return t
 
 
+class resizeU8(object):
+    """Host half of the GPU collate: the same PIL bicubic resize as resizeNormalize, returned as the raw uint8 HWC pixels --
+    ToTensor and the mask channel run on the GPU (csrc/misc.hip k_collate_u8 through finish_on_gpu)."""
+
+    def __init__(self, size, interpolation=None):
+        from PIL import Image
+        self.size = size
+        self.interpolation = Image.BICUBIC if interpolation is None else interpolation
+
+    def __call__(self, img):
+        return torch.from_numpy(np.asarray(img.resize(self.size, self.interpolation), dtype=np.uint8).copy())
+
+
+def finish_on_gpu(images_u8, mask, device):
+    """(B, H, W, 3) uint8 from a gpu_finish collate -> (B, 3 + mask, H, W) float on `device` (one 3-byte-per-pixel upload and one
+    kernel per batch instead of B x (ToTensor + convert('L') + point + cat) on the host and a 16-byte-per-pixel upload)."""
+    from .. import ops
+    return ops.collate_u8(images_u8.to(device, non_blocking=True), mask)
+
+
 class alignCollate_realWTLAMask(object):
     """collate_fn of the training loader (base.py:99-102); returns the 9-tuple of dataset.py:2076 with None in the positions of
-    the YUV copies and the pseudo-LR batch."""
+    the YUV copies and the pseudo-LR batch.  gpu_finish=True (ours): positions 0 and 2 hold the resized uint8 (B, H, W, 3) pixels
+    and `sr_batches(loader, device)` finishes them on the GPU -- same values, bit for bit (tests/test_gpu_dataset.py)."""
 
     def __init__(self, imgH=64, imgW=256, down_sample_scale=4, keep_ratio=False, min_ratio=1, mask=False, alphabet=53, train=True,
-                 y_domain=False):
+                 y_domain=False, gpu_finish=False):
         self.imgH, self.imgW, self.down_sample_scale, self.mask = imgH, imgW, down_sample_scale, mask
+        self.gpu_finish = gpu_finish
         self.alphabet = "0123456789abcdefghijklmnopqrstuvwxyz"
         self.d2a = "-" + self.alphabet
         self.alsize = len(self.d2a)
         self.a2d = {ch: i for i, ch in enumerate(self.d2a)}
-        self.transform = resizeNormalize((imgW, imgH), mask)
-        self.transform2 = resizeNormalize((imgW // down_sample_scale, imgH // down_sample_scale), mask)
+        if gpu_finish:
+            self.transform = resizeU8((imgW, imgH))
+            self.transform2 = resizeU8((imgW // down_sample_scale, imgH // down_sample_scale))
+        else:
+            self.transform = resizeNormalize((imgW, imgH), mask)
+            self.transform2 = resizeNormalize((imgW // down_sample_scale, imgH // down_sample_scale), mask)
 
     def __call__(self, batch):
         images_HR, images_lr, _, _, label_strs = zip(*batch)
@@ -137,8 +163,12 @@ class alignCollate_realWTLAMask(object):
         return images_HR, None, images_lr, None, None, label_strs, label_rebatches, torch.tensor(weighted_masks).long(), torch.tensor(weighted_tics)
 
 
-def sr_batches(loader):
+def sr_batches(loader, device=None, mask=True):
     """Adapter for TextSR.train / eval / test: (images_hr, images_lr, label_vecs, label_strs) per batch.  label_vecs is None: for
-    --arch tatt the reference derives them from a CRNN on the LR image (super_resolution.py:165-169), not from the dataset."""
+    --arch tatt the reference derives them from a CRNN on the LR image (super_resolution.py:165-169), not from the dataset.
+    Batches of a gpu_finish collate (uint8 pixels) are finished on `device` here."""
     for data in loader:
-        yield data[0], data[2], None, list(data[5])
+        hr, lr = data[0], data[2]
+        if hr.dtype == torch.uint8:
+            hr, lr = finish_on_gpu(hr, mask, device), finish_on_gpu(lr, mask, device)
+        yield hr, lr, None, list(data[5])

@@ -78,7 +78,8 @@ class TextBase(object):
         loader = torch.utils.data.DataLoader(
             ds, batch_size=bs, shuffle=shuffle and sampler is None, sampler=sampler, num_workers=int(cfg.workers), pin_memory=True,
             drop_last=drop_last,
-            collate_fn=tz.alignCollate_realWTLAMask(imgH=cfg.height, imgW=cfg.width, down_sample_scale=cfg.down_sample_scale, mask=self.mask))
+            collate_fn=tz.alignCollate_realWTLAMask(imgH=cfg.height, imgW=cfg.width, down_sample_scale=cfg.down_sample_scale, mask=self.mask,
+                                                    gpu_finish=True))      # ToTensor + mask channel on the GPU (dataset/textzoom.py)
         if shard:
             self.train_sampler = sampler
         return ds, loader

@@ -2,10 +2,11 @@
 
 ``refine`` is the forward stack shared by eval()/test() in the reference (super_resolution.py:370-449 /
 628-704): frozen PSN -> branch 1 (text-prior PGRMs) -> branch 2 (mask-prior PGRMs) -> CMM -> alpha
-blend with the PSN image.  Every tensor op runs in libdpmn_hip.so.  Text priors come from a callable
-(``text_prior_fn(cascade_images, k) -> (B,2,H,W)`` uint8-valued floats, quirk Q6): the recogniser +
-glyph renderer that produce them in the reference are out of scope, so
-the synthetic source of dpmn_amd.utils.synth is the default.
+blend with the PSN image.  Every tensor op of the SR path runs in libdpmn_hip.so.  Text priors come from a callable
+(``text_prior_fn(cascade_images, k) -> (B,2,H,W)`` uint8-valued floats, quirk Q6): by default the batched VisionLAN +
+glyph-atlas pipeline of interfaces/text_prior.py (--rec_path), or seeded noise priors with
+--synthetic_prior.  On real TextZoom data (dataset/textzoom.py) --arch tatt gets its label_vecs from the frozen CRNN mirror
+(model/crnn.py, super_resolution.py:165-169).
 """
 import csv
 import os
@@ -122,6 +123,8 @@ class TextSR(base.TextBase):
         for data in val_loader:
             images_hr, images_lr = data[0].to(self.device), data[1].to(self.device)
             label_vecs = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
+            if label_vecs is None and self.args.arch == 'tatt':      # real data: TATT's label_vecs come from the frozen CRNN (lines 165-169)
+                label_vecs = self.label_vecs_from_crnn(images_lr)
             if getattr(self.args, "rotate_test", 0):      # super_resolution.py:358-365 (angle range from rotate_train, as there)
                 images_lr, images_hr = self.rotate_pair(images_lr, images_hr, self.args.rotate_train)
             sr = self.refine(model_list, model_psn, images_lr, label_vecs, fn)
@@ -263,7 +266,8 @@ class TextSR(base.TextBase):
         return run
 
     def train(self, loader=None, steps=None, val_loader=None, rec=None, epochs=None, sampler=None):
-        """Training loop (super_resolution.py:125-337) over (images_hr, images_lr, label_vecs) batches.
+        """Training loop (super_resolution.py:125-337) over (images_hr, images_lr, label_vecs) batches (synthetic ones, or the
+        TextZoom reader of dataset/textzoom.py through main.py).
         loader: a callable `loader(epoch) -> iterable` (a fresh pass per epoch), a re-iterable (list, DataLoader-like: walked
         once per epoch for `epochs` / config.TRAIN.epochs epochs, `for epoch in range(cfg.epochs)` of the reference), or a
         one-shot iterator (a single epoch).  sampler: a DistributedSampler whose set_epoch is called per epoch.
@@ -357,6 +361,6 @@ class TextSR(base.TextBase):
         under --resume (all required: there is no evaluation of untrained weights)."""
         models, psn = self.build_models(testing=True)
         if loader is None:
-            raise RuntimeError("dpmn_amd: TextZoom LMDB loading is out of scope (SURVEY.md section 2 row 18); pass a loader of "
-                               "(images_hr, images_lr, label_vecs) batches, e.g. dpmn_amd.utils.synth.synth_batch")
+            raise RuntimeError("dpmn_amd: pass a loader of (images_hr, images_lr, label_vecs) batches: "
+                               "dataset.textzoom.sr_batches(self.get_test_data(dir)[1], device) or dpmn_amd.utils.synth.synth_batch")
         return self.eval(models, loader, 0, rec=rec, model_psn=psn)

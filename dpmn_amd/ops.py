@@ -99,6 +99,18 @@ def ln_qkv_window_attn_train(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv,
     return out, q, kv
 
 
+def collate_u8(img_u8, with_mask):
+    """(B, H, W, 3) uint8 (PIL-resized RGB, on the GPU) -> (B, 3 + mask, H, W) float: ToTensor + the mask channel of
+    resizeNormalize (dataset.py:1266-1319)."""
+    if not img_u8.is_cuda or img_u8.dtype != torch.uint8:
+        raise _abi.DpmnError("collate_u8: a CUDA uint8 (B, H, W, 3) tensor is required")
+    img_u8 = img_u8.contiguous()
+    B, H, W, _ = img_u8.shape
+    out = torch.empty(B, 4 if with_mask else 3, H, W, device=img_u8.device)
+    check(lib.dpmn_collate_u8_f32(img_u8.data_ptr(), dptr(out), B, H, W, int(bool(with_mask)), stream()))
+    return out
+
+
 def maxpool(x, kh, kw, scale=None, shift=None):
     """nn.MaxPool2d((kh,kw), stride (kh,kw)) over NHWC; scale/shift: the producer's BatchNorm affine + ReLU applied on load."""
     B, H, W, Cc = x.shape

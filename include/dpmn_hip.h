@@ -242,6 +242,11 @@ int dpmn_text_prior_compose_f32(const int* cls, const int* length, const float* 
                                 int n_glyph, int GH, int GW, int Ho, int Wo, dpmn_stream_t stream);
 int dpmn_layernorm_std_f32(const float* x, const float* a2, const float* b2, float eps, float* y, long M, int C,
                            dpmn_stream_t stream);
+/* GPU half of the TextZoom collate (dataset/dataset.py:1266-1319 resizeNormalize, 2007-2013 alignCollate_realWTLAMask.__call__):
+ * img (B, H, W, 3) uint8 = the PIL-resized RGB pixels, out (B, 3 + with_mask, H, W) = ToTensor (/255, CHW) and, with_mask, the mask
+ * channel (PIL RGB -> L, threshold at the image's mean L: L > mean ? 0 : 1). */
+int dpmn_collate_u8_f32(const unsigned char* img, float* out, int B, int H, int W, int with_mask, dpmn_stream_t stream);
+
 /* rotation augmentation of the trainer (utils/util.py:37-58 torch_rotate_img; super_resolution.py:144-151, 358-365):
  * per-image affine with aspect-ratio jitter -> affine_grid (align_corners=False) -> bilinear grid_sample, zeros padding.
  * img / out: contiguous NCHW (N,C,H,W); arc, rand_offs: (N) */

@@ -58,7 +58,7 @@ def main(config, args):
                 csv.writer(out).writerow(["recognizer", "subset", "accuracy", "psnr", "ssim"])
         if args.test_data_dir and os.path.isdir(args.test_data_dir):       # a TextZoom LMDB directory (needs the lmdb package)
             from dpmn_amd.dataset.textzoom import sr_batches
-            loader = sr_batches(mission.get_test_data(args.test_data_dir)[1])
+            loader = sr_batches(mission.get_test_data(args.test_data_dir)[1], mission.device, mission.mask)
         else:
             loader = synthetic_loader(bs, args.synthetic_steps, 1000 + rank)
         res = mission.test(loader)
@@ -75,7 +75,7 @@ def main(config, args):
         if dirs and all(os.path.isdir(d) for d in dirs):                   # TextZoom LMDBs from the config, like base.py:85-103
             from dpmn_amd.dataset.textzoom import sr_batches
             dl = mission.get_train_data()[1]           # per-rank shard of a per-epoch permutation (DistributedSampler)
-            mission.train(lambda epoch: sr_batches(dl), epochs=config.TRAIN.epochs, sampler=getattr(mission, "train_sampler", None))
+            mission.train(lambda epoch: sr_batches(dl, mission.device, mission.mask), epochs=config.TRAIN.epochs, sampler=getattr(mission, "train_sampler", None))
         else:
             mission.train(synthetic_loader(bs, args.synthetic_steps, 2000 + rank), steps=args.synthetic_steps)
 

@@ -85,3 +85,35 @@ def test_collate_tuple_layout_and_label_vectors():
     assert float(vecs[4].sum()) == 26.0                 # 30 characters truncated to 26
     batches = list(tz.sr_batches([out]))
     assert batches[0][0] is hr and batches[0][1] is lr and batches[0][2] is None and batches[0][3] == list(strs)
+
+
+def _fixture_batch():
+    from helpers import load_golden
+    g = load_golden("collate")
+    env, raw, words = _fake_env()
+    ds = tz.lmdbDataset_real(env=env, voc_type='all')
+    return g, [ds[i] for i in range(5)]
+
+
+def test_collate_equals_the_reference_class_fixture():
+    """tests/golden/collate.npz = outputs of the IMPORTED reference classes (tools/gen_golden.py gen_collate: resizeNormalize,
+    alignCollate_realWTLAMask.__call__, str_filt of dataset/dataset.py and utils/util.py) on the same five synthetic images."""
+    g, batch = _fixture_batch()
+    for mask, tag in ((True, "mask"), (False, "nomask")):
+        out = tz.alignCollate_realWTLAMask(imgH=32, imgW=128, down_sample_scale=2, mask=mask)(batch)
+        assert torch.equal(out[0], torch.from_numpy(g["hr_" + tag])) and torch.equal(out[2], torch.from_numpy(g["lr_" + tag]))
+        if mask:
+            assert list(out[5]) == [str(s) for s in g["label_strs"]]
+            assert torch.equal(out[6], torch.from_numpy(g["label_vecs"]))
+            assert out[7].tolist() == g["weighted_masks"].tolist() and out[8].tolist() == g["weighted_tics"].tolist()
+    for voc in ("lower", "upper", "all", "digit"):
+        assert [tz.str_filt(str(w), voc) for w in g["str_filt_in"]] == [str(s) for s in g["str_filt_" + voc]], voc
+
+
+def test_gpu_finish_collate_returns_the_resized_uint8_pixels():
+    g, batch = _fixture_batch()
+    out = tz.alignCollate_realWTLAMask(imgH=32, imgW=128, down_sample_scale=2, mask=True, gpu_finish=True)(batch)
+    assert out[0].dtype == torch.uint8 and out[0].shape == (5, 32, 128, 3) and out[2].shape == (5, 16, 64, 3)
+    # the uint8 pixels are what ToTensor divides by 255 in the reference
+    assert torch.equal(out[0].permute(0, 3, 1, 2).float() / 255, torch.from_numpy(g["hr_nomask"]))
+    assert torch.equal(out[6], torch.from_numpy(g["label_vecs"]))

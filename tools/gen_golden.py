@@ -461,6 +461,25 @@ GENS = {"visionlan": gen_visionlan, "grads": gen_grads, "step": gen_step, "stack
 
 
 
+def gen_crnn():
+    """The frozen CRNN that produces TATT's label_vecs on real data (model/crnn/crnn.py through the import; CRNN_init's
+    CRNN(32, 1, 37, 256), base.py:411-417) + the reference lines around it: parse_crnn_data (base.py:419-425) and the softmax /
+    permute of super_resolution.py:165-169, on name-seeded synthetic weights and LR images."""
+    import torch.nn.functional as F
+    from model.crnn import crnn
+    m = crnn.CRNN(32, 1, 37, 256).eval()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, seed=71)
+    sd = {k: v.clone() for k, v in sd.items()}
+    m.load_state_dict(sd)
+    imgs = synth.uniform("crnn_lr", (3, 3, 16, 64), 0, 1, 72)
+    x = F.interpolate(imgs, (32, 100), mode='bicubic')                                   # parse_crnn_data
+    gray = 0.299 * x[:, 0:1] + 0.587 * x[:, 1:2] + 0.114 * x[:, 2:3]
+    logits = m(gray)
+    lv = torch.nn.functional.softmax(logits, -1).permute(1, 0, 2).unsqueeze(1).permute(0, 3, 1, 2)
+    save("crnn", logits=logits, label_vecs=lv.contiguous(), manifest=manifest(sd), checksum=checksum(sd))
+
+
 def gen_collate():
     """Data path: the reference's own `resizeNormalize` and `alignCollate_realWTLAMask.__call__`
     (dataset/dataset.py:1266-1319, 1966-2076) and `str_filt` (utils/util.py) run on five synthetic RGB images of ragged sizes
@@ -532,6 +551,7 @@ def gen_collate():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["all"]
+    GENS["crnn"] = gen_crnn
     GENS["collate"] = gen_collate      # last: it installs extra import shims (lmdb, imgaug, torchvision.utils)
     for name, fn in GENS.items():
         if "all" in which or name in which:
