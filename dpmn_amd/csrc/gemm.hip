@@ -593,6 +593,219 @@ __global__ __launch_bounds__(256, 2) void k_gemm_pw(const float* __restrict__ g,
   }
 }
 
+
+// ---------------------------------------------------------------------------------- whole-K, rows straight into the B operand
+// The scheme of the fused attention kernel's projection (attn_fused.hip) for the K <= 192 token GEMMs: a WAVE owns a 16-token
+// tile; lane (j = l & 15, kq = l >> 4) loads x[token j][16 c + 4 kq .. + 3] straight from global memory into the MFMA B-operand
+// registers (the k index is permuted identically on both operands), A = the block's 96 weight rows from an LDS copy, and the
+// accumulator layout (lane (j, kq) holds y[token j][16 nt + 4 kq + r]) is stored with one float4 per n tile.  No X tile in LDS,
+// no barrier after the weight staging: the four waves of a block walk their tiles independently, 3-4 blocks per CU.
+// (k_gemm_wstat stages X through LDS with two barriers per 32/64-row tile: 21 us for M = 49152, N = K = 96 -- 0.25 of either
+// roof -- against ~6 us of MFMA time and ~6 us of HBM time.)
+// PRO_LN: LayerNorm folded as in the attention kernel -- gamma into the weights while they are staged, the normalisation
+// behind the MFMAs: y = rstd * (W' x - mean * rowsum(W')) + (b + W beta).
+// RR_EPI: 1 bias, 2 bias + GELU, 3 bias + two residuals, 5 bias + one residual.
+template <int K, int PRO, int EPI>
+__global__ __launch_bounds__(256, (K <= 96 ? 3 : 2)) void k_gemm_rowreg(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                      float* __restrict__ y, int ldy, int M, int N, ProArgs p, EpiArgs e) {
+  constexpr int KC = K / 16, LDW = K + PAD, BN = 96, NT = 6;
+  constexpr int G = PRO == PRO_SKSEL ? 3 : 1;              // SKConv select: x = sum_g A[b][g] * cat[:, g K : (g + 1) K]
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                  // [96][LDW]
+  float* pb = Ws + BN * LDW;         // [96] bias (b' under PRO_LN), [96] rowsum(W') (PRO_LN)
+  float* scr = pb + 2 * BN;          // PRO_LN: [96][K / 4][2] partial sums of the fold
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+  const int n_blk = blockIdx.y * BN;
+  const int tiles = M / 16;
+  const int stride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+
+  // global loads in the order they are consumed: weights, then the first tile's rows
+  constexpr int KV = K / 4, WL = (BN * KV + 255) / 256;
+  float4 wv[WL];
+#pragma unroll
+  for (int u = 0; u < WL; ++u) {
+    const int i = min(tid + u * 256, BN * KV - 1);
+    wv[u] = *reinterpret_cast<const float4*>(w + (size_t)(n_blk + i / KV) * K + (i % KV) * 4);
+  }
+  f32x4 xr[G][KC];
+  auto load_rows = [&](int t_) {
+    const size_t m = (size_t)(t_ < tiles ? t_ : tiles - 1) * 16 + lr;      // clamped, never predicated
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int c = 0; c < KC; ++c) xr[g][c] = *reinterpret_cast<const f32x4*>(x + m * ldx + g * K + 16 * c + 4 * kq);
+  };
+  load_rows(tile);
+#pragma unroll
+  for (int u = 0; u < WL; ++u) {
+    const int i = tid + u * 256;
+    if (i < BN * KV) {
+      const int r = i / KV, c4 = (i % KV) * 4;
+      float4 v = wv[u];
+      if (PRO == PRO_LN) {
+        const float4 gm = *reinterpret_cast<const float4*>(p.ln_w + c4), bt = *reinterpret_cast<const float4*>(p.ln_b + c4);
+        const float4 wb = make_float4(v.x * bt.x, v.y * bt.y, v.z * bt.z, v.w * bt.w);
+        v = make_float4(v.x * gm.x, v.y * gm.y, v.z * gm.z, v.w * gm.w);
+        scr[(r * KV + c4 / 4) * 2] = (v.x + v.y) + (v.z + v.w);
+        scr[(r * KV + c4 / 4) * 2 + 1] = (wb.x + wb.y) + (wb.z + wb.w);
+      }
+      *reinterpret_cast<float4*>(Ws + r * LDW + c4) = v;
+    }
+  }
+  if (PRO == PRO_LN) __syncthreads();
+  if (tid < BN) {
+    float bb = e.bias ? e.bias[n_blk + tid] : 0.f, cw = 0.f;
+    if (PRO == PRO_LN)
+      for (int k = 0; k < KV; ++k) { cw += scr[(tid * KV + k) * 2]; bb += scr[(tid * KV + k) * 2 + 1]; }      // fixed order
+    pb[tid] = bb;
+    pb[BN + tid] = cw;
+  }
+  __syncthreads();
+
+  for (; tile < tiles; tile += stride) {
+    const size_t m = (size_t)tile * 16 + lr;
+    const size_t yoff = m * ldy + n_blk + 4 * kq;
+    f32x4 r1[NT], r2[NT];
+    if (EPI == 3 || EPI == 5) {            // residual rows: in flight during the MFMAs
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        r1[nt] = *reinterpret_cast<const f32x4*>(e.res1 + yoff + 16 * nt);
+        if (EPI == 3) r2[nt] = *reinterpret_cast<const f32x4*>(e.res2 + yoff + 16 * nt);
+      }
+    }
+    f32x4 xb[KC];
+    float mean = 0.f, rstd = 1.f;
+    if (PRO == PRO_SKSEL) {
+      const size_t b = m / p.rows_per_image;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        xb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(p.sel + (b * G + g) * K + 16 * c + 4 * kq);
+          xb[c][0] += a[0] * xr[g][c][0]; xb[c][1] += a[1] * xr[g][c][1]; xb[c][2] += a[2] * xr[g][c][2]; xb[c][3] += a[3] * xr[g][c][3];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) xb[c] = xr[0][c];
+    }
+    // the next tile's rows are requested NOW (second register set): they fly during this tile's MFMAs and epilogue.  With one
+    // tile per wave every wave of the chip loads, multiplies and stores in lockstep -- load / MFMA / store phases in sequence,
+    // 18 us for 6 us of MFMA and 6 us of HBM time -- so the launcher gives a wave several tiles and this pipeline overlaps them
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(tile + stride);
+    __builtin_amdgcn_sched_barrier(0);
+    if (PRO != PRO_SKSEL) {
+      if (PRO == PRO_LN) {                 // two-pass row statistics over the 4 kq partners of the row (like nn.LayerNorm)
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) { s0 += xb[c][0] + xb[c][1]; s1 += xb[c][2] + xb[c][3]; }
+        float s_ = s0 + s1;
+        s_ += __shfl_xor(s_, 16, 64); s_ += __shfl_xor(s_, 32, 64);
+        mean = s_ * (1.0f / K);
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+          const float d0 = xb[c][0] - mean, d1 = xb[c][1] - mean, d2 = xb[c][2] - mean, d3 = xb[c][3] - mean;
+          q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
+        }
+        float q = (q0 + q1) + (q2 + q3);
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        rstd = 1.0f / sqrtf(q * (1.0f / K) + p.eps);
+      }
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // weight operands double-buffered one k-chunk ahead; the scheduling fences keep hipcc from hoisting ALL the chunks' LDS reads
+    // to the top of the tile (6 x 24 registers: it then spills the row and residual registers to scratch)
+    f32x4 wf[2][NT];
+    const float* wa = Ws + lr * LDW + 4 * kq;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wf[0][nt] = *reinterpret_cast<const f32x4*>(wa + 16 * nt * LDW);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (c + 1 < KC) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[(c + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(wa + 16 * nt * LDW + 16 * (c + 1));
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[c & 1][nt][s4], xb[c][s4], acc[nt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float nm = -mean * rstd;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 16 * nt + 4 * kq);
+      f32x4 v;
+      if (PRO == PRO_LN) {
+        const f32x4 cw = *reinterpret_cast<const f32x4*>(pb + BN + 16 * nt + 4 * kq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[nt][r], rstd, fmaf(nm, cw[r], b4[r]));
+      } else {
+        v = acc[nt] + b4;
+      }
+      if (EPI == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      }
+      if (EPI == 3 || EPI == 5) v += r1[nt];
+      if (EPI == 3) v += r2[nt];
+      *reinterpret_cast<f32x4*>(y + yoff + 16 * nt) = v;
+    }
+  }
+}
+
+template <int K, int PRO, int EPI>
+int launch_rowreg(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p, const EpiArgs& e,
+                  hipStream_t st) {
+  const size_t smem = (size_t)(96 * (K + PAD) + 2 * 96 + (PRO == PRO_LN ? 96 * (K / 4) * 2 : 0)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_rowreg<K, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const int tiles = M / 16, ny = N / 96;
+  // resident waves: LDS-limited blocks per CU x 4; every wave gets the same number of tiles when that divides evenly
+  static const int rr_blocks = getenv("DPMN_RR_BLOCKS") ? atoi(getenv("DPMN_RR_BLOCKS")) : 0;
+  const int per_cu = smem <= 40 * 1024 ? 3 : (smem <= 80 * 1024 ? 2 : 1);
+  int gx = (rr_blocks > 0 ? rr_blocks : 256 * per_cu) / ny;
+  if (gx < 1) gx = 1;
+  // at least 3 tiles per wave, so that the load / MFMA / store pipeline of a wave has something to overlap
+  static const int rr_tpw = getenv("DPMN_RR_TPW") ? atoi(getenv("DPMN_RR_TPW")) : 3;
+  while (gx > 256 / ny && gx > 1 && (long)gx * 4 * rr_tpw > tiles) gx -= 256 / ny > 0 ? 256 / ny : 1;
+  if (gx * 4 > tiles) gx = cdiv(tiles, 4);
+  ProfScope prof(PRO == PRO_LN ? PT_GEMM_WSTAT_LN : PT_GEMM_WSTAT, st, 2.0 * M * (double)N * K,
+                 4.0 * ((double)M * K * (PRO == PRO_SKSEL ? 3 : 1) + (double)M * N * (1 + (EPI == 3 ? 2 : (EPI == 5 ? 1 : 0))) + (double)N * K));
+  hipLaunchKernelGGL((k_gemm_rowreg<K, PRO, EPI>), dim3(gx, ny), dim3(256), smem, st, x, ldx, w, y, ldy, M, N, p, e);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// rows-in-registers path for the shapes it is built for; returns -1 when the call does not qualify
+template <int K, int PRO>
+int try_rowreg(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p, const EpiArgs& e,
+               hipStream_t st) {
+  static const int on = getenv("DPMN_ROWREG") ? atoi(getenv("DPMN_ROWREG")) : 1;
+  if (!on || M % 16 || N % 96 || e.atomic || e.colsum || ldy % 4 || ldx % 4 || M < 1024) return -1;
+  if constexpr (PRO == PRO_SKSEL) {
+    if (K != 32 || p.groups != 3 || p.rows_per_image % 16 || !(e.res1 && e.res2) || e.act != ACT_NONE) return -1;
+    return launch_rowreg<32, PRO_SKSEL, 3>(x, ldx, w, y, ldy, M, N, p, e, st);
+  } else if constexpr ((PRO == PRO_NONE || PRO == PRO_LN) && (K == 96 || K == 192)) {
+    if (e.act == ACT_GELU && !e.res1 && !e.res2) return launch_rowreg<K, PRO, 2>(x, ldx, w, y, ldy, M, N, p, e, st);
+    if (e.act != ACT_NONE) return -1;
+    if (e.res1 && e.res2) return launch_rowreg<K, PRO, 3>(x, ldx, w, y, ldy, M, N, p, e, st);
+    if (e.res1) return launch_rowreg<K, PRO, 5>(x, ldx, w, y, ldy, M, N, p, e, st);
+    if (e.res2) return -1;
+    return launch_rowreg<K, PRO, 1>(x, ldx, w, y, ldy, M, N, p, e, st);
+  }
+  return -1;
+}
+
 template <int K, int PRO, int TH, bool FULL = false, int EPI = 0>
 int launch_wholeK_th(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
                      const EpiArgs& e, hipStream_t st, int target_blocks) {
@@ -623,6 +836,10 @@ int launch_wholeK(const float* x, int ldx, const float* w, float* y, int ldy, in
   // 256-thread blocks (32-token tiles): 51 KB -> 3 blocks = 12 waves per CU, and the only variant with the per-32-row
   // column-sum epilogue (SKConv GAP partials)
   static const int big = getenv("DPMN_WSTAT_TH") ? atoi(getenv("DPMN_WSTAT_TH")) : 512;
+  {
+    const int rc = try_rowreg<K, PRO>(x, ldx, w, y, ldy, M, N, p, e, st);
+    if (rc != -1) return rc;
+  }
   if constexpr (K <= 128) {
     if (big == 512 && !e.colsum && M >= 4096) {
       if (M % 64 == 0 && N % WS_BN == 0 && !e.atomic) {    // every tile interior: the predicate-free instantiations
