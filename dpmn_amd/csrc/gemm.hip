@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_pw(const float* __restrict__ g,
 // behind the MFMAs: y = rstd * (W' x - mean * rowsum(W')) + (b + W beta).
 // RR_EPI: 1 bias, 2 bias + GELU, 3 bias + two residuals, 5 bias + one residual.
 template <int K, int PRO, int EPI>
-__global__ __launch_bounds__(256, (K <= 96 ? 3 : 2)) void k_gemm_rowreg(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+__global__ __launch_bounds__(256, ((K <= 96 && !(PRO == PRO_SKSEL && K > 32)) ? 3 : 2)) void k_gemm_rowreg(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                       float* __restrict__ y, int ldy, int M, int N, ProArgs p, EpiArgs e) {
   constexpr int KC = K / 16, LDW = K + PAD, BN = 96, NT = 6;
   constexpr int G = PRO == PRO_SKSEL ? 3 : 1;              // SKConv select: x = sum_g A[b][g] * cat[:, g K : (g + 1) K]
@@ -617,8 +617,8 @@ __global__ __launch_bounds__(256, (K <= 96 ? 3 : 2)) void k_gemm_rowreg(const fl
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
   const int n_blk = blockIdx.y * BN;
   const int tiles = M / 16;
-  const int stride = gridDim.x * 4;
-  int tile = blockIdx.x * 4 + wave;
+  const int stride = gridDim.x * 4;                        // in units of SUB consecutive 16-row tiles (SUB = 2 under RR_EPI 4)
+  int tile = (blockIdx.x * 4 + wave) * (EPI == 4 ? 2 : 1);
 
   // global loads in the order they are consumed: weights, then the first tile's rows
   constexpr int KV = K / 4, WL = (BN * KV + 255) / 256;
@@ -663,8 +663,13 @@ __global__ __launch_bounds__(256, (K <= 96 ? 3 : 2)) void k_gemm_rowreg(const fl
   }
   __syncthreads();
 
-  for (; tile < tiles; tile += stride) {
+  // RR_EPI 4 (SKConv projection + global-average-pool partials, pgrm.py:84-86): a wave takes PAIRS of 16-row tiles and writes one
+  // partial (column sums of GELU(y) over the pair's 32 rows) per pair -- the consumer's one-partial-per-32-rows contract
+  constexpr int SUB = EPI == 4 ? 2 : 1;
+  float cs[NT][4];
+  for (; tile < tiles; tile = ((tile % SUB) + 1 < SUB) ? tile + 1 : (tile / SUB + stride) * SUB) {
     const size_t m = (size_t)tile * 16 + lr;
+    const int next_tile = ((tile % SUB) + 1 < SUB) ? tile + 1 : (tile / SUB + stride) * SUB;
     const size_t yoff = m * ldy + n_blk + 4 * kq;
     f32x4 r1[NT], r2[NT];
     if (EPI == 3 || EPI == 5) {            // residual rows: in flight during the MFMAs
@@ -695,7 +700,7 @@ __global__ __launch_bounds__(256, (K <= 96 ? 3 : 2)) void k_gemm_rowreg(const fl
     // tile per wave every wave of the chip loads, multiplies and stores in lockstep -- load / MFMA / store phases in sequence,
     // 18 us for 6 us of MFMA and 6 us of HBM time -- so the launcher gives a wave several tiles and this pipeline overlaps them
     __builtin_amdgcn_sched_barrier(0);
-    load_rows(tile + stride);
+    load_rows(next_tile);
     __builtin_amdgcn_sched_barrier(0);
     if (PRO != PRO_SKSEL) {
       if (PRO == PRO_LN) {                 // two-pass row statistics over the 4 kq partners of the row (like nn.LayerNorm)
@@ -756,6 +761,23 @@ __global__ __launch_bounds__(256, (K <= 96 ? 3 : 2)) void k_gemm_rowreg(const fl
       if (EPI == 3 || EPI == 5) v += r1[nt];
       if (EPI == 3) v += r2[nt];
       *reinterpret_cast<f32x4*>(y + yoff + 16 * nt) = v;
+      if (EPI == 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[nt][r] = (tile % SUB == 0 ? 0.f : cs[nt][r]) + gelu_erf(v[r]);
+      }
+    }
+    if (EPI == 4 && tile % SUB == SUB - 1) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        f32x4 c4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float c = cs[nt][r];
+          c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 8, 64);
+          c4[r] = c;
+        }
+        if (lr == 0) *reinterpret_cast<f32x4*>(e.colsum + (size_t)(tile / SUB) * N + n_blk + 16 * nt + 4 * kq) = c4;
+      }
     }
   }
 }
@@ -769,7 +791,7 @@ int launch_rowreg(const float* x, int ldx, const float* w, float* y, int ldy, in
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_rowreg<K, PRO, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
-  const int tiles = M / 16, ny = N / 96;
+  const int tiles = M / (EPI == 4 ? 32 : 16), ny = N / 96;      // work items of a wave (pairs of 16-row tiles under RR_EPI 4)
   // resident waves: LDS-limited blocks per CU x 4; every wave gets the same number of tiles when that divides evenly
   static const int rr_blocks = getenv("DPMN_RR_BLOCKS") ? atoi(getenv("DPMN_RR_BLOCKS")) : 0;
   const int per_cu = smem <= 40 * 1024 ? 3 : (smem <= 80 * 1024 ? 2 : 1);
@@ -791,11 +813,17 @@ template <int K, int PRO>
 int try_rowreg(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p, const EpiArgs& e,
                hipStream_t st) {
   static const int on = getenv("DPMN_ROWREG") ? atoi(getenv("DPMN_ROWREG")) : 1;
-  if (!on || M % 16 || N % 96 || e.atomic || e.colsum || ldy % 4 || ldx % 4 || M < 1024) return -1;
-  if constexpr (PRO == PRO_SKSEL) {
-    if (K != 32 || p.groups != 3 || p.rows_per_image % 16 || !(e.res1 && e.res2) || e.act != ACT_NONE) return -1;
-    return launch_rowreg<32, PRO_SKSEL, 3>(x, ldx, w, y, ldy, M, N, p, e, st);
+  if (!on || M % 16 || N % 96 || e.atomic || ldy % 4 || ldx % 4 || M < 1024) return -1;
+  if constexpr (PRO == PRO_SKSEL && (K == 32 || K == 64)) {
+    if (p.groups != 3 || p.rows_per_image % 16 || !(e.res1 && e.res2) || e.act != ACT_NONE || e.colsum) return -1;
+    return launch_rowreg<K, PRO_SKSEL, 3>(x, ldx, w, y, ldy, M, N, p, e, st);
   } else if constexpr ((PRO == PRO_NONE || PRO == PRO_LN) && (K == 96 || K == 192)) {
+    if (e.colsum) {
+      if constexpr (PRO == PRO_NONE) {
+        if (M % 32 == 0 && !e.res1 && !e.res2 && e.act == ACT_NONE) return launch_rowreg<K, PRO_NONE, 4>(x, ldx, w, y, ldy, M, N, p, e, st);
+      }
+      return -1;
+    }
     if (e.act == ACT_GELU && !e.res1 && !e.res2) return launch_rowreg<K, PRO, 2>(x, ldx, w, y, ldy, M, N, p, e, st);
     if (e.act != ACT_NONE) return -1;
     if (e.res1 && e.res2) return launch_rowreg<K, PRO, 3>(x, ldx, w, y, ldy, M, N, p, e, st);

@@ -404,6 +404,160 @@ int launch_window_attn8_mfma(const float* q, const float* kv, const float* table
   return DPMN_OK;
 }
 
+
+// ---------------------------------------------------------------------------------- window attention on MFMA, head dim 32
+// The stress configuration (BASELINE.json configs[4]: dim 192 = 3 groups x 2 heads x 32, windows 4 / 8 / 16) spent 44 ms of its
+// 311 ms step in the scalar kernel above (VALU-bound: a lane walks every key of its query).  Same scheme as the 8x8 kernel, with
+// the window size and the head dim as template parameters:
+//   * one "key set" per block: a 64-token slab (4 windows of 4x4, or one 8x8 window; two slabs per block) or one 16x16 window
+//     (256 tokens, 139 KB of K / V in LDS, eight waves);
+//   * a wave = (64-query slab, head) walks its 4 query tiles; per tile S^T = K Q^T over the KT key tiles the tile's windows
+//     cover (1, 4, 16), Q read straight from global memory in operand order, P kept in the accumulator registers, O^T = V^T P.
+// Relative-position bias and shift mask are looked up per logit like in the scalar kernel (pgrm.py:234-243).
+template <int WS, int D>
+__global__ __launch_bounds__((WS == 16 ? 512 : 256)) void k_window_attn_mfma(const float* __restrict__ q, const float* __restrict__ kv,
+                                                                             const float* __restrict__ bias_table, float* __restrict__ out,
+                                                                             int B, int H, int W, int C, int g, int shift) {
+  constexpr int N = WS * WS, CG = 2 * D, DC = D / 16, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
+  constexpr int ROWS = WS == 16 ? 256 : 64;            // tokens of one key set
+  constexpr int SETS = WS == 16 ? 1 : 2;               // key sets per block
+  constexpr int KT = N >= 64 ? N / 16 : 1;             // key tiles a query tile attends to
+  constexpr int TH = WS == 16 ? 512 : 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tbl = smem;                                   // [TBL][2]
+  float* base = smem + ((TBL * 2 + 3) & ~3);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lr = lane & 15, kq = lane >> 4;
+  const int set_in_blk = WS == 16 ? 0 : wave >> 1, head = wave & 1;
+  const int slab_in_set = WS == 16 ? wave >> 1 : 0;    // 64-query slab of this wave inside the key set
+  float* Ks = base + set_in_blk * 2 * ROWS * LDR;
+  float* Vs = Ks + ROWS * LDR;
+  int* reg_s = reinterpret_cast<int*>(base + SETS * 2 * ROWS * LDR) + set_in_blk * ROWS;
+  const int L = H * W;
+  const int sets_per_img = L / ROWS;
+  const long set = (long)blockIdx.x * SETS + set_in_blk;
+  const int b = (int)(set / sets_per_img);
+  const int t0 = (int)(set % sets_per_img) * ROWS;     // first window-major token of the key set
+  const int nWc = W / WS;
+  const bool active = b < B;
+  for (int i = threadIdx.x; i < TBL * 2; i += TH) tbl[i] = bias_table[i];
+  // source row (roll by -shift, window partition; pgrm.py:209-213) of window-major token t of image b
+  auto src_row = [&](int t, int& hr, int& wcol) {
+    const int win = t / N, n = t % N;
+    hr = (win / nWc) * WS + n / WS;
+    wcol = (win % nWc) * WS + n % WS;
+    return (size_t)b * L + ((hr + shift) % H) * W + (wcol + shift) % W;
+  };
+  if (active) {
+    constexpr int V4 = CG / 4, TPS = TH / SETS;        // threads staging one key set
+    const int tl = threadIdx.x % TPS;
+    for (int i = tl; i < ROWS * V4; i += TPS) {
+      const int r = i / V4, c4 = (i % V4) * 4;
+      int hr, wcol;
+      const size_t src = src_row(t0 + r, hr, wcol);
+      *reinterpret_cast<float4*>(Ks + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + src * 2 * C + g * CG + c4);
+      *reinterpret_cast<float4*>(Vs + r * LDR + c4) = *reinterpret_cast<const float4*>(kv + src * 2 * C + C + g * CG + c4);
+      if (c4 == 0) {
+        const int rh = hr < H - WS ? 0 : (hr < H - shift ? 1 : 2), rw = wcol < W - WS ? 0 : (wcol < W - shift ? 1 : 2);
+        reg_s[r] = 3 * rh + rw;
+      }
+    }
+  }
+  __syncthreads();
+  if (!active) return;
+  const float scale = D == 32 ? 0.17677669529663687f : 0.25f;      // head_dim ** -0.5
+#pragma unroll 1
+  for (int qt = 0; qt < 4; ++qt) {
+    const int rq = 64 * slab_in_set + 16 * qt + lr;    // my query's row inside the key set
+    int hr_, wc_;
+    const size_t qsrc = src_row(t0 + rq, hr_, wc_);
+    f32x4 qf[DC];
+#pragma unroll
+    for (int dc = 0; dc < DC; ++dc) {
+      qf[dc] = *reinterpret_cast<const f32x4*>(q + qsrc * C + g * CG + head * D + 16 * dc + 4 * kq);
+      qf[dc] *= scale;
+    }
+    const int kbase = WS == 16 ? 0 : (WS == 8 ? 0 : 16 * qt);      // first key row of the windows this query tile sees
+    f32x4 sacc[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dc = 0; dc < DC; ++dc) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kbase + 16 * kt + lr) * LDR + head * D + 16 * dc + 4 * kq);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) a = mfma16(kf[s4], qf[dc][s4], a);
+      }
+      sacc[kt] = a;
+      if (KT > 4) __builtin_amdgcn_sched_barrier(0);      // 16 key tiles: keep hipcc from hoisting every operand read to the top (spills)
+    }
+    // + relative position bias, shift mask; softmax over the keys of query column lr
+    const int nq = rq % N, iq = nq / WS, jq = nq % WS;
+    const int my_reg = reg_s[rq];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int krow = kbase + 16 * kt + 4 * kq + r, m = krow % N, im = m / WS, jm = m % WS;
+        float a = sacc[kt][r] + tbl[((iq - im + WS - 1) * (2 * WS - 1) + (jq - jm + WS - 1)) * 2 + head];
+        if (shift > 0 && reg_s[krow] != my_reg) a += -100.0f;
+        if (WS == 4 && (krow >> 4) != (rq >> 4)) a = -INFINITY;      // (never: a 4x4 query tile is exactly one window)
+        sacc[kt][r] = a;
+        mx = fmaxf(mx, a);
+        if (KT > 4 && r == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float den = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pexp = __expf(sacc[kt][r] - mx);
+        sacc[kt][r] = pexp;
+        den += pexp;
+      }
+    den += __shfl_xor(den, 16, 64);
+    den += __shfl_xor(den, 32, 64);
+    const float inv = 1.0f / den;
+    // O^T = V^T . P: A = V^T[d = 16 dt + lr][key], B = P (the accumulator registers)
+    f32x4 oacc[DC];
+#pragma unroll
+    for (int dt = 0; dt < DC; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float* vrow = Vs + (kbase + 16 * kt + 4 * kq + r) * LDR + head * D + lr;
+#pragma unroll
+        for (int dt = 0; dt < DC; ++dt) oacc[dt] = mfma16(vrow[16 * dt], sacc[kt][r], oacc[dt]);
+        if (KT > 4 && r == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    float* dst = out + ((size_t)b * L + t0 + rq) * C + g * CG + head * D + 4 * kq;
+#pragma unroll
+    for (int dt = 0; dt < DC; ++dt)
+      *reinterpret_cast<float4*>(dst + 16 * dt) = make_float4(oacc[dt][0] * inv, oacc[dt][1] * inv, oacc[dt][2] * inv, oacc[dt][3] * inv);
+  }
+}
+
+template <int WS, int D>
+int launch_window_attn_mfma(const float* q, const float* kv, const float* table, float* out, int B, int H, int W, int C, int g,
+                            int shift, hipStream_t st) {
+  constexpr int N = WS * WS, CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1), ROWS = WS == 16 ? 256 : 64, SETS = WS == 16 ? 1 : 2;
+  const size_t smem = (size_t)(((TBL * 2 + 3) & ~3) + SETS * 2 * ROWS * LDR) * 4 + (size_t)SETS * ROWS * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn_mfma<WS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const long sets = (long)B * (H * W / ROWS);
+  ProfScope prof(PT_WATTN_SCALAR, st, 4.0 * N * D * 2 * (double)B * H * W, 4.0 * 4 * CG * (double)B * H * W);
+  hipLaunchKernelGGL((k_window_attn_mfma<WS, D>), dim3((unsigned)((sets + SETS - 1) / SETS)), dim3(WS == 16 ? 512 : 256), smem, st, q, kv, table,
+                     out, B, H, W, C, g, shift);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
 template <int WS, int D, bool DROP>
 int launch_window_attn(const float* q, const float* kv, const float* table, float* out, int B, int H, int W, int C, int g,
                        int shift, float p_drop, unsigned long long seed, hipStream_t st) {
@@ -676,6 +830,13 @@ int dpmn_window_attn_drop_f32(const float* q, const float* kv, const float* cons
     if (ws == 8 && D == 16 && wa_mfma) {
       rc = p_drop > 0.f ? launch_window_attn8_mfma<true>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, p_drop, seed, st)
                         : launch_window_attn8_mfma<false>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, 0.f, 0ull, st);
+      if (rc != DPMN_OK) return rc;
+      continue;
+    }
+    if (D == 32 && wa_mfma && p_drop == 0.f && (ws == 4 || ws == 8 || ws == 16) && (H * W) % (ws == 16 ? 256 : 64) == 0) {
+      rc = ws == 4 ? launch_window_attn_mfma<4, 32>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st)
+                   : (ws == 8 ? launch_window_attn_mfma<8, 32>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st)
+                              : launch_window_attn_mfma<16, 32>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st));
       if (rc != DPMN_OK) return rc;
       continue;
     }
