@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--prior", default="synthetic", choices=["synthetic", "visionlan"],
                     help="branch-1 text priors: precomputed synthetic tensors (default) or the in-loop batched VisionLAN + glyph-atlas "
                          "pipeline inside the timed step (BASELINE.json configs[3]: 'VisionLAN text-prior branch enabled')")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic of the GEMM-shaped kernels: f32 (the reference's precision, the headline) or bf16 MFMA operands with fp32 "
+                         "accumulation (BASELINE.json configs[2..4] name bf16; a separate line, never the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="fwd mode: skip the `train` object (configs[2] step timed after the forward region)")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the `train` object")
@@ -300,6 +303,7 @@ def main():
         else:
             dist.init_process_group(backend)
     from dpmn_amd import workload, _abi
+    _abi.check(_abi.lib.dpmn_set_compute_dtype(1 if args.dtype == "bf16" else 0))
     spec = workload.describe(args.workload)
     arch, b1, b2 = spec["arch"], spec["b1"], spec["b2"]
     if args.mode == "train":
@@ -326,7 +330,9 @@ def main():
             "metric": "SR images/sec (%s, bs=%d per GPU, fp32 %s)" % (spec["shape"], B, what),
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the implicit-GEMM convs / pointwise GEMM, fp32 accumulation, storage and statistics",
+            "data": "synthetic",
             "config": {"workload": "%s: %s, %s" % (
                 args.workload, spec["text"],
                 ("forward-only" + (", in-loop VisionLAN + glyph-atlas text priors" if args.prior == "visionlan" else "")) if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"
@@ -342,7 +348,7 @@ def main():
     # the configs[2] training step, timed after the forward region in the same process (every rank takes part: the step holds
     # the RCCL gradient exchange when N > 1); headline `value` stays the forward
     train = None
-    if args.mode == "fwd" and args.workload == "cfg1" and args.prior == "synthetic" and not args.no_train and not args.graph:
+    if args.mode == "fwd" and args.workload == "cfg1" and args.prior == "synthetic" and not args.no_train and not args.graph and args.dtype == "f32":
         del step
         train = train_object(args, workload, world, rank, force_dist, dist, torch, _abi)
     if rank == 0:

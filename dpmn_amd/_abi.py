@@ -58,6 +58,8 @@ _IP = C.POINTER(C.c_int)
 SIGNATURES = {
     "dpmn_abi_version": (_i, []),
     "dpmn_last_error": (C.c_char_p, []),
+    "dpmn_set_compute_dtype": (_i, [_i]),
+    "dpmn_get_compute_dtype": (_i, []),
     "dpmn_linear_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _f, fp]),
     "dpmn_add_linear_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_cat2_linear_f32": (_i, [fp, _i, fp, _i, fp, fp, fp, _i, _i, _i, fp]),

@@ -128,6 +128,20 @@ enum ProfTag { PT_CONV_IGEMM_128 = 0, PT_CONV_IGEMM_64, PT_CONV_IGEMM_NARROW, PT
                PT_GEMM_PW, PT_GEMM_WSTAT, PT_GEMM_KLOOP, PT_DWCONV_GELU, PT_WATTN8, PT_WATTN_SCALAR, PT_ATTN_FUSED, PT_BIGRU,
                PT_MHA32, PT_PATCH_EMBED, PT_SK_GATE, PT_TAIL, PT_DWPW_FUSED, PT_GEMM_WSTAT_LN, PT_COUNT };
 extern unsigned long long g_dpmn_prof_mask;
+extern int g_dpmn_bf16;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// four fp32 -> four bf16 (round to nearest even, v_cvt_pk_bf16_f32) as two dwords
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  const bf16x2 lo = __builtin_convertvector((f32x2_){a, b}, bf16x2), hi = __builtin_convertvector((f32x2_){c, d}, bf16x2);
+  return make_uint2(__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi));
+}
+// D(16x16) += A(16x32) * B(32x16) on bf16 operands, fp32 accumulation.  Lane l supplies A[i = l&15][k = 8*(l>>4) .. +7] and
+// B[k = 8*(l>>4) .. +7][j = l&15]; the result layout is that of mfma16.
+__device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 struct ProfScope {
   int slot;
   hipStream_t st;

@@ -14,6 +14,7 @@
 //     train-mode BatchNorm statistics, NHWC or NCHW store, optional PixelShuffle(2) store.
 // MFMA roles as in gemm.hip: "A" = weight rows (co), "B" = pixels, so a lane owns 4 consecutive co.
 #include <cstdlib>
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -143,8 +144,11 @@ __device__ __forceinline__ float vmax_raw(float x, float y) {
 // at most 31 taps.  The in-image test of a (pixel row, tap) pair is then precomputed ONCE per block into a per-row tap
 // bitmask, the per-chunk address of a row is `voff[row] | bit31-if-outside` (2 vector instructions) with the tap / channel
 // part of the address in the buffer load's scalar offset, and the store to LDS needs no validity mask (act(0) = 0).
-template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false>
+// BF (with SIMPLE): the operands are rounded to bf16 on the way into LDS (80-byte rows: conflict-free ds_read_b128) and one
+// v_mfma_f32_16x16x32_bf16 per tile pair replaces the eight fp32 MFMAs of a 32-deep chunk; accumulation and epilogue stay fp32.
+template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  static_assert(!BF || (SIMPLE && BKT == 32), "the bf16 variant exists for the SIMPLE path with 32-deep chunks");
   static_assert(!SIMPLE || UNI, "SIMPLE is a refinement of the UNI path");
   static_assert(!AFF || SIMPLE, "AFF is a variant of the SIMPLE path");
 #ifndef DPMN_IGEMM_FENCE
@@ -159,8 +163,10 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   constexpr int TPR = BKT / 4, RPP = 256 / TPR;          // threads per tile row, tile rows per pass
   constexpr int APASS = BM / RPP, BPASS = (BN + RPP - 1) / RPP;
   constexpr int BK = BKT, LDK = BKT + PAD;
-  __shared__ __attribute__((aligned(16))) float Xs[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+  constexpr int LDKB = BKT + 8;                               // bf16 row: 32 + 8 elements = 80 bytes
+  typedef typename std::conditional<BF, unsigned short, float>::type lds_t;
+  __shared__ __attribute__((aligned(16))) lds_t Xs[2][BM * (BF ? LDKB : LDK)];
+  __shared__ __attribute__((aligned(16))) lds_t Ws[2][BN * (BF ? LDKB : LDK)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int M = a.B * a.Hp * a.Wp;
@@ -417,13 +423,24 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
       for (int p = 0; p < APASS; ++p)
         if (inv[p]) xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if constexpr (BF) {
 #pragma unroll
-    for (int p = 0; p < APASS; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * RPP) * LDK + lcol]) = xr[p];
+      for (int p = 0; p < APASS; ++p)
+        *reinterpret_cast<uint2*>(&Xs[buf][(lrow + p * RPP) * LDKB + lcol]) = pack_bf16x4(xr[p].x, xr[p].y, xr[p].z, xr[p].w);
 #pragma unroll
-    for (int p = 0; p < BPASS; ++p)
-      if (BN % RPP == 0 || lrow + p * RPP < BN) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * RPP) * LDK + lcol]) = wr[p];
+      for (int p = 0; p < BPASS; ++p)
+        if (BN % RPP == 0 || lrow + p * RPP < BN)
+          *reinterpret_cast<uint2*>(&Ws[buf][(lrow + p * RPP) * LDKB + lcol]) = pack_bf16x4(wr[p].x, wr[p].y, wr[p].z, wr[p].w);
+    } else {
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * RPP) * LDK + lcol]) = xr[p];
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p)
+        if (BN % RPP == 0 || lrow + p * RPP < BN) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * RPP) * LDK + lcol]) = wr[p];
+    }
   };
   auto sstore = [&](int buf) {
+    if constexpr (!BF) {
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
       float4 v = xr[p];
@@ -444,6 +461,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
 #pragma unroll
     for (int p = 0; p < BPASS; ++p)
       if (lrow + p * RPP < BN) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * RPP) * LDK + lcol]) = wr[p];
+    }
   };
 
   const int wm = wave % WM, wn = wave / WM;
@@ -474,8 +492,21 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     // hipcc otherwise sinks the buffer loads deep into the MFMA block (the last ones ~100 MFMAs down): they must be in
     // flight for the WHOLE block to cover HBM / L2 latency before sstore waits for them
     if (UNI && SCHED_FENCE) __builtin_amdgcn_sched_barrier(0);
-    const float* xa = &Xs[buf][(wm * (MT * 16) + lr) * LDK + kq * 4];
-    const float* wa = &Ws[buf][(wn * (NT * 16) + lr) * LDK + kq * 4];
+    if constexpr (BF) {
+      const lds_t* xa = &Xs[buf][(wm * (MT * 16) + lr) * LDKB + kq * 8];
+      const lds_t* wa = &Ws[buf][(wn * (NT * 16) + lr) * LDKB + kq * 8];
+      bf16x8 xf[MT], wf[NT];
+#pragma unroll
+      for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(xa + j * 16 * LDKB);
+#pragma unroll
+      for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wa + i * 16 * LDKB);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = mfma16_bf16(wf[i], xf[j], acc[i][j]);
+    } else {
+    const float* xa = reinterpret_cast<const float*>(&Xs[buf][0]) + (wm * (MT * 16) + lr) * LDK + kq * 4;
+    const float* wa = reinterpret_cast<const float*>(&Ws[buf][0]) + (wn * (NT * 16) + lr) * LDK + kq * 4;
 #pragma unroll
     for (int kc = 0; kc < BK; kc += 16) {
       f32x4 xf[MT], wf[NT];
@@ -491,6 +522,7 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         for (int i = 0; i < NT; ++i)
 #pragma unroll
           for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[i][s], xf[j][s], acc[i][j]);
+    }
     }
     if (SIMPLE) sstore_simple(buf ^ 1);
     else if (UNI || kt + 1 < nk) sstore(buf ^ 1);
@@ -605,11 +637,15 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows
 // window straight from LDS, so activations cross L2->LDS once instead of K*K times (the im2col redundancy that
 // made k_conv_igemm L2-bound); only the (BN x 32) weight slice of each (chunk, tap) is streamed, double-buffered.
 // One output row of the tile = one 16-pixel MFMA column block; waves 4(m: 2 rows each) x 1(n).
-template <int KS, int BN, int TH>    // TH x 16 output pixels per block (TH = 8: 2 rows per wave, TH = 4: 1 row per wave)
+// BF: bf16 operands (halo tile and weight slices rounded on the way into LDS, 80-byte rows), one v_mfma_f32_16x16x32_bf16 per tap
+// and tile pair instead of eight fp32 MFMAs; fp32 accumulation and epilogue.
+template <int KS, int BN, int TH, bool BF = false>    // TH x 16 output pixels per block (TH = 8: 2 rows per wave, TH = 4: 1 row per wave)
 __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
+  constexpr int LDH = BF ? (BK + 8) / 2 : LDK;           // LDS row stride in FLOAT units (bf16 rows: 40 halves = 20 floats = 80 bytes)
   constexpr int TW = 16, HH = TH + KS - 1, HW_ = TW + KS - 1, NPX = HH * HW_;
   constexpr int NT = BN / 16, T = KS * KS, MR = TH / 4;
-  constexpr bool PREFETCH = false;   // halo staged directly into ONE LDS buffer: 3 blocks per CU hide the staging latency
+  constexpr bool PREFETCH = false;
+  static_assert(!BF || !PREFETCH, "bf16 variant: direct staging only");   // halo staged directly into ONE LDS buffer: 3 blocks per CU hide the staging latency
                                      // (measured: tatt 3x3 60.6 -> 55.3 us, en2b 118 -> 84 us vs the register-prefetch variant;
                                      //  weights straight from L1/L2 to registers instead of LDS measured 76 / 146 us: rejected)
   constexpr int HBUF = PREFETCH ? 2 : 1;
@@ -617,7 +653,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   constexpr int WV = (BN * 8 + 255) / 256;               // weight float4 per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* halo = smem;                                    // [HBUF][NPX][LDK]
-  float* Wt = smem + HBUF * NPX * LDK;                   // [2][BN][LDK]
+  float* Wt = smem + HBUF * NPX * LDH;                   // [2][BN][LDK]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = a.Win / TW, tiles_y = a.Hin / TH;
@@ -629,6 +665,11 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   const int nchunks = a.cin / BK;
 
   float4 hraw[HV], wraw[WV];
+  // one staged float4 (4 consecutive k of one row) -> LDS, fp32 or rounded to bf16
+  auto put4 = [&](float* base, int row, int c4, const float4& v) {
+    if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base + row * LDH) + c4) = pack_bf16x4(v.x, v.y, v.z, v.w);
+    else *reinterpret_cast<float4*>(base + row * LDH + c4) = v;
+  };
   // fetch (and transform) halo element i of channel chunk `chunk`
   auto halo_elem = [&](int chunk, int i) -> float4 {
     const int c0 = chunk * BK;
@@ -664,7 +705,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   auto stage_halo_direct = [&](int chunk) {
     if constexpr (!HALO_BUF) {
       for (int i = tid; i < NPX * 8; i += 256)
-        *reinterpret_cast<float4*>(halo + (i >> 3) * LDK + (i & 7) * 4) = halo_elem(chunk, i);
+        put4(halo, i >> 3, (i & 7) * 4, halo_elem(chunk, i));
       return;
     }
     const int c0 = chunk * BK;                                   // wave-uniform chunk decode
@@ -698,7 +739,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
         val.z = apply_act(val.z, a.pro_act, 0.f); val.w = apply_act(val.w, a.pro_act, 0.f);
       }
       if (!((inb >> v) & 1u)) val = make_float4(0.f, 0.f, 0.f, 0.f);      // padding stays exactly 0 after the transform
-      if (HVD * 32 == NPX || px < NPX) *reinterpret_cast<float4*>(halo + px * LDK + (tid & 7) * 4) = val;
+      if (HVD * 32 == NPX || px < NPX) put4(halo, px, (tid & 7) * 4, val);
     }
   };
   auto issue_halo = [&](int chunk) {
@@ -712,7 +753,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
 #pragma unroll
     for (int v = 0; v < HV; ++v) {
       const int i = tid + v * 256;
-      if (i < NPX * 8) *reinterpret_cast<float4*>(halo + (size_t)buf * NPX * LDK + (i >> 3) * LDK + (i & 7) * 4) = hraw[v];
+      if (i < NPX * 8) put4(halo + (size_t)buf * NPX * LDH, i >> 3, (i & 7) * 4, hraw[v]);
     }
   };
   // weight slice of one (chunk, tap): raw buffer loads -- per-thread byte offsets are loop invariants, the (chunk, tap) part
@@ -746,7 +787,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
 #pragma unroll
     for (int v = 0; v < WV; ++v) {
       const int i = tid + v * 256;
-      if (i < BN * 8) *reinterpret_cast<float4*>(Wt + (size_t)buf * BN * LDK + (i >> 3) * LDK + (i & 7) * 4) = wraw[v];
+      if (i < BN * 8) put4(Wt + (size_t)buf * BN * LDH, i >> 3, (i & 7) * 4, wraw[v]);
     }
   };
 
@@ -774,8 +815,8 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
     // 3x3: the nine taps fully unrolled -- (ky, kx), the halo offsets of the B-operand reads and the weight-buffer parity become
     // immediates instead of per-tap scalar / vector arithmetic (81 VALU + 81 SALU per 64-MFMA tap before; the vector ALU shares
     // its issue with the fp32 matrix pipe).  T = 9 is odd, so the buffer parity of tap t is (chunk + t) & 1.
-    const float* hp0 = halo + (size_t)hb * NPX * LDK + ((MR * wave) * HW_ + lr) * LDK + kq * 4;
-    const float* wp0 = Wt + lr * LDK + kq * 4;
+    const float* hp0 = halo + (size_t)hb * NPX * LDH + ((MR * wave) * HW_ + lr) * LDH + kq * 4;      // (bf16: 8 halves = 4 float units)
+    const float* wp0 = Wt + lr * LDH + kq * 4;
     constexpr int TAP_UNROLL = KS == 3 ? 9 : 1;
 #pragma unroll TAP_UNROLL
     for (int tap = 0; tap < T; ++tap) {
@@ -783,16 +824,27 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
       if (!lastt) issue_w(chunk, tap + 1);
       else if (more) issue_w(chunk + 1, 0);
       const int ky = tap / KS, kx = tap % KS;
-      const float* hp = hp0 + (ky * HW_ + kx) * LDK;
-      const float* wp = wp0 + (size_t)wb * BN * LDK;
+      const float* hp = hp0 + (ky * HW_ + kx) * LDH;
+      const float* wp = wp0 + (size_t)wb * BN * LDH;
+      if constexpr (BF) {
+        bf16x8 xf[MR], wf[NT];
+#pragma unroll
+        for (int j = 0; j < MR; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(hp + j * HW_ * LDH);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(wp + i * 16 * LDH);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MR; ++j) acc[i][j] = mfma16_bf16(wf[i], xf[j], acc[i][j]);
+      } else
 #pragma unroll
       for (int kc = 0; kc < BK; kc += 16) {
         f32x4 xf[MR];
 #pragma unroll
-        for (int j = 0; j < MR; ++j) xf[j] = *reinterpret_cast<const f32x4*>(hp + j * HW_ * LDK + kc);
+        for (int j = 0; j < MR; ++j) xf[j] = *reinterpret_cast<const f32x4*>(hp + j * HW_ * LDH + kc);
         f32x4 wf[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wp + i * 16 * LDK + kc);
+        for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wp + i * 16 * LDH + kc);
 #pragma unroll
         for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
@@ -1105,18 +1157,21 @@ int launch_halo_c4(const ConvArgs& a, hipStream_t st) {
   return DPMN_OK;
 }
 
-template <int KS, int BN, int TH>
+template <int KS, int BN, int TH, bool BF = false>
 int launch_halo_th(const ConvArgs& a, hipStream_t st) {
+  if constexpr (!BF && KS == 3 && BN == 64) {
+    if (g_dpmn_bf16) return launch_halo_th<KS, BN, TH, true>(a, st);
+  }
   constexpr int NPX = (TH + KS - 1) * (16 + KS - 1);
-  const size_t smem = (size_t)(NPX + 2 * BN) * LDK * sizeof(float);
+  const size_t smem = (size_t)(NPX + 2 * BN) * (BF ? (BK + 8) / 2 : LDK) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<KS, BN, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<KS, BN, TH, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   dim3 grid(a.B * (a.Hin / TH) * (a.Win / 16), cdiv(a.Cout, BN));
   ProfScope prof(PT_CONV_HALO, st, conv_flops(a), conv_bytes(a));
-  hipLaunchKernelGGL((k_conv_halo<KS, BN, TH>), grid, dim3(256), smem, st, a);
+  hipLaunchKernelGGL((k_conv_halo<KS, BN, TH, BF>), grid, dim3(256), smem, st, a);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -1183,6 +1238,10 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
                ((size_t)a.B * a.Hin * a.Win + (size_t)(abs(a.pad_y) + a.KH * abs(a.dil_y) + 2) * a.Win) * a.cseg[i] * 4 < (1ull << 31);
     }
     simple = simple && (n_aff == 0 || n_aff == n_seg);       // mixed segments: the general UNI path
+  if (g_dpmn_bf16 && simple && BM == BN && (BM == 128 || BM == 64)) {
+    if (n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, false, true>), grid, dim3(256), 0, st, a);
+  } else
   if (uni && BM == 128 && BN == 128 && bk16) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 16>), grid, dim3(256), 0, st, a);
   else if (simple && n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true>), grid, dim3(256), 0, st, a);
   else if (simple) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true>), grid, dim3(256), 0, st, a);

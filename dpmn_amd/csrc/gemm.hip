@@ -594,6 +594,112 @@ __global__ __launch_bounds__(256, 2) void k_gemm_pw(const float* __restrict__ g,
 }
 
 
+// ---------------------------------------------------------------------------------- pointwise GEMM, bf16 operands
+// dpmn_set_compute_dtype(1): the same 128 x BC tile on v_mfma_f32_16x16x32_bf16 (fp32 accumulation, fp32 tensors in HBM).  G is
+// k-major in memory (rows = channels, s contiguous) and the MFMA wants 8 consecutive k per lane, so the chunk is staged as
+// k-PAIRS: dword (p, s) = (bf16 G[2p][s], bf16 G[2p+1][s]) -- written with one ds_write_b128 per thread and pair (a thread owns 4
+// consecutive s of two adjacent channels), read with four conflict-free ds_read_b32 per operand tile (pairs 4 kq .. 4 kq + 3 of
+// column s).  W rows are k-contiguous: [BC][32 + 8] bf16, one ds_read_b128 per tile.  32-deep chunks, the two-set register
+// prefetch of the fp32 kernel.
+template <int BC>
+__global__ __launch_bounds__(256, 2) void k_gemm_pw_bf16(const float* __restrict__ g, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ z, int Ch, int L) {
+  constexpr int BS = 128, BK = 32, LDP = BS + 4, LDWB = BK + 8, NJ = BC / 32, WP = BC / 32;
+  __shared__ __attribute__((aligned(16))) unsigned Gp[2][(BK / 2) * LDP];        // [16 pairs][128 s + pad] dwords
+  __shared__ __attribute__((aligned(16))) unsigned short Wb[2][BC * LDWB];       // [BC][40] bf16
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s_blk = blockIdx.x * BS, c_blk = blockIdx.y * BC, b = blockIdx.z;
+  const float* gb = g + (size_t)b * Ch * L;
+  float* zb = z + (size_t)b * Ch * L;
+  const int gp_ = tid >> 5, gcol = (tid & 31) * 4;      // pair rows (2 gp_, 2 gp_ + 1) and (+16, +17)
+  const int wrow = tid >> 3, wcol = (tid & 7) * 4;      // rows 0..31 (+32 per pass)
+  float4 ag0, ag1, ag2, ag3, aw0, aw1, aw2, aw3, aw4, aw5, bg0, bg1, bg2, bg3, bw0, bw1, bw2, bw3, bw4, bw5;
+#define PB_GLOAD(P, k0)                                                                                \
+  do {                                                                                                 \
+    P##g0 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + 2 * gp_) * L + s_blk + gcol);        \
+    P##g1 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + 2 * gp_ + 1) * L + s_blk + gcol);    \
+    P##g2 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + 2 * gp_ + 16) * L + s_blk + gcol);   \
+    P##g3 = *reinterpret_cast<const float4*>(gb + (size_t)((k0) + 2 * gp_ + 17) * L + s_blk + gcol);   \
+    P##w0 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow) * Ch + (k0) + wcol);           \
+    P##w1 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 32) * Ch + (k0) + wcol);      \
+    P##w2 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 64) * Ch + (k0) + wcol);      \
+    P##w3 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 96) * Ch + (k0) + wcol);      \
+    if (WP == 6) {                                                                                     \
+      P##w4 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 128) * Ch + (k0) + wcol);   \
+      P##w5 = *reinterpret_cast<const float4*>(w + (size_t)(c_blk + wrow + 160) * Ch + (k0) + wcol);   \
+    }                                                                                                  \
+  } while (0)
+#define PB_PAIR(lo, hi) __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2__){lo, hi}, bf16x2))
+#define PB_SSTORE(P, buf)                                                                              \
+  do {                                                                                                 \
+    *reinterpret_cast<uint4*>(&Gp[buf][gp_ * LDP + gcol]) =                                            \
+        make_uint4(PB_PAIR(P##g0.x, P##g1.x), PB_PAIR(P##g0.y, P##g1.y), PB_PAIR(P##g0.z, P##g1.z), PB_PAIR(P##g0.w, P##g1.w)); \
+    *reinterpret_cast<uint4*>(&Gp[buf][(gp_ + 8) * LDP + gcol]) =                                      \
+        make_uint4(PB_PAIR(P##g2.x, P##g3.x), PB_PAIR(P##g2.y, P##g3.y), PB_PAIR(P##g2.z, P##g3.z), PB_PAIR(P##g2.w, P##g3.w)); \
+    *reinterpret_cast<uint2*>(&Wb[buf][wrow * LDWB + wcol]) = pack_bf16x4(P##w0.x, P##w0.y, P##w0.z, P##w0.w);          \
+    *reinterpret_cast<uint2*>(&Wb[buf][(wrow + 32) * LDWB + wcol]) = pack_bf16x4(P##w1.x, P##w1.y, P##w1.z, P##w1.w);   \
+    *reinterpret_cast<uint2*>(&Wb[buf][(wrow + 64) * LDWB + wcol]) = pack_bf16x4(P##w2.x, P##w2.y, P##w2.z, P##w2.w);   \
+    *reinterpret_cast<uint2*>(&Wb[buf][(wrow + 96) * LDWB + wcol]) = pack_bf16x4(P##w3.x, P##w3.y, P##w3.z, P##w3.w);   \
+    if (WP == 6) {                                                                                     \
+      *reinterpret_cast<uint2*>(&Wb[buf][(wrow + 128) * LDWB + wcol]) = pack_bf16x4(P##w4.x, P##w4.y, P##w4.z, P##w4.w); \
+      *reinterpret_cast<uint2*>(&Wb[buf][(wrow + 160) * LDWB + wcol]) = pack_bf16x4(P##w5.x, P##w5.y, P##w5.z, P##w5.w); \
+    }                                                                                                  \
+  } while (0)
+  typedef float f32x2__ __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4__ __attribute__((ext_vector_type(4)));
+  const int ws_ = wave & 1, wc_ = wave >> 1;
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[4][NJ];   // [s tile][co tile]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define PB_MMA(buf)                                                                                    \
+  do {                                                                                                 \
+    bf16x8 wf[NJ];                                                                                     \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                     \
+      wf[j] = *reinterpret_cast<const bf16x8*>(&Wb[buf][(wc_ * (BC / 2) + j * 16 + lr) * LDWB + kq * 8]); \
+    const unsigned* gp = &Gp[buf][(kq * 4) * LDP + ws_ * 64 + lr];                                     \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                    \
+      const u32x4__ av = {gp[i * 16], gp[LDP + i * 16], gp[2 * LDP + i * 16], gp[3 * LDP + i * 16]};   \
+      const bf16x8 a8 = __builtin_bit_cast(bf16x8, av);                                                \
+      _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16_bf16(a8, wf[j], acc[i][j]);    \
+    }                                                                                                  \
+  } while (0)
+  const int nk = Ch / BK;      // >= 2 (Ch is a multiple of 128)
+  PB_GLOAD(a, 0);
+  PB_GLOAD(b, BK);
+  PB_SSTORE(a, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    PB_GLOAD(a, min(kt + 2, nk - 1) * BK);
+    PB_MMA(0);
+    PB_SSTORE(b, 1);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      PB_GLOAD(b, min(kt + 3, nk - 1) * BK);
+      PB_MMA(1);
+      PB_SSTORE(a, 0);
+      __syncthreads();
+    }
+  }
+#undef PB_GLOAD
+#undef PB_SSTORE
+#undef PB_PAIR
+#undef PB_MMA
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int co = c_blk + wc_ * (BC / 2) + j * 16 + lr;
+    const float bv = bias[co];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s_ = s_blk + ws_ * 64 + i * 16 + kq * 4;
+      *reinterpret_cast<float4*>(zb + (size_t)co * L + s_) =
+          make_float4(acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- whole-K, rows straight into the B operand
 // The scheme of the fused attention kernel's projection (attn_fused.hip) for the K <= 192 token GEMMs: a WAVE owns a 16-token
 // tile; lane (j = l & 15, kq = l >> 4) loads x[token j][16 c + 4 kq .. + 3] straight from global memory into the MFMA B-operand
@@ -1006,7 +1112,11 @@ int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float*
   DPMN_REQUIRE(g && w && bias && z && Ch % 128 == 0 && L % 128 == 0, "pointwise: Ch and L must be multiples of 128");
   static const int pw_bc = getenv("DPMN_PW_BC") ? atoi(getenv("DPMN_PW_BC")) : 192;
   ProfScope prof(PT_GEMM_PW, as_stream(stream), 2.0 * Ch * Ch * (double)L * B, 4.0 * (2.0 * B * Ch * (double)L + (double)Ch * Ch + Ch));
-  if (Ch % 192 == 0 && pw_bc == 192)
+  if (g_dpmn_bf16 && Ch % 192 == 0)
+    hipLaunchKernelGGL((k_gemm_pw_bf16<192>), dim3(L / 128, Ch / 192, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
+  else if (g_dpmn_bf16)
+    hipLaunchKernelGGL((k_gemm_pw_bf16<128>), dim3(L / 128, Ch / 128, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
+  else if (Ch % 192 == 0 && pw_bc == 192)
     hipLaunchKernelGGL((k_gemm_pw<192>), dim3(L / 128, Ch / 192, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
   else
     hipLaunchKernelGGL((k_gemm_pw<128>), dim3(L / 128, Ch / 128, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);

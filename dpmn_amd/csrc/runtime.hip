@@ -12,6 +12,7 @@ int dpmn_set_error(int code, const char* msg) {
 
 // ------------------------------------------------------------------ in-pipeline kernel profiler (common.h ProfScope)
 unsigned long long g_dpmn_prof_mask = 0ull;
+int g_dpmn_bf16 = 0;      // dpmn_set_compute_dtype: 1 = bf16 MFMA operands (fp32 accumulation) in the kernels that have the variant
 namespace {
 const char* const kTagNames[PT_COUNT] = {
     "k_conv_igemm<128,128>", "k_conv_igemm<64,64>", "k_conv_igemm<128,16|32>", "k_conv_splitk_reduce", "k_conv_halo", "k_conv_halo_c4",
@@ -35,7 +36,9 @@ int dpmn_prof_open(int tag, hipStream_t st, double flops, double bytes) {
 void dpmn_prof_close(int slot, hipStream_t st) { (void)hipEventRecord(g_prof.ev[2 * slot + 1], st); }
 
 extern "C" {
-int dpmn_abi_version(void) { return 3; }
+int dpmn_abi_version(void) { return 4; }
+int dpmn_set_compute_dtype(int bf16) { g_dpmn_bf16 = bf16 ? 1 : 0; return DPMN_OK; }
+int dpmn_get_compute_dtype(void) { return g_dpmn_bf16; }
 const char* dpmn_last_error(void) { return g_err; }
 
 int dpmn_profile_tag_count(void) { return PT_COUNT; }

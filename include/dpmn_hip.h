@@ -32,6 +32,12 @@ enum { DPMN_ACT_NONE = 0, DPMN_ACT_GELU = 1, DPMN_ACT_RELU = 2, DPMN_ACT_LEAKY02
 
 int dpmn_abi_version(void);
 const char* dpmn_last_error(void);
+/* Arithmetic of the GEMM-shaped kernels (BASELINE.json configs[2..4] name bf16; the reference itself is fp32 and fp32 is the
+ * default and the headline): bf16 != 0 -> the kernels that have the variant (implicit-GEMM conv, pointwise GEMM) round their MFMA
+ * operands to bf16 on the way into LDS and run v_mfma_f32_16x16x32_bf16 with fp32 accumulation; tensors in HBM, LayerNorm /
+ * softmax / BatchNorm statistics and every epilogue stay fp32.  Process-wide switch, not thread-safe. */
+int dpmn_set_compute_dtype(int bf16);
+int dpmn_get_compute_dtype(void);
 
 /* ------------------------------------------------------------------ GEMM family (gemm.hip) */
 /* y = act(x . w^T + bias) + res1 + res2 ; x (M,K), w (N,K), y/res (M,N).  nn.Linear call sites:
