@@ -20,7 +20,10 @@
 namespace {
 
 constexpr int PAD = 4, BK = 32, LDK = BK + PAD;
-constexpr int STAT_SLOTS = 32;   // BatchNorm statistics are accumulated into (STAT_SLOTS, 2, Cout) and summed by bn_finalize
+constexpr int STAT_SLOTS = 32;   // BatchNorm statistics are accumulated into (STAT_SLOTS, 2, Cout) DOUBLES and summed by bn_finalize.
+// fp64 atomics: a block's fp32 partial sum is exact in fp64 and the fp64 additions of <= a few thousand partials lose nothing a
+// final rounding to fp32 can see, so the statistics -- hence the whole training forward -- no longer depend on the order in which
+// the blocks arrive (fp32 atomics made two runs of the same step differ by 1e-7 ... 5e-4 downstream)
 
 struct ConvArgs {
   const float* in[3];
@@ -572,9 +575,9 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
         s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
         q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
         if (lr == 0 && n + r < a.Cout) {
-          float* st = a.stats + (size_t)(bx % STAT_SLOTS) * 2 * a.Cout;   // slotted: spreads same-address atomics
-          atomicAdd(st + n + r, s);
-          atomicAdd(st + a.Cout + n + r, q);
+          double* st = reinterpret_cast<double*>(a.stats) + (size_t)(bx % STAT_SLOTS) * 2 * a.Cout;   // slotted: spreads same-address atomics
+          atomicAdd(st + n + r, (double)(s));
+          atomicAdd(st + a.Cout + n + r, (double)(q));
         }
       }
     }
@@ -618,13 +621,13 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows
     for (int r = 0; r < 4; ++r) { red[rl][threadIdx.x & 63][r] = ssum[r]; red[rl][threadIdx.x & 63][4 + r] = ssq[r]; }
     __syncthreads();
     if (rl == 0 && cq < n4) {
-      float* st = a.stats + (size_t)(blockIdx.y % STAT_SLOTS) * 2 * a.Cout;
+      double* st = reinterpret_cast<double*>(a.stats) + (size_t)(blockIdx.y % STAT_SLOTS) * 2 * a.Cout;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (n + r < a.Cout) {
           const int c = threadIdx.x & 63;
-          atomicAdd(st + n + r, red[0][c][r] + red[1][c][r] + red[2][c][r] + red[3][c][r]);
-          atomicAdd(st + a.Cout + n + r, red[0][c][4 + r] + red[1][c][4 + r] + red[2][c][4 + r] + red[3][c][4 + r]);
+          atomicAdd(st + n + r, (double)(red[0][c][r] + red[1][c][r] + red[2][c][r] + red[3][c][r]));
+          atomicAdd(st + a.Cout + n + r, (double)(red[0][c][4 + r] + red[1][c][4 + r] + red[2][c][4 + r] + red[3][c][4 + r]));
         }
     }
   }
@@ -886,8 +889,8 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
         s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64); s_ += __shfl_xor(s_, 8, 64);
         q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
         if (lr == 0 && n + r < a.Cout) {
-          float* st = a.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
-          atomicAdd(st + n + r, s_); atomicAdd(st + a.Cout + n + r, q);
+          double* st = reinterpret_cast<double*>(a.stats) + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
+          atomicAdd(st + n + r, (double)(s_)); atomicAdd(st + a.Cout + n + r, (double)(q));
         }
       }
     }
@@ -1030,8 +1033,8 @@ __global__ __launch_bounds__(256) void k_conv_halo_c4(ConvArgs a) {
       s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64); s_ += __shfl_xor(s_, 8, 64);
       q_ += __shfl_xor(q_, 1, 64); q_ += __shfl_xor(q_, 2, 64); q_ += __shfl_xor(q_, 4, 64); q_ += __shfl_xor(q_, 8, 64);
       if (lane == 0 && r < a.Cout) {
-        float* st = a.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
-        atomicAdd(st + r, s_); atomicAdd(st + a.Cout + r, q_);
+        double* st = reinterpret_cast<double*>(a.stats) + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
+        atomicAdd(st + r, (double)(s_)); atomicAdd(st + a.Cout + r, (double)(q_));
       }
     }
   }
@@ -1125,8 +1128,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
     if (t < NG * 8) {
       const int g = t >> 3, r = t & 3, sq = (t >> 2) & 1, n = g * 4 + r;
       if (n < a.Cout) {
-        float* st = a.stats + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
-        atomicAdd(st + (sq ? a.Cout : 0) + n, red[0][t] + red[1][t] + red[2][t] + red[3][t]);
+        double* st = reinterpret_cast<double*>(a.stats) + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
+        atomicAdd(st + (sq ? a.Cout : 0) + n, (double)(red[0][t] + red[1][t] + red[2][t] + red[3][t]));
       }
     }
   }

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_conv_pack_multi(const PackDesc* __restr
 }
 
 // ---------------------------------------------------------------------------------- train-mode BatchNorm
-// stats (32,2,C) = slotted (sum, sumsq) over `count` values per channel (accumulated by the conv epilogue)
+// stats (32,2,C) DOUBLES = slotted (sum, sumsq) over `count` values per channel (accumulated by the conv epilogue with fp64 atomics)
 // clear: zero the slots after reading them (a persistent statistics buffer then needs no memset per conv); nbt: the module's
 // num_batches_tracked counter, incremented here instead of by a separate one-element kernel
 __global__ void k_bn_finalize(float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -401,13 +401,15 @@ __global__ void k_bn_finalize(float* __restrict__ stats, const float* __restrict
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && nbt) *nbt += 1;
   if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
+  double* sd = reinterpret_cast<double*>(stats);      // (32, 2, C) doubles (conv.hip STAT_SLOTS)
+  double s1 = 0.0, s2 = 0.0;
   for (int slot = 0; slot < 32; ++slot) {   // STAT_SLOTS
-    s1 += stats[(size_t)slot * 2 * C + c]; s2 += stats[(size_t)slot * 2 * C + C + c];
-    if (clear) { stats[(size_t)slot * 2 * C + c] = 0.f; stats[(size_t)slot * 2 * C + C + c] = 0.f; }
+    s1 += sd[(size_t)slot * 2 * C + c]; s2 += sd[(size_t)slot * 2 * C + C + c];
+    if (clear) { sd[(size_t)slot * 2 * C + c] = 0.0; sd[(size_t)slot * 2 * C + C + c] = 0.0; }
   }
-  const float mean = s1 / count;
-  float var = s2 / count - mean * mean;   // biased variance used for normalisation
+  const double mean_d = s1 / (double)count;
+  const float mean = (float)mean_d;
+  float var = (float)(s2 / (double)count - mean_d * mean_d);   // biased variance used for normalisation
   var = var > 0.f ? var : 0.f;
   const float rstd = 1.0f / sqrtf(var + eps);
   const float s = gamma[c] * rstd;

@@ -248,6 +248,18 @@ def conv_desc(inputs, k, stride=1, pad=0, dil=1, cout=0, pro_act="none", affine=
     return d
 
 
+def _stats_ptr(stats, cout):
+    """BatchNorm-statistics accumulator of a conv launch: (32, 2, cout) float64 (or a float32 buffer of twice as many elements
+    that is zero: the kernels add into it with fp64 atomics, include/dpmn_hip.h dpmn_conv_desc.stats)."""
+    if stats is None:
+        return None
+    ok = stats.is_cuda and stats.is_contiguous() and stats.data_ptr() % 8 == 0 and (
+        (stats.dtype == torch.float64 and stats.numel() >= 64 * cout) or (stats.dtype == torch.float32 and stats.numel() >= 128 * cout))
+    if not ok:
+        raise _abi.DpmnError("conv2d: stats must be a contiguous CUDA (32, 2, Cout) float64 accumulator")
+    return stats.data_ptr()
+
+
 def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", epi_act="none", slope=0.0, res=None,
            affine=None, out=None, out_nchw=False, pixel_shuffle=False, stats=None, phase=None, geom=None, out_coff=None, groups=1):
     """inputs: list of 1..3 NHWC tensors (channel-concatenated on the fly).  k: int or (KH, KW).
@@ -285,7 +297,7 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
     d.out_ld, d.out_coff, d.out_nchw, d.pixel_shuffle = 0, 0, int(out_nchw), int(pixel_shuffle)
     if out_coff is not None:      # write channels [out_coff, out_coff + cout) of a wider NHWC buffer
         d.out_ld, d.out_coff = out.shape[3], int(out_coff)
-    d.stats = dptr(stats, True)
+    d.stats = _stats_ptr(stats, cout)
     ws = splitk_workspace(wp.device)
     d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     import ctypes as _C
@@ -309,7 +321,7 @@ def convT_s2k4(inputs, packs, cout, pro_act="none", affine=None, stats=None):
     d = conv_desc(inputs, 2, cout=cout, pro_act=pro_act, affine=affine, phase=(0, 0))
     d.nphase, d.w_phase_stride = 4, wp4.shape[1] * wp4.shape[2]
     d.w, d.bias = dptr(wp4), dptr(bias, True)
-    d.out, d.stats = dptr(out), dptr(stats, True)
+    d.out, d.stats = dptr(out), _stats_ptr(stats, cout)
     ws = splitk_workspace(out.device)
     d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
     import ctypes as _C

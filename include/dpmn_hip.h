@@ -136,7 +136,8 @@ typedef struct {
   int out_ld, out_coff;      /* NHWC channel stride (0 = Cout) and channel offset */
   int out_nchw;              /* store NCHW instead */
   int pixel_shuffle;         /* PixelShuffle(2) store: NHWC (B,2Hout,2Wout,Cout/4) (tsrn.py:110-111) */
-  float* stats;              /* (32,2,Cout) slotted += sum / sum of squares of pre-activation outputs (summed by
+  float* stats;              /* (32,2,Cout) DOUBLES (8-byte aligned, 64*Cout floats of storage x 2), slotted += sum / sum of squares of
+                              * the pre-activation outputs by fp64 atomics -- order-independent after the final rounding -- (summed by
                               * dpmn_bn_finalize_f32), or NULL */
   float* splitk_ws;          /* optional scratch enabling split-K for small-M / large-K convs (deep CMM levels) */
   size_t splitk_ws_bytes;
@@ -413,7 +414,7 @@ int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int K
                                  dpmn_stream_t stream);
 int dpmn_conv2d_wgrad_strided_f32(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co,
                                   long s_ci, long s_ky, long s_kx, long base, dpmn_stream_t stream);
-/* num_batches_tracked (int64, may be NULL) is incremented by one; clear_stats != 0 zeroes the (32,2,C) slots after they are
+/* num_batches_tracked (int64, may be NULL) is incremented by one; clear_stats != 0 zeroes the (32,2,C) fp64 slots after they are
  * read, so that a persistent statistics buffer serves the next convolution without a memset */
 int dpmn_bn_finalize_f32(float* stats, const float* gamma, const float* beta, float count, float eps, float momentum,
                          float* scale, float* shift, float* mean, float* rstd, float* running_mean, float* running_var,

@@ -103,12 +103,12 @@ def test_conv2d_bn_fold_segments_residual_and_pixelshuffle(dev):
     xa = torch.cat([x * s[None, :, None, None] + h[None, :, None, None] for x, s, h in zip(xs, sc, sh)], 1)
     ref2 = F.conv2d(F.relu(xa), w, b, padding=1)
     wp2, bp2 = packing.pack_conv(w.to(dev), b.to(dev))
-    stats = torch.zeros(32, 2, cout, device=dev)
+    stats = torch.zeros(32, 2, cout, device=dev, dtype=torch.float64)
     got2 = ops.conv2d([nhwc(x).to(dev) for x in xs], wp2, bp2, cout, 3, pad=1, pro_act="relu",
                       affine=[(s.to(dev), h.to(dev)) for s, h in zip(sc, sh)], stats=stats)
     assert_close(got2.permute(0, 3, 1, 2), ref2, ATOL, RTOL, "affine on load")
-    assert_close(stats.sum(0)[0], ref2.sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sum")
-    assert_close(stats.sum(0)[1], (ref2 * ref2).sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sumsq")
+    assert_close(stats.sum(0)[0].float(), ref2.sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sum")
+    assert_close(stats.sum(0)[1].float(), (ref2 * ref2).sum(dim=(0, 2, 3)), 2e-3, 1e-4, "stats sumsq")
     # PixelShuffle(2) epilogue (UpsampleBLock, tsrn.py:110-112)
     w4 = u("w4", (256, 64, 3, 3)) * 0.05
     b4 = u("b4", (256,))
@@ -231,11 +231,11 @@ def test_conv2d_direct_small_channels(dev, segs, cout, act, affine, stats, B, H,
     pre = {"none": lambda t_: t_, "relu": F.relu, "leaky02": lambda t_: F.leaky_relu(t_, 0.2)}[act](pre)
     ref = F.conv2d(pre, w, b, padding=1)
     wp, bp = packing.pack_conv(w.to(dev), b.to(dev))
-    st = torch.zeros(32, 2, cout, device=dev) if stats else None
+    st = torch.zeros(32, 2, cout, device=dev, dtype=torch.float64) if stats else None
     got = ops.conv2d([nhwc(x).to(dev) for x in xs], wp, bp, cout, 3, pad=1, pro_act=act,
                      affine=None if not affine else [(s.to(dev), h.to(dev)) for s, h in aff], stats=st)
     assert_close(got.permute(0, 3, 1, 2), ref, ATOL, RTOL, "direct conv %s" % (segs,))
     if stats:
-        s12 = st.sum(0).cpu()
+        s12 = st.sum(0).float().cpu()
         assert_close(s12[0], ref.sum((0, 2, 3)), 2e-2, 1e-4, "stats sum")
         assert_close(s12[1], (ref * ref).sum((0, 2, 3)), 2e-2, 1e-4, "stats sumsq")

@@ -137,5 +137,5 @@ def test_real_training_step_world2_shared_gpu(zero1):
     for rank, same_start, same_end, err, scale in res:
         assert same_start, "rank %d did not start from rank 0's parameters" % rank
         assert same_end, "ranks hold different parameters after the step (rank %d)" % rank
-        record("dp_world2_%s" % ("zero1" if zero1 else "allreduce"), "rank %d exchanged-gradient rel L2 vs mean of single-rank gradients" % rank, err, 1.5e-3)
-        assert scale > 0 and err < 1.5e-3, (rank, err, scale)      # two runs of the same step differ by 1e-7 ... 5e-4 (fp32 atomics in the BatchNorm statistics feed forward)
+        record("dp_world2_%s" % ("zero1" if zero1 else "allreduce"), "rank %d exchanged-gradient rel L2 vs mean of single-rank gradients" % rank, err, 1e-5)
+        assert scale > 0 and err < 1e-5, (rank, err, scale)      # BatchNorm statistics are order-independent (fp64 atomics) since round 3: 1e-7, was 1e-7 ... 5e-4

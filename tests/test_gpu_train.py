@@ -561,3 +561,34 @@ def test_test_mode_loads_every_checkpoint_including_cmm(dev, tmp_path):
     fn = sr2.synthetic_text_prior()
     ref2 = sr.refine(models, psn, inp["images_lr"], None, text_prior_fn=fn)
     assert torch.equal(got["out"], ref2)
+
+
+def test_training_forward_is_bitwise_reproducible(dev):
+    """Two runs of the same training step from the same state: the loss -- i.e. the whole training forward incl. the batch-statistics
+    BatchNorm of CMM / DistillModule (fp64-atomic statistics, conv.hip STAT_SLOTS) -- is bitwise equal; the gradients, which still
+    end in fp32 atomics for LayerNorm / depthwise-conv / bias-table terms, agree to 1e-6."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    B, b1, b2 = 4, 2, 2
+    losses, grads = [], []
+    for _ in range(2):
+        sr_ = TextSR(workload.make_config(B), workload.make_args("tsrn", b1, b2, B))
+        models, psn, distill, crit, trainer = sr_.build_training()
+        for i, m in enumerate([psn] + models + distill):
+            sd = m.state_dict()
+            synth.synth_fill_(sd, 300 + i)
+            with torch.no_grad():
+                for k, v in m.state_dict().items():
+                    v.copy_(sd[k])
+        psn.eval()
+        batch = synth.synth_batch(B, seed=4)
+        priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)).to(dev) for k in range(b1)]
+        trainer.lr = 0.0            # keep the parameters: the gradients stay in the arena after the step
+        loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev), None, text_priors=priors)
+        losses.append(loss.clone())
+        grads.append(trainer.flat_g.clone())
+    assert torch.equal(losses[0], losses[1]), "training forward is not reproducible: %r vs %r" % (float(losses[0]), float(losses[1]))
+    e = float((grads[0] - grads[1]).norm() / grads[0].norm())
+    from helpers import record
+    record("train_step_reproducibility", "gradient rel L2 between two runs", e, 1e-6)
+    assert e < 1e-6
