@@ -154,26 +154,51 @@ def cpu_baseline(workload_name, n_img, budget_s=300):
             "sample": "%s forward on one batch of %d synthetic images, %s, torch %s CPU fp32 oracle" % (workload_name, n_img, note, torch.__version__)}
 
 
-def timed_leg(step, steps, warmup, profiling, torch, dist, _abi, post=3):
+def set_branch_streams(on):
+    """The two refinement branches of a step run on two HIP streams (interfaces/super_resolution.py).  Per-kernel durations are only
+    meaningful when kernels do not overlap, so the family ranking and the per-family table are measured with the branches on ONE
+    stream; the timed region always runs the product configuration (two streams)."""
+    from dpmn_amd.interfaces import super_resolution as sr_mod
+    prev = (sr_mod.BRANCH_STREAMS, sr_mod.TRAIN_BRANCH_STREAMS)
+    if not os.environ.get("DPMN_BRANCH_STREAMS") == "0":
+        sr_mod.BRANCH_STREAMS = bool(on)
+    if not os.environ.get("DPMN_TRAIN_BRANCH_STREAMS") == "0":
+        sr_mod.TRAIN_BRANCH_STREAMS = bool(on)
+    return prev
+
+
+# families whose launches all lie outside the two-stream section of a step (PSN before the fork, CMM after the join): their
+# per-launch event durations inside the timed region are their own
+UNFORKED_FAMILIES = ("k_conv_igemm<128,128>", "k_conv_splitk_reduce", "k_bigru", "k_mha32")
+
+
+def timed_leg(step, steps, warmup, profiling, torch, dist, _abi, post=3, arm_timed=True):
     """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks.
-    Returns (seconds, rows of the dominant family event-timed inside the timed steps, per-family rows of `post` extra steps)."""
+    Returns (seconds, rows of the dominant family event-timed inside the timed steps, per-family rows of `post` extra steps).
+    Family ranking (last warm-up steps) and the per-family table (`post` steps after the region): branches on one stream."""
     dominant = None
     n_pick = min(2, warmup)                        # all families armed on the last warm-up steps: who is the dominant kernel?
+    rank_in_warmup = profiling and arm_timed        # legs that do not arm the timed region rank the families in the post steps
     for i in range(warmup):                         # (two steps: the top two families of the forward are within 5 % of each other)
-        if profiling and i == warmup - n_pick:
+        if rank_in_warmup and i == warmup - n_pick:
             torch.cuda.synchronize()
+            set_branch_streams(False)
             _abi.profile_begin(None)
         step()
-        if profiling and i == warmup - 1:
+        if rank_in_warmup and i == warmup - 1:
             torch.cuda.synchronize()
             rows = _abi.profile_end()
+            set_branch_streams(True)
             if rows:
                 dominant = max(rows, key=lambda r: r["total_ms"])["kernel"]
+    if rank_in_warmup:
+        step()                                      # one more warm-up in the product configuration (side streams, allocator pools)
+    arm_timed = arm_timed and dominant in UNFORKED_FAMILIES      # else: measured in the joined-stream steps after the region
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
-    if profiling and dominant:
+    if profiling and dominant and arm_timed:
         _abi.profile_begin([dominant])     # only this family is bracketed by events inside the timed region
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -183,24 +208,36 @@ def timed_leg(step, steps, warmup, profiling, torch, dist, _abi, post=3):
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    live = _abi.profile_end() if (profiling and dominant) else []
+    live = _abi.profile_end() if (profiling and dominant and arm_timed) else []
     if dist.is_initialized():
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernels = []
     if profiling and post:
+        set_branch_streams(False)
         _abi.profile_begin(None)
         for _ in range(post):
             step()
         torch.cuda.synchronize()
-        kernels = sorted((kernel_row(r, post) for r in _abi.profile_end()), key=lambda k: -k["ms_per_step"])[:10]
+        rows = _abi.profile_end()
+        set_branch_streams(True)
+        kernels = sorted((kernel_row(r, post) for r in rows), key=lambda k: -k["ms_per_step"])[:10]
+        if not arm_timed and rows:
+            if dominant is None:
+                dominant = max(rows, key=lambda r: r["total_ms"])["kernel"]
+            live = [r for r in rows if r["kernel"] == dominant]
+            for r in live:
+                r["_post_steps"] = post
     return elapsed, live, kernels
 
 
 def roofline_of(live, steps, B):
     if not live:
         return None
+    post = live[0].get("_post_steps")
+    if post:
+        steps = post
     r = kernel_row(live[0], steps)
     traffic, src = static_traffic(r["kernel"], B)
     return {"kernel": r["kernel"], "bound": r["bound"],
@@ -211,7 +248,9 @@ def roofline_of(live, steps, B):
             "algorithmic_bytes_per_launch": round(live[0]["bytes"] / live[0]["launches"]),
             "flops_per_launch": round(live[0]["flops"] / live[0]["launches"]),
             "launches_timed": live[0]["launches"], "us_per_launch": r["us_per_launch"], "ms_per_step": r["ms_per_step"],
-            "timing": "HIP events around each of the %d launches of this family inside the timed steps, on the launch stream" % live[0]["launches"]}
+            "timing": ("HIP events around each of the %d launches of this family inside the timed steps, on the launch stream" % live[0]["launches"]) if not post else
+                      ("HIP events around each of the %d launches of this family in %d untimed steps after the timed region, the two branch streams "
+                       "joined into one (in the timed region this family's kernels overlap the other branch's: a launch's duration is not its own there)" % (live[0]["launches"], post))}
 
 
 TRAIN_GFLOP_PER_IMAGE = 36.0      # 3 x (6 PGRM 6.81 + CMM 4.46) + PSN forward, config 1 / 2 stack
@@ -253,9 +292,12 @@ def train_object(args, workload, world, rank, force_dist, dist, torch, _abi):
     out = {}
     profiling = rank == 0 and not args.no_kernel_profile
     for drop in (0.0, 0.1):
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()            # the forward leg's cached blocks (three streams' pools) otherwise fragment this leg's arena
         step, trainer, B = build_train_step(args, workload, world, force_dist, dist, torch, drop)
-        steps, warmup = args.train_steps, max(2, min(args.warmup, 3))
-        elapsed, live, kernels = timed_leg(step, steps, warmup, profiling and drop == 0.0, torch, dist, _abi, post=2 if drop == 0.0 else 0)
+        steps, warmup = args.train_steps, max(8, args.warmup)      # three streams: the caching allocator needs a few steps to settle
+        elapsed, live, kernels = timed_leg(step, steps, warmup, profiling and drop == 0.0, torch, dist, _abi, post=3 if drop == 0.0 else 0,
+                                           arm_timed=False)
         ms = elapsed / steps * 1e3
         rec = {"ms_per_step": round(ms, 3), "images_per_s": round(world * B * steps / elapsed, 2), "steps": steps, "warmup": warmup,
                "timed_seconds": round(elapsed, 4)}

@@ -19,6 +19,22 @@ from ..model.cmm import ComplementationModulationModule
 from ..utils import synth
 
 
+TRAIN_BRANCH_STREAMS = os.environ.get("DPMN_TRAIN_BRANCH_STREAMS", "1") != "0"
+BRANCH_STREAMS = os.environ.get("DPMN_BRANCH_STREAMS", "1") != "0"      # 0: branch 1 and branch 2 of refine() on one stream
+
+
+_SIDE_STREAMS = {}
+
+
+def side_streams(device):
+    """The two branch streams of a device, shared by every TextSR object of the process (per-stream workspaces and allocator pools
+    are then warmed once)."""
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
+    return _SIDE_STREAMS[key]
+
+
 class TextSR(base.TextBase):
     def build_models(self, testing=False):
         """Model list in the reference's order (super_resolution.py:38-76): b1 PGRMs (mode=False), b2 PGRMs
@@ -85,22 +101,45 @@ class TextSR(base.TextBase):
             images_lr_psn, _ = model_psn(images_lr, label_vecs)
         else:
             raise NotImplementedError(self.args.arch)
-        cascade = images_lr_psn
-        branch1 = []
-        for k in range(b1):
-            x_q = text_priors[k] if text_priors is not None else text_prior_fn(cascade, k)
-            x_kv = cascade[:, :3]
-            sr = model_list[0 if share else k](x_q, x_kv, branch1[:k])
-            branch1.append(sr)
-            cascade = sr
-        cascade = images_lr_psn
-        branch2 = []
-        for k in range(b1, b1 + b2):
-            x_q = ops.to_mask(cascade)                      # batched toMask (util.py:27-35) on the GPU
-            x_kv = cascade[:, :3]
-            sr = model_list[0 if share else k](x_q, x_kv, branch2[:(k - b2)])   # slice quirk Q11
-            branch2.append(sr)
-            cascade = sr
+        branch1, branch2 = [], []
+
+        def run_branch1():
+            cascade = images_lr_psn
+            for k in range(b1):
+                x_q = text_priors[k] if text_priors is not None else text_prior_fn(cascade, k)
+                x_kv = cascade[:, :3]
+                sr = model_list[0 if share else k](x_q, x_kv, branch1[:k])
+                branch1.append(sr)
+                cascade = sr
+
+        def run_branch2():
+            cascade = images_lr_psn
+            for k in range(b1, b1 + b2):
+                x_q = ops.to_mask(cascade)                      # batched toMask (util.py:27-35) on the GPU
+                x_kv = cascade[:, :3]
+                sr = model_list[0 if share else k](x_q, x_kv, branch2[:(k - b2)])   # slice quirk Q11
+                branch2.append(sr)
+                cascade = sr
+
+        # The two branches only meet in the CMM: they run on two HIP streams, so that one branch's launch-, ramp- and tail-bound
+        # kernels (the K = 96 GEMMs, gate, patch embedding: a third of a PGRM's launches) overlap the other branch's work.  Shared
+        # modules (--sr_share) own ONE workspace and stay on one stream.
+        if BRANCH_STREAMS and not share and images_lr.is_cuda:
+            cur = torch.cuda.current_stream()
+            s1, s2 = self._side_streams = side_streams(images_lr.device)
+            s1.wait_stream(cur)
+            s2.wait_stream(cur)
+            with torch.cuda.stream(s1):
+                run_branch1()
+            with torch.cuda.stream(s2):
+                run_branch2()
+            cur.wait_stream(s1)
+            cur.wait_stream(s2)
+            for t_ in branch1 + branch2:
+                t_.record_stream(cur)
+        else:
+            run_branch1()
+            run_branch2()
         fused = model_list[-1](branch1[-1], branch2[-1])
         out = ops.blend(fused, images_lr_psn, self.args.alpha)
         if return_all:
@@ -186,22 +225,50 @@ class TextSR(base.TextBase):
                 images_lr_psn = psn(images_lr)
             else:
                 images_lr_psn, _ = psn(images_lr, label_vecs)
-        loss = 0
-        cascade, br1 = images_lr_psn, []
-        for k in range(b1):
-            x_q = text_priors[k] if text_priors is not None else text_prior_fn(cascade.detach(), k)
-            sr = models[0 if share else k](x_q, cascade[:, :3, :], br1[:k])
-            br1.append(sr)
-            cascade = sr
-            loss = loss + crit(sr, hr3).mean() * 100
-        cascade, br2 = images_lr_psn, []
-        for k in range(b1, b1 + b2):
-            with torch.no_grad():
-                x_q = ops.to_mask(cascade.detach())      # toMask is not differentiable (PIL round trip in the reference)
-            sr = models[0 if share else k](x_q, cascade[:, :3, :], br2[:(k - b2)])
-            br2.append(sr)
-            cascade = sr
-            loss = loss + crit(sr, hr3).mean() * 100
+        br1, br2, part = [], [], [0, 0]
+
+        def run_branch1():
+            cascade = images_lr_psn
+            for k in range(b1):
+                x_q = text_priors[k] if text_priors is not None else text_prior_fn(cascade.detach(), k)
+                sr = models[0 if share else k](x_q, cascade[:, :3, :], br1[:k])
+                br1.append(sr)
+                cascade = sr
+                part[0] = part[0] + crit(sr, hr3).mean() * 100
+
+        def run_branch2():
+            cascade = images_lr_psn
+            for k in range(b1, b1 + b2):
+                with torch.no_grad():
+                    x_q = ops.to_mask(cascade.detach())      # toMask is not differentiable (PIL round trip in the reference)
+                sr = models[0 if share else k](x_q, cascade[:, :3, :], br2[:(k - b2)])
+                br2.append(sr)
+                cascade = sr
+                part[1] = part[1] + crit(sr, hr3).mean() * 100
+
+        # two HIP streams for the two branches (see refine()); autograd runs each node's backward on its forward's stream and joins
+        # the streams at the end of backward().  The step's weight packs are refreshed on the main stream before the fork.
+        forked = TRAIN_BRANCH_STREAMS and not share and images_lr.is_cuda and not torch.cuda.is_current_stream_capturing()
+        if forked:
+            from ..model import packing
+            if packing.ACTIVE is not None:
+                packing.ACTIVE.ensure_fresh()
+            cur = torch.cuda.current_stream()
+            s1, s2 = self._side_streams = side_streams(images_lr.device)
+            s1.wait_stream(cur)
+            s2.wait_stream(cur)
+            with torch.cuda.stream(s1):
+                run_branch1()
+            with torch.cuda.stream(s2):
+                run_branch2()
+            cur.wait_stream(s1)
+            cur.wait_stream(s2)
+            for t_ in br1 + br2:
+                t_.record_stream(cur)
+        else:
+            run_branch1()
+            run_branch2()
+        loss = part[0] + part[1]
         feat = br1[-1]
         for k in range(b1 - 1, 0, -1):
             ld, feat = distill[k - 1](feat, br1[k - 1])
@@ -214,6 +281,12 @@ class TextSR(base.TextBase):
         loss = loss + crit(sr, hr3).mean() * 100
         loss = loss / (b1 + b2 + 1)
         loss.backward()
+        if forked:
+            # the PGRMs' backward kernels ran on the side streams and wrote the gradient arena directly (no AccumulateGrad node the
+            # autograd engine would join on): the optimizer kernels on this stream must wait for them explicitly
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(self._side_streams[0])
+            cur.wait_stream(self._side_streams[1])
         trainer.step()
         return loss.detach()
 

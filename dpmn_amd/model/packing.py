@@ -149,6 +149,11 @@ class PackCache:
         check(lib.dpmn_conv_pack_multi_f32(descs.data_ptr(), prefix.data_ptr(), len(self.order), nb, stream()))
         self.fresh = self.epoch
 
+    def ensure_fresh(self):
+        """Refresh the registered packs now, on the current stream (callers that are about to fork work onto side streams)."""
+        if self.entries and self.fresh != self.epoch:
+            self._refresh()
+
     def get(self, key, w, geom, out):
         from .._abi import lib, check, dptr, stream
         e = self.entries.get(key)

@@ -196,9 +196,9 @@ _SPLITK_WS = {}
 
 
 def splitk_workspace(device, floats=16 << 20):
-    """One 64 MB scratch per device for split-K partial sums (stream-ordered reuse: every conv consumes it before
-    the next launch on the same stream)."""
-    key = (device.type, device.index)
+    """One 64 MB scratch per (device, stream) for split-K partial sums (stream-ordered reuse: every conv consumes it before
+    the next launch on the same stream; the two refinement branches run on two streams, interfaces/super_resolution.py)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty(floats, device=device)
     return _SPLITK_WS[key]

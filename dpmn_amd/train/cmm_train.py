@@ -42,9 +42,10 @@ def stats_buffer(cout, device):
     """(32, 2, cout) zeroed fp64 BatchNorm-statistics slots for ONE convolution (order-independent sums: conv.hip STAT_SLOTS).  A single persistent buffer per device: the conv that
     fills it and the _bn_finalize that reads it are stream-ordered, and the finalize kernel zeroes what it read, so the next
     convolution gets the same memory back clean (33 memsets per step otherwise)."""
-    buf = _STATS.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _STATS.get(key)
     if buf is None or buf.numel() < 128 * cout:
-        buf = _STATS[device] = torch.zeros(128 * max(cout, 1024), device=device)
+        buf = _STATS[key] = torch.zeros(128 * max(cout, 1024), device=device)
     return buf[:128 * cout]          # (32 slots, 2, cout) fp64 accumulators seen as floats by the allocator (include/dpmn_hip.h)
 
 

@@ -131,6 +131,11 @@ class FlatBucket:
 
     def _mark_ready(self):
         self.ready = True
+        # the backward of the two refinement branches runs on two HIP streams (interfaces/super_resolution.py): the group's
+        # collective is enqueued behind the stream of its LAST reporter only, so every member leaves an event for it to wait on
+        if self.group is not None and self.group.multi and self.flat_g.is_cuda:
+            self.ready_event = torch.cuda.Event()
+            self.ready_event.record()
         if self.group is not None:
             self.group.member_ready()
 
@@ -209,6 +214,13 @@ class CommGroup:
         self.launched = True
         if not self.multi:
             return
+        if self.flat_g.is_cuda:
+            cur = torch.cuda.current_stream()
+            for b in self.buckets:
+                ev = getattr(b, "ready_event", None)
+                if ev is not None:
+                    cur.wait_event(ev)
+                    b.ready_event = None
         avg = dist.ReduceOp.AVG
         self._post_scale = None
         if dist.get_backend(self.pg) != "nccl":        # test hook (gloo): no AVG / reduce-scatter guarantee on every build

@@ -124,7 +124,7 @@ def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
         check(lib.dpmn_conv2d_wgrad_excl_slots(C.byref(d), C.cast(C.pointer(slots), C.c_void_p)))
     if slots.value == 0:      # (the library advises the slotted-atomic path for tiny gradients over many pixels)
         nslots = 32 if d.Cout * kp <= 12288 else 1     # small gradients: spread the pixel splits' atomics over 32 copies
-        key = (dy.device, d.Cout, kp, nslots)
+        key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream, d.Cout, kp, nslots)
         ws = _WGRAD_WS.get(key)
         if ws is None:
             ws = _WGRAD_WS[key] = torch.zeros(nslots, d.Cout, kp, device=dy.device)
@@ -132,9 +132,10 @@ def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
         check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 1, nslots, stream()))
         return
     n = slots.value * d.Cout * kp
-    ws = _WGRAD_WS.get(dy.device)
-    if ws is None or ws.numel() < n:       # one workspace per device: wgrad -> unpack pairs are stream-ordered
-        ws = _WGRAD_WS[dy.device] = torch.empty(max(n, 16 << 20), device=dy.device)
+    skey = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
+    ws = _WGRAD_WS.get(skey)
+    if ws is None or ws.numel() < n:       # one workspace per (device, stream): wgrad -> unpack pairs are stream-ordered
+        ws = _WGRAD_WS[skey] = torch.empty(max(n, 16 << 20), device=dy.device)
     check(lib.dpmn_conv2d_wgrad_excl_f32(C.byref(d), dptr(dy), dptr(ws), slots.value, stream()))
     check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 0, slots.value, stream()))
 
