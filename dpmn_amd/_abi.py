@@ -47,7 +47,7 @@ class ConvDesc(C.Structure):
         ("w", fp), ("bias", fp), ("Cout", C.c_int), ("epi_act", C.c_int), ("slope", C.c_float), ("res", fp),
         ("out", fp), ("out_ld", C.c_int), ("out_coff", C.c_int), ("out_nchw", C.c_int), ("pixel_shuffle", C.c_int),
         ("stats", fp), ("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t), ("nphase", C.c_int), ("w_phase_stride", C.c_long),
-        ("groups", C.c_int), ("w_group_stride", C.c_long)]
+        ("groups", C.c_int), ("w_group_stride", C.c_long), ("arrive_cnt", fp), ("arrive_cnt_len", C.c_int)]
 
 
 _i, _f, _sz, _l, _u64 = C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_ulonglong

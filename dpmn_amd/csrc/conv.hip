@@ -633,6 +633,292 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows
   }
 }
 
+// ---------------------------------------------------------------------------------- stream-K implicit GEMM
+// The split-K layers of the CMM (deep levels: 8 ... 384 output tiles against 256 CUs, K = 512 ... 13824) as ONE persistent launch:
+// the (tile, k chunk) steps of the whole layer -- T tiles x nk 32-deep chunks -- are cut into G equal contiguous ranges, one per
+// workgroup (G = the resident capacity, 2 per CU), so every CU does the same number of MFMAs whatever T is (the fixed-split
+// grid gave 384 whole tiles to 256 CUs, or 768 short blocks in 1.5 rounds of 512 slots).  A range that covers a tile's whole K
+// runs the epilogue directly.  Otherwise the accumulators go to slot (block + tile) of the workspace in their register
+// layout (16-byte lane-consecutive stores), the block bumps the tile's arrival counter, and the block that arrives LAST reads all
+// contributions back IN BLOCK ORDER (its own included: the sum is the same whoever arrives last -- bitwise reproducible) and runs
+// the epilogue.  No reduce launch; partial tiles <= G + T - 1 per launch instead of S T.  Nothing waits on another workgroup.
+// Logical block ids are XCD-contiguous (workgroups are dealt to the 8 XCDs round-robin): one XCD walks consecutive tiles, which
+// share a weight column tile (order 0: row tile fastest) or an input row tile (order 1), as the wlocal mapping above does.
+struct SkArgs {
+  int tiles_m, tiles_n, nk, order;
+  long total;                 // T * nk chunk steps
+  float* partial;             // (G + T) slots of BM * BN floats
+  unsigned* cnt;              // T arrival counters: zero on entry, zero again on exit
+};
+
+template <int BM, int BN, int WM, int WN, bool AFF>
+__global__ __launch_bounds__(256) void k_conv_igemm_sk(ConvArgs a, SkArgs sk) {
+  constexpr int MT = BM / WM / 16, NT = BN / WN / 16;
+  constexpr int RPP = 32;                                 // 8 threads per 32-float tile row, 32 rows per pass
+  constexpr int APASS = BM / RPP, BPASS = BN / RPP;
+  constexpr int BK = 32, LDK = BK + PAD;
+  static_assert(WM * WN == 4 && BM % RPP == 0 && BN % RPP == 0, "4 waves; whole staging passes");
+  __shared__ __attribute__((aligned(16))) float Xs[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+  __shared__ int s_fix[2];
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int M = a.B * a.Hp * a.Wp;
+  const int G = (int)gridDim.x, pb_ = (int)blockIdx.x;
+  const int L = (G & 7) == 0 ? (pb_ & 7) * (G >> 3) + (pb_ >> 3) : pb_;
+  long c = sk.total * L / G;
+  const long c_end = sk.total * (L + 1) / G;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  const int HWp = a.Hp * a.Wp;
+  const float inv_hw = 1.0f / (float)HWp, inv_w = 1.0f / (float)a.Wp;
+  const int c01 = a.cseg[0] + a.cseg[1];
+  const int ktaps = a.KH * a.KW;
+  const int minoff = (a.dil_y < 0 ? (a.KH - 1) * a.dil_y : 0) * a.Win + (a.dil_x < 0 ? (a.KW - 1) * a.dil_x : 0);
+  const int wm = wave % WM, wn = wave / WM;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int nph = a.nphase > 1 ? a.nphase : 1;
+
+  while (c < c_end) {
+    const int t = (int)(c / sk.nk);
+    const int kt0 = (int)(c - (long)t * sk.nk);
+    const int kt1 = min(sk.nk, kt0 + (int)(c_end - c));
+    c += kt1 - kt0;
+    int bx, by, phs;
+    if (sk.order == 0) { bx = t % sk.tiles_m; const int r = t / sk.tiles_m; by = r % sk.tiles_n; phs = r / sk.tiles_n; }
+    else { by = t % sk.tiles_n; const int r = t / sk.tiles_n; phs = r % nph; bx = r / nph; }
+    const int m_blk = bx * BM, n_blk = by * BN;
+    int pad_y = a.pad_y, pad_x = a.pad_x, ooy = a.ooy, oox = a.oox;
+    const float* wbase = a.w + (conv_group_of(a, m_blk) ? a.wgs : 0L);
+    if (a.nphase > 1) { pad_y = -(phs >> 1); pad_x = -(phs & 1); ooy = phs >> 1; oox = phs & 1; wbase += (size_t)phs * a.wps; }
+
+    // ---- per-tile state of the SIMPLE load path (see k_conv_igemm)
+    int pix[APASS];
+    unsigned nok[APASS];
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      const int m = m_blk + lrow + p * RPP;
+      int py = -(1 << 20), px = -(1 << 20);
+      pix[p] = 0;
+      if (m < M) {
+        int b = (int)((float)m * inv_hw), r = m - b * HWp;
+        if (r < 0) { --b; r += HWp; }
+        if (r >= HWp) { ++b; r -= HWp; }
+        int y = (int)((float)r * inv_w), x = r - y * a.Wp;
+        if (x < 0) { --y; x += a.Wp; }
+        if (x >= a.Wp) { ++y; x -= a.Wp; }
+        py = y * a.stride - pad_y;
+        px = x * a.stride - pad_x;
+        pix[p] = (b * a.Hin + py) * a.Win + px;
+      }
+      unsigned colm = 0, okb = 0;
+      for (int kx = 0; kx < a.KW; ++kx) colm |= ((unsigned)(px + kx * a.dil_x) < (unsigned)a.Win ? 1u : 0u) << kx;
+      for (int ky = 0; ky < a.KH; ++ky)
+        if ((unsigned)(py + ky * a.dil_y) < (unsigned)a.Hin) okb |= colm << (ky * a.KW);
+      nok[p] = ~okb;
+    }
+    const int padoff = pad_y * a.Win + pad_x;
+    const int baseshift = padoff - minoff;
+    int voff[APASS], wofs[BPASS];
+    unsigned inv[APASS];
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) wofs[p] = ((n_blk + lrow + p * RPP) * a.Kp + lcol) * 4;
+    const __amdgpu_buffer_rsrc_t s_wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wbase), 0, a.Cout * a.Kp * 4, 0x00020000);
+    __amdgpu_buffer_rsrc_t s_xrs, s_scrs, s_shrs;
+    int s_seg = -1, s_segstart = 0;
+    int u_tap = 0, u_c0 = 0, u_ky = 0, u_kx = 0, u_k0 = -2;
+    float4 xr[APASS], wr[BPASS];
+    float4 s4r, h4r;
+    auto gload = [&](int kt_) {
+      if (kt_ == u_k0 + 1) {
+        ++u_tap;
+        if (++u_kx == a.KW) { u_kx = 0; ++u_ky; }
+        if (u_tap == ktaps) { u_tap = 0; u_ky = 0; u_c0 += BK; }
+      } else if (kt_ != u_k0) {
+        const int cch = kt_ / ktaps;
+        u_tap = kt_ - cch * ktaps; u_c0 = cch * BK;
+        u_ky = u_tap / a.KW; u_kx = u_tap - u_ky * a.KW;
+      }
+      u_k0 = kt_;
+      const int k0 = u_tap * a.cin + u_c0;
+      const int seg = u_c0 >= c01 ? 2 : (u_c0 >= a.cseg[0] ? 1 : 0);
+      const int cs = seg == 2 ? a.cseg[2] : (seg == 1 ? a.cseg[1] : a.cseg[0]);
+      if (seg != s_seg) {
+        s_seg = seg;
+        s_segstart = seg == 2 ? c01 : (seg == 1 ? a.cseg[0] : 0);
+        const float* src = seg == 2 ? a.in[2] : (seg == 1 ? a.in[1] : a.in[0]);
+        s_xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src) - (ptrdiff_t)baseshift * cs, 0,
+                                                  (a.B * a.Hin * a.Win + baseshift) * cs * 4, 0x00020000);
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) voff[p] = (__mul24(pix[p] + padoff, cs) + lcol) * 4;
+        if (AFF) {
+          const float* sc = seg == 2 ? a.in_scale[2] : (seg == 1 ? a.in_scale[1] : a.in_scale[0]);
+          const float* sf = seg == 2 ? a.in_shift[2] : (seg == 1 ? a.in_shift[1] : a.in_shift[0]);
+          s_scrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc), 0, cs * 4, 0x00020000);
+          s_shrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sf), 0, cs * 4, 0x00020000);
+        }
+      }
+      const int soff = __builtin_amdgcn_readfirstlane(((u_ky * a.dil_y * a.Win + u_kx * a.dil_x - minoff) * cs + u_c0 - s_segstart) * 4);
+      const int sh = 31 - min(u_tap, 31);
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) {
+        const unsigned oob = (nok[p] << sh) & 0x80000000u;
+        if (AFF) inv[p] = oob;
+        xr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_xrs, (int)(oob | (unsigned)voff[p]), soff, 0));
+      }
+      if (AFF) {
+        const int coff = __builtin_amdgcn_readfirstlane((u_c0 - s_segstart) * 4);
+        s4r = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_scrs, lcol * 4, coff, 0));
+        h4r = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_shrs, lcol * 4, coff, 0));
+      }
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p)
+        wr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(s_wrs, wofs[p], k0 * 4, 0));
+    };
+    auto sstore = [&](int buf) {
+      if (AFF) {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+          xr[p].x = xr[p].x * s4r.x + h4r.x; xr[p].y = xr[p].y * s4r.y + h4r.y;
+          xr[p].z = xr[p].z * s4r.z + h4r.z; xr[p].w = xr[p].w * s4r.w + h4r.w;
+        }
+      }
+      if (a.pro_act != ACT_NONE) {
+        const float sl = a.pro_act == ACT_LEAKY02 ? 0.2f : 0.0f;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+          xr[p].x = vmax_raw(xr[p].x, sl * xr[p].x); xr[p].y = vmax_raw(xr[p].y, sl * xr[p].y);
+          xr[p].z = vmax_raw(xr[p].z, sl * xr[p].z); xr[p].w = vmax_raw(xr[p].w, sl * xr[p].w);
+        }
+      }
+      if (AFF) {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p)
+          if (inv[p]) xr[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) *reinterpret_cast<float4*>(&Xs[buf][(lrow + p * RPP) * LDK + lcol]) = xr[p];
+#pragma unroll
+      for (int p = 0; p < BPASS; ++p) *reinterpret_cast<float4*>(&Ws[buf][(lrow + p * RPP) * LDK + lcol]) = wr[p];
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(kt0);
+    sstore(0);
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const int buf = (kt - kt0) & 1;
+      gload(min(kt + 1, kt1 - 1));
+      __builtin_amdgcn_sched_barrier(0);
+      const float* xa = &Xs[buf][0] + (wm * (MT * 16) + lr) * LDK + kq * 4;
+      const float* wa = &Ws[buf][0] + (wn * (NT * 16) + lr) * LDK + kq * 4;
+#pragma unroll
+      for (int kc = 0; kc < BK; kc += 16) {
+        f32x4 xf[MT], wf[NT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xa + j * 16 * LDK + kc);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 16 * LDK + kc);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[i][s], xf[j][s], acc[i][j]);
+      }
+      sstore(buf ^ 1);
+      __syncthreads();
+    }
+
+    // ---- partial tile: hand over / collect
+    if (kt0 != 0 || kt1 != sk.nk) {
+      // The 8 XCDs have separate L2s.  A device-scope fence would write back and invalidate the WHOLE L2 of the XCD per workgroup
+      // and partial tile (measured: every layer 1.5-2x slower -- the weight / input working set is refetched each time);
+      // instead only the partial tiles themselves move with system-scope cache policy (sc0 sc1: stores write through, loads
+      // miss), ordered by plain vmcnt waits around the device-scope arrival counter.
+      constexpr int QN = NT * MT;
+      constexpr int POL = 0x11;              // cache policy of the buffer instructions: sc0 | sc1 (gfx940+ encoding of the aux operand)
+      const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(sk.partial, 0, (G + sk.tiles_m * sk.tiles_n * nph) * (QN * 4096), 0x00020000);
+      {
+        const int so = __builtin_amdgcn_readfirstlane((L + t) * (QN * 4096));
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_, acc[i][j]), prs, tid * 16 + (i * MT + j) * 4096, so, POL);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // written through before this wave reaches the barrier
+      __syncthreads();
+      if (tid == 0) {
+        const long x0 = (long)t * sk.nk;
+        const int Lf = (int)(((x0 + 1) * G - 1) / sk.total), Ll = (int)(((x0 + sk.nk) * G - 1) / sk.total);
+        const unsigned old = __hip_atomic_fetch_add(sk.cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = old == (unsigned)(Ll - Lf);
+        if (last) __hip_atomic_store(sk.cnt + t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody else touches it before the next launch
+        s_fix[0] = last ? Lf : -1;
+        s_fix[1] = Ll;
+      }
+      __syncthreads();
+      const int Lf = s_fix[0], Ll = s_fix[1];
+      __syncthreads();                       // (s_fix is rewritten by the next partial tile of this block)
+      if (Lf < 0) continue;
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int Lc = Lf; Lc <= Ll; ++Lc) {
+        const int so = __builtin_amdgcn_readfirstlane((Lc + t) * (QN * 4096));
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+          for (int j = 0; j < MT; ++j)
+            acc[i][j] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, tid * 16 + (i * MT + j) * 4096, so, POL));
+      }
+    }
+
+    // ---- epilogue: lane holds out[pixel m = .. + (l&15)][co = .. + (l>>4)*4 + r]
+    float ssum[NT][4], ssq[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ssum[i][r] = 0.f; ssq[i][r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+      const int m = m_blk + wm * (MT * 16) + j * 16 + lr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = n_blk + wn * (NT * 16) + i * 16 + kq * 4;
+        if (n >= a.Cout) continue;
+        float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+        conv_store(a, m, n, v, ssum[i], ssq[i], ooy, oox);
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int i = 0; i < NT; ++i) {
+        const int n = n_blk + wn * (NT * 16) + i * 16 + kq * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s = ssum[i][r], q = ssq[i][r];
+          s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+          q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+          if (lr == 0 && n + r < a.Cout) {
+            double* st = reinterpret_cast<double*>(a.stats) + (size_t)(bx % STAT_SLOTS) * 2 * a.Cout;
+            atomicAdd(st + n + r, (double)(s));
+            atomicAdd(st + a.Cout + n + r, (double)(q));
+          }
+        }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- halo-tile direct conv
 // Stride-1 "same" KxK convs (3x3 of the CMM / PSN trunks, 9x9 output conv) with the INPUT tile resident in LDS:
 // a block owns 8x16 output pixels of one image x BN output channels.  Per 32-channel chunk the (8+K-1)x(16+K-1)
@@ -1190,6 +1476,56 @@ int launch_halo(const ConvArgs& a, hipStream_t st) {
   return launch_halo_th<KS, BN, 8>(a, st);
 }
 
+// stream-K launch (k_conv_igemm_sk): returns -1 when the layer does not qualify (the caller falls through to the fixed-split path)
+template <int BM, int BN, int WM, int WN>
+int launch_conv_sk(const ConvArgs& a, float* ws, size_t ws_bytes, unsigned* cnt, int cnt_len, hipStream_t st) {
+  static const int sk_on = getenv("DPMN_CONV_SK") ? atoi(getenv("DPMN_CONV_SK")) : 1;
+  if (!sk_on || !ws || !cnt || g_dpmn_bf16) return -1;
+  if ((long)a.B * a.Hp * a.Wp >= (1L << 24) || (a.groups == 2 && a.m_per_group % BM != 0)) return -1;
+  // the SIMPLE load path (see launch_conv): 32-channel chunks in one segment, <= 31 taps, act(0) = 0 prologue, all-or-none affine
+  bool simple = a.cin % 32 == 0 && (size_t)a.Cout * a.Kp * 4 < (1ull << 31) && a.KH * a.KW <= 31 &&
+                (a.pro_act == ACT_NONE || a.pro_act == ACT_RELU || a.pro_act == ACT_LEAKY02);
+  int n_seg = 0, n_aff = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (a.cseg[i] > 0) { ++n_seg; n_aff += a.in_scale[i] != nullptr; }
+    simple = simple && a.cseg[i] % 32 == 0 &&
+             ((size_t)a.B * a.Hin * a.Win + (size_t)(abs(a.pad_y) + a.KH * abs(a.dil_y) + 2) * a.Win) * a.cseg[i] * 4 < (1ull << 31);
+  }
+  if (!simple || (n_aff != 0 && n_aff != n_seg)) return -1;
+  static int capacity = 0;      // resident workgroups of the device (2 per CU by LDS and registers)
+  if (!capacity) {
+    int dev = 0, cus = 0, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&k_conv_igemm_sk<128, 128, 2, 2, false>), 256, 0);
+    capacity = (cus > 0 ? cus : 256) * (per_cu > 0 ? per_cu : 2);
+    if (getenv("DPMN_SK_BLOCKS")) capacity = atoi(getenv("DPMN_SK_BLOCKS"));      // experiment / test knob
+  }
+  const int M = a.B * a.Hp * a.Wp;
+  const int nph = a.nphase > 1 ? a.nphase : 1;
+  SkArgs sk{};
+  sk.tiles_m = cdiv(M, BM); sk.tiles_n = cdiv(a.Cout, BN); sk.nk = a.Kp / BK;
+  const int T = sk.tiles_m * sk.tiles_n * nph;
+  sk.total = (long)T * sk.nk;
+  int G = capacity;
+  if (T >= 2 * G || T > cnt_len) return -1;      // enough whole tiles to balance the CUs without sharing any
+  if (sk.total < 4L * G) G = (int)(sk.total / 4);      // at least 4 chunks per block
+  if (G >= 8) G &= ~7;
+  if (G < 1) G = 1;
+  if ((size_t)(G + T) * BM * BN * sizeof(float) > ws_bytes) return -1;
+  sk.partial = ws; sk.cnt = cnt;
+  // consecutive tiles run on one XCD: let them share what costs more to re-read (as the wlocal rule of the fixed-split path)
+  const double w_reread = (double)a.Cout * a.Kp * nph * (a.groups > 1 ? 2 : 1) * (sk.tiles_m > 8 ? 8 : sk.tiles_m);
+  const double x_reread = (double)a.B * a.Hin * a.Win * a.cin * (sk.tiles_n > 8 ? 8 : sk.tiles_n);
+  static const int force_order = getenv("DPMN_SK_ORDER") ? atoi(getenv("DPMN_SK_ORDER")) : -1;
+  sk.order = force_order >= 0 ? force_order : (w_reread > x_reread ? 0 : 1);
+  ProfScope prof(PT_CONV_IGEMM_SK, st, conv_flops(a), conv_bytes(a));
+  if (n_aff) hipLaunchKernelGGL((k_conv_igemm_sk<BM, BN, WM, WN, true>), dim3(G), dim3(256), 0, st, a, sk);
+  else hipLaunchKernelGGL((k_conv_igemm_sk<BM, BN, WM, WN, false>), dim3(G), dim3(256), 0, st, a, sk);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
   if ((long)a.B * a.Hp * a.Wp >= (1L << 24))
@@ -1358,7 +1694,36 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   // parallelism through split-K (deep CMM levels: K = 2304..13824)
   static const int force_tile = getenv("DPMN_CONV_TILE") ? atoi(getenv("DPMN_CONV_TILE")) : 0;          // experiment knob
   if (force_tile == 64) return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
-  if (a.Cout >= 128 && M >= 128) return launch_conv<128, 128, 2, 2>(a, ws, wsb, st);
+  if (a.Cout >= 128 && M >= 128) {
+    // stream-K (one persistent launch, no reduce kernel) where the fixed-split path would split K or leave CUs idle; 64-pixel
+    // row tiles when 128-pixel ones would be partly empty (the 1x4 bottleneck maps: M = 192 per branch / phase)
+    const int mg = a.groups == 2 ? a.m_per_group : M;
+    const bool rows64 = mg % 128 != 0 && mg % 64 == 0 && M <= 1024;
+    // DPMN_CONV_SK: 0 never, 1 (default) the 64-row layers only, 2 every layer that qualifies (measured: the deep-K layers lose
+    // to the fixed split + parallel reduce launch -- a tile shared by 5 ... 21 workgroups is collected by ONE of them)
+    static const int sk_mode = getenv("DPMN_CONV_SK") ? atoi(getenv("DPMN_CONV_SK")) : 1;
+    static const int rows64_fixed = getenv("DPMN_ROWS64_FIXED") ? atoi(getenv("DPMN_ROWS64_FIXED")) : 0;
+    if (rows64 && rows64_fixed && (a.groups != 2 || mg % 64 == 0)) return launch_conv<64, 128, 1, 4>(a, ws, wsb, st);
+    const int r = rows64 ? launch_conv_sk<64, 128, 1, 4>(a, ws, wsb, d->arrive_cnt, d->arrive_cnt_len, st)
+                         : (sk_mode >= 2 ? launch_conv_sk<128, 128, 2, 2>(a, ws, wsb, d->arrive_cnt, d->arrive_cnt_len, st) : -1);
+    if (r >= 0) return r;
+    if (a.groups == 2 && mg % 128 != 0 && !a.out_nchw && !a.pixel_shuffle && !a.res) {
+      // the fixed-split path needs whole 128-pixel row tiles per half: one launch per half instead
+      for (int g = 0; g < 2; ++g) {
+        dpmn_conv_desc h = *d;
+        h.B = d->B / 2; h.groups = 1;
+        for (int s = 0; s < 3; ++s)
+          if (h.in[s]) h.in[s] += (size_t)g * h.B * d->Hin * d->Win * d->cseg[s];
+        h.w += (size_t)g * d->w_group_stride;
+        if (h.bias) h.bias += (size_t)g * d->Cout;
+        h.out += (size_t)g * h.B * d->Hout * d->Wout * a.out_ld;
+        const int e = dpmn_conv2d_nhwc_f32(&h, stream);
+        if (e != DPMN_OK) return e;
+      }
+      return DPMN_OK;
+    }
+    return launch_conv<128, 128, 2, 2>(a, ws, wsb, st);
+  }
   return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
 }
 

@@ -195,13 +195,32 @@ def pgrm_tail(tokens, w0, b0, w1, b1, weight_list, residuals, H, W, hidden, patc
 _SPLITK_WS = {}
 
 
-def splitk_workspace(device, floats=16 << 20):
-    """One 64 MB scratch per (device, stream) for split-K partial sums (stream-ordered reuse: every conv consumes it before
+def splitk_workspace(device, floats=24 << 20):
+    """One 96 MB scratch per (device, stream) for split-K partial sums (stream-ordered reuse: every conv consumes it before
     the next launch on the same stream; the two refinement branches run on two streams, interfaces/super_resolution.py)."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty(floats, device=device)
     return _SPLITK_WS[key]
+
+
+_ARRIVE_CNT = {}
+ARRIVE_CNT_LEN = 4096
+STREAM_K = True      # False: the fixed-split path with its reduce launch (tests / A-B runs)
+
+
+def _attach_workspace(d, device):
+    """split-K scratch + the zero-initialised tile-arrival counters of the stream-K conv launch (include/dpmn_hip.h
+    dpmn_conv_desc.arrive_cnt: the kernel leaves them zero), one pair per (device, stream)."""
+    ws = splitk_workspace(device)
+    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+    if not STREAM_K:
+        d.arrive_cnt, d.arrive_cnt_len = None, 0
+        return
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _ARRIVE_CNT:
+        _ARRIVE_CNT[key] = torch.zeros(ARRIVE_CNT_LEN, dtype=torch.int32, device=device)
+    d.arrive_cnt, d.arrive_cnt_len = _ARRIVE_CNT[key].data_ptr(), ARRIVE_CNT_LEN
 
 
 def nchw_to_nhwc(x, cpad=None):
@@ -271,7 +290,7 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
     if groups == 2:
         B0, h = inputs[0].shape[0], inputs[0].shape[0] // 2
         d0 = conv_desc(inputs, k, stride, pad, dil, cout, pro_act, affine, phase, geom)
-        if B0 % 2 or (h * d0.Hp * d0.Wp) % 128 or stats is not None or res is not None or out_nchw or pixel_shuffle:
+        if B0 % 2 or (h * d0.Hp * d0.Wp) % (64 if h * d0.Hp * d0.Wp <= 512 else 128) or stats is not None or res is not None or out_nchw or pixel_shuffle:
             assert out is None and out_coff is None and B0 % 2 == 0
             outs = [conv2d([t[g * h:(g + 1) * h] for t in inputs], wp[g], None if bias is None else bias[g], cout, k, stride, pad, dil,
                            pro_act, epi_act, slope, None if res is None else res[g * h:(g + 1) * h], affine, None, out_nchw,
@@ -298,8 +317,7 @@ def conv2d(inputs, wp, bias, cout, k, stride=1, pad=0, dil=1, pro_act="none", ep
     if out_coff is not None:      # write channels [out_coff, out_coff + cout) of a wider NHWC buffer
         d.out_ld, d.out_coff = out.shape[3], int(out_coff)
     d.stats = _stats_ptr(stats, cout)
-    ws = splitk_workspace(wp.device)
-    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+    _attach_workspace(d, wp.device)
     import ctypes as _C
     check(lib.dpmn_conv2d_nhwc_f32(_C.byref(d), stream()))
     return out
@@ -322,8 +340,7 @@ def convT_s2k4(inputs, packs, cout, pro_act="none", affine=None, stats=None):
     d.nphase, d.w_phase_stride = 4, wp4.shape[1] * wp4.shape[2]
     d.w, d.bias = dptr(wp4), dptr(bias, True)
     d.out, d.stats = dptr(out), _stats_ptr(stats, cout)
-    ws = splitk_workspace(out.device)
-    d.splitk_ws, d.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+    _attach_workspace(d, out.device)
     import ctypes as _C
     check(lib.dpmn_conv2d_nhwc_f32(_C.byref(d), stream()))
     return out

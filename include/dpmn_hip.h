@@ -149,6 +149,13 @@ typedef struct {
                               * encoder branches of the CMM (cmm.py:86-99: same shapes, own weights) in one launch; needs an
                               * even B, no stats, and (implicit-GEMM path) B/2*Hp*Wp % 128 == 0 */
   long w_group_stride;
+  unsigned* arrive_cnt;      /* optional: arrive_cnt_len tile-arrival counters, ZERO before the first launch that uses them (the
+                              * library leaves them zero; one array per stream, like splitk_ws).  With them the split-K layers run
+                              * as ONE persistent "stream-K" launch: every workgroup walks an equal share of all (tile, k chunk)
+                              * steps, partial tiles go to splitk_ws and the LAST workgroup to arrive at a tile sums them in a
+                              * fixed order and runs the epilogue -- no reduce kernel, run-to-run bitwise reproducible.
+                              * NULL: the two-launch split-K path */
+  int arrive_cnt_len;
 } dpmn_conv_desc;
 int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream);
 /* layout plumbing at the module boundary: NCHW images <-> NHWC (channels zero-padded to Cpad) */
