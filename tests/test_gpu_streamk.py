@@ -164,11 +164,11 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("blocks", ["", "37", "24", "1000"])
+@pytest.mark.parametrize("blocks", ["", "37", "32", "1000"])
 def test_streamk_every_layer_and_other_workgroup_counts(blocks):
     """DPMN_CONV_SK=2: every qualifying layer (deep encoder convs, 3-segment decoder convs, phase-fused transposed convs, affine
     on load, BatchNorm statistics) through the stream-K launch.  DPMN_SK_BLOCKS: ranges that cut tiles in other places -- dozens
-    of contributors per tile (1000), odd counts without the XCD remap (37), whole tiles only where the count divides (24)."""
+    of contributors per tile (1000), odd counts without the XCD remap (37), whole tiles only where the count divides (32)."""
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, DPMN_CONV_SK="2")
     if blocks:
