@@ -135,6 +135,77 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, i
   }
 }
 
+// ---------------------------------------------------------------------------------- dW += dY^T X, operands straight into registers
+// The same 96 x 96 block tile / 2 x 2 waves of 48 x 48, but NO LDS and NO barrier: both MFMA operands of a reduction over rows are
+// row-major global data already -- lane (lr, kq) of a 4-row step needs dY[m0 + kq][n] for its A values and X[m0 + kq][k] for its B
+// values -- and which 16 columns form an MFMA tile is free.  Tile i of a wave takes the columns {3 lr + i}: a lane's three A
+// values are 12 consecutive bytes of one dY row (one buffer_load_dwordx3, 16 lanes = 192 contiguous bytes), likewise X.  So a
+// step is 2 loads + 9 MFMAs per lane, the loads of the next D steps are in flight (rotating register sets, the compiler's own
+// vmcnt accounting; rows past the block's range and columns past N / K are beyond num_records: the range check returns 0, no
+// branches), and a block's only synchronisation is its end.  Result lane (lr, kq) holds dW[n_w + 3 (4 kq + r) + i][k_w + 3 lr + j].
+// (k_gemm_tn staged 32-row tiles through LDS with predicated loads and fed every MFMA operand with its own ds_read_b32:
+//  34.5 us per launch on average at M = 24576 -- 13 TFLOP/s, 0.55 TB/s -- against ~5-12 us of HBM time.)
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+template <int D>
+__global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
+                                                      int M, int N, int K, int rows_per_block, float* __restrict__ db,
+                                                      float* __restrict__ part) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave & 1, wk = wave >> 1;
+  const int lr = lane & 15, kq = lane >> 4;
+  const int n_w = blockIdx.x * 96 + wn * 48, k_w = blockIdx.y * 96 + wk * 48;
+  const int m_lo = blockIdx.z * rows_per_block;
+  const int nrows = min(M, m_lo + rows_per_block) - m_lo;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy) + (size_t)m_lo * N, 0, nrows * N * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)m_lo * K, 0, nrows * K * 4, 0x00020000);
+  const int offy = n_w + 3 * lr < N ? (kq * N + n_w + 3 * lr) * 4 : (int)0x80000000;
+  const int offx = k_w + 3 * lr < K ? (kq * K + k_w + 3 * lr) * 4 : (int)0x80000000;
+  const int nsteps = (nrows + 3) >> 2;
+  f32x4 acc[3][3], accb[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const bool with_db = db != nullptr && blockIdx.y == 0 && wk == 0;     // wave-uniform
+  f32x3 a[D], b[D];
+  auto load = [&](int d, int step) {       // steps past the range: beyond num_records -> zeros
+    a[d] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(yrs, offy, step * 16 * N, 0));
+    b[d] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(xrs, offx, step * 16 * K, 0));
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) load(d, d);
+  for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(a[d][i], b[d][j], acc[i][j]);
+      if (with_db) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) accb[i] = mfma16(a[d][i], 1.0f, accb[i]);
+      }
+      load(d, s0 + D + d);
+    }
+  }
+  float* pz = part + (size_t)blockIdx.z * ((size_t)N * K + N);
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n_w + 3 * (4 * kq + r) + i;
+      if (n >= N) continue;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int k = k_w + 3 * lr + j;
+        if (k < K) pz[(size_t)n * K + k] = acc[i][j][r];
+      }
+      if (with_db && lr == 0) pz[(size_t)N * K + n] = accb[i][r];
+    }
+}
+
 // dw[e] += sum_z part[z][e] for e < N*K ; db[n] += sum_z part[z][N*K + n].  Block = 64 elements x 4 split groups.
 __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
                                                     int NK, int N, int splits) {
@@ -507,7 +578,7 @@ int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int 
   const int tiles = cdiv(N, 96) * cdiv(K, 96);
   static const int want = getenv("DPMN_TN_BLOCKS") ? atoi(getenv("DPMN_TN_BLOCKS")) : 256;       // experiment knob
   int splits = cdiv(want, tiles);
-  int rows = cdiv(cdiv(M, splits), 32) * 32;
+  int rows = cdiv(cdiv(M, splits), 32) * 32;      // (multiples of 32: the LDS kernel's chunk; of 4: an MFMA step of the register kernel)
   if (rows < 32) rows = 32;
   splits = cdiv(M, rows);
   dim3 grid(cdiv(N, 96), cdiv(K, 96), splits);
@@ -515,7 +586,13 @@ int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int 
   // without one they are accumulated with fp32 atomics
   const size_t need = (size_t)splits * ((size_t)N * K + N) * sizeof(float);
   float* part = (ws && ws_bytes >= need && splits > 1) ? ws : nullptr;
-  hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, as_stream(stream), dy, N, x, K, dw, K, M, N, K, rows, db, part);
+  // operands straight from global memory into the MFMA registers when a wave's 48 columns tile N and K (every Linear of the
+  // PGRM block: 96 / 192 / 384) and the byte offsets fit the buffer instructions
+  static const int reg_on = getenv("DPMN_TN_REG") ? atoi(getenv("DPMN_TN_REG")) : 1;
+  if (reg_on && part && N % 48 == 0 && K % 48 == 0 && (size_t)rows * (N > K ? N : K) * 4 < (1ull << 31))
+    hipLaunchKernelGGL(k_gemm_tn_reg<8>, grid, dim3(256), 0, as_stream(stream), dy, x, dw, M, N, K, rows, db, part);
+  else
+    hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, as_stream(stream), dy, N, x, K, dw, K, M, N, K, rows, db, part);
   DPMN_CHECK_LAUNCH();
   if (part) {
     const int tot = N * K + (db ? N : 0);

@@ -113,6 +113,30 @@ def test_layernorm_backward_ragged_rows_vs_torch(dev, M, accumulate):
     assert_close(db, b.grad, 2e-3, 2e-4, "dbeta")
 
 
+@pytest.mark.parametrize("M,N,K", [(49152, 96, 96), (49152, 384, 96), (24576, 96, 384), (8190, 192, 96), (1001, 144, 48),
+                                   (4099, 96, 32), (777, 32, 96), (515, 16, 96)])
+@pytest.mark.parametrize("with_db", [False, True])
+def test_linear_weight_gradient_vs_torch(dev, M, N, K, with_db):
+    """dpmn_gemm_tn_f32: dW += dY^T X (+ db += column sums), every nn.Linear weight gradient of pgrm.py.  N, K multiples of 48
+    take the operands-in-registers kernel (ragged row counts: the last 4-row step and the last block run past M; 144 = one and
+    a half block tiles), the others the LDS kernel.  Reference: fp64 on the CPU; accumulation into a non-zero dW; two runs equal."""
+    from dpmn_amd.train import pgrm_train
+    dy, x = u("tndy", (M, N)), u("tnx", (M, K))
+    dw0, db0 = u("tndw0", (N, K)), u("tndb0", (N,))
+    ref_w = (dw0.double() + dy.double().t() @ x.double()).float()
+    ref_b = (db0.double() + dy.double().sum(0)).float()
+    outs = []
+    for _ in range(2):
+        dw, db = dw0.clone().to(dev), db0.clone().to(dev)
+        pgrm_train.gemm_tn(dy.to(dev), x.to(dev), dw, db if with_db else None)
+        outs.append((dw, db))
+    tol = 2e-6 * M ** 0.5 + 1e-5             # fp32 sums of M products of magnitude <= 1
+    assert_close(outs[0][0], ref_w, tol, 1e-5, "dW %s" % ((M, N, K),))
+    if with_db:
+        assert_close(outs[0][1], ref_b, tol, 1e-5, "db")
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_dropout_kernel_masks_equal_oracle_hash(dev):
     """dpmn_dropout_f32 (elementwise + per-sample DropPath + residual) vs the numpy restatement of the mask hash: the kept set
     is bit-identical, values equal to fp32 round-off of the single multiply."""
