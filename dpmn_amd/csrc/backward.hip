@@ -161,14 +161,15 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ d
   const int offy = n_w + 3 * lr < N ? (kq * N + n_w + 3 * lr) * 4 : (int)0x80000000;
   const int offx = k_w + 3 * lr < K ? (kq * K + k_w + 3 * lr) * 4 : (int)0x80000000;
   const int nsteps = (nrows + 3) >> 2;
-  f32x4 acc[3][3], accb[3];
+  f32x4 acc[3][3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  }
+  // bias gradient db[n] = sum_m dY[m][n]: the lane already holds the dY values of its rows -- three vector adds per step and
+  // one cross-kq shuffle at the end (as dY^T . 1 on the matrix pipe it cost 3 more MFMAs per step on half the waves: +35 %)
   const bool with_db = db != nullptr && blockIdx.y == 0 && wk == 0;     // wave-uniform
+  f32x3 sb = (f32x3){0.f, 0.f, 0.f};
   f32x3 a[D], b[D];
   auto load = [&](int d, int step) {       // steps past the range: beyond num_records -> zeros
     a[d] = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(yrs, offy, step * 16 * N, 0));
@@ -183,27 +184,32 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ d
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = mfma16(a[d][i], b[d][j], acc[i][j]);
-      if (with_db) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) accb[i] = mfma16(a[d][i], 1.0f, accb[i]);
-      }
+      if (with_db) sb += a[d];
       load(d, s0 + D + d);
     }
   }
   float* pz = part + (size_t)blockIdx.z * ((size_t)N * K + N);
+  typedef int i32x3_ __attribute__((ext_vector_type(3)));
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pz, 0, N * K * 4, 0x00020000);
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n = n_w + 3 * (4 * kq + r) + i;
-      if (n >= N) continue;
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int k = k_w + 3 * lr + j;
-        if (k < K) pz[(size_t)n * K + k] = acc[i][j][r];
-      }
-      if (with_db && lr == 0) pz[(size_t)N * K + n] = accb[i][r];
+      // the lane's three k are consecutive: one 12-byte store, 16 lanes = 192 contiguous bytes of row n (K % 48 == 0: all or none)
+      const int off = (n < N && k_w + 3 * lr < K) ? (n * K + k_w + 3 * lr) * 4 : (int)0x80000000;
+      __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(i32x3_, (f32x3){acc[i][0][r], acc[i][1][r], acc[i][2][r]}), prs, off, 0, 0);
     }
+  if (with_db) {       // lane (lr, kq) summed the rows = kq (mod 4) of columns n_w + 3 lr + i
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      float v = sb[i];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int n = n_w + 3 * lr + i;
+      if (kq == 0 && n < N) pz[(size_t)N * K + n] = v;
+    }
+  }
 }
 
 // dw[e] += sum_z part[z][e] for e < N*K ; db[n] += sum_z part[z][N*K + n].  Block = 64 elements x 4 split groups.
