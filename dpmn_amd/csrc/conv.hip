@@ -149,8 +149,15 @@ __device__ __forceinline__ float vmax_raw(float x, float y) {
 // part of the address in the buffer load's scalar offset, and the store to LDS needs no validity mask (act(0) = 0).
 // BF (with SIMPLE): the operands are rounded to bf16 on the way into LDS (80-byte rows: conflict-free ds_read_b128) and one
 // v_mfma_f32_16x16x32_bf16 per tile pair replaces the eight fp32 MFMAs of a 32-deep chunk; accumulation and epilogue stay fp32.
-template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false>
+// M32 (with SIMPLE, fp32, 64 x 64 wave tiles): v_mfma_f32_32x32x2_f32 instead of 16x16x4 -- the same FLOPs per cycle and the same
+// LDS words per FLOP (a ds_read_b128 still feeds 4 MFMAs: lane (l & 31, l >> 5) holds k = 4 (l >> 5) + s of an 8-deep step), but
+// half the MFMA instructions, each with a 64-cycle shadow: the per-chunk vector work (prologue activation, LDS staging) costs
+// less matrix time (profiles/r03e_ubench_mfma_valu.txt).  D layout: register v of lane l = out[co = 8 (v / 4) + 4 (l >> 5) +
+// v % 4][pixel = l & 31] -- again 4 consecutive output channels per lane and register quad.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false, bool M32 = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  static_assert(!M32 || (SIMPLE && !BF && BKT == 32 && BM / WM == 64 && BN / WN == 64), "the 32x32x2 variant: fp32 SIMPLE path, 64 x 64 wave tiles");
   static_assert(!BF || (SIMPLE && BKT == 32), "the bf16 variant exists for the SIMPLE path with 32-deep chunks");
   static_assert(!SIMPLE || UNI, "SIMPLE is a refinement of the UNI path");
   static_assert(!AFF || SIMPLE, "AFF is a variant of the SIMPLE path");
@@ -474,6 +481,16 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   for (int i = 0; i < NT; ++i)
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x16 acc32[2][2];
+  if constexpr (M32) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc32[i][j][v] = 0.f;
+  }
+  const int l31 = lane & 31, lh = lane >> 5;
 
   const int nk_all = a.Kp / BK;
   const int cps = (nk_all + a.ksplit - 1) / a.ksplit;          // chunks per split
@@ -507,6 +524,23 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
       for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = mfma16_bf16(wf[i], xf[j], acc[i][j]);
+    } else if constexpr (M32) {
+      const float* xa = reinterpret_cast<const float*>(&Xs[buf][0]) + (wm * 64 + l31) * LDK + lh * 4;
+      const float* wa = reinterpret_cast<const float*>(&Ws[buf][0]) + (wn * 64 + l31) * LDK + lh * 4;
+#pragma unroll
+      for (int kc = 0; kc < BK; kc += 8) {
+        f32x4 xf[2], wf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xa + j * 32 * LDK + kc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 32 * LDK + kc);
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[i][s_], xf[j][s_], acc32[i][j], 0, 0, 0);
+      }
     } else {
     const float* xa = reinterpret_cast<const float*>(&Xs[buf][0]) + (wm * (MT * 16) + lr) * LDK + kq * 4;
     const float* wa = reinterpret_cast<const float*>(&Ws[buf][0]) + (wn * (NT * 16) + lr) * LDK + kq * 4;
@@ -532,6 +566,51 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
     if (!(ABL & 4)) __syncthreads();
   }
 
+  if constexpr (M32) {
+    // lane holds out[pixel m = .. + j * 32 + (l & 31)][co = .. + i * 32 + 8 g + 4 (l >> 5) + r], r = register 4 g + r of tile (i, j)
+    float ssum[8][4], ssq[8][4];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ssum[q][r] = 0.f; ssq[q][r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m_blk + wm * 64 + j * 32 + l31;
+      if (m >= M) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n = n_blk + wn * 64 + i * 32 + g * 8 + lh * 4;
+          if (a.ksplit > 1) {
+            if (n < a.npad)
+              *reinterpret_cast<float4*>(ph.partial + ((size_t)zsplit * M + m) * a.npad + n) =
+                  make_float4(acc32[i][j][4 * g], acc32[i][j][4 * g + 1], acc32[i][j][4 * g + 2], acc32[i][j][4 * g + 3]);
+          } else if (n < a.Cout) {
+            float v[4] = {acc32[i][j][4 * g], acc32[i][j][4 * g + 1], acc32[i][j][4 * g + 2], acc32[i][j][4 * g + 3]};
+            conv_store(a, m, n, v, ssum[i * 4 + g], ssq[i * 4 + g], ph.ooy, ph.oox);
+          }
+        }
+    }
+    if (a.stats && a.ksplit <= 1) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int n = n_blk + wn * 64 + (q >> 2) * 32 + (q & 3) * 8 + lh * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float s_ = ssum[q][r], q_ = ssq[q][r];
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) { s_ += __shfl_xor(s_, o, 64); q_ += __shfl_xor(q_, o, 64); }
+          if (l31 == 0 && n + r < a.Cout) {
+            double* st = reinterpret_cast<double*>(a.stats) + (size_t)(bx % STAT_SLOTS) * 2 * a.Cout;
+            atomicAdd(st + n + r, (double)(s_));
+            atomicAdd(st + a.Cout + n + r, (double)(q_));
+          }
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue: lane holds out[pixel m = .. + (l&15)][co = .. + (l>>4)*4 + r]
   if (a.ksplit > 1) {
 #pragma unroll
@@ -1569,6 +1648,7 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     ProfScope prof(BN == 128 ? PT_CONV_IGEMM_128 : (BN == 64 ? PT_CONV_IGEMM_64 : PT_CONV_IGEMM_NARROW), st, conv_flops(a), conv_bytes(a));
     static const int bk16 = getenv("DPMN_CONV_BK16") ? atoi(getenv("DPMN_CONV_BK16")) : 0;
     static const int simple_on = getenv("DPMN_CONV_SIMPLE") ? atoi(getenv("DPMN_CONV_SIMPLE")) : 1;
+    static const int m32_on = getenv("DPMN_CONV_M32") ? atoi(getenv("DPMN_CONV_M32")) : 0;      // 32x32x2 MFMAs on the 128 x 128 tile
     bool simple = simple_on && uni && a.KH * a.KW <= 31 && (a.pro_act == ACT_NONE || a.pro_act == ACT_RELU || a.pro_act == ACT_LEAKY02);
     int n_seg = 0, n_aff = 0;
     for (int i = 0; i < 3; ++i) {    // + the shift of the buffer base must keep the byte range below 2^31
@@ -1582,6 +1662,12 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, false, true>), grid, dim3(256), 0, st, a);
   } else
   if (uni && BM == 128 && BN == 128 && bk16) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 16>), grid, dim3(256), 0, st, a);
+  else if (simple && m32_on && BM / WM == 64 && BN / WN == 64) {
+    if constexpr (BM / WM == 64 && BN / WN == 64) {
+      if (n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true, false, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, false, false, true>), grid, dim3(256), 0, st, a);
+    }
+  }
   else if (simple && n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true>), grid, dim3(256), 0, st, a);
   else if (simple) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true>), grid, dim3(256), 0, st, a);
   else if (uni) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
