@@ -50,6 +50,16 @@ class ConvDesc(C.Structure):
         ("groups", C.c_int), ("w_group_stride", C.c_long), ("arrive_cnt", fp), ("arrive_cnt_len", C.c_int)]
 
 
+class CmmWeights(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("c_img", "cnum", "img_h", "img_w")] + [("en_w", fp * 10), ("en_b", fp * 10)] + [
+        (n, fp) for n in ("fc1_w", "fc1_b", "fc2_w", "fc2_b", "de6_w", "de6_b")] + [
+        ("dea_w", fp * 4), ("dea_b", fp * 4), ("deb_w", fp * 4), ("deb_b", fp * 4), ("de1_w", fp), ("de1_b", fp)]
+
+
+class CmmScratch(C.Structure):
+    _fields_ = [("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t), ("arrive_cnt", fp), ("arrive_cnt_len", C.c_int)]
+
+
 _i, _f, _sz, _l, _u64 = C.c_int, C.c_float, C.c_size_t, C.c_long, C.c_ulonglong
 _PP = C.POINTER(fp)
 _IP = C.POINTER(C.c_int)
@@ -153,6 +163,8 @@ SIGNATURES = {
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_gelu_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_f32": (_i, [fp, fp, fp, fp, fp, _PP, _PP, _i, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "dpmn_cmm_workspace_bytes": (_sz, [C.POINTER(CmmWeights), _i]),
+    "dpmn_cmm_forward_f32": (_i, [C.POINTER(CmmWeights), fp, fp, fp, fp, _sz, C.POINTER(CmmScratch), _i, fp]),
     "dpmn_pgrm_workspace_bytes": (_sz, [C.POINTER(PgrmWeights), _i]),
     "dpmn_pgrm_forward_f32": (_i, [C.POINTER(PgrmWeights), fp, _i, fp, _PP, _i, fp, fp, _sz, _i, fp]),
 }

@@ -1774,6 +1774,23 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
     if (a.KH == 3) return a.Cout <= 16 ? launch_halo<3, 16>(a, st) : launch_halo<3, 64>(a, st);
     return a.Cout <= 16 ? launch_halo<9, 16>(a, st) : launch_halo<9, 64>(a, st);
   }
+  // groups = 2 on the implicit-GEMM tiles needs the pixels of one half to fill whole row tiles; otherwise one launch per half
+  auto split_groups = [&]() -> int {
+    DPMN_REQUIRE(!a.out_nchw && !a.pixel_shuffle && !a.res, "conv2d: groups = 2 with partial row tiles needs a plain NHWC output");
+    for (int g = 0; g < 2; ++g) {
+      dpmn_conv_desc h = *d;
+      h.B = d->B / 2; h.groups = 1;
+      for (int s = 0; s < 3; ++s)
+        if (h.in[s]) h.in[s] += (size_t)g * h.B * d->Hin * d->Win * d->cseg[s];
+      h.w += (size_t)g * d->w_group_stride;
+      if (h.bias) h.bias += (size_t)g * d->Cout;
+      h.out += (size_t)g * h.B * d->Hout * d->Wout * a.out_ld;
+      const int e = dpmn_conv2d_nhwc_f32(&h, stream);
+      if (e != DPMN_OK) return e;
+    }
+    return DPMN_OK;
+  };
+  if (a.groups == 2 && !(a.Cout >= 128 && M >= 128) && a.m_per_group % (a.Cout <= 32 ? 128 : 64) != 0) return split_groups();
   if (a.Cout <= 16) return launch_conv<128, 16, 4, 1>(a, ws, wsb, st);
   if (a.Cout <= 32) return launch_conv<128, 32, 4, 1>(a, ws, wsb, st);
   // 128x128 tiles halve the L2->LDS bytes per FLOP of the 64x64 tile (which is L2-bound); small-M convs regain
@@ -1793,21 +1810,7 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
     const int r = rows64 ? launch_conv_sk<64, 128, 1, 4>(a, ws, wsb, d->arrive_cnt, d->arrive_cnt_len, st)
                          : (sk_mode >= 2 ? launch_conv_sk<128, 128, 2, 2>(a, ws, wsb, d->arrive_cnt, d->arrive_cnt_len, st) : -1);
     if (r >= 0) return r;
-    if (a.groups == 2 && mg % 128 != 0 && !a.out_nchw && !a.pixel_shuffle && !a.res) {
-      // the fixed-split path needs whole 128-pixel row tiles per half: one launch per half instead
-      for (int g = 0; g < 2; ++g) {
-        dpmn_conv_desc h = *d;
-        h.B = d->B / 2; h.groups = 1;
-        for (int s = 0; s < 3; ++s)
-          if (h.in[s]) h.in[s] += (size_t)g * h.B * d->Hin * d->Win * d->cseg[s];
-        h.w += (size_t)g * d->w_group_stride;
-        if (h.bias) h.bias += (size_t)g * d->Cout;
-        h.out += (size_t)g * h.B * d->Hout * d->Wout * a.out_ld;
-        const int e = dpmn_conv2d_nhwc_f32(&h, stream);
-        if (e != DPMN_OK) return e;
-      }
-      return DPMN_OK;
-    }
+    if (a.groups == 2 && mg % 128 != 0) return split_groups();
     return launch_conv<128, 128, 2, 2>(a, ws, wsb, st);
   }
   return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);

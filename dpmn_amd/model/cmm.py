@@ -6,6 +6,8 @@ NHWC implicit-GEMM kernel in libdpmn_hip.so (csrc/conv.hip) and the channel gate
 csrc/cmm.hip.  Activations stay NHWC between kernels; only the module boundary is NCHW.
 Eval-mode BatchNorm is folded into the producing conv at pack time (quirk Q12).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -23,6 +25,9 @@ def _decode_block(cin, cout):
     # cmm.py:58-77: [act, convT3x3, bn, act, convT4x4 s2, bn]
     return nn.Sequential(nn.Identity(), nn.ConvTranspose2d(cin, cout, 3, 1, padding=1), nn.BatchNorm2d(cout),
                          nn.Identity(), nn.ConvTranspose2d(cout, cout, 4, 2, padding=1), nn.BatchNorm2d(cout))
+
+
+NATIVE_FORWARD = os.environ.get("DPMN_CMM_NATIVE", "1") != "0"      # eval forward through dpmn_cmm_forward_f32 (one native call)
 
 
 class _Holder(nn.Module):
@@ -91,6 +96,29 @@ class ComplementationModulationModule(nn.Module):
         self._pack = (key, P)
         return P
 
+    def _native(self, P, H, W):
+        """dpmn_cmm_weights over the packed eval weights (include/dpmn_hip.h), rebuilt when the pack is."""
+        from .. import _abi
+        nat = getattr(self, "_nat", None)
+        if nat is not None and nat[0] is P and nat[1] == (H, W):
+            return nat[2], nat[3]
+        w = _abi.CmmWeights()
+        w.c_img, w.cnum, w.img_h, w.img_w = self.c_img, self.cnum, H, W
+        names = ["en_1"] + ["en_%d.%s" % (lvl, ab) for lvl in (2, 3, 4, 5) for ab in "ab"] + ["en_6"]
+        keep = [self.fc_1.weight, self.fc_1.bias, self.fc_2.weight, self.fc_2.bias]
+        for i, n in enumerate(names):
+            w.en_w[i], w.en_b[i] = P[n][0].data_ptr(), P[n][1].data_ptr()
+        w.fc1_w, w.fc1_b, w.fc2_w, w.fc2_b = (t.data_ptr() for t in keep)
+        w.de6_w, w.de6_b = P["de_6"][0].data_ptr(), P["de_6"][1].data_ptr()
+        for j, lvl in enumerate((5, 4, 3, 2)):
+            w.dea_w[j], w.dea_b[j] = P["de_%d.a" % lvl][0].data_ptr(), P["de_%d.a" % lvl][1].data_ptr()
+            w.deb_w[j], w.deb_b[j] = P["de_%d.b" % lvl][0].data_ptr(), P["de_%d.b" % lvl][1].data_ptr()
+        w.de1_w, w.de1_b = P["de_1"][0].data_ptr(), P["de_1"][1].data_ptr()
+        self._nat = (P, (H, W), w, keep)
+        if not hasattr(self, "_native_ws"):
+            self._native_ws = {}
+        return w, keep
+
     def forward(self, x1, x2):
         if self.training:
             from ..train import cmm_train       # train-mode BatchNorm (batch statistics) + explicit HIP backward
@@ -103,6 +131,8 @@ class ComplementationModulationModule(nn.Module):
         P = self._packed()
         c = self.cnum
         Bn = x1.shape[0]
+        if NATIVE_FORWARD and x1.shape[2] % 32 == 0 and x1.shape[3] % 32 == 0 and c % 8 == 0:
+            return ops.cmm_forward(*self._native(P, x1.shape[2], x1.shape[3]), x1, x2, self.c_img, self._native_ws)
         xin = torch.cat([ops.nchw_to_nhwc(x1.contiguous().float(), 4), ops.nchw_to_nhwc(x2.contiguous().float(), 4)], 0)
         o = [ops.conv2d([xin], *P["en_1"], c, 3, pad=1, groups=2)]
         chans = {2: (c, 2 * c), 3: (2 * c, 4 * c), 4: (4 * c, 8 * c), 5: (8 * c, 8 * c)}

@@ -223,6 +223,23 @@ def _attach_workspace(d, device):
     d.arrive_cnt, d.arrive_cnt_len = _ARRIVE_CNT[key].data_ptr(), ARRIVE_CNT_LEN
 
 
+def cmm_forward(weights, keep, x1, x2, c_img, workspaces):
+    """ComplementationModulationModule.forward in eval mode as ONE native call (csrc/cmm_forward.hip).  weights: a filled
+    _abi.CmmWeights (keep = the tensors it points to); workspaces: dict B -> activation workspace, owned by the module."""
+    import ctypes as _C
+    B, _, H, W = x1.shape
+    x1, x2 = x1.contiguous().float(), x2.contiguous().float()
+    if B not in workspaces:
+        workspaces[B] = torch.empty(lib.dpmn_cmm_workspace_bytes(_C.byref(weights), B) // 4, device=x1.device)
+    ws = workspaces[B]
+    d = _abi.ConvDesc()
+    _attach_workspace(d, x1.device)
+    sc = _abi.CmmScratch(d.splitk_ws, d.splitk_ws_bytes, d.arrive_cnt, d.arrive_cnt_len)
+    out = torch.empty(B, c_img, H, W, device=x1.device)
+    check(lib.dpmn_cmm_forward_f32(_C.byref(weights), dptr(x1), dptr(x2), dptr(out), dptr(ws), ws.numel() * 4, _C.byref(sc), B, stream()))
+    return out
+
+
 def nchw_to_nhwc(x, cpad=None):
     B, Cc, H, W = x.shape
     cpad = cpad or Cc

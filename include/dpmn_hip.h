@@ -478,6 +478,33 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
                           const float* const* residuals, int n_residuals, float* out, void* workspace,
                           size_t workspace_bytes, int B, dpmn_stream_t stream);
 
+/* ------------------------------------------------------------------ native CMM forward (cmm_forward.hip) */
+/* ComplementationModulationModule.forward(x1, x2) in eval mode (cmm.py:120-161) as ONE call: 2 layout kernels, 10 grouped
+ * encoder convs (the twin branches of cmm.py:86-99 share a launch), the channel gate, 5 phase-fused transposed convs and
+ * 5 three-segment decoder convs.  All weights are the PACKED forms of dpmn_amd/model/packing.py with the eval BatchNorm folded:
+ * encoder entries are (2, Cout, Kp) / (2, Cout) stacks of the two branches in the order en_1, en_2.a, en_2.b, ..., en_5.b, en_6;
+ * transposed 4x4 convs are (4, Cout, Kp) phase-major packs; dea / deb entries are de_5 .. de_2. */
+typedef struct {
+  int c_img, cnum, img_h, img_w;
+  const float *en_w[10], *en_b[10];
+  const float *fc1_w, *fc1_b, *fc2_w, *fc2_b;     /* nn.Linear layouts of fc_1 / fc_2 (cmm.py:97-98) */
+  const float *de6_w, *de6_b;
+  const float *dea_w[4], *dea_b[4];
+  const float *deb_w[4], *deb_b[4];
+  const float *de1_w, *de1_b;
+} dpmn_cmm_weights;
+typedef struct {            /* the per-stream conv scratch of dpmn_conv_desc (split-K partial sums, stream-K arrival counters) */
+  float* splitk_ws;
+  size_t splitk_ws_bytes;
+  unsigned* arrive_cnt;
+  int arrive_cnt_len;
+} dpmn_cmm_scratch;
+size_t dpmn_cmm_workspace_bytes(const dpmn_cmm_weights* w, int B);
+/* x1, x2 (B, c_img, H, W) NCHW; out (B, c_img, H, W) NCHW; workspace >= dpmn_cmm_workspace_bytes (activations; contents are
+ * scratch).  H, W multiples of 32. */
+int dpmn_cmm_forward_f32(const dpmn_cmm_weights* w, const float* x1, const float* x2, float* out, void* workspace,
+                         size_t workspace_bytes, const dpmn_cmm_scratch* scratch, int B, dpmn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

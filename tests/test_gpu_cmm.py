@@ -166,6 +166,32 @@ def test_cmm_module_vs_reference_golden(dev, cnum):
     assert_close(out, t(g["out_eval"]), 2e-4, 2e-4, "CMM eval vs reference golden cnum=%d" % cnum)
 
 
+@pytest.mark.parametrize("cnum,B,H,W", [(8, 2, 32, 128), (64, 3, 32, 128), (64, 48, 32, 128), (16, 2, 64, 256)])
+def test_cmm_native_driver_equals_composed_ops(dev, cnum, B, H, W):
+    """dpmn_cmm_forward_f32 (one native call per CMM forward, csrc/cmm_forward.hip) issues the launches of the per-op host path
+    (model/cmm.py) with the same arguments: bitwise-equal outputs, also on the second call (cached weights struct / workspace) and
+    after the eval pack was rebuilt; 64x256 = the stress configuration's map."""
+    from dpmn_amd.model import cmm as cmm_mod
+    m = cmm_mod.ComplementationModulationModule(cnum=cnum).eval()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 35)
+    m.load_state_dict(sd)
+    m = m.to(dev)
+    x1, x2 = u("nx1", (B, 3, H, W), 0, 1).to(dev), u("nx2", (B, 3, H, W), 0, 1).to(dev)
+    assert cmm_mod.NATIVE_FORWARD
+    with torch.no_grad():
+        nat = m(x1, x2)
+        nat2 = m(x1, x2)
+        cmm_mod.NATIVE_FORWARD = False
+        try:
+            ref = m(x1, x2)
+        finally:
+            cmm_mod.NATIVE_FORWARD = True
+        m._pack = None
+        nat3 = m(x1, x2)
+    assert torch.equal(nat, ref) and torch.equal(nat2, ref) and torch.equal(nat3, ref)
+
+
 def test_cmm_module_batch48_vs_oracle(dev):
     from dpmn_amd.model.cmm import ComplementationModulationModule
     from oracle import cmm as ocmm
