@@ -29,6 +29,7 @@ struct WgArgs {
   long slot_stride;
   int excl;             // packed destination with one slot PER split: plain stores, no atomics, slots need no zero-init
   float inv_hw, inv_w;
+  int lgW, lgHW;        // P2 kernels: log2(Wp), log2(Hp * Wp)
 };
 
 // exact m / d for 0 <= m < 2^24 through one float multiply and a +-1 fix-up
@@ -44,7 +45,12 @@ __device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r)
 // tiles.  The contraction index of the 16x16x4 MFMA is the pixel; each lane's co / k indices are interleaved
 // (co = 4*i + ti, k = NJ*j + tj) so that ONE ds_read_b128 along the channel axis feeds 4 MFMA tiles.  The 4 waves split
 // the k columns, every wave holds all BN_ rows: no cross-wave reduction, one atomic per tile element per block.
-template <int BN_, int BKT>
+// P2: Hp and Wp are powers of two (every conv of the CMM / PSN trunks) and the input transform is none / ReLU / LeakyReLU(0.2):
+// the pixel decode is two shifts and two masks instead of reciprocal divisions and wrap loops, dY comes through raw buffer loads
+// (rows past the block's range / channels past Cout: offset bit 31 -> the range check returns 0, no masks), the activation is one
+// v_max per element instead of a switch.  The generic path spent several hundred vector instructions and ~40 branches per
+// 128-MFMA chunk on that -- paid in matrix time ("What bounds these fp32 kernels").
+template <int BN_, int BKT, bool P2 = false>
 __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
   constexpr int BMc = 32, NI = BN_ / 16, NJ = BKT / 64, LDY = BN_ + 4, LDX = BKT + 4;
   constexpr int YC4 = BN_ / 4, XC4 = BKT / 4;             // float4 columns
@@ -94,7 +100,33 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
   const int cs_v = kvalid ? cs : a.cseg[0], cl_v = kvalid ? cl : 0;
   const int yn_v = yn < a.Cout ? yn : 0;
   unsigned ymask = 0;
+  const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.B * a.Hout * a.Wout * a.Cout * 4, 0x00020000);
+  const int wmask = a.Wp - 1, hmask = a.Hp - 1;
   auto gload = [&](int m0) {
+    if constexpr (P2) {
+#pragma unroll
+      for (int p = 0; p < YP; ++p) {
+        const int row = yrow0 + p * YRS, m = m0 + row;
+        const int px = m & wmask, py = (m >> a.lgW) & hmask, b = m >> a.lgHW;
+        const bool ok = (YP * YRS == BMc || row < BMc) && m < m_hi && yn < a.Cout;
+        const int pix = __mul24(__mul24(b, a.Hout) + py * a.ostep + a.ooy, a.Wout) + px * a.ostep + a.oox;
+        const unsigned off = ok ? (unsigned)(__mul24(pix, a.Cout) + yn) * 4u : 0x80000000u;
+        yr[p] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(yrs, (int)off, 0, 0));
+      }
+      xmask = 0;
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        const int m = m0 + xrow0 + p * XRS;
+        const int px = m & wmask, py = (m >> a.lgW) & hmask, b = m >> a.lgHW;
+        const int iy = py * a.stride + iy_off, ix = px * a.stride + ix_off;
+        const bool ok = kvalid && m < m_hi && (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+        const int pix = __mul24(__mul24(b, a.Hin) + iy, a.Win) + ix;
+        const int off = ok ? __mul24(pix, cs_v) + cl_v : 0;
+        xr[p] = *reinterpret_cast<const float4*>(src_v + off);
+        xmask |= (ok ? 1u : 0u) << p;
+      }
+      return;
+    }
     {
       int b, rr, py, px;
       fdivmod(min(m0 + yrow0, M - 1), HW, a.inv_hw, b, rr);
@@ -131,6 +163,25 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
     }
   };
   auto sstore = [&]() {
+    if constexpr (P2) {
+#pragma unroll
+      for (int p = 0; p < YP; ++p) {
+        const int row = yrow0 + p * YRS;
+        if (YP * YRS == BMc || row < BMc) *reinterpret_cast<float4*>(&Ys[row * LDY + yc]) = yr[p];
+      }
+      const float sl = a.pro_act == ACT_LEAKY02 ? 0.2f : 0.0f;
+#pragma unroll
+      for (int p = 0; p < XP; ++p) {
+        float4 xv = xr[p];
+        if (aff) { xv.x = xv.x * s4.x + h4.x; xv.y = xv.y * s4.y + h4.y; xv.z = xv.z * s4.z + h4.z; xv.w = xv.w * s4.w + h4.w; }
+        if (a.pro_act != ACT_NONE) {
+          xv.x = fmaxf(xv.x, sl * xv.x); xv.y = fmaxf(xv.y, sl * xv.y); xv.z = fmaxf(xv.z, sl * xv.z); xv.w = fmaxf(xv.w, sl * xv.w);
+        }
+        if (!((xmask >> p) & 1u)) xv = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&Xs[(xrow0 + p * XRS) * LDX + xc]) = xv;
+      }
+      return;
+    }
 #pragma unroll
     for (int p = 0; p < YP; ++p) {
       const int row = yrow0 + p * YRS;
@@ -705,6 +756,19 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
   }
   a.pix_per_block = ppb; a.gz = splits;
   const dim3 grid((unsigned)(tiles * splits));
+  static const int p2_on = getenv("DPMN_WG_P2") ? atoi(getenv("DPMN_WG_P2")) : 1;
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  bool p2 = p2_on && pow2(a.Hp) && pow2(a.Wp) && (a.pro_act == ACT_NONE || a.pro_act == ACT_RELU || a.pro_act == ACT_LEAKY02) &&
+            (size_t)a.B * a.Hout * a.Wout * a.Cout * 4 < (1ull << 31);
+  for (int s = 0; s < 3; ++s) p2 = p2 && (size_t)a.B * a.Hin * a.Win * (a.cseg[s] > 0 ? a.cseg[s] : 1) * 4 < (1ull << 31);
+  if (p2) {
+    for (a.lgW = 0; (1 << a.lgW) < a.Wp; ++a.lgW) {}
+    for (a.lgHW = 0; (1 << a.lgHW) < a.Hp * a.Wp; ++a.lgHW) {}
+    if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256, true>), grid, dim3(256), 0, as_stream(stream), a);
+    else if (bn == 64 && bk == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128, true>), grid, dim3(256), 0, as_stream(stream), a);
+    else if (bn == 64) hipLaunchKernelGGL((k_conv_wgrad<64, 256, true>), grid, dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((k_conv_wgrad<128, 128, true>), grid, dim3(256), 0, as_stream(stream), a);
+  } else
   if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256>), grid, dim3(256), 0, as_stream(stream), a);
   else if (bn == 64 && bk == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128>), grid, dim3(256), 0, as_stream(stream), a);
   else if (bn == 64) hipLaunchKernelGGL((k_conv_wgrad<64, 256>), grid, dim3(256), 0, as_stream(stream), a);
