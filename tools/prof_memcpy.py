@@ -18,6 +18,13 @@ for m in models + distill:
         p.requires_grad = True
 trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25)
 step = lambda: sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
+if len(sys.argv) > 1 and sys.argv[1] == "fwd":        # the eval forward instead of the training step
+    for m in models:
+        m.eval()
+    _fwd = lambda: sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
+    def step():
+        with torch.no_grad():
+            return _fwd()
 for _ in range(3):
     step()
 torch.cuda.synchronize()
