@@ -123,3 +123,18 @@ def gemm_tn_case(N, K):
 
 for N_, K_ in ((96, 96), (192, 96), (384, 96), (96, 384)):
     gemm_tn_case(N_, K_)
+
+
+# ---- k-loop GEMM users: fc2 (K = 384 -> 96, + residual) and the pointwise-conv weight gradient (384 x 384 outputs, K = B * L)
+def kloop_cases():
+    from dpmn_amd._abi import lib, check, dptr, stream
+    Ch = 384
+    y = u("kl_y", (M, Ch)); w2 = u("kl_w2", (C, Ch), -0.1, 0.1); b2 = u("kl_b2", (C,)); res = u("kl_r", (M, C))
+    timeit("kloop fc2 K=384 N=96 +res", lambda: ops.linear(y, w2, b2, res1=res), 2.0 * M * C * Ch, 4.0 * M * (Ch + 2 * C))
+    dz = u("kl_dz", (B, Ch, L)); g = u("kl_g", (B, Ch, L)); dw = torch.zeros(Ch, Ch, device=dev)
+    timeit("kloop pointwise wgrad 384x384 K=49152", lambda: check(lib.dpmn_pointwise_wgrad_f32(dptr(dz), dptr(g), dptr(dw), B, Ch, L, stream())),
+           2.0 * Ch * Ch * B * L, 8.0 * B * Ch * L)
+
+
+if not flt or "kloop" in flt:
+    kloop_cases()
