@@ -98,9 +98,12 @@ int dpmn_cmm_forward_f32(const dpmn_cmm_weights* w, const float* x1, const float
   // en_2 .. en_5: EncodeBlock = LeakyReLU, Conv2d(cin, cin, 4, 2, dilation 2, padding 3), BN, LeakyReLU, Conv2d(cin, cout, 3, 1, 1), BN (cmm.py:38-55)
   for (int i = 1; i <= 4; ++i) {
     const int ci = l[i - 1].C, co = l[i].C;
-    RUN(grouped(conv_desc(s.enc[i - 1], ci, nullptr, 0, nullptr, 0, B2, l[i - 1].H, l[i - 1].W, 4, 2, 3, 2, DPMN_ACT_LEAKY02, w->en_w[2 * i - 1],
-                          w->en_b[2 * i - 1], ci, s.tmp, sc), (long)ci * kp(4, ci)));
-    RUN(grouped(conv_desc(s.tmp, ci, nullptr, 0, nullptr, 0, B2, l[i].H, l[i].W, 3, 1, 1, 1, DPMN_ACT_LEAKY02, w->en_w[2 * i], w->en_b[2 * i], co,
+    // the block's inner LeakyReLU runs in the first conv's epilogue (once per element) instead of on load in the second
+    dpmn_conv_desc da = conv_desc(s.enc[i - 1], ci, nullptr, 0, nullptr, 0, B2, l[i - 1].H, l[i - 1].W, 4, 2, 3, 2, DPMN_ACT_LEAKY02,
+                                  w->en_w[2 * i - 1], w->en_b[2 * i - 1], ci, s.tmp, sc);
+    da.epi_act = DPMN_ACT_LEAKY02;
+    RUN(grouped(da, (long)ci * kp(4, ci)));
+    RUN(grouped(conv_desc(s.tmp, ci, nullptr, 0, nullptr, 0, B2, l[i].H, l[i].W, 3, 1, 1, 1, DPMN_ACT_NONE, w->en_w[2 * i], w->en_b[2 * i], co,
                           s.enc[i], sc), (long)co * kp(3, ci)));
   }
   // en_6: LeakyReLU, Conv2d(8c, 8c, 4, 2, 1) (cmm.py:91-92)
@@ -117,13 +120,13 @@ int dpmn_cmm_forward_f32(const dpmn_cmm_weights* w, const float* x1, const float
   float* gated = s.bott + (size_t)B * P * 16 * c;
   RUN(dpmn_se_gate_f32(s.bott, w->fc1_w, w->fc1_b, w->fc2_w, w->fc2_b, gated, s.hid, B, P, 16 * c, 4 * c, stream));   // cmm.py:136-147
   // de_6: ReLU, ConvTranspose2d(16c, 8c, 4, 2, 1), BN (cmm.py:100-102) -- the 4 output phases in one launch
-  auto convT = [&](const float* in, int cin, int H, int W, const float* wp, const float* bias, int cout, float* o) {
-    dpmn_conv_desc d = conv_desc(in, cin, nullptr, 0, nullptr, 0, B, H, W, 2, 1, 0, -1, DPMN_ACT_RELU, wp, bias, cout, o, sc);
+  auto convT = [&](const float* in, int cin, int H, int W, const float* wp, const float* bias, int cout, float* o, int pro_act) {
+    dpmn_conv_desc d = conv_desc(in, cin, nullptr, 0, nullptr, 0, B, H, W, 2, 1, 0, -1, pro_act, wp, bias, cout, o, sc);
     d.Hp = H; d.Wp = W; d.Hout = 2 * H; d.Wout = 2 * W; d.ostep = 2;
     d.nphase = 4; d.w_phase_stride = (long)cout * kp(2, cin);
     return dpmn_conv2d_nhwc_f32(&d, stream);
   };
-  RUN(convT(gated, 16 * c, l[5].H, l[5].W, w->de6_w, w->de6_b, 8 * c, s.dec));
+  RUN(convT(gated, 16 * c, l[5].H, l[5].W, w->de6_w, w->de6_b, 8 * c, s.dec, DPMN_ACT_RELU));
   // de_5 .. de_2: DecodeBlock on cat([d, skip_1, skip_2]) (cmm.py:150-158): ReLU, ConvTranspose2d(cin, cout, 3, 1, 1), BN, ReLU,
   // ConvTranspose2d(cout, cout, 4, 2, 1), BN
   const int outc[4] = {8 * c, 4 * c, 2 * c, c};
@@ -134,8 +137,9 @@ int dpmn_cmm_forward_f32(const dpmn_cmm_weights* w, const float* x1, const float
     const float* b = s.enc[lv] + (size_t)B * l[lv].H * l[lv].W * l[lv].C;
     dpmn_conv_desc d = conv_desc(s.dec, dch, a, l[lv].C, b, l[lv].C, B, l[lv].H, l[lv].W, 3, 1, 1, 1, DPMN_ACT_RELU, w->dea_w[j], w->dea_b[j], outc[j],
                                  s.tmp, sc);
+    d.epi_act = DPMN_ACT_RELU;      // the block's inner ReLU: epilogue of the first conv, none on load in the second
     RUN(dpmn_conv2d_nhwc_f32(&d, stream));
-    RUN(convT(s.tmp, outc[j], l[lv].H, l[lv].W, w->deb_w[j], w->deb_b[j], outc[j], s.dec));
+    RUN(convT(s.tmp, outc[j], l[lv].H, l[lv].W, w->deb_w[j], w->deb_b[j], outc[j], s.dec, DPMN_ACT_NONE));
     dch = outc[j];
   }
   // de_1: ReLU, ConvTranspose2d(3c, c_img, 3, 1, 1) (cmm.py:117-118), NCHW store at the module boundary

@@ -138,8 +138,10 @@ class ComplementationModulationModule(nn.Module):
         chans = {2: (c, 2 * c), 3: (2 * c, 4 * c), 4: (4 * c, 8 * c), 5: (8 * c, 8 * c)}
         for lvl in (2, 3, 4, 5):
             ci, co = chans[lvl]
-            t = ops.conv2d([o[-1]], *P["en_%d.a" % lvl], ci, 4, stride=2, pad=3, dil=2, pro_act="leaky02", groups=2)
-            o.append(ops.conv2d([t], *P["en_%d.b" % lvl], co, 3, pad=1, pro_act="leaky02", groups=2))
+            # the block's inner activation (cmm.py:48 / 69) runs in the producer's epilogue, once per element, instead of on load
+            # in every (tap, output-tile) pass of the consumer; the block's outputs stay raw (skip connections use them twice)
+            t = ops.conv2d([o[-1]], *P["en_%d.a" % lvl], ci, 4, stride=2, pad=3, dil=2, pro_act="leaky02", epi_act="leaky02", groups=2)
+            o.append(ops.conv2d([t], *P["en_%d.b" % lvl], co, 3, pad=1, groups=2))
         o.append(ops.conv2d([o[-1]], *P["en_6"], 8 * c, 4, stride=2, pad=1, pro_act="leaky02", groups=2))
         a, b = [t[:Bn] for t in o], [t[Bn:] for t in o]          # batch halves: contiguous views
         bott = torch.cat([a[5], b[5]], dim=3)  # (B,1,4,16c) tiny concat feeding the gate (device memory plumbing)
@@ -147,6 +149,6 @@ class ComplementationModulationModule(nn.Module):
         d = ops.convT_s2k4([gated], P["de_6"], 8 * c, pro_act="relu")
         outc = {5: 8 * c, 4: 4 * c, 3: 2 * c, 2: c}
         for lvl, skip in ((5, 4), (4, 3), (3, 2), (2, 1)):
-            t = ops.conv2d([d, a[skip], b[skip]], *P["de_%d.a" % lvl], outc[lvl], 3, pad=1, pro_act="relu")
-            d = ops.convT_s2k4([t], P["de_%d.b" % lvl], outc[lvl], pro_act="relu")
+            t = ops.conv2d([d, a[skip], b[skip]], *P["de_%d.a" % lvl], outc[lvl], 3, pad=1, pro_act="relu", epi_act="relu")
+            d = ops.convT_s2k4([t], P["de_%d.b" % lvl], outc[lvl])
         return ops.conv2d([d, a[0], b[0]], *P["de_1"], self.c_img, 3, pad=1, pro_act="relu", out_nchw=True)

@@ -3,6 +3,8 @@ usage: python tools/prof_convs.py [fwd]"""
 import os
 import sys
 
+os.environ.setdefault("DPMN_CMM_NATIVE", "0")      # the composed per-op CMM path: ops.conv2d is what this tool wraps
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dpmn_amd import ops, workload
