@@ -8,6 +8,8 @@ affine (accumulated per producer) -> BatchNorm backward through the batch statis
 """
 import ctypes as C
 
+import os
+
 import torch
 
 from .. import ops
@@ -99,8 +101,9 @@ class Unit:
             self.out = T(r)
         return self.out
 
-    def backward(self, gr):
-        """Consumes self.out.G; accumulates parameter grads into gr; pushes gradients to the inputs' G buffers."""
+    def backward(self, gr, side=None):
+        """Consumes self.out.G; accumulates parameter grads into gr; pushes gradients to the inputs' G buffers.
+        side: a stream for the weight gradient (the caller joins it before anything reads gr), or None = in stream order."""
         o = self.out
         w, b = self.conv.weight, self.conv.bias
         transposed = self.kind in ("convT3", "convT4s2")
@@ -130,16 +133,27 @@ class Unit:
         aff = [t.aff for t in self.inputs]
         cin = sum(x.shape[3] for x in xs)
         dev = dr.device
-        # ---- weight gradient
-        if self.kind == "convT4s2":
-            for py in range(2):
-                for px in range(2):
-                    d = ops.conv_desc(xs, 2, cout=cout, pro_act=self.pro_act, affine=aff, phase=(py, px))
-                    conv_wgrad_into(d, dr, gr[w], "convT_s2k4", (py, px))
+        # ---- weight gradient: a leaf of the backward graph (nothing downstream reads it before the optimizer), so it runs on a
+        # side stream beside the data-gradient chain that the next unit waits for; backward() joins the streams at its end
+        def wgrad():
+            if self.kind == "convT4s2":
+                for py in range(2):
+                    for px in range(2):
+                        d = ops.conv_desc(xs, 2, cout=cout, pro_act=self.pro_act, affine=aff, phase=(py, px))
+                        conv_wgrad_into(d, dr, gr[w], "convT_s2k4", (py, px))
+            else:
+                f = self._fw()
+                d = ops.conv_desc(xs, f["k"], f["stride"], f["pad"], f["dil"], cout=cout, pro_act=self.pro_act, affine=aff)
+                conv_wgrad_into(d, dr, gr[w], "convT_s1" if self.kind == "convT3" else "conv")
+        if side is None:
+            wgrad()
         else:
-            f = self._fw()
-            d = ops.conv_desc(xs, f["k"], f["stride"], f["pad"], f["dil"], cout=cout, pro_act=self.pro_act, affine=aff)
-            conv_wgrad_into(d, dr, gr[w], "convT_s1" if self.kind == "convT3" else "conv")
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                wgrad()
+            dr.record_stream(side)       # dr dies with this call: its memory must not be reused before the side stream read it
         # ---- data gradients, one launch per input segment, then activation backward through the producer's affine
         c0 = 0
         for t in self.inputs:
@@ -176,6 +190,21 @@ class Unit:
             check(lib.dpmn_affine_act_bwd_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
                                               0 if first else 1, t.r.numel() // cs, cs, stream()))
             c0 += cs
+
+
+WGRAD_STREAM = os.environ.get("DPMN_WGRAD_STREAM", "1") != "0"
+_SIDE = {}
+
+
+def wgrad_stream(dev):
+    """The side stream of the CMM weight gradients (one per device), or None: switched off, or the step is being captured into
+    a hipGraph (graphed_train_step keeps the single-stream order)."""
+    if not WGRAD_STREAM or torch.cuda.is_current_stream_capturing():
+        return None
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 def build(m, x1, x2):
@@ -228,11 +257,10 @@ def backward(m, graph, dout, need_dx=(True, True)):
     B, Cc, H, W = dout.shape
     last.out.G = dout.permute(0, 2, 3, 1).contiguous()     # layout plumbing of a (B,3,32,128) tensor
     last.out.r = last.out.G
+    side = wgrad_stream(dout.device)
     for u in reversed(units):
         if u is last or u.out.G is not None:
-            if u.kind == "convT4s2" and u.inputs[0] is graph["gated"]:
-                pass
-            u.backward(gr)
+            u.backward(gr, side)
         if u.inputs and u.inputs[0] is graph["gated"]:
             # channel gate backward, then split the bottleneck gradient into the two en_6 outputs
             g = graph["gated"]
@@ -249,6 +277,8 @@ def backward(m, graph, dout, need_dx=(True, True)):
     dxs = []
     for leaf, need in zip(graph["leaves"], need_dx):
         dxs.append(ops.nhwc_to_nchw(leaf.G)[:, :3].contiguous() if need else None)
+    if side is not None:
+        torch.cuda.current_stream(dout.device).wait_stream(side)      # every weight gradient is in place before the bucket is signalled
     return dxs, gr, direct
 
 
