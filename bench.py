@@ -164,15 +164,20 @@ def set_branch_streams(on):
         sr_mod.BRANCH_STREAMS = bool(on)
     if not os.environ.get("DPMN_TRAIN_BRANCH_STREAMS") == "0":
         sr_mod.TRAIN_BRANCH_STREAMS = bool(on)
+    if not os.environ.get("DPMN_WGRAD_STREAM") == "0":      # the CMM weight gradients' side stream (train/cmm_train.py)
+        from dpmn_amd.train import cmm_train
+        cmm_train.WGRAD_STREAM = bool(on)
     return prev
 
 
 # families whose launches all lie outside the two-stream section of a step (PSN before the fork, CMM after the join): their
 # per-launch event durations inside the timed region are their own
 UNFORKED_FAMILIES = ("k_conv_igemm<128,128>", "k_conv_splitk_reduce", "k_bigru", "k_mha32")
+# training step: the CMM's data-gradient convs overlap its weight gradients (side stream), so only the PSN families qualify
+UNFORKED_FAMILIES_TRAIN = ("k_bigru", "k_mha32")
 
 
-def timed_leg(step, steps, warmup, profiling, torch, dist, _abi, post=3, arm_timed=True):
+def timed_leg(step, steps, warmup, profiling, torch, dist, _abi, post=3, arm_timed=True, unforked=UNFORKED_FAMILIES):
     """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks.
     Returns (seconds, rows of the dominant family event-timed inside the timed steps, per-family rows of `post` extra steps).
     Family ranking (last warm-up steps) and the per-family table (`post` steps after the region): branches on one stream."""
@@ -193,7 +198,7 @@ def timed_leg(step, steps, warmup, profiling, torch, dist, _abi, post=3, arm_tim
                 dominant = max(rows, key=lambda r: r["total_ms"])["kernel"]
     if rank_in_warmup:
         step()                                      # one more warm-up in the product configuration (side streams, allocator pools)
-    arm_timed = arm_timed and dominant in UNFORKED_FAMILIES      # else: measured in the joined-stream steps after the region
+    arm_timed = arm_timed and dominant in unforked      # else: measured in the joined-stream steps after the region
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
@@ -365,7 +370,8 @@ def main():
             return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
 
     profiling = rank == 0 and not args.graph and not args.no_kernel_profile
-    elapsed, live, kernels = timed_leg(step, args.steps, args.warmup, profiling, torch, dist, _abi)
+    elapsed, live, kernels = timed_leg(step, args.steps, args.warmup, profiling, torch, dist, _abi,
+                                       unforked=UNFORKED_FAMILIES if args.mode == "fwd" else UNFORKED_FAMILIES_TRAIN)
     if rank == 0:
         what = "forward" if args.mode == "fwd" else "training step"
         line = {
