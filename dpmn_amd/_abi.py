@@ -129,6 +129,8 @@ SIGNATURES = {
     "dpmn_bn_finalize_f32": (_i, [fp, fp, fp, _f, _f, _f, fp, fp, fp, fp, fp, fp, _i, fp, _i, fp]),
     "dpmn_affine_act_bwd_f32": (_i, [fp, fp, fp, fp, _i, fp, _i, C.c_long, _i, fp]),
     "dpmn_bn_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_long, _i, fp]),
+    "dpmn_affine_act_bwd_stats_f32": (_i, [fp, fp, fp, fp, _i, fp, _i, C.c_long, _i, fp, fp, fp, fp]),
+    "dpmn_bn_bwd_apply_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, C.c_long, _i, fp]),
     "dpmn_se_gate_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_affine_act_fwd_f32": (_i, [fp, fp, fp, _i, fp, C.c_long, _i, fp]),
     "dpmn_l1_loss_fwd_f32": (_i, [fp, fp, _f, fp, fp, C.c_long, fp]),

@@ -489,6 +489,94 @@ __global__ void k_affine_act_bwd(const float* __restrict__ dA, const float* __re
   }
   G[idx] = accumulate ? G[idx] + g : g;
 }
+// four channels of one pixel per thread (C % 4 == 0): no per-element modulo, 16-byte loads / stores
+__global__ void k_affine_act_bwd_v4(const float* __restrict__ dA, const float* __restrict__ r, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, int act, float* __restrict__ G, int accumulate, long quads, int Cq) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= quads) return;
+  const int cq = (int)(idx % Cq);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (scale) { sc = *reinterpret_cast<const float4*>(scale + cq * 4); sh = *reinterpret_cast<const float4*>(shift + cq * 4); }
+  const float slope = act == ACT_RELU ? 0.f : (act == ACT_LEAKY02 ? 0.2f : (act == ACT_LEAKY001 ? 0.01f : 1.f));
+  const float4 x = *reinterpret_cast<const float4*>(r + idx * 4);
+  float4 g = *reinterpret_cast<const float4*>(dA + idx * 4);
+  g.x = (x.x * sc.x + sh.x) > 0.f ? g.x : slope * g.x; g.y = (x.y * sc.y + sh.y) > 0.f ? g.y : slope * g.y;
+  g.z = (x.z * sc.z + sh.z) > 0.f ? g.z : slope * g.z; g.w = (x.w * sc.w + sh.w) > 0.f ? g.w : slope * g.w;
+  if (accumulate) {
+    const float4 o = *reinterpret_cast<const float4*>(G + idx * 4);
+    g.x = o.x + g.x; g.y = o.y + g.y; g.z = o.z + g.z; g.w = o.w + g.w;
+  }
+  *reinterpret_cast<float4*>(G + idx * 4) = g;
+}
+// The same with the BatchNorm-backward reduction of the PRODUCER folded in: the call that completes G (the last consumer's) has
+// the final value of every element in registers, so sum G and sum G * xhat per channel are accumulated here -- block-reduced,
+// then one fp64 atomic per channel and block (order-independent after the final rounding, like the forward statistics) -- and
+// dpmn_bn_bwd_f32's own pass over G and r (k_bn_bwd_reduce: 33 launches, 1.2 ms per step) disappears.  One float4 (4 channels
+// of one pixel) per thread and iteration; C % 4 == 0, C / 4 divides 256.
+__global__ __launch_bounds__(256) void k_affine_act_bwd_stats(const float* __restrict__ dA, const float* __restrict__ r,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                               float* __restrict__ G, int accumulate, long pixels, int C,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               double* __restrict__ sums, int pix_per_block) {
+  __shared__ float red[256][8];
+  const int Cq = C >> 2, PL = 256 / Cq;
+  const int cq = threadIdx.x % Cq, pl = threadIdx.x / Cq;
+  const long p0 = (long)blockIdx.x * pix_per_block;
+  const long p1 = p0 + pix_per_block < pixels ? p0 + pix_per_block : pixels;
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (pl < PL) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + cq * 4), rs = *reinterpret_cast<const float4*>(rstd + cq * 4);
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) { sc = *reinterpret_cast<const float4*>(scale + cq * 4); sh = *reinterpret_cast<const float4*>(shift + cq * 4); }
+    const float slope = act == ACT_RELU ? 0.f : (act == ACT_LEAKY02 ? 0.2f : (act == ACT_LEAKY001 ? 0.01f : 1.f));
+    // (-ffp-contract=off: z = r * scale + shift is a multiply then an add, as in k_affine_act_bwd and the forward's on-load affine)
+    auto one = [&](const float4& x, float4 g, const float4& o, long e) {
+      g.x = (x.x * sc.x + sh.x) > 0.f ? g.x : slope * g.x; g.y = (x.y * sc.y + sh.y) > 0.f ? g.y : slope * g.y;
+      g.z = (x.z * sc.z + sh.z) > 0.f ? g.z : slope * g.z; g.w = (x.w * sc.w + sh.w) > 0.f ? g.w : slope * g.w;
+      if (accumulate) { g.x = o.x + g.x; g.y = o.y + g.y; g.z = o.z + g.z; g.w = o.w + g.w; }
+      *reinterpret_cast<float4*>(G + e) = g;
+      s1[0] += g.x; s1[1] += g.y; s1[2] += g.z; s1[3] += g.w;
+      s2[0] += g.x * (x.x - mu.x) * rs.x; s2[1] += g.y * (x.y - mu.y) * rs.y;
+      s2[2] += g.z * (x.z - mu.z) * rs.z; s2[3] += g.w * (x.w - mu.w) * rs.w;
+    };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    long p = p0 + pl;
+    for (; p + 3 * PL < p1; p += 4 * PL) {      // 4 pixels per thread in flight: 8 (12) independent float4 loads
+      float4 x[4], g[4], o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long e = (p + u * PL) * C + cq * 4;
+        x[u] = *reinterpret_cast<const float4*>(r + e);
+        g[u] = *reinterpret_cast<const float4*>(dA + e);
+        o[u] = accumulate ? *reinterpret_cast<const float4*>(G + e) : z4;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(x[u], g[u], o[u], (p + u * PL) * C + cq * 4);
+    }
+    for (; p < p1; p += PL) {
+      const long e = p * C + cq * 4;
+      one(*reinterpret_cast<const float4*>(r + e), *reinterpret_cast<const float4*>(dA + e),
+          accumulate ? *reinterpret_cast<const float4*>(G + e) : z4, e);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { red[threadIdx.x][q] = s1[q]; red[threadIdx.x][4 + q] = s2[q]; }
+  __syncthreads();
+  if (pl == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float a = 0.f, b2 = 0.f;
+      for (int l = 0; l < PL; ++l) { a += red[l * Cq + cq][q]; b2 += red[l * Cq + cq][4 + q]; }
+      atomicAdd(sums + cq * 4 + q, (double)a);
+      atomicAdd(sums + C + cq * 4 + q, (double)b2);
+    }
+  }
+}
+// fp64 (2, C) sums -> the fp32 pair k_bn_bwd_apply reads
+__global__ void k_sums_to_f32(const double* __restrict__ s, float* __restrict__ o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = (float)s[i];
+}
 // sums (2,C): sum G, sum G * xhat
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ G, const float* __restrict__ r,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -863,8 +951,41 @@ int dpmn_affine_act_bwd_f32(const float* dA, const float* r, const float* scale,
                             int accumulate, long pixels, int C, dpmn_stream_t stream) {
   DPMN_REQUIRE(dA && r && G && pixels > 0 && C > 0, "affine_act_bwd: bad arguments");
   const long total = pixels * C;
+  const bool lin = act == ACT_NONE || act == ACT_RELU || act == ACT_LEAKY02 || act == ACT_LEAKY001;      // (the only ones the old kernel handles too)
+  if (C % 4 == 0 && lin)
+    hipLaunchKernelGGL(k_affine_act_bwd_v4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, as_stream(stream), dA, r, scale, shift,
+                       act, G, accumulate, total / 4, C / 4);
+  else
   hipLaunchKernelGGL(k_affine_act_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), dA, r, scale, shift,
                      act, G, accumulate, pixels, C);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_affine_act_bwd_stats_f32(const float* dA, const float* r, const float* scale, const float* shift, int act, float* G,
+                                  int accumulate, long pixels, int C, const float* mean, const float* rstd, double* sums,
+                                  dpmn_stream_t stream) {
+  DPMN_REQUIRE(dA && r && G && mean && rstd && sums && pixels > 0, "affine_act_bwd_stats: bad arguments");
+  DPMN_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "affine_act_bwd_stats: C/4 must divide 256");
+  DPMN_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LEAKY02 || act == ACT_LEAKY001, "affine_act_bwd_stats: piecewise-linear activations");
+  int ppb = (int)((pixels + 2047) / 2048);       // <= 2048 blocks: one fp64 atomic pair per channel and block
+  const int pl = 256 / (C / 4);
+  if (ppb < 8 * pl) ppb = 8 * pl;                // two 4-pixel rounds per thread at least
+  hipLaunchKernelGGL(k_affine_act_bwd_stats, dim3((unsigned)((pixels + ppb - 1) / ppb)), dim3(256), 0, as_stream(stream), dA, r, scale,
+                     shift, act, G, accumulate, pixels, C, mean, rstd, sums, ppb);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_bn_bwd_apply_f32(const float* G, const float* r, const float* gamma, const float* mean, const float* rstd, const double* sums,
+                          float* sums_ws, float* dr, float* dgamma, float* dbeta, long pixels, int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(G && r && gamma && mean && rstd && sums && sums_ws && dr && dgamma && dbeta && pixels > 1 && C % 4 == 0, "bn_bwd_apply: bad arguments");
+  hipLaunchKernelGGL(k_sums_to_f32, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, as_stream(stream), sums, sums_ws, 2 * C);
+  DPMN_CHECK_LAUNCH();
+  long total = pixels * C / 4;
+  if (total < C) total = C;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), G, r, gamma, mean, rstd,
+                     sums_ws, (float)pixels, dr, dgamma, dbeta, pixels, C);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

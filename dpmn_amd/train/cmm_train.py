@@ -113,8 +113,13 @@ class Unit:
         if self.bn is not None:
             dr = torch.empty_like(G)
             ws = torch.empty(2, cout, device=G.device)
-            check(lib.dpmn_bn_bwd_f32(dptr(G), dptr(o.r), dptr(self.bn.weight), dptr(o.mean), dptr(o.rstd), dptr(ws), dptr(dr),
-                                      dptr(gr[self.bn.weight]), dptr(gr[self.bn.bias]), pixels, cout, stream()))
+            if getattr(o, "gsums_done", False):
+                # the consumer that completed G already reduced (sum G, sum G * xhat) per channel: no pass over G and r here
+                check(lib.dpmn_bn_bwd_apply_f32(dptr(G), dptr(o.r), dptr(self.bn.weight), dptr(o.mean), dptr(o.rstd), o.gsums.data_ptr(), dptr(ws),
+                                                dptr(dr), dptr(gr[self.bn.weight]), dptr(gr[self.bn.bias]), pixels, cout, stream()))
+            else:
+                check(lib.dpmn_bn_bwd_f32(dptr(G), dptr(o.r), dptr(self.bn.weight), dptr(o.mean), dptr(o.rstd), dptr(ws), dptr(dr),
+                                          dptr(gr[self.bn.weight]), dptr(gr[self.bn.bias]), pixels, cout, stream()))
         else:
             dr = G
         cout_real = cout
@@ -187,12 +192,23 @@ class Unit:
             first = t.G is None          # first consumer writes, later ones accumulate: no zero fill of the activation
             if first:
                 t.G = torch.empty_like(t.r)
-            check(lib.dpmn_affine_act_bwd_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
-                                              0 if first else 1, t.r.numel() // cs, cs, stream()))
+            t.n_done = getattr(t, "n_done", 0) + 1
+            if (getattr(t, "gsums", None) is not None and t.n_done == t.n_cons and cs % 4 == 0 and 256 % (cs // 4) == 0
+                    and self.pro_act in ("none", "relu", "leaky02", "leaky001")):
+                # last consumer of a BatchNorm output: G is complete after this call -- fold the producer's BatchNorm-backward
+                # reduction into it (csrc/conv_bwd.hip k_affine_act_bwd_stats)
+                check(lib.dpmn_affine_act_bwd_stats_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
+                                                        0 if first else 1, t.r.numel() // cs, cs, dptr(t.mean), dptr(t.rstd), t.gsums.data_ptr(),
+                                                        stream()))
+                t.gsums_done = True
+            else:
+                check(lib.dpmn_affine_act_bwd_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
+                                                  0 if first else 1, t.r.numel() // cs, cs, stream()))
             c0 += cs
 
 
 WGRAD_STREAM = os.environ.get("DPMN_WGRAD_STREAM", "1") != "0"
+FUSE_BN_REDUCE = os.environ.get("DPMN_BN_BWD_FUSED", "1") != "0"      # 0: dpmn_bn_bwd_f32 with its own reduction pass
 _SIDE = {}
 
 
@@ -257,6 +273,18 @@ def backward(m, graph, dout, need_dx=(True, True)):
     B, Cc, H, W = dout.shape
     last.out.G = dout.permute(0, 2, 3, 1).contiguous()     # layout plumbing of a (B,3,32,128) tensor
     last.out.r = last.out.G
+    # consumers per tensor + one zero-filled fp64 slab for the (sum G, sum G * xhat) pairs that the last consumer of every
+    # BatchNorm output accumulates (Unit.backward)
+    if FUSE_BN_REDUCE:
+        for u in units:
+            for t in u.inputs:
+                t.n_cons = getattr(t, "n_cons", 0) + 1
+        bn_outs = [u.out for u in units if u.bn is not None and u.out.mean is not None]
+        slab = torch.zeros(sum(2 * t.r.shape[3] for t in bn_outs), dtype=torch.float64, device=dout.device)
+        off = 0
+        for t in bn_outs:
+            n = 2 * t.r.shape[3]
+            t.gsums, off = slab[off:off + n], off + n
     side = wgrad_stream(dout.device)
     for u in reversed(units):
         if u is last or u.out.G is not None:

@@ -428,6 +428,15 @@ int dpmn_bn_finalize_f32(float* stats, const float* gamma, const float* beta, fl
                          int C, long long* num_batches_tracked, int clear_stats, dpmn_stream_t stream);
 int dpmn_affine_act_bwd_f32(const float* dA, const float* r, const float* scale, const float* shift, int act, float* G,
                             int accumulate, long pixels, int C, dpmn_stream_t stream);
+/* dpmn_affine_act_bwd_f32 by the LAST consumer of a BatchNorm output, with the producer's BatchNorm-backward reduction folded in:
+ * sums (2, C) DOUBLES, zero on entry, += (sum G, sum G * xhat) of the completed G (xhat = (r - mean) * rstd of the producer's
+ * batch statistics).  dpmn_bn_bwd_apply_f32 is dpmn_bn_bwd_f32 without its own reduction pass over G and r (autograd of
+ * nn.BatchNorm2d in batch-statistics mode, cmm.py:12); sums_ws: 2 C floats of scratch. */
+int dpmn_affine_act_bwd_stats_f32(const float* dA, const float* r, const float* scale, const float* shift, int act, float* G,
+                                  int accumulate, long pixels, int C, const float* mean, const float* rstd, double* sums,
+                                  dpmn_stream_t stream);
+int dpmn_bn_bwd_apply_f32(const float* G, const float* r, const float* gamma, const float* mean, const float* rstd, const double* sums,
+                          float* sums_ws, float* dr, float* dgamma, float* dbeta, long pixels, int C, dpmn_stream_t stream);
 int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const float* mean, const float* rstd, float* sums_ws,
                     float* dr, float* dgamma, float* dbeta, long pixels, int C, dpmn_stream_t stream);
 int dpmn_se_gate_bwd_f32(const float* x, const float* dg, const float* fc1_w, const float* fc1_b, const float* fc2_w,
