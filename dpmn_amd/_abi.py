@@ -111,6 +111,7 @@ SIGNATURES = {
     "dpmn_sk_gate_bwd_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_feats_grad_f32": (_i, [fp, fp, fp, fp, C.c_long, _i, _i, fp]),
     "dpmn_dwconv3x3_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_dwconv3x3_gelu_in_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_train_f32": (_i, [fp, fp, fp, fp, fp, _i, _f, _u64, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_bwd_fused_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _f, _u64, _i, _i, _i, fp]),

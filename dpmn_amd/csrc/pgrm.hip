@@ -875,6 +875,20 @@ int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, f
   return DPMN_OK;
 }
 
+// y holds fc1's PRE-activation: its GELU (pgrm.py:33) is applied on the way into the LDS tile -- once per element, in a kernel that
+// waits on HBM anyway -- instead of in the epilogue of the MFMA-bound fc1 GEMM
+int dpmn_dwconv3x3_gelu_in_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream) {
+  DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
+  const long planes = (long)B * Ch;
+  const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  ProfScope prof(PT_DWCONV_GELU, as_stream(stream), 18.0 * planes * r * r, 8.0 * planes * r * r);
+  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1,
+                     static_cast<float*>(nullptr), 1, 0.f, 0ull);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
 int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream) {
   DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;

@@ -355,6 +355,8 @@ int dpmn_sk_feats_grad_f32(const float* dout, const float* feats, const float* d
                            dpmn_stream_t stream);
 /* Mlp depthwise conv without the activation (training keeps the pre-activation), its backward, and the
  * pointwise-conv weight gradient dw (Ch,Ch) += sum_b dz_b . g_b^T over the raw (B,Ch,L) views */
+/* y = fc1's pre-activation: GELU applied on load (pgrm.py:33-35 in one pass), g = GELU(dwconv(GELU(y))) */
+int dpmn_dwconv3x3_gelu_in_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream);
 int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream);
 /* the same two kernels with the GELUs of the Mlp chain (pgrm.py:31-37: fc1 -> GELU -> dwconv -> GELU -> pointwise) fused in:
  *   _train : gpre = dwconv(in_gelu ? GELU(y) : y) and g = GELU(gpre) in one pass (the backward needs both)
