@@ -137,6 +137,45 @@ def test_linear_weight_gradient_vs_torch(dev, M, N, K, with_db):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("pixels,C,act,accumulate", [(1000, 64, "leaky02", False), (4099, 128, "relu", True), (515, 512, "none", False),
+                                                     (196608, 64, "relu", False)])
+def test_batchnorm_backward_with_folded_reduction_vs_torch_autograd(dev, pixels, C, act, accumulate):
+    """dpmn_affine_act_bwd_stats_f32 (activation backward of the last consumer + the producer's per-channel sums in fp64) followed
+    by dpmn_bn_bwd_apply_f32 == autograd of act(nn.BatchNorm2d(r)) in batch-statistics mode (cmm.py:12, 48, 69); two runs equal."""
+    from dpmn_amd import ops
+    from dpmn_amd._abi import lib, check, dptr, stream
+    r = u("bnr", (pixels, C), -2, 2).requires_grad_(True)
+    gamma, beta = u("bng", (C,), 0.5, 1.5).requires_grad_(True), u("bnb", (C,), -0.5, 0.5).requires_grad_(True)
+    dA, G0 = u("bndA", (pixels, C)), u("bnG0", (pixels, C))
+    z = torch.nn.functional.batch_norm(r, None, None, gamma, beta, True, 0.0, 1e-5)
+    fn = {"leaky02": lambda t: torch.nn.functional.leaky_relu(t, 0.2), "relu": torch.relu, "none": lambda t: t}[act]
+    (fn(z) * dA).sum().backward(retain_graph=True)
+    if accumulate:          # a second consumer already left its gradient w.r.t. z in G
+        z.backward(G0)
+    with torch.no_grad():
+        mean, var = r.mean(0), r.var(0, unbiased=False)
+        rstd = 1.0 / torch.sqrt(var + 1e-5)
+        scale, shift = gamma * rstd, beta - mean * gamma * rstd
+    outs = []
+    for _ in range(2):
+        G = G0.clone().to(dev) if accumulate else torch.full((pixels, C), float("nan"), device=dev)
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        ws, dr = torch.empty(2 * C, device=dev), torch.empty(pixels, C, device=dev)
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        rd, md, sd = r.detach().to(dev), mean.to(dev), rstd.to(dev)      # (named: a temporary's memory is reused by the next upload)
+        dAd, scd, shd, gad = dA.to(dev), scale.detach().to(dev), shift.detach().to(dev), gamma.detach().to(dev)
+        check(lib.dpmn_affine_act_bwd_stats_f32(dptr(dAd), dptr(rd), dptr(scd), dptr(shd), ops.ACT[act],
+                                                dptr(G), 1 if accumulate else 0, pixels, C, dptr(md), dptr(sd), sums.data_ptr(), stream()))
+        check(lib.dpmn_bn_bwd_apply_f32(dptr(G), dptr(rd), dptr(gad), dptr(md), dptr(sd), sums.data_ptr(), dptr(ws), dptr(dr),
+                                        dptr(dg), dptr(db), pixels, C, stream()))
+        outs.append((dr, dg, db))
+    tol = 3e-6 * pixels ** 0.5 + 2e-5
+    assert_close(outs[0][0], r.grad, 1e-4, 1e-4, "d(raw conv output)")
+    assert_close(outs[0][1], gamma.grad, tol * 4, 1e-4, "dgamma")
+    assert_close(outs[0][2], beta.grad, tol * 4, 1e-4, "dbeta")
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
 def test_dropout_kernel_masks_equal_oracle_hash(dev):
     """dpmn_dropout_f32 (elementwise + per-sample DropPath + residual) vs the numpy restatement of the mask hash: the kept set
     is bit-identical, values equal to fp32 round-off of the single multiply."""
