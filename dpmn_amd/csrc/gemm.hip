@@ -384,7 +384,19 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
   __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m_blk = blockIdx.x * BM, n_blk = blockIdx.y * BN;
+  // Split-K launches (the pointwise-conv weight gradient: 6 x 4 tiles x 32 k splits): workgroups are dealt to the 8 XCDs round-robin
+  // by linear id, so the 24 tiles of one k split -- which read the same 2 x 2.4 MB operand slices -- landed on 8 different L2s and
+  // every slice crossed the fabric 4 / 6 times (750 MB per launch = the whole 185 us at HBM rate).  XCD c takes the splits
+  // z = c, c + 8, ... and runs their tiles back to back.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (gridDim.z > 1 && (gridDim.z & 7) == 0) {
+    const int tiles = gridDim.x * gridDim.y;
+    const int lid = bx + gridDim.x * (by + gridDim.y * bz);
+    const int c = lid & 7, j = lid >> 3;
+    const int zq = j / tiles, t = j - zq * tiles;
+    bz = c + 8 * zq; by = t / (int)gridDim.x; bx = t - by * (int)gridDim.x;
+  }
+  const int m_blk = bx * BM, n_blk = by * BN;
   // loader mapping: 8 float4 per row
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;   // rows 0..31 (+32 per pass)
   // Two named register sets (a, b), same scheme as k_gemm_pw: the loads of k-step kt+2 are issued at the end of step kt and
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
 
   const int nk_all = K / BK;
   const int cps = (nk_all + gridDim.z - 1) / gridDim.z;      // K chunks per split (grid.z > 1 only with e.atomic)
-  const int kt0 = blockIdx.z * cps;
+  const int kt0 = bz * cps;
   const int nk = min(nk_all, kt0 + cps);
   if (kt0 >= nk) return;
   KL_GLOAD(a, kt0 * BK);
