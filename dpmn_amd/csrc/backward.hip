@@ -153,8 +153,18 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ d
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wk = wave >> 1;
   const int lr = lane & 15, kq = lane >> 4;
-  const int n_w = blockIdx.x * 96 + wn * 48, k_w = blockIdx.y * 96 + wk * 48;
-  const int m_lo = blockIdx.z * rows_per_block;
+  // the tiles of one row split read the same dY / X rows: XCD c (workgroups are dealt round-robin by linear id) takes the splits
+  // z = c, c + 8, ... and runs their tiles back to back, so the shared rows cross the fabric once
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if ((gridDim.z & 7) == 0 && gridDim.x * gridDim.y > 1) {
+    const int tiles = gridDim.x * gridDim.y;
+    const int lid = bx + gridDim.x * (by + gridDim.y * bz);
+    const int c = lid & 7, j = lid >> 3;
+    const int zq = j / tiles, t = j - zq * tiles;
+    bz = c + 8 * zq; by = t / (int)gridDim.x; bx = t - by * (int)gridDim.x;
+  }
+  const int n_w = bx * 96 + wn * 48, k_w = by * 96 + wk * 48;
+  const int m_lo = bz * rows_per_block;
   const int nrows = min(M, m_lo + rows_per_block) - m_lo;
   const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy) + (size_t)m_lo * N, 0, nrows * N * 4, 0x00020000);
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x) + (size_t)m_lo * K, 0, nrows * K * 4, 0x00020000);
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ d
     for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // bias gradient db[n] = sum_m dY[m][n]: the lane already holds the dY values of its rows -- three vector adds per step and
   // one cross-kq shuffle at the end (as dY^T . 1 on the matrix pipe it cost 3 more MFMAs per step on half the waves: +35 %)
-  const bool with_db = db != nullptr && blockIdx.y == 0 && wk == 0;     // wave-uniform
+  const bool with_db = db != nullptr && by == 0 && wk == 0;     // wave-uniform
   f32x3 sb = (f32x3){0.f, 0.f, 0.f};
   f32x3 a[D], b[D];
   auto load = [&](int d, int step) {       // steps past the range: beyond num_records -> zeros
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ d
       load(d, s0 + D + d);
     }
   }
-  float* pz = part + (size_t)blockIdx.z * ((size_t)N * K + N);
+  float* pz = part + (size_t)bz * ((size_t)N * K + N);
   typedef int i32x3_ __attribute__((ext_vector_type(3)));
   const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(pz, 0, N * K * 4, 0x00020000);
 #pragma unroll
