@@ -225,13 +225,14 @@ def _attach_workspace(d, device):
 
 def cmm_forward(weights, keep, x1, x2, c_img, workspaces):
     """ComplementationModulationModule.forward in eval mode as ONE native call (csrc/cmm_forward.hip).  weights: a filled
-    _abi.CmmWeights (keep = the tensors it points to); workspaces: dict B -> activation workspace, owned by the module."""
+    _abi.CmmWeights (keep = the tensors it points to); workspaces: dict (B, H, W, stream) -> activation workspace, owned by the module."""
     import ctypes as _C
     B, _, H, W = x1.shape
     x1, x2 = x1.contiguous().float(), x2.contiguous().float()
-    if B not in workspaces:
-        workspaces[B] = torch.empty(lib.dpmn_cmm_workspace_bytes(_C.byref(weights), B) // 4, device=x1.device)
-    ws = workspaces[B]
+    key = (B, H, W, torch.cuda.current_stream(x1.device).cuda_stream)
+    if key not in workspaces:
+        workspaces[key] = torch.empty(lib.dpmn_cmm_workspace_bytes(_C.byref(weights), B) // 4, device=x1.device)
+    ws = workspaces[key]
     d = _abi.ConvDesc()
     _attach_workspace(d, x1.device)
     sc = _abi.CmmScratch(d.splitk_ws, d.splitk_ws_bytes, d.arrive_cnt, d.arrive_cnt_len)
