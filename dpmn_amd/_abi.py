@@ -56,6 +56,15 @@ class CmmWeights(C.Structure):
         ("dea_w", fp * 4), ("dea_b", fp * 4), ("deb_w", fp * 4), ("deb_b", fp * 4), ("de1_w", fp), ("de1_b", fp)]
 
 
+class PsnSrb(C.Structure):
+    _fields_ = [(n, fp) for n in ("c1_w", "c1_b", "c2_w", "c2_b", "g1_w", "g1_b", "g1_whh", "g1_bhh", "g2_w", "g2_b", "g2_whh", "g2_bhh")]
+
+
+class PsnWeights(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("in_planes", "ch", "hidden", "srb_nums")] + [("srb", PsnSrb * 8)] + [
+        (n, fp) for n in ("b7_w", "b7_b", "up_w", "up_b", "last_w", "last_b")]
+
+
 class CmmScratch(C.Structure):
     _fields_ = [("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t), ("arrive_cnt", fp), ("arrive_cnt_len", C.c_int)]
 
@@ -166,6 +175,8 @@ SIGNATURES = {
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_gelu_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_f32": (_i, [fp, fp, fp, fp, fp, _PP, _PP, _i, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "dpmn_psn_trunk_workspace_bytes": (_sz, [C.POINTER(PsnWeights), _i, _i, _i]),
+    "dpmn_psn_trunk_f32": (_i, [C.POINTER(PsnWeights), fp, fp, _i, fp, fp, _sz, C.POINTER(CmmScratch), _i, _i, _i, fp]),
     "dpmn_cmm_workspace_bytes": (_sz, [C.POINTER(CmmWeights), _i]),
     "dpmn_cmm_forward_f32": (_i, [C.POINTER(CmmWeights), fp, fp, fp, fp, _sz, C.POINTER(CmmScratch), _i, fp]),
     "dpmn_pgrm_workspace_bytes": (_sz, [C.POINTER(PgrmWeights), _i]),

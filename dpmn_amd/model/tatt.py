@@ -171,7 +171,4 @@ class TSRN_TL_TRANS(_PSNBase):
             raise ValueError("TATT: text_emb batch must match the image batch")
         b1 = self._head(x, P)
         tp_map, prw = self._tp_interpreter(b1, text_emb, P)
-        f = b1
-        for i in range(self.srb_nums):
-            f = self._srb(f, P, i, tp_map)
-        return self._tail(b1, f, P), prw
+        return self._trunk(b1, P, tp_map), prw

@@ -9,12 +9,16 @@ PixelShuffle epilogues (csrc/conv.hip), the BiGRU recurrence with the 1x1 conv f
 input projection, and the TPInterpreter transformer pieces (csrc/tatt.hip, csrc/gemm.hip).
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from .. import ops
 from . import packing
+
+
+NATIVE_TRUNK = os.environ.get("DPMN_PSN_NATIVE", "1") != "0"      # SRBs + tail through dpmn_psn_trunk_f32 (one native call)
 
 
 class _GruBlock(nn.Module):
@@ -141,6 +145,37 @@ class _PSNBase(nn.Module):
         gi = ops.linear(s.reshape(M, Cc), w2, b2)
         return ops.bigru(gi, whh2, bhh2, B, H, W, "w")
 
+    def _native(self, P):
+        """dpmn_psn_weights over the packed weights (include/dpmn_hip.h), rebuilt when the pack is."""
+        from .. import _abi
+        nat = getattr(self, "_nat", None)
+        if nat is not None and nat[0] is P:
+            return nat[1], nat[2]
+        w = _abi.PsnWeights()
+        w.in_planes, w.ch, w.hidden, w.srb_nums = self.in_planes, self.ch, self.ch // 2, self.srb_nums
+        keep = []
+        for i in range(self.srb_nums):
+            q = w.srb[i]
+            (q.c1_w, q.c1_b), (q.c2_w, q.c2_b) = [(t.data_ptr() for t in P["srb%d.c%d" % (i, j)]) for j in (1, 2)]
+            for g in (1, 2):
+                gw, gb, whh, bhh = P["srb%d.g%d" % (i, g)]
+                setattr(q, "g%d_w" % g, gw.data_ptr()); setattr(q, "g%d_b" % g, gb.data_ptr())
+                setattr(q, "g%d_whh" % g, whh.data_ptr()); setattr(q, "g%d_bhh" % g, bhh.data_ptr())
+        (w.b7_w, w.b7_b), (w.up_w, w.up_b), (w.last_w, w.last_b) = [(t.data_ptr() for t in P[k]) for k in ("b7", "up", "last")]
+        self._nat = (P, w, keep)
+        if not hasattr(self, "_native_ws"):
+            self._native_ws = {}
+        return w, keep
+
+    def _trunk(self, b1, P, tp=None):
+        """SRBs + tail: one native call (csrc/psn_forward.hip), or (DPMN_PSN_NATIVE=0) the per-op composition below."""
+        if NATIVE_TRUNK and "srb0.g1" in P:
+            return ops.psn_trunk(*self._native(P), b1, tp, self.in_planes, self._native_ws)
+        f = b1
+        for i in range(self.srb_nums):
+            f = self._srb(f, P, i, tp)
+        return self._tail(b1, f, P)
+
     def _head(self, x, P):
         xin = ops.nchw_to_nhwc(x.contiguous().float(), 4)
         return ops.conv2d([xin], *P["block1"], self.ch, 9, pad=4, epi_act="prelu", slope=P["prelu"])
@@ -162,8 +197,4 @@ class TSRN(_PSNBase):
     def forward(self, x):
         self._check_mode()
         P = self._trunk_pack()
-        b1 = self._head(x, P)
-        f = b1
-        for i in range(self.srb_nums):
-            f = self._srb(f, P, i)
-        return self._tail(b1, f, P)
+        return self._trunk(self._head(x, P), P)

@@ -241,6 +241,24 @@ def cmm_forward(weights, keep, x1, x2, c_img, workspaces):
     return out
 
 
+def psn_trunk(weights, keep, b1, tp, in_planes, workspaces):
+    """SRBs + tail of the frozen PSN (TSRN / TATT trunk) as ONE native call (csrc/psn_forward.hip).  b1: block1's NHWC output,
+    tp: TATT's NHWC text-prior map or None; returns the NCHW image (B, in_planes, 2H, 2W)."""
+    import ctypes as _C
+    B, H, W, _ = b1.shape
+    key = (B, H, W, torch.cuda.current_stream(b1.device).cuda_stream)
+    if key not in workspaces:
+        workspaces[key] = torch.empty(lib.dpmn_psn_trunk_workspace_bytes(_C.byref(weights), B, H, W) // 4, device=b1.device)
+    ws = workspaces[key]
+    d = _abi.ConvDesc()
+    _attach_workspace(d, b1.device)
+    sc = _abi.CmmScratch(d.splitk_ws, d.splitk_ws_bytes, d.arrive_cnt, d.arrive_cnt_len)
+    out = torch.empty(B, in_planes, 2 * H, 2 * W, device=b1.device)
+    check(lib.dpmn_psn_trunk_f32(_C.byref(weights), dptr(b1), dptr(tp, True), 0 if tp is None else tp.shape[3], dptr(out), dptr(ws),
+                                 ws.numel() * 4, _C.byref(sc), B, H, W, stream()))
+    return out
+
+
 def nchw_to_nhwc(x, cpad=None):
     B, Cc, H, W = x.shape
     cpad = cpad or Cc

@@ -516,6 +516,27 @@ size_t dpmn_cmm_workspace_bytes(const dpmn_cmm_weights* w, int B);
 int dpmn_cmm_forward_f32(const dpmn_cmm_weights* w, const float* x1, const float* x2, float* out, void* workspace,
                          size_t workspace_bytes, const dpmn_cmm_scratch* scratch, int B, dpmn_stream_t stream);
 
+/* ------------------------------------------------------------------ native PSN trunk (psn_forward.hip) */
+/* The SRBs and the tail of TSRN.forward (tsrn.py:58-74) / TSRN_TL_TRANS.forward (tatt.py:645-691) in eval mode as ONE call:
+ * per SRB conv+bn+mish, conv+bn, [cat with tp] -> GRU input projection (1x1 conv folded in) -> BiGRU along H (+ x) -> projection ->
+ * BiGRU along W; then conv+bn + block1, conv + PixelShuffle + mish, 9x9 conv + tanh.  Weights are the packed forms of
+ * dpmn_amd/model/packing.py / tsrn.py::_pack_gru_block (eval BatchNorm folded). */
+typedef struct {
+  const float *c1_w, *c1_b, *c2_w, *c2_b;              /* packed 3x3 convs */
+  const float *g1_w, *g1_b, *g1_whh, *g1_bhh;          /* gru1: (6 hidden, Cin [+ tp channels]) input projection, (2, 3 hidden, hidden) recurrent */
+  const float *g2_w, *g2_b, *g2_whh, *g2_bhh;
+} dpmn_psn_srb;
+typedef struct {
+  int in_planes, ch, hidden, srb_nums;
+  dpmn_psn_srb srb[8];
+  const float *b7_w, *b7_b, *up_w, *up_b, *last_w, *last_b;
+} dpmn_psn_weights;
+size_t dpmn_psn_trunk_workspace_bytes(const dpmn_psn_weights* w, int B, int H, int W);
+/* b1 (B,H,W,ch) NHWC = block1's output (9x9 conv + PReLU, run by the caller); tp (B,H,W,tp_channels) NHWC = TATT's text-prior map
+ * or NULL (TSRN); out (B, in_planes, 2H, 2W) NCHW. */
+int dpmn_psn_trunk_f32(const dpmn_psn_weights* w, const float* b1, const float* tp, int tp_channels, float* out, void* workspace,
+                       size_t workspace_bytes, const dpmn_cmm_scratch* scratch, int B, int H, int W, dpmn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,6 +115,27 @@ def test_tatt_batch48_vs_oracle(dev):
     assert_close(out, ref, 2e-4, 2e-4, "TATT B=48 vs oracle")
 
 
+@pytest.mark.parametrize("arch,B", [("tsrn", 2), ("tsrn", 48), ("tatt", 3), ("tatt", 48)])
+def test_psn_native_trunk_equals_composed_ops(dev, arch, B):
+    """dpmn_psn_trunk_f32 (SRBs + tail from one native call, csrc/psn_forward.hip) issues the launches of the per-op host path
+    with the same arguments: bitwise-equal outputs, also on the second call (cached weights struct / workspace)."""
+    from dpmn_amd.model import tsrn as tsrn_mod
+    from dpmn_amd.model.tatt import TSRN_TL_TRANS
+    _, m = _load(tsrn_mod.TSRN if arch == "tsrn" else TSRN_TL_TRANS, arch, 44, dev)
+    b = synth.synth_batch(B, seed=4)
+    args = (b["images_lr"].to(dev),) + ((b["label_vecs"].to(dev),) if arch == "tatt" else ())
+    first = lambda o: o[0] if isinstance(o, tuple) else o
+    assert tsrn_mod.NATIVE_TRUNK
+    with torch.no_grad():
+        nat, nat2 = first(m(*args)), first(m(*args))
+        tsrn_mod.NATIVE_TRUNK = False
+        try:
+            ref = first(m(*args))
+        finally:
+            tsrn_mod.NATIVE_TRUNK = True
+    assert torch.equal(nat, ref) and torch.equal(nat2, ref)
+
+
 def test_mha32_and_layernorm_std_match_oracle(dev):
     """TBSRN FeatureEnhancer kernels (tbsrn.py:110-150, 23-36) vs plain softmax attention / std LayerNorm."""
     import math
