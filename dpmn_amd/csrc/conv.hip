@@ -156,7 +156,7 @@ __device__ __forceinline__ float vmax_raw(float x, float y) {
 // v % 4][pixel = l & 31] -- again 4 consecutive output channels per lane and register quad.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false, bool M32 = false>
-__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+__device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   static_assert(!M32 || (SIMPLE && !BF && BKT == 32 && BM / WM == 64 && BN / WN == 64), "the 32x32x2 variant: fp32 SIMPLE path, 64 x 64 wave tiles");
   static_assert(!BF || (SIMPLE && BKT == 32), "the bf16 variant exists for the SIMPLE path with 32-deep chunks");
   static_assert(!SIMPLE || UNI, "SIMPLE is a refinement of the UNI path");
@@ -661,6 +661,17 @@ __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
       }
     }
   }
+}
+
+template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false, bool M32 = false>
+__global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
+  conv_igemm_body<BM, BN, WM, WN, UNI, BKT, SIMPLE, AFF, BF, M32>(a);
+}
+// the SIMPLE path with 16-deep chunks (36.9 KB of LDS) AND a register budget for three waves per SIMD (<= 168 registers): three
+// resident blocks per CU instead of two -- the 16-deep switch alone (DPMN_CONV_BK16) stayed at two because of its 200 registers
+template <int BM, int BN, int WM, int WN, bool AFF>
+__global__ __launch_bounds__(256, 3) void k_conv_igemm_o3(ConvArgs a) {
+  conv_igemm_body<BM, BN, WM, WN, true, 16, true, AFF, false, false>(a);
 }
 
 // sum the split-K partials and run the epilogue.  Block = 64 channel-quads x 4 row lanes, 64 rows per block, so the
@@ -1648,7 +1659,8 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     ProfScope prof(BN == 128 ? PT_CONV_IGEMM_128 : (BN == 64 ? PT_CONV_IGEMM_64 : PT_CONV_IGEMM_NARROW), st, conv_flops(a), conv_bytes(a));
     static const int bk16 = getenv("DPMN_CONV_BK16") ? atoi(getenv("DPMN_CONV_BK16")) : 0;
     static const int simple_on = getenv("DPMN_CONV_SIMPLE") ? atoi(getenv("DPMN_CONV_SIMPLE")) : 1;
-    static const int m32_on = getenv("DPMN_CONV_M32") ? atoi(getenv("DPMN_CONV_M32")) : 0;      // 32x32x2 MFMAs on the 128 x 128 tile
+    static const int m32_on = getenv("DPMN_CONV_M32") ? atoi(getenv("DPMN_CONV_M32")) : 0;
+    static const int o3_on = getenv("DPMN_CONV_O3") ? atoi(getenv("DPMN_CONV_O3")) : 0;          // 16-deep chunks + 3 waves per SIMD      // 32x32x2 MFMAs on the 128 x 128 tile
     bool simple = simple_on && uni && a.KH * a.KW <= 31 && (a.pro_act == ACT_NONE || a.pro_act == ACT_RELU || a.pro_act == ACT_LEAKY02);
     int n_seg = 0, n_aff = 0;
     for (int i = 0; i < 3; ++i) {    // + the shift of the buffer base must keep the byte range below 2^31
@@ -1662,6 +1674,12 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, false, true>), grid, dim3(256), 0, st, a);
   } else
   if (uni && BM == 128 && BN == 128 && bk16) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 16>), grid, dim3(256), 0, st, a);
+  else if (simple && o3_on && BM == 128 && BN == 128) {
+    if constexpr (BM == 128 && BN == 128) {
+      if (n_aff) hipLaunchKernelGGL((k_conv_igemm_o3<BM, BN, WM, WN, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_conv_igemm_o3<BM, BN, WM, WN, false>), grid, dim3(256), 0, st, a);
+    }
+  }
   else if (simple && m32_on && BM / WM == 64 && BN / WN == 64) {
     if constexpr (BM / WM == 64 && BN / WN == 64) {
       if (n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true, false, true>), grid, dim3(256), 0, st, a);
