@@ -1029,10 +1029,15 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
                                      //  weights straight from L1/L2 to registers instead of LDS measured 76 / 146 us: rejected)
   constexpr int HBUF = PREFETCH ? 2 : 1;
   constexpr int HV = PREFETCH ? (NPX * 8 + 255) / 256 : 1;   // halo float4 per thread held in registers
-  constexpr int WV = (BN * 8 + 255) / 256;               // weight float4 per thread
+  constexpr int WV = (BN * 8 + 255) / 256;               // weight float4 per thread and tap
+#ifndef DPMN_HALO_TPS
+#define DPMN_HALO_TPS 1                                   // 3: the three taps of a kernel row share one weight stage and ONE barrier
+#endif
+  constexpr int TPS = (KS == 3 && !BF && TH == 4) ? DPMN_HALO_TPS : 1;      // taps per weight stage
+  static_assert(T % TPS == 0, "whole stages");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* halo = smem;                                    // [HBUF][NPX][LDK]
-  float* Wt = smem + HBUF * NPX * LDH;                   // [2][BN][LDK]
+  float* Wt = smem + HBUF * NPX * LDH;                   // [2][TPS][BN][LDK]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = a.Win / TW, tiles_y = a.Hin / TH;
@@ -1043,7 +1048,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   const int c01 = a.cseg[0] + a.cseg[1];
   const int nchunks = a.cin / BK;
 
-  float4 hraw[HV], wraw[WV];
+  float4 hraw[HV], wraw[TPS * WV];
   // one staged float4 (4 consecutive k of one row) -> LDS, fp32 or rounded to bf16
   auto put4 = [&](float* base, int row, int c4, const float4& v) {
     if constexpr (BF) *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base + row * LDH) + c4) = pack_bf16x4(v.x, v.y, v.z, v.w);
@@ -1147,27 +1152,33 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
   const bool w_buf_ok = (size_t)a.Cout * a.Kp * 4 < (1ull << 31);
   const float* wg = a.w + (conv_group_of(a, (b * a.Hin + ty0) * a.Win + tx0) ? a.wgs : 0L);       // the tile's image decides the group
   const __amdgpu_buffer_rsrc_t wrs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wg), 0, w_buf_ok ? a.Cout * a.Kp * 4 : 0, 0x00020000);
-  auto issue_w = [&](int chunk, int tap) {
-    const size_t k0 = (size_t)tap * a.cin + chunk * BK;
-    if (w_buf_ok) {
+  auto issue_w = [&](int chunk, int stage) {       // the TPS taps stage * TPS ... of the chunk
 #pragma unroll
-      for (int v = 0; v < WV; ++v) wraw[v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs_h, wofs_h[v], (int)k0 * 4, 0));
-      return;
-    }
+    for (int tp = 0; tp < TPS; ++tp) {
+      const size_t k0 = (size_t)(stage * TPS + tp) * a.cin + chunk * BK;
+      if (w_buf_ok) {
 #pragma unroll
-    for (int v = 0; v < WV; ++v) {
-      const int i = tid + v * 256;
-      const int r = i >> 3, c4 = (i & 7) * 4;
-      wraw[v] = (i < BN * 8 && n_blk + r < a.Cout) ? *reinterpret_cast<const float4*>(wg + (size_t)(n_blk + r) * a.Kp + k0 + c4)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int v = 0; v < WV; ++v)
+          wraw[tp * WV + v] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wrs_h, wofs_h[v], (int)k0 * 4, 0));
+        continue;
+      }
+#pragma unroll
+      for (int v = 0; v < WV; ++v) {
+        const int i = tid + v * 256;
+        const int r = i >> 3, c4 = (i & 7) * 4;
+        wraw[tp * WV + v] = (i < BN * 8 && n_blk + r < a.Cout) ? *reinterpret_cast<const float4*>(wg + (size_t)(n_blk + r) * a.Kp + k0 + c4)
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
   };
   auto commit_w = [&](int buf) {
 #pragma unroll
-    for (int v = 0; v < WV; ++v) {
-      const int i = tid + v * 256;
-      if (i < BN * 8) put4(Wt + (size_t)buf * BN * LDH, i >> 3, (i & 7) * 4, wraw[v]);
-    }
+    for (int tp = 0; tp < TPS; ++tp)
+#pragma unroll
+      for (int v = 0; v < WV; ++v) {
+        const int i = tid + v * 256;
+        if (i < BN * 8) put4(Wt + (size_t)(buf * TPS + tp) * BN * LDH, i >> 3, (i & 7) * 4, wraw[tp * WV + v]);
+      }
   };
 
   const int lr = lane & 15, kq = lane >> 4;
@@ -1196,15 +1207,19 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
     // its issue with the fp32 matrix pipe).  T = 9 is odd, so the buffer parity of tap t is (chunk + t) & 1.
     const float* hp0 = halo + (size_t)hb * NPX * LDH + ((MR * wave) * HW_ + lr) * LDH + kq * 4;      // (bf16: 8 halves = 4 float units)
     const float* wp0 = Wt + lr * LDH + kq * 4;
-    constexpr int TAP_UNROLL = KS == 3 ? 9 : 1;
+    constexpr int NS = T / TPS;
+    constexpr int TAP_UNROLL = KS == 3 ? NS : 1;
 #pragma unroll TAP_UNROLL
-    for (int tap = 0; tap < T; ++tap) {
-      const bool lastt = tap == T - 1;
-      if (!lastt) issue_w(chunk, tap + 1);
+    for (int stage = 0; stage < NS; ++stage) {
+      const bool lastt = stage == NS - 1;
+      if (!lastt) issue_w(chunk, stage + 1);
       else if (more) issue_w(chunk + 1, 0);
+#pragma unroll
+      for (int tp = 0; tp < TPS; ++tp) {
+      const int tap = stage * TPS + tp;
       const int ky = tap / KS, kx = tap % KS;
       const float* hp = hp0 + (ky * HW_ + kx) * LDH;
-      const float* wp = wp0 + (size_t)wb * BN * LDH;
+      const float* wp = wp0 + (size_t)(wb * TPS + tp) * BN * LDH;
       if constexpr (BF) {
         bf16x8 xf[MR], wf[NT];
 #pragma unroll
@@ -1230,6 +1245,7 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
           for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MR; ++j) acc[i][j] = mfma16(wf[i][s4], xf[j][s4], acc[i][j]);
+      }
       }
       if (!lastt || more) commit_w(wb ^ 1);
       if (PREFETCH && lastt && more) commit_halo(hb ^ 1);
@@ -1542,7 +1558,8 @@ int launch_halo_th(const ConvArgs& a, hipStream_t st) {
     if (g_dpmn_bf16) return launch_halo_th<KS, BN, TH, true>(a, st);
   }
   constexpr int NPX = (TH + KS - 1) * (16 + KS - 1);
-  const size_t smem = (size_t)(NPX + 2 * BN) * (BF ? (BK + 8) / 2 : LDK) * sizeof(float);
+  constexpr int TPS = (KS == 3 && !BF && TH == 4) ? DPMN_HALO_TPS : 1;      // as in the kernel
+  const size_t smem = (size_t)(NPX + 2 * TPS * BN) * (BF ? (BK + 8) / 2 : LDK) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo<KS, BN, TH, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
