@@ -65,6 +65,16 @@ class PsnWeights(C.Structure):
         (n, fp) for n in ("b7_w", "b7_b", "up_w", "up_b", "last_w", "last_b")]
 
 
+class TattDecLayer(C.Structure):
+    _fields_ = [(n, fp) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "out_w", "out_b", "norm2_w", "norm2_b", "lin1_w", "lin1_b",
+                                  "lin2_w", "lin2_b", "norm3_w", "norm3_b")]
+
+
+class TattInterpWeights(C.Structure):
+    _fields_ = [("n_dec", C.c_int), ("nhead", C.c_int), ("fc_in_w", fp), ("fc_in_b", fp), ("fc_in_slope", C.c_float), ("enc", fp * 12),
+                ("dec", TattDecLayer * 4), ("dec_norm_w", fp), ("dec_norm_b", fp)]
+
+
 class CmmScratch(C.Structure):
     _fields_ = [("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t), ("arrive_cnt", fp), ("arrive_cnt_len", C.c_int)]
 
@@ -175,6 +185,8 @@ SIGNATURES = {
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_gelu_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_f32": (_i, [fp, fp, fp, fp, fp, _PP, _PP, _i, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "dpmn_tatt_interpreter_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dpmn_tatt_interpreter_f32": (_i, [C.POINTER(TattInterpWeights), fp, _i, fp, fp, fp, fp, fp, fp, _sz, _i, _i, _i, fp]),
     "dpmn_psn_trunk_workspace_bytes": (_sz, [C.POINTER(PsnWeights), _i, _i, _i]),
     "dpmn_psn_trunk_f32": (_i, [C.POINTER(PsnWeights), fp, fp, _i, fp, fp, _sz, C.POINTER(CmmScratch), _i, _i, _i, fp]),
     "dpmn_cmm_workspace_bytes": (_sz, [C.POINTER(CmmWeights), _i]),

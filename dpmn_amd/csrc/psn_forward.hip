@@ -89,3 +89,76 @@ int dpmn_psn_trunk_f32(const dpmn_psn_weights* w, const float* b1, const float* 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- TATT text-prior interpreter
+// TPInterpreter.forward (tatt.py:196-237) + InfoTransformer (transformer_v2.py: one encoder layer over the 26 text slots, three
+// decoder layers whose queries are the image feature map + the cached query embedding, mean of the normalised layer outputs):
+// 2 + 3 x 9 launches from one C call.  x: the (B * S, t_emb) text-prior rows, qe: (B * L, 64) query embedding (quirk Q5: computed
+// once per batch size by the host mirror), pos: (S, 64) sinusoid rows; out tp (B * L, 64), pw (B, L, S) or NULL.
+namespace {
+struct TpiWs {
+  float *src, *mem, *q, *k, *v, *o, *t1, *out[2], *f;
+  size_t total;
+};
+TpiWs carve_tpi(int B, int L, int S, int E, char* base) {
+  size_t off = 0;
+  auto take = [&](size_t n) {
+    float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+    off += ((n * sizeof(float) + 255) / 256) * 256;
+    return p;
+  };
+  TpiWs s;
+  const size_t BL = (size_t)B * L, BS = (size_t)B * S;
+  s.src = take(BS * E); s.mem = take(BS * E); s.q = take(BL * E); s.k = take(BS * E); s.v = take(BS * E);
+  s.o = take(BL * E); s.t1 = take(BL * E); s.out[0] = take(BL * E); s.out[1] = take(BL * E); s.f = take(BL * E);
+  s.total = off;
+  return s;
+}
+}  // namespace
+
+extern "C" {
+
+size_t dpmn_tatt_interpreter_workspace_bytes(int B, int L, int S) {
+  if (B <= 0 || L <= 0 || S <= 0) return 0;
+  return carve_tpi(B, L, S, 64, nullptr).total;
+}
+
+int dpmn_tatt_interpreter_f32(const dpmn_tatt_interp_weights* w, const float* x, int t_emb, const float* b1, const float* qe,
+                              const float* pos, float* tp, float* pw, void* workspace, size_t workspace_bytes, int B, int L, int S,
+                              dpmn_stream_t stream) {
+  DPMN_REQUIRE(w && x && b1 && qe && pos && tp && workspace, "tatt_interpreter: null pointer");
+  DPMN_REQUIRE(w->n_dec >= 1 && w->n_dec <= 4 && w->nhead > 0, "tatt_interpreter: 1..4 decoder layers");
+  const int E = 64;
+  TpiWs s = carve_tpi(B, L, S, E, static_cast<char*>(workspace));
+  if (s.total > workspace_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "tatt_interpreter: workspace too small");
+  const int BL = B * L, BS = B * S;
+  int rc;
+#define RUN(call) do { rc = (call); if (rc != DPMN_OK) return rc; } while (0)
+  // fc_in + PReLU (tatt.py:209-210), encoder layer with the sinusoid added to q / k (transformer_v2.py:453-470)
+  RUN(dpmn_small_linear_f32(x, nullptr, 0, w->fc_in_w, w->fc_in_b, s.src, BS, E, t_emb, DPMN_ACT_PRELU, w->fc_in_slope, stream));
+  RUN(dpmn_tatt_encoder_layer_f32(s.src, pos, w->enc, s.mem, B, S, E, w->nhead, stream));
+  const float* out = b1;
+  for (int li = 0; li < w->n_dec; ++li) {
+    const dpmn_tatt_dec_layer& d = w->dec[li];
+    const bool last = li == w->n_dec - 1;
+    // cross attention: q = (tgt + query_embed) Wq, k = (memory + pos) Wk, v = memory Wv (transformer_v2.py:826-838)
+    RUN(dpmn_add_linear_f32(out, qe, d.wq, d.bq, s.q, BL, E, E, DPMN_ACT_NONE, stream));
+    RUN(dpmn_small_linear_f32(s.mem, pos, S, d.wk, d.bk, s.k, BS, E, E, DPMN_ACT_NONE, 0.f, stream));
+    RUN(dpmn_small_linear_f32(s.mem, nullptr, 0, d.wv, d.bv, s.v, BS, E, E, DPMN_ACT_NONE, 0.f, stream));
+    RUN(dpmn_cross_attn_f32(s.q, s.k, s.v, s.o, last ? pw : nullptr, B, L, S, E, w->nhead, stream));
+    RUN(dpmn_linear_f32(s.o, d.out_w, d.out_b, out, nullptr, s.t1, BL, E, E, DPMN_ACT_NONE, 0.f, stream));
+    float* o1 = s.out[0];
+    RUN(dpmn_add_layernorm64_f32(s.t1, nullptr, d.norm2_w, d.norm2_b, o1, nullptr, nullptr, nullptr, 1.0f, 0, BL, stream));
+    // FFN (transformer_v2.py:785) + norm3; the decoder's final norm of every layer output is averaged into tp (return_intermediate)
+    RUN(dpmn_linear_f32(o1, d.lin1_w, d.lin1_b, nullptr, nullptr, s.f, BL, E, E, DPMN_ACT_RELU, 0.f, stream));
+    RUN(dpmn_linear_f32(s.f, d.lin2_w, d.lin2_b, o1, nullptr, s.t1, BL, E, E, DPMN_ACT_NONE, 0.f, stream));
+    float* o2 = s.out[1];
+    RUN(dpmn_add_layernorm64_f32(s.t1, nullptr, d.norm3_w, d.norm3_b, o2, w->dec_norm_w, w->dec_norm_b, tp, 1.0f / w->n_dec, li > 0 ? 1 : 0,
+                                 BL, stream));
+    out = o2;       // (the next layer last reads it as out_proj's residual, long before its own norm3 rewrites the buffer)
+  }
+#undef RUN
+  return DPMN_OK;
+}
+
+}  // extern "C"

@@ -131,12 +131,56 @@ class TSRN_TL_TRANS(_PSNBase):
         self._qe = (B, qe)
         return qe
 
+    def _interp_native(self, P):
+        """dpmn_tatt_interp_weights over the module's own parameter tensors (include/dpmn_hip.h), rebuilt with the pack."""
+        from .. import _abi
+        nat = getattr(self, "_inat", None)
+        if nat is not None and nat[0] is P:
+            return nat[1]
+        ig = self.infoGen
+        layers = ig.upsample_transformer.decoder.layers
+        w = _abi.TattInterpWeights()
+        w.n_dec, w.nhead = len(layers), 4
+        w.fc_in_w, w.fc_in_b, w.fc_in_slope = ig.fc_in.weight.data_ptr(), ig.fc_in.bias.data_ptr(), P["fc_in_slope"]
+        for i, t in enumerate(P["enc"]):
+            w.enc[i] = t.data_ptr()
+        for i, (d, pk) in enumerate(zip(layers, P["dec"])):
+            q = w.dec[i]
+            for n in ("wq", "bq", "wk", "bk", "wv", "bv"):
+                setattr(q, n, pk[n].data_ptr())
+            q.out_w, q.out_b = d.multihead_attn.out_proj.weight.data_ptr(), d.multihead_attn.out_proj.bias.data_ptr()
+            q.norm2_w, q.norm2_b, q.norm3_w, q.norm3_b = (t.data_ptr() for t in (d.norm2.weight, d.norm2.bias, d.norm3.weight, d.norm3.bias))
+            q.lin1_w, q.lin1_b, q.lin2_w, q.lin2_b = (t.data_ptr() for t in (d.linear1.weight, d.linear1.bias, d.linear2.weight, d.linear2.bias))
+        dn = ig.upsample_transformer.decoder.norm
+        w.dec_norm_w, w.dec_norm_b = dn.weight.data_ptr(), dn.bias.data_ptr()
+        self._inat = (P, w)
+        return w
+
     def _tp_interpreter(self, b1, text_emb, P):
         ig = self.infoGen
         B, H, W, E = b1.shape
         L = H * W
         x = text_emb.float().squeeze(2).transpose(1, 2).contiguous()          # (N, 26, 37) layout plumbing
         S = x.shape[1]
+        from . import tsrn as _tsrn
+        if _tsrn.NATIVE_TRUNK and len(ig.upsample_transformer.decoder.layers) <= 4:
+            # the whole interpreter from one native call (csrc/psn_forward.hip dpmn_tatt_interpreter_f32)
+            import ctypes as _C
+            from .._abi import lib, check, dptr, stream
+            w = self._interp_native(P)
+            pos = ig.pe.pe[0, :S].contiguous()
+            qe = self._query_embed(B, b1.device)
+            tp = torch.empty(B * L, E, device=b1.device)
+            pw = torch.empty(B, L, S, device=b1.device) if self.need_pr_weights else None
+            if not hasattr(self, "_interp_ws"):
+                self._interp_ws = {}
+            key = (B, L, S, torch.cuda.current_stream(b1.device).cuda_stream)
+            if key not in self._interp_ws:
+                self._interp_ws[key] = torch.empty(lib.dpmn_tatt_interpreter_workspace_bytes(B, L, S) // 4, device=b1.device)
+            ws = self._interp_ws[key]
+            check(lib.dpmn_tatt_interpreter_f32(_C.byref(w), dptr(x), x.shape[2], dptr(b1), dptr(qe), dptr(pos), dptr(tp), dptr(pw, True),
+                                                dptr(ws), ws.numel() * 4, B, L, S, stream()))
+            return tp.reshape(B, H, W, E), pw
         src = ops.small_linear(x.reshape(B * S, -1), ig.fc_in.weight, ig.fc_in.bias, act="prelu", slope=P["fc_in_slope"])
         pos = ig.pe.pe[0, :S].contiguous()                                     # (26, 64)
         mem = ops.tatt_encoder_layer(src.reshape(B, S, E), pos, P["enc"]).reshape(B * S, E)

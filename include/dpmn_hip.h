@@ -537,6 +537,28 @@ size_t dpmn_psn_trunk_workspace_bytes(const dpmn_psn_weights* w, int B, int H, i
 int dpmn_psn_trunk_f32(const dpmn_psn_weights* w, const float* b1, const float* tp, int tp_channels, float* out, void* workspace,
                        size_t workspace_bytes, const dpmn_cmm_scratch* scratch, int B, int H, int W, dpmn_stream_t stream);
 
+/* TPInterpreter.forward of TATT (tatt.py:196-237; InfoTransformer, transformer_v2.py) in eval mode as ONE call: fc_in + PReLU, one
+ * encoder layer over the S text slots, n_dec decoder layers (cross attention of the feature map + query embedding against the
+ * encoded slots, FFN), mean of the finally-normalised layer outputs.  nn.Linear / nn.LayerNorm / in_proj slices in their own layouts. */
+typedef struct {
+  const float *wq, *bq, *wk, *bk, *wv, *bv;       /* multihead_attn.in_proj rows [0,E) / [E,2E) / [2E,3E) */
+  const float *out_w, *out_b, *norm2_w, *norm2_b, *lin1_w, *lin1_b, *lin2_w, *lin2_b, *norm3_w, *norm3_b;
+} dpmn_tatt_dec_layer;
+typedef struct {
+  int n_dec, nhead;
+  const float *fc_in_w, *fc_in_b;
+  float fc_in_slope;                               /* nn.PReLU() single slope */
+  const float* enc[12];                            /* encoder layer: in_proj w/b, out_proj w/b, linear1 w/b, linear2 w/b, norm1 w/b, norm2 w/b */
+  dpmn_tatt_dec_layer dec[4];
+  const float *dec_norm_w, *dec_norm_b;            /* decoder.norm */
+} dpmn_tatt_interp_weights;
+size_t dpmn_tatt_interpreter_workspace_bytes(int B, int L, int S);
+/* x (B*S, t_emb) text-prior rows, b1 (B*L, 64) block1's NHWC output, qe (B*L, 64) query embedding, pos (S, 64);
+ * tp (B*L, 64) out, pw (B, L, S) attention weights of the last layer or NULL. */
+int dpmn_tatt_interpreter_f32(const dpmn_tatt_interp_weights* w, const float* x, int t_emb, const float* b1, const float* qe,
+                              const float* pos, float* tp, float* pw, void* workspace, size_t workspace_bytes, int B, int L, int S,
+                              dpmn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
