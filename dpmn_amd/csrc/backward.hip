@@ -593,7 +593,8 @@ int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int 
   DPMN_REQUIRE(dy && x && dw && M > 0 && N % 4 == 0 && K % 4 == 0, "gemm_tn: bad arguments (N, K multiples of 4)");
   const int tiles = cdiv(N, 96) * cdiv(K, 96);
   static const int want = getenv("DPMN_TN_BLOCKS") ? atoi(getenv("DPMN_TN_BLOCKS")) : 256;       // experiment knob
-  int splits = cdiv(want, tiles);
+  // (the MFMA-bound 4-tile shapes, fc1 / fc2: two blocks per CU -- 48.2 -> 45.0 us; the 1-tile shapes pay for more partial slots)
+  int splits = cdiv(tiles >= 4 && !getenv("DPMN_TN_BLOCKS") ? 2 * want : want, tiles);
   int rows = cdiv(cdiv(M, splits), 32) * 32;      // (multiples of 32: the LDS kernel's chunk; of 4: an MFMA step of the register kernel)
   if (rows < 32) rows = 32;
   splits = cdiv(M, rows);
