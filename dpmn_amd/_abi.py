@@ -115,6 +115,7 @@ SIGNATURES = {
     "dpmn_psnr_ssim_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_gemm_tn_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp, _sz, fp]),
     "dpmn_colsum_f32": (_i, [fp, fp, C.c_long, _i, fp]),
+    "dpmn_colsum_det_f32": (_i, [fp, fp, C.c_long, _i, fp, _sz, fp]),
     "dpmn_layernorm_bwd_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp]),
     "dpmn_layernorm_f32": (_i, [fp, fp, fp, _f, fp, C.c_long, _i, fp]),
     "dpmn_act_bwd_f32": (_i, [fp, fp, fp, _i, _f, C.c_long, fp]),

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ par
 // db[n] += sum_m dy[m][n].  Block = 256 threads over a (rows_per_block x N) slab: thread -> (row lane = tid / cols4,
 // float4 column = tid % cols4); LDS reduction over the row lanes, one atomic per column per block.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, int ldy, float* __restrict__ db, long M, int N,
-                                                 int rows_per_block) {
+                                                 int rows_per_block, float* __restrict__ part = nullptr) {
   __shared__ float4 red[256];
   const int cols4 = (N + 3) / 4;                       // N % 4 == 0 for every caller
   const int lanes = 256 / cols4 > 0 ? 256 / cols4 : 1; // row lanes per column group
@@ -278,8 +278,25 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, in
   if (rl == 0 && cg * 4 < N) {
     float4 a = red[cg];
     for (int r = 1; r < lanes; ++r) { const float4 v = red[r * cols4 + cg]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+    if (part) {      // deterministic form: this block's column sums go to part[block][N], summed in block order by k_colsum_finish
+      *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * N + cg * 4) = a;
+      return;
+    }
     atomicAdd(db + cg * 4, a.x); atomicAdd(db + cg * 4 + 1, a.y); atomicAdd(db + cg * 4 + 2, a.z); atomicAdd(db + cg * 4 + 3, a.w);
   }
+}
+// db[n] += sum over blocks (in block order) of part[block][n]; one thread per column, four partial chains in flight
+__global__ void k_colsum_finish(const float* __restrict__ part, float* __restrict__ db, int N, int nblocks) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += part[(size_t)b * N + n]; s1 += part[(size_t)(b + 1) * N + n];
+    s2 += part[(size_t)(b + 2) * N + n]; s3 += part[(size_t)(b + 3) * N + n];
+  }
+  for (; b < nblocks; ++b) s0 += part[(size_t)b * N + n];
+  db[n] += (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm backward
@@ -622,7 +639,21 @@ int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int 
 int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream) {
   DPMN_REQUIRE(dy && db && M > 0 && N > 0 && N % 4 == 0 && N <= 1024, "colsum: N must be a multiple of 4 (<= 1024)");
   const int rows = 256;
-  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, as_stream(stream), dy, N, db, M, N, rows);
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)((M + rows - 1) / rows)), dim3(256), 0, as_stream(stream), dy, N, db, M, N, rows,
+                     static_cast<float*>(nullptr));
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// the same without atomics: per-block partial sums in ws (ceil(M / 256) * N floats), added to db in block order -- bitwise reproducible
+int dpmn_colsum_det_f32(const float* dy, float* db, long M, int N, float* ws, size_t ws_bytes, dpmn_stream_t stream) {
+  DPMN_REQUIRE(dy && db && ws && M > 0 && N > 0 && N % 4 == 0 && N <= 1024, "colsum_det: N must be a multiple of 4 (<= 1024)");
+  const int rows = 256;
+  const long nb = (M + rows - 1) / rows;
+  if ((size_t)nb * N * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "colsum_det: workspace too small");
+  hipLaunchKernelGGL(k_colsum, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, N, db, M, N, rows, ws);
+  DPMN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), ws, db, N, (int)nb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -72,7 +72,9 @@ def gemm_tn(dy, x, dw, db=None):
 
 
 def colsum(dy, db):
-    check(lib.dpmn_colsum_f32(dptr(dy), dptr(db), dy.shape[0], dy.shape[1], stream()))
+    """db (N) += column sums of dy (M, N), without atomics (per-block partials summed in block order: bitwise reproducible)."""
+    ws = ops.splitk_workspace(dy.device)
+    check(lib.dpmn_colsum_det_f32(dptr(dy), dptr(db), dy.shape[0], dy.shape[1], dptr(ws), ws.numel() * 4, stream()))
 
 
 def linear_bwd(dy, x, w, dw, db):

@@ -284,6 +284,8 @@ int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db /* (N
                      dpmn_stream_t stream);
 /* db (N) += column sums of dy (M,N) */
 int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream);
+/* the same without atomics (per-block partial sums in ws, >= ceil(M / 256) * N floats, added in block order): bitwise reproducible */
+int dpmn_colsum_det_f32(const float* dy, float* db, long M, int N, float* ws, size_t ws_bytes, dpmn_stream_t stream);
 /* LayerNorm backward from the saved pre-norm input x; dx written or accumulated; dgamma/dbeta accumulated */
 int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
                            float* dgamma, float* dbeta, long M, int C, dpmn_stream_t stream);

@@ -291,6 +291,36 @@ def test_cmm_train_forward_backward_vs_oracle_autograd(dev, cnum):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("cnum,B", [(64, 4), (64, 6)])
+def test_cmm_backward_is_bitwise_reproducible(dev, cnum, B):
+    """Every gradient of the CMM's training step -- conv weight gradients (exclusive slots), BatchNorm backward (fp64 per-channel
+    sums folded into the last consumer), bias column sums (per-block partials in block order), the channel gate -- and both input
+    gradients are independent of the order in which workgroups finish: three runs of forward + backward give identical bits.
+    (cnum = 64, the only width the trainer builds, super_resolution.py:72: a 3 -> 16 channel first conv of a narrower CMM would
+    take the slotted-atomic weight-gradient path of the tiny convs, which is not order-independent.)"""
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    m = ComplementationModulationModule(cnum=cnum)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 97)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    x1, x2 = u("rx1", (B, 3, 32, 128), 0, 1).to(dev), u("rx2", (B, 3, 32, 128), 0, 1).to(dev)
+    cot = u("rcot", (B, 3, 32, 128), -1, 1).to(dev)
+    runs = []
+    for _ in range(3):
+        for p in m.parameters():
+            p.grad = None
+        a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        out = m(a, b)
+        (out * cot).sum().backward()
+        torch.cuda.synchronize()
+        runs.append([out.detach().clone(), a.grad.clone(), b.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+    names = ["out", "dx1", "dx2"] + [n for n, _ in m.named_parameters()]
+    for r in runs[1:]:
+        bad = [n for n, t0, t1 in zip(names, runs[0], r) if not torch.equal(t0, t1)]
+        assert not bad, "not bitwise reproducible: %s" % bad[:8]
+
+
 def test_distill_module_train_vs_oracle_autograd(dev):
     from dpmn_amd.model.distill_module import DistillModule
     from oracle import cmm as ocmm
