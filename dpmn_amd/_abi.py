@@ -117,6 +117,7 @@ SIGNATURES = {
     "dpmn_colsum_f32": (_i, [fp, fp, C.c_long, _i, fp]),
     "dpmn_colsum_det_f32": (_i, [fp, fp, C.c_long, _i, fp, _sz, fp]),
     "dpmn_layernorm_bwd_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp]),
+    "dpmn_layernorm_bwd_det_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp, _sz, fp]),
     "dpmn_layernorm_f32": (_i, [fp, fp, fp, _f, fp, C.c_long, _i, fp]),
     "dpmn_act_bwd_f32": (_i, [fp, fp, fp, _i, _f, C.c_long, fp]),
     "dpmn_act_fwd_f32": (_i, [fp, fp, _i, _f, C.c_long, fp]),

@@ -286,16 +286,17 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, in
   }
 }
 // db[n] += sum over blocks (in block order) of part[block][n]; one thread per column, four partial chains in flight
-__global__ void k_colsum_finish(const float* __restrict__ part, float* __restrict__ db, int N, int nblocks) {
+// (stride: floats between consecutive blocks' rows; the LayerNorm backward keeps [dgamma | dbeta] pairs of 2 C floats per block)
+__global__ void k_colsum_finish(const float* __restrict__ part, float* __restrict__ db, int N, int nblocks, int stride) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int b = 0;
   for (; b + 3 < nblocks; b += 4) {
-    s0 += part[(size_t)b * N + n]; s1 += part[(size_t)(b + 1) * N + n];
-    s2 += part[(size_t)(b + 2) * N + n]; s3 += part[(size_t)(b + 3) * N + n];
+    s0 += part[(size_t)b * stride + n]; s1 += part[(size_t)(b + 1) * stride + n];
+    s2 += part[(size_t)(b + 2) * stride + n]; s3 += part[(size_t)(b + 3) * stride + n];
   }
-  for (; b < nblocks; ++b) s0 += part[(size_t)b * N + n];
+  for (; b < nblocks; ++b) s0 += part[(size_t)b * stride + n];
   db[n] += (s0 + s1) + (s2 + s3);
 }
 
@@ -304,7 +305,8 @@ __global__ void k_colsum_finish(const float* __restrict__ part, float* __restric
 template <int C>
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ dy,
                                                  const float* __restrict__ gamma, float eps, float* __restrict__ dx,
-                                                 int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long M) {
+                                                 int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
+                                                 float* __restrict__ part = nullptr) {
   constexpr int PER = C / 32;
   __shared__ float red_g[8][C], red_b[8][C];
   const int sub = threadIdx.x >> 5, t = threadIdx.x & 31;   // 8 rows per block pass, 32 threads per row
@@ -384,6 +386,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
     float g = 0.f, b = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) { g += red_g[r][c]; b += red_b[r][c]; }
+    if (part) { part[(size_t)blockIdx.x * 2 * C + c] = g; part[(size_t)blockIdx.x * 2 * C + C + c] = b; continue; }   // summed in block order by k_colsum_finish
     atomicAdd(dgamma + c, g);
     atomicAdd(dbeta + c, b);
   }
@@ -395,7 +398,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
 template <int C>
 __global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, const float* __restrict__ dy,
                                                     const float* __restrict__ gamma, float eps, float* __restrict__ dx,
-                                                    int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long M) {
+                                                    int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
+                                                 float* __restrict__ part = nullptr) {
   constexpr int V = C / 32;                 // float4 per thread
   __shared__ float red_g[32][C + 4], red_b[32][C + 4];
   const int sub = threadIdx.x >> 3, t = threadIdx.x & 7;      // 32 row groups per block, 8 threads per row
@@ -496,6 +500,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, 
     float g = 0.f, b = 0.f;
 #pragma unroll
     for (int r = 0; r < 32; ++r) { g += red_g[r][c]; b += red_b[r][c]; }
+    if (part) { part[(size_t)blockIdx.x * 2 * C + c] = g; part[(size_t)blockIdx.x * 2 * C + C + c] = b; continue; }
     atomicAdd(dgamma + c, g);
     atomicAdd(dbeta + c, b);
   }
@@ -653,35 +658,54 @@ int dpmn_colsum_det_f32(const float* dy, float* db, long M, int N, float* ws, si
   if ((size_t)nb * N * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "colsum_det: workspace too small");
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, N, db, M, N, rows, ws);
   DPMN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), ws, db, N, (int)nb);
+  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), ws, db, N, (int)nb, N);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
 
-int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
-                           float* dgamma, float* dbeta, long M, int C, dpmn_stream_t stream) {
+static int layernorm_bwd_impl(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
+                              float* dgamma, float* dbeta, long M, int C, float* part, size_t part_bytes, dpmn_stream_t stream) {
   DPMN_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && M > 0, "layernorm_bwd: bad arguments");
+  DPMN_REQUIRE(!part || part_bytes >= (size_t)512 * 2 * C * sizeof(float), "layernorm_bwd_det: workspace of 512 * 2 C floats");
   // every block ends with 2*C same-address atomics (dgamma, dbeta), which serialise: few, fat blocks (4 rows in flight per
   // 32-thread group).  In-pipeline sweep at M = 49152: 256 blocks 46.6 us, 512: 36.9, 1024: 41.9, 2048: 59.9
   static const long cap = getenv("DPMN_LNB_BLOCKS") ? atol(getenv("DPMN_LNB_BLOCKS")) : 512;
   const unsigned blocks = (unsigned)(M / 8 < cap ? (M + 7) / 8 : cap);
+  unsigned nblk = blocks;
   static const int v4 = getenv("DPMN_LNB_V4") ? atoi(getenv("DPMN_LNB_V4")) : 1;
   if (C == 96 && v4) {
     // in-pipeline sweep of the vector kernel at M = 49152: 256 blocks 20.2 us, 384: 21.2, 512: 24.3, 768: 27.6, 1024: 33.3
     // (the scalar kernel it replaces: 36.8 us) -- one block per CU, the same-address dgamma / dbeta atomics set the slope
     static const long cap4 = getenv("DPMN_LNB_BLOCKS") ? atol(getenv("DPMN_LNB_BLOCKS")) : 256;
     const unsigned b4 = (unsigned)(M / 32 < cap4 ? (M + 31) / 32 : cap4);
-    hipLaunchKernelGGL((k_ln_bwd_v4<96>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
+    hipLaunchKernelGGL((k_ln_bwd_v4<96>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
+    nblk = b4;
   } else if (C == 96)
-    hipLaunchKernelGGL((k_ln_bwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
+    hipLaunchKernelGGL((k_ln_bwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
   else if (C == 192)
-    hipLaunchKernelGGL((k_ln_bwd<192>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
+    hipLaunchKernelGGL((k_ln_bwd<192>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
   else if (C == 64)
-    hipLaunchKernelGGL((k_ln_bwd<64>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M);
+    hipLaunchKernelGGL((k_ln_bwd<64>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
   else
     return dpmn_set_error(DPMN_ERR_ARG, "layernorm_bwd: C must be 64, 96 or 192");
   DPMN_CHECK_LAUNCH();
+  if (part) {      // the blocks' [dgamma | dbeta] rows, added in block order (no atomics: bitwise reproducible)
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), part, dgamma, C, (int)nblk, 2 * C);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), part + C, dbeta, C, (int)nblk, 2 * C);
+    DPMN_CHECK_LAUNCH();
+  }
   return DPMN_OK;
+}
+
+int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
+                           float* dgamma, float* dbeta, long M, int C, dpmn_stream_t stream) {
+  return layernorm_bwd_impl(x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, C, nullptr, 0, stream);
+}
+
+int dpmn_layernorm_bwd_det_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
+                               float* dgamma, float* dbeta, long M, int C, float* ws, size_t ws_bytes, dpmn_stream_t stream) {
+  DPMN_REQUIRE(ws, "layernorm_bwd_det: null workspace");
+  return layernorm_bwd_impl(x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, C, ws, ws_bytes, stream);
 }
 
 int dpmn_act_bwd_f32(const float* dy, const float* pre, float* dpre, int act, float slope, long n, dpmn_stream_t stream) {

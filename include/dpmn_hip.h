@@ -289,6 +289,9 @@ int dpmn_colsum_det_f32(const float* dy, float* db, long M, int N, float* ws, si
 /* LayerNorm backward from the saved pre-norm input x; dx written or accumulated; dgamma/dbeta accumulated */
 int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
                            float* dgamma, float* dbeta, long M, int C, dpmn_stream_t stream);
+/* the same without atomics: per-block [dgamma | dbeta] partials in ws (>= 512 * 2 C floats), added in block order */
+int dpmn_layernorm_bwd_det_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
+                               float* dgamma, float* dbeta, long M, int C, float* ws, size_t ws_bytes, dpmn_stream_t stream);
 int dpmn_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, long M, int C,
                        dpmn_stream_t stream);
 /* dpre = dy * act'(pre) ; y = act(x) */

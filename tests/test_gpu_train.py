@@ -97,9 +97,12 @@ def test_pgrm_backward_vs_oracle_autograd(dev, it, mode):
 
 @pytest.mark.parametrize("M", [49, 1000, 4096])
 @pytest.mark.parametrize("accumulate", [False, True])
-def test_layernorm_backward_ragged_rows_vs_torch(dev, M, accumulate):
-    """dpmn_layernorm_bwd_f32 (vector kernel: 32 rows per block pass, rows past M clamped and masked) vs torch autograd."""
+@pytest.mark.parametrize("det", [False, True])
+def test_layernorm_backward_ragged_rows_vs_torch(dev, M, accumulate, det, monkeypatch):
+    """dpmn_layernorm_bwd_f32 (vector kernel: 32 rows per block pass, rows past M clamped and masked) and its atomics-free form
+    dpmn_layernorm_bwd_det_f32 (per-block dgamma / dbeta partials added in block order) vs torch autograd."""
     from dpmn_amd.train import pgrm_train
+    monkeypatch.setattr(pgrm_train, "LNB_DET", det)
     C = 96
     x = u("lnx", (M, C), -2, 3).requires_grad_(True)
     g, b = u("lng", (C,), 0.5, 1.5).requires_grad_(True), u("lnb", (C,)).requires_grad_(True)
