@@ -75,6 +75,10 @@ class TattInterpWeights(C.Structure):
                 ("dec", TattDecLayer * 4), ("dec_norm_w", fp), ("dec_norm_b", fp)]
 
 
+class TnPending(C.Structure):
+    _fields_ = [("part", fp), ("dw", fp), ("db", fp), ("NK", C.c_int), ("N", C.c_int), ("splits", C.c_int)]
+
+
 class CmmScratch(C.Structure):
     _fields_ = [("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t), ("arrive_cnt", fp), ("arrive_cnt_len", C.c_int)]
 
@@ -114,6 +118,9 @@ SIGNATURES = {
     "dpmn_psnr_ssim_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpmn_psnr_ssim_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_gemm_tn_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp, _sz, fp]),
+    "dpmn_gemm_tn_partial_bytes": (_sz, [_i, _i, _i]),
+    "dpmn_gemm_tn_partial_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp, _sz, C.POINTER(TnPending), fp]),
+    "dpmn_tn_reduce_multi_f32": (_i, [C.POINTER(TnPending), _i, fp]),
     "dpmn_colsum_f32": (_i, [fp, fp, C.c_long, _i, fp]),
     "dpmn_colsum_det_f32": (_i, [fp, fp, C.c_long, _i, fp, _sz, fp]),
     "dpmn_layernorm_bwd_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp]),

@@ -247,6 +247,41 @@ __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ par
   }
 }
 
+// up to 16 pending reductions in ONE launch (the weight gradients of a whole PGRM backward: 14 separate k_tn_reduce launches of
+// ~6 us each were paid at the launch rate of the two-stream backward).  Same per-element arithmetic as k_tn_reduce.
+struct TnMulti {
+  dpmn_tn_pending d[16];
+  int first_block[17];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_tn_reduce_multi(TnMulti m) {
+  __shared__ float red[4][64];
+  int i = 0;
+  while (i + 1 < m.n && (int)blockIdx.x >= m.first_block[i + 1]) ++i;
+  const dpmn_tn_pending& d = m.d[i];
+  const float* part = d.part;
+  const int NK = d.NK, N = d.N, splits = d.splits;
+  const int e = ((int)blockIdx.x - m.first_block[i]) * 64 + (threadIdx.x & 63), zg = threadIdx.x >> 6;
+  const int tot = NK + (d.db ? N : 0);
+  const size_t zs = (size_t)NK + N;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < tot) {
+    int z = zg;
+    for (; z + 12 < splits; z += 16) {
+      s0 += part[(size_t)z * zs + e]; s1 += part[(size_t)(z + 4) * zs + e];
+      s2 += part[(size_t)(z + 8) * zs + e]; s3 += part[(size_t)(z + 12) * zs + e];
+    }
+    for (; z < splits; z += 4) s0 += part[(size_t)z * zs + e];
+  }
+  red[zg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (zg == 0 && e < tot) {
+    const int c = threadIdx.x;
+    const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    if (e < NK) d.dw[e] += v; else d.db[e - NK] += v;
+  }
+}
+
 // db[n] += sum_m dy[m][n].  Block = 256 threads over a (rows_per_block x N) slab: thread -> (row lane = tid / cols4,
 // float4 column = tid % cols4); LDS reduction over the row lanes, one atomic per column per block.
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, int ldy, float* __restrict__ db, long M, int N,
@@ -610,16 +645,23 @@ __global__ void k_image_loss_bwd(const float* __restrict__ o, long o_stride, con
 
 extern "C" {
 
-int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
-                     dpmn_stream_t stream) {
-  DPMN_REQUIRE(dy && x && dw && M > 0 && N % 4 == 0 && K % 4 == 0, "gemm_tn: bad arguments (N, K multiples of 4)");
+static void tn_plan(int M, int N, int K, int* splits_out, int* rows_out) {
   const int tiles = cdiv(N, 96) * cdiv(K, 96);
   static const int want = getenv("DPMN_TN_BLOCKS") ? atoi(getenv("DPMN_TN_BLOCKS")) : 256;       // experiment knob
   // (the MFMA-bound 4-tile shapes, fc1 / fc2: two blocks per CU -- 48.2 -> 45.0 us; the 1-tile shapes pay for more partial slots)
   int splits = cdiv(tiles >= 4 && !getenv("DPMN_TN_BLOCKS") ? 2 * want : want, tiles);
   int rows = cdiv(cdiv(M, splits), 32) * 32;      // (multiples of 32: the LDS kernel's chunk; of 4: an MFMA step of the register kernel)
   if (rows < 32) rows = 32;
-  splits = cdiv(M, rows);
+  *splits_out = cdiv(M, rows);
+  *rows_out = rows;
+}
+
+// split plan + launch of the partial-sum kernel; defer != nullptr: no reduce launch, the caller gets the descriptor of the pending one
+static int gemm_tn_impl(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
+                        dpmn_tn_pending* defer, dpmn_stream_t stream) {
+  DPMN_REQUIRE(dy && x && dw && M > 0 && N % 4 == 0 && K % 4 == 0, "gemm_tn: bad arguments (N, K multiples of 4)");
+  int splits, rows;
+  tn_plan(M, N, K, &splits, &rows);
   dim3 grid(cdiv(N, 96), cdiv(K, 96), splits);
   // with a workspace the splits are reduced by a second kernel (deterministic, no same-address atomic pile-up);
   // without one they are accumulated with fp32 atomics
@@ -633,9 +675,50 @@ int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int 
   else
     hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, as_stream(stream), dy, N, x, K, dw, K, M, N, K, rows, db, part);
   DPMN_CHECK_LAUNCH();
+  if (defer) {
+    DPMN_REQUIRE(part, "gemm_tn_partial: the workspace must hold the split partials (dpmn_gemm_tn_partial_bytes)");
+    *defer = dpmn_tn_pending{part, dw, db, N * K, N, splits};
+    return DPMN_OK;
+  }
   if (part) {
     const int tot = N * K + (db ? N : 0);
     hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(tot, 64)), dim3(256), 0, as_stream(stream), part, dw, db, N * K, N, splits);
+    DPMN_CHECK_LAUNCH();
+  }
+  return DPMN_OK;
+}
+
+int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
+                     dpmn_stream_t stream) {
+  return gemm_tn_impl(dy, x, dw, db, M, N, K, ws, ws_bytes, nullptr, stream);
+}
+
+size_t dpmn_gemm_tn_partial_bytes(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int splits, rows;
+  tn_plan(M, N, K, &splits, &rows);
+  return ((size_t)splits * ((size_t)N * K + N) * sizeof(float) + 255) / 256 * 256;
+}
+
+int dpmn_gemm_tn_partial_f32(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
+                             dpmn_tn_pending* pending, dpmn_stream_t stream) {
+  DPMN_REQUIRE(pending && ws, "gemm_tn_partial: null pointer");
+  return gemm_tn_impl(dy, x, dw, db, M, N, K, ws, ws_bytes, pending, stream);
+}
+
+int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending, int n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(pending && n >= 0, "tn_reduce_multi: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += 16) {
+    TnMulti m{};
+    m.n = n - i0 < 16 ? n - i0 : 16;
+    int nb = 0;
+    for (int i = 0; i < m.n; ++i) {
+      m.d[i] = pending[i0 + i];
+      m.first_block[i] = nb;
+      nb += cdiv(m.d[i].NK + (m.d[i].db ? m.d[i].N : 0), 64);
+    }
+    m.first_block[m.n] = nb;
+    hipLaunchKernelGGL(k_tn_reduce_multi, dim3(nb), dim3(256), 0, as_stream(stream), m);
     DPMN_CHECK_LAUNCH();
   }
   return DPMN_OK;

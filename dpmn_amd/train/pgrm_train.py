@@ -76,11 +76,52 @@ def act_bwd(dy, pre, act=GELU):
     return d
 
 
-def gemm_tn(dy, x, dw, db=None):
-    """dw (N,K) += dy (M,N)^T x (M,K) ; db (N) += column sums of dy (fused into the same kernel)"""
+TN_DEFER = os.environ.get("DPMN_TN_DEFER", "1") != "0"
+_TN_WS = {}
+_tn_pending = None     # set by backward() for one PGRM backward: [workspace, bytes used, [TnPending, ...], keep-alive tensors]
+
+
+def _tn_workspace(device):
+    """partial-sum regions of the deferred Linear weight gradients of one PGRM backward (per device and stream)."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _TN_WS:
+        _TN_WS[key] = torch.empty(48 << 20, device=device)      # 192 MB: the 14 Linear layers of a dim-96 PGRM need ~120 MB at B = 48
+    return _TN_WS[key]
+
+
+def tn_flush():
+    """One reduce launch for every pending Linear weight gradient (dpmn_tn_reduce_multi_f32)."""
+    if _tn_pending is None or not _tn_pending[2]:
+        return
+    arr = (_abi.TnPending * len(_tn_pending[2]))(*_tn_pending[2])
+    check(lib.dpmn_tn_reduce_multi_f32(arr, len(_tn_pending[2]), stream()))
+    _tn_pending[1] = 0
+    _tn_pending[2].clear()
+    _tn_pending[3].clear()
+
+
+def gemm_tn(dy, x, dw, db=None, leaf=True):
+    """dw (N,K) += dy (M,N)^T x (M,K) ; db (N) += column sums of dy (fused into the same kernel).
+    Inside a PGRM backward (leaf=True: nothing reads dw / db before its end) only the split partial sums are launched, each into
+    its own region of a per-stream workspace; ONE reduce launch at the end adds them all (tn_flush) -- 14 small launches less per
+    PGRM backward, whose two-stream phase is launch-rate sensitive."""
+    M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
+    if _tn_pending is not None and leaf:
+        need = lib.dpmn_gemm_tn_partial_bytes(M, N, K)
+        ws = _tn_pending[0]
+        if _tn_pending[1] + need > ws.numel() * 4:
+            tn_flush()
+        if need <= ws.numel() * 4:
+            pend = _abi.TnPending()
+            import ctypes as _C
+            check(lib.dpmn_gemm_tn_partial_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), M, N, K, ws.data_ptr() + _tn_pending[1], need,
+                                               _C.byref(pend), stream()))
+            _tn_pending[1] += need
+            _tn_pending[2].append(pend)
+            _tn_pending[3].append((dw, db))
+            return
     ws = ops.splitk_workspace(dy.device)
-    check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), dy.shape[0], dy.shape[1], x.shape[1], dptr(ws),
-                               ws.numel() * 4, stream()))
+    check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), M, N, K, dptr(ws), ws.numel() * 4, stream()))
 
 
 def colsum(dy, db):
@@ -393,7 +434,7 @@ def backward(m, sv, dout, need_dx_kv=True):
                                            dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
                                            dptr(gr[pe.norm.weight]), dptr(gr[pe.norm.bias]), B, img.shape[2], img.shape[3], Cd, stream()))
         dw16 = zeros(Cd, 16)
-        gemm_tn(dconv, patches, dw16, gr[pe.proj.bias])
+        gemm_tn(dconv, patches, dw16, gr[pe.proj.bias], leaf=False)      # dw16 is read right below
         gr[pe.proj.weight] += dw16[:, :12].reshape(pe.proj.weight.shape)
         need_din = fuse or (which == "kv" and need_dx_kv)
         if need_din:
@@ -423,8 +464,15 @@ class PGRMFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        global _tn_pending
         m = ctx.m
-        dx_kv, dres, gr, direct = backward(m, ctx.sv, dout, need_dx_kv=ctx.need_kv)
+        if TN_DEFER and not torch.cuda.is_current_stream_capturing():
+            _tn_pending = [_tn_workspace(dout.device), 0, [], []]
+        try:
+            dx_kv, dres, gr, direct = backward(m, ctx.sv, dout, need_dx_kv=ctx.need_kv)
+            tn_flush()          # every Linear weight gradient is in place before the bucket is signalled
+        finally:
+            _tn_pending = None
         ctx.sv = None
         dres_out = [None if d is None else d for d in dres] + [None] * (ctx.n_res - len(dres))
         return (None, None, dx_kv, None) + tuple(dres_out[:ctx.n_res]) + finish_grads(m, gr, direct)

@@ -282,6 +282,19 @@ int dpmn_psnr_ssim_f32(const float* x, long x_stride, const float* y, long y_str
 int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db /* (N) += column sums of dy, or NULL */, int M,
                      int N, int K, float* ws /* split partials; NULL or too small: fp32 atomics instead */, size_t ws_bytes,
                      dpmn_stream_t stream);
+/* the same in two steps, for callers that issue many of them: dpmn_gemm_tn_partial_f32 launches only the split partial sums (into
+ * ws, >= dpmn_gemm_tn_partial_bytes; every pending call needs its OWN region) and fills *pending; dpmn_tn_reduce_multi_f32 then adds
+ * any number of pending results into their dw / db in one launch per 16 (same arithmetic and order as the single-call form). */
+typedef struct {
+  const float* part;
+  float* dw;
+  float* db;
+  int NK, N, splits;
+} dpmn_tn_pending;
+size_t dpmn_gemm_tn_partial_bytes(int M, int N, int K);
+int dpmn_gemm_tn_partial_f32(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
+                             dpmn_tn_pending* pending, dpmn_stream_t stream);
+int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending /* HOST array */, int n, dpmn_stream_t stream);
 /* db (N) += column sums of dy (M,N) */
 int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream);
 /* the same without atomics (per-block partial sums in ws, >= ceil(M / 256) * N floats, added in block order): bitwise reproducible */
