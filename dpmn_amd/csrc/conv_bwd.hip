@@ -572,11 +572,6 @@ __global__ __launch_bounds__(256) void k_affine_act_bwd_stats(const float* __res
     }
   }
 }
-// fp64 (2, C) sums -> the fp32 pair k_bn_bwd_apply reads
-__global__ void k_sums_to_f32(const double* __restrict__ s, float* __restrict__ o, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) o[i] = (float)s[i];
-}
 // sums (2,C): sum G, sum G * xhat
 __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__ G, const float* __restrict__ r,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -630,20 +625,22 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const float* __restrict__
   }
 }
 // dr = gamma*rstd*(G - sums0/count - xhat*sums1/count) ; dgamma += sums1 ; dbeta += sums0 (done once by block 0)
+template <typename ST>      // sums as fp32 (k_bn_bwd_reduce) or fp64 (k_affine_act_bwd_stats): converted on load, no separate pass
 __global__ void k_bn_bwd_apply(const float* __restrict__ G, const float* __restrict__ r, const float* __restrict__ gamma,
-                               const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ sums,
+                               const float* __restrict__ mean, const float* __restrict__ rstd, const ST* __restrict__ sums,
                                float count, float* __restrict__ dr, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                long pixels, int C) {
   // one float4 (4 channels of one pixel) per thread; C % 4 == 0
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < C && dgamma) { atomicAdd(dgamma + idx, sums[C + idx]); atomicAdd(dbeta + idx, sums[idx]); }
+  if (idx < C && dgamma) { atomicAdd(dgamma + idx, (float)sums[C + idx]); atomicAdd(dbeta + idx, (float)sums[idx]); }
   const long e = idx * 4;
   if (e >= pixels * C) return;
   const int c = (int)(e % C);
   const float4 g4 = *reinterpret_cast<const float4*>(G + e), r4 = *reinterpret_cast<const float4*>(r + e);
   const float4 ga = *reinterpret_cast<const float4*>(gamma + c), mu = *reinterpret_cast<const float4*>(mean + c);
   const float4 rs = *reinterpret_cast<const float4*>(rstd + c);
-  const float4 a0 = *reinterpret_cast<const float4*>(sums + c), a1 = *reinterpret_cast<const float4*>(sums + C + c);
+  const float4 a0 = make_float4((float)sums[c], (float)sums[c + 1], (float)sums[c + 2], (float)sums[c + 3]);
+  const float4 a1 = make_float4((float)sums[C + c], (float)sums[C + c + 1], (float)sums[C + c + 2], (float)sums[C + c + 3]);
   float4 o;
   o.x = ga.x * rs.x * (g4.x - a0.x / count - (r4.x - mu.x) * rs.x * a1.x / count);
   o.y = ga.y * rs.y * (g4.y - a0.y / count - (r4.y - mu.y) * rs.y * a1.y / count);
@@ -980,12 +977,11 @@ int dpmn_affine_act_bwd_stats_f32(const float* dA, const float* r, const float* 
 int dpmn_bn_bwd_apply_f32(const float* G, const float* r, const float* gamma, const float* mean, const float* rstd, const double* sums,
                           float* sums_ws, float* dr, float* dgamma, float* dbeta, long pixels, int C, dpmn_stream_t stream) {
   DPMN_REQUIRE(G && r && gamma && mean && rstd && sums && sums_ws && dr && dgamma && dbeta && pixels > 1 && C % 4 == 0, "bn_bwd_apply: bad arguments");
-  hipLaunchKernelGGL(k_sums_to_f32, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, as_stream(stream), sums, sums_ws, 2 * C);
-  DPMN_CHECK_LAUNCH();
+  (void)sums_ws;      // (the fp64 sums are converted on load)
   long total = pixels * C / 4;
   if (total < C) total = C;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), G, r, gamma, mean, rstd,
-                     sums_ws, (float)pixels, dr, dgamma, dbeta, pixels, C);
+  hipLaunchKernelGGL(k_bn_bwd_apply<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), G, r, gamma, mean, rstd,
+                     sums, (float)pixels, dr, dgamma, dbeta, pixels, C);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -1002,7 +998,7 @@ int dpmn_bn_bwd_f32(const float* G, const float* r, const float* gamma, const fl
   DPMN_CHECK_LAUNCH();
   long total = pixels * C / 4;                 // one float4 per thread; at least C threads for the dgamma / dbeta adds
   if (total < C) total = C;
-  hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), G, r, gamma, mean, rstd,
+  hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), G, r, gamma, mean, rstd,
                      sums_ws, (float)pixels, dr, dgamma, dbeta, pixels, C);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
