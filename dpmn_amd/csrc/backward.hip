@@ -666,7 +666,7 @@ static int gemm_tn_impl(const float* dy, const float* x, float* dw, float* db, i
   // with a workspace the splits are reduced by a second kernel (deterministic, no same-address atomic pile-up);
   // without one they are accumulated with fp32 atomics
   const size_t need = (size_t)splits * ((size_t)N * K + N) * sizeof(float);
-  float* part = (ws && ws_bytes >= need && splits > 1) ? ws : nullptr;
+  float* part = (ws && ws_bytes >= need && (splits > 1 || defer)) ? ws : nullptr;      // (deferred: also a single split goes through the reduce)
   // operands straight from global memory into the MFMA registers when a wave's 48 columns tile N and K (every Linear of the
   // PGRM block: 96 / 192 / 384) and the byte offsets fit the buffer instructions
   static const int reg_on = getenv("DPMN_TN_REG") ? atoi(getenv("DPMN_TN_REG")) : 1;
