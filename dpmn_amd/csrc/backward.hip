@@ -313,26 +313,12 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ dy, in
   if (rl == 0 && cg * 4 < N) {
     float4 a = red[cg];
     for (int r = 1; r < lanes; ++r) { const float4 v = red[r * cols4 + cg]; a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
-    if (part) {      // deterministic form: this block's column sums go to part[block][N], summed in block order by k_colsum_finish
+    if (part) {      // deterministic form: this block's column sums go to part[block][N], summed in block order by k_tn_reduce
       *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * N + cg * 4) = a;
       return;
     }
     atomicAdd(db + cg * 4, a.x); atomicAdd(db + cg * 4 + 1, a.y); atomicAdd(db + cg * 4 + 2, a.z); atomicAdd(db + cg * 4 + 3, a.w);
   }
-}
-// db[n] += sum over blocks (in block order) of part[block][n]; one thread per column, four partial chains in flight
-// (stride: floats between consecutive blocks' rows; the LayerNorm backward keeps [dgamma | dbeta] pairs of 2 C floats per block)
-__global__ void k_colsum_finish(const float* __restrict__ part, float* __restrict__ db, int N, int nblocks, int stride) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
-    s0 += part[(size_t)b * stride + n]; s1 += part[(size_t)(b + 1) * stride + n];
-    s2 += part[(size_t)(b + 2) * stride + n]; s3 += part[(size_t)(b + 3) * stride + n];
-  }
-  for (; b < nblocks; ++b) s0 += part[(size_t)b * stride + n];
-  db[n] += (s0 + s1) + (s2 + s3);
 }
 
 // ---------------------------------------------------------------------------------- LayerNorm backward
@@ -421,7 +407,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
     float g = 0.f, b = 0.f;
 #pragma unroll
     for (int r = 0; r < 8; ++r) { g += red_g[r][c]; b += red_b[r][c]; }
-    if (part) { part[(size_t)blockIdx.x * 2 * C + c] = g; part[(size_t)blockIdx.x * 2 * C + C + c] = b; continue; }   // summed in block order by k_colsum_finish
+    if (part) { part[(size_t)blockIdx.x * 2 * C + c] = g; part[(size_t)blockIdx.x * 2 * C + C + c] = b; continue; }   // summed in block order by k_tn_reduce
     atomicAdd(dgamma + c, g);
     atomicAdd(dbeta + c, b);
   }
@@ -741,7 +727,8 @@ int dpmn_colsum_det_f32(const float* dy, float* db, long M, int N, float* ws, si
   if ((size_t)nb * N * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "colsum_det: workspace too small");
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, N, db, M, N, rows, ws);
   DPMN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, as_stream(stream), ws, db, N, (int)nb, N);
+  // (the block-order sum of the partial rows is k_tn_reduce's job: 64 columns x 4 split groups per block, fixed order)
+  hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(N, 64)), dim3(256), 0, as_stream(stream), ws, db, static_cast<float*>(nullptr), N, 0, (int)nb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -773,8 +760,8 @@ static int layernorm_bwd_impl(const float* x, const float* dy, const float* gamm
     return dpmn_set_error(DPMN_ERR_ARG, "layernorm_bwd: C must be 64, 96 or 192");
   DPMN_CHECK_LAUNCH();
   if (part) {      // the blocks' [dgamma | dbeta] rows, added in block order (no atomics: bitwise reproducible)
-    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), part, dgamma, C, (int)nblk, 2 * C);
-    hipLaunchKernelGGL(k_colsum_finish, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), part + C, dbeta, C, (int)nblk, 2 * C);
+    // one launch: k_tn_reduce's [N * K | N] row layout with N * K = C (-> dgamma) and N = C (-> dbeta)
+    hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(2 * C, 64)), dim3(256), 0, as_stream(stream), part, dgamma, dbeta, C, C, (int)nblk);
     DPMN_CHECK_LAUNCH();
   }
   return DPMN_OK;

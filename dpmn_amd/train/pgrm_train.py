@@ -47,10 +47,10 @@ def layernorm(x, w, b):
     return y
 
 
-# 1: dgamma / dbeta as per-block partials added in block order (dpmn_layernorm_bwd_det_f32: bitwise reproducible, two more small
-# launches per call -- measured +0.6 ms per training step, 36 calls: the two-stream PGRM backward is launch-rate sensitive);
-# default: the atomics
-LNB_DET = os.environ.get("DPMN_LNB_DET", "0") != "0"
+# 1 (default): dgamma / dbeta as per-block partials added in block order by ONE k_tn_reduce launch (dpmn_layernorm_bwd_det_f32:
+# bitwise reproducible; measured the same step time as the atomics -- with two finish launches per call it had cost +0.6 ms per
+# step: every tiny serial launch of the two-stream PGRM backward is paid in wall time); 0: the atomics
+LNB_DET = os.environ.get("DPMN_LNB_DET", "1") != "0"
 
 
 def layernorm_bwd(x, dy, w, dx, accumulate, dgamma, dbeta):
