@@ -130,6 +130,9 @@ SIGNATURES = {
     "dpmn_act_fwd_f32": (_i, [fp, fp, _i, _f, C.c_long, fp]),
     "dpmn_axpby_f32": (_i, [fp, fp, fp, _f, _f, _i, C.c_long, fp]),
     "dpmn_rowsum_mod_f32": (_i, [fp, fp, C.c_long, _i, _i, fp]),
+    "dpmn_rows_reduce_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_rowsum_mod_det_f32": (_i, [fp, fp, C.c_long, _i, _i, fp, _sz, fp]),
+    "dpmn_dwconv3x3_bwd_fused_det_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _f, _u64, _i, _i, _i, fp, _sz, fp]),
     "dpmn_image_loss_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpmn_image_loss_fwd_f32": (_i, [fp, C.c_long, fp, C.c_long, _f, _f, _i, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_image_loss_bwd_f32": (_i, [fp, C.c_long, fp, C.c_long, fp, fp, fp, _f, _f, _i, fp, _i, _i, _i, _i, _i, fp]),

@@ -710,6 +710,15 @@ int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending, int n, dpmn_stream_
   return DPMN_OK;
 }
 
+// dw[e] += sum_z part[z][e] (e < NK), db[n] += sum_z part[z][NK + n]: rows of NK + N floats added in row order (k_tn_reduce) -- the
+// finish step of every "per-block / per-image partials instead of atomics" gradient in backward_pgrm.hip
+int dpmn_rows_reduce_f32(const float* part, float* dw, float* db, int NK, int N, int rows, dpmn_stream_t stream) {
+  DPMN_REQUIRE(part && dw && NK > 0 && N >= 0 && rows > 0 && (db || N == 0), "rows_reduce: bad arguments");
+  hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(NK + N, 64)), dim3(256), 0, as_stream(stream), part, dw, db, NK, N, rows);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
 int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream) {
   DPMN_REQUIRE(dy && db && M > 0 && N > 0 && N % 4 == 0 && N <= 1024, "colsum: N must be a multiple of 4 (<= 1024)");
   const int rows = 256;

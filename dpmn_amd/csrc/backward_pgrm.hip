@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P,
                                                      const float* __restrict__ w, float* __restrict__ dP, float* __restrict__ dw,
                                                      float* __restrict__ db, int Ch, int r, long planes,
                                                      const float* __restrict__ gpre = nullptr, int in_gelu = 0, int out_gelu_bwd = 0,
-                                                     float p_drop = 0.f, unsigned long long seed = 0ull) {
+                                                     float p_drop = 0.f, unsigned long long seed = 0ull, float* __restrict__ part = nullptr) {
   // p_drop > 0: the forward input was dropout(GELU(P)) -- the same mask on load, and again on dP before GELU'
   const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   // per wave: P tile and dg tile, (r+2) rows x LD = r+8 floats, plane starting at column 4 (16-byte aligned rows, r % 4 == 0)
@@ -586,9 +586,19 @@ __global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P,
     *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
   }
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { const float s = wave_sum(aw[i]); if (lane == 0) atomicAdd(dw + c * 9 + i, s); }
+  for (int i = 0; i < 9; ++i) {
+    const float s = wave_sum(aw[i]);
+    if (lane == 0) {
+      // part: image b's row [Ch * 9 weight sums | Ch bias sums], added over the images in order by dpmn_rows_reduce_f32 (no atomics)
+      if (part) part[(plane / Ch) * (long)(Ch * 10) + c * 9 + i] = s;
+      else atomicAdd(dw + c * 9 + i, s);
+    }
+  }
   ab = wave_sum(ab);
-  if (lane == 0) atomicAdd(db + c, ab);
+  if (lane == 0) {
+    if (part) part[(plane / Ch) * (long)(Ch * 10) + Ch * 9 + c] = ab;
+    else atomicAdd(db + c, ab);
+  }
 }
 
 // ---------------------------------------------------------------------------------- small elementwise helpers
@@ -658,7 +668,7 @@ __global__ void k_axpby(const float* __restrict__ x, const float* __restrict__ z
 }
 // rowsum: out[r] += sum_c x[r*cols + c]  (bias gradient of the pointwise conv over the raw (B*Ch, L) view folded per channel)
 __global__ __launch_bounds__(256) void k_rowsum_mod(const float* __restrict__ x, float* __restrict__ out, long rows, int cols,
-                                                     int mod) {
+                                                     int mod, float* __restrict__ part = nullptr) {
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -673,7 +683,10 @@ __global__ __launch_bounds__(256) void k_rowsum_mod(const float* __restrict__ x,
     for (int c = lane; c < cols; c += 64) s += x[row * cols + c];
   }
   s = wave_sum(s);
-  if (lane == 0) atomicAdd(out + row % mod, s);
+  if (lane == 0) {
+    if (part) part[row] = s;      // (rows / mod, mod): added over the leading axis in order by dpmn_rows_reduce_f32
+    else atomicAdd(out + row % mod, s);
+  }
 }
 
 // ---------------------------------------------------------------------------------- PGRM tail (training variant)
@@ -983,6 +996,30 @@ int dpmn_dwconv3x3_bwd_fused_f32(const float* P, const float* dg, const float* g
                      planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
+}
+
+// the same without atomics: per-image [Ch * 9 | Ch] partial rows in ws (B * Ch * 10 floats), added in image order -- bitwise reproducible
+int dpmn_dwconv3x3_bwd_fused_det_f32(const float* P, const float* dg, const float* gpre, const float* w, float* dP, float* dw, float* db,
+                                     int in_gelu, int out_gelu_bwd, float p_drop, unsigned long long seed, int B, int Ch, int r,
+                                     float* ws, size_t ws_bytes, dpmn_stream_t stream) {
+  DPMN_REQUIRE(P && dg && w && dP && dw && db && ws && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_bwd_fused_det: bad arguments");
+  DPMN_REQUIRE(!out_gelu_bwd || in_gelu, "dwconv_bwd_fused_det: out_gelu_bwd needs P to be the pre-activation (in_gelu)");
+  if ((size_t)B * Ch * 10 * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "dwconv_bwd_fused_det: workspace too small");
+  const long planes = (long)B * Ch;
+  const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+                     planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, ws);
+  DPMN_CHECK_LAUNCH();
+  return dpmn_rows_reduce_f32(ws, dw, db, Ch * 9, Ch, B, stream);
+}
+
+int dpmn_rowsum_mod_det_f32(const float* x, float* out, long rows, int cols, int mod, float* ws, size_t ws_bytes, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && out && ws && rows > 0 && cols > 0 && mod > 0 && rows % mod == 0, "rowsum_mod_det: bad arguments (rows a multiple of mod)");
+  if ((size_t)rows * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "rowsum_mod_det: workspace too small");
+  hipLaunchKernelGGL(k_rowsum_mod, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, as_stream(stream), x, out, rows, cols, mod, ws);
+  DPMN_CHECK_LAUNCH();
+  return dpmn_rows_reduce_f32(ws, out, nullptr, mod, 0, (int)(rows / mod), stream);
 }
 
 int dpmn_act_fwd_f32(const float* x, float* y, int act, float slope, long n, dpmn_stream_t stream) {

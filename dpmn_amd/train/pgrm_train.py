@@ -51,6 +51,8 @@ def layernorm(x, w, b):
 # bitwise reproducible; measured the same step time as the atomics -- with two finish launches per call it had cost +0.6 ms per
 # step: every tiny serial launch of the two-stream PGRM backward is paid in wall time); 0: the atomics
 LNB_DET = os.environ.get("DPMN_LNB_DET", "1") != "0"
+# depthwise-conv weight / bias and pointwise-conv bias gradients as per-image partial rows added in image order (no atomics)
+DET_SMALL = os.environ.get("DPMN_DET_SMALL", "1") != "0"
 
 
 def layernorm_bwd(x, dy, w, dx, accumulate, dgamma, dbeta):
@@ -379,13 +381,22 @@ def backward(m, sv, dout, need_dx_kv=True):
         wp = mlp.pointwise_conv.weight.reshape(Ch, Ch)
         dg = ops.pointwise(dz.reshape(B, L, Ch), packing.transposed(wp), _zero_bias(Ch, dz.device)).reshape(M, Ch)
         check(lib.dpmn_pointwise_wgrad_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, stream()))
-        check(lib.dpmn_rowsum_mod_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, stream()))
+        wsd = ops.splitk_workspace(dz.device)       # per-image partial rows of the atomics-free bias / depthwise-conv gradients
+        if DET_SMALL:
+            check(lib.dpmn_rowsum_mod_det_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, dptr(wsd), wsd.numel() * 4, stream()))
+        else:
+            check(lib.dpmn_rowsum_mod_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, stream()))
         # GELU'(gpre) on the way in, GELU (+ the dropout mask) on the forward input, mask and GELU'(ypre) on the way out
         dypre = torch.empty_like(dg)
         r = int(round(L ** 0.5))
-        check(lib.dpmn_dwconv3x3_bwd_fused_f32(dptr(s["ypre"]), dptr(dg), dptr(s["gpre"]), dptr(mlp.depthwise_conv.weight),
-                                               dptr(dypre), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
-                                               1, 1, float(pd), int(sb[2]), B, Ch, r, stream()))
+        if DET_SMALL:
+            check(lib.dpmn_dwconv3x3_bwd_fused_det_f32(dptr(s["ypre"]), dptr(dg), dptr(s["gpre"]), dptr(mlp.depthwise_conv.weight),
+                                                       dptr(dypre), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
+                                                       1, 1, float(pd), int(sb[2]), B, Ch, r, dptr(wsd), wsd.numel() * 4, stream()))
+        else:
+            check(lib.dpmn_dwconv3x3_bwd_fused_f32(dptr(s["ypre"]), dptr(dg), dptr(s["gpre"]), dptr(mlp.depthwise_conv.weight),
+                                                   dptr(dypre), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
+                                                   1, 1, float(pd), int(sb[2]), B, Ch, r, stream()))
         dn2 = linear_bwd(dypre, s["n2"], mlp.fc1.weight, gr[mlp.fc1.weight], gr[mlp.fc1.bias])
         dx1 = dx2.clone()
         layernorm_bwd(s["x1"], dn2, blk.norm2.weight, dx1, True, gr[blk.norm2.weight], gr[blk.norm2.bias])

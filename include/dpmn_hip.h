@@ -314,6 +314,14 @@ int dpmn_act_fwd_f32(const float* x, float* y, int act, float slope, long n, dpm
 int dpmn_axpby_f32(const float* x, const float* z, float* y, float a, float b, int accumulate, long n, dpmn_stream_t stream);
 /* out[row % mod] += sum_c x[row][c] */
 int dpmn_rowsum_mod_f32(const float* x, float* out, long rows, int cols, int mod, dpmn_stream_t stream);
+/* atomics-free forms (bitwise reproducible): per-image partial rows in ws, added in image order by dpmn_rows_reduce_f32
+ * (dw[e] += sum_z part[z][e], db[n] += sum_z part[z][NK + n] over `rows` rows of NK + N floats) */
+int dpmn_rows_reduce_f32(const float* part, float* dw, float* db, int NK, int N, int rows, dpmn_stream_t stream);
+int dpmn_rowsum_mod_det_f32(const float* x, float* out, long rows, int cols, int mod, float* ws /* rows floats */, size_t ws_bytes,
+                            dpmn_stream_t stream);
+int dpmn_dwconv3x3_bwd_fused_det_f32(const float* P, const float* dg, const float* gpre, const float* w, float* dP, float* dw, float* db,
+                                     int in_gelu, int out_gelu_bwd, float p_drop, unsigned long long seed, int B, int Ch, int r,
+                                     float* ws /* B * Ch * 10 floats */, size_t ws_bytes, dpmn_stream_t stream);
 /* ImageLoss (loss/image_loss.py:15-43): loss = w_mse*MSE + w_grad*L1(gradient maps of the first 3 channels).
  * U, V: (B,3,H,W) scratch written by the forward and consumed by the backward (may be NULL when gradient == 0).
  * grad_out (B,C,H,W) (+)= grad_scale[0] * dloss/dout. */
