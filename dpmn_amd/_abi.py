@@ -147,6 +147,7 @@ SIGNATURES = {
     "dpmn_dwconv3x3_train_f32": (_i, [fp, fp, fp, fp, fp, _i, _f, _u64, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_bwd_fused_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _f, _u64, _i, _i, _i, fp]),
     "dpmn_pointwise_wgrad_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_pointwise_wgrad_det_f32": (_i, [fp, fp, fp, _i, _i, _i, fp, _sz, fp]),
     "dpmn_pgrm_tail_elem_f32": (_i, [fp, _PP, _PP, _i, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_elem_bwd_f32": (_i, [fp, fp, _PP, _PP, _PP, _PP, _i, fp, _i, _i, _i, fp]),
     "dpmn_patch_embed_bwd_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

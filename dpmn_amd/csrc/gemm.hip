@@ -30,6 +30,8 @@ struct EpiArgs {
   int act;             // ACT_*
   float slope;         // PReLU slope
   int atomic;          // 1: y += acc with fp32 atomics (split-K weight gradients); bias/act/res ignored
+  long zstride;        // k-loop split launches: != 0: split z STORES its partial result at y + z * zstride (no atomics; the caller adds
+                       // the splits in order)
 };
 
 struct ProArgs {
@@ -397,6 +399,7 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
     bz = c + 8 * zq; by = t / (int)gridDim.x; bx = t - by * (int)gridDim.x;
   }
   const int m_blk = bx * BM, n_blk = by * BN;
+  y += (size_t)bz * e.zstride;
   // loader mapping: 8 float4 per row
   const int lrow = tid >> 3, lcol = (tid & 7) * 4;   // rows 0..31 (+32 per pass)
   // Two named register sets (a, b), same scheme as k_gemm_pw: the loads of k-step kt+2 are issued at the end of step kt and
@@ -1117,6 +1120,20 @@ int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, 
                      (long)Ch * L, (long)Ch * L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
+}
+
+// the same without atomics: the 32 k splits store their (Ch, Ch) partial results in ws (32 * Ch * Ch floats), added in split order
+int dpmn_pointwise_wgrad_det_f32(const float* dz, const float* g, float* dw, int B, int Ch, int L, float* ws, size_t ws_bytes,
+                                 dpmn_stream_t stream) {
+  DPMN_REQUIRE(dz && g && dw && ws && L % 32 == 0 && Ch % 4 == 0, "pointwise_wgrad_det: bad arguments");
+  const int S = 32;
+  if ((size_t)S * Ch * Ch * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "pointwise_wgrad_det: workspace too small");
+  EpiArgs e{nullptr, nullptr, nullptr, nullptr, ACT_NONE, 0.f, 0, (long)Ch * Ch};
+  dim3 grid(cdiv(Ch, 64), cdiv(Ch, 96), S);
+  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, ws, Ch, Ch, Ch, B * L, e, L,
+                     (long)Ch * L, (long)Ch * L);
+  DPMN_CHECK_LAUNCH();
+  return dpmn_rows_reduce_f32(ws, dw, nullptr, Ch * Ch, 0, S, stream);
 }
 
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,

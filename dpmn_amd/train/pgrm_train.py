@@ -380,8 +380,12 @@ def backward(m, sv, dout, need_dx_kv=True):
         # pointwise conv on the raw (B, Ch, L) views
         wp = mlp.pointwise_conv.weight.reshape(Ch, Ch)
         dg = ops.pointwise(dz.reshape(B, L, Ch), packing.transposed(wp), _zero_bias(Ch, dz.device)).reshape(M, Ch)
-        check(lib.dpmn_pointwise_wgrad_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, stream()))
-        wsd = ops.splitk_workspace(dz.device)       # per-image partial rows of the atomics-free bias / depthwise-conv gradients
+        wsd = ops.splitk_workspace(dz.device)       # partial rows of the atomics-free pointwise / bias / depthwise-conv gradients
+        if DET_SMALL:
+            check(lib.dpmn_pointwise_wgrad_det_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, dptr(wsd),
+                                                   wsd.numel() * 4, stream()))
+        else:
+            check(lib.dpmn_pointwise_wgrad_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, stream()))
         if DET_SMALL:
             check(lib.dpmn_rowsum_mod_det_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, dptr(wsd), wsd.numel() * 4, stream()))
         else:
