@@ -334,6 +334,10 @@ class TextSR(base.TextBase):
                 for d, s_ in zip(st["tp"], text_priors):
                     d.copy_(s_)
             graph.replay()
+            # the replayed optimizer kernels rewrote the parameters through raw pointers: eval-mode weight packs (CMM) and the
+            # PGRMs' LayerNorm-folded attention weights cached before this step are stale now (trainer.step() in Python, which
+            # drops them on the eager path, ran only while the graph was captured)
+            trainer.invalidate_packs()
             return loss
         run.graph = graph
         return run

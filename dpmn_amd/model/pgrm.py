@@ -274,7 +274,8 @@ class PGRM(nn.Module):
         out = torch.empty(B, self.hidden_size, self.img_size[0], self.img_size[1], device=x_kv.device)
         # the LayerNorm-folded attention weights in the workspace stay valid while nothing touched the parameters: torch-side
         # writes bump _version, the optimizer kernels (raw pointers) reset self._pack through Trainer.invalidate_packs()
-        fkey = (self._ws.data_ptr(), B, tuple(p._version for p in self.layers[0].parameters()))
+        # (code that writes parameters through raw pointers outside Trainer.step must set module._pack = None itself)
+        fkey = (self._ws.data_ptr(), B, tuple((p.data_ptr(), p._version) for p in self.layers[0].parameters()))
         w.reuse_folded = int(self._fold_key == fkey and self._pack is not None)
         self._fold_key, self._pack = fkey, True
         _abi.check(_abi.lib.dpmn_pgrm_forward_f32(C.byref(w), _abi.dptr(x_q), x_q.shape[1], _abi.dptr(x_kv),

@@ -34,6 +34,46 @@ def refine(sd_psn, sd_pgrms, sd_cmm, arch, b1, b2, images_lr, label_vecs, text_p
     return out
 
 
+def train_loss(sd_psn, sd_pgrms, sd_distill, sd_cmm, arch, b1, b2, images_lr, images_hr, label_vecs, text_priors, windows=(2, 4, 8)):
+    """The loss of one optimisation step (interfaces/super_resolution.py:140-262), differentiable by torch autograd through
+    the restated modules: frozen PSN (no_grad, :56-59) -> both PGRM cascades with ImageLoss x 100 on every cascade image
+    (:201-203, :232-234) -> the DistillModule chains walking each branch backwards (:237-252) -> CMM + its ImageLoss
+    (:254-258) -> sum / (b1 + b2 + 1) (:262).  The state dicts hold the leaves (requires_grad set by the caller); the
+    DistillModules are ordered [branch-1 chain (b1 - 1), branch-2 chain (b2 - 1)].  Pinned through
+    tests/golden/step_tsrn_2p2.npz (tests/test_oracle_grads.py)."""
+    import torch
+    with torch.no_grad():
+        if arch == "tatt":
+            psn, _ = otsrn.tatt_forward(sd_psn, images_lr, label_vecs)
+        elif arch == "tbsrn":
+            psn = otsrn.tbsrn_forward(sd_psn, images_lr)
+        else:
+            psn = otsrn.tsrn_forward(sd_psn, images_lr)
+    hr3 = images_hr[:, :3]
+    tot, casc, l1, l2 = 0, psn, [], []
+    for k in range(b1):
+        o = opgrm.pgrm_forward(sd_pgrms[k], text_priors[k], casc[:, :3], l1[:k], windows=windows)
+        l1.append(o)
+        casc = o
+        tot = tot + ocmm.image_loss(o, hr3, True) * 100
+    casc = psn
+    for k in range(b1, b1 + b2):
+        o = opgrm.pgrm_forward(sd_pgrms[k], ocmm.to_mask(casc.detach()[:, :3]), casc[:, :3], l2[:k - b2], windows=windows)
+        l2.append(o)
+        casc = o
+        tot = tot + ocmm.image_loss(o, hr3, True) * 100
+    feat = l1[-1]
+    for k in range(b1 - 1, 0, -1):
+        ld, feat = ocmm.distill_forward(sd_distill[k - 1], feat, l1[k - 1], True)
+        tot = tot + ld * 100
+    feat = l2[-1]
+    for k in range(b2 - 1, 0, -1):
+        ld, feat = ocmm.distill_forward(sd_distill[k + b1 - 2], feat, l2[k - 1], True)
+        tot = tot + ld * 100
+    o = ocmm.cmm_forward(sd_cmm, l1[-1], l2[-1], True)
+    return (tot + ocmm.image_loss(o, hr3, True) * 100) / (b1 + b2 + 1)
+
+
 def rotate_img(img, arc, rand_offs, off_range=0.2):
     """torch_rotate_img (utils/util.py:37-58) written out at index level: theta = [[cos, sin*r, 0], [-sin/r, cos, 0]],
     r = H/W + (2*rand-1)*off_range (line 44); affine_grid with align_corners=False (base x_j = (2j+1)/W - 1) and

@@ -509,6 +509,49 @@ def test_graphed_train_step_matches_eager(dev):
     assert graph_losses[1] < graph_losses[0]
 
 
+def test_graph_replay_invalidates_eval_packs(dev):
+    """replay -> eval -> replay -> eval: the evals between graph replays must see the parameters the replayed optimizer
+    kernels wrote (raw pointers: no torch version counter moves), not the CMM packs / LayerNorm-folded attention weights
+    cached by the previous eval."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    B, b1, b2 = 2, 1, 1
+    sr_ = TextSR(workload.make_config(B), workload.make_args("tsrn", b1, b2, B))
+    models, psn, distill, crit, trainer = sr_.build_training()
+    for i, m in enumerate([psn] + models + distill):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, 520 + i)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                v.copy_(sd[k])
+    psn.eval()
+    b = synth.synth_batch(B, seed=23)
+    lr, hr = b["images_lr"].to(dev), b["images_hr"].to(dev)
+    priors = [torch.floor(synth.uniform("rtp%d" % k, (B, 2, 32, 128), 0, 256, 4)).to(dev) for k in range(b1)]
+    run = sr_.graphed_train_step(models, psn, distill, crit, trainer, lr, hr, None, priors, warmup=2)
+
+    def evaluate(drop_caches):
+        for m in models:
+            m.eval()
+            if drop_caches:
+                m._pack = None
+                if hasattr(m, "_fold_key"):
+                    m._fold_key = None
+        with torch.no_grad():
+            out = sr_.refine(models, psn, lr, None, text_priors=priors).clone()
+        for m in models:
+            m.train()
+        return out
+    outs = []
+    for _ in range(2):
+        run(lr, hr, None, priors)
+        got = evaluate(False)
+        want = evaluate(True)
+        assert torch.equal(got, want), "eval after a graph replay used stale packs: max diff %g" % float((got - want).abs().max())
+        outs.append(got)
+    assert not torch.equal(outs[0], outs[1])
+
+
 def test_adam_device_step_counter_equals_host_step(dev):
     from dpmn_amd.train.optim import FlatBucket
     torch.manual_seed(3)

@@ -152,3 +152,17 @@ def test_oracle_training_step_vs_reference_step_fixture():
         # 8 samples per channel at the CMM bottleneck (B = 2, 1x4 maps) amplifies 1e-7 forward differences, and every
         # PGRM gradient passes through the CMM backward
         _check(g, named, "m%d/" % i, tol=2e-2)
+
+
+def test_oracle_train_loss_equals_reference_step_fixture():
+    """oracle/dpmn.py train_loss (what bench.py's CPU training-step baseline differentiates) vs the loss of the reference's
+    own step (tests/golden/step_tsrn_2p2.npz)."""
+    from oracle import dpmn as odpmn
+    g = load_golden("step_tsrn_2p2")
+    B, b1, b2 = 2, 2, 2
+    sd0 = step_state_dicts(b1, b2)
+    batch = synth.synth_batch(B, seed=4)
+    priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)) for k in range(b1)]
+    n = b1 + b2
+    loss = odpmn.train_loss(sd0[0], sd0[1:1 + n], sd0[2 + n:], sd0[1 + n], "tsrn", b1, b2, batch["images_lr"], batch["images_hr"], None, priors)
+    assert abs(float(loss) - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))

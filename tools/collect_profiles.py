@@ -61,7 +61,7 @@ def latest(base, pattern):
 
 
 def do_reduce(out):
-    for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_fetch_train", "pmc_write_train", "pmc_mfma_train"):
         f = latest(out, sub + "/**/*counter_collection.csv")
         if f:
             json.dump(reduce_pmc(f), open(os.path.join(out, sub + ".json"), "w"), indent=1)
@@ -81,32 +81,36 @@ def do_collect(tag):
             shutil.copy(p, os.path.join(dst, "%s_%s.json" % (tag, name)))
             if name == "bench_default":
                 B = json.load(open(p))["config"]["per_gpu_batch"]
-    fe, wr, mf = (json.load(open(os.path.join(src, n + ".json"))) if os.path.exists(os.path.join(src, n + ".json")) else {}
-                  for n in ("pmc_fetch", "pmc_write", "pmc_mfma"))
-    if fe and wr:
-        rec = {"per_gpu_batch": B, "workload": "cfg1 forward, bench.py --steps 3 --warmup 2 under rocprofv3 --pmc (one counter per pass)",
-               "correction": "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
-               "kernels": {}}
-        for fam in sorted(set(fe) & set(wr)):
-            rec["kernels"][fam] = {"FETCH_SIZE_KB": fe[fam].get("FETCH_SIZE"), "WRITE_SIZE_KB": wr[fam].get("WRITE_SIZE"),
-                                   "launches": fe[fam]["launches"], "avg_us_in_pmc_pass": fe[fam]["avg_us"],
-                                   "hbm_bytes_per_launch": (2 * fe[fam].get("FETCH_SIZE", 0.0) + wr[fam].get("WRITE_SIZE", 0.0)) * 1024}
-        json.dump(rec, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
-    if mf:
-        rows, tb, ta = [], 0.0, 0.0
-        for fam, c in mf.items():
-            busy, act, mops = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0), c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)
-            avail = act / 8.0 * 1024.0
-            rows.append((c["avg_us"] * c["launches"], fam, c["launches"], c["avg_us"], 100.0 * busy / avail if avail else 0.0,
-                         mops * 512 / c["avg_us"] / 1e6 if c["avg_us"] else 0.0))
-            tb += busy * c["launches"]; ta += avail * c["launches"]
-        rows.sort(reverse=True)
-        with open(os.path.join(dst, tag + "_pmc_mfma_util.csv"), "w") as o:
-            o.write("kernel_family,launches,avg_us,mfma_busy_pct,mfma_tflops\n")
-            for _, fam, n, us, util, tf in rows:
-                o.write('"%s",%d,%.2f,%.2f,%.2f\n' % (fam, n, us, util, tf))
-            o.write('"ALL dpmn kernels (time-weighted)",,,%.2f,\n' % (100.0 * tb / ta if ta else 0.0))
-        print(open(os.path.join(dst, tag + "_pmc_mfma_util.csv")).read())
+    for suffix, mode, text in (("", "fwd", "cfg1 forward, bench.py --steps 3 --warmup 2 under rocprofv3 --pmc (one counter per pass)"),
+                               ("_train", "train", "cfg1 TRAINING step, bench.py --mode train --steps 3 --warmup 2 under rocprofv3 --pmc (one counter group per "
+                                "pass; branch and weight-gradient streams active, so kernels overlap: the per-launch durations are inflated, the byte counts are not)")):
+        fe, wr, mf = (json.load(open(os.path.join(src, n + suffix + ".json"))) if os.path.exists(os.path.join(src, n + suffix + ".json")) else {}
+                      for n in ("pmc_fetch", "pmc_write", "pmc_mfma"))
+        pre = tag + ("_train" if mode == "train" else "")
+        if fe and wr:
+            rec = {"per_gpu_batch": B, "mode": mode, "workload": text,
+                   "correction": "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
+                   "kernels": {}}
+            for fam in sorted(set(fe) & set(wr)):
+                rec["kernels"][fam] = {"FETCH_SIZE_KB": fe[fam].get("FETCH_SIZE"), "WRITE_SIZE_KB": wr[fam].get("WRITE_SIZE"),
+                                       "launches": fe[fam]["launches"], "avg_us_in_pmc_pass": fe[fam]["avg_us"],
+                                       "hbm_bytes_per_launch": (2 * fe[fam].get("FETCH_SIZE", 0.0) + wr[fam].get("WRITE_SIZE", 0.0)) * 1024}
+            json.dump(rec, open(os.path.join(dst, pre + "_pmc_traffic.json"), "w"), indent=1)
+        if mf:
+            rows, tb, ta = [], 0.0, 0.0
+            for fam, c in mf.items():
+                busy, act, mops = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0), c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)
+                avail = act / 8.0 * 1024.0
+                rows.append((c["avg_us"] * c["launches"], fam, c["launches"], c["avg_us"], 100.0 * busy / avail if avail else 0.0,
+                             mops * 512 / c["avg_us"] / 1e6 if c["avg_us"] else 0.0))
+                tb += busy * c["launches"]; ta += avail * c["launches"]
+            rows.sort(reverse=True)
+            with open(os.path.join(dst, pre + "_pmc_mfma_util.csv"), "w") as o:
+                o.write("kernel_family,launches,avg_us,mfma_busy_pct,mfma_tflops\n")
+                for _, fam, n, us, util, tf in rows:
+                    o.write('"%s",%d,%.2f,%.2f,%.2f\n' % (fam, n, us, util, tf))
+                o.write('"ALL dpmn kernels (time-weighted)",,,%.2f,\n' % (100.0 * tb / ta if ta else 0.0))
+            print(open(os.path.join(dst, pre + "_pmc_mfma_util.csv")).read())
     pe = os.path.join(ROOT, "gpurun_out", "parity_errors.json")
     if os.path.exists(pe):
         shutil.copy(pe, os.path.join(dst, tag + "_parity_errors.json"))

@@ -14,6 +14,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 3 --warmup 2 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --steps 3 --warmup 2 > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- $B --steps 3 --warmup 2 > $OUT/pmc_mfma.log 2>&1
+if [ "${1:-}" != "quick" ]; then
+  T="$B --mode train --steps 3 --warmup 2"
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_train -- $T > $OUT/pmc_fetch_train.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_train -- $T > $OUT/pmc_write_train.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_train -- $T > $OUT/pmc_mfma_train.log 2>&1
+fi
 cd $R
 timeout 900 python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 timeout 600 python bench.py --mode train 2>/dev/null | tail -1 > $OUT/bench_train.json
