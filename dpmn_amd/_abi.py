@@ -101,6 +101,9 @@ SIGNATURES = {
     "dpmn_sk_select_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_pointwise_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_conv2d_nhwc_f32": (_i, [C.POINTER(ConvDesc), fp]),
+    "dpmn_xred_fallbacks": (_i, [C.POINTER(C.c_uint), _i]),
+    "dpmn_xred_test_force_recompute": (_i, [_i]),
+    "dpmn_xred_enable": (_i, [_i]),
     "dpmn_nchw_to_nhwc_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_nhwc_to_nchw_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_se_gate_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),

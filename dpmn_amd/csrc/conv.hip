@@ -57,7 +57,19 @@ struct ConvArgs {
   int m_per_group;            //    m >= m_per_group use w + wgs and bias + Cout -- one launch, twice the tiles, half the split-K
   long wgs;
   int wlocal;                 // implicit GEMM: 1 = blocks that share a weight slice (same n tile, same k split) are dealt to ONE XCD
+  // XRED (in-L2 split-K reduction, see conv_igemm_body): 1-D grid of 8 * xr_t8 * ksplit workgroups
+  unsigned* xr_cnt;           // one arrival word per tile: zero on entry, zero again on exit
+  int xr_tm, xr_tn;           // row / column tiles
+  int xr_t8;                  // tiles per XCD (ceil(T / 8)): XCD c owns the tiles [c * xr_t8, (c + 1) * xr_t8)
+  int xr_order;               // 0: row tile fastest (consecutive tiles share a weight column tile), 1: column tile fastest
+  int xr_force_redo;          // test hook: treat every tile as misplaced (the recompute path)
+  int xr_group;               // splits per first-level group
+  int xr_cstride;             // words between two arrival words
+  int xr_ablate;              // timing experiments only (DPMN_XRED_ABLATE): 1 no collect loads, 2 no wait for the partial stores, 4 no atomics / barriers
 };
+int g_xred_enabled = -1;                     // -1: DPMN_CONV_XRED (default 0: measured slower than the reduce launch); dpmn_xred_enable
+int g_xred_force_recompute = 0;              // test hook (dpmn_xred_test_force_recompute): every tile takes the recompute path
+__device__ unsigned g_xred_fallbacks = 0;      // tiles that took the recompute path (contributors on different XCDs): diagnostics
 __device__ __forceinline__ int conv_group_of(const ConvArgs& a, int m) { return (a.groups > 1 && m >= a.m_per_group) ? 1 : 0; }
 
 // phase-fused launch: the phase-dependent arguments of this workgroup (the kernel argument struct itself stays
@@ -155,8 +167,21 @@ __device__ __forceinline__ float vmax_raw(float x, float y) {
 // less matrix time (profiles/r03e_ubench_mfma_valu.txt).  D layout: register v of lane l = out[co = 8 (v / 4) + 4 (l >> 5) +
 // v % 4][pixel = l & 31] -- again 4 consecutive output channels per lane and register quad.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false, bool M32 = false>
+// XRED (with SIMPLE, 16x16x4 MFMAs): the split-K reduction inside the launch, through the L2 of ONE XCD.  Workgroups are dealt to
+// the 8 XCDs round-robin by linear id; the grid is 1-D and block L = 8 j + c is the j-th block of XCD c, which works on tile
+// c * xr_t8 + j / S, k split j % S: all S splits of a tile run on the same XCD, next to each other in time.  A block stores its
+// accumulators (register layout) to its slot of the workspace with PLAIN stores -- after s_waitcnt vmcnt(0) they are in that XCD's
+// L2 -- and bumps the tile's arrival word; the block that arrives LAST reads all S slots back with device-scope loads (sc1: miss in
+// the vector L1, hit in L2), adds them IN SPLIT ORDER (bitwise reproducible whoever arrives last) and runs the epilogue.  No reduce
+// launch, no cross-XCD visibility protocol, nothing ever waits on another workgroup.
+// The placement is an observed property of the dispatcher, not an architectural guarantee, so it is CHECKED: every block adds
+// (1, x, x^2) of its hardware XCC id x to the arrival word; the last block takes the fast path only if all S ids equal its own
+// (sum x = S m and sum x^2 = S m^2).  Otherwise it recomputes the S splits itself, in order, with the running sum parked in its
+// own slot -- the same additions in the same order, so even a misplaced tile is bitwise equal (counted in g_xred_fallbacks).
+template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false, bool M32 = false,
+          bool XRED = false>
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
+  static_assert(!XRED || (SIMPLE && !M32 && BKT == 32), "the in-L2 reduction exists for the SIMPLE path");
   static_assert(!M32 || (SIMPLE && !BF && BKT == 32 && BM / WM == 64 && BN / WN == 64), "the 32x32x2 variant: fp32 SIMPLE path, 64 x 64 wave tiles");
   static_assert(!BF || (SIMPLE && BKT == 32), "the bf16 variant exists for the SIMPLE path with 32-deep chunks");
   static_assert(!SIMPLE || UNI, "SIMPLE is a refinement of the UNI path");
@@ -187,6 +212,18 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   // of one k split read the same input slice, and with Z a multiple of 8 they all sit on one XCD (in general on
   // min(n tiles, 8 / gcd(Z, 8)) of them).
   int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  int xr_tile = 0;
+  if constexpr (XRED) {
+    const int L = blockIdx.x, c = L & 7, j = L >> 3;
+    const int tl = j / a.ksplit, z = j - tl * a.ksplit;
+    const int nph_ = a.nphase > 1 ? a.nphase : 1;
+    xr_tile = c * a.xr_t8 + tl;
+    if (tl >= a.xr_t8 || xr_tile >= a.xr_tm * a.xr_tn * nph_) return;
+    int phs;
+    if (a.xr_order == 0) { bx = xr_tile % a.xr_tm; const int r = xr_tile / a.xr_tm; by = r % a.xr_tn; phs = r / a.xr_tn; }
+    else { by = xr_tile % a.xr_tn; const int r = xr_tile / a.xr_tn; phs = r % nph_; bx = r / nph_; }
+    bz = phs * a.ksplit + z;
+  } else
   if (a.wlocal) {
     const int L = bx + gridDim.x * (by + gridDim.y * bz);
     const int c = L & 7, j = L >> 3;
@@ -494,8 +531,19 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 
   const int nk_all = a.Kp / BK;
   const int cps = (nk_all + a.ksplit - 1) / a.ksplit;          // chunks per split
-  const int kt0 = zsplit * cps;
+  // XRED: the pass below runs once for this block's own split; a last-arriving block whose contributors were NOT all on its XCD
+  // runs it again for every split (redo), see the hand-over behind the loop
+  int zcur = zsplit;
+  int mode = 0;                // 0: this block's own split; 1 / 2: recomputing its group / every split (XRED)
+  for (;;) {
+  const int kt0 = zcur * cps;
   const int nk = min(nk_all, kt0 + cps);
+  if constexpr (XRED) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+      for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   if (kt0 < nk) {
     if (SIMPLE) { gload_simple(kt0); sstore_simple(0); }
     else {
@@ -565,6 +613,125 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     else if (UNI || kt + 1 < nk) sstore(buf ^ 1);
     if (!(ABL & 4)) __syncthreads();
   }
+  if constexpr (!XRED) break;
+  else {
+    if (a.ksplit <= 1) break;
+    constexpr int QN = NT * MT, HQ = QN / 2;
+    static_assert(QN % 2 == 0, "the collect moves half slots");
+    typedef int i32x4x_ __attribute__((ext_vector_type(4)));
+    const int S = a.ksplit, GS = a.xr_group, ngrp = (S + GS - 1) / GS;
+    const int g_lo = (zsplit / GS) * GS, g_hi = min(S, g_lo + GS);
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.partial, 0, a.xr_tm * a.xr_tn * (a.nphase > 1 ? a.nphase : 1) * S * (QN * 4096), 0x00020000);
+    constexpr int SC1 = 0x10;               // cache policy of the loads: device scope (miss in the vector L1, served by this XCD's L2)
+    auto slot_of = [&](int z_) { return __builtin_amdgcn_readfirstlane((xr_tile * S + z_) * (QN * 4096)); };
+    auto st_slot = [&](int z_) {            // accumulators -> slot z_ of this tile, complete (in L2) on return
+      const int so = slot_of(z_);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4x_, acc[i][j]), prs, tid * 16 + (i * MT + j) * 4096, so, 0);
+      if (!(a.xr_ablate & 2)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto add_slot = [&](int z_) {           // accumulators = slot z_ + accumulators
+      const int so = slot_of(z_);
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+          const f32x4 t_ = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, tid * 16 + (i * MT + j) * 4096, so, SC1));
+          acc[i][j] = t_ + acc[i][j];
+        }
+    };
+    int* s_flag = reinterpret_cast<int*>(&Xs[0][0]);      // (the tiles are dead: every wave passed the loop's last barrier)
+    // arrival at a word that expects `target` workgroups.  Returns 0: others still to come (this block is done); 1: last, and
+    // every contributor ran on this block's XCD (their partial tiles are in the L2 this block reads); 2: last, but not so
+    auto arrive = [&](unsigned* w, int target) -> int {
+      __syncthreads();                      // every wave's stores are complete (st_slot waited)
+      if (tid == 0 && (a.xr_ablate & 8)) s_flag[0] = (zcur == (target == ngrp ? S - 1 : g_hi - 1)) ? 1 : 0;      // timing only: no atomic
+      else if (tid == 0) {
+        const unsigned x = (a.xr_ablate & 16) ? 0u : (__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 15u);      // hwreg(HW_REG_XCC_ID, 0, 4)
+        const unsigned add = 1u | (x << 7) | ((x * x) << 16);
+        const unsigned old = (a.xr_ablate & 32) ? __hip_atomic_fetch_add(w, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                                : __hip_atomic_fetch_add(w, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int f = 0;
+        if ((old & 127u) == (unsigned)(target - 1)) {
+          __hip_atomic_store(w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // nobody touches it before the next launch
+          const unsigned sx = ((old >> 7) & 511u) + x, sxx = (old >> 16) + x * x;   // sum x = n m and sum x^2 = n m^2 <=> all x = m
+          f = (sx == (unsigned)target * x && sxx == (unsigned)target * x * x && !a.xr_force_redo) ? 1 : 2;
+          if (f == 2) atomicAdd(&g_xred_fallbacks, 1u);
+        }
+        s_flag[0] = f;
+      }
+      __syncthreads();
+      const int f = s_flag[0];
+      __syncthreads();
+      return f;
+    };
+    // accumulators = slot z0 + slot (z0 + step) + ... (n slots, in this order, from zero); half slots in flight two deep
+    auto collect = [&](int z0, int n, int step) {
+      f32x4 t0[HQ], t1[HQ];
+      auto ldhalf = [&](f32x4 (&t_)[HQ], int u_) {      // unit u = 2 i + h of slot z0 + i step
+        const int uu = min(u_, 2 * n - 1);
+        const int so = __builtin_amdgcn_readfirstlane((xr_tile * S + z0 + (uu >> 1) * step) * (QN * 4096) + (uu & 1) * (HQ * 4096));
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) t_[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, tid * 16 + q * 4096, so, SC1));
+      };
+#pragma unroll
+      for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ldhalf(t0, 0);
+      for (int i_ = 0; i_ < n; ++i_) {
+        ldhalf(t1, 2 * i_ + 1);
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) acc[q / MT][q % MT] += t0[q];
+        ldhalf(t0, 2 * i_ + 2);
+#pragma unroll
+        for (int q = 0; q < HQ; ++q) acc[(HQ + q) / MT][(HQ + q) % MT] += t1[q];
+      }
+    };
+    // Two levels: the S splits are cut into groups of GS consecutive ones.  The last block of a GROUP adds the group's partial
+    // tiles (in split order); with more than one group it stores the group sum over the group's first slot and arrives at the
+    // tile's word, where the last group adds the group sums in group order -- the groups are collected by different CUs in
+    // parallel (one CU reads a 64 KB slot in ~0.5 us: 32 splits in one chain cost 17 us at the end of the launch).
+    // Word layout (stride xr_cstride words each: atomics on one line serialise): tile * (ngrp + 1) + group, the tile's word last.
+    unsigned* words = a.xr_cnt + (size_t)xr_tile * (ngrp + 1) * a.xr_cstride;
+    bool to_l2 = false;
+    if (mode == 0) {
+      st_slot(zsplit);
+      if (a.xr_ablate & 4) { if (zsplit != S - 1) return; break; }
+      const int f = arrive(words + (zsplit / GS) * a.xr_cstride, g_hi - g_lo);
+      if (f == 0) return;
+      if (f == 2) { mode = 1; zcur = g_lo; continue; }
+      if (!(a.xr_ablate & 1)) collect(g_lo, g_hi - g_lo, 1);
+      to_l2 = true;
+    } else {
+      // recompute (a contributor ran on another XCD): acc = split zcur; the same additions in the same order as the collect
+      // path, with the running group sum parked in slot B and (mode 2) the running sum of the groups in slot A -- every slot of
+      // the tile is dead by now, and a thread reads back only words it wrote itself
+      const int zlo = mode == 1 ? g_lo : (zcur / GS) * GS, zhi = min(S, zlo + GS);
+      const int slotB = mode == 1 ? zsplit : 1, slotA = 0;
+      if (zcur > zlo) add_slot(slotB);
+      if (zcur + 1 < zhi) { st_slot(slotB); ++zcur; continue; }
+      if (mode == 1) to_l2 = true;
+      else {
+        if (zlo > 0) add_slot(slotA);
+        if (zhi < S) { st_slot(slotA); zcur = zhi; continue; }
+        break;
+      }
+    }
+    if (to_l2) {
+      if (ngrp == 1) break;
+      st_slot(g_lo);                         // the group's first slot now holds the group sum (only this block read the group's slots)
+      const int f = arrive(words + ngrp * a.xr_cstride, ngrp);
+      if (f == 0) return;
+      if (f == 2) { mode = 2; zcur = 0; continue; }
+      if (!(a.xr_ablate & 1)) collect(0, ngrp, GS);
+    }
+    break;
+  }
+  }
 
   if constexpr (M32) {
     // lane holds out[pixel m = .. + j * 32 + (l & 31)][co = .. + i * 32 + 8 g + 4 (l >> 5) + r], r = register 4 g + r of tile (i, j)
@@ -612,7 +779,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     return;
   }
   // ---- epilogue: lane holds out[pixel m = .. + (l&15)][co = .. + (l>>4)*4 + r]
-  if (a.ksplit > 1) {
+  if (!XRED && a.ksplit > 1) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
       const int m = m_blk + wm * (MT * 16) + j * 16 + lr;
@@ -666,6 +833,11 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false, bool M32 = false>
 __global__ __launch_bounds__(256) void k_conv_igemm(ConvArgs a) {
   conv_igemm_body<BM, BN, WM, WN, UNI, BKT, SIMPLE, AFF, BF, M32>(a);
+}
+// split-K with the reduction inside the launch (XRED above)
+template <int BM, int BN, int WM, int WN, bool AFF>
+__global__ __launch_bounds__(256, 2) void k_conv_igemm_xr(ConvArgs a) {      // two resident blocks per CU (<= 256 registers), as the fixed-split kernel
+  conv_igemm_body<BM, BN, WM, WN, true, 32, true, AFF, false, false, true>(a);
 }
 // the SIMPLE path with 16-deep chunks (36.9 KB of LDS) AND a register budget for three waves per SIMD (<= 168 registers): three
 // resident blocks per CU instead of two -- the 16-deep switch alone (DPMN_CONV_BK16) stayed at two because of its 200 registers
@@ -1633,8 +1805,23 @@ int launch_conv_sk(const ConvArgs& a, float* ws, size_t ws_bytes, unsigned* cnt,
   return DPMN_OK;
 }
 
+// group size of the two-level in-launch reduction (XRED): minimise the chain (group size + number of groups) a tile's last
+// blocks walk; and the arrival words, one line apart, must fit the counter array
+static bool xred_fits(int tiles, int S, int cnt_len, ConvArgs& a) {
+  static const int force_g = getenv("DPMN_XRED_GROUP") ? atoi(getenv("DPMN_XRED_GROUP")) : 0;
+  static const int cstride = getenv("DPMN_XRED_CSTRIDE") ? atoi(getenv("DPMN_XRED_CSTRIDE")) : 32;
+  int best = S, best_cost = S;         // one group: a chain of S slots
+  for (int g = S - 1; g >= 2; --g)
+    if (g + cdiv(S, g) + 1 < best_cost) { best = g; best_cost = g + cdiv(S, g) + 1; }      // (+1: the group sum is stored once more)
+  if (force_g > 0) best = force_g < S ? force_g : S;
+  a.xr_group = best;
+  a.xr_cstride = cstride > 0 ? cstride : 1;
+  while (a.xr_cstride > 1 && (long)tiles * (cdiv(S, best) + 1) * a.xr_cstride > cnt_len) a.xr_cstride >>= 1;
+  return (long)tiles * (cdiv(S, best) + 1) * a.xr_cstride <= cnt_len;
+}
+
 template <int BM, int BN, int WM, int WN>
-int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
+int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st, unsigned* cnt = nullptr, int cnt_len = 0) {
   if ((long)a.B * a.Hp * a.Wp >= (1L << 24))
     return dpmn_set_error(DPMN_ERR_ARG, "conv2d: the implicit-GEMM path decodes pixel indices in fp32 (B*Hp*Wp must be below 2^24)");
   if (a.groups == 2 && a.m_per_group % BM != 0)
@@ -1677,6 +1864,8 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     static const int bk16 = getenv("DPMN_CONV_BK16") ? atoi(getenv("DPMN_CONV_BK16")) : 0;
     static const int simple_on = getenv("DPMN_CONV_SIMPLE") ? atoi(getenv("DPMN_CONV_SIMPLE")) : 1;
     static const int m32_on = getenv("DPMN_CONV_M32") ? atoi(getenv("DPMN_CONV_M32")) : 0;
+    static const int xred_env = getenv("DPMN_CONV_XRED") ? atoi(getenv("DPMN_CONV_XRED")) : 0;      // split-K reduced in the launch through one XCD's L2
+    const int xred_on = g_xred_enabled >= 0 ? g_xred_enabled : xred_env;
     static const int o3_on = getenv("DPMN_CONV_O3") ? atoi(getenv("DPMN_CONV_O3")) : 0;          // 16-deep chunks + 3 waves per SIMD      // 32x32x2 MFMAs on the 128 x 128 tile
     bool simple = simple_on && uni && a.KH * a.KW <= 31 && (a.pro_act == ACT_NONE || a.pro_act == ACT_RELU || a.pro_act == ACT_LEAKY02);
     int n_seg = 0, n_aff = 0;
@@ -1701,6 +1890,44 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st) {
     if constexpr (BM / WM == 64 && BN / WN == 64) {
       if (n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true, false, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, false, false, true>), grid, dim3(256), 0, st, a);
+    }
+  }
+  else if (simple && S > 1 && BM == 128 && BN == 128 && xred_on && cnt && xred_fits(tiles, S, cnt_len, a) &&
+           (size_t)tiles * S * BM * BN * sizeof(float) <= ws_bytes) {
+    // split-K reduced inside the launch through one XCD's L2 (XRED in conv_igemm_body): 1-D grid, XCD c owns a contiguous run of
+    // tiles.  Tile order = the one that re-reads fewer bytes: every XCD fetches the weight column tiles and the input row tiles
+    // its run touches once (counted exactly: T <= 4096 tiles)
+    if constexpr (BM == 128 && BN == 128) {
+      const int tm = cdiv(M, BM), tn = cdiv(a.Cout, BN), t8 = cdiv(tiles, 8);
+      double cost[2];
+      for (int order = 0; order < 2; ++order) {
+        double wsets = 0, xsets = 0;
+        for (int c = 0; c < 8; ++c) {
+          const int t0 = c * t8, t1 = (c + 1) * t8 < tiles ? (c + 1) * t8 : tiles;
+          if (t0 >= t1) break;
+          if (order == 0) {      // t = (ph * tn + by) * tm + bx
+            const int r0 = t0 / tm, r1 = (t1 - 1) / tm;
+            wsets += (a.groups > 1 && r0 == r1) ? ((t0 % tm) * BM < a.m_per_group && ((t1 - 1) % tm) * BM >= a.m_per_group ? 2 : 1)
+                                                : (r1 - r0 + 1) * (a.groups > 1 ? 2 : 1);
+            xsets += r1 > r0 ? tm : t1 - t0;
+          } else {                // t = (bx * nph + ph) * tn + by
+            const int per = tn * nph, r0 = t0 / per, r1 = (t1 - 1) / per;
+            xsets += r1 - r0 + 1;
+            wsets += r1 > r0 ? per : t1 - t0;
+          }
+        }
+        cost[order] = wsets * BN * (double)a.Kp + xsets * BM * (double)a.stride * a.stride * a.cin;
+      }
+      static const int force_order = getenv("DPMN_XRED_ORDER") ? atoi(getenv("DPMN_XRED_ORDER")) : -1;
+      static const int ablate = getenv("DPMN_XRED_ABLATE") ? atoi(getenv("DPMN_XRED_ABLATE")) : 0;
+      a.xr_cnt = cnt; a.xr_tm = tm; a.xr_tn = tn; a.xr_t8 = t8; a.xr_force_redo = g_xred_force_recompute; a.xr_ablate = ablate;      // (xr_group / xr_cstride: xred_fits)
+      a.xr_order = force_order >= 0 ? force_order : (cost[0] <= cost[1] ? 0 : 1);
+      a.wlocal = 0;
+      const dim3 g1(8 * t8 * S);
+      if (n_aff) hipLaunchKernelGGL((k_conv_igemm_xr<BM, BN, WM, WN, true>), g1, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((k_conv_igemm_xr<BM, BN, WM, WN, false>), g1, dim3(256), 0, st, a);
+      DPMN_CHECK_LAUNCH();
+      return DPMN_OK;
     }
   }
   else if (simple && n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true>), grid, dim3(256), 0, st, a);
@@ -1846,9 +2073,31 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
                          : (sk_mode >= 2 ? launch_conv_sk<128, 128, 2, 2>(a, ws, wsb, d->arrive_cnt, d->arrive_cnt_len, st) : -1);
     if (r >= 0) return r;
     if (a.groups == 2 && mg % 128 != 0) return split_groups();
-    return launch_conv<128, 128, 2, 2>(a, ws, wsb, st);
+    return launch_conv<128, 128, 2, 2>(a, ws, wsb, st, d->arrive_cnt, d->arrive_cnt_len);
   }
   return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
+}
+
+int dpmn_xred_fallbacks(unsigned* count_out, int reset) {
+  DPMN_REQUIRE(count_out, "xred_fallbacks: null pointer");
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_xred_fallbacks), sizeof(v)) != hipSuccess) return dpmn_set_error(DPMN_ERR_RUNTIME, "xred_fallbacks: copy failed");
+  *count_out = v;
+  if (reset) {
+    v = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_xred_fallbacks), &v, sizeof(v)) != hipSuccess) return dpmn_set_error(DPMN_ERR_RUNTIME, "xred_fallbacks: reset failed");
+  }
+  return DPMN_OK;
+}
+
+int dpmn_xred_enable(int on) {
+  g_xred_enabled = on < 0 ? -1 : (on ? 1 : 0);
+  return DPMN_OK;
+}
+
+int dpmn_xred_test_force_recompute(int on) {
+  g_xred_force_recompute = on ? 1 : 0;
+  return DPMN_OK;
 }
 
 int dpmn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, dpmn_stream_t stream) {

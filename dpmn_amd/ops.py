@@ -205,7 +205,7 @@ def splitk_workspace(device, floats=24 << 20):
 
 
 _ARRIVE_CNT = {}
-ARRIVE_CNT_LEN = 4096
+ARRIVE_CNT_LEN = 32768      # 128 KB: the in-launch split-K reduction keeps its arrival words one 128-byte line apart
 STREAM_K = True      # False: the fixed-split path with its reduce launch (tests / A-B runs)
 
 

@@ -154,10 +154,22 @@ typedef struct {
                               * as ONE persistent "stream-K" launch: every workgroup walks an equal share of all (tile, k chunk)
                               * steps, partial tiles go to splitk_ws and the LAST workgroup to arrive at a tile sums them in a
                               * fixed order and runs the epilogue -- no reduce kernel, run-to-run bitwise reproducible.
+                              * The fixed-split layers on 128 x 128 tiles use the same counters for the in-launch reduction
+                              * through ONE XCD's L2 (round 4, csrc/conv.hip XRED: all k splits of a tile run on one XCD, the
+                              * last-arriving workgroup adds the partial tiles in split order and runs the epilogue).
                               * NULL: the two-launch split-K path */
   int arrive_cnt_len;
 } dpmn_conv_desc;
 int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream);
+/* Diagnostics of the in-L2 split-K reduction: number of tiles whose contributing workgroups were NOT all placed on one XCD and
+ * that were therefore recomputed by the last-arriving workgroup (bitwise-equal result, slower).  0 on the observed round-robin
+ * placement.  Synchronises the device.  reset != 0 zeroes the counter. */
+int dpmn_xred_fallbacks(unsigned* count_out, int reset);
+/* 1 / 0: use / do not use the in-L2 split-K reduction for the layers that qualify; -1: the DPMN_CONV_XRED environment variable
+ * (default 0: on MI355X the reduce launch measured faster, DESIGN.md "Measured and rejected", round 4). */
+int dpmn_xred_enable(int on);
+/* Test hook: on != 0 makes every split-K tile of the in-L2 reduction take the recompute path (as if misplaced). */
+int dpmn_xred_test_force_recompute(int on);
 /* layout plumbing at the module boundary: NCHW images <-> NHWC (channels zero-padded to Cpad) */
 int dpmn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, dpmn_stream_t stream);
 int dpmn_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, dpmn_stream_t stream);
