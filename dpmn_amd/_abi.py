@@ -99,6 +99,8 @@ SIGNATURES = {
     "dpmn_ln_linear_f32": (_i, [fp, fp, fp, _f, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_proj_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, fp]),
     "dpmn_sk_select_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_sk_mlp_in_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_sk_mlp_in_supported": (_i, [_i, _i, _i, _i, _i]),
     "dpmn_pointwise_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_conv2d_nhwc_f32": (_i, [C.POINTER(ConvDesc), fp]),
     "dpmn_xred_fallbacks": (_i, [C.POINTER(C.c_uint), _i]),

@@ -903,6 +903,236 @@ __global__ __launch_bounds__(256, ((K <= 96 && !(PRO == PRO_SKSEL && K > 32)) ? 
   }
 }
 
+
+// ---------------------------------------------------------------------------------- SKConv select -> x1 -> LayerNorm2 -> fc1
+// The second half of a Swin block up to the Mlp's first Linear (pgrm.py:91-96, 327-331, 31) in ONE launch: per 16-token tile of
+// a wave
+//   sel  = sum_g A[b][g] * cat[:, g CG : (g + 1) CG]                  (the SKConv's softmax-weighted group sum)
+//   x1   = proj_head(sel) + b_head + feats + shortcut                   (both residuals, = k_gemm_rowreg<CG, PRO_SKSEL, 3>: same
+//                                                                        instructions in the same order, bitwise-equal x1)
+//   y    = fc1(LayerNorm2(x1))                                          (= k_gemm_rowreg<C, PRO_LN, 1> on the x1 REGISTERS: the MFMA D
+//                                                                        layout of x1 is the B-operand layout of the next product)
+// x1 is written once (fc2's residual) by the blocks of the first column group and never read back; the other column groups of the
+// N = 4 C outputs recompute the cheap first product (K = CG against K = C) instead: one launch and one 4 M C read less per
+// block than sk_select + ln_linear.  Measured (B = 48, tools/prof_skmlp.py): 62 us against 60-62 us for the two launches it
+// replaces (22 + 44 in the pipeline), 70 us with the two training outputs against four launches (select 9 + proj_head 22 +
+// LayerNorm 10 + fc1 45): the time of these K <= 96 products is the MFMA time PLUS the vector / LDS issue time of the waves of a
+// SIMD (DESIGN.md "What bounds these fp32 kernels"), ~2x the MFMA floor in both forms -- fusing removes launches, not that.
+// SAVE (training forward): the first column group also writes sel (M, CG) and n2 = LayerNorm2(x1) (M, C) for the backward.
+template <int C, int CG, bool SAVE, int OCC>      // OCC: resident blocks per CU (3: <= 168 registers, weight fragments single-buffered)
+__global__ __launch_bounds__(256, OCC) void k_sk_mlp_in(const float* __restrict__ cat, const float* __restrict__ sel, int rows_per_image,
+                                                      const float* __restrict__ w_head, const float* __restrict__ b_head,
+                                                      const float* __restrict__ feats, const float* __restrict__ shortcut, float* __restrict__ x1,
+                                                      const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
+                                                      const float* __restrict__ w_fc1, const float* __restrict__ b_fc1, float* __restrict__ y,
+                                                      int M, int N, float* __restrict__ v_out, float* __restrict__ n2_out) {
+  constexpr int KC = C / 16, KV = C / 4, LDW = C + PAD, BN = 96, NT = 6, G = C / CG, HC = CG / 16, LDH = CG + PAD;
+  static_assert(C == 96 && G == 3, "built for dim 96, three window groups");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Ws = smem;                  // [96][LDW]  fc1 rows of this column group, gamma folded in
+  float* pb = Ws + BN * LDW;         // [96] b' = b + W beta, [96] rowsum(W'), [96] b_head
+  float* Wh = pb + 3 * BN;           // [96][LDH]  proj_head (staged behind the fold's scratch, which lives here first)
+  float* scr = Wh;                   // [96][KV] partial sums of W beta (dead before Wh is written); 53.4 KB in all: three blocks per CU
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lr = lane & 15, kq = lane >> 4;
+  const int n_blk = blockIdx.y * BN;
+  const int tiles = M / 16;
+  const int stride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wave;
+  const bool write_x1 = blockIdx.y == 0;
+
+  constexpr int WL = (BN * KV + 255) / 256;
+  float4 wv[WL];
+#pragma unroll
+  for (int u = 0; u < WL; ++u) {
+    const int i = min(tid + u * 256, BN * KV - 1);
+    wv[u] = *reinterpret_cast<const float4*>(w_fc1 + (size_t)(n_blk + i / KV) * C + (i % KV) * 4);
+  }
+  f32x4 xr[G][HC];
+  auto load_rows = [&](int t_) {
+    const size_t m = (size_t)(t_ < tiles ? t_ : tiles - 1) * 16 + lr;      // clamped, never predicated
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int c = 0; c < HC; ++c) xr[g][c] = *reinterpret_cast<const f32x4*>(cat + m * C + g * CG + 16 * c + 4 * kq);
+  };
+  // the residual rows of a tile are requested as soon as the previous tile has consumed its own (same registers), BEFORE that
+  // tile's stores: vmcnt retires loads and stores in order, so a load issued behind the y stores of the previous tile would make
+  // its consumer wait for those stores to reach memory as well
+  f32x4 r1[NT], r2[NT];
+  auto load_res = [&](int t_) {
+    const size_t ro = ((size_t)(t_ < tiles ? t_ : tiles - 1) * 16 + lr) * C + 4 * kq;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      r1[nt] = *reinterpret_cast<const f32x4*>(feats + ro + 16 * nt);
+      r2[nt] = *reinterpret_cast<const f32x4*>(shortcut + ro + 16 * nt);
+    }
+  };
+  load_rows(tile);
+  load_res(tile);
+#pragma unroll
+  for (int u = 0; u < WL; ++u) {
+    const int i = tid + u * 256;
+    if (i < BN * KV) {
+      const int r = i / KV, c4 = (i % KV) * 4;
+      float4 v = wv[u];
+      const float4 gm = *reinterpret_cast<const float4*>(ln_w + c4), bt = *reinterpret_cast<const float4*>(ln_b + c4);
+      const float4 wb = make_float4(v.x * bt.x, v.y * bt.y, v.z * bt.z, v.w * bt.w);
+      v = make_float4(v.x * gm.x, v.y * gm.y, v.z * gm.z, v.w * gm.w);
+      scr[r * KV + c4 / 4] = (wb.x + wb.y) + (wb.z + wb.w);
+      *reinterpret_cast<float4*>(Ws + r * LDW + c4) = v;
+    }
+  }
+  __syncthreads();
+  if (tid < BN) {
+    float bb = b_fc1 ? b_fc1[n_blk + tid] : 0.f, cw = 0.f;
+    for (int k = 0; k < KV; ++k) {             // fixed order, the same sums as k_gemm_rowreg's fold
+      const float4 v = *reinterpret_cast<const float4*>(Ws + tid * LDW + 4 * k);
+      cw += (v.x + v.y) + (v.z + v.w);
+      bb += scr[tid * KV + k];
+    }
+    pb[tid] = bb;
+    pb[BN + tid] = cw;
+    pb[2 * BN + tid] = b_head ? b_head[tid] : 0.f;
+  }
+  __syncthreads();
+  for (int i = tid; i < C * (CG / 4); i += 256) {      // proj_head: (C, CG) row-major
+    const int r = i / (CG / 4), c4 = (i % (CG / 4)) * 4;
+    *reinterpret_cast<float4*>(Wh + r * LDH + c4) = *reinterpret_cast<const float4*>(w_head + (size_t)r * CG + c4);
+  }
+  __syncthreads();
+
+  for (; tile < tiles; tile += stride) {
+    const size_t m = (size_t)tile * 16 + lr;
+    const size_t roff = m * C + 4 * kq;
+    f32x4 xb[HC];
+    {
+      const size_t b = m / rows_per_image;
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        xb[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(sel + (b * G + g) * CG + 16 * c + 4 * kq);
+          xb[c][0] += a[0] * xr[g][c][0]; xb[c][1] += a[1] * xr[g][c][1]; xb[c][2] += a[2] * xr[g][c][2]; xb[c][3] += a[3] * xr[g][c][3];
+        }
+      }
+    }
+    if (SAVE && write_x1) {
+#pragma unroll
+      for (int c = 0; c < HC; ++c) *reinterpret_cast<f32x4*>(v_out + m * CG + 16 * c + 4 * kq) = xb[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(tile + stride);                  // the next tile's rows fly during this tile's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- x1 = proj_head(sel) + b_head + feats + shortcut
+    f32x4 x1r[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) x1r[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+      const float* ha = Wh + lr * LDH + 4 * kq;
+#pragma unroll
+      for (int c = 0; c < HC; ++c) {
+        f32x4 hf[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) hf[nt] = *reinterpret_cast<const f32x4*>(ha + 16 * nt * LDH + 16 * c);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) x1r[nt] = mfma16(hf[nt][s4], xb[c][s4], x1r[nt]);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 2 * BN + 16 * nt + 4 * kq);
+      f32x4 v = x1r[nt] + b4;
+      v += r1[nt];
+      v += r2[nt];
+      x1r[nt] = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    load_res(tile + stride);                   // the next tile's residual rows, ahead of this tile's stores
+    __builtin_amdgcn_sched_barrier(0);
+    if (write_x1) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(x1 + roff + 16 * nt) = x1r[nt];
+    }
+    // ---- LayerNorm2 statistics of the row (two passes over the 4 kq partners, as nn.LayerNorm / k_gemm_rowreg)
+    float mean, rstd;
+    {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) { s0 += x1r[c][0] + x1r[c][1]; s1 += x1r[c][2] + x1r[c][3]; }
+      float s_ = s0 + s1;
+      s_ += __shfl_xor(s_, 16, 64); s_ += __shfl_xor(s_, 32, 64);
+      mean = s_ * (1.0f / C);
+      float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        const float d0 = x1r[c][0] - mean, d1 = x1r[c][1] - mean, d2 = x1r[c][2] - mean, d3 = x1r[c][3] - mean;
+        q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
+      }
+      float q = (q0 + q1) + (q2 + q3);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
+    }
+    if (SAVE && write_x1) {                    // n2 = (x1 - mean) * rstd * gamma + beta  (the expression of dpmn_layernorm_f32)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(ln_w + 16 * nt + 4 * kq), bt = *reinterpret_cast<const f32x4*>(ln_b + 16 * nt + 4 * kq);
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (x1r[nt][r] - mean) * rstd * gm[r] + bt[r];
+        *reinterpret_cast<f32x4*>(n2_out + roff + 16 * nt) = v;
+      }
+    }
+    // ---- y = rstd * (W' x1 - mean * rowsum(W')) + b'
+    f32x4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* wa = Ws + lr * LDW + 4 * kq;
+    if constexpr (OCC >= 3) {
+#pragma unroll
+      for (int c = 0; c < KC; ++c) {
+        f32x4 wf1[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf1[nt] = *reinterpret_cast<const f32x4*>(wa + 16 * nt * LDW + 16 * c);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf1[nt][s4], x1r[c][s4], acc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+    f32x4 wf[2][NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) wf[0][nt] = *reinterpret_cast<const f32x4*>(wa + 16 * nt * LDW);
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+      if (c + 1 < KC) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[(c + 1) & 1][nt] = *reinterpret_cast<const f32x4*>(wa + 16 * nt * LDW + 16 * (c + 1));
+      }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16(wf[c & 1][nt][s4], x1r[c][s4], acc[nt]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    }
+    const float nm = -mean * rstd;
+    const size_t yoff = m * N + n_blk + 4 * kq;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 16 * nt + 4 * kq);
+      const f32x4 cw = *reinterpret_cast<const f32x4*>(pb + BN + 16 * nt + 4 * kq);
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = fmaf(acc[nt][r], rstd, fmaf(nm, cw[r], b4[r]));
+      *reinterpret_cast<f32x4*>(y + yoff + 16 * nt) = v;
+    }
+  }
+}
+
 template <int K, int PRO, int EPI>
 int launch_rowreg(const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p, const EpiArgs& e,
                   hipStream_t st) {
@@ -1109,6 +1339,47 @@ int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_h
   ProArgs p{};
   p.sel = attn_vec; p.rows_per_image = rows_per_image; p.groups = groups;
   return dispatch_wholeK<PRO_SKSEL>(C / groups, cat, C, w_head, out, C, M, C, p, e, as_stream(stream));
+}
+
+int dpmn_sk_mlp_in_f32(const float* cat, const float* attn_vec, const float* w_head, const float* b_head, const float* feats,
+                       const float* shortcut, float* x1, const float* ln_w, const float* ln_b, float eps, const float* w_fc1,
+                       const float* b_fc1, float* y, float* v_out, float* n2_out, int M, int rows_per_image, int C, int groups, int N,
+                       dpmn_stream_t stream) {
+  DPMN_REQUIRE(cat && attn_vec && w_head && feats && shortcut && x1 && ln_w && ln_b && w_fc1 && y, "sk_mlp_in: null pointer");
+  DPMN_REQUIRE((v_out == nullptr) == (n2_out == nullptr), "sk_mlp_in: the two training outputs go together");
+  DPMN_REQUIRE(C == 96 && groups == 3 && N % 96 == 0 && M % 16 == 0 && rows_per_image % 16 == 0 && M >= 1024,
+               "sk_mlp_in: built for dim 96, three window groups, whole 16-token tiles (dpmn_sk_mlp_in_supported)");
+  constexpr int Cc = 96, CG = 32;
+  const size_t smem = (size_t)(96 * (Cc + PAD) + 3 * 96 + 96 * (CG + PAD)) * sizeof(float);      // 53376 B: proj_head is the larger tenant of its region
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sk_mlp_in<Cc, CG, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sk_mlp_in<Cc, CG, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sk_mlp_in<Cc, CG, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sk_mlp_in<Cc, CG, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  static const int occ = getenv("DPMN_SKMLP_OCC") ? atoi(getenv("DPMN_SKMLP_OCC")) : 2;
+  const int tiles = M / 16, ny = N / 96;
+  static const int blocks = getenv("DPMN_SKMLP_BLOCKS") ? atoi(getenv("DPMN_SKMLP_BLOCKS")) : 256 * (occ >= 3 ? 3 : 2);
+  int gx = blocks / ny;
+  if (gx < 1) gx = 1;
+  if (gx * 4 > tiles) gx = cdiv(tiles, 4);
+  hipStream_t st = as_stream(stream);
+  // algorithmic work of the two products; compulsory bytes: cat, feats, shortcut in, x1 and y out, both weight matrices
+  ProfScope prof(PT_GEMM_WSTAT_LN, st, 2.0 * M * ((double)N * Cc + (double)Cc * CG),
+                 4.0 * ((double)M * Cc * 4 + (double)M * N + (double)N * Cc + (double)Cc * CG));
+#define SKMLP_LAUNCH(SAVE_, OCC_) hipLaunchKernelGGL((k_sk_mlp_in<Cc, CG, SAVE_, OCC_>), dim3(gx, ny), dim3(256), smem, st, cat, attn_vec, rows_per_image, \
+                                                    w_head, b_head, feats, shortcut, x1, ln_w, ln_b, eps, w_fc1, b_fc1, y, M, N, v_out, n2_out)
+  if (v_out) { if (occ >= 3) SKMLP_LAUNCH(true, 3); else SKMLP_LAUNCH(true, 2); }
+  else { if (occ >= 3) SKMLP_LAUNCH(false, 3); else SKMLP_LAUNCH(false, 2); }
+#undef SKMLP_LAUNCH
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_sk_mlp_in_supported(int M, int rows_per_image, int C, int groups, int N) {
+  return C == 96 && groups == 3 && N % 96 == 0 && M % 16 == 0 && rows_per_image % 16 == 0 && M >= 1024 && !g_dpmn_bf16;
 }
 
 int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, int Ch, int L, dpmn_stream_t stream) {

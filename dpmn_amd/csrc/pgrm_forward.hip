@@ -92,10 +92,18 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
     const int cg = C / w->n_groups;
     RUN(dpmn_sk_gate_f32(s.partial, (L + 31) / 32, L, p.sk_fc1_w, p.sk_fc1_b, p.sk_fc2_w, p.sk_fc2_b, s.avec, B, C,
                          w->n_groups, cg / 2, stream));
+    static const int skmlp = getenv("DPMN_SKMLP") ? atoi(getenv("DPMN_SKMLP")) : 1;
+    const bool fused_in = skmlp && dpmn_sk_mlp_in_supported(M, L, C, w->n_groups, Ch);
+    if (fused_in)      // select + proj_head + residuals -> x1 -> LayerNorm2 -> fc1 in one launch (gemm.hip k_sk_mlp_in)
+      RUN(dpmn_sk_mlp_in_f32(s.cat, s.avec, p.sk_head_w, p.sk_head_b, s.feats, s.tkv, s.x1, p.norm2_w, p.norm2_b, 1e-5f, p.fc1_w, p.fc1_b,
+                             s.y, nullptr, nullptr, M, L, C, w->n_groups, Ch, stream));
+    else
     RUN(dpmn_sk_select_f32(s.cat, s.avec, p.sk_head_w, p.sk_head_b, s.feats, s.tkv, s.x1, M, L, C, w->n_groups, stream));
     // fc1's GELU (pgrm.py:33): on load in the depthwise conv (HBM-bound, the erf is free there: fc1 48.7 -> 44.2 us, dwconv 36.6 -> 37.8 us), or (DPMN_GELU_ON_LOAD=0) in the epilogue of the MFMA-bound fc1 GEMM
     static const int gelu_on_load = getenv("DPMN_GELU_ON_LOAD") ? atoi(getenv("DPMN_GELU_ON_LOAD")) : 1;
-    if (gelu_on_load) {
+    if (fused_in) {
+      RUN(dpmn_dwconv3x3_gelu_in_f32(s.y, p.dw_w, p.dw_b, s.g, B, Ch, r, stream));
+    } else if (gelu_on_load) {
       RUN(dpmn_ln_linear_f32(s.x1, p.norm2_w, p.norm2_b, 1e-5f, p.fc1_w, p.fc1_b, s.y, M, Ch, C, DPMN_ACT_NONE, stream));
       RUN(dpmn_dwconv3x3_gelu_in_f32(s.y, p.dw_w, p.dw_b, s.g, B, Ch, r, stream));
     } else {

@@ -167,6 +167,43 @@ def sk_fuse(cat, shortcut, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, head_w, h
     return out, avec
 
 
+def sk_mlp_in_supported(M, L, Cd, groups, N):
+    return bool(lib.dpmn_sk_mlp_in_supported(M, L, Cd, groups, N))
+
+
+def sk_mlp_in(cat, avec, head_w, head_b, feats, shortcut, ln_w, ln_b, fc1_w, fc1_b, L, save=False, eps=1e-5):
+    """One launch for x1 = proj_head(sum_g avec_g cat_g) + b + feats + shortcut and y = fc1(LayerNorm(x1)) on (M, C) rows.
+    Returns (x1, y) or, save=True (training forward), (x1, y, V, n2)."""
+    M, Cd = cat.shape
+    G, N = avec.shape[1], fc1_w.shape[0]
+    x1, y = torch.empty_like(cat), torch.empty(M, N, device=cat.device)
+    V = torch.empty(M, Cd // G, device=cat.device) if save else None
+    n2 = torch.empty_like(cat) if save else None
+    check(lib.dpmn_sk_mlp_in_f32(dptr(cat), dptr(avec), dptr(head_w), dptr(head_b), dptr(feats), dptr(shortcut), dptr(x1), dptr(ln_w), dptr(ln_b),
+                                 eps, dptr(fc1_w), dptr(fc1_b, True), dptr(y), dptr(V, True), dptr(n2, True), M, L, Cd, G, N, stream()))
+    return (x1, y, V, n2) if save else (x1, y)
+
+
+def sk_fuse_mlp_in(cat, shortcut, proj_w, proj_b, fc1_w, fc1_b, fc2_w, fc2_b, head_w, head_b, groups, ln_w, ln_b, mlp_fc1_w, mlp_fc1_b,
+                   eps=1e-5):
+    """x1 = shortcut + SKConv(cat) and y = Mlp.fc1(LayerNorm2(x1)) (no activation) with the select / proj_head / residual /
+    LayerNorm / fc1 part in ONE launch (dpmn_sk_mlp_in_f32; pgrm.py:79-96, 327-331, 31).  Returns (x1, y)."""
+    B, L, Cd = cat.shape
+    M, N = B * L, mlp_fc1_w.shape[0]
+    feats = torch.empty_like(cat)
+    parts = (L + 31) // 32
+    partial = torch.empty(B * parts, Cd, device=cat.device)
+    avec = torch.empty(B, groups, Cd // groups, device=cat.device)
+    x1 = torch.empty_like(cat)
+    y = torch.empty(B, L, N, device=cat.device)
+    check(lib.dpmn_sk_proj_f32(dptr(cat), dptr(proj_w), dptr(proj_b), dptr(feats), dptr(partial), M, Cd, stream()))
+    check(lib.dpmn_sk_gate_f32(dptr(partial), parts, L, dptr(fc1_w), dptr(fc1_b), dptr(fc2_w), dptr(fc2_b), dptr(avec), B,
+                               Cd, groups, fc1_w.shape[0], stream()))
+    check(lib.dpmn_sk_mlp_in_f32(dptr(cat), dptr(avec), dptr(head_w), dptr(head_b), dptr(feats), dptr(shortcut), dptr(x1), dptr(ln_w), dptr(ln_b),
+                                 eps, dptr(mlp_fc1_w), dptr(mlp_fc1_b, True), dptr(y), None, None, M, L, Cd, groups, N, stream()))
+    return x1, y
+
+
 def dwconv3x3_gelu(y, w, bias, r):
     B, L, Ch = y.shape
     g = torch.empty_like(y)

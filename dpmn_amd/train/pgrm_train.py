@@ -227,6 +227,8 @@ class ConvSpec:
 
 FUSED_ATTN = os.environ.get("DPMN_ATTN_FUSED_TRAIN", "1") != "0"      # 0: LayerNorm / q / kv / window-attention as separate launches
 
+FUSED_SKMLP = os.environ.get("DPMN_SKMLP_TRAIN", "1") != "0"          # 0: select / proj_head / LayerNorm2 / fc1 as separate launches
+
 N_SEEDS = 12     # [0] pos_drop(x_q) [1] pos_drop(x_kv); block bi at 2+5*bi: attn_drop, DropPath(attn), Mlp drop 1, Mlp drop 2, DropPath(mlp)
 
 
@@ -294,15 +296,21 @@ def forward(m, x_q, x_kv, residuals, drop=None):
         s["avec"] = _e(B, G, Cd // G, like=tkv)
         check(lib.dpmn_sk_gate_f32(dptr(s["partial"]), parts, L, dptr(sk.fc1.weight), dptr(sk.fc1.bias), dptr(sk.fc2.weight),
                                    dptr(sk.fc2.bias), dptr(s["avec"]), B, Cd, G, sk.fc1.weight.shape[0], stream()))
-        s["V"] = _e(M, Cd // G, like=tkv)
-        check(lib.dpmn_sk_select_only_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(s["V"]), M, L, Cd, G, stream()))
-        if dpb > 0:      # x1 = shortcut + DropPath(attention branch)
-            branch = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"])
-            s["x1"] = ops.dropout(branch, p_row=dpb, seed_row=sb[1], row_len=L * Cd, res=tkv)
+        if FUSED_SKMLP and dpb <= 0 and ops.sk_mlp_in_supported(M, L, Cd, G, Ch):
+            # select + proj_head + both residuals -> x1 -> LayerNorm2 -> fc1 in one launch (gemm.hip k_sk_mlp_in), V and n2 written
+            # on the way for the backward's weight-gradient GEMMs: replaces four launches
+            s["x1"], s["ypre"], s["V"], s["n2"] = ops.sk_mlp_in(s["cat"], s["avec"], sk.proj_head.weight, sk.proj_head.bias, s["feats"], tkv,
+                                                                 blk.norm2.weight, blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, L, save=True)
         else:
-            s["x1"] = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"], res2=tkv)
-        s["n2"] = layernorm(s["x1"], blk.norm2.weight, blk.norm2.bias)
-        s["ypre"] = ops.linear(s["n2"], mlp.fc1.weight, mlp.fc1.bias)
+            s["V"] = _e(M, Cd // G, like=tkv)
+            check(lib.dpmn_sk_select_only_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(s["V"]), M, L, Cd, G, stream()))
+            if dpb > 0:      # x1 = shortcut + DropPath(attention branch)
+                branch = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"])
+                s["x1"] = ops.dropout(branch, p_row=dpb, seed_row=sb[1], row_len=L * Cd, res=tkv)
+            else:
+                s["x1"] = ops.linear(s["V"], sk.proj_head.weight, sk.proj_head.bias, res1=s["feats"], res2=tkv)
+            s["n2"] = layernorm(s["x1"], blk.norm2.weight, blk.norm2.bias)
+            s["ypre"] = ops.linear(s["n2"], mlp.fc1.weight, mlp.fc1.bias)
         # the two GELUs and the element dropout between fc1's GELU and the conv ride in the depthwise conv (on load / second output)
         r = int(round(L ** 0.5))
         s["gpre"], s["g"] = _e(M, Ch, like=tkv), _e(M, Ch, like=tkv)

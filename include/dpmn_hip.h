@@ -63,6 +63,16 @@ int dpmn_sk_proj_f32(const float* cat, const float* w, const float* bias, float*
 int dpmn_sk_select_f32(const float* cat, const float* attn_vec, const float* w_head, const float* b_head,
                        const float* feats, const float* shortcut, float* out, int M, int rows_per_image, int C,
                        int groups, dpmn_stream_t stream);
+/* SKConv select + proj_head + both residuals (= dpmn_sk_select_f32) -> LayerNorm2 -> Mlp.fc1 (= dpmn_ln_linear_f32) in ONE launch
+ * (pgrm.py:91-96, 327-331, 31): x1 = proj_head(sum_g A[b][g] cat_g) + b_head + feats + shortcut is written once (fc2's residual)
+ * and fed to fc1 from registers; y (M, N) = fc1(LayerNorm(x1)) WITHOUT activation (the depthwise conv applies fc1's GELU on load).
+ * v_out (M, C / groups), n2_out (M, C): both NULL, or (training forward) the group sum fed to proj_head and LayerNorm2(x1), which the
+ * backward's weight-gradient GEMMs read.  Bitwise equal to the two calls it replaces.  dim 96 / three window groups only: ask dpmn_sk_mlp_in_supported first. */
+int dpmn_sk_mlp_in_f32(const float* cat, const float* attn_vec, const float* w_head, const float* b_head, const float* feats,
+                       const float* shortcut, float* x1, const float* ln_w, const float* ln_b, float eps, const float* w_fc1,
+                       const float* b_fc1, float* y, float* v_out, float* n2_out, int M, int rows_per_image, int C, int groups, int N,
+                       dpmn_stream_t stream);
+int dpmn_sk_mlp_in_supported(int M, int rows_per_image, int C, int groups, int N);
 /* z[b] = w (Ch,Ch) . g[b] (Ch,L) + bias : Mlp.pointwise_conv on the raw (B,Ch,r,r) view (pgrm.py:34,37) */
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream);

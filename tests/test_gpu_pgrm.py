@@ -262,6 +262,34 @@ def test_sk_fuse(dev):
     assert_close(got, ref, ATOL, RTOL, "shortcut + SKConv")
 
 
+@pytest.mark.parametrize("B", [1, 3, 48])
+def test_sk_select_ln2_fc1_one_launch_equals_two_and_oracle(dev, B):
+    """dpmn_sk_mlp_in_f32 (select + proj_head + residuals -> x1 -> LayerNorm2 -> fc1 in one launch) is bitwise equal to
+    dpmn_sk_select_f32 + dpmn_ln_linear_f32, and both match the oracle (pgrm.py:79-96, 327-331, 31)."""
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    L, C, N = 1024, 96, 384
+    sd = {"proj.weight": u("a", (C, C), -0.2, 0.2), "proj.bias": u("b", (C,)),
+          "fc1.weight": u("c", (16, C), -0.3, 0.3), "fc1.bias": u("d", (16,)),
+          "fc2.weight": u("e", (C, 16), -0.5, 0.5), "fc2.bias": u("f", (C,)),
+          "proj_head.weight": u("g", (C, 32), -0.3, 0.3), "proj_head.bias": u("h", (C,))}
+    ln_w, ln_b = u("lnw", (C,), 0.5, 1.5), u("lnb", (C,), -0.3, 0.3)
+    w1, b1 = u("w1", (N, C), -0.2, 0.2), u("b1", (N,))
+    cat, sc = u("cat", (B, L, C)), u("sc", (B, L, C))
+    d = cu(sd, dev)
+    args = (d["proj.weight"], d["proj.bias"], d["fc1.weight"], d["fc1.bias"], d["fc2.weight"], d["fc2.bias"], d["proj_head.weight"],
+            d["proj_head.bias"], 3)
+    x1_two, _ = ops.sk_fuse(cat.to(dev), sc.to(dev), *args)
+    y_two = ops.ln_linear(x1_two.reshape(-1, C), ln_w.to(dev), ln_b.to(dev), w1.to(dev), b1.to(dev)).reshape(B, L, N)
+    x1, y = ops.sk_fuse_mlp_in(cat.to(dev), sc.to(dev), *args, ln_w.to(dev), ln_b.to(dev), w1.to(dev), b1.to(dev))
+    assert torch.equal(x1, x1_two) and torch.equal(y, y_two)
+    if B <= 3:
+        x1_ref = sc + o.sk_fuse(cat, sd, "", 3)
+        y_ref = F.linear(F.layer_norm(x1_ref, (C,), ln_w, ln_b, 1e-5), w1, b1)
+        assert_close(x1, x1_ref, ATOL, RTOL, "x1")
+        assert_close(y, y_ref, 2e-4, 2e-4, "fc1(LayerNorm2(x1))")
+
+
 def test_mlp_chain_vs_golden(dev):
     from dpmn_amd import ops
     g = load_golden("mlp")
