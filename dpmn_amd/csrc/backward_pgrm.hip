@@ -412,7 +412,8 @@ __global__ void k_sk_select(const float* __restrict__ cat, const float* __restri
 // dcat[m][g*cg+c] (+)= A[b][g][c] * dV[m][c] ; dA[b][g][c] += sum over the block's tokens of cat * dV
 __global__ __launch_bounds__(256) void k_sk_select_bwd(const float* __restrict__ cat, const float* __restrict__ A,
                                                         const float* __restrict__ dV, float* __restrict__ dcat,
-                                                        float* __restrict__ dA, int L, int C, int G, int rows_per_block) {
+                                                        float* __restrict__ dA, int L, int C, int G, int rows_per_block, int part_mode) {
+  // part_mode 1: dA is (gridDim.x, B, C) -- every block STORES its partial row, the gate backward adds them in block order (no atomics)
   const int cg = C / G;
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block;
@@ -426,7 +427,8 @@ __global__ __launch_bounds__(256) void k_sk_select_bwd(const float* __restrict__
       acc += cat[m * C + col] * dv;
       dcat[m * C + col] += a * dv;
     }
-    atomicAdd(dA + ((size_t)b * G + g) * cg + c, acc);
+    if (part_mode) dA[((size_t)blockIdx.x * gridDim.y + b) * C + col] = acc;
+    else atomicAdd(dA + ((size_t)b * G + g) * cg + c, acc);
   }
 }
 // one workgroup per image: gate MLP backward (pgrm.py:86-91).  S = mean_t GELU(feats) from the forward partials.
@@ -434,14 +436,27 @@ __global__ void k_sk_gate_bwd(const float* __restrict__ partial, int parts_per_i
                               const float* __restrict__ fc1_b, const float* __restrict__ fc2_w, const float* __restrict__ A,
                               const float* __restrict__ dA, float* __restrict__ dS, float* __restrict__ dfc1_w,
                               float* __restrict__ dfc1_b, float* __restrict__ dfc2_w, float* __restrict__ dfc2_b, int C, int G,
-                              int dmid) {
+                              int dmid, int nparts, float* __restrict__ wpart2, float* __restrict__ wpart1) {
+  // nparts > 0: dA is the (nparts, B, C) partial-row buffer of k_sk_select_bwd (part_mode), added here in block order;
+  // wpart2 / wpart1 != null: this image's weight-gradient contributions are STORED as row b of (B, C dmid + C) / (B, dmid C + dmid)
+  // buffers (fc2 | bias, fc1 | bias) that the caller adds in image order (dpmn_rows_reduce_f32 / the deferred multi reduce)
   extern __shared__ float sm[];
   float* S = sm;             // [C]
   float* zp = S + C;         // [dmid] pre-GELU
   float* Z = zp + dmid;      // [dmid]
   float* dl = Z + dmid;      // [C] dlogit
   float* dz = dl + C;        // [dmid] grad wrt pre-GELU
+  float* dAs = dz + dmid;    // [C] (nparts > 0)
   const int b = blockIdx.x, cg = C / G;
+  if (nparts > 0) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float s = 0.f;
+      for (int p = 0; p < nparts; ++p) s += dA[((size_t)p * gridDim.x + b) * C + c];
+      dAs[c] = s;
+    }
+    __syncthreads();
+  }
+  auto dA_at = [&](int g, int c) { return nparts > 0 ? dAs[g * cg + c] : dA[((size_t)b * G + g) * cg + c]; };
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
     for (int p = 0; p < parts_per_image; ++p) s += partial[((size_t)b * parts_per_image + p) * C + c];
@@ -456,15 +471,21 @@ __global__ void k_sk_gate_bwd(const float* __restrict__ partial, int parts_per_i
   }
   for (int c = threadIdx.x; c < cg; c += blockDim.x) {
     float dot = 0.f;
-    for (int g = 0; g < G; ++g) dot += A[((size_t)b * G + g) * cg + c] * dA[((size_t)b * G + g) * cg + c];
+    for (int g = 0; g < G; ++g) dot += A[((size_t)b * G + g) * cg + c] * dA_at(g, c);
     for (int g = 0; g < G; ++g) {
       const float a = A[((size_t)b * G + g) * cg + c];
-      dl[g * cg + c] = a * (dA[((size_t)b * G + g) * cg + c] - dot);
+      dl[g * cg + c] = a * (dA_at(g, c) - dot);
     }
   }
   __syncthreads();
+  if (wpart2) {
+    float* row = wpart2 + (size_t)b * (C * dmid + C);
+    for (int i = threadIdx.x; i < C * dmid; i += blockDim.x) row[i] = dl[i / dmid] * Z[i % dmid];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) row[C * dmid + c] = dl[c];
+  } else {
   for (int i = threadIdx.x; i < C * dmid; i += blockDim.x) atomicAdd(dfc2_w + i, dl[i / dmid] * Z[i % dmid]);
   for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(dfc2_b + c, dl[c]);
+  }
   for (int j = threadIdx.x; j < dmid; j += blockDim.x) {
     float a = 0.f;
     for (int c = 0; c < C; ++c) a += dl[c] * fc2_w[c * dmid + j];
@@ -473,8 +494,14 @@ __global__ void k_sk_gate_bwd(const float* __restrict__ partial, int parts_per_i
     dz[j] = a * (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x));
   }
   __syncthreads();
+  if (wpart1) {
+    float* row = wpart1 + (size_t)b * (dmid * C + dmid);
+    for (int i = threadIdx.x; i < dmid * C; i += blockDim.x) row[i] = dz[i / C] * S[i % C];
+    for (int j = threadIdx.x; j < dmid; j += blockDim.x) row[dmid * C + j] = dz[j];
+  } else {
   for (int i = threadIdx.x; i < dmid * C; i += blockDim.x) atomicAdd(dfc1_w + i, dz[i / C] * S[i % C]);
   for (int j = threadIdx.x; j < dmid; j += blockDim.x) atomicAdd(dfc1_b + j, dz[j]);
+  }
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float a = 0.f;
     for (int j = 0; j < dmid; ++j) a += dz[j] * fc1_w[j * C + c];
@@ -947,7 +974,17 @@ int dpmn_sk_select_bwd_f32(const float* cat, const float* attn_vec, const float*
                            int G, dpmn_stream_t stream) {
   DPMN_REQUIRE(cat && attn_vec && dV && dcat && dA && B > 0, "sk_select_bwd: bad arguments");
   const int rows = 32;
-  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA, L, C, G, rows);
+  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA, L, C, G, rows, 0);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// the same without atomics: dA_part is (ceil(L / 32), B, C); dpmn_sk_gate_bwd_det_f32 adds the rows in order
+int dpmn_sk_select_bwd_det_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA_part, int B, int L, int C,
+                               int G, dpmn_stream_t stream) {
+  DPMN_REQUIRE(cat && attn_vec && dV && dcat && dA_part && B > 0, "sk_select_bwd_det: bad arguments");
+  const int rows = 32;
+  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA_part, L, C, G, rows, 1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -957,8 +994,23 @@ int dpmn_sk_gate_bwd_f32(const float* colsum_partials, int parts_per_image, int 
                          float* dfc2_w, float* dfc2_b, int B, int C, int G, int dmid, dpmn_stream_t stream) {
   DPMN_REQUIRE(colsum_partials && fc1_w && fc1_b && fc2_w && attn_vec && dA && dS && dfc1_w && dfc1_b && dfc2_w && dfc2_b,
                "sk_gate_bwd: null pointer");
-  hipLaunchKernelGGL(k_sk_gate_bwd, dim3(B), dim3(128), (size_t)(2 * C + 3 * dmid) * 4, as_stream(stream), colsum_partials,
-                     parts_per_image, L, fc1_w, fc1_b, fc2_w, attn_vec, dA, dS, dfc1_w, dfc1_b, dfc2_w, dfc2_b, C, G, dmid);
+  hipLaunchKernelGGL(k_sk_gate_bwd, dim3(B), dim3(128), (size_t)(3 * C + 3 * dmid) * 4, as_stream(stream), colsum_partials,
+                     parts_per_image, L, fc1_w, fc1_b, fc2_w, attn_vec, dA, dS, dfc1_w, dfc1_b, dfc2_w, dfc2_b, C, G, dmid, 0,
+                     static_cast<float*>(nullptr), static_cast<float*>(nullptr));
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// the same without atomics: dA_part (nparts, B, C) from dpmn_sk_select_bwd_det_f32; the weight gradients as per-image rows
+// wpart2 (B, C dmid + C) = [dfc2_w | dfc2_b], wpart1 (B, dmid C + dmid) = [dfc1_w | dfc1_b] for dpmn_rows_reduce_f32
+int dpmn_sk_gate_bwd_det_f32(const float* colsum_partials, int parts_per_image, int L, const float* fc1_w, const float* fc1_b,
+                             const float* fc2_w, const float* attn_vec, const float* dA_part, int nparts, float* dS, float* wpart2,
+                             float* wpart1, int B, int C, int G, int dmid, dpmn_stream_t stream) {
+  DPMN_REQUIRE(colsum_partials && fc1_w && fc1_b && fc2_w && attn_vec && dA_part && nparts > 0 && dS && wpart2 && wpart1,
+               "sk_gate_bwd_det: null pointer");
+  hipLaunchKernelGGL(k_sk_gate_bwd, dim3(B), dim3(128), (size_t)(3 * C + 3 * dmid) * 4, as_stream(stream), colsum_partials,
+                     parts_per_image, L, fc1_w, fc1_b, fc2_w, attn_vec, dA_part, dS, static_cast<float*>(nullptr), static_cast<float*>(nullptr),
+                     static_cast<float*>(nullptr), static_cast<float*>(nullptr), C, G, dmid, nparts, wpart2, wpart1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -399,6 +399,14 @@ int dpmn_sk_select_bwd_f32(const float* cat, const float* attn_vec, const float*
 int dpmn_sk_gate_bwd_f32(const float* colsum_partials, int parts_per_image, int L, const float* fc1_w, const float* fc1_b,
                          const float* fc2_w, const float* attn_vec, const float* dA, float* dS, float* dfc1_w,
                          float* dfc1_b, float* dfc2_w, float* dfc2_b, int B, int C, int G, int dmid, dpmn_stream_t stream);
+/* atomics-free forms (bitwise reproducible): dA_part is (ceil(L / 32), B, C) partial rows that the gate backward adds in order; the
+ * gate's weight gradients come back as per-image rows wpart2 (B, C dmid + C) = [dfc2_w | dfc2_b] and wpart1 (B, dmid C + dmid) =
+ * [dfc1_w | dfc1_b] for dpmn_rows_reduce_f32 (pgrm.py:86-93 backward) */
+int dpmn_sk_select_bwd_det_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA_part, int B, int L,
+                               int C, int G, dpmn_stream_t stream);
+int dpmn_sk_gate_bwd_det_f32(const float* colsum_partials, int parts_per_image, int L, const float* fc1_w, const float* fc1_b,
+                             const float* fc2_w, const float* attn_vec, const float* dA_part, int nparts, float* dS, float* wpart2,
+                             float* wpart1, int B, int C, int G, int dmid, dpmn_stream_t stream);
 int dpmn_sk_feats_grad_f32(const float* dout, const float* feats, const float* dS, float* dfeats, long M, int L, int C,
                            dpmn_stream_t stream);
 /* Mlp depthwise conv without the activation (training keeps the pre-activation), its backward, and the

@@ -114,22 +114,35 @@ def test_cmm_cnum64_train_fwd_bwd_at_b8_vs_oracle_autograd(dev):
     assert (num / den) ** 0.5 < 1e-2
 
 
-# tolerances of the step test = ~3x the errors recorded in profiles/ (r02f at B = 4, r03 at B = 48), floor 1e-5
-CFG2_TOL = {4: dict(loss=1e-6, pgrm=3e-4, pgrm_b2=2.5e-3, cmm=2e-3, distill=2e-3),
-            48: dict(loss=2e-6, pgrm=5e-4, pgrm_b2=3e-3, cmm=3.6e-3, distill=4.5e-4)}
+# config 4 cascades six PGRMs per branch and the error grows along the cascade: per-stage tolerance = 3x the recorded error
+# (r03l: 1.2e-5, 1.3e-5, 2.6e-5, 3.5e-5, 7.3e-5, 1.5e-4 at stages 0..5)
+CFG4_STAGE_TOL = [4e-5, 4e-5, 8e-5, 1.1e-4, 2.3e-4, 4.5e-4]
+
+# tolerances of the step test = 3x the errors recorded in profiles/r03l_parity_errors.json (per model kind and batch), floor 1e-5
+# (loss: floor 5e-7).  Recorded: B = 4 -- loss 1.1e-7, text-prior PGRMs 4.8e-5, mask-prior PGRMs 3.2e-4, CMM 4.3e-4, DistillModules
+# 8e-7; B = 48 -- loss 6e-7, 1.2e-4, 5.8e-4, 1.2e-3, 9e-5
+CFG2_TOL = {4: dict(loss=5e-7, pgrm=1.5e-4, pgrm_b2=1e-3, cmm=1.3e-3, distill=1e-5),
+            48: dict(loss=2e-6, pgrm=3.6e-4, pgrm_b2=1.8e-3, cmm=3.6e-3, distill=2.7e-4)}
 
 
-@pytest.mark.parametrize("B", [4, 48])
-def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev, B):
+# the same step with bf16 MFMA operands (BASELINE.json configs[2] names bf16; dpmn_set_compute_dtype(1): convs and the pointwise GEMM
+# of forward and data-gradient passes, fp32 everything else) against the SAME fp32 oracle autograd: 3x the recorded errors (r04)
+# recorded (r04a): loss 1.7e-3, text-prior PGRMs 5.3e-3, mask-prior PGRMs 1.4e-2, CMM 1.4e-2, DistillModules 4.9e-3
+CFG2_TOL_BF16 = {48: dict(loss=5e-3, pgrm=1.6e-2, pgrm_b2=4.2e-2, cmm=4.2e-2, distill=1.5e-2)}
+
+
+@pytest.mark.parametrize("B,bf16", [(4, False), (48, False), (48, True)])
+def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev, B, bf16):
     """BASELINE.json configs[2]'s step on its own stack -- TATT PSN (frozen) + 3+3 PGRM + 4 DistillModules + CMM -- at B = 4 and
     at the batch bench.py times (B = 48: other split factors, block counts and workspace sizes than B = 4):
     loss, and every model's gradient (whole-model relative L2, what the per-model clip sees) vs autograd through the oracle."""
     from dpmn_amd import workload
     from dpmn_amd.interfaces.super_resolution import TextSR
     from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn
-    name = "cfg2_step_tatt3p3_B%d" % B
+    name = "cfg2_step_tatt3p3_B%d%s" % (B, "_bf16" if bf16 else "")
     b1, b2 = 3, 3
-    tols = CFG2_TOL[B]
+    tols = CFG2_TOL_BF16[B] if bf16 else CFG2_TOL[B]
+    from dpmn_amd import _abi
     torch.set_num_threads(min(32, torch.get_num_threads()))
     sr_ = TextSR(workload.make_config(B), workload.make_args("tatt", b1, b2, B))
     models, psn, distill, crit, trainer = sr_.build_training()
@@ -143,8 +156,13 @@ def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev, B):
     sd0 = [{k: v.detach().cpu().clone() for k, v in m.state_dict().items()} for m in [psn] + models + distill]
     batch = synth.synth_batch(B, seed=6)
     priors = [torch.floor(synth.uniform("tq%d" % k, (B, 2, 32, 128), 0, 256, 6)) for k in range(b1)]
-    loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev),
-                          batch["label_vecs"].to(dev), text_priors=[p.to(dev) for p in priors])
+    _abi.check(_abi.lib.dpmn_set_compute_dtype(1 if bf16 else 0))
+    try:
+        loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev),
+                              batch["label_vecs"].to(dev), text_priors=[p.to(dev) for p in priors])
+        torch.cuda.synchronize()
+    finally:
+        _abi.check(_abi.lib.dpmn_set_compute_dtype(0))
     ref = [{k: v.clone().requires_grad_(torch.is_floating_point(v) and "running" not in k and "index" not in k and "mask" not in k)
             for k, v in sd.items()} for sd in sd0]
     with torch.no_grad():
@@ -301,15 +319,15 @@ def test_cfg4_stress_at_bench_batch_rows_vs_small_batch_and_oracle(dev):
         casc, l1 = r_psn, []
         for k in range(6):
             o = opgrm.pgrm_forward(sds[k], pri2[k], casc[:, :3], l1[:k], windows=win); l1.append(o); casc = o
-            record(name, "branch1[%d] rows max|err|" % k, max_abs_err(mid["branch1"][k][rows], o), 4.5e-4)
-            assert_close(mid["branch1"][k][rows], o, 4.5e-4, 4.5e-4, "cfg4 B=96 branch1[%d]" % k)
+            record(name, "branch1[%d] rows max|err|" % k, max_abs_err(mid["branch1"][k][rows], o), CFG4_STAGE_TOL[k])
+            assert_close(mid["branch1"][k][rows], o, CFG4_STAGE_TOL[k], CFG4_STAGE_TOL[k], "cfg4 B=96 branch1[%d]" % k)
         casc_gpu, casc, l2 = mid["psn"][rows], r_psn, []
         for k in range(6, 12):
             m_gpu = ops.to_mask(casc_gpu.contiguous()).cpu()
             o = opgrm.pgrm_forward(sds[k], m_gpu, casc[:, :3], l2[:(k - 6)], windows=win); l2.append(o); casc = o
             casc_gpu = mid["branch2"][k - 6][rows]
-            record(name, "branch2[%d] rows max|err|" % (k - 6), max_abs_err(casc_gpu, o), 4.5e-4)
-            assert_close(casc_gpu, o, 4.5e-4, 4.5e-4, "cfg4 B=96 branch2[%d]" % (k - 6))
+            record(name, "branch2[%d] rows max|err|" % (k - 6), max_abs_err(casc_gpu, o), CFG4_STAGE_TOL[k - 6])
+            assert_close(casc_gpu, o, CFG4_STAGE_TOL[k - 6], CFG4_STAGE_TOL[k - 6], "cfg4 B=96 branch2[%d]" % (k - 6))
         fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
         ref = 0.5 * fused + 0.5 * r_psn[:, :3]
     record(name, "output rows max|err|", max_abs_err(out[rows], ref), 8e-4)

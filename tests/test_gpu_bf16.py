@@ -150,3 +150,77 @@ def test_training_step_bf16_close_to_fp32(bf16_mode):
     record("bf16_train_step_B4", "loss rel diff vs fp32", dl, 2e-2)
     assert dl < 2e-2
     assert torch.isfinite(res[1][1]).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bf16 operands against the fp32 ORACLE at the shapes BASELINE.json names with "bf16" (configs[2..4]).  The oracle stays fp32 (the
+# reference has no bf16 path): the stated tolerances are the operand-rounding budget of the stack, 3x the errors recorded in
+# profiles/r04*_parity_errors.json.  The oracle is driven stage by stage on ITS OWN cascade (errors accumulate as they do in a run);
+# only the discrete mask priors of branch 2 are handed over from the GPU (a flipped mask pixel is not an arithmetic error).
+# recorded (r04a): worst stage 6.6e-3 (cfg3) / 6.0e-3 (cfg4), CMM 4.8e-3 / 2.0e-3, |dPSNR| 1.2e-3 / 4.7e-3 dB, |dSSIM| 2.3e-6 / 1.1e-7
+BF16_STAGE_TOL = {"cfg3": 2e-2, "cfg4": 1.8e-2}    # relative L2 error ||gpu - oracle|| / ||oracle|| of a cascade image at any stage (CMM: 2x)
+BF16_PSNR_TOL, BF16_SSIM_TOL = 1.5e-2, 1e-5        # |dPSNR| (dB), |dSSIM| of the final output against the oracle's
+
+
+def _stack_bf16_vs_oracle(name, bf16_mode, rows=None):
+    from dpmn_amd import workload, ops
+    from oracle import pgrm as opgrm, cmm as ocmm, tsrn as otsrn
+    from helpers import l2_rel
+    sr, models, psn, inp = workload.build(name)
+    spec = workload.describe(name)
+    b1, b2, win = spec["b1"], spec["b2"], spec["windows"]
+    with bf16_mode:
+        out, mid = sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"], return_all=True)
+        torch.cuda.synchronize()
+    sl = slice(None) if rows is None else rows
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    lr = inp["images_lr"][sl].cpu()
+    pri = [t_[sl].cpu() for t_ in inp["text_priors"]]
+    hr = inp["images_hr"][sl].cpu()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    tag = "bf16_%s_B%d" % (name, inp["images_lr"].shape[0])
+    tol = BF16_STAGE_TOL[name]
+    worst = 0.0
+
+    def stage(what, got, ref, t_):
+        e = l2_rel(got, ref)
+        record(tag, "%s rel L2 vs fp32 oracle (max-norm rel %.2e)" % (what, float((got.cpu() - ref).abs().max() / ref.abs().max())), e, t_)
+        return e
+    with torch.no_grad():
+        if spec["arch"] == "tbsrn":
+            r_psn = otsrn.tbsrn_forward(sd_psn, lr)
+        elif spec["arch"] == "tatt":
+            r_psn, _ = otsrn.tatt_forward(sd_psn, lr, inp["label_vecs"][sl].cpu())
+        else:
+            r_psn = otsrn.tsrn_forward(sd_psn, lr)
+        worst = max(worst, stage("psn", mid["psn"][sl], r_psn, tol))
+        casc, l1 = r_psn, []
+        for k in range(b1):
+            o = opgrm.pgrm_forward(sds[k], pri[k], casc[:, :3], l1[:k], windows=win); l1.append(o); casc = o
+            worst = max(worst, stage("branch1[%d]" % k, mid["branch1"][k][sl], o, tol))
+        casc_gpu, casc, l2 = mid["psn"][sl], r_psn, []
+        for k in range(b1, b1 + b2):
+            m_gpu = ops.to_mask(casc_gpu.contiguous()).cpu()
+            o = opgrm.pgrm_forward(sds[k], m_gpu, casc[:, :3], l2[:(k - b1)], windows=win); l2.append(o); casc = o
+            casc_gpu = mid["branch2"][k - b1][sl]
+            worst = max(worst, stage("branch2[%d]" % (k - b1), casc_gpu, o, tol))
+        fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
+        e_cmm = stage("cmm", mid["cmm"][sl], fused, 2 * tol)
+        ref = 0.5 * fused + 0.5 * r_psn[:, :3]
+        dp = abs(float(ocmm.psnr(out[sl].cpu(), hr)) - float(ocmm.psnr(ref, hr)))
+        ds = abs(float(ocmm.ssim(out[sl].cpu(), hr)) - float(ocmm.ssim(ref, hr)))
+    record(tag, "|dPSNR| vs fp32 oracle (dB)", dp, BF16_PSNR_TOL)
+    record(tag, "|dSSIM| vs fp32 oracle", ds, BF16_SSIM_TOL)
+    assert 1e-6 < worst < tol and e_cmm < 2 * tol, (worst, e_cmm)
+    assert dp < BF16_PSNR_TOL and ds < BF16_SSIM_TOL, (dp, ds)
+
+
+def test_cfg3_b64_bf16_vs_fp32_oracle(bf16_mode):
+    """BASELINE.json configs[3] (TBSRN PSN + 3+3 PGRM + CMM, B = 64) with bf16 MFMA operands vs the fp32 oracle, every stage."""
+    _stack_bf16_vs_oracle("cfg3", bf16_mode)
+
+
+def test_cfg4_b96_bf16_rows_vs_fp32_oracle(bf16_mode):
+    """BASELINE.json configs[4] (stress: dim 192, 6+6 PGRM, windows 4/8/16, 64x256, B = 96) with bf16 MFMA operands: two rows of the
+    B = 96 call vs the fp32 oracle on those rows, every stage."""
+    _stack_bf16_vs_oracle("cfg4", bf16_mode, rows=slice(57, 59))

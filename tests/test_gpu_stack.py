@@ -8,6 +8,8 @@ from dpmn_amd.utils import synth
 from helpers import load_golden, t, assert_close
 
 pytestmark = pytest.mark.gpu
+# config 4: six PGRMs per branch, the error grows along the cascade; per-stage tolerance = 3x the recorded error (r03l)
+CFG4_STAGE_TOL = [4e-5, 4e-5, 8e-5, 1.1e-4, 2.3e-4, 4.5e-4]
 
 
 def test_stack_cfg0_vs_reference_golden():
@@ -160,18 +162,18 @@ def test_stack_cfg4_stress_vs_oracle_small_batch():
         casc, l1 = r_psn, []
         for k in range(6):
             o = opgrm.pgrm_forward(sds[k], cpu["text_priors"][k], casc[:, :3], l1[:k], windows=win); l1.append(o); casc = o
-            record("cfg4_B2", "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), 4.5e-4)
-            assert_close(mid["branch1"][k], o, 4.5e-4, 4.5e-4, "cfg4 branch1[%d]" % k)
+            record("cfg4_B2", "branch1[%d] max|err|" % k, max_abs_err(mid["branch1"][k], o), CFG4_STAGE_TOL[k])
+            assert_close(mid["branch1"][k], o, CFG4_STAGE_TOL[k], CFG4_STAGE_TOL[k], "cfg4 branch1[%d]" % k)
         casc_gpu, casc, l2 = mid["psn"], r_psn, []
         for k in range(6, 12):
             o = opgrm.pgrm_forward(sds[k], ops.to_mask(casc_gpu).cpu(), casc[:, :3], l2[:(k - 6)], windows=win); l2.append(o); casc = o
             casc_gpu = mid["branch2"][k - 6]
-            record("cfg4_B2", "branch2[%d] max|err|" % (k - 6), max_abs_err(casc_gpu, o), 4.5e-4)
-            assert_close(casc_gpu, o, 4.5e-4, 4.5e-4, "cfg4 branch2[%d]" % (k - 6))
+            record("cfg4_B2", "branch2[%d] max|err|" % (k - 6), max_abs_err(casc_gpu, o), CFG4_STAGE_TOL[k - 6])
+            assert_close(casc_gpu, o, CFG4_STAGE_TOL[k - 6], CFG4_STAGE_TOL[k - 6], "cfg4 branch2[%d]" % (k - 6))
         fused = ocmm.cmm_forward(sds[-1], l1[-1], l2[-1], False)
         ref = 0.5 * fused + 0.5 * r_psn[:, :3]
-    record("cfg4_B2", "output max|err|", max_abs_err(out, ref), 2e-3)
-    assert_close(out, ref, 2e-3, 2e-3, "cfg4 output")
+    record("cfg4_B2", "output max|err|", max_abs_err(out, ref), 7.5e-4)      # (r03l: 2.4e-4 -- the CMM on 64 x 256 maps behind 12 PGRMs)
+    assert_close(out, ref, 7.5e-4, 7.5e-4, "cfg4 output")
     p, s = ops.psnr_ssim(out, inp["images_hr"])
     assert abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"]))) < 1e-3
     assert abs(float(s) - float(ocmm.ssim(ref, cpu["images_hr"]))) < 1e-3

@@ -423,7 +423,7 @@ def test_full_train_step_vs_oracle_autograd(dev):
     o = ocmm.cmm_forward(ref[1 + b1 + b2], l1[-1], l2[-1], True)
     tot = (tot + ocmm.image_loss(o, hr3, True) * 100) / (b1 + b2 + 1)
     tot.backward()
-    assert abs(float(loss) - float(tot)) < 2e-4 * abs(float(tot)), (float(loss), float(tot))
+    assert abs(float(loss) - float(tot)) < 2e-6 * abs(float(tot)), (float(loss), float(tot))
     # gradients of every model vs oracle autograd (the fused clip+Adam kernel is pinned separately above; comparing
     # Adam's first, sign-like update would amplify round-off on near-zero gradients)
     mods = models + distill
@@ -439,8 +439,10 @@ def test_full_train_step_vs_oracle_autograd(dev):
                 worst = max(worst, (n, e), key=lambda t_: t_[1])
         tot_err = (num / max(den, 1e-30)) ** 0.5
         from helpers import record
-        record("full_train_step_tsrn2p2_B2", "model %d whole-gradient rel L2 (worst tensor %s %.2e)" % (i, worst[0], worst[1]), tot_err, 1.5e-3)
-        assert tot_err < 1.5e-3, "model %d gradient differs from oracle autograd: %.3e (%s %.3e)" % (i, tot_err, worst[0], worst[1])
+        # 3x the recorded errors (r03l: text-prior PGRMs 3.1e-5, mask-prior PGRMs 2.2e-4, CMM 3.6e-4, DistillModules 8e-7), floor 1e-5
+        tol = 1e-4 if i < b1 else 7e-4 if i < b1 + b2 else 1.1e-3 if i == b1 + b2 else 1e-5
+        record("full_train_step_tsrn2p2_B2", "model %d whole-gradient rel L2 (worst tensor %s %.2e)" % (i, worst[0], worst[1]), tot_err, tol)
+        assert tot_err < tol, "model %d gradient differs from oracle autograd: %.3e (%s %.3e)" % (i, tot_err, worst[0], worst[1])
 
 
 def test_checkpoint_roundtrip_reference_format(tmp_path):
@@ -665,9 +667,14 @@ def test_training_step_vs_reference_step_fixture(dev):
         named = {n: p.grad for n, p in m.named_parameters()}
         norm = float(torch.sqrt(sum((v.double() ** 2).sum() for v in named.values())))
         ne = abs(norm - float(g["grad_norms"][i])) / float(g["grad_norms"][i])
-        record("step_fixture", "model %d clip-norm rel err" % i, ne, 5e-4)
-        assert ne < 5e-4, "model %d: the norm clip_grad_norm_ sees differs from the reference's by %.2e" % (i, ne)
-        _fixture_check("step_fixture", g, named, "m%d/" % i, tol=2e-2)
+        # 3x the recorded errors (r03l), floor 1e-5.  Clip norm: PGRMs 1.1e-4, CMM 1.4e-6, DistillModules 2.9e-7 / 3.3e-5; worst
+        # tensor vs the reference's own gradients: PGRMs 4.2e-3, CMM 6e-3 (the fp32-conditioned 1 x 4 BatchNorm levels, see
+        # tests/test_oracle_grads.py), DistillModules 2.6e-6 / 7.5e-4
+        ntol = 3.3e-4 if i < b1 + b2 else 1e-5 if i <= b1 + b2 + 1 else 1e-4
+        gtol = 1.25e-2 if i < b1 + b2 else 2e-2 if i == b1 + b2 else 1e-5 if i == b1 + b2 + 1 else 2.5e-3
+        record("step_fixture", "model %d clip-norm rel err" % i, ne, ntol)
+        assert ne < ntol, "model %d: the norm clip_grad_norm_ sees differs from the reference's by %.2e" % (i, ne)
+        _fixture_check("step_fixture", g, named, "m%d/" % i, tol=gtol)
 
 
 def test_test_mode_loads_every_checkpoint_including_cmm(dev, tmp_path):

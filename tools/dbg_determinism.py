@@ -1,0 +1,44 @@
+"""Which parameter gradients differ bitwise between two runs of the same training step?  python tools/dbg_determinism.py [tatt|tsrn] [B]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dpmn_amd import workload
+from dpmn_amd.utils import synth
+from dpmn_amd.interfaces.super_resolution import TextSR
+arch = sys.argv[1] if len(sys.argv) > 1 else "tsrn"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+b1 = b2 = 2 if arch == "tsrn" else 3
+dev = torch.device("cuda:0")
+runs = []
+for _ in range(3):
+    sr_ = TextSR(workload.make_config(B), workload.make_args(arch, b1, b2, B))
+    models, psn, distill, crit, trainer = sr_.build_training()
+    for i, m in enumerate([psn] + models + distill):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, 300 + i)
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                v.copy_(sd[k])
+    psn.eval()
+    batch = synth.synth_batch(B, seed=4)
+    priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)).to(dev) for k in range(b1)]
+    trainer.lr = 0.0
+    lv = batch["label_vecs"].to(dev) if arch == "tatt" else None
+    loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev), lv, text_priors=priors)
+    torch.cuda.synchronize()
+    runs.append((float(loss), {("m%d/" % i) + n: p.grad.detach().clone() for i, m in enumerate(models + distill) for n, p in m.named_parameters()}))
+print("losses", [r[0] for r in runs])
+bad = {}
+for k in runs[0][1]:
+    for j in (1, 2):
+        if not torch.equal(runs[0][1][k], runs[j][1][k]):
+            d = float((runs[0][1][k] - runs[j][1][k]).abs().max() / (runs[0][1][k].abs().max() + 1e-30))
+            bad[k] = max(bad.get(k, 0.0), d)
+print("%d of %d tensors differ between runs" % (len(bad), len(runs[0][1])))
+import re
+fam = {}
+for k, d in bad.items():
+    f = re.sub(r"^m\d+/", "", k); f = re.sub(r"blocks\.\d", "blocks.N", f); f = re.sub(r"table_\d", "table_N", f)
+    fam.setdefault(f, []).append(d)
+for f, ds in sorted(fam.items()):
+    print("  %-60s x%d  max rel diff %.2e" % (f, len(ds), max(ds)))
