@@ -160,6 +160,8 @@ SIGNATURES = {
     "dpmn_patch_embed_bwd_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_patch_scatter_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_prior_fusion_wgrad_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
+    "dpmn_patch_embed_bwd_det_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_prior_fusion_wgrad_det_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), fp, fp, _i, fp]),
     "dpmn_conv_pack_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, fp]),
     "dpmn_conv2d_wgrad_excl_slots": (_i, [C.POINTER(ConvDesc), fp]),
@@ -181,6 +183,8 @@ SIGNATURES = {
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_drop_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_window_attn_drop_bwd_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _i, _i, _i, _i, _f, _u64, fp]),
+    "dpmn_window_attn_drop_bwd_det_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _IP, _i, _i, _i, _i, _f, _u64, fp]),
+    "dpmn_window_attn_bwd_part_rows": (_i, [_i, _i, _i]),
     "dpmn_conv_pack_multi_f32": (_i, [fp, fp, _i, _i, fp]),
     "dpmn_conv_pack_tile_shape": (_i, [_i, _i, _i, _l, _l, fp]),
     "dpmn_mha64_f32": (_i, [fp, fp, _i, _i, _i, _f, fp]),

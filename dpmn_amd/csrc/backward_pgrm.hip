@@ -18,15 +18,20 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
                                                           const float* __restrict__ bias_table, const float* __restrict__ dout,
                                                           float* __restrict__ dq, float* __restrict__ dkv,
                                                           float* __restrict__ dtable, int B, int H, int W, int C, int g, int shift,
-                                                          float p_drop, unsigned long long seed) {
+                                                          float p_drop, unsigned long long seed, int part_mode) {
+  // part_mode 1: dtable is a (gridDim.x, TBL * 2) buffer -- every block STORES its table-gradient partial row (the caller adds
+  // the rows in block order).  The block's two slabs accumulate into their own LDS copies (the two heads of a slab write
+  // disjoint entries), added slab 0 + slab 1 at the end: no cross-wave LDS atomics on one word, bitwise reproducible.
   constexpr int N = WS * WS, CG = 2 * D, ROWS = 64, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
   static_assert(N <= 64, "windows larger than 64 tokens are not built yet");
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TB4 = (TBL * 2 + 3) & ~3;
   float* tbl = smem;                                 // [TBL*2]
-  float* dtb = smem + ((TBL * 2 + 3) & ~3);          // [TBL*2] gradient accumulator
-  float* base = dtb + ((TBL * 2 + 3) & ~3);
+  float* dtb0 = smem + TB4;                          // [2 slabs][TBL*2] gradient accumulators
+  float* base = dtb0 + 2 * TB4;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int slab_in_blk = wave >> 1, head = wave & 1;
+  float* dtb = dtb0 + slab_in_blk * TB4;
   float* Qs = base + slab_in_blk * (4 * ROWS * LDR + 6 * ROWS);
   float* Ks = Qs + ROWS * LDR;
   float* Vs = Ks + ROWS * LDR;
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
   const int t0 = (slab % slabs_per_img) * ROWS;
   const int nWc = W / WS;
   const bool active = b < B;
-  for (int i = threadIdx.x; i < TBL * 2; i += 256) { tbl[i] = bias_table[i]; dtb[i] = 0.f; }
+  for (int i = threadIdx.x; i < TBL * 2; i += 256) { tbl[i] = bias_table[i]; dtb0[i] = 0.f; dtb0[TB4 + i] = 0.f; }
   size_t src_tok = 0;
   if (active) {
     const int tl = threadIdx.x & 127;
@@ -160,7 +165,11 @@ __global__ __launch_bounds__(256) void k_window_attn_bwd(const float* __restrict
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < TBL * 2; i += 256) atomicAdd(dtable + i, dtb[i]);
+  for (int i = threadIdx.x; i < TBL * 2; i += 256) {
+    const float v = dtb0[i] + dtb0[TB4 + i];
+    if (part_mode) dtable[(size_t)blockIdx.x * (TBL * 2) + i] = v;
+    else atomicAdd(dtable + i, v);
+  }
 }
 
 // ---------------------------------------------------------------------------------- 8x8 window attention backward on MFMA
@@ -178,7 +187,8 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
                                                                 const float* __restrict__ bias_table, const float* __restrict__ dout,
                                                                 float* __restrict__ dq, float* __restrict__ dkv,
                                                                 float* __restrict__ dtable, int H, int W, int C, int g, int shift,
-                                                                float p_drop, unsigned long long seed) {
+                                                                float p_drop, unsigned long long seed, int part_mode) {
+  // part_mode 1: dtable is (gridDim.x, TBL * 2): the block stores its partial row (each wave = head owns its half of the LDS table)
   constexpr int WS = 8, D = 16, N = 64, CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1), TB4 = (TBL * 2 + 3) & ~3;
   __shared__ __attribute__((aligned(16))) float tbl[TB4];
   __shared__ __attribute__((aligned(16))) float dtb[TB4];
@@ -376,14 +386,17 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
     }
   }
   __syncthreads();
-  for (int i = tid; i < TBL * 2; i += 128) atomicAdd(dtable + i, dtb[(i & 1) * TBL + (i >> 1)]);     // table layout is [entry][head]
+  for (int i = tid; i < TBL * 2; i += 128) {     // table layout is [entry][head]
+    if (part_mode) dtable[(size_t)blockIdx.x * (TBL * 2) + i] = dtb[(i & 1) * TBL + (i >> 1)];
+    else atomicAdd(dtable + i, dtb[(i & 1) * TBL + (i >> 1)]);
+  }
 }
 
 template <int WS, int D, bool DROP>
 int launch_wattn_bwd(const float* q, const float* kv, const float* tbl, const float* dout, float* dq, float* dkv, float* dtable,
-                     int B, int H, int W, int C, int g, int shift, float p_drop, unsigned long long seed, hipStream_t st) {
+                     int B, int H, int W, int C, int g, int shift, float p_drop, unsigned long long seed, hipStream_t st, int part_mode = 0) {
   constexpr int CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
-  const size_t smem = (size_t)(2 * ((TBL * 2 + 3) & ~3) + 2 * (4 * 64 * LDR + 6 * 64)) * 4 + 2 * 64 * 4;
+  const size_t smem = (size_t)(3 * ((TBL * 2 + 3) & ~3) + 2 * (4 * 64 * LDR + 6 * 64)) * 4 + 2 * 64 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn_bwd<WS, D, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -391,7 +404,7 @@ int launch_wattn_bwd(const float* q, const float* kv, const float* tbl, const fl
   }
   const long slabs = (long)B * (H * W / 64);
   hipLaunchKernelGGL((k_window_attn_bwd<WS, D, DROP>), dim3((unsigned)((slabs + 1) / 2)), dim3(256), smem, st, q, kv, tbl, dout, dq, dkv,
-                     dtable, B, H, W, C, g, shift, p_drop, seed);
+                     dtable, B, H, W, C, g, shift, p_drop, seed, part_mode);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -776,11 +789,14 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
                                                           const float* __restrict__ pe_b, const float* __restrict__ ln_w,
                                                           const float* __restrict__ dtok, float* __restrict__ dconv,
                                                           float* __restrict__ patches, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int B, int Hi, int Wi) {
+                                                          float* __restrict__ dbeta, int B, int Hi, int Wi, float* __restrict__ lnpart) {
+  // lnpart != null: the block STORES its [dgamma (C) | dbeta (C)] partial as row blockIdx.x (added in block order by the caller);
+  // the 16 tokens of a wave are summed by shuffles, the four waves' sums in wave order -- no atomics, bitwise reproducible
   constexpr int CQ = C / 4, KP = 12;
   __shared__ float wt[KP * C];
   __shared__ float pfw[57];
   __shared__ float rg[C], rb[C];
+  __shared__ float wsum[4][2 * C];
   for (int i = threadIdx.x; i < KP * C; i += 256) wt[(i % KP) * C + i / KP] = pe_w[i];
   if (FUSE && threadIdx.x < 57) pfw[threadIdx.x] = threadIdx.x < 54 ? pf_w[threadIdx.x] : pf_b[threadIdx.x - 54];
   for (int i = threadIdx.x; i < C; i += 256) { rg[i] = 0.f; rb[i] = 0.f; }
@@ -852,8 +868,15 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
     dg[i] = d * ln_w[c];
     s1 += dg[i];
     s2 += dg[i] * xh[i];
-    atomicAdd(&rg[c], d * xh[i]);
-    atomicAdd(&rb[c], d);
+    if (lnpart) {
+      float a = d * xh[i], bsum = d;            // sum over the wave's 16 tokens (lanes with the same channel quarter)
+      a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+      bsum += __shfl_xor(bsum, 4, 64); bsum += __shfl_xor(bsum, 8, 64); bsum += __shfl_xor(bsum, 16, 64); bsum += __shfl_xor(bsum, 32, 64);
+      if (lane < 4) { wsum[threadIdx.x >> 6][c] = a; wsum[threadIdx.x >> 6][C + c] = bsum; }
+    } else {
+      atomicAdd(&rg[c], d * xh[i]);
+      atomicAdd(&rb[c], d);
+    }
   }
   s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
   s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
@@ -867,7 +890,12 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(dgamma + i, rg[i]); atomicAdd(dbeta + i, rb[i]); }
+  if (lnpart) {
+    for (int i = threadIdx.x; i < 2 * C; i += 256)
+      lnpart[(size_t)blockIdx.x * 2 * C + i] = ((wsum[0][i] + wsum[1][i]) + wsum[2][i]) + wsum[3][i];
+  } else {
+    for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(dgamma + i, rg[i]); atomicAdd(dbeta + i, rb[i]); }
+  }
 }
 // din (M,16): gradient wrt the 12 patch inputs of each token.  Without prior fusion: scatter (+=) into the NCHW image
 // gradient.  With prior fusion: accumulate the 3x3 conv weight / bias gradients (the text prior itself needs no gradient).
@@ -880,8 +908,10 @@ __global__ void k_patch_scatter(const float* __restrict__ din, float* __restrict
 }
 __global__ __launch_bounds__(256) void k_prior_fusion_wgrad(const float* __restrict__ din, const float* __restrict__ prior,
                                                              float* __restrict__ dpf_w, float* __restrict__ dpf_b, int B, int Hi,
-                                                             int Wi) {
+                                                             int Wi, float* __restrict__ part) {
+  // part != null: the block stores its [dw (54) | db (3)] partial as row blockIdx.x; the waves' sums are added in wave order
   __shared__ float acc[57];
+  __shared__ float wacc[4][57];
   if (threadIdx.x < 57) acc[threadIdx.x] = 0.f;
   __syncthreads();
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -909,10 +939,15 @@ __global__ __launch_bounds__(256) void k_prior_fusion_wgrad(const float* __restr
 #pragma unroll
   for (int i = 0; i < 57; ++i) {
     const float s = wave_sum(loc[i]);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&acc[i], s);
+    if ((threadIdx.x & 63) == 0) {
+      if (part) wacc[threadIdx.x >> 6][i] = s;
+      else atomicAdd(&acc[i], s);
+    }
   }
   __syncthreads();
-  if (threadIdx.x < 54) atomicAdd(dpf_w + threadIdx.x, acc[threadIdx.x]);
+  if (part) {
+    if (threadIdx.x < 57) part[(size_t)blockIdx.x * 57 + threadIdx.x] = ((wacc[0][threadIdx.x] + wacc[1][threadIdx.x]) + wacc[2][threadIdx.x]) + wacc[3][threadIdx.x];
+  } else if (threadIdx.x < 54) atomicAdd(dpf_w + threadIdx.x, acc[threadIdx.x]);
   else if (threadIdx.x < 57) atomicAdd(dpf_b + threadIdx.x - 54, acc[threadIdx.x]);
 }
 
@@ -927,10 +962,10 @@ int dpmn_window_attn_bwd_f32(const float* q, const float* kv, const float* const
                                        H, W, C, 0.f, 0ull, stream);
 }
 
-int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
-                                  const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
-                                  float* const* dtables, int B, int H, int W, int C, float p_drop, unsigned long long seed,
-                                  dpmn_stream_t stream) {
+static int window_attn_bwd_impl(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                                const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
+                                float* const* dtables, int B, int H, int W, int C, float p_drop, unsigned long long seed,
+                                dpmn_stream_t stream, int part_mode, int* rows_out) {
   DPMN_REQUIRE(q && kv && bias_tables && windows && shifts && dout && dq && dkv && dtables, "window_attn_bwd: null pointer");
   DPMN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "window_attn_bwd: attn_drop must be in [0, 1)");
   DPMN_REQUIRE(heads_per_group == 2 && C % n_groups == 0 && (H * W) % 64 == 0, "window_attn_bwd: unsupported geometry");
@@ -941,25 +976,52 @@ int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* 
     DPMN_REQUIRE(H % ws == 0 && W % ws == 0 && sh >= 0 && sh < ws, "window_attn_bwd: bad window / shift");
     int rc = DPMN_ERR_ARG;
     static const int wb_mfma = getenv("DPMN_WATTN_MFMA") ? atoi(getenv("DPMN_WATTN_MFMA")) : 1;
+    const long slabs = (long)B * (H * W / 64);
     if (ws == 8 && D == 16 && wb_mfma) {
+      if (rows_out) rows_out[g] = (int)slabs;
       if (p_drop > 0.f)
-        hipLaunchKernelGGL((k_window_attn8_bwd_mfma<true>), dim3((unsigned)(B * (H * W / 64))), dim3(128), 0, st, q, kv, bias_tables[g],
-                           dout, dq, dkv, dtables[g], H, W, C, g, sh, p_drop, seed);
+        hipLaunchKernelGGL((k_window_attn8_bwd_mfma<true>), dim3((unsigned)slabs), dim3(128), 0, st, q, kv, bias_tables[g],
+                           dout, dq, dkv, dtables[g], H, W, C, g, sh, p_drop, seed, part_mode);
       else
-        hipLaunchKernelGGL((k_window_attn8_bwd_mfma<false>), dim3((unsigned)(B * (H * W / 64))), dim3(128), 0, st, q, kv, bias_tables[g],
-                           dout, dq, dkv, dtables[g], H, W, C, g, sh, 0.f, 0ull);
+        hipLaunchKernelGGL((k_window_attn8_bwd_mfma<false>), dim3((unsigned)slabs), dim3(128), 0, st, q, kv, bias_tables[g],
+                           dout, dq, dkv, dtables[g], H, W, C, g, sh, 0.f, 0ull, part_mode);
       DPMN_CHECK_LAUNCH();
       continue;
     }
+    if (rows_out) rows_out[g] = (int)((slabs + 1) / 2);
 #define WB_CASE(WSV, DV) if (ws == WSV && D == DV) rc = p_drop > 0.f \
-      ? launch_wattn_bwd<WSV, DV, true>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, p_drop, seed, st) \
-      : launch_wattn_bwd<WSV, DV, false>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, 0.f, 0ull, st); else
+      ? launch_wattn_bwd<WSV, DV, true>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, p_drop, seed, st, part_mode) \
+      : launch_wattn_bwd<WSV, DV, false>(q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, 0.f, 0ull, st, part_mode); else
     WB_CASE(2, 16) WB_CASE(4, 16) WB_CASE(8, 16) WB_CASE(4, 32) WB_CASE(8, 32)
     return dpmn_set_error(DPMN_ERR_ARG, "window_attn_bwd: unsupported (window, head_dim)");
 #undef WB_CASE
     if (rc != DPMN_OK) return rc;
   }
   return DPMN_OK;
+}
+
+int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                                  const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
+                                  float* const* dtables, int B, int H, int W, int C, float p_drop, unsigned long long seed,
+                                  dpmn_stream_t stream) {
+  return window_attn_bwd_impl(q, kv, bias_tables, windows, shifts, n_groups, heads_per_group, dout, dq, dkv, dtables, B, H, W, C, p_drop, seed,
+                              stream, 0, nullptr);
+}
+
+// the same without atomics on the bias-table gradients: dtable_parts[g] is a (rows, (2 ws_g - 1)^2 * 2) buffer with
+// rows = dpmn_window_attn_bwd_part_rows(B, H, W, ws_g, D) >= rows_out[g]: every block stores its partial row, the caller adds the rows
+// in order (dpmn_rows_reduce_f32)
+int dpmn_window_attn_drop_bwd_det_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                                      const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
+                                      float* const* dtable_parts, int* rows_out, int B, int H, int W, int C, float p_drop,
+                                      unsigned long long seed, dpmn_stream_t stream) {
+  DPMN_REQUIRE(rows_out, "window_attn_bwd_det: null pointer");
+  return window_attn_bwd_impl(q, kv, bias_tables, windows, shifts, n_groups, heads_per_group, dout, dq, dkv, dtable_parts, B, H, W, C, p_drop,
+                              seed, stream, 1, rows_out);
+}
+
+int dpmn_window_attn_bwd_part_rows(int B, int H, int W) {
+  return B * (H * W / 64);          // the largest row count any (window, head_dim) kernel uses: one block per 64-token slab
 }
 
 int dpmn_sk_select_only_f32(const float* cat, const float* attn_vec, float* V, long M, int L, int C, int G, dpmn_stream_t stream) {
@@ -1146,14 +1208,14 @@ int dpmn_pgrm_tail_elem_bwd_f32(const float* dout, const float* c1, const float*
   return DPMN_OK;
 }
 
-int dpmn_patch_embed_bwd_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
-                             const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
-                             float* dgamma, float* dbeta, int B, int Hi, int Wi, int C, dpmn_stream_t stream) {
-  DPMN_REQUIRE(img && pe_w && pe_b && ln_w && dtok && dconv && patches && dgamma && dbeta, "patch_embed_bwd: null pointer");
+static int patch_embed_bwd_impl(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
+                                float* dgamma, float* dbeta, float* part, int B, int Hi, int Wi, int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(img && pe_w && pe_b && ln_w && dtok && dconv && patches && ((dgamma && dbeta) || part), "patch_embed_bwd: null pointer");
   const long tokens_n = (long)B * (Hi / 2) * (Wi / 2);
   dim3 grid((unsigned)((tokens_n + 63) / 64));
   hipStream_t st = as_stream(stream);
-#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi)
+#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi, part)
   if (C == 96 && pf_w) PB_LAUNCH(96, true);
   else if (C == 96) PB_LAUNCH(96, false);
   else if (C == 192 && pf_w) PB_LAUNCH(192, true);
@@ -1162,6 +1224,20 @@ int dpmn_patch_embed_bwd_f32(const float* img, int cin, const float* pf_w, const
 #undef PB_LAUNCH
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
+}
+
+int dpmn_patch_embed_bwd_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                             const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
+                             float* dgamma, float* dbeta, int B, int Hi, int Wi, int C, dpmn_stream_t stream) {
+  return patch_embed_bwd_impl(img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, nullptr, B, Hi, Wi, C, stream);
+}
+
+// the same without atomics: ln_part is (ceil(tokens / 64), 2 C) rows of [dgamma | dbeta] partial sums for dpmn_rows_reduce_f32
+int dpmn_patch_embed_bwd_det_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                 const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
+                                 float* ln_part, int B, int Hi, int Wi, int C, dpmn_stream_t stream) {
+  DPMN_REQUIRE(ln_part, "patch_embed_bwd_det: null pointer");
+  return patch_embed_bwd_impl(img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, nullptr, nullptr, ln_part, B, Hi, Wi, C, stream);
 }
 
 int dpmn_patch_scatter_f32(const float* din, float* dimg, int cimg, int B, int Hi, int Wi, dpmn_stream_t stream) {
@@ -1176,7 +1252,18 @@ int dpmn_prior_fusion_wgrad_f32(const float* din, const float* prior, float* dpf
                                 dpmn_stream_t stream) {
   DPMN_REQUIRE(din && prior && dpf_w && dpf_b, "prior_fusion_wgrad: bad arguments");
   const long total = (long)B * Hi * Wi;
-  hipLaunchKernelGGL(k_prior_fusion_wgrad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), din, prior, dpf_w, dpf_b, B, Hi, Wi);
+  hipLaunchKernelGGL(k_prior_fusion_wgrad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), din, prior, dpf_w, dpf_b, B, Hi, Wi,
+                     static_cast<float*>(nullptr));
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// the same without atomics: part is (ceil(B Hi Wi / 256), 57) rows of [dw (54) | db (3)] partial sums for dpmn_rows_reduce_f32
+int dpmn_prior_fusion_wgrad_det_f32(const float* din, const float* prior, float* part, int B, int Hi, int Wi, dpmn_stream_t stream) {
+  DPMN_REQUIRE(din && prior && part, "prior_fusion_wgrad_det: bad arguments");
+  const long total = (long)B * Hi * Wi;
+  hipLaunchKernelGGL(k_prior_fusion_wgrad, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), din, prior,
+                     static_cast<float*>(nullptr), static_cast<float*>(nullptr), B, Hi, Wi, part);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

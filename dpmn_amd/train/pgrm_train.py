@@ -126,6 +126,18 @@ def gemm_tn(dy, x, dw, db=None, leaf=True):
     check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), M, N, K, dptr(ws), ws.numel() * 4, stream()))
 
 
+def defer_rows(part, dw, db, NK, N, rows):
+    """dw (NK) += sum over `rows` rows of part[:, :NK], db (N) += ... part[:, NK:] in ROW ORDER (atomics-free finish of per-block /
+    per-image partial sums).  Inside a PGRM backward the sum joins the one multi-descriptor reduce launch at its end (tn_flush)."""
+    if _tn_pending is not None:
+        pend = _abi.TnPending()
+        pend.part, pend.dw, pend.db, pend.NK, pend.N, pend.splits = dptr(part), dptr(dw), dptr(db, True), NK, N, rows
+        _tn_pending[2].append(pend)
+        _tn_pending[3].append((part, dw, db))
+        return
+    check(lib.dpmn_rows_reduce_f32(dptr(part), dptr(dw), dptr(db, True), NK, N, rows, stream()))
+
+
 def colsum(dy, db):
     """db (N) += column sums of dy (M, N), without atomics (per-block partials summed in block order: bitwise reproducible)."""
     ws = ops.splitk_workspace(dy.device)
@@ -416,12 +428,25 @@ def backward(m, sv, dout, need_dx_kv=True):
         dat = ops.dropout(dx1, p_row=dpb, seed_row=sb[1], row_len=L * Cd, out=torch.empty_like(dx1)) if dpb > 0 else dx1
         dV = linear_bwd(dat, s["V"], sk.proj_head.weight, gr[sk.proj_head.weight], gr[sk.proj_head.bias])
         dcat = zeros(M, Cd)
-        dA = zeros(B, G, Cd // G)
-        check(lib.dpmn_sk_select_bwd_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(dV), dptr(dcat), dptr(dA), B, L, Cd, G, stream()))
         dS = torch.empty(B, Cd, device=dout.device)
-        check(lib.dpmn_sk_gate_bwd_f32(dptr(s["partial"]), parts, L, dptr(sk.fc1.weight), dptr(sk.fc1.bias), dptr(sk.fc2.weight),
-                                       dptr(s["avec"]), dptr(dA), dptr(dS), dptr(gr[sk.fc1.weight]), dptr(gr[sk.fc1.bias]),
-                                       dptr(gr[sk.fc2.weight]), dptr(gr[sk.fc2.bias]), B, Cd, G, sk.fc1.weight.shape[0], stream()))
+        dmid = sk.fc1.weight.shape[0]
+        if DET_SMALL:
+            # the gate's gradient dA as per-block partial rows added in block order by the gate backward (it feeds the DATA path:
+            # with atomics every gradient upstream of this block differed from run to run), the gate's weight gradients as
+            # per-image rows added in image order by the backward's one reduce launch
+            dA = torch.empty(parts, B, Cd, device=dout.device)
+            check(lib.dpmn_sk_select_bwd_det_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(dV), dptr(dcat), dptr(dA), B, L, Cd, G, stream()))
+            wp2, wp1 = torch.empty(B, Cd * dmid + Cd, device=dout.device), torch.empty(B, dmid * Cd + dmid, device=dout.device)
+            check(lib.dpmn_sk_gate_bwd_det_f32(dptr(s["partial"]), parts, L, dptr(sk.fc1.weight), dptr(sk.fc1.bias), dptr(sk.fc2.weight),
+                                               dptr(s["avec"]), dptr(dA), parts, dptr(dS), dptr(wp2), dptr(wp1), B, Cd, G, dmid, stream()))
+            defer_rows(wp2, gr[sk.fc2.weight], gr[sk.fc2.bias], Cd * dmid, Cd, B)
+            defer_rows(wp1, gr[sk.fc1.weight], gr[sk.fc1.bias], dmid * Cd, dmid, B)
+        else:
+            dA = zeros(B, G, Cd // G)
+            check(lib.dpmn_sk_select_bwd_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(dV), dptr(dcat), dptr(dA), B, L, Cd, G, stream()))
+            check(lib.dpmn_sk_gate_bwd_f32(dptr(s["partial"]), parts, L, dptr(sk.fc1.weight), dptr(sk.fc1.bias), dptr(sk.fc2.weight),
+                                           dptr(s["avec"]), dptr(dA), dptr(dS), dptr(gr[sk.fc1.weight]), dptr(gr[sk.fc1.bias]),
+                                           dptr(gr[sk.fc2.weight]), dptr(gr[sk.fc2.bias]), B, Cd, G, dmid, stream()))
         dfeats = torch.empty(M, Cd, device=dout.device)
         check(lib.dpmn_sk_feats_grad_f32(dptr(dat), dptr(s["feats"]), dptr(dS), dptr(dfeats), M, L, Cd, stream()))
         gemm_tn(dfeats, s["cat"], gr[sk.proj.weight], gr[sk.proj.bias])
@@ -430,9 +455,20 @@ def backward(m, sv, dout, need_dx_kv=True):
         dq = torch.empty(M, Cd, device=dout.device)
         dkv = torch.empty(M, 2 * Cd, device=dout.device)
         dtab = [gr[t] for t in s["tables"]]
-        check(lib.dpmn_window_attn_drop_bwd_f32(dptr(s["q"]), dptr(s["kv"]), _abi.ptr_array(s["tables"]), _abi.int_array(s["win"]),
-                                                _abi.int_array(s["shift"]), G, hpg, dptr(dcat), dptr(dq), dptr(dkv),
-                                                _abi.ptr_array(dtab), B, H, Wd, Cd, float(pa), int(sb[0]), stream()))
+        if DET_SMALL:
+            # bias-table gradients as per-block partial rows, added in block order by the backward's one reduce launch
+            nrows = lib.dpmn_window_attn_bwd_part_rows(B, H, Wd)
+            tparts = [torch.empty(nrows, t.numel(), device=dout.device) for t in s["tables"]]
+            rows = _abi.int_array([0] * G)
+            check(lib.dpmn_window_attn_drop_bwd_det_f32(dptr(s["q"]), dptr(s["kv"]), _abi.ptr_array(s["tables"]), _abi.int_array(s["win"]),
+                                                        _abi.int_array(s["shift"]), G, hpg, dptr(dcat), dptr(dq), dptr(dkv),
+                                                        _abi.ptr_array(tparts), rows, B, H, Wd, Cd, float(pa), int(sb[0]), stream()))
+            for g_ in range(G):
+                defer_rows(tparts[g_], dtab[g_], None, s["tables"][g_].numel(), 0, rows[g_])
+        else:
+            check(lib.dpmn_window_attn_drop_bwd_f32(dptr(s["q"]), dptr(s["kv"]), _abi.ptr_array(s["tables"]), _abi.int_array(s["win"]),
+                                                    _abi.int_array(s["shift"]), G, hpg, dptr(dcat), dptr(dq), dptr(dkv),
+                                                    _abi.ptr_array(dtab), B, H, Wd, Cd, float(pa), int(sb[0]), stream()))
         nq = s["nq"] if s["nq"] is not None else layernorm(sv["tq"], blk.norm1_q.weight, blk.norm1_q.bias)
         dnq = linear_bwd(dq, nq, a.q.weight, gr[a.q.weight], gr[a.q.bias])
         del nq
@@ -453,9 +489,22 @@ def backward(m, sv, dout, need_dx_kv=True):
         pfw, pfb = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
         dconv = torch.empty(M, Cd, device=dout.device)
         patches = torch.empty(M, 16, device=dout.device)
-        check(lib.dpmn_patch_embed_bwd_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
-                                           dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
-                                           dptr(gr[pe.norm.weight]), dptr(gr[pe.norm.bias]), B, img.shape[2], img.shape[3], Cd, stream()))
+        if DET_SMALL:      # LayerNorm parameter gradients as per-block partial rows, added in block order at the end of the backward
+            # (ONE buffer and one pending sum for both token streams: the patch embedding is shared, and two pending sums into the
+            #  same tensor would race in the multi-descriptor reduce launch)
+            nr = (M + 63) // 64
+            if which == "kv":
+                lnp = torch.empty(2 * nr, 2 * Cd, device=dout.device)
+            check(lib.dpmn_patch_embed_bwd_det_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
+                                                   dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
+                                                   lnp.data_ptr() + (0 if which == "kv" else nr * 2 * Cd * 4), B, img.shape[2], img.shape[3], Cd,
+                                                   stream()))
+            if which == "q":
+                defer_rows(lnp, gr[pe.norm.weight], gr[pe.norm.bias], Cd, Cd, 2 * nr)
+        else:
+            check(lib.dpmn_patch_embed_bwd_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
+                                               dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
+                                               dptr(gr[pe.norm.weight]), dptr(gr[pe.norm.bias]), B, img.shape[2], img.shape[3], Cd, stream()))
         dw16 = zeros(Cd, 16)
         gemm_tn(dconv, patches, dw16, gr[pe.proj.bias], leaf=False)      # dw16 is read right below
         gr[pe.proj.weight] += dw16[:, :12].reshape(pe.proj.weight.shape)
@@ -464,7 +513,11 @@ def backward(m, sv, dout, need_dx_kv=True):
             w16 = zeros(16, Cd)
             w16[:12] = pe.proj.weight.reshape(Cd, 12).t()
             din = ops.linear(dconv, w16)
-            if fuse:
+            if fuse and DET_SMALL:
+                pfp = torch.empty((B * img.shape[2] * img.shape[3] + 255) // 256, 57, device=dout.device)
+                check(lib.dpmn_prior_fusion_wgrad_det_f32(dptr(din), dptr(img), dptr(pfp), B, img.shape[2], img.shape[3], stream()))
+                defer_rows(pfp, gr[m.prior_fusion.weight], gr[m.prior_fusion.bias], 54, 3, pfp.shape[0])
+            elif fuse:
                 check(lib.dpmn_prior_fusion_wgrad_f32(dptr(din), dptr(img), dptr(gr[m.prior_fusion.weight]), dptr(gr[m.prior_fusion.bias]),
                                                       B, img.shape[2], img.shape[3], stream()))
             else:

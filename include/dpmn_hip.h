@@ -373,6 +373,14 @@ int dpmn_window_attn_drop_bwd_f32(const float* q, const float* kv, const float* 
                                   const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq,
                                   float* dkv, float* const* dtables, int B, int H, int W, int C, float p_drop,
                                   unsigned long long seed, dpmn_stream_t stream);
+/* the same with the bias-table gradients as per-block partial rows instead of atomics (bitwise reproducible): dtable_parts[g] is a
+ * (dpmn_window_attn_bwd_part_rows(B, H, W), (2 ws_g - 1)^2 * heads_per_group) buffer; rows_out[g] = the rows group g wrote, which
+ * the caller adds in order into the table gradient (dpmn_rows_reduce_f32) */
+int dpmn_window_attn_drop_bwd_det_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
+                                      const int* shifts, int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
+                                      float* const* dtable_parts, int* rows_out, int B, int H, int W, int C, float p_drop,
+                                      unsigned long long seed, dpmn_stream_t stream);
+int dpmn_window_attn_bwd_part_rows(int B, int H, int W);
 /* Row a15 -- the PSNs' spatial-transformer front end (reached only in PSN train mode: tatt.py / tbsrn.py `if self.stn and
  * self.training`).
  *   maxpool : nn.MaxPool2d(k, stride k) over NHWC (stn_head.py:36-46); scale/shift != NULL applies the producing
@@ -446,6 +454,13 @@ int dpmn_patch_embed_bwd_f32(const float* img, int cin, const float* pf_w, const
 int dpmn_patch_scatter_f32(const float* din, float* dimg, int cimg, int B, int Hi, int Wi, dpmn_stream_t stream);
 int dpmn_prior_fusion_wgrad_f32(const float* din, const float* prior, float* dpf_w, float* dpf_b, int B, int Hi, int Wi,
                                 dpmn_stream_t stream);
+/* atomics-free forms of the two calls above (bitwise reproducible): per-block partial rows for dpmn_rows_reduce_f32 --
+ * ln_part (ceil(tokens / 64), 2 C) = [dgamma | dbeta] of the patch-embed LayerNorm, part (ceil(B Hi Wi / 256), 57) = [dw (54) | db (3)]
+ * of prior_fusion */
+int dpmn_patch_embed_bwd_det_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                 const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
+                                 float* ln_part, int B, int Hi, int Wi, int C, dpmn_stream_t stream);
+int dpmn_prior_fusion_wgrad_det_f32(const float* din, const float* prior, float* part, int B, int Hi, int Wi, dpmn_stream_t stream);
 /* conv weight gradient in the packed (Cout, Kp) layout, train-mode BatchNorm plumbing, CMM gate backward (conv_bwd.hip) */
 int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp,
                           int nslots /* > 1: dwp holds nslots copies (Cout*Kp apart); pixel splits spread over them so that
