@@ -79,6 +79,16 @@ class TnPending(C.Structure):
     _fields_ = [("part", fp), ("dw", fp), ("db", fp), ("NK", C.c_int), ("N", C.c_int), ("splits", C.c_int)]
 
 
+class DistillParams(C.Structure):
+    _fields_ = [("conv_cat_w", fp), ("conv_cat_b", fp), ("bn1_w", fp), ("bn1_b", fp), ("bn1_rm", fp), ("bn1_rv", fp), ("bn1_nbt", fp),
+                ("conv_feat_w", fp), ("conv_feat_b", fp), ("bn2_w", fp), ("bn2_b", fp), ("bn2_rm", fp), ("bn2_rv", fp), ("bn2_nbt", fp)]
+
+
+class DistillGrads(C.Structure):
+    _fields_ = [("dconv_cat_w", fp), ("dconv_cat_b", fp), ("dbn1_w", fp), ("dbn1_b", fp), ("dconv_feat_w", fp), ("dconv_feat_b", fp),
+                ("dbn2_w", fp), ("dbn2_b", fp)]
+
+
 class CmmScratch(C.Structure):
     _fields_ = [("splitk_ws", fp), ("splitk_ws_bytes", C.c_size_t), ("arrive_cnt", fp), ("arrive_cnt_len", C.c_int)]
 
@@ -103,6 +113,9 @@ SIGNATURES = {
     "dpmn_sk_mlp_in_supported": (_i, [_i, _i, _i, _i, _i]),
     "dpmn_pointwise_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_conv2d_nhwc_f32": (_i, [C.POINTER(ConvDesc), fp]),
+    "dpmn_distill_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dpmn_distill_forward_f32": (_i, [C.POINTER(DistillParams), fp, fp, _i, fp, fp, fp, fp, fp, _sz, _i, _i, _i, fp]),
+    "dpmn_distill_backward_f32": (_i, [C.POINTER(DistillParams), C.POINTER(DistillGrads), fp, fp, fp, fp, fp, fp, fp, fp, fp, _sz, _i, _i, _i, fp]),
     "dpmn_xred_fallbacks": (_i, [C.POINTER(C.c_uint), _i]),
     "dpmn_xred_test_force_recompute": (_i, [_i]),
     "dpmn_xred_enable": (_i, [_i]),

@@ -1,135 +1,94 @@
-"""Host-side mirror of ``model/distill_module.py::DistillModule`` (distill_module.py:4-31): two 3x3 convs + BatchNorm +
-ReLU and an L1 between them; returns (loss, feature_cat).  Same state_dict keys.  All arithmetic runs in
-libdpmn_hip.so through the NHWC implicit-GEMM conv (channels zero-padded 3 -> 4 / 6 -> 8 so rows stay 16-byte aligned)
-with train-mode BatchNorm statistics from the conv epilogue; backward is explicit (dpmn_amd/train/cmm_train.Unit)."""
+"""Host-side mirror of ``model/distill_module.py::DistillModule`` (distill_module.py:4-31): conv_cat_feature (6 -> 3, 3x3) and
+conv_feature (3 -> 3, 3x3) + BatchNorm2d(3) + ReLU and the L1 between the two feature maps; returns (loss, feature_cat).
+Same constructor, forward signature and state_dict keys.  The torch layers are parameter holders that are never called: forward
+and backward are the native module csrc/distill.hip (dpmn_distill_forward_f32 / dpmn_distill_backward_f32: 4 + 5 launches on the
+NCHW images, every reduction a per-block partial row added in block order -- bitwise reproducible), bridged into autograd by one
+torch.autograd.Function.  Gradients go straight into the trainer's flat gradient arena (direct mode, train/optim.py)."""
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import _abi
 from .._abi import lib, check, dptr, stream
-from ..train import cmm_train as ct
+
+_WS = {}
 
 
-class _PadConv(nn.Module):
-    """view of a Conv2d with channels zero-padded for the kernels; maps gradients back."""
-
-    def __init__(self, conv, in_map, cin_p):
-        super().__init__()
-        self.conv, self.in_map, self.cin_p = conv, in_map, cin_p
-
-    def padded(self):
-        w, b = self.conv.weight, self.conv.bias
-        wp = w.new_zeros(4, self.cin_p, 3, 3)
-        # in_map is made of runs of consecutive channels: slice copies only (a list index would be an H2D index tensor,
-        # which cannot be captured into a hipGraph)
-        src = 0
-        while src < len(self.in_map):
-            run = 1
-            while src + run < len(self.in_map) and self.in_map[src + run] == self.in_map[src] + run:
-                run += 1
-            wp[:w.shape[0], self.in_map[src]:self.in_map[src] + run] = w[:, src:src + run]
-            src += run
-        bp = b.new_zeros(4)
-        bp[:b.shape[0]] = b
-        return wp, bp
+def _workspace(dev, B, H, W):
+    """one scratch per (device, stream, shape): statistics / loss rows, the raw-output gradient, the weight-gradient rows"""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B, H, W)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = _WS[key] = torch.empty(lib.dpmn_distill_workspace_bytes(B, H, W) // 4 + 64, device=dev)
+    return ws
 
 
-class _PadBN:
-    def __init__(self, bn):
-        self.bn = bn
-        self.eps, self.momentum = bn.eps, bn.momentum
-        z = bn.weight.new_zeros(1)
-        self.weight = torch.cat([bn.weight.detach(), z])
-        self.bias = torch.cat([bn.bias.detach(), z])
-        self.running_mean = torch.cat([bn.running_mean, z])
-        self.running_var = torch.cat([bn.running_var, z + 1])
-        self.num_batches_tracked = bn.num_batches_tracked
-
-    def writeback(self):
-        self.bn.running_mean.copy_(self.running_mean[:3])
-        self.bn.running_var.copy_(self.running_var[:3])
+def _params(m):
+    p = _abi.DistillParams()
+    p.conv_cat_w, p.conv_cat_b = dptr(m.conv_cat_feature.weight), dptr(m.conv_cat_feature.bias)
+    p.bn1_w, p.bn1_b, p.bn1_rm, p.bn1_rv = dptr(m.bn_1.weight), dptr(m.bn_1.bias), dptr(m.bn_1.running_mean), dptr(m.bn_1.running_var)
+    p.bn1_nbt = m.bn_1.num_batches_tracked.data_ptr()
+    p.conv_feat_w, p.conv_feat_b = dptr(m.conv_feature.weight), dptr(m.conv_feature.bias)
+    p.bn2_w, p.bn2_b, p.bn2_rm, p.bn2_rv = dptr(m.bn_2.weight), dptr(m.bn_2.bias), dptr(m.bn_2.running_mean), dptr(m.bn_2.running_var)
+    p.bn2_nbt = m.bn_2.num_batches_tracked.data_ptr()
+    return p
 
 
-class _Shim:
-    """Conv2d-like holder of padded tensors for cmm_train.Unit."""
-
-    def __init__(self, w, b):
-        self.weight, self.bias = w, b
+def _forward(m, x_deep, x_shallow, training):
+    xd, xs = x_deep.contiguous().float(), x_shallow.contiguous().float()
+    if not xd.is_cuda:
+        raise _abi.DpmnError("dpmn_amd DistillModule: tensors must live on the GPU (there is no CPU path)")
+    B, c, H, W = xd.shape
+    assert c == 3 and xs.shape == xd.shape, "DistillModule: (B, 3, H, W) images"
+    for t in (m.conv_cat_feature.weight, m.conv_feature.weight):
+        assert t.is_contiguous()
+    r = torch.empty(B, 6, H, W, device=xd.device)
+    state = torch.empty(24, device=xd.device)
+    feat = torch.empty_like(xd)
+    loss = torch.empty(1, device=xd.device)
+    ws = _workspace(xd.device, B, H, W)
+    check(lib.dpmn_distill_forward_f32(C.byref(_params(m)), dptr(xd), dptr(xs), int(training), dptr(r), dptr(state), dptr(feat), dptr(loss),
+                                       dptr(ws), ws.numel() * 4, B, H, W, stream()))
+    return loss, feat, (xd, xs, r, state)
 
 
 class _DistillFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, x_deep, x_shallow, *params):
-        training = m.training
-        d4 = ct.T(ops.nchw_to_nhwc(x_deep.contiguous().float(), 4))
-        s4 = ct.T(ops.nchw_to_nhwc(x_shallow.contiguous().float(), 4))
-        wc, bc = _PadConv(m.conv_cat_feature, [0, 1, 2, 4, 5, 6], 8).padded()
-        wf, bf = _PadConv(m.conv_feature, [0, 1, 2], 4).padded()
-        bn1, bn2 = _PadBN(m.bn_1), _PadBN(m.bn_2)
-        u1 = ct.Unit("conv3", _Shim(wc, bc), bn1 if training else None, [d4, s4], "none")
-        u2 = ct.Unit("conv3", _Shim(wf, bf), bn2 if training else None, [s4], "none")
-        t1, t2 = u1.forward(), u2.forward()
-        if training:
-            bn1.writeback(); bn2.writeback()
-        else:   # eval: running statistics as a fixed affine
-            for t, bn in ((t1, bn1), (t2, bn2)):
-                rstd = 1.0 / torch.sqrt(bn.running_var + bn.eps)
-                t.scale = (bn.weight * rstd).contiguous()
-                t.shift = (bn.bias - bn.running_mean * bn.weight * rstd).contiguous()
-        B, H, W, _ = t1.r.shape
-        pixels = B * H * W
-        f1, f2 = torch.empty_like(t1.r), torch.empty_like(t2.r)
-        RELU = ops.ACT["relu"]
-        check(lib.dpmn_affine_act_fwd_f32(dptr(t1.r), dptr(t1.scale), dptr(t1.shift), RELU, dptr(f1), pixels, 4, stream()))
-        check(lib.dpmn_affine_act_fwd_f32(dptr(t2.r), dptr(t2.scale), dptr(t2.shift), RELU, dptr(f2), pixels, 4, stream()))
-        loss = torch.empty(1, device=f1.device)
-        part = torch.empty((pixels * 4 + 255) // 256, device=f1.device)
-        check(lib.dpmn_l1_loss_fwd_f32(dptr(f1), dptr(f2), 1.0 / (pixels * 3), dptr(loss), dptr(part), pixels * 4, stream()))
-        feat = ops.nhwc_to_nchw(f1)[:, :3].contiguous()
-        ctx.m, ctx.st = m, (u1, u2, t1, t2, f1, f2, d4, s4, bn1, bn2, training)
+        loss, feat, saved = _forward(m, x_deep, x_shallow, m.training)
+        ctx.m, ctx.saved, ctx.training = m, saved, m.training
         ctx.need = (x_deep.requires_grad, x_shallow.requires_grad)
         return loss[0], feat
 
     @staticmethod
     def backward(ctx, dloss, dfeat):
+        from ..train.pgrm_train import grad_targets, finish_grads
         m = ctx.m
-        u1, u2, t1, t2, f1, f2, d4, s4, bn1, bn2, training = ctx.st
-        if not training:
+        if not ctx.training:
             raise NotImplementedError("DistillModule: gradients through eval-mode BatchNorm are not built; use .train()")
-        B, H, W, _ = t1.r.shape
-        pixels = B * H * W
-        extra = None
-        if dfeat is not None:
-            extra = ops.nchw_to_nhwc(dfeat.contiguous().float(), 4)
-        df1, df2 = torch.empty_like(f1), torch.empty_like(f2)
-        gs = dloss.reshape(1).float().contiguous()
-        check(lib.dpmn_l1_loss_bwd_f32(dptr(f1), dptr(f2), dptr(gs), 1.0 / (pixels * 3), dptr(extra, True), dptr(df1), dptr(df2), pixels * 4, stream()))
-        RELU = ops.ACT["relu"]
-        for t, df in ((t1, df1), (t2, df2)):
-            t.G = torch.empty_like(df)
-            check(lib.dpmn_affine_act_bwd_f32(dptr(df), dptr(t.r), dptr(t.scale), dptr(t.shift), RELU, dptr(t.G), 0, pixels, 4, stream()))
-        if not ctx.need[0]:
-            d4.G = False
-        gr = {}
-        for u, bn in ((u1, bn1), (u2, bn2)):
-            for tns in (u.conv.weight, u.conv.bias, bn.weight, bn.bias):
-                gr[tns] = torch.zeros_like(tns)
-        u1.backward(gr)
-        u2.backward(gr)
-        gw = gr[u1.conv.weight]
-        g_wc = torch.cat([gw[:3, 0:3], gw[:3, 4:7]], dim=1).contiguous()   # slices, not a list index (hipGraph-capturable)
-        g_wf = gr[u2.conv.weight][:3, :3].contiguous()
-        dx_deep = ops.nhwc_to_nchw(d4.G)[:, :3].contiguous() if ctx.need[0] else None
-        dx_sh = ops.nhwc_to_nchw(s4.G)[:, :3].contiguous() if ctx.need[1] else None
-        by_param = {m.conv_cat_feature.weight: g_wc, m.conv_cat_feature.bias: gr[u1.conv.bias][:3].contiguous(),
-                    m.bn_1.weight: gr[bn1.weight][:3].contiguous(), m.bn_1.bias: gr[bn1.bias][:3].contiguous(),
-                    m.conv_feature.weight: g_wf, m.conv_feature.bias: gr[u2.conv.bias][:3].contiguous(),
-                    m.bn_2.weight: gr[bn2.weight][:3].contiguous(), m.bn_2.bias: gr[bn2.bias][:3].contiguous()}
-        ctx.st = None
-        return (None, dx_deep, dx_sh) + tuple(by_param[p] for p in m.parameters())
+        xd, xs, r, state = ctx.saved
+        B, _, H, W = xd.shape
+        gr, direct = grad_targets(m)
+        g = _abi.DistillGrads()
+        g.dconv_cat_w, g.dconv_cat_b = dptr(gr[m.conv_cat_feature.weight]), dptr(gr[m.conv_cat_feature.bias])
+        g.dbn1_w, g.dbn1_b = dptr(gr[m.bn_1.weight]), dptr(gr[m.bn_1.bias])
+        g.dconv_feat_w, g.dconv_feat_b = dptr(gr[m.conv_feature.weight]), dptr(gr[m.conv_feature.bias])
+        g.dbn2_w, g.dbn2_b = dptr(gr[m.bn_2.weight]), dptr(gr[m.bn_2.bias])
+        gl = dloss.reshape(1).float().contiguous()
+        df = None if dfeat is None else dfeat.contiguous().float()
+        dxd = torch.empty_like(xd) if ctx.need[0] else None
+        dxs = torch.empty_like(xs) if ctx.need[1] else None
+        ws = _workspace(xd.device, B, H, W)
+        check(lib.dpmn_distill_backward_f32(C.byref(_params(m)), C.byref(g), dptr(xd), dptr(xs), dptr(r), dptr(state), dptr(df, True), dptr(gl),
+                                            dptr(dxd, True), dptr(dxs, True), dptr(ws), ws.numel() * 4, B, H, W, stream()))
+        ctx.saved = None
+        return (None, dxd, dxs) + finish_grads(m, gr, direct)
 
 
 class DistillModule(nn.Module):
+    direct_grad = True   # see train/optim.py (direct mode)
+
     def __init__(self):
         super().__init__()
         self.conv_cat_feature = nn.Conv2d(6, 3, 3, 1, 1)
@@ -138,4 +97,9 @@ class DistillModule(nn.Module):
         self.bn_2 = nn.BatchNorm2d(3)
 
     def forward(self, x_deep, x_shallow):
-        return _DistillFn.apply(self, x_deep, x_shallow, *list(self.parameters()))
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or x_deep.requires_grad or x_shallow.requires_grad):
+            if getattr(self, "_dpmn_bucket", None) is not None:
+                self._dpmn_bucket.note_use()
+            return _DistillFn.apply(self, x_deep, x_shallow, *list(self.parameters()))
+        loss, feat, _ = _forward(self, x_deep, x_shallow, self.training)
+        return loss[0], feat

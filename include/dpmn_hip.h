@@ -184,6 +184,36 @@ int dpmn_xred_test_force_recompute(int on);
 int dpmn_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int Cpad, dpmn_stream_t stream);
 int dpmn_nhwc_to_nchw_f32(const float* in, float* out, int B, int C, int H, int W, dpmn_stream_t stream);
 
+/* ---- DistillModule (distill_module.py:4-31) as a native module: conv_cat_feature (6 -> 3, 3x3) and conv_feature (3 -> 3, 3x3) on NCHW
+ * (B, 3, H, W) images, train-mode BatchNorm2d(3) (batch statistics, running statistics updated: momentum 0.1, eps 1e-5) or the
+ * running statistics in eval mode, ReLU, and loss = mean |feature_cat - feature_shallow|; returns the loss (device scalar) and
+ * feature_cat.  Forward = 4 launches, backward = 5, every reduction a per-block partial row added in block order (statistics and
+ * loss in fp64): bitwise reproducible.  Pointers are the reference module's own parameter tensors (state_dict layout). */
+typedef struct {
+  const float *conv_cat_w, *conv_cat_b;   /* conv_cat_feature.weight (3,6,3,3), .bias (3) */
+  const float *bn1_w, *bn1_b;             /* bn_1.weight / .bias (3) */
+  float *bn1_rm, *bn1_rv;                 /* bn_1.running_mean / running_var (3), updated in training mode */
+  long long* bn1_nbt;                     /* bn_1.num_batches_tracked or NULL */
+  const float *conv_feat_w, *conv_feat_b; /* conv_feature.weight (3,3,3,3), .bias (3) */
+  const float *bn2_w, *bn2_b;
+  float *bn2_rm, *bn2_rv;
+  long long* bn2_nbt;
+} dpmn_distill_params;
+typedef struct {                          /* gradients are ACCUMULATED (+=) into these */
+  float *dconv_cat_w, *dconv_cat_b, *dbn1_w, *dbn1_b, *dconv_feat_w, *dconv_feat_b, *dbn2_w, *dbn2_b;
+} dpmn_distill_grads;
+size_t dpmn_distill_workspace_bytes(int B, int H, int W);
+/* r (B,6,H,W): the raw conv outputs [conv_cat | conv_feature], state (24): [scale | shift | mean | rstd] x 6 channels -- both kept
+ * by the caller for the backward; feat (B,3,H,W) = feature_cat; loss: one float on the device */
+int dpmn_distill_forward_f32(const dpmn_distill_params* p, const float* x_deep, const float* x_shallow, int training, float* r,
+                             float* state, float* feat, float* loss, void* workspace, size_t workspace_bytes, int B, int H, int W,
+                             dpmn_stream_t stream);
+/* gloss: d(objective) / d(loss), one float on the device; dfeat (B,3,H,W) = gradient wrt feature_cat or NULL; dx_deep / dx_shallow
+ * (B,3,H,W) are WRITTEN (NULL: not needed) */
+int dpmn_distill_backward_f32(const dpmn_distill_params* p, const dpmn_distill_grads* g, const float* x_deep, const float* x_shallow,
+                              const float* r, const float* state, const float* dfeat, const float* gloss, float* dx_deep,
+                              float* dx_shallow, void* workspace, size_t workspace_bytes, int B, int H, int W, dpmn_stream_t stream);
+
 /* CMM channel gate (cmm.py:135-147) on the NHWC bottleneck x (B,P,C): out = x * sigmoid(fc2(relu(fc1(mean_p x)))) + x.
  * hidden_ws: B*Cmid floats of scratch. */
 int dpmn_se_gate_f32(const float* x, const float* fc1_w, const float* fc1_b, const float* fc2_w, const float* fc2_b,

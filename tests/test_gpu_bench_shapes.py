@@ -119,10 +119,11 @@ def test_cmm_cnum64_train_fwd_bwd_at_b8_vs_oracle_autograd(dev):
 CFG4_STAGE_TOL = [4e-5, 4e-5, 8e-5, 1.1e-4, 2.3e-4, 4.5e-4]
 
 # tolerances of the step test = 3x the errors recorded in profiles/r03l_parity_errors.json (per model kind and batch), floor 1e-5
-# (loss: floor 5e-7).  Recorded: B = 4 -- loss 1.1e-7, text-prior PGRMs 4.8e-5, mask-prior PGRMs 3.2e-4, CMM 4.3e-4, DistillModules
-# 8e-7; B = 48 -- loss 6e-7, 1.2e-4, 5.8e-4, 1.2e-3, 9e-5
-CFG2_TOL = {4: dict(loss=5e-7, pgrm=1.5e-4, pgrm_b2=1e-3, cmm=1.3e-3, distill=1e-5),
-            48: dict(loss=2e-6, pgrm=3.6e-4, pgrm_b2=1.8e-3, cmm=3.6e-3, distill=2.7e-4)}
+# (loss: floor 5e-7).  Recorded: B = 4 -- loss 1.1e-7, text-prior PGRMs 6.1e-5, mask-prior PGRMs 6.4e-4, CMM 4.5e-4, DistillModules
+# 1.3e-6 ... 6.4e-4 (the second module of a chain sees the first one's BatchNorm output over 4 images); B = 48 -- loss 7e-7,
+# 1.8e-4, 7.6e-4, 1.1e-3, 9e-5
+CFG2_TOL = {4: dict(loss=5e-7, pgrm=1.8e-4, pgrm_b2=1.9e-3, cmm=1.4e-3, distill=1.9e-3),
+            48: dict(loss=2.2e-6, pgrm=5.4e-4, pgrm_b2=2.3e-3, cmm=3.6e-3, distill=2.7e-4)}
 
 
 # the same step with bf16 MFMA operands (BASELINE.json configs[2] names bf16; dpmn_set_compute_dtype(1): convs and the pointwise GEMM
@@ -189,6 +190,7 @@ def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev, B, bf16):
     le = abs(float(loss) - float(tot)) / abs(float(tot))
     record(name, "loss rel err", le, tols["loss"])
     assert le < tols["loss"], (float(loss), float(tot))
+    fails = []
     for i, m in enumerate(models + distill):
         rsd = ref[1 + i]
         num = den = 0.0
@@ -199,7 +201,9 @@ def test_cfg2_training_step_tatt_3p3_vs_oracle_autograd(dev, B, bf16):
         e = (num / max(den, 1e-30)) ** 0.5
         tol = tols["pgrm"] if i < b1 else tols["pgrm_b2"] if i < b1 + b2 else tols["cmm"] if i == b1 + b2 else tols["distill"]
         record(name, "model %d whole-gradient rel L2" % i, e, tol)
-        assert e < tol, "model %d gradient differs from oracle autograd: %.3e (tol %.1e)" % (i, e, tol)
+        if e >= tol:
+            fails.append((i, e, tol))
+    assert not fails, "model gradients differ from oracle autograd (model, rel L2, tol): %r" % (fails,)
 
 
 def test_cfg3_as_named_inloop_visionlan_prior_b64_vs_oracle(dev):
