@@ -74,8 +74,17 @@ def main(config, args):
         dirs = config.TRAIN.train_data_dir or []
         if dirs and all(os.path.isdir(d) for d in dirs):                   # TextZoom LMDBs from the config, like base.py:85-103
             from dpmn_amd.dataset.textzoom import sr_batches
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            if bs % world != 0 or bs // world < 2:
+                raise SystemExit("main.py: batch_size %d does not shard over %d ranks in per-rank batches of >= 2 images (the global batch "
+                                 "stays batch_size: nn.DataParallel's scatter, base.py:160-162)" % (bs, world))
             dl = mission.get_train_data()[1]           # per-rank shard of a per-epoch permutation (DistributedSampler)
-            mission.train(lambda epoch: sr_batches(dl, mission.device, mission.mask), epochs=config.TRAIN.epochs, sampler=getattr(mission, "train_sampler", None))
+            val_dirs = (config.TRAIN.VAL or {}).get("val_data_dir") or []
+            val_dls = mission.get_val_data()[1] if val_dirs and all(os.path.isdir(d) for d in val_dirs) else []
+            # eval every VAL.valInterval over every validation subset + best-model checkpoints (super_resolution.py:283-337)
+            val_loader = (lambda: (b for vdl in val_dls for b in sr_batches(vdl, mission.device, mission.mask))) if val_dls else None
+            mission.train(lambda epoch: sr_batches(dl, mission.device, mission.mask), epochs=config.TRAIN.epochs,
+                          sampler=getattr(mission, "train_sampler", None), val_loader=val_loader)
         else:
             mission.train(synthetic_loader(bs, args.synthetic_steps, 2000 + rank), steps=args.synthetic_steps)
 
