@@ -7,6 +7,7 @@
 //   * k_image_loss_*   ImageLoss = MSE + L1 of gradient-magnitude maps (loss/image_loss.py:15-43), forward + backward
 // Data-gradients of linears / convs reuse the forward GEMM / implicit-GEMM kernels with transposed weights.
 #include <cstdlib>
+#include <vector>
 #include "common.h"
 
 namespace {
@@ -280,6 +281,22 @@ __global__ __launch_bounds__(256) void k_tn_reduce_multi(TnMulti m) {
     const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
     if (e < NK) d.dw[e] += v; else d.db[e - NK] += v;
   }
+}
+
+// ---- deferred ordered reductions.  Every "partial rows added in order" finish (k_tn_reduce) of a backward pass can be postponed and
+// run as ONE multi-descriptor launch at its end (dpmn_reduce_defer_*): the branch streams' backward is a chain of short kernels and
+// every tiny serial launch in it costs wall time.  The caller guarantees that the partial rows stay untouched until the flush (it
+// hands out workspace slices from an arena it does not reuse before).  Per host thread: autograd runs a backward node on one thread.
+struct DeferCtx {
+  bool on = false;
+  std::vector<dpmn_tn_pending> v;
+};
+thread_local DeferCtx g_defer;
+// true: the reduction was queued (the caller must not launch it)
+static bool reduce_deferred(const float* part, float* dw, float* db, int NK, int N, int rows) {
+  if (!g_defer.on) return false;
+  g_defer.v.push_back(dpmn_tn_pending{const_cast<float*>(part), dw, db, NK, N, rows});
+  return true;
 }
 
 // db[n] += sum_m dy[m][n].  Block = 256 threads over a (rows_per_block x N) slab: thread -> (row lane = tid / cols4,
@@ -666,7 +683,7 @@ static int gemm_tn_impl(const float* dy, const float* x, float* dw, float* db, i
     *defer = dpmn_tn_pending{part, dw, db, N * K, N, splits};
     return DPMN_OK;
   }
-  if (part) {
+  if (part && !reduce_deferred(part, dw, db, N * K, N, splits)) {
     const int tot = N * K + (db ? N : 0);
     hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(tot, 64)), dim3(256), 0, as_stream(stream), part, dw, db, N * K, N, splits);
     DPMN_CHECK_LAUNCH();
@@ -694,26 +711,63 @@ int dpmn_gemm_tn_partial_f32(const float* dy, const float* x, float* dw, float* 
 
 int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending, int n, dpmn_stream_t stream) {
   DPMN_REQUIRE(pending && n >= 0, "tn_reduce_multi: bad arguments");
-  for (int i0 = 0; i0 < n; i0 += 16) {
+  int i0 = 0;
+  while (i0 < n) {
+    // one launch = up to 16 descriptors with pairwise DIFFERENT destinations (two sums into one tensor inside a launch would race:
+    // the second one goes to the next launch, i.e. behind the first in stream order)
     TnMulti m{};
-    m.n = n - i0 < 16 ? n - i0 : 16;
-    int nb = 0;
-    for (int i = 0; i < m.n; ++i) {
-      m.d[i] = pending[i0 + i];
-      m.first_block[i] = nb;
-      nb += cdiv(m.d[i].NK + (m.d[i].db ? m.d[i].N : 0), 64);
+    int nb = 0, cnt = 0;
+    for (; i0 + cnt < n && cnt < 16; ++cnt) {
+      const dpmn_tn_pending& d = pending[i0 + cnt];
+      bool clash = false;
+      for (int j = 0; j < cnt && !clash; ++j)
+        clash = m.d[j].dw == d.dw || (d.db && (m.d[j].db == d.db || m.d[j].dw == d.db)) || (m.d[j].db && m.d[j].db == d.dw);
+      if (clash) break;
+      m.d[cnt] = d;
+      m.first_block[cnt] = nb;
+      nb += cdiv(d.NK + (d.db ? d.N : 0), 64);
     }
-    m.first_block[m.n] = nb;
+    m.n = cnt;
+    m.first_block[cnt] = nb;
     hipLaunchKernelGGL(k_tn_reduce_multi, dim3(nb), dim3(256), 0, as_stream(stream), m);
     DPMN_CHECK_LAUNCH();
+    i0 += cnt;
   }
   return DPMN_OK;
+}
+
+int dpmn_reduce_defer_begin(void) {
+  g_defer.on = true;
+  g_defer.v.clear();
+  return DPMN_OK;
+}
+
+int dpmn_reduce_defer_enable(int on) {       // pause / resume queueing without touching the queue (a reduction whose result is read at once)
+  g_defer.on = on != 0;
+  return DPMN_OK;
+}
+
+int dpmn_reduce_defer_push(const dpmn_tn_pending* p) {
+  DPMN_REQUIRE(p && p->part && p->dw && p->NK > 0 && p->splits > 0, "reduce_defer_push: bad descriptor");
+  g_defer.v.push_back(*p);
+  return DPMN_OK;
+}
+
+int dpmn_reduce_defer_pending(void) { return (int)g_defer.v.size(); }
+
+int dpmn_reduce_defer_flush(int end, dpmn_stream_t stream) {
+  int rc = DPMN_OK;
+  if (!g_defer.v.empty()) rc = dpmn_tn_reduce_multi_f32(g_defer.v.data(), (int)g_defer.v.size(), stream);
+  g_defer.v.clear();
+  if (end) g_defer.on = false;
+  return rc;
 }
 
 // dw[e] += sum_z part[z][e] (e < NK), db[n] += sum_z part[z][NK + n]: rows of NK + N floats added in row order (k_tn_reduce) -- the
 // finish step of every "per-block / per-image partials instead of atomics" gradient in backward_pgrm.hip
 int dpmn_rows_reduce_f32(const float* part, float* dw, float* db, int NK, int N, int rows, dpmn_stream_t stream) {
   DPMN_REQUIRE(part && dw && NK > 0 && N >= 0 && rows > 0 && (db || N == 0), "rows_reduce: bad arguments");
+  if (reduce_deferred(part, dw, db, NK, N, rows)) return DPMN_OK;
   hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(NK + N, 64)), dim3(256), 0, as_stream(stream), part, dw, db, NK, N, rows);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -737,6 +791,7 @@ int dpmn_colsum_det_f32(const float* dy, float* db, long M, int N, float* ws, si
   hipLaunchKernelGGL(k_colsum, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), dy, N, db, M, N, rows, ws);
   DPMN_CHECK_LAUNCH();
   // (the block-order sum of the partial rows is k_tn_reduce's job: 64 columns x 4 split groups per block, fixed order)
+  if (reduce_deferred(ws, db, nullptr, N, 0, (int)nb)) return DPMN_OK;
   hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(N, 64)), dim3(256), 0, as_stream(stream), ws, db, static_cast<float*>(nullptr), N, 0, (int)nb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -770,6 +825,7 @@ static int layernorm_bwd_impl(const float* x, const float* dy, const float* gamm
   DPMN_CHECK_LAUNCH();
   if (part) {      // the blocks' [dgamma | dbeta] rows, added in block order (no atomics: bitwise reproducible)
     // one launch: k_tn_reduce's [N * K | N] row layout with N * K = C (-> dgamma) and N = C (-> dbeta)
+    if (reduce_deferred(part, dgamma, dbeta, C, C, (int)nblk)) return DPMN_OK;
     hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(2 * C, 64)), dim3(256), 0, as_stream(stream), part, dgamma, dbeta, C, C, (int)nblk);
     DPMN_CHECK_LAUNCH();
   }

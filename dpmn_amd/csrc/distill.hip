@@ -46,6 +46,26 @@ __device__ __forceinline__ void block_rows(const T (&val)[NV], T* __restrict__ r
   for (int v = threadIdx.x; v < NV; v += TPB) row[v] = ((sm[0][v] + sm[1][v]) + sm[2][v]) + sm[3][v];
 }
 
+
+// sum of `nrows` rows of NV values in a FIXED order with 16 lanes per value: lane l adds the rows l, l + 16, ... (two independent
+// chains), the 16 lane sums are then added in lane order by the value's first lane.  One block of NV * 16 threads (<= 1024).
+template <int NV, typename T>
+__device__ __forceinline__ T rows_sum16(const T* __restrict__ rows, int nrows, T (*sm)[16]) {
+  const int v = threadIdx.x >> 4, l = threadIdx.x & 15;
+  T s0 = 0, s1 = 0;
+  if (v < NV) {
+    int z = l;
+    for (; z + 16 < nrows; z += 32) { s0 += rows[(size_t)z * NV + v]; s1 += rows[(size_t)(z + 16) * NV + v]; }
+    if (z < nrows) s0 += rows[(size_t)z * NV + v];
+    sm[v][l] = s0 + s1;
+  }
+  __syncthreads();
+  T tot = 0;
+  if (v < NV && l == 0)
+    for (int i = 0; i < 16; ++i) tot += sm[v][i];
+  return tot;      // valid in lane 0 of each value's 16-lane group
+}
+
 // ---- forward 1: both convs (raw outputs r: (B, 6, H, W) = [conv_cat (3) | conv_feature (3)]) + per-block (sum, sum of squares)
 __global__ __launch_bounds__(TPB) void k_distill_conv_fwd(const float* __restrict__ xd, const float* __restrict__ xs, DistillWPtr wp,
                                                           float* __restrict__ r, double* __restrict__ stat_rows, int B, int H, int W) {
@@ -98,10 +118,10 @@ __global__ void k_distill_bn_finalize(const double* __restrict__ stat_rows, int 
                                       float* __restrict__ rm2, float* __restrict__ rv2, long long* __restrict__ nbt2, float eps,
                                       float momentum, float* __restrict__ state) {
   __shared__ double tot[12];
-  if (threadIdx.x < 12) {
-    double s = 0.0;
-    for (int z = 0; z < nrows; ++z) s += stat_rows[(size_t)z * 12 + threadIdx.x];
-    tot[threadIdx.x] = s;
+  __shared__ double sm16[12][16];
+  {
+    const double s = rows_sum16<12, double>(stat_rows, nrows, sm16);
+    if ((threadIdx.x & 15) == 0 && threadIdx.x < 192) tot[threadIdx.x >> 4] = s;
   }
   __syncthreads();
   if (threadIdx.x < 6) {
@@ -159,11 +179,9 @@ __global__ __launch_bounds__(TPB) void k_distill_act_loss(const float* __restric
 }
 
 __global__ void k_distill_loss_finalize(const double* __restrict__ loss_rows, int nrows, double inv_n, float* __restrict__ loss) {
-  if (threadIdx.x == 0) {
-    double s = 0.0;
-    for (int z = 0; z < nrows; ++z) s += loss_rows[z];
-    *loss = (float)(s * inv_n);
-  }
+  __shared__ double sm16[1][16];
+  const double s = rows_sum16<1, double>(loss_rows, nrows, sm16);
+  if (threadIdx.x == 0) *loss = (float)(s * inv_n);
 }
 
 // gradient wrt the two BatchNorm outputs before the ReLU: G1 = (gl * sign(f1 - f2) + dfeat) [f1 > 0], G2 = -gl * sign(f1 - f2) [f2 > 0]
@@ -207,13 +225,13 @@ __global__ __launch_bounds__(TPB) void k_distill_bn_bwd_stats(const float* __res
 __global__ void k_distill_bn_bwd_finalize(const double* __restrict__ rows, int nrows, double count, float* __restrict__ dg1,
                                           float* __restrict__ db1, float* __restrict__ dg2, float* __restrict__ db2,
                                           float* __restrict__ coef) {
-  if (threadIdx.x < 12) {
-    double s = 0.0;
-    for (int z = 0; z < nrows; ++z) s += rows[(size_t)z * 12 + threadIdx.x];
-    const int c = threadIdx.x % 6, cc = c % 3;
-    if (threadIdx.x < 6) { float* db = c < 3 ? db1 : db2; db[cc] += (float)s; }
+  __shared__ double sm16[12][16];
+  const double s = rows_sum16<12, double>(rows, nrows, sm16);
+  if ((threadIdx.x & 15) == 0 && threadIdx.x < 192) {
+    const int v = threadIdx.x >> 4, c = v % 6, cc = c % 3;
+    if (v < 6) { float* db = c < 3 ? db1 : db2; db[cc] += (float)s; }
     else { float* dg = c < 3 ? dg1 : dg2; dg[cc] += (float)s; }
-    coef[threadIdx.x] = (float)(s / count);
+    coef[v] = (float)(s / count);
   }
 }
 
@@ -320,16 +338,20 @@ __global__ __launch_bounds__(TPB) void k_distill_conv_bwd(const float* __restric
 // ---- backward 5: weight-gradient rows added in block order into the parameter gradients
 __global__ __launch_bounds__(TPB) void k_distill_wgrad_finalize(const float* __restrict__ wrows, int nrows, float* __restrict__ dwc,
                                                                 float* __restrict__ dbc, float* __restrict__ dwf, float* __restrict__ dbf) {
-  const int v = blockIdx.x * TPB + threadIdx.x;
-  if (v >= NWG) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int z = 0;
-  for (; z + 3 < nrows; z += 4) {          // four chains in flight; the order of the additions is fixed
-    s0 += wrows[(size_t)z * NWG + v]; s1 += wrows[(size_t)(z + 1) * NWG + v];
-    s2 += wrows[(size_t)(z + 2) * NWG + v]; s3 += wrows[(size_t)(z + 3) * NWG + v];
+  // 16 values per block, 16 lanes per value (fixed order: lane l adds the rows l, l + 16, ..., the lanes are added in lane order)
+  __shared__ float sm[16][16];
+  const int v = blockIdx.x * 16 + (threadIdx.x >> 4), l = threadIdx.x & 15;
+  float s0 = 0.f, s1 = 0.f;
+  if (v < NWG) {
+    int z = l;
+    for (; z + 16 < nrows; z += 32) { s0 += wrows[(size_t)z * NWG + v]; s1 += wrows[(size_t)(z + 16) * NWG + v]; }
+    if (z < nrows) s0 += wrows[(size_t)z * NWG + v];
   }
-  for (; z < nrows; ++z) s0 += wrows[(size_t)z * NWG + v];
-  const float s = (s0 + s1) + (s2 + s3);
+  sm[threadIdx.x >> 4][l] = s0 + s1;
+  __syncthreads();
+  if (v >= NWG || l != 0) return;
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += sm[threadIdx.x >> 4][i];
   if (v < 162) dwc[v] += s;
   else if (v < 243) dwf[v - 162] += s;
   else if (v < 246) dbc[v - 243] += s;
@@ -382,7 +404,7 @@ int dpmn_distill_forward_f32(const dpmn_distill_params* p, const float* x_deep, 
   hipLaunchKernelGGL(k_distill_conv_fwd, dim3(nb), dim3(TPB), 0, st, x_deep, x_shallow, wp, r, s.rows, B, H, W);
   DPMN_CHECK_LAUNCH();
   if (training)
-    hipLaunchKernelGGL(k_distill_bn_finalize, dim3(1), dim3(64), 0, st, s.rows, nb, (double)total, p->bn1_w, p->bn1_b, p->bn2_w, p->bn2_b,
+    hipLaunchKernelGGL(k_distill_bn_finalize, dim3(1), dim3(192), 0, st, s.rows, nb, (double)total, p->bn1_w, p->bn1_b, p->bn2_w, p->bn2_b,
                        p->bn1_rm, p->bn1_rv, p->bn1_nbt, p->bn2_rm, p->bn2_rv, p->bn2_nbt, 1e-5f, 0.1f, state);
   else
     hipLaunchKernelGGL(k_distill_bn_eval, dim3(1), dim3(64), 0, st, p->bn1_w, p->bn1_b, p->bn2_w, p->bn2_b, p->bn1_rm, p->bn1_rv, p->bn2_rm,
@@ -410,14 +432,14 @@ int dpmn_distill_backward_f32(const dpmn_distill_params* p, const dpmn_distill_g
   const DistillWPtr wp{p->conv_cat_w, p->conv_cat_b, p->conv_feat_w, p->conv_feat_b};
   hipLaunchKernelGGL(k_distill_bn_bwd_stats, dim3(nb), dim3(TPB), 0, st, r, state, dfeat, gloss, inv_n, s.rows, B, H, W);
   DPMN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_distill_bn_bwd_finalize, dim3(1), dim3(64), 0, st, s.rows, nb, (double)total, g->dbn1_w, g->dbn1_b, g->dbn2_w,
+  hipLaunchKernelGGL(k_distill_bn_bwd_finalize, dim3(1), dim3(192), 0, st, s.rows, nb, (double)total, g->dbn1_w, g->dbn1_b, g->dbn2_w,
                      g->dbn2_b, s.coef);
   DPMN_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_distill_dr, dim3(nb), dim3(TPB), 0, st, r, state, dfeat, gloss, inv_n, s.coef, s.dr, B, H, W);
   DPMN_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_distill_conv_bwd, dim3(nb), dim3(TPB), 0, st, x_deep, x_shallow, s.dr, wp, dx_deep, dx_shallow, s.wrows, B, H, W);
   DPMN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_distill_wgrad_finalize, dim3(1), dim3(TPB), 0, st, s.wrows, nb, g->dconv_cat_w, g->dconv_cat_b, g->dconv_feat_w,
+  hipLaunchKernelGGL(k_distill_wgrad_finalize, dim3((NWG + 15) / 16), dim3(TPB), 0, st, s.wrows, nb, g->dconv_cat_w, g->dconv_cat_b, g->dconv_feat_w,
                      g->dconv_feat_b);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;

@@ -61,9 +61,10 @@ def layernorm_bwd(x, dy, w, dx, accumulate, dgamma, dbeta):
         check(lib.dpmn_layernorm_bwd_f32(dptr(x), dptr(dy), dptr(w), 1e-5, dptr(dx), int(accumulate), dptr(dgamma), dptr(dbeta),
                                          x.shape[0], x.shape[1], stream()))
         return
-    ws = ops.splitk_workspace(x.device)
+    ptr, nb = _ws(x.device, 512 * 2 * x.shape[1] * 4)
     check(lib.dpmn_layernorm_bwd_det_f32(dptr(x), dptr(dy), dptr(w), 1e-5, dptr(dx), int(accumulate), dptr(dgamma), dptr(dbeta),
-                                         x.shape[0], x.shape[1], dptr(ws), ws.numel() * 4, stream()))
+                                         x.shape[0], x.shape[1], ptr, nb, stream()))
+    _ws_done()
 
 
 def act_fwd(x, act=GELU):
@@ -80,68 +81,87 @@ def act_bwd(dy, pre, act=GELU):
 
 TN_DEFER = os.environ.get("DPMN_TN_DEFER", "1") != "0"
 _TN_WS = {}
-_tn_pending = None     # set by backward() for one PGRM backward: [workspace, bytes used, [TnPending, ...], keep-alive tensors]
+_tn_pending = None     # set by PGRMFunction.backward for one PGRM backward: [arena tensor, bytes used, keep-alive tensors]
 
 
 def _tn_workspace(device):
-    """partial-sum regions of the deferred Linear weight gradients of one PGRM backward (per device and stream)."""
+    """Arena of one PGRM backward (per device and stream): every partial-row buffer of its atomics-free reductions -- the split
+    partials of the 14 Linear weight gradients (~120 MB at B = 48), the pointwise-conv weight gradient's 32 splits (19 MB per
+    block), column / row sums, LayerNorm parameter gradients -- lives here until the backward's ONE reduce launch."""
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _TN_WS:
-        _TN_WS[key] = torch.empty(48 << 20, device=device)      # 192 MB: the 14 Linear layers of a dim-96 PGRM need ~120 MB at B = 48
+        _TN_WS[key] = torch.empty(80 << 20, device=device)      # 320 MB
     return _TN_WS[key]
 
 
-def tn_flush():
-    """One reduce launch for every pending Linear weight gradient (dpmn_tn_reduce_multi_f32)."""
-    if _tn_pending is None or not _tn_pending[2]:
+def _ws(device, nbytes):
+    """(pointer, bytes) of a workspace slice for one atomics-free reduction: a slice of the backward's arena while its reductions
+    are deferred (include/dpmn_hip.h dpmn_reduce_defer_*: the slice must stay untouched until the flush), else the shared
+    per-stream scratch (the reduction then runs at once)."""
+    if _tn_pending is not None:
+        nbytes = (int(nbytes) + 255) // 256 * 256
+        arena = _tn_pending[0]
+        if nbytes <= arena.numel() * 4:
+            if _tn_pending[1] + nbytes > arena.numel() * 4:
+                tn_flush()
+            ptr = arena.data_ptr() + _tn_pending[1]
+            _tn_pending[1] += nbytes
+            return ptr, nbytes
+        check(lib.dpmn_reduce_defer_enable(0))       # does not fit the arena at all: run this one immediately
+        _tn_pending[2].append("resume")
+    ws = ops.splitk_workspace(device)
+    return ws.data_ptr(), ws.numel() * 4
+
+
+def _ws_done():
+    if _tn_pending is not None and _tn_pending[2] and _tn_pending[2][-1] == "resume":
+        _tn_pending[2].pop()
+        check(lib.dpmn_reduce_defer_enable(1))
+
+
+def tn_flush(end=False):
+    """One multi-descriptor reduce launch for every queued ordered reduction (dpmn_reduce_defer_flush); the arena is free again."""
+    if _tn_pending is None:
         return
-    arr = (_abi.TnPending * len(_tn_pending[2]))(*_tn_pending[2])
-    check(lib.dpmn_tn_reduce_multi_f32(arr, len(_tn_pending[2]), stream()))
+    check(lib.dpmn_reduce_defer_flush(1 if end else 0, stream()))
     _tn_pending[1] = 0
-    _tn_pending[2].clear()
-    _tn_pending[3].clear()
+    del _tn_pending[2][:]
 
 
 def gemm_tn(dy, x, dw, db=None, leaf=True):
     """dw (N,K) += dy (M,N)^T x (M,K) ; db (N) += column sums of dy (fused into the same kernel).
     Inside a PGRM backward (leaf=True: nothing reads dw / db before its end) only the split partial sums are launched, each into
-    its own region of a per-stream workspace; ONE reduce launch at the end adds them all (tn_flush) -- 14 small launches less per
-    PGRM backward, whose two-stream phase is launch-rate sensitive."""
+    its own slice of the backward's arena; ONE reduce launch at the end adds them all (tn_flush) -- the two-stream phase of the
+    backward is launch-rate sensitive.  leaf=False: the result is read right away, the reduction runs immediately."""
     M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
-    if _tn_pending is not None and leaf:
-        need = lib.dpmn_gemm_tn_partial_bytes(M, N, K)
-        ws = _tn_pending[0]
-        if _tn_pending[1] + need > ws.numel() * 4:
-            tn_flush()
-        if need <= ws.numel() * 4:
-            pend = _abi.TnPending()
-            import ctypes as _C
-            check(lib.dpmn_gemm_tn_partial_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), M, N, K, ws.data_ptr() + _tn_pending[1], need,
-                                               _C.byref(pend), stream()))
-            _tn_pending[1] += need
-            _tn_pending[2].append(pend)
-            _tn_pending[3].append((dw, db))
-            return
-    ws = ops.splitk_workspace(dy.device)
-    check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), M, N, K, dptr(ws), ws.numel() * 4, stream()))
+    if _tn_pending is not None and not leaf:
+        check(lib.dpmn_reduce_defer_enable(0))
+    try:
+        ptr, nb = _ws(dy.device, lib.dpmn_gemm_tn_partial_bytes(M, N, K)) if leaf else (ops.splitk_workspace(dy.device).data_ptr(),
+                                                                                       ops.splitk_workspace(dy.device).numel() * 4)
+        check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), M, N, K, ptr, nb, stream()))
+        if leaf:
+            _ws_done()
+    finally:
+        if _tn_pending is not None and not leaf:
+            check(lib.dpmn_reduce_defer_enable(1))
 
 
 def defer_rows(part, dw, db, NK, N, rows):
     """dw (NK) += sum over `rows` rows of part[:, :NK], db (N) += ... part[:, NK:] in ROW ORDER (atomics-free finish of per-block /
-    per-image partial sums).  Inside a PGRM backward the sum joins the one multi-descriptor reduce launch at its end (tn_flush)."""
+    per-image partial sums).  Inside a PGRM backward the sum joins the one multi-descriptor reduce launch at its end (tn_flush);
+    `part` is kept alive until then."""
     if _tn_pending is not None:
-        pend = _abi.TnPending()
-        pend.part, pend.dw, pend.db, pend.NK, pend.N, pend.splits = dptr(part), dptr(dw), dptr(db, True), NK, N, rows
-        _tn_pending[2].append(pend)
-        _tn_pending[3].append((part, dw, db))
-        return
+        _tn_pending[2].append((part, dw, db))
     check(lib.dpmn_rows_reduce_f32(dptr(part), dptr(dw), dptr(db, True), NK, N, rows, stream()))
 
 
 def colsum(dy, db):
     """db (N) += column sums of dy (M, N), without atomics (per-block partials summed in block order: bitwise reproducible)."""
-    ws = ops.splitk_workspace(dy.device)
-    check(lib.dpmn_colsum_det_f32(dptr(dy), dptr(db), dy.shape[0], dy.shape[1], dptr(ws), ws.numel() * 4, stream()))
+    M, N = dy.shape
+    ptr, nb = _ws(dy.device, (M + 255) // 256 * N * 4)
+    check(lib.dpmn_colsum_det_f32(dptr(dy), dptr(db), M, N, ptr, nb, stream()))
+    _ws_done()
 
 
 def linear_bwd(dy, x, w, dw, db):
@@ -400,23 +420,28 @@ def backward(m, sv, dout, need_dx_kv=True):
         # pointwise conv on the raw (B, Ch, L) views
         wp = mlp.pointwise_conv.weight.reshape(Ch, Ch)
         dg = ops.pointwise(dz.reshape(B, L, Ch), packing.transposed(wp), _zero_bias(Ch, dz.device)).reshape(M, Ch)
-        wsd = ops.splitk_workspace(dz.device)       # partial rows of the atomics-free pointwise / bias / depthwise-conv gradients
+        # partial rows of the atomics-free pointwise / bias / depthwise-conv gradients: slices of the backward's arena
         if DET_SMALL:
-            check(lib.dpmn_pointwise_wgrad_det_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, dptr(wsd),
-                                                   wsd.numel() * 4, stream()))
+            ptr, nb = _ws(dz.device, 32 * Ch * Ch * 4)
+            check(lib.dpmn_pointwise_wgrad_det_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, ptr, nb, stream()))
+            _ws_done()
         else:
             check(lib.dpmn_pointwise_wgrad_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, stream()))
         if DET_SMALL:
-            check(lib.dpmn_rowsum_mod_det_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, dptr(wsd), wsd.numel() * 4, stream()))
+            ptr, nb = _ws(dz.device, B * Ch * 4)
+            check(lib.dpmn_rowsum_mod_det_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, ptr, nb, stream()))
+            _ws_done()
         else:
             check(lib.dpmn_rowsum_mod_f32(dptr(dz), dptr(gr[mlp.pointwise_conv.bias]), B * Ch, L, Ch, stream()))
         # GELU'(gpre) on the way in, GELU (+ the dropout mask) on the forward input, mask and GELU'(ypre) on the way out
         dypre = torch.empty_like(dg)
         r = int(round(L ** 0.5))
         if DET_SMALL:
+            ptr, nb = _ws(dz.device, B * Ch * 10 * 4)
             check(lib.dpmn_dwconv3x3_bwd_fused_det_f32(dptr(s["ypre"]), dptr(dg), dptr(s["gpre"]), dptr(mlp.depthwise_conv.weight),
                                                        dptr(dypre), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
-                                                       1, 1, float(pd), int(sb[2]), B, Ch, r, dptr(wsd), wsd.numel() * 4, stream()))
+                                                       1, 1, float(pd), int(sb[2]), B, Ch, r, ptr, nb, stream()))
+            _ws_done()
         else:
             check(lib.dpmn_dwconv3x3_bwd_fused_f32(dptr(s["ypre"]), dptr(dg), dptr(s["gpre"]), dptr(mlp.depthwise_conv.weight),
                                                    dptr(dypre), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
@@ -543,11 +568,14 @@ class PGRMFunction(torch.autograd.Function):
         global _tn_pending
         m = ctx.m
         if TN_DEFER and not torch.cuda.is_current_stream_capturing():
-            _tn_pending = [_tn_workspace(dout.device), 0, [], []]
+            _tn_pending = [_tn_workspace(dout.device), 0, []]
+            check(lib.dpmn_reduce_defer_begin())
         try:
             dx_kv, dres, gr, direct = backward(m, ctx.sv, dout, need_dx_kv=ctx.need_kv)
-            tn_flush()          # every Linear weight gradient is in place before the bucket is signalled
+            tn_flush(end=True)          # every parameter gradient is in place before the bucket is signalled
         finally:
+            if _tn_pending is not None:
+                lib.dpmn_reduce_defer_flush(1, stream())      # (after an exception: drop the queue, leave deferral off)
             _tn_pending = None
         ctx.sv = None
         dres_out = [None if d is None else d for d in dres] + [None] * (ctx.n_res - len(dres))

@@ -347,6 +347,17 @@ size_t dpmn_gemm_tn_partial_bytes(int M, int N, int K);
 int dpmn_gemm_tn_partial_f32(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
                              dpmn_tn_pending* pending, dpmn_stream_t stream);
 int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending /* HOST array */, int n, dpmn_stream_t stream);
+/* Deferred ordered reductions: between dpmn_reduce_defer_begin() and dpmn_reduce_defer_flush(end = 1, stream) every "partial rows added
+ * in order" finish of the backward entry points (dpmn_gemm_tn_f32, dpmn_colsum_det_f32, dpmn_layernorm_bwd_det_f32,
+ * dpmn_rows_reduce_f32 and the functions built on it) is queued instead of launched, and the flush runs the queue as multi-descriptor
+ * launches (sums into the same tensor in separate launches, in queue order).  The CALLER keeps every workspace it passed to those
+ * functions untouched until the flush.  Per host thread.  dpmn_reduce_defer_enable(0 / 1) pauses / resumes queueing (for a reduction
+ * whose result is read immediately); dpmn_reduce_defer_push queues a descriptor of the caller's own. */
+int dpmn_reduce_defer_begin(void);
+int dpmn_reduce_defer_enable(int on);
+int dpmn_reduce_defer_push(const dpmn_tn_pending* p);
+int dpmn_reduce_defer_pending(void);
+int dpmn_reduce_defer_flush(int end, dpmn_stream_t stream);
 /* db (N) += column sums of dy (M,N) */
 int dpmn_colsum_f32(const float* dy, float* db, long M, int N, dpmn_stream_t stream);
 /* the same without atomics (per-block partial sums in ws, >= ceil(M / 256) * N floats, added in block order): bitwise reproducible */
