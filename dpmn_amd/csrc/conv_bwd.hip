@@ -441,6 +441,20 @@ __global__ __launch_bounds__(256) void k_conv_pack_multi(const PackDesc* __restr
   pack_tile<false>(d, (int)blockIdx.x - block_prefix[lo], lds, 1, 0);
 }
 
+// The weight-gradient unpacks of a whole backward pass (the CMM's ~40 convs) in ONE launch, like k_conv_pack_multi: the slot count of a
+// descriptor travels in its last field (exclusive-slot workspaces: nothing to clear).  Destinations of different descriptors are
+// disjoint (own weights; the four phases of a ConvTranspose2d(4,2,1) write interleaved elements of one tensor).
+__global__ __launch_bounds__(256) void k_wgrad_unpack_multi(const PackDesc* __restrict__ descs, const int* __restrict__ block_prefix, int n_desc) {
+  __shared__ float lds[PK_LDS];
+  int lo = 0, hi = n_desc - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (block_prefix[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  pack_tile<true>(d, (int)blockIdx.x - block_prefix[lo], lds, d.pad_ > 1 ? d.pad_ : 1, 0);
+}
+
 // ---------------------------------------------------------------------------------- train-mode BatchNorm
 // stats (32,2,C) DOUBLES = slotted (sum, sumsq) over `count` values per channel (accumulated by the conv epilogue with fp64 atomics)
 // clear: zero the slots after reading them (a persistent statistics buffer then needs no memset per conv); nbt: the module's
@@ -925,6 +939,14 @@ int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int K
   DPMN_REQUIRE(dwp && dw && Cout > 0 && cin > 0 && KH > 0 && KW > 0 && KH * KW <= 2304, "conv2d_wgrad_unpack: bad arguments");
   const PackDesc d = make_pack_desc(dw, dwp, Cout, cin, KH, KW, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base);
   hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)pack_tile_blocks(d)), dim3(256), 0, as_stream(stream), d, clear, nslots > 1 ? nslots : 1);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_conv2d_wgrad_unpack_multi_f32(const void* descs, const int* block_prefix, int n_desc, int n_blocks, dpmn_stream_t stream) {
+  DPMN_REQUIRE(descs && block_prefix && n_desc > 0 && n_blocks > 0, "conv2d_wgrad_unpack_multi: bad arguments");
+  hipLaunchKernelGGL(k_wgrad_unpack_multi, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const PackDesc*>(descs),
+                     block_prefix, n_desc);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -286,22 +286,40 @@ def backward(m, graph, dout, need_dx=(True, True)):
             n = 2 * t.r.shape[3]
             t.gsums, off = slab[off:off + n], off + n
     side = wgrad_stream(dout.device)
-    for u in reversed(units):
-        if u is last or u.out.G is not None:
-            u.backward(gr, side)
-        if u.inputs and u.inputs[0] is graph["gated"]:
-            # channel gate backward, then split the bottleneck gradient into the two en_6 outputs
-            g = graph["gated"]
-            dbott = torch.empty_like(graph["bott"])
-            _c, _cm = dbott.shape[3], m.fc_1.weight.shape[0]
-            se_ws = torch.empty(dbott.shape[0] * (5 * _c + 2 * _cm) + 2 * _c * _cm, device=dbott.device)
-            check(lib.dpmn_se_gate_bwd_f32(dptr(graph["bott"]), dptr(g.G), dptr(m.fc_1.weight), dptr(m.fc_1.bias), dptr(m.fc_2.weight),
-                                           dptr(m.fc_2.bias), dptr(dbott), dptr(gr[m.fc_1.weight]), dptr(gr[m.fc_1.bias]),
-                                           dptr(gr[m.fc_2.weight]), dptr(gr[m.fc_2.bias]), dptr(se_ws), dbott.shape[0], dbott.shape[1] * dbott.shape[2],
-                                           dbott.shape[3], m.fc_1.weight.shape[0], stream()))
-            half = dbott.shape[3] // 2
-            a[5].G = dbott[..., :half].contiguous()
-            b[5].G = dbott[..., half:].contiguous()
+    # every conv's weight-gradient unpack in ONE launch at the end (train/pgrm_train.py UnpackQueue; per module: the descriptor
+    # table holds this module's gradient sinks)
+    from . import pgrm_train as _pt
+    uq = None
+    if _pt.UNPACK_MULTI and direct and not torch.cuda.is_current_stream_capturing():
+        uq = getattr(m, "_unpack_queue", None)
+        if uq is None:
+            uq = m._unpack_queue = _pt.UnpackQueue()
+        _pt.UNPACK_QUEUE = uq
+    try:
+      for u in reversed(units):
+          if u is last or u.out.G is not None:
+              u.backward(gr, side)
+          if u.inputs and u.inputs[0] is graph["gated"]:
+              # channel gate backward, then split the bottleneck gradient into the two en_6 outputs
+              g = graph["gated"]
+              dbott = torch.empty_like(graph["bott"])
+              _c, _cm = dbott.shape[3], m.fc_1.weight.shape[0]
+              se_ws = torch.empty(dbott.shape[0] * (5 * _c + 2 * _cm) + 2 * _c * _cm, device=dbott.device)
+              check(lib.dpmn_se_gate_bwd_f32(dptr(graph["bott"]), dptr(g.G), dptr(m.fc_1.weight), dptr(m.fc_1.bias), dptr(m.fc_2.weight),
+                                             dptr(m.fc_2.bias), dptr(dbott), dptr(gr[m.fc_1.weight]), dptr(gr[m.fc_1.bias]),
+                                             dptr(gr[m.fc_2.weight]), dptr(gr[m.fc_2.bias]), dptr(se_ws), dbott.shape[0], dbott.shape[1] * dbott.shape[2],
+                                             dbott.shape[3], m.fc_1.weight.shape[0], stream()))
+              half = dbott.shape[3] // 2
+              a[5].G = dbott[..., :half].contiguous()
+              b[5].G = dbott[..., half:].contiguous()
+    finally:
+        _pt.UNPACK_QUEUE = None
+    if uq is not None:
+        if side is not None:
+            with torch.cuda.stream(side):
+                uq.flush()
+        else:
+            uq.flush()
     dxs = []
     for leaf, need in zip(graph["leaves"], need_dx):
         dxs.append(ops.nhwc_to_nchw(leaf.G)[:, :3].contiguous() if need else None)

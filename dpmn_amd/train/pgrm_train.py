@@ -221,6 +221,13 @@ def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
         check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 1, nslots, stream()))
         return
     n = slots.value * d.Cout * kp
+    if UNPACK_QUEUE is not None and not torch.cuda.is_current_stream_capturing():
+        # deferred: the weight gradient goes to this conv's OWN persistent slot workspace; one multi-descriptor unpack launch at
+        # the end of the module's backward sums the slots of every conv into the parameter layout (UnpackQueue.flush)
+        ws = UNPACK_QUEUE.region((dweight.data_ptr(), layout, phase, d.Cout, cin_d, d.KH, d.KW, slots.value), n, dweight, (d.Cout, cin_d, d.KH, d.KW, co, ci, st),
+                                 slots.value)
+        check(lib.dpmn_conv2d_wgrad_excl_f32(C.byref(d), dptr(dy), dptr(ws), slots.value, stream()))
+        return
     skey = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
     ws = _WGRAD_WS.get(skey)
     if ws is None or ws.numel() < n:       # one workspace per (device, stream): wgrad -> unpack pairs are stream-ordered
@@ -228,6 +235,59 @@ def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
     check(lib.dpmn_conv2d_wgrad_excl_f32(C.byref(d), dptr(dy), dptr(ws), slots.value, stream()))
     check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dweight), d.Cout, cin_d, d.KH, d.KW, co, ci, *st, 0, slots.value, stream()))
 
+
+class UnpackQueue:
+    """The weight-gradient unpacks of one module's backward (the CMM: ~40 convs, 57 launches of k_wgrad_unpack per step) as ONE launch.
+    Every conv gets its own persistent exclusive-slot workspace (the wgrad kernel's partial tiles, no zero-init) and a 112-byte
+    descriptor in a device table built once (the gradient sinks of a Trainer and these workspaces keep their addresses for the
+    whole run); flush() sums the slots of every conv that ran since the last flush into the parameter layout."""
+
+    def __init__(self):
+        self.entries, self.order, self.touched, self.table = {}, [], set(), None
+
+    def region(self, key, n, dweight, geom, slots):
+        e = self.entries.get(key)
+        if e is None:
+            e = self.entries[key] = [torch.empty(n, device=dweight.device), dweight, geom, slots]
+            self.order.append(key)
+            self.table = None
+        self.touched.add(key)
+        return e[0]
+
+    def flush(self):
+        import struct
+        if not self.touched:
+            return
+        if len(self.touched) != len(self.order):      # a partial pass (not every registered conv ran): one launch per conv
+            for key in self.order:
+                if key in self.touched:
+                    ws, dw, (cout, cin, kh, kw, co, ci, st), slots = self.entries[key]
+                    check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dw), cout, cin, kh, kw, co, ci, *st, 0, slots, stream()))
+            self.touched.clear()
+            return
+        if self.table is None:
+            raw, prefix, nb = bytearray(), [], 0
+            shape = (C.c_int * 3)()
+            for key in self.order:
+                ws, dw, (cout, cin, kh, kw, co, ci, st), slots = self.entries[key]
+                K = kh * kw * cin
+                kp = (K + 31) // 32 * 32
+                check(lib.dpmn_conv_pack_tile_shape(cout, cin, kh * kw, st[0], st[1], C.cast(shape, C.c_void_p)))
+                co_t, ci_t, order = shape[0], shape[1], shape[2]
+                nci = (cin + ci_t - 1) // ci_t
+                raw += struct.pack("<2Q6q12i", dw.data_ptr(), ws.data_ptr(), st[0], st[1], st[2], st[3], st[4], cout * kp, cout, kp, K, cin, kw,
+                                   min(co, cout), min(ci, cin), co_t, ci_t, order, nci, slots)
+                prefix.append(nb)
+                nb += (cout + co_t - 1) // co_t * nci
+            dev = self.entries[self.order[0]][0].device
+            self.table = (torch.frombuffer(raw, dtype=torch.uint8).to(dev), torch.tensor(prefix, dtype=torch.int32, device=dev), nb)
+        descs, prefix, nb = self.table
+        check(lib.dpmn_conv2d_wgrad_unpack_multi_f32(descs.data_ptr(), prefix.data_ptr(), len(self.order), nb, stream()))
+        self.touched.clear()
+
+
+UNPACK_QUEUE = None      # set by a module's backward (train/cmm_train.py) around its conv_wgrad_into calls
+UNPACK_MULTI = os.environ.get("DPMN_UNPACK_MULTI", "1") != "0"
 
 import os as _os
 WGRAD_MODE = _os.environ.get("DPMN_WGRAD", "excl")      # "atomic": the previous accumulate-by-atomics path (A/B switch)

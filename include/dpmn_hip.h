@@ -536,6 +536,10 @@ int dpmn_conv2d_wgrad_excl_f32(const dpmn_conv_desc* d, const float* dy, float* 
 int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int KH, int KW, int co_lim, int ci_lim, long s_co,
                                  long s_ci, long s_ky, long s_kx, long base, int clear, int nslots /* copies to sum */,
                                  dpmn_stream_t stream);
+/* Every weight-gradient unpack of a backward pass in ONE launch: descs = device array of the 112-byte pack descriptors of
+ * dpmn_conv_pack_multi_f32 (w = the gradient tensor, wp = the exclusive-slot workspace, last int = slot count), block_prefix[i] = first
+ * block of descriptor i.  The descriptors' destination elements must be disjoint. */
+int dpmn_conv2d_wgrad_unpack_multi_f32(const void* descs, const int* block_prefix, int n_desc, int n_blocks, dpmn_stream_t stream);
 int dpmn_conv2d_wgrad_strided_f32(const dpmn_conv_desc* d, const float* dy, float* dw, int co_lim, int ci_lim, long s_co,
                                   long s_ci, long s_ky, long s_kx, long base, dpmn_stream_t stream);
 /* num_batches_tracked (int64, may be NULL) is incremented by one; clear_stats != 0 zeroes the (32,2,C) fp64 slots after they are
