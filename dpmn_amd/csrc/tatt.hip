@@ -328,6 +328,24 @@ __global__ void k_gru_gate(const float* __restrict__ gi, const float* __restrict
   hist[(size_t)r_ * hist_row_stride + j] = hn;
 }
 
+// TPGSR (tsrn.py:226-227): the InfoGen map (N, 1, Win, C) stretched to the LR feature map (N, H, W, C) by F.interpolate(..., mode
+// 'bilinear', align_corners=True): the single source row is repeated over H, columns x -> x (Win - 1) / (W - 1)
+__global__ void k_tl_interp(const float* __restrict__ in, float* __restrict__ out, int N, int Win, int C, int H, int W) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C / 4;
+  if (idx >= (long)N * H * W * c4) return;
+  const int c = (idx % c4) * 4;
+  const int x = (idx / c4) % W, n = idx / ((long)c4 * W * H);
+  const float sx = W > 1 ? (float)x * ((float)(Win - 1) / (float)(W - 1)) : 0.f;
+  int x0 = (int)sx;
+  if (x0 > Win - 1) x0 = Win - 1;
+  const int x1 = x0 + 1 < Win ? x0 + 1 : Win - 1;
+  const float l1 = sx - (float)x0, l0 = 1.f - l1;
+  const float4 a = *reinterpret_cast<const float4*>(in + ((size_t)n * Win + x0) * C + c);
+  const float4 b = *reinterpret_cast<const float4*>(in + ((size_t)n * Win + x1) * C + c);
+  *reinterpret_cast<float4*>(out + idx * 4) = make_float4(l0 * a.x + l1 * b.x, l0 * a.y + l1 * b.y, l0 * a.z + l1 * b.z, l0 * a.w + l1 * b.w);
+}
+
 }  // namespace
 
 extern "C" {
@@ -388,6 +406,14 @@ int dpmn_gru_gate_f32(const float* gi, const float* gh, float* h, float* hist, l
   const long total = (long)R * H;
   hipLaunchKernelGGL(k_gru_gate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), gi, gh, h, hist,
                      hist_row_stride, R, H);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+int dpmn_tl_interp_f32(const float* in, float* out, int N, int Win, int C, int H, int W, dpmn_stream_t stream) {
+  DPMN_REQUIRE(in && out && N > 0 && Win > 0 && H > 0 && W > 0 && C % 4 == 0, "tl_interp: bad arguments");
+  const long total = (long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(k_tl_interp, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), in, out, N, Win, C, H, W);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -107,8 +107,10 @@ class TextBase(object):
             model = tatt.TSRN_TL_TRANS(**kw)
         elif psn and self.args.arch == 'tbsrn':
             model = tbsrn.TBSRN(**kw)
+        elif psn and self.args.arch == 'tpgsr':       # base.py:141-144
+            model = tsrn.TSRN_TL(**kw)
         elif psn:
-            raise NotImplementedError("dpmn_amd: PSN arch %r is not built (built: tsrn, tg, tatt, tbsrn)" % self.args.arch)
+            raise NotImplementedError("dpmn_amd: PSN arch %r is not built (built: tsrn, tg, tatt, tbsrn, tpgsr)" % self.args.arch)
         else:
             # base.py:151 never passes img_size, so the reference PGRM is hard-wired to 32x128 outputs (weight_list_i is
             # (1, hidden, 32, 128), pgrm.py:497, quirk Q7).  Here the size follows the config (height x width), which is the

@@ -99,6 +99,8 @@ class TextSR(base.TextBase):
             images_lr_psn = model_psn(images_lr)
         elif self.args.arch == 'tatt':
             images_lr_psn, _ = model_psn(images_lr, label_vecs)
+        elif self.args.arch == 'tpgsr':      # super_resolution.py:372-377: the PSN takes the recogniser's probabilities, returns the image
+            images_lr_psn = model_psn(images_lr, label_vecs)
         else:
             raise NotImplementedError(self.args.arch)
         branch1, branch2 = [], []
@@ -162,7 +164,7 @@ class TextSR(base.TextBase):
         for data in val_loader:
             images_hr, images_lr = data[0].to(self.device), data[1].to(self.device)
             label_vecs = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
-            if label_vecs is None and self.args.arch == 'tatt':      # real data: TATT's label_vecs come from the frozen CRNN (lines 165-169)
+            if label_vecs is None and self.args.arch in ('tatt', 'tpgsr'):      # real data: TATT's label_vecs come from the frozen CRNN (lines 165-169)
                 label_vecs = self.label_vecs_from_crnn(images_lr)
             if getattr(self.args, "rotate_test", 0):      # super_resolution.py:358-365 (angle range from rotate_train, as there)
                 images_lr, images_hr = self.rotate_pair(images_lr, images_hr, self.args.rotate_train)
@@ -223,6 +225,8 @@ class TextSR(base.TextBase):
         with torch.no_grad():
             if self.args.arch in ('tsrn', 'tbsrn', 'tg'):
                 images_lr_psn = psn(images_lr)
+            elif self.args.arch == 'tpgsr':
+                images_lr_psn = psn(images_lr, label_vecs)
             else:
                 images_lr_psn, _ = psn(images_lr, label_vecs)
         br1, br2, part = [], [], [0, 0]
@@ -388,7 +392,7 @@ class TextSR(base.TextBase):
             for data in passes(epoch):
                 hr, lr = data[0].to(self.device), data[1].to(self.device)
                 lv = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
-                if lv is None and self.args.arch == 'tatt':
+                if lv is None and self.args.arch in ('tatt', 'tpgsr'):
                     lv = self.label_vecs_from_crnn(lr)
                 loss = self.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_prior_fn=fn)
                 it += 1

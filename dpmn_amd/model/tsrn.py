@@ -198,3 +198,75 @@ class TSRN(_PSNBase):
         self._check_mode()
         P = self._trunk_pack()
         return self._trunk(self._head(x, P), P)
+
+
+class _InfoGen(nn.Module):
+    """parameter holder of tsrn.py:280-304"""
+
+    def __init__(self, t_emb, output_size):
+        super().__init__()
+        self.tconv1 = nn.ConvTranspose2d(t_emb, 512, 3, 2, padding=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(512)
+        self.tconv2 = nn.ConvTranspose2d(512, 128, 3, 2, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(128)
+        self.tconv3 = nn.ConvTranspose2d(128, 64, 3, 2, padding=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(64)
+        self.tconv4 = nn.ConvTranspose2d(64, output_size, 3, (2, 1), padding=(1, 0), bias=False)
+        self.bn4 = nn.BatchNorm2d(output_size)
+
+
+class TSRN_TL(_PSNBase):
+    """Drop-in for ``model.tsrn.TSRN_TL`` (tsrn.py:153-247; ``--arch tpgsr``), eval forward: TSRN whose residual blocks take a
+    text-prior map -- the recogniser's (N, 37, 1, 26) probabilities through InfoGen (four ConvTranspose2d + BatchNorm + ReLU,
+    tsrn.py:280-304) and a bilinear stretch to the LR feature map.  forward(x, text_emb) -> sr (N, 4, 2H, 2W).
+    On the GPU the four transposed convolutions see a 1-pixel-high map, so only the middle kernel row acts: each is a 1 x 3
+    convolution (flipped taps, eval BatchNorm folded, ReLU epilogue) of the zero-stuffed row through the implicit-GEMM kernel."""
+
+    def __init__(self, scale_factor=2, width=128, height=32, STN=False, srb_nums=5, mask=True, hidden_units=32, word_vec_d=300,
+                 text_emb=37, out_text_channels=32):
+        super().__init__()
+        self._build_trunk(scale_factor, width, height, STN, srb_nums, mask, hidden_units, out_text_channels)
+        self.feature_enhancer = None
+        self.infoGen = _InfoGen(text_emb, out_text_channels)
+        self.emb_cls = text_emb
+        self._build_tail(srb_nums)
+
+    def _extra_pack(self, P):
+        ig = self.infoGen
+        for i in range(1, 5):
+            w = getattr(ig, "tconv%d" % i).weight                      # (Cin, Cout, 3, 3)
+            # H = 1 in, H = 1 out: only ky = 1 contributes; transposed conv along W = conv of the zero-stuffed row with flipped taps
+            wc = w[:, :, 1, :].flip(2).permute(1, 0, 2).unsqueeze(2).contiguous()       # (Cout, Cin, 1, 3)
+            cin = wc.shape[1]
+            P["ig%d" % i] = packing.pack_conv(wc, None, _bn(getattr(ig, "bn%d" % i)), cin_pad=(cin + 3) // 4 * 4)
+
+    def _info_gen(self, text_emb, H, W, P):
+        """(N, 37, 1, 26) -> NHWC (N, H, W, 32)"""
+        from .._abi import lib, check, dptr, stream
+        N = text_emb.shape[0]
+        x = text_emb.float().squeeze(2).transpose(1, 2)                # (N, 26, 37): layout plumbing
+        cp = (x.shape[2] + 3) // 4 * 4
+        cur = x.new_zeros(N, 1, x.shape[1], cp)
+        cur[:, 0, :, :x.shape[2]] = x
+        for i in range(1, 5):
+            cout = getattr(self.infoGen, "tconv%d" % i).weight.shape[1]
+            if i < 4:      # stride 2 along W, padding 1: zero-stuff to 2 Win - 1 columns, 1 x 3 conv with padding 1
+                up = cur.new_zeros(N, 1, 2 * cur.shape[2] - 1, cur.shape[3])
+                up[:, :, ::2] = cur
+                cur = ops.conv2d([up], *P["ig%d" % i], cout, (1, 3), pad=(0, 1), epi_act="relu")
+            else:          # stride 1 along W, padding 0: 1 x 3 conv with padding 2
+                cur = ops.conv2d([cur], *P["ig%d" % i], cout, (1, 3), pad=(0, 2), epi_act="relu")
+        out = torch.empty(N, H, W, cur.shape[3], device=cur.device)
+        check(lib.dpmn_tl_interp_f32(dptr(cur), dptr(out), N, cur.shape[2], cur.shape[3], H, W, stream()))
+        return out
+
+    def forward(self, x, text_emb=None):
+        self._check_mode()
+        P = self._trunk_pack()
+        if text_emb is None:
+            text_emb = torch.zeros(x.shape[0], self.emb_cls, 1, 26, device=x.device)
+        if text_emb.shape[0] != x.shape[0]:
+            raise ValueError("TSRN_TL: text_emb batch must match the image batch")
+        b1 = self._head(x, P)
+        tp = self._info_gen(text_emb.to(x.device), x.shape[2], x.shape[3], P)
+        return self._trunk(b1, P, tp)

@@ -108,13 +108,14 @@ def cpu_state_dicts(workload_name, seed=100):
     from .model.tsrn import TSRN
     from .model.tatt import TSRN_TL_TRANS
     from .model.tbsrn import TBSRN
+    from .model.tsrn import TSRN_TL
     arch, b1, b2, _ = CONFIGS[workload_name]
     n = b1 + b2
     dim, win, h, w = geom(workload_name)
     args = dict(img_size=[h, w], patch_size=[2] * n, embed_dim=[dim] * n, depths=[1] * n, num_heads=[[6]] * n, window_size=[list(win)] * n,
                 mlp_ratio=[4.] * n, drop_rate=[0.] * n, attn_drop_rate=[0.] * n, drop_path_rate=[0.] * n)
     kw = dict(scale_factor=2, width=w, height=h, STN=False, mask=True, srb_nums=5, hidden_units=32)
-    psn = {"tatt": TSRN_TL_TRANS, "tbsrn": TBSRN}.get(arch, TSRN)(**kw)
+    psn = {"tatt": TSRN_TL_TRANS, "tbsrn": TBSRN, "tpgsr": TSRN_TL}.get(arch, TSRN)(**kw)
     mods = [PGRM(iter=k, mode=False, hidden_size=3, **args) for k in range(b1)]
     mods += [PGRM(iter=k, mode=True, hidden_size=3, **args) for k in range(b1, b1 + b2)]
     mods.append(ComplementationModulationModule())

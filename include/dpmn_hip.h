@@ -240,6 +240,9 @@ int dpmn_tatt_encoder_layer_f32(const float* src, const float* pos, const float*
 /* softmax(q k^T / sqrt(d)) v over S<=32 keys, 4 heads (transformer_v2.py:821-824); pw (N,L,S) head-averaged or NULL */
 int dpmn_cross_attn_f32(const float* q, const float* k, const float* v, float* o, float* pw, int N, int L, int S, int E,
                         int nhead, dpmn_stream_t stream);
+/* TPGSR's TSRN_TL (tsrn.py:226-227): F.interpolate(InfoGen map (N, 1, Win, C) NHWC, (H, W), mode 'bilinear', align_corners=True)
+ * -> (N, H, W, C) NHWC, the text-prior map concatenated into every RecurrentResidualBlockTL */
+int dpmn_tl_interp_f32(const float* in, float* out, int N, int Win, int C, int H, int W, dpmn_stream_t stream);
 /* y = LayerNorm64(x + res); optional acc_out (+)= alpha * LayerNorm64'(y) (decoder.norm on intermediates,
  * transformer_v2.py:377-378, then mean over layers tatt.py:218) */
 int dpmn_add_layernorm64_f32(const float* x, const float* res, const float* g, const float* b, float* y,

@@ -15,6 +15,8 @@ def refine(sd_psn, sd_pgrms, sd_cmm, arch, b1, b2, images_lr, label_vecs, text_p
         psn, _ = otsrn.tatt_forward(sd_psn, images_lr, label_vecs)
     elif arch == "tbsrn":
         psn = otsrn.tbsrn_forward(sd_psn, images_lr)
+    elif arch == "tpgsr":
+        psn = otsrn.tsrn_tl_forward(sd_psn, images_lr, label_vecs)
     else:
         psn = otsrn.tsrn_forward(sd_psn, images_lr)
     cascade, br1 = psn, []

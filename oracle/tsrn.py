@@ -227,3 +227,28 @@ def tatt_forward(sd, x, text_emb, srb_nums=5):
     for i in range(srb_nums):
         f = srb(f, sd, "block%d." % (i + 2), tp_map)
     return _tail(b1, f, sd, srb_nums), prw
+
+
+# ---------------------------------------------------------------------------------- TPGSR (--arch tpgsr)
+def info_gen(sd, text_emb, pre="infoGen."):
+    """InfoGen.forward (tsrn.py:280-304): four ConvTranspose2d (k3, stride 2 / 2 / 2 / (2,1), padding 1 / 1 / 1 / (1,0), no bias) each
+    followed by eval BatchNorm and ReLU: (N, 37, 1, 26) -> (N, 32, 1, 203)."""
+    x = text_emb
+    for i, (st, pad) in enumerate(((2, 1), (2, 1), (2, 1), ((2, 1), (1, 0)))):
+        x = F.conv_transpose2d(x, sd[pre + "tconv%d.weight" % (i + 1)], None, stride=st, padding=pad)
+        x = F.relu(bn_eval(x, sd, pre + "bn%d." % (i + 1)))
+    return x
+
+
+def tsrn_tl_forward(sd, x, text_emb=None, srb_nums=5):
+    """TSRN_TL.forward in eval mode (tsrn.py:214-247): the text embedding goes through InfoGen, is stretched bilinearly
+    (align_corners=True) to the LR feature map and concatenated into every RecurrentResidualBlockTL (tsrn.py:262-277, the same
+    block as TATT's)."""
+    b1 = F.prelu(F.conv2d(x, sd["block1.0.weight"], sd["block1.0.bias"], padding=4), sd["block1.1.weight"])
+    if text_emb is None:
+        text_emb = torch.zeros(x.shape[0], 37, 1, 26)
+    tp = F.interpolate(info_gen(sd, text_emb), (x.shape[2], x.shape[3]), mode="bilinear", align_corners=True)
+    f = b1
+    for i in range(srb_nums):
+        f = srb(f, sd, "block%d." % (i + 2), tp)
+    return _tail(b1, f, sd, srb_nums)

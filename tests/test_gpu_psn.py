@@ -115,6 +115,59 @@ def test_tatt_batch48_vs_oracle(dev):
     assert_close(out, ref, 2e-4, 2e-4, "TATT B=48 vs oracle")
 
 
+def test_tpgsr_module_vs_reference_golden(dev):
+    """--arch tpgsr: TSRN_TL (tsrn.py:153-247) eval forward vs the imported reference class (tests/golden/tpgsr.npz)."""
+    from dpmn_amd.model.tsrn import TSRN_TL
+    g, m = _load(TSRN_TL, "tpgsr", 44, dev)
+    b = synth.synth_batch(2, seed=2)
+    with torch.no_grad():
+        out = m(b["images_lr"].to(dev), b["label_vecs"].to(dev))
+        P = m._trunk_pack()
+        info = m._info_gen(b["label_vecs"].to(dev), 1, 203, P)      # a 203-column target = the InfoGen map itself
+    assert_close(out, t(g["out"]), 2e-4, 2e-4, "TSRN_TL vs reference golden")
+    assert_close(info[:, 0, ::7, :].permute(0, 2, 1), t(g["info"]), 2e-5, 2e-5, "InfoGen map vs reference golden")
+
+
+def test_tpgsr_batch48_vs_oracle_and_native_trunk(dev):
+    from dpmn_amd.model import tsrn as tsrn_mod
+    from oracle import tsrn as ot
+    _, m = _load(tsrn_mod.TSRN_TL, "tpgsr", 45, dev)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    b = synth.synth_batch(48, seed=3)
+    ref = ot.tsrn_tl_forward(sd, b["images_lr"], b["label_vecs"])
+    x, lv = b["images_lr"].to(dev), b["label_vecs"].to(dev)
+    with torch.no_grad():
+        out = m(x, lv)
+        tsrn_mod.NATIVE_TRUNK = False
+        try:
+            composed = m(x, lv)
+        finally:
+            tsrn_mod.NATIVE_TRUNK = True
+    assert_close(out, ref, 2e-4, 2e-4, "TSRN_TL B=48 vs oracle")
+    assert torch.equal(out, composed), "native trunk differs from the composed ops"
+
+
+def test_tpgsr_stack_refine_vs_oracle(dev):
+    """`--arch tpgsr` through TextSR.refine (TSRN_TL PSN + 1+1 PGRM + CMM, B = 4) vs the oracle stack."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    from oracle import dpmn as odpmn
+    B = 4
+    sr = TextSR(workload.make_config(B), workload.make_args("tpgsr", 1, 1, B))
+    models, psn = sr.build_models()
+    for i, m in enumerate([psn] + models):
+        sd = m.state_dict()
+        synth.synth_fill_(sd, seed=140 + i)
+        m.load_state_dict(sd)
+        m.eval()
+    b = synth.synth_batch(B, seed=9)
+    pri = [torch.floor(synth.uniform("tpg_prior", (B, 2, 32, 128), 0.0, 256.0, 9))]
+    out = sr.refine(models, psn, b["images_lr"].to(dev), b["label_vecs"].to(dev), text_priors=[p.to(dev) for p in pri])
+    sds, sd_psn = workload.state_dicts_cpu(models, psn)
+    ref = odpmn.refine(sd_psn, sds[:-1], sds[-1], "tpgsr", 1, 1, b["images_lr"], b["label_vecs"], pri, 0.5)
+    assert_close(out, ref, 5e-4, 5e-4, "tpgsr stack")
+
+
 @pytest.mark.parametrize("arch,B", [("tsrn", 2), ("tsrn", 48), ("tatt", 3), ("tatt", 48)])
 def test_psn_native_trunk_equals_composed_ops(dev, arch, B):
     """dpmn_psn_trunk_f32 (SRBs + tail from one native call, csrc/psn_forward.hip) issues the launches of the per-op host path

@@ -25,6 +25,14 @@ def test_tatt_matches_reference():
     assert_close(prw[:, ::16], t(g["pr_weights"]), 1e-6, 1e-5, "tatt pr_weights")
 
 
+def test_tpgsr_matches_reference():
+    """--arch tpgsr: TSRN_TL eval forward and the InfoGen map (every 7th column) vs the imported reference class."""
+    g, sd = _sd("tpgsr", 44)
+    b = synth.synth_batch(2, seed=2)
+    assert_close(ot.info_gen(sd, b["label_vecs"])[:, :, 0, ::7], t(g["info"]), 2e-5, 1e-5, "InfoGen")
+    assert_close(ot.tsrn_tl_forward(sd, b["images_lr"], b["label_vecs"]), t(g["out"]), 2e-5, 1e-5, "tsrn_tl")
+
+
 def test_tbsrn_matches_reference():
     """a14: TBSRN eval forward + the first block's FeatureEnhancer output (every 8th position)."""
     g, sd = _sd("tbsrn", 43)

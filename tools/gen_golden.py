@@ -255,6 +255,19 @@ def gen_psn():
          manifest=manifest(sd), checksum=checksum(sd))
 
 
+def gen_tpgsr():
+    """--arch tpgsr: TSRN_TL (tsrn.py:153-247) in eval mode on the same inputs as the TATT fixture + the InfoGen map."""
+    from model import tsrn
+    b = synth.synth_batch(2, seed=2)
+    x, lv = b["images_lr"], b["label_vecs"]
+    m = tsrn.TSRN_TL(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32).eval()
+    sd = m.state_dict()
+    synth.synth_fill_(sd, seed=44)
+    sd = {k: v.clone() for k, v in sd.items()}
+    m.load_state_dict(sd)
+    save("tpgsr", out=m(x, lv), info=m.infoGen(lv)[:, :, 0, ::7].contiguous(), manifest=manifest(sd), checksum=checksum(sd))
+
+
 def gen_stack():
     """config 0 (BASELINE.json): TSRN PSN + 1+1 PGRM + CMM, B=4, eval forward of
     interfaces/super_resolution.py:370-449 re-stated around the IMPORTED reference modules.  toMask needs
@@ -457,7 +470,7 @@ def gen_visionlan():
          manifest=manifest(sd), checksum=checksum(sd))
 
 
-GENS = {"visionlan": gen_visionlan, "grads": gen_grads, "step": gen_step, "stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
+GENS = {"tpgsr": gen_tpgsr, "visionlan": gen_visionlan, "grads": gen_grads, "step": gen_step, "stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
 
 
 
