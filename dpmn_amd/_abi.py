@@ -118,6 +118,7 @@ SIGNATURES = {
     "dpmn_distill_backward_f32": (_i, [C.POINTER(DistillParams), C.POINTER(DistillGrads), fp, fp, fp, fp, fp, fp, fp, fp, fp, _sz, _i, _i, _i, fp]),
     "dpmn_conv2d_wgrad_unpack_multi_f32": (_i, [fp, fp, _i, _i, fp]),
     "dpmn_tl_interp_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_pointwise_wgrad_det_bytes": (_sz, [_i, _i]),
     "dpmn_reduce_defer_begin": (_i, []),
     "dpmn_reduce_defer_enable": (_i, [_i]),
     "dpmn_reduce_defer_push": (_i, [C.POINTER(TnPending)]),

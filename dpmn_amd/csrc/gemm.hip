@@ -503,6 +503,105 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
   epilogue<3, 2>(acc, m_blk + wm * 32, n_blk + wn * 48, M, N, ldy, y, e, nullptr, BN, n_blk);
 }
 
+
+// ---------------------------------------------------------------------------------- k-loop, 128 x 128 tiles (pointwise-conv weight gradient)
+// dW (M, N) = sum_b X_b (M, L) . Y_b (N, L)^T over the raw (B, Ch, L) views (pgrm.py:37: X = dz, Y = g, M = N = Ch = 384, L = 1024,
+// B = 48: 14.5 GFLOP, the largest single GEMM of the backward).  The 64 x 96 k-loop above ran it at 78 TFLOP/s; this is the same
+// pipeline (two named register sets, loads of step kt + 2 in flight during step kt) on the implicit-GEMM conv's 128 x 128 tile
+// (waves 2 x 2, 64 x 64 each: half the LDS operand reads per MFMA).  The reduction (b, s) is cut into `splits` contiguous ranges
+// of 32-wide chunks (a range may cross image boundaries: the chunk -> (image, offset) decode is per chunk); split z STORES its
+// tile at y + z * zstride, the caller adds the splits in order.  grid = (M / 128 * N / 128 * splits) workgroups, tile fastest within
+// an XCD's share as in k_gemm_kloop (XCD c takes the splits c, c + 8, ...: the 9 tiles of a split read the same operand slices).
+__global__ __launch_bounds__(256, 2) void k_gemm_kloop128(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                           int M, int N, int L, int nchunks, int splits, long bstride, long zstride) {
+  constexpr int BM = 128, BN = 128, BK = 32, LDK = BK + PAD;
+  __shared__ __attribute__((aligned(16))) float Xs[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Ws[2][BN * LDK];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_m = M / BM, tiles = tiles_m * (N / BN);
+  int lid = blockIdx.x, bz, t;
+  if ((splits & 7) == 0) { const int c = lid & 7, j = lid >> 3; const int zq = j / tiles; t = j - zq * tiles; bz = c + 8 * zq; }
+  else { bz = lid / tiles; t = lid - bz * tiles; }
+  const int m_blk = (t % tiles_m) * BM, n_blk = (t / tiles_m) * BN;
+  y += (size_t)bz * zstride;
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  float4 ax0, ax1, ax2, ax3, aw0, aw1, aw2, aw3, bx0, bx1, bx2, bx3, bw0, bw1, bw2, bw3;
+  const int cpi = L / BK;                                    // chunks per image
+#define K8_GLOAD(P, kt_)                                                                                \
+  do {                                                                                                  \
+    const int kb = (kt_) / cpi, kk = ((kt_) - kb * cpi) * BK + lcol;                                     \
+    const float* xb = x + (size_t)kb * bstride + (size_t)(m_blk + lrow) * L + kk;                        \
+    const float* wb = w + (size_t)kb * bstride + (size_t)(n_blk + lrow) * L + kk;                        \
+    P##x0 = *reinterpret_cast<const float4*>(xb);                                                        \
+    P##x1 = *reinterpret_cast<const float4*>(xb + (size_t)32 * L);                                       \
+    P##x2 = *reinterpret_cast<const float4*>(xb + (size_t)64 * L);                                       \
+    P##x3 = *reinterpret_cast<const float4*>(xb + (size_t)96 * L);                                       \
+    P##w0 = *reinterpret_cast<const float4*>(wb);                                                        \
+    P##w1 = *reinterpret_cast<const float4*>(wb + (size_t)32 * L);                                       \
+    P##w2 = *reinterpret_cast<const float4*>(wb + (size_t)64 * L);                                       \
+    P##w3 = *reinterpret_cast<const float4*>(wb + (size_t)96 * L);                                       \
+  } while (0)
+#define K8_SSTORE(P, buf)                                                                               \
+  do {                                                                                                  \
+    *reinterpret_cast<float4*>(&Xs[buf][lrow * LDK + lcol]) = P##x0;                                    \
+    *reinterpret_cast<float4*>(&Xs[buf][(lrow + 32) * LDK + lcol]) = P##x1;                             \
+    *reinterpret_cast<float4*>(&Xs[buf][(lrow + 64) * LDK + lcol]) = P##x2;                             \
+    *reinterpret_cast<float4*>(&Xs[buf][(lrow + 96) * LDK + lcol]) = P##x3;                             \
+    *reinterpret_cast<float4*>(&Ws[buf][lrow * LDK + lcol]) = P##w0;                                    \
+    *reinterpret_cast<float4*>(&Ws[buf][(lrow + 32) * LDK + lcol]) = P##w1;                             \
+    *reinterpret_cast<float4*>(&Ws[buf][(lrow + 64) * LDK + lcol]) = P##w2;                             \
+    *reinterpret_cast<float4*>(&Ws[buf][(lrow + 96) * LDK + lcol]) = P##w3;                             \
+  } while (0)
+  const int wm = wave & 1, wn = wave >> 1;
+  const int lr = lane & 15, kq = lane >> 4;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#define K8_MMA(buf)                                                                                     \
+  do {                                                                                                  \
+    const float* xa = &Xs[buf][(wm * 64 + lr) * LDK + kq * 4];                                          \
+    const float* wa = &Ws[buf][(wn * 64 + lr) * LDK + kq * 4];                                          \
+    _Pragma("unroll") for (int kc = 0; kc < BK; kc += 16) {                                             \
+      f32x4 xf[4], wf[4];                                                                               \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const f32x4*>(xa + j * 16 * LDK + kc); \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) wf[i] = *reinterpret_cast<const f32x4*>(wa + i * 16 * LDK + kc); \
+      _Pragma("unroll") for (int s4 = 0; s4 < 4; ++s4)                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(wf[i][s4], xf[j][s4], acc[i][j]); \
+    }                                                                                                   \
+  } while (0)
+  // split bz takes the chunks [kt0, nk): equal shares up to one chunk
+  const int kt0 = (int)((long)nchunks * bz / splits), nk = (int)((long)nchunks * (bz + 1) / splits);
+  if (kt0 < nk) {
+    K8_GLOAD(a, kt0);
+    K8_GLOAD(b, min(kt0 + 1, nk - 1));
+    K8_SSTORE(a, 0);
+    __syncthreads();
+    for (int kt = kt0; kt < nk; kt += 2) {
+      K8_GLOAD(a, min(kt + 2, nk - 1));
+      K8_MMA(0);
+      K8_SSTORE(b, 1);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      K8_GLOAD(b, min(kt + 3, nk - 1));
+      K8_MMA(1);
+      K8_SSTORE(a, 0);
+      __syncthreads();
+    }
+  }
+#undef K8_GLOAD
+#undef K8_SSTORE
+#undef K8_MMA
+  // lane holds y[m = .. + lr][n = .. + 4 kq + r]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<f32x4*>(y + (size_t)(m_blk + wm * 64 + j * 16 + lr) * N + n_blk + wn * 64 + i * 16 + kq * 4) = acc[i][j];
+}
+
 // ---------------------------------------------------------------------------------- batched NN
 // z[b][co][s] = sum_c w[co][c] * g[b][c][s] + bias[co]      (pointwise 1x1 conv, pgrm.py:37)
 // g, z are the raw (B, Ch, L) views of token buffers (quirk Q2).  Output is s-contiguous, so the
@@ -1402,12 +1501,37 @@ int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, 
   return DPMN_OK;
 }
 
-// the same without atomics: the 32 k splits store their (Ch, Ch) partial results in ws (32 * Ch * Ch floats), added in split order
+// the same without atomics: the k splits store their (Ch, Ch) partial results in ws, added in split order (dpmn_rows_reduce_f32).
+// Ch a multiple of 128, L of 32: 128 x 128 tiles with ~504 workgroups (k_gemm_kloop128: 56 splits for Ch = 384); otherwise the
+// 64 x 96 k-loop with 32 splits.  Workspace: dpmn_pointwise_wgrad_det_bytes(Ch, L).
+static int pw_wgrad_splits(int Ch, int L) {
+  static const int nt_on = getenv("DPMN_PW_WGRAD_128") ? atoi(getenv("DPMN_PW_WGRAD_128")) : 1;
+  if (!nt_on || Ch % 128 != 0 || L % 32 != 0) return 0;
+  const int tiles = (Ch / 128) * (Ch / 128);
+  int s = 504 / tiles;                 // just under the 512 resident workgroups (2 per CU)
+  s &= ~7;                             // a multiple of 8: the XCD-local order
+  return s >= 8 ? s : 0;
+}
+
+size_t dpmn_pointwise_wgrad_det_bytes(int Ch, int L) {
+  const int s = pw_wgrad_splits(Ch, L);
+  return (size_t)(s ? s : 32) * Ch * Ch * sizeof(float);
+}
+
 int dpmn_pointwise_wgrad_det_f32(const float* dz, const float* g, float* dw, int B, int Ch, int L, float* ws, size_t ws_bytes,
                                  dpmn_stream_t stream) {
   DPMN_REQUIRE(dz && g && dw && ws && L % 32 == 0 && Ch % 4 == 0, "pointwise_wgrad_det: bad arguments");
-  const int S = 32;
+  const int s128 = pw_wgrad_splits(Ch, L);
+  const int S = s128 ? s128 : 32;
   if ((size_t)S * Ch * Ch * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "pointwise_wgrad_det: workspace too small");
+  if (s128) {
+    const int nchunks = B * (L / 32);
+    ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * Ch * (double)Ch * B * L, 4.0 * (2.0 * B * Ch * (double)L + (double)Ch * Ch));
+    hipLaunchKernelGGL(k_gemm_kloop128, dim3((Ch / 128) * (Ch / 128) * S), dim3(256), 0, as_stream(stream), dz, g, ws, Ch, Ch, L, nchunks, S,
+                       (long)Ch * L, (long)Ch * Ch);
+    DPMN_CHECK_LAUNCH();
+    return dpmn_rows_reduce_f32(ws, dw, nullptr, Ch * Ch, 0, S, stream);
+  }
   EpiArgs e{nullptr, nullptr, nullptr, nullptr, ACT_NONE, 0.f, 0, (long)Ch * Ch};
   dim3 grid(cdiv(Ch, 64), cdiv(Ch, 96), S);
   hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, ws, Ch, Ch, Ch, B * L, e, L,

@@ -482,7 +482,7 @@ def backward(m, sv, dout, need_dx_kv=True):
         dg = ops.pointwise(dz.reshape(B, L, Ch), packing.transposed(wp), _zero_bias(Ch, dz.device)).reshape(M, Ch)
         # partial rows of the atomics-free pointwise / bias / depthwise-conv gradients: slices of the backward's arena
         if DET_SMALL:
-            ptr, nb = _ws(dz.device, 32 * Ch * Ch * 4)
+            ptr, nb = _ws(dz.device, lib.dpmn_pointwise_wgrad_det_bytes(Ch, L))
             check(lib.dpmn_pointwise_wgrad_det_f32(dptr(dz), dptr(s["g"]), dptr(gr[mlp.pointwise_conv.weight]), B, Ch, L, ptr, nb, stream()))
             _ws_done()
         else:

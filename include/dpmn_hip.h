@@ -483,6 +483,7 @@ int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, 
 /* atomics-free form: ws >= 32 * Ch * Ch floats (the k splits' partial results, added in split order) */
 int dpmn_pointwise_wgrad_det_f32(const float* dz, const float* g, float* dw, int B, int Ch, int L, float* ws, size_t ws_bytes,
                                  dpmn_stream_t stream);
+size_t dpmn_pointwise_wgrad_det_bytes(int Ch, int L);      /* workspace of the call above (its split count depends on Ch) */
 
 /* PGRM tail in training form: out = lrelu(c1) pixel-shuffled * weight_list_0 + sum_i residual_i * weight_list_i
  * (pgrm.py:560-565; residual 0 skipped, Q11) and its backward (dresiduals[i] may be NULL; dweight_list accumulated) */
