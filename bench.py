@@ -3,7 +3,9 @@
 
 A "step" = one pass of the hot path over one synthetic batch already resident in HBM:
 frozen TATT PSN -> 3 text-prior PGRMs -> 3 mask-prior PGRMs (toMask on the GPU) -> CMM -> alpha blend,
-fp32, per-GPU batch 48 (BASELINE.json configs[1]).  `--gpus N` runs N ranks, one per GPU, over RCCL: launched by the
+fp32, per-GPU batch 48 (BASELINE.json configs[1]).  The K timed steps are K independent batches; by default two of them are in
+flight (--pipeline 2, interfaces/super_resolution.py RefinePipeline: the single-stream PSN / CMM phases of one batch overlap the
+next batch's work) -- `value` is the whole-job throughput, `one_batch_at_a_time` the same step with one batch in flight.  `--gpus N` runs N ranks, one per GPU, over RCCL: launched by the
 driver under torch.distributed.run (WORLD_SIZE in the environment) or, when started as a plain `python bench.py --gpus N`,
 by re-executing itself under torch.distributed.run.  Every rank runs the same step on its own batch shard (weak
 scaling, no data-path collective in the forward path; `--mode train` adds the bucketed RCCL gradient exchange); the
@@ -55,6 +57,9 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the GEMM-shaped kernels: f32 (the reference's precision, the headline) or bf16 MFMA operands with fp32 "
                          "accumulation (BASELINE.json configs[2..4] name bf16; a separate line, never the headline)")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="fwd mode: batches in flight (interfaces/super_resolution.py RefinePipeline: batch i runs on lane i %% N, so the "
+                         "single-stream PSN / CMM phases of one batch overlap the next batch's work); 1 = one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="fwd mode: skip the `train` object (configs[2] step timed after the forward region)")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the `train` object")
@@ -208,12 +213,16 @@ def cpu_baseline(workload_name, n_img, budget_s=240, train=False):
     return rec
 
 
+PIPE_ON = [True]      # False while per-kernel durations are measured: batches in flight on several lanes overlap each other's kernels
+
+
 def set_branch_streams(on):
     """The two refinement branches of a step run on two HIP streams (interfaces/super_resolution.py).  Per-kernel durations are only
     meaningful when kernels do not overlap, so the family ranking and the per-family table are measured with the branches on ONE
     stream; the timed region always runs the product configuration (two streams)."""
     from dpmn_amd.interfaces import super_resolution as sr_mod
     prev = (sr_mod.BRANCH_STREAMS, sr_mod.TRAIN_BRANCH_STREAMS)
+    PIPE_ON[0] = bool(on)
     if not os.environ.get("DPMN_BRANCH_STREAMS") == "0":
         sr_mod.BRANCH_STREAMS = bool(on)
     if not os.environ.get("DPMN_TRAIN_BRANCH_STREAMS") == "0":
@@ -414,18 +423,34 @@ def main():
         B = inp["images_lr"].shape[0]
     if args.mode == "train":
         pass
-    elif args.prior == "visionlan":
-        prior_fn = workload.build_text_prior(sr, b1)
-
-        def step():
-            return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_prior_fn=prior_fn)
     else:
-        def step():
-            return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), text_priors=inp["text_priors"])
+        from dpmn_amd.interfaces.super_resolution import RefinePipeline
+        depth = max(1, args.pipeline)
+        pipe = RefinePipeline(sr, models, psn, depth) if depth > 1 else None
+        kw = dict(text_prior_fn=workload.build_text_prior(sr, b1)) if args.prior == "visionlan" else dict(text_priors=inp["text_priors"])
+
+        def step():     # every call is one more independent batch (the same synthetic one): `depth` of them are in flight
+            if pipe is not None and PIPE_ON[0]:
+                return pipe.submit(inp["images_lr"], inp.get("label_vecs"), **kw)
+            return sr.refine(models, psn, inp["images_lr"], inp.get("label_vecs"), **kw)
 
     profiling = rank == 0 and not args.graph and not args.no_kernel_profile
+    pipelined = args.mode == "fwd" and max(1, args.pipeline) > 1
     elapsed, live, kernels = timed_leg(step, args.steps, args.warmup, profiling, torch, dist, _abi,
-                                       unforked=UNFORKED_FAMILIES if args.mode == "fwd" else UNFORKED_FAMILIES_TRAIN)
+                                       unforked=() if pipelined else (UNFORKED_FAMILIES if args.mode == "fwd" else UNFORKED_FAMILIES_TRAIN))
+    latency_ms = None
+    if pipelined:       # the same step one batch at a time (what `ms_per_step` meant before round 4's pipeline): reported next to the throughput
+        PIPE_ON[0] = False
+        n_lat = max(4, args.steps // 2)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_lat):
+            step()
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - t0) / n_lat * 1e3
+        PIPE_ON[0] = True
     if rank == 0:
         what = "forward" if args.mode == "fwd" else "training step"
         line = {
@@ -439,12 +464,16 @@ def main():
                 args.workload, spec["text"],
                 ("forward-only" + (", in-loop VisionLAN + glyph-atlas text priors" if args.prior == "visionlan" else "")) if args.mode == "fwd" else "training step: ImageLoss+distill, backward, per-model clip 0.25, Adam"
                 + (", dropout/attn_drop/drop_path %g" % args.drop if args.drop else "")),
-                "per_gpu_batch": B, "global_batch": B * world, "ranks": world, "backend": (backend + (" (RCCL)" if backend == "nccl" else "") + (", collectives forced at world size 1 (DPMN_FORCE_DIST)" if world == 1 else "")) if dist.is_initialized() else None,
+                "per_gpu_batch": B, "global_batch": B * world, "ranks": world,
+                "batches_in_flight": (max(1, args.pipeline) if args.mode == "fwd" else 1), "backend": (backend + (" (RCCL)" if backend == "nccl" else "") + (", collectives forced at world size 1 (DPMN_FORCE_DIST)" if world == 1 else "")) if dist.is_initialized() else None,
                 "parallelism": ("dp%d (independent batch shards, no forward collective)" % world) if args.mode == "fwd" else
                                ("dp%d (coalesced gradient groups, RCCL %s overlapped with backward)" % (
                                    world, "reduce-scatter + sharded clip/Adam + all-gather" if trainer.zero1 else "all-reduce"))},
         }
         roof = roofline_of(live, args.steps, B, args.mode)
+        if latency_ms is not None:
+            line["one_batch_at_a_time"] = {"ms_per_step": round(latency_ms, 3), "images_per_s": round(world * B / latency_ms * 1e3, 2),
+                                           "what": "the same step with ONE batch in flight (--pipeline 1), timed after the region on rank 0"}
         line["roofline"] = roof
         line["kernels"] = kernels
     # the configs[2] training step, timed after the forward region in the same process (every rank takes part: the step holds

@@ -27,12 +27,58 @@ _SIDE_STREAMS = {}
 
 
 def side_streams(device):
-    """The two branch streams of a device, shared by every TextSR object of the process (per-stream workspaces and allocator pools
-    are then warmed once)."""
-    key = (device.type, device.index)
+    """The two branch streams that belong to the CURRENT stream of a device, shared by every TextSR object of the process (per-stream
+    workspaces and allocator pools are then warmed once).  One pair per main stream: batches that run concurrently on different
+    lanes (RefinePipeline) must not meet on a shared branch stream."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = (torch.cuda.Stream(device), torch.cuda.Stream(device))
     return _SIDE_STREAMS[key]
+
+
+class RefinePipeline:
+    """Throughput mode of `TextSR.refine` for a stream of INDEPENDENT batches (eval / test loops, serving): `depth` lanes, each a HIP
+    stream with its own pair of branch streams; batch i runs on lane i % depth.  A batch has two single-stream phases -- the frozen
+    PSN before the two branches fork and the CMM after they join -- whose launch-, ramp- and tail-bound kernels leave CUs idle; with
+    two batches in flight those phases overlap the other batch's work (measured at B = 48: 8.31 -> 7.72 ms per batch).  Results are
+    the same tensors `refine` returns (every module keeps one workspace per stream); a lane's work is ordered behind the caller's
+    current stream at submit time, and `out.record_stream` / `wait(out)` order the caller behind the lane.
+    Not for training: consecutive optimisation steps depend on each other."""
+
+    def __init__(self, sr, model_list, model_psn, depth=2):
+        assert depth >= 1
+        self.sr, self.models, self.psn = sr, model_list, model_psn
+        dev = next(model_list[-1].parameters()).device
+        self.lanes = [torch.cuda.Stream(dev) for _ in range(depth)]
+        self.events = [None] * depth
+        self.i = 0
+
+    def submit(self, images_lr, label_vecs=None, text_prior_fn=None, text_priors=None):
+        """Enqueue one batch; returns its output tensor (complete when the lane reaches it: `wait(out)` or `synchronize()`)."""
+        k = self.i % len(self.lanes)
+        self.i += 1
+        lane = self.lanes[k]
+        lane.wait_stream(torch.cuda.current_stream(lane.device))      # the inputs were produced on the caller's stream
+        with torch.cuda.stream(lane):
+            out = self.sr.refine(self.models, self.psn, images_lr, label_vecs, text_prior_fn=text_prior_fn, text_priors=text_priors)
+            ev = torch.cuda.Event()
+            ev.record(lane)
+        self.events[k] = ev
+        out._dpmn_ready = ev
+        return out
+
+    @staticmethod
+    def wait(out):
+        """Order the caller's current stream behind the batch that produced `out`."""
+        ev = getattr(out, "_dpmn_ready", None)
+        if ev is not None:
+            torch.cuda.current_stream(out.device).wait_event(ev)
+            out.record_stream(torch.cuda.current_stream(out.device))
+        return out
+
+    def synchronize(self):
+        for lane in self.lanes:
+            lane.synchronize()
 
 
 class TextSR(base.TextBase):

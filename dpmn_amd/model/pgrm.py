@@ -210,8 +210,8 @@ class PGRM(nn.Module):
         self.conv_before_upsample = nn.ModuleList([_Affine((pp, self.embed_dim, 3, 3), kind="conv"),
                                                    _Affine((pp, pp, 3, 3), kind="conv")])
         self._packed = None
-        self._ws = None
-        self._fold_key = None      # (workspace pointer, B, parameter versions) the workspace holds folded attention weights for
+        self._wss = {}             # stream -> workspace (concurrent batches on several lanes, interfaces/super_resolution.py RefinePipeline)
+        self._fold_key = None      # {stream: (workspace pointer, B, parameter versions)} the workspaces hold folded attention weights for
         self._pack = None          # train/optim.py Trainer.invalidate_packs() resets this after every optimizer step (raw-pointer updates)
 
     # ------------------------------------------------------------------ C-ABI weight table
@@ -269,16 +269,20 @@ class PGRM(nn.Module):
         res = [r.contiguous().float() for r in residual_list]
         w = self._weights()
         need = _abi.lib.dpmn_pgrm_workspace_bytes(C.byref(w), B)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != x_kv.device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=x_kv.device)
+        sid = torch.cuda.current_stream(x_kv.device).cuda_stream
+        ws = self._wss.get(sid)
+        if ws is None or ws.numel() < need or ws.device != x_kv.device:
+            ws = self._wss[sid] = torch.empty(need, dtype=torch.uint8, device=x_kv.device)
         out = torch.empty(B, self.hidden_size, self.img_size[0], self.img_size[1], device=x_kv.device)
         # the LayerNorm-folded attention weights in the workspace stay valid while nothing touched the parameters: torch-side
         # writes bump _version, the optimizer kernels (raw pointers) reset self._pack through Trainer.invalidate_packs()
         # (code that writes parameters through raw pointers outside Trainer.step must set module._pack = None itself)
-        fkey = (self._ws.data_ptr(), B, tuple((p.data_ptr(), p._version) for p in self.layers[0].parameters()))
-        w.reuse_folded = int(self._fold_key == fkey and self._pack is not None)
-        self._fold_key, self._pack = fkey, True
+        fkey = (ws.data_ptr(), B, tuple((p.data_ptr(), p._version) for p in self.layers[0].parameters()))
+        if self._pack is None or not isinstance(self._fold_key, dict):
+            self._fold_key = {}
+        w.reuse_folded = int(self._fold_key.get(sid) == fkey)
+        self._fold_key[sid], self._pack = fkey, True
         _abi.check(_abi.lib.dpmn_pgrm_forward_f32(C.byref(w), _abi.dptr(x_q), x_q.shape[1], _abi.dptr(x_kv),
-                                                  _abi.ptr_array(res), len(res), _abi.dptr(out), self._ws.data_ptr(),
-                                                  self._ws.numel(), B, _abi.stream()))
+                                                  _abi.ptr_array(res), len(res), _abi.dptr(out), ws.data_ptr(),
+                                                  ws.numel(), B, _abi.stream()))
         return out

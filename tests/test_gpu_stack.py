@@ -177,3 +177,28 @@ def test_stack_cfg4_stress_vs_oracle_small_batch():
     p, s = ops.psnr_ssim(out, inp["images_hr"])
     assert abs(float(p) - float(ocmm.psnr(ref, cpu["images_hr"]))) < 1e-3
     assert abs(float(s) - float(ocmm.ssim(ref, cpu["images_hr"]))) < 1e-3
+
+
+def test_refine_pipeline_two_lanes_equals_sequential():
+    """RefinePipeline (two batches in flight on two lanes, shared modules with one workspace per stream) returns bitwise the tensors
+    sequential refine() calls return, for a run of distinct batches, and an eval after it still does."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import RefinePipeline
+    dev = torch.device("cuda:0")
+    sr, models, psn, inp = workload.build("cfg1", batch=6)
+    batches = []
+    for i in range(5):
+        b = synth.synth_batch(6, seed=60 + i)
+        pri = [torch.floor(synth.uniform("pp%d_%d" % (i, k), (6, 2, 32, 128), 0.0, 256.0, 3)).to(dev) for k in range(3)]
+        batches.append((b["images_lr"].to(dev), b["label_vecs"].to(dev), pri))
+    seq = [sr.refine(models, psn, lr, lv, text_priors=pri).clone() for lr, lv, pri in batches]
+    torch.cuda.synchronize()
+    pipe = RefinePipeline(sr, models, psn, depth=2)
+    for rep in range(2):
+        outs = [pipe.submit(lr, lv, text_priors=pri) for lr, lv, pri in batches]
+        pipe.synchronize()
+        for i, (a, b) in enumerate(zip(outs, seq)):
+            assert torch.equal(a, b), "batch %d of pass %d differs from the sequential result: %g" % (i, rep, float((a - b).abs().max()))
+    got = RefinePipeline.wait(pipe.submit(*batches[0][:2], text_priors=batches[0][2]))
+    assert torch.equal(got + 0, seq[0])
+    assert torch.equal(sr.refine(models, psn, batches[1][0], batches[1][1], text_priors=batches[1][2]), seq[1])
