@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="fwd mode: batches in flight (interfaces/super_resolution.py RefinePipeline: batch i runs on lane i %% N, so the "
                          "single-stream PSN / CMM phases of one batch overlap the next batch's work); 1 = one batch at a time")
+    ap.add_argument("--no-psn-prefetch", action="store_true",
+                    help="train mode: run the frozen PSN inside the step instead of prefetching the next batch's PSN image during it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="fwd mode: skip the `train` object (configs[2] step timed after the forward region)")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the `train` object")
@@ -342,9 +344,18 @@ def build_train_step(args, workload, world, force_dist, dist, torch, drop):
     trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=world, zero1=args.zero1,
                       force_collectives=force_dist and dist.is_initialized())
 
+    state = {"h": None}
+
     def step():
-        return sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
-                             text_priors=inp["text_priors"])
+        # like TextSR.train: the frozen PSN's image of the NEXT batch (here: the same synthetic one) is computed on a lane stream of
+        # its own during this step (--no-psn-prefetch: inside the step, as before round 4)
+        if args.no_psn_prefetch:
+            return sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
+                                 text_priors=inp["text_priors"])
+        loss = sr.train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"], inp.get("label_vecs"),
+                             text_priors=inp["text_priors"], psn_out=state["h"], prefetch=(inp["images_lr"], inp.get("label_vecs")))
+        state["h"] = sr.psn_prefetched
+        return loss
     if args.graph and world == 1:
         run = sr.graphed_train_step(models, psn, distill, crit, trainer, inp["images_lr"], inp["images_hr"],
                                     inp.get("label_vecs"), inp["text_priors"])
@@ -371,6 +382,7 @@ def train_object(args, workload, world, rank, force_dist, dist, torch, _abi):
                "timed_seconds": round(elapsed, 4)}
         if drop == 0.0:
             out.update(rec)
+            out["psn_prefetch"] = not args.no_psn_prefetch
             out["what"] = "config 2 step on the same stack: forward, ImageLoss + distill, backward, per-model clip 0.25, Adam%s" % (
                 "" if world == 1 else ", RCCL gradient exchange (%s)" % ("reduce-scatter + sharded clip/Adam + all-gather" if trainer.zero1 else "all-reduce"))
             out["algorithmic_gflop_per_image"] = TRAIN_GFLOP_PER_IMAGE

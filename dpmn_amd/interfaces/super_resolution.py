@@ -259,22 +259,49 @@ class TextSR(base.TextBase):
         rand_offs = torch.tensor(np.random.rand(bs)).float().to(images_lr.device)
         return torch_rotate_img(images_lr, arc, rand_offs), torch_rotate_img(images_hr, arc, rand_offs)
 
+    def psn_forward(self, psn, images_lr, label_vecs=None):
+        """The frozen PSN's image (super_resolution.py:156-169): the arch decides the call signature."""
+        with torch.no_grad():
+            if self.args.arch in ('tsrn', 'tbsrn', 'tg'):
+                return psn(images_lr)
+            if self.args.arch == 'tpgsr':
+                return psn(images_lr, label_vecs)
+            return psn(images_lr, label_vecs)[0]
+
+    def prefetch_psn(self, psn, images_lr, label_vecs=None):
+        """The PSN image of the NEXT batch, computed on a lane stream of its own while the current step runs: the PSN is frozen
+        (super_resolution.py:56-59), so its output does not depend on the optimisation steps in between, and the step it overlaps
+        has single-stream phases (CMM forward / backward, optimizer) with idle CUs.  Returns a handle for train_step(psn_out=...)."""
+        dev = images_lr.device
+        lane = getattr(self, "_psn_lane", None)
+        if lane is None:
+            lane = self._psn_lane = torch.cuda.Stream(dev)
+        lane.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(lane):
+            out = self.psn_forward(psn, images_lr, label_vecs)
+            ev = torch.cuda.Event()
+            ev.record(lane)
+        return out, ev, images_lr.data_ptr()
+
     def train_step(self, models, psn, distill, crit, trainer, images_lr, images_hr, label_vecs=None, text_priors=None,
-                   text_prior_fn=None):
-        """One optimisation step = super_resolution.py:140-278 (loss sum / (b1+b2+1), per-model clip 0.25, Adam)."""
+                   text_prior_fn=None, psn_out=None, prefetch=None):
+        """One optimisation step = super_resolution.py:140-278 (loss sum / (b1+b2+1), per-model clip 0.25, Adam).
+        psn_out: the handle prefetch_psn returned for THIS batch (else the PSN runs here); prefetch = (images_lr, label_vecs) of the
+        next batch: its PSN image is started behind this step's branch forward and left in self.psn_prefetched."""
         b1, b2 = self.args.stu_iter_b1, self.args.stu_iter_b2
         share = self.args.sr_share
         trainer.zero_grad()
         if getattr(self.args, "rotate_train", 0):
             images_lr, images_hr = self.rotate_pair(images_lr, images_hr, self.args.rotate_train)
+            psn_out = None       # the prefetched image belongs to the unrotated batch
         hr3 = images_hr[:, :3, :]
-        with torch.no_grad():
-            if self.args.arch in ('tsrn', 'tbsrn', 'tg'):
-                images_lr_psn = psn(images_lr)
-            elif self.args.arch == 'tpgsr':
-                images_lr_psn = psn(images_lr, label_vecs)
-            else:
-                images_lr_psn, _ = psn(images_lr, label_vecs)
+        if psn_out is not None and psn_out[2] == images_lr.data_ptr():
+            images_lr_psn, ev, _ = psn_out
+            cur = torch.cuda.current_stream(images_lr.device)
+            cur.wait_event(ev)
+            images_lr_psn.record_stream(cur)
+        else:
+            images_lr_psn = self.psn_forward(psn, images_lr, label_vecs)
         br1, br2, part = [], [], [0, 0]
 
         def run_branch1():
@@ -318,6 +345,9 @@ class TextSR(base.TextBase):
         else:
             run_branch1()
             run_branch2()
+        self.psn_prefetched = None
+        if prefetch is not None and not getattr(self.args, "rotate_train", 0) and not torch.cuda.is_current_stream_capturing():
+            self.psn_prefetched = self.prefetch_psn(psn, *prefetch)      # overlaps the CMM forward, the backward and the optimizer
         loss = part[0] + part[1]
         feat = br1[-1]
         for k in range(b1 - 1, 0, -1):
@@ -435,12 +465,23 @@ class TextSR(base.TextBase):
         for epoch in range(n_epochs):
             if sampler is not None and hasattr(sampler, "set_epoch"):
                 sampler.set_epoch(epoch)
-            for data in passes(epoch):
+            def on_device(data):
                 hr, lr = data[0].to(self.device), data[1].to(self.device)
                 lv = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
                 if lv is None and self.args.arch in ('tatt', 'tpgsr'):
                     lv = self.label_vecs_from_crnn(lr)
-                loss = self.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_prior_fn=fn)
+                return hr, lr, lv
+            batches = iter(passes(epoch))
+            nxt = next(batches, None)
+            nxt = on_device(nxt) if nxt is not None else None
+            handle = None
+            while nxt is not None:
+                hr, lr, lv = nxt
+                nxt = next(batches, None)                  # one batch of look-ahead: its frozen-PSN image is computed during this step
+                nxt = on_device(nxt) if nxt is not None else None
+                loss = self.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_prior_fn=fn, psn_out=handle,
+                                       prefetch=None if nxt is None else (nxt[1], nxt[2]))
+                handle = self.psn_prefetched
                 it += 1
                 if it % cfg.displayInterval == 0 and rank == 0:
                     print('Epoch: [%d] iter %d | Loss: %f' % (epoch, it, float(loss)))

@@ -746,3 +746,35 @@ def test_training_step_is_bitwise_reproducible(dev):
     assert ndiff_g == 0 and ndiff_p == 0, (ndiff_g, ndiff_p)
     assert torch.equal(runs[0][3], runs[1][3]), "BatchNorm running statistics differ between runs"
     assert float(runs[0][0][2]) != float(runs[0][0][0])
+
+
+def test_psn_prefetch_equals_in_step_psn(dev):
+    """train_step(psn_out=..., prefetch=...): the frozen PSN's image of the next batch computed on a lane stream during the current
+    step gives bitwise the losses and parameters of the plain step over three different batches (TATT PSN, label vectors)."""
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces.super_resolution import TextSR
+    B, b1, b2 = 2, 1, 1
+    res = []
+    for use in (False, True):
+        sr_ = TextSR(workload.make_config(B), workload.make_args("tatt", b1, b2, B))
+        models, psn, distill, crit, trainer = sr_.build_training()
+        for i, m in enumerate([psn] + models + distill):
+            sd = m.state_dict()
+            synth.synth_fill_(sd, 900 + i)
+            with torch.no_grad():
+                for k, v in m.state_dict().items():
+                    v.copy_(sd[k])
+        psn.eval()
+        bs = [synth.synth_batch(B, seed=70 + i) for i in range(3)]
+        bs = [(b["images_lr"].to(dev), b["images_hr"].to(dev), b["label_vecs"].to(dev)) for b in bs]
+        pri = [torch.floor(synth.uniform("pf_tp", (B, 2, 32, 128), 0, 256, 4)).to(dev)]
+        losses, handle = [], None
+        for i, (lr, hr, lv) in enumerate(bs):
+            nxt = bs[i + 1] if use and i + 1 < len(bs) else None
+            losses.append(sr_.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_priors=pri, psn_out=handle,
+                                         prefetch=None if nxt is None else (nxt[0], nxt[2])).clone())
+            handle = sr_.psn_prefetched
+            assert (handle is not None) == (nxt is not None)
+        torch.cuda.synchronize()
+        res.append((torch.stack(losses), trainer.flat_p.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
