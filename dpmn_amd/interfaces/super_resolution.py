@@ -21,6 +21,7 @@ from ..utils import synth
 
 TRAIN_BRANCH_STREAMS = os.environ.get("DPMN_TRAIN_BRANCH_STREAMS", "1") != "0"
 BRANCH_STREAMS = os.environ.get("DPMN_BRANCH_STREAMS", "1") != "0"      # 0: branch 1 and branch 2 of refine() on one stream
+EVAL_PIPELINE = os.environ.get("DPMN_EVAL_PIPELINE", "1") != "0"        # 0: TextSR.eval / test run one batch at a time
 
 
 _SIDE_STREAMS = {}
@@ -207,6 +208,11 @@ class TextSR(base.TextBase):
         fn = text_prior_fn or self.default_text_prior()
         psnr, ssim, n = [], [], 0
         n_correct, n_labelled = 0, 0
+        # the batches of an evaluation pass are independent: two of them in flight (RefinePipeline); the metrics of a batch are
+        # queued on this stream behind the lane that produced it
+        # (not with the recogniser-driven prior: the VisionLAN mirrors keep one set of activations per module, not per stream)
+        pipe = RefinePipeline(self, model_list, model_psn, 2) if (EVAL_PIPELINE and self.device.type == "cuda" and not self.args.sr_share and
+                                                                   not hasattr(fn, "recognizers")) else None
         for data in val_loader:
             images_hr, images_lr = data[0].to(self.device), data[1].to(self.device)
             label_vecs = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
@@ -214,7 +220,10 @@ class TextSR(base.TextBase):
                 label_vecs = self.label_vecs_from_crnn(images_lr)
             if getattr(self.args, "rotate_test", 0):      # super_resolution.py:358-365 (angle range from rotate_train, as there)
                 images_lr, images_hr = self.rotate_pair(images_lr, images_hr, self.args.rotate_train)
-            sr = self.refine(model_list, model_psn, images_lr, label_vecs, fn)
+            if pipe is not None:
+                sr = RefinePipeline.wait(pipe.submit(images_lr, label_vecs, text_prior_fn=fn))
+            else:
+                sr = self.refine(model_list, model_psn, images_lr, label_vecs, fn)
             p, s = ops.psnr_ssim(sr, images_hr)
             psnr.append(p)
             ssim.append(s)
