@@ -24,7 +24,7 @@
 // Algorithmic work per unit: projections 2*64*96*96 = 1.18 MFLOP + attention 4*N*16 FLOP per (token, head); bytes: the unit's
 // 128 input rows (49 KB) + 8 KB of output -- the kernel is MFMA-bound (AI ~57 FLOP/B).
 #include <cstdlib>
-#include "common.h"
+#include "attn_fused.h"
 
 #ifndef FA_SKIP
 #define FA_SKIP 0
@@ -43,72 +43,10 @@ __device__ unsigned long long g_fa_t[512][9][8];
 #define FA_STAMP(u, k) do {} while (0)
 #endif
 
+using namespace dpmn_fa;
+
 namespace {
 
-constexpr float QSCALE = 0.25f * 1.44269504088896340736f;      // head_dim ** -0.5 * log2(e)
-constexpr float LOG2E = 1.44269504088896340736f;
-constexpr int FC = 96, FCG = 32, FD = 16, LDW = FC + 4, LDK = FCG + 4, TBLMAX = 15 * 15 * 2, TBLPAD = 452;
-constexpr int FOLD_STRIDE = FC * LDW + 2 * FC + TBLPAD;     // floats per group in the folded-weight workspace (a multiple of 4)
-
-struct FusedAttnArgs {
-  const float *tq, *tkv, *lnq_w, *lnq_b, *lnkv_w, *lnkv_b, *wq, *bq, *wkv, *bkv;
-  const float* table[3];
-  float *q_out, *kv_out;            // TRAIN: the projections, (B L, 96) and (B L, 192) in raster token order, saved for the backward
-  float p_drop, inv_keep;           // TRAIN: attn_drop (pgrm.py:248), counter-based masks (common.h drop_scale)
-  unsigned long long seed;
-  float* folded;                    // [3 groups][FOLD_STRIDE]: k_attn_fold's output, indexed by GROUP (not slot)
-  int ws[3], shift[3], gid[3];      // processing slot s (expensive windows first) -> group gid[s]
-  int cost[3];                      // measured cost of one unit of slot s (hundreds of cycles), for the static load balance
-  int nblk[2][3];                   // blocks per slot on an XCD holding ceil(B/8) ([0]) / floor(B/8) ([1]) images; nblk[.][0] = 0: contiguous ranges
-  float* out;
-  int B, H, W;
-  int lgW, lgS;                     // H, W (hence S = H*W/64 and every W / ws) are powers of two: index math is shifts and masks
-  float eps;
-};
-
-// source row of window-major token t of image b through the roll (pgrm.py:209-213); also the token's rolled-frame coordinates
-template <int WS>
-__device__ __forceinline__ unsigned source_row(int t, int H, int W, int lgW, int shift, int& hr, int& wcol) {
-  constexpr int N = WS * WS, LGWS = WS == 8 ? 3 : (WS == 4 ? 2 : 1);
-  const int lgnWc = lgW - LGWS;            // windows per row = W / WS
-  const int win = t / N, n = t % N;
-  hr = ((win >> lgnWc) << LGWS) + n / WS;
-  wcol = ((win & ((1 << lgnWc) - 1)) << LGWS) + n % WS;
-  return (unsigned)((((hr + shift) & (H - 1)) << lgW) + ((wcol + shift) & (W - 1)));   // token index inside the image
-}
-
-// mean and 1/sqrt(var + eps) of the 96-value row this lane shares with its 3 kq partners (two-pass, like nn.LayerNorm)
-__device__ __forceinline__ void row_stats(const f32x4 (&x)[6], float eps, float& mean, float& rstd) {
-  float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < 6; ++c) { s0 += x[c][0] + x[c][1]; s1 += x[c][2] + x[c][3]; }
-  float s = s0 + s1;
-  s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-  mean = s * (1.0f / FC);
-  float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;      // four independent chains
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    const float d0 = x[c][0] - mean, d1 = x[c][1] - mean, d2 = x[c][2] - mean, d3 = x[c][3] - mean;
-    q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
-  }
-  float q = (q0 + q1) + (q2 + q3);
-  q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-  rstd = 1.0f / sqrtf(q * (1.0f / FC) + eps);
-}
-
-template <int WS>
-__device__ __forceinline__ void load_rows(const FusedAttnArgs& a, int xcd, int i, int shift, int wave, int lr, int kq, f32x4 (&xq)[6],
-                                          f32x4 (&xkv)[6]) {
-  const int b = xcd + 8 * (i >> a.lgS), t = ((i & ((1 << a.lgS) - 1)) << 6) + 16 * wave + lr;
-  int hr, wc;
-  const size_t src = (size_t)b * a.H * a.W + source_row<WS>(t, a.H, a.W, a.lgW, shift, hr, wc);
-  const float* pq = a.tq + src * FC + 4 * kq;
-  const float* pk = a.tkv + src * FC + 4 * kq;
-#pragma unroll
-  for (int c = 0; c < 6; ++c) xq[c] = *reinterpret_cast<const f32x4*>(pq + 16 * c);
-#pragma unroll
-  for (int c = 0; c < 6; ++c) xkv[c] = *reinterpret_cast<const f32x4*>(pk + 16 * c);
-}
 
 // Folded projection weights, once per call (they used to be rebuilt by every block at every slot change: 15 k cycles of a
 // 120 k-cycle kernel).  LayerNorm's affine goes into the projection, y = W (gamma * xhat + beta) + b = (W diag gamma) xhat +
@@ -295,7 +233,7 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
 #pragma unroll
       for (int e = 0; e < 4; ++e) qa[h][e] = fmaf(qa[h][e], rqs, fmaf(nmq, cq[e], bq4[e]));
     }
-    if (TRAIN) {
+    if (TRAIN && a.q_out) {
       // training forward: q / k / v of this (token, group) go to HBM in raster token order, exactly the tensors the unfused
       // q / kv Linear layers produce (pgrm.py:188,194) -- the backward kernels read them; q without the folded softmax scale
       int hr_, wc_;
@@ -401,20 +339,6 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
   FA_STAMP(8, 6 + (slot == 2 ? 1 : 0));
 }
 
-// units of this XCD's list whose cumulative start cost is < c
-__device__ __forceinline__ int units_before(long c, int per, const int (&cs)[3]) {
-  long base = 0;
-  int n = 0;
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const long rem = c - base;
-    long k = rem <= 0 ? 0 : (rem + cs[s] - 1) / cs[s];
-    if (k > per) k = per;
-    n += (int)k;
-    base += (long)per * cs[s];
-  }
-  return n;
-}
 
 // Persistent: 2 blocks per CU, each walks a contiguous, cost-balanced range of the unit list of "its" XCD (blocks are
 // dealt to XCDs round-robin -- observed placement, used for speed only): images b with b % 8 == xcd, ordered slot-major, so
@@ -475,25 +399,27 @@ int dpmn_ln_qkv_window_attn_supported(int C, int n_groups, int heads_per_group, 
   return 1;
 }
 
-static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
-                             const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
-                             const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
-                             int n_groups, int heads_per_group, float* out, int B, int H, int W, int C, dpmn_stream_t stream,
-                             void* workspace, int refold, bool train, float* q_out, float* kv_out, float p_drop, unsigned long long seed) {
-  DPMN_REQUIRE(tq && tkv && lnq_w && lnq_b && lnkv_w && lnkv_b && wq && bq && wkv && bkv && bias_tables && windows && shifts && out,
+}  // extern "C" (reopened below)
+
+namespace dpmn_fa {
+
+void fa_fold(const FusedAttnArgs& a, hipStream_t st) { hipLaunchKernelGGL(k_attn_fold, dim3(FC + 1, 3), dim3(64), 0, st, a); }
+
+int fa_prepare(FusedAttnArgs& a, const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+               const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv, const float* bkv,
+               const float* const* bias_tables, const int* windows, const int* shifts, int n_groups, int heads_per_group, int B, int H,
+               int W, int C, void* workspace, const int* cost_ws, int blocks_per_cu, long* blocks_out) {
+  DPMN_REQUIRE(tq && tkv && lnq_w && lnq_b && lnkv_w && lnkv_b && wq && bq && wkv && bkv && bias_tables && windows && shifts,
                "ln_qkv_window_attn: null pointer");
   DPMN_REQUIRE(B > 0, "ln_qkv_window_attn: empty batch");
   DPMN_REQUIRE(!(H & (H - 1)) && !(W & (W - 1)) && H >= 8 && W >= 8, "ln_qkv_window_attn: token grid sides must be powers of two >= 8");
   DPMN_REQUIRE(C == FC && n_groups == 3 && heads_per_group == 2 && (H * W) % 64 == 0,
                "ln_qkv_window_attn: built for dim 96 = 3 groups x 2 heads x 16 (config 1/2/3); other shapes use the unfused kernels");
-  DPMN_REQUIRE(!train || (q_out && kv_out && p_drop >= 0.f && p_drop < 1.f), "ln_qkv_window_attn_train: q_out / kv_out missing or p_drop outside [0, 1)");
-  FusedAttnArgs a{};
-  a.q_out = q_out; a.kv_out = kv_out; a.p_drop = p_drop; a.inv_keep = train ? 1.0f / (1.0f - p_drop) : 1.0f; a.seed = seed;
   a.tq = tq; a.tkv = tkv; a.lnq_w = lnq_w; a.lnq_b = lnq_b; a.lnkv_w = lnkv_w; a.lnkv_b = lnkv_b;
-  a.wq = wq; a.bq = bq; a.wkv = wkv; a.bkv = bkv; a.out = out; a.B = B; a.H = H; a.W = W; a.eps = eps;
+  a.wq = wq; a.bq = bq; a.wkv = wkv; a.bkv = bkv; a.B = B; a.H = H; a.W = W; a.eps = eps;
   for (a.lgW = 0; (1 << a.lgW) < W; ++a.lgW) {}
   for (a.lgS = 0; (64 << a.lgS) < H * W; ++a.lgS) {}
-  int order[3] = {0, 1, 2};      // largest windows first: their units carry 30 % more MFMA work, the short ones fill the tail
+  int order[3] = {0, 1, 2};      // largest windows first: their units carry the most MFMA work, the short ones fill the tail
   for (int i = 0; i < 3; ++i)
     for (int j = i + 1; j < 3; ++j)
       if (windows[order[j]] > windows[order[i]]) { const int t_ = order[i]; order[i] = order[j]; order[j] = t_; }
@@ -503,24 +429,10 @@ static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq
                  "ln_qkv_window_attn: windows must be 2, 4 or 8 and divide the token grid (padding path of pgrm.py:200-207 not built)");
     DPMN_REQUIRE(bias_tables[g], "ln_qkv_window_attn: null bias table");
     a.gid[s] = g; a.ws[s] = ws; a.shift[s] = shifts[g]; a.table[s] = bias_tables[g];
-    a.cost[s] = ws == 8 ? 183 : (ws == 4 ? 151 : 146);   // cycles / 100 per unit at B = 48 (tools/fa_timeline.py, round 3)
+    a.cost[s] = ws == 8 ? cost_ws[0] : (ws == 4 ? cost_ws[1] : cost_ws[2]);
   }
-  const size_t smem = (size_t)(FOLD_STRIDE + 4 * 64 * LDK + 2 * 64) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    attr_set = true;
-  }
-  const long slabs = (long)B * (H * W / 64);
-  const double tokens = (double)B * H * W;
-  double attn = 0.0;
-  for (int g = 0; g < 3; ++g) attn += 4.0 * windows[g] * windows[g] * FD * 2 * tokens;
-  hipStream_t st = as_stream(stream);
   DPMN_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0, "ln_qkv_window_attn: workspace (dpmn_ln_qkv_window_attn_workspace_bytes, 16-byte aligned) missing");
   a.folded = static_cast<float*>(workspace);
-  if (refold) hipLaunchKernelGGL(k_attn_fold, dim3(FC + 1, 3), dim3(64), 0, st, a);
-  ProfScope prof(PT_ATTN_FUSED, st, 2.0 * tokens * FC * (3 * FC) + attn, 4.0 * (3.0 * tokens * FC + 3.0 * FC * FC));
   static int n_cu = 0;
   if (!n_cu) {
     int dev = 0;
@@ -528,8 +440,8 @@ static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return dpmn_set_error(DPMN_ERR_LAUNCH, "ln_qkv_window_attn: device query failed");
     n_cu = prop.multiProcessorCount > 8 ? prop.multiProcessorCount / 8 * 8 : 8;
   }
-  static const int bpc = getenv("DPMN_FA_BPC") ? atoi(getenv("DPMN_FA_BPC")) : 2;
-  long blocks = (long)bpc * n_cu;          // 2 resident blocks per CU (78 KB of LDS each); a multiple of 8
+  const long slabs = (long)B * (H * W / 64);
+  long blocks = (long)blocks_per_cu * n_cu;          // resident blocks per CU x CUs; a multiple of 8
   const long need = ((3 * slabs + 7) / 8) * 8;
   if (blocks > need) blocks = need;
   {
@@ -555,11 +467,49 @@ static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq
     static const int contiguous = getenv("DPMN_FA_CONTIG") ? atoi(getenv("DPMN_FA_CONTIG")) : 0;
     if (contiguous) a.nblk[0][0] = a.nblk[1][0] = 0;
   }
+  *blocks_out = blocks;
+  return DPMN_OK;
+}
+
+}  // namespace dpmn_fa
+
+static int fused_attn_launch(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                             const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                             const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                             int n_groups, int heads_per_group, float* out, int B, int H, int W, int C, dpmn_stream_t stream,
+                             void* workspace, int refold, bool train, float* q_out, float* kv_out, float p_drop, unsigned long long seed) {
+  DPMN_REQUIRE(out, "ln_qkv_window_attn: null pointer");
+  DPMN_REQUIRE(!train || (((q_out != nullptr) == (kv_out != nullptr)) && p_drop >= 0.f && p_drop < 1.f),
+               "ln_qkv_window_attn_train: q_out / kv_out must both be given or both be null (the recomputing backward needs neither), p_drop in [0, 1)");
+  FusedAttnArgs a{};
+  const int cost_ws[3] = {183, 151, 146};      // cycles / 100 per unit at B = 48 (tools/fa_timeline.py, round 3)
+  static const int bpc = getenv("DPMN_FA_BPC") ? atoi(getenv("DPMN_FA_BPC")) : 2;      // 2 resident blocks per CU (78 KB of LDS each)
+  long blocks = 0;
+  const int rc = fa_prepare(a, tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, eps, wq, bq, wkv, bkv, bias_tables, windows, shifts, n_groups,
+                            heads_per_group, B, H, W, C, workspace, cost_ws, bpc, &blocks);
+  if (rc != DPMN_OK) return rc;
+  a.q_out = q_out; a.kv_out = kv_out; a.p_drop = p_drop; a.inv_keep = train ? 1.0f / (1.0f - p_drop) : 1.0f; a.seed = seed;
+  a.out = out;
+  const size_t smem = (size_t)(FOLD_STRIDE + 4 * 64 * LDK + 2 * 64) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ln_qkv_window_attn<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    attr_set = true;
+  }
+  const double tokens = (double)B * H * W;
+  double attn = 0.0;
+  for (int g = 0; g < 3; ++g) attn += 4.0 * windows[g] * windows[g] * FD * 2 * tokens;
+  hipStream_t st = as_stream(stream);
+  if (refold) fa_fold(a, st);
+  ProfScope prof(PT_ATTN_FUSED, st, 2.0 * tokens * FC * (3 * FC) + attn, 4.0 * (3.0 * tokens * FC + 3.0 * FC * FC));
   if (train) hipLaunchKernelGGL(k_ln_qkv_window_attn<true>, dim3((unsigned)blocks), dim3(256), smem, st, a);
   else hipLaunchKernelGGL(k_ln_qkv_window_attn<false>, dim3((unsigned)blocks), dim3(256), smem, st, a);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
+
+extern "C" {
 
 int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
                                 const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,

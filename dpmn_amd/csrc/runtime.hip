@@ -17,7 +17,7 @@ namespace {
 const char* const kTagNames[PT_COUNT] = {
     "k_conv_igemm<128,128>", "k_conv_igemm<64,64>", "k_conv_igemm<128,16|32>", "k_conv_splitk_reduce", "k_conv_halo", "k_conv_halo_c4",
     "k_gemm_pw", "k_gemm_wstat", "k_gemm_kloop", "k_dwconv_gelu", "k_window_attn8_mfma", "k_window_attn<2|4|16>", "k_ln_qkv_window_attn",
-    "k_bigru", "k_mha32", "k_patch_embed_ln", "k_sk_gate", "k_tail_conv2", "k_mlp_dw_pw", "k_gemm_wstat<LN prologue>", "k_conv_igemm_sk"};
+    "k_bigru", "k_mha32", "k_patch_embed_ln", "k_sk_gate", "k_tail_conv2", "k_mlp_dw_pw", "k_gemm_wstat<LN prologue>", "k_conv_igemm_sk", "k_ln_qkv_window_attn_bwd"};
 struct Rec { int tag; double flops, bytes; };
 struct Prof {
   int cap = 0, count = 0;

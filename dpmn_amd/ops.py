@@ -85,18 +85,40 @@ def ln_qkv_window_attn(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, 
 
 
 def ln_qkv_window_attn_train(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, tables, windows, shifts, heads_per_group, H, W,
-                             p_drop=0.0, seed=0, eps=1e-5):
-    """Training forward of ln_qkv_window_attn: returns (cat, q, kv) -- q (B, L, C) and kv (B, L, 2C) are what the backward reads."""
+                             p_drop=0.0, seed=0, eps=1e-5, save_qkv=True, fold_out=None):
+    """Training forward of ln_qkv_window_attn: returns (cat, q, kv) -- q (B, L, C) and kv (B, L, 2C) are what the unfused backward
+    reads; save_qkv=False: (cat, None, None) for the recomputing backward (ln_qkv_window_attn_bwd).  fold_out: a list that receives
+    the folded-weight workspace of this call (the backward reuses it)."""
     B, L, Cd = tq.shape
     out = torch.empty_like(tq)
-    q = torch.empty_like(tq)
-    kv = torch.empty(B, L, 2 * Cd, device=tq.device)
+    q = torch.empty_like(tq) if save_qkv else None
+    kv = torch.empty(B, L, 2 * Cd, device=tq.device) if save_qkv else None
     ws = torch.empty(lib.dpmn_ln_qkv_window_attn_workspace_bytes() // 4, device=tq.device)
     check(lib.dpmn_ln_qkv_window_attn_train_f32(dptr(tq), dptr(tkv), dptr(lnq_w), dptr(lnq_b), dptr(lnkv_w), dptr(lnkv_b), float(eps),
                                                 dptr(wq), dptr(bq), dptr(wkv), dptr(bkv), _abi.ptr_array(tables), _abi.int_array(windows),
-                                                _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), dptr(q), dptr(kv),
+                                                _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), dptr(q, True), dptr(kv, True),
                                                 float(p_drop), int(seed), dptr(ws), B, H, W, Cd, stream()))
+    if fold_out is not None:
+        fold_out.append(ws)
     return out, q, kv
+
+
+def ln_qkv_window_attn_bwd(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, tables, windows, shifts, heads_per_group, H, W, dout,
+                           p_drop=0.0, seed=0, eps=1e-5, fold=None):
+    """Backward of ln_qkv_window_attn_train with q / k / v recomputed: returns (dq (B L, C), dkv (B L, 2C), [per-group partial rows of
+    the bias-table gradients, (rows, table.numel())]).  fold: the forward's folded-weight workspace (None: fold again)."""
+    B, L, Cd = tq.shape
+    dq = torch.empty(B * L, Cd, device=tq.device)
+    dkv = torch.empty(B * L, 2 * Cd, device=tq.device)
+    rows = lib.dpmn_ln_qkv_window_attn_bwd_part_rows(B, H, W)
+    parts = [torch.empty(rows, t.numel(), device=tq.device) for t in tables]
+    ws = fold if fold is not None else torch.empty(lib.dpmn_ln_qkv_window_attn_workspace_bytes() // 4, device=tq.device)
+    check(lib.dpmn_ln_qkv_window_attn_bwd_f32(dptr(tq), dptr(tkv), dptr(lnq_w), dptr(lnq_b), dptr(lnkv_w), dptr(lnkv_b), float(eps),
+                                              dptr(wq), dptr(bq), dptr(wkv), dptr(bkv), _abi.ptr_array(tables), _abi.int_array(windows),
+                                              _abi.int_array(shifts), len(windows), heads_per_group, dptr(dout), dptr(dq), dptr(dkv),
+                                              _abi.ptr_array(parts), float(p_drop), int(seed), dptr(ws), 0 if fold is not None else 1,
+                                              B, H, W, Cd, stream()))
+    return dq, dkv, parts
 
 
 def collate_u8(img_u8, with_mask):

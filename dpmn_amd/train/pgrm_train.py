@@ -319,6 +319,7 @@ class ConvSpec:
 
 FUSED_ATTN = os.environ.get("DPMN_ATTN_FUSED_TRAIN", "1") != "0"      # 0: LayerNorm / q / kv / window-attention as separate launches
 
+FUSED_ATTN_BWD = os.environ.get("DPMN_ATTN_FUSED_BWD", "1") != "0"    # 0: the training forward saves q / kv, the backward runs one attention kernel per window size
 FUSED_SKMLP = os.environ.get("DPMN_SKMLP_TRAIN", "1") != "0"          # 0: select / proj_head / LayerNorm2 / fc1 as separate launches
 
 N_SEEDS = 12     # [0] pos_drop(x_q) [1] pos_drop(x_kv); block bi at 2+5*bi: attn_drop, DropPath(attn), Mlp drop 1, Mlp drop 2, DropPath(mlp)
@@ -370,10 +371,15 @@ def forward(m, x_q, x_kv, residuals, drop=None):
             # norm1_q / norm1_kv + q / kv Linear + the three window sizes (+ attn_drop) in one launch; q and kv come back for the
             # backward, the normalised tokens are NOT kept (the backward recomputes them: two LayerNorm launches there instead of
             # two LayerNorm + two GEMM + three attention launches and 2 x 19 MB of saved activations here)
+            # (FUSED_ATTN_BWD: q / kv are not even written -- the backward kernel repeats the projection from tq / tkv and the folded
+            #  weights of this call, kept in s["fold"])
+            fold = []
             cat, q_, kv_ = ops.ln_qkv_window_attn_train(tq.reshape(B, L, Cd), tkv.reshape(B, L, Cd), blk.norm1_q.weight, blk.norm1_q.bias,
                                                         blk.norm1_kv.weight, blk.norm1_kv.bias, a.q.weight, a.q.bias, a.kv.weight, a.kv.bias,
-                                                        tables, win, shift, hpg, H, Wd, p_drop=pa, seed=sb[0])
-            s["q"], s["kv"], s["cat"] = q_.reshape(M, Cd), kv_.reshape(M, 2 * Cd), cat.reshape(M, Cd)
+                                                        tables, win, shift, hpg, H, Wd, p_drop=pa, seed=sb[0], save_qkv=not FUSED_ATTN_BWD,
+                                                        fold_out=fold)
+            s["cat"], s["fold"] = cat.reshape(M, Cd), fold[0]
+            s["q"], s["kv"] = (None, None) if FUSED_ATTN_BWD else (q_.reshape(M, Cd), kv_.reshape(M, 2 * Cd))
             s["nq"] = s["nkv"] = None
         else:
             s["nq"] = layernorm(tq, blk.norm1_q.weight, blk.norm1_q.bias)
@@ -537,10 +543,19 @@ def backward(m, sv, dout, need_dx_kv=True):
         gemm_tn(dfeats, s["cat"], gr[sk.proj.weight], gr[sk.proj.bias])
         dcat = ops.linear(dfeats, packing.transposed(sk.proj.weight), None, res1=dcat)
         # window attention
-        dq = torch.empty(M, Cd, device=dout.device)
-        dkv = torch.empty(M, 2 * Cd, device=dout.device)
         dtab = [gr[t] for t in s["tables"]]
-        if DET_SMALL:
+        if s["q"] is None:
+            # one launch: q / k / v recomputed, all three window sizes on MFMA, bias-table gradients as per-block partial rows
+            dq, dkv, tparts = ops.ln_qkv_window_attn_bwd(sv["tq"].reshape(B, L, Cd), s["tkv_in"].reshape(B, L, Cd), blk.norm1_q.weight,
+                                                         blk.norm1_q.bias, blk.norm1_kv.weight, blk.norm1_kv.bias, a.q.weight, a.q.bias,
+                                                         a.kv.weight, a.kv.bias, s["tables"], s["win"], s["shift"], hpg, H, Wd,
+                                                         dcat.reshape(B, L, Cd), p_drop=pa, seed=sb[0], fold=s["fold"])
+            for g_ in range(G):
+                defer_rows(tparts[g_], dtab[g_], None, s["tables"][g_].numel(), 0, tparts[g_].shape[0])
+        else:
+            dq = torch.empty(M, Cd, device=dout.device)
+            dkv = torch.empty(M, 2 * Cd, device=dout.device)
+        if s["q"] is not None and DET_SMALL:
             # bias-table gradients as per-block partial rows, added in block order by the backward's one reduce launch
             nrows = lib.dpmn_window_attn_bwd_part_rows(B, H, Wd)
             tparts = [torch.empty(nrows, t.numel(), device=dout.device) for t in s["tables"]]
@@ -550,7 +565,7 @@ def backward(m, sv, dout, need_dx_kv=True):
                                                         _abi.ptr_array(tparts), rows, B, H, Wd, Cd, float(pa), int(sb[0]), stream()))
             for g_ in range(G):
                 defer_rows(tparts[g_], dtab[g_], None, s["tables"][g_].numel(), 0, rows[g_])
-        else:
+        elif s["q"] is not None:
             check(lib.dpmn_window_attn_drop_bwd_f32(dptr(s["q"]), dptr(s["kv"]), _abi.ptr_array(s["tables"]), _abi.int_array(s["win"]),
                                                     _abi.int_array(s["shift"]), G, hpg, dptr(dcat), dptr(dq), dptr(dkv),
                                                     _abi.ptr_array(dtab), B, H, Wd, Cd, float(pa), int(sb[0]), stream()))

@@ -102,6 +102,24 @@ int dpmn_ln_qkv_window_attn_train_f32(const float* tq, const float* tkv, const f
                                       const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
                                       int n_groups, int heads_per_group, float* out, float* q_out, float* kv_out, float p_drop,
                                       unsigned long long seed, void* workspace, int B, int H, int W, int C, dpmn_stream_t stream);
+/* q_out and kv_out may both be NULL: the recomputing backward below needs neither.
+ *
+ * Backward of the fused kernel, recomputing q / k / v from the forward's inputs (WindowAttention.forward, pgrm.py:184-271, from the
+ * gradient of its concatenated head outputs back to the outputs of a.q / a.kv):
+ *   dout (B, L, C): gradient of `out` above (same window-major layout);  dq (B L, C), dkv (B L, 2 C): gradients of the q / kv
+ *   Linear outputs in raster token order (what the LayerNorm backward + weight-gradient GEMMs of norm1_* / a.q / a.kv consume);
+ *   dtable_parts[g]: (dpmn_ln_qkv_window_attn_bwd_part_rows(B, H, W), (2 ws_g - 1)^2 * heads_per_group) -- every block stores its
+ *   partial row of group g's relative-position-bias table gradient (rows of blocks without work for g are zero); the caller adds
+ *   the rows in row order (dpmn_tn_reduce_*), so the result is bitwise reproducible.
+ * p_drop / seed: the attn_drop masks of the forward call.  workspace / refold as in dpmn_ln_qkv_window_attn_f32 (refold = 0: the
+ * workspace still holds the forward's fold of these weights). */
+int dpmn_ln_qkv_window_attn_bwd_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                                    const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                                    const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                                    int n_groups, int heads_per_group, const float* dout, float* dq, float* dkv,
+                                    float* const* dtable_parts, float p_drop, unsigned long long seed, void* workspace, int refold,
+                                    int B, int H, int W, int C, dpmn_stream_t stream);
+int dpmn_ln_qkv_window_attn_bwd_part_rows(int B, int H, int W);
 
 /* Measurement hooks for bench.py's roofline objects (no reference counterpart: the reference has no profiler, SURVEY.md
  * section 5).  While armed, every launch of a kernel family whose tag bit is set in tag_mask -- issued directly or from

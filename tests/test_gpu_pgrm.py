@@ -426,3 +426,62 @@ def test_fused_attention_training_variant_vs_oracle_and_unfused(dev, B, shifts, 
     assert_close(cat, ref, 2e-5, 2e-5, "fused training forward, attn_drop %g" % p)
     unf = ops.window_attn(q_d, kv_d, tables, [2, 4, 8], shifts, 2, H, W, p_drop=p, seed=seed)
     assert_close(cat, unf, 2e-5, 2e-5, "fused vs unfused DROP kernels on the saved q / kv")
+
+
+@pytest.mark.parametrize("B,shifts", [(1, [0, 0, 0]), (3, [1, 2, 4]), (5, [0, 0, 0]), (48, [1, 2, 4])])
+def test_fused_attention_backward_vs_oracle(dev, B, shifts):
+    """The recomputing backward of the fused kernel (attn_fused_bwd.hip: one launch, q / k / v rebuilt from the token rows, all three
+    window sizes on MFMA) against torch autograd through the oracle's window_attention_core (pgrm.py:184-271) on the same
+    q = a.q(norm1_q(tq)), kv = a.kv(norm1_kv(tkv)): dq, dkv, the three bias-table gradients; and against the unfused backward
+    kernels with attention dropout on (same counter-based masks)."""
+    from dpmn_amd import ops, _abi
+    from dpmn_amd._abi import lib, check, dptr
+    from oracle import pgrm as o
+    from helpers import record, max_abs_err
+    H, W, C = 16, 64, 96
+    g = load_golden("wattn_shift0" if shifts[0] == 0 else "wattn_shifted")
+    sd = sd_from_manifest(g["manifest"], 21)
+    lnq_w, lnq_b = u("lnq_w", (C,), 0.5, 1.5), u("lnq_b", (C,), -0.5, 0.5)
+    lnk_w, lnk_b = u("lnk_w", (C,), 0.5, 1.5), u("lnk_b", (C,), -0.5, 0.5)
+    tq, tkv = u("f_tq%d" % B, (B, H * W, C), -2, 3), u("f_tkv%d" % B, (B, H * W, C), -3, 2)
+    dout = u("f_dout%d" % B, (B, H * W, C), -1, 1)
+    q = F.linear(F.layer_norm(tq, (C,), lnq_w, lnq_b), sd["q.weight"], sd["q.bias"]).requires_grad_(True)
+    kv = F.linear(F.layer_norm(tkv, (C,), lnk_w, lnk_b), sd["kv.weight"], sd["kv.bias"]).requires_grad_(True)
+    sdg = dict(sd)
+    for i in range(3):
+        sdg["relative_position_bias_table_%d" % i] = sd["relative_position_bias_table_%d" % i].clone().requires_grad_(True)
+    ref = o.window_attention_core(q, kv[..., :C], kv[..., C:], sdg, "", H, W, [2, 4, 8], shifts, 2)
+    (ref * dout).sum().backward()
+    d = cu(sd, dev)
+    tables = [d["relative_position_bias_table_%d" % i] for i in range(3)]
+    args = (tq.to(dev), tkv.to(dev), lnq_w.to(dev), lnq_b.to(dev), lnk_w.to(dev), lnk_b.to(dev), d["q.weight"], d["q.bias"], d["kv.weight"],
+            d["kv.bias"], tables, [2, 4, 8], shifts, 2, H, W)
+    dq, dkv, parts = ops.ln_qkv_window_attn_bwd(*args, dout.to(dev))
+    tol = 3e-5
+    for name, got, want in (("dq", dq, q.grad.reshape(-1, C)), ("dkv", dkv, kv.grad.reshape(-1, 2 * C))):
+        record("fused_attn_bwd_%s_B%d_shift%d" % (name, B, shifts[0]), "max|err| vs oracle autograd", max_abs_err(got, want), tol)
+        assert_close(got, want, tol, tol, "fused attention backward %s B=%d" % (name, B))
+    for i in range(3):
+        want = sdg["relative_position_bias_table_%d" % i].grad
+        got = parts[i].double().sum(0).float().reshape(want.shape)
+        ttol = 2e-5 * max(1.0, float(want.abs().max()))
+        record("fused_attn_bwd_table%d_B%d_shift%d" % (i, B, shifts[0]), "max|err| vs oracle autograd", max_abs_err(got, want), ttol)
+        assert_close(got, want, ttol, 1e-4, "fused attention backward table %d B=%d" % (i, B))
+    # twice the same launch: bitwise equal (no atomics reach HBM)
+    dq2, dkv2, parts2 = ops.ln_qkv_window_attn_bwd(*args, dout.to(dev))
+    assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2) and all(torch.equal(a_, b_) for a_, b_ in zip(parts, parts2))
+    # attention dropout: the unfused backward kernels on the saved q / kv of the training forward, same seed
+    pa, seed = 0.1, 1234
+    cat_s, q_s, kv_s = ops.ln_qkv_window_attn_train(*args, p_drop=pa, seed=seed)
+    cat_n, _, _ = ops.ln_qkv_window_attn_train(*args, p_drop=pa, seed=seed, save_qkv=False)
+    assert torch.equal(cat_s, cat_n)
+    dq_f, dkv_f, parts_f = ops.ln_qkv_window_attn_bwd(*args, dout.to(dev), p_drop=pa, seed=seed)
+    dq_u, dkv_u = torch.empty_like(dq_f), torch.empty_like(dkv_f)
+    dt_u = [torch.zeros_like(t_) for t_ in tables]
+    check(lib.dpmn_window_attn_drop_bwd_f32(dptr(q_s), dptr(kv_s), _abi.ptr_array(tables), _abi.int_array([2, 4, 8]), _abi.int_array(shifts), 3, 2,
+                                            dptr(dout.to(dev)), dptr(dq_u), dptr(dkv_u), _abi.ptr_array(dt_u), B, H, W, C, pa, seed, ops.stream()))
+    assert_close(dq_f, dq_u, tol, tol, "fused vs unfused attention backward with dropout: dq")
+    assert_close(dkv_f, dkv_u, tol, tol, "fused vs unfused attention backward with dropout: dkv")
+    for i in range(3):
+        got = parts_f[i].double().sum(0).float().reshape(dt_u[i].shape)
+        assert_close(got, dt_u[i], 2e-5 * max(1.0, float(dt_u[i].abs().max())), 1e-4, "fused vs unfused attention backward with dropout: table %d" % i)
