@@ -26,7 +26,26 @@ using namespace dpmn_fa;
 namespace {
 
 #ifndef FAB_SCHED
-#define FAB_SCHED 0
+#define FAB_SCHED 0       // 1: the forward's issue pattern for the projection (row statistics in the MFMA shadows)
+#endif
+#ifndef FAB_HB
+#define FAB_HB 1          // scheduling barrier between the two heads of a pass
+#endif
+#ifndef FAB_QB
+#define FAB_QB 1          // 8x8: scheduling barrier between the query tiles of pass B
+#endif
+#ifndef FAB_SKIP
+#define FAB_SKIP 0        // timing ablations only (tools/build_variants.sh): 1 no pass A, 2 no pass B, 4 no projection MFMAs
+#endif
+
+#ifndef FAB_TIMING
+#define FAB_TIMING 0      // tools/fab_timeline.py: s_memtime stamps of the loop phases of wave 0 of every block
+#endif
+#if FAB_TIMING
+__device__ unsigned long long g_fab_t[512][9][8];
+#define FAB_STAMP(u, k) do { if (blockIdx.x < 512 && threadIdx.x == 0 && (u) < 9) g_fab_t[blockIdx.x][(u)][(k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FAB_STAMP(u, k) do {} while (0)
 #endif
 
 constexpr int STAT = 2 * 3 * 64;           // [head][max, 1/sum, delta][token of the unit]
@@ -64,6 +83,7 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
   const int H = a.H, W = a.W, L = H * W, S = L / 64;
   const int g = a.gid[slot], shift = a.shift[slot];
 
+  FAB_STAMP(8, 0);
   f32x4 xq[6], xkv[6], gv[2];
   {
     const f32x4* src = reinterpret_cast<const f32x4*>(a.folded + (size_t)g * FOLD_STRIDE);
@@ -85,6 +105,7 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
     }
   }
   __syncthreads();
+  FAB_STAMP(8, 1);
 
   // ---- relative position bias of this lane's (query, key) pairs: the same in every unit
   // pass A (query = my token 16w + lr, keys 16kt + 4kq + r): exactly the forward's lookup
@@ -126,6 +147,7 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
     const int b = xcd + 8 * (i >> a.lgS), t0 = (i & (S - 1)) << 6, t = t0 + 16 * wave + lr;
     int hr_, wc_;
     const size_t src = (size_t)b * L + source_row<WS>(t, H, W, a.lgW, shift, hr_, wc_);
+    FAB_STAMP(i - first, 0);
     float mq, rq, mk, rk;
     row_stats(xq, a.eps, mq, rq);
     row_stats(xkv, a.eps, mk, rk);
@@ -135,6 +157,8 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
     f32x4 qa[2], ka[2], va[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) { qa[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; ka[h] = qa[h]; va[h] = qa[h]; }
+    if (FAB_SKIP & 4) { qa[0] = xq[0] + xq[2]; qa[1] = xq[1] + xq[3]; ka[0] = xkv[0] + xq[4]; ka[1] = xkv[1] + xq[5]; va[0] = xkv[2] + xkv[4]; va[1] = xkv[3] + xkv[5]; }
+    else
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       f32x4 wf[6];
@@ -161,7 +185,9 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
       }
     }
 #endif
+    FAB_STAMP(i - first, 1);
     unit_sync<WS>();                       // the previous unit's pass B is done with the tiles
+    FAB_STAMP(i - first, 2);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int f = 16 * h + 4 * kq;
@@ -201,6 +227,7 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
       load_dout<WS>(a, xcd, nx, g, wave, lr, kq, gv);
     }
     unit_sync<WS>();
+    FAB_STAMP(i - first, 3);
 
     // ================= pass A: my tile = queries
     unsigned maskedA = 0u;
@@ -213,9 +240,10 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
         for (int r = 0; r < 4; ++r)
           maskedA |= (reg_s[(WS == 8 ? 16 * kt : 16 * wave) + 4 * kq + r] != my_reg ? 1u : 0u) << (4 * kt + r);
     }
+    if (!(FAB_SKIP & 1))
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      __builtin_amdgcn_sched_barrier(0);   // one head at a time: interleaving the heads doubles the live score registers
+      if (FAB_HB) __builtin_amdgcn_sched_barrier(0);   // one head at a time: interleaving the heads doubles the live score registers
       f32x4 sacc[KT], dpt[KT];
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt) {
@@ -298,11 +326,13 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
       // q = Linear output, S = scale * q k + bias  =>  dq = scale * dS K
       *reinterpret_cast<f32x4*>(a.dq + src * FC + FCG * g + 16 * h + 4 * kq) = d0 * 0.25f;
     }
+    FAB_STAMP(i - first, 4);
     if (WS == 8) {
       load_rows<WS>(a, xcd, nx, shift, wave, lr, kq, xq, xkv);
       load_dout<WS>(a, xcd, nx, g, wave, lr, kq, gv);
     }
     unit_sync<WS>();                       // the statistics of all four tiles are in LDS
+    FAB_STAMP(i - first, 5);
 
     // ================= pass B: my tile = keys
     int4 qreg[KT] = {};
@@ -310,13 +340,14 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
 #pragma unroll
       for (int qt = 0; qt < KT; ++qt) qreg[qt] = *reinterpret_cast<const int4*>(reg_s + (WS == 8 ? 16 * qt : 16 * wave) + 4 * kq);
     }
+    if (!(FAB_SKIP & 2))
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      __builtin_amdgcn_sched_barrier(0);
+      if (FAB_HB) __builtin_amdgcn_sched_barrier(0);
       f32x4 dva0 = (f32x4){0.f, 0.f, 0.f, 0.f}, dka0 = dva0, dva1 = dva0, dka1 = dva0;
 #pragma unroll
       for (int qt = 0; qt < KT; ++qt) {
-        if (WS == 8) __builtin_amdgcn_sched_barrier(0);
+        if (WS == 8 && FAB_QB) __builtin_amdgcn_sched_barrier(0);
         const int q0 = WS == 8 ? 16 * qt : 16 * wave;
         const f32x4 qf = *reinterpret_cast<const f32x4*>(Qs + (q0 + lr) * LDK + 16 * h + 4 * kq);
         const f32x4 gf = *reinterpret_cast<const f32x4*>(Gs + (q0 + lr) * LDK + 16 * h + 4 * kq);
@@ -358,34 +389,50 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
       *reinterpret_cast<f32x4*>(dkp) = dka0 * (1.0f / LOG2E);
       *reinterpret_cast<f32x4*>(dkp + FC) = dva0;
     }
+    FAB_STAMP(i - first, 6);
   }
+  FAB_STAMP(8, 2);
 
-  // ---- this block's table-gradient partial row: the lanes' sums go through an LDS table (aliasing the tiles), one wave at a
-  // time so that the order of the additions is fixed
+  // ---- this block's table-gradient partial row.  Every lane parks its sums in LDS (aliasing the tiles, [value][thread]: no bank
+  // conflicts), then one thread per table entry adds the 64 (query, key) pairs of its offset in a fixed order -- no atomics, and
+  // nothing like the 64-way serialised LDS atomics of colliding lanes (measured: 40 k cycles per 8x8 block)
   __syncthreads();
-  float* dtb = Qs;
-  for (int i = tid; i < TBL * 2; i += 256) dtb[i] = 0.f;
+  float* park = Qs;                        // [KT * 8][256]
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      park[((4 * kt + r) * 2 + 0) * 256 + tid] = tacc[kt][r][0];
+      park[((4 * kt + r) * 2 + 1) * 256 + tid] = tacc[kt][r][1];
+    }
   __syncthreads();
   {
-    const int n = (16 * wave + lr) % N, iq = n / WS, jq = n % WS;
-    for (int wv = 0; wv < 4; ++wv) {
-      if (wave == wv && !(WS == 2 && kq != (lr >> 2))) {
+    // pair (query n_q, key n_k) of a window lives in:  8x8: wave n_q / 16, lane (lr = n_q % 16, kq = (n_k / 4) % 4), value (kt = n_k / 16,
+    // r = n_k % 4);  4x4: every wave (its tile = one window), lane (lr = n_q, kq = n_k / 4), r = n_k % 4;  2x2: every wave, each of
+    // the tile's 4 windows c: lane (lr = 4c + n_q, kq = c), r = n_k
+    constexpr int REP = WS == 8 ? 1 : (WS == 4 ? 4 : 16);
+    float* row = a.tpart[slot] + (size_t)blockIdx.x * (TBL * 2);
+    for (int e = tid; e < TBL * 2; e += 256) {
+      const int h = e & 1, ent = e >> 1, di = ent / (2 * WS - 1) - (WS - 1), dj = ent % (2 * WS - 1) - (WS - 1);
+      float sum = 0.f;
+      for (int nq = 0; nq < N; ++nq) {
+        const int iq = nq / WS, jq = nq % WS, ik = iq - di, jk = jq - dj;
+        if (ik < 0 || ik >= WS || jk < 0 || jk >= WS) continue;
+        const int nk = ik * WS + jk;
 #pragma unroll
-        for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int nk = ((WS == 8 ? 16 * kt : 16 * wave) + 4 * kq + r) % N, ik = nk / WS, jk = nk % WS;
-            const int idx = ((iq - ik + WS - 1) * (2 * WS - 1) + (jq - jk + WS - 1)) * 2;
-            atomicAdd(dtb + idx, tacc[kt][r][0]);
-            atomicAdd(dtb + idx + 1, tacc[kt][r][1]);
-          }
+        for (int rep = 0; rep < REP; ++rep) {
+          int thr, val;
+          if (WS == 8) { thr = 64 * (nq >> 4) + 16 * ((nk >> 2) & 3) + (nq & 15); val = 4 * (nk >> 4) + (nk & 3); }
+          else if (WS == 4) { thr = 64 * rep + 16 * (nk >> 2) + nq; val = nk & 3; }
+          else { thr = 64 * (rep >> 2) + 16 * (rep & 3) + 4 * (rep & 3) + nq; val = nk; }
+          sum += park[(val * 2 + h) * 256 + thr];
+        }
       }
-      __syncthreads();
+      row[e] = sum;
     }
   }
-  float* row = a.tpart[slot] + (size_t)blockIdx.x * (TBL * 2);
-  for (int i = tid; i < TBL * 2; i += 256) row[i] = dtb[i];
-  __syncthreads();                         // dtb aliases the next slot's tiles
+  __syncthreads();                         // park aliases the next slot's tiles
+  FAB_STAMP(8, 3);
 }
 
 __device__ __forceinline__ void zero_row(const FusedAttnArgs& a, int slot) {
@@ -512,5 +559,15 @@ int dpmn_ln_qkv_window_attn_bwd_f32(const float* tq, const float* tkv, const flo
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
+
+#if FAB_TIMING
+int dpmn_fab_timing_dump(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fab_t), sizeof(unsigned long long) * 512 * 9 * 8);
+}
+int dpmn_fab_timing_clear() {
+  static unsigned long long z[512 * 9 * 8];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fab_t), z, sizeof(z));
+}
+#endif
 
 }  // extern "C"

@@ -457,14 +457,14 @@ def test_fused_attention_backward_vs_oracle(dev, B, shifts):
     args = (tq.to(dev), tkv.to(dev), lnq_w.to(dev), lnq_b.to(dev), lnk_w.to(dev), lnk_b.to(dev), d["q.weight"], d["q.bias"], d["kv.weight"],
             d["kv.bias"], tables, [2, 4, 8], shifts, 2, H, W)
     dq, dkv, parts = ops.ln_qkv_window_attn_bwd(*args, dout.to(dev))
-    tol = 3e-5
+    tol = 7e-6       # measured 1.2e-6 .. 2.3e-6
     for name, got, want in (("dq", dq, q.grad.reshape(-1, C)), ("dkv", dkv, kv.grad.reshape(-1, 2 * C))):
         record("fused_attn_bwd_%s_B%d_shift%d" % (name, B, shifts[0]), "max|err| vs oracle autograd", max_abs_err(got, want), tol)
         assert_close(got, want, tol, tol, "fused attention backward %s B=%d" % (name, B))
     for i in range(3):
         want = sdg["relative_position_bias_table_%d" % i].grad
         got = parts[i].double().sum(0).float().reshape(want.shape)
-        ttol = 2e-5 * max(1.0, float(want.abs().max()))
+        ttol = 1.5e-6 * max(1.0, float(want.abs().max()))      # measured <= 5.4e-7 of the largest entry
         record("fused_attn_bwd_table%d_B%d_shift%d" % (i, B, shifts[0]), "max|err| vs oracle autograd", max_abs_err(got, want), ttol)
         assert_close(got, want, ttol, 1e-4, "fused attention backward table %d B=%d" % (i, B))
     # twice the same launch: bitwise equal (no atomics reach HBM)
@@ -480,8 +480,8 @@ def test_fused_attention_backward_vs_oracle(dev, B, shifts):
     dt_u = [torch.zeros_like(t_) for t_ in tables]
     check(lib.dpmn_window_attn_drop_bwd_f32(dptr(q_s), dptr(kv_s), _abi.ptr_array(tables), _abi.int_array([2, 4, 8]), _abi.int_array(shifts), 3, 2,
                                             dptr(dout.to(dev)), dptr(dq_u), dptr(dkv_u), _abi.ptr_array(dt_u), B, H, W, C, pa, seed, ops.stream()))
-    assert_close(dq_f, dq_u, tol, tol, "fused vs unfused attention backward with dropout: dq")
-    assert_close(dkv_f, dkv_u, tol, tol, "fused vs unfused attention backward with dropout: dkv")
+    assert_close(dq_f, dq_u, 3e-5, 3e-5, "fused vs unfused attention backward with dropout: dq")
+    assert_close(dkv_f, dkv_u, 3e-5, 3e-5, "fused vs unfused attention backward with dropout: dkv")
     for i in range(3):
         got = parts_f[i].double().sum(0).float().reshape(dt_u[i].shape)
         assert_close(got, dt_u[i], 2e-5 * max(1.0, float(dt_u[i].abs().max())), 1e-4, "fused vs unfused attention backward with dropout: table %d" % i)
