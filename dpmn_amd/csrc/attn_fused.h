@@ -42,13 +42,43 @@ __device__ __forceinline__ unsigned source_row(int t, int H, int W, int lgW, int
   return (unsigned)((((hr + shift) & (H - 1)) << lgW) + ((wcol + shift) & (W - 1)));   // token index inside the image
 }
 
+
+// xor-16 / xor-32 butterflies of the softmax / LayerNorm row reductions.  FA_PERMLANE: v_permlane16_swap / v_permlane32_swap (gfx950,
+// one VALU instruction) instead of ds_bpermute (a round trip through the LDS pipe); the sums and maxima are bitwise the same.
+#ifndef FA_PERMLANE
+#define FA_PERMLANE 1
+#endif
+typedef unsigned fa_u32x2 __attribute__((ext_vector_type(2)));
+// v (op) v[lane ^ D]: after the swap of a register with itself the two results hold (own, partner) in one half of every lane pair
+// and (partner, own) in the other -- the operation is commutative, so no select is needed
+template <int D>
+__device__ __forceinline__ float fa_xor_sum(float v) {
+#if FA_PERMLANE
+  const unsigned u = __float_as_uint(v);
+  const fa_u32x2 r = D == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false) : __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#else
+  return v + __shfl_xor(v, D, 64);
+#endif
+}
+template <int D>
+__device__ __forceinline__ float fa_xor_max(float v) {
+#if FA_PERMLANE
+  const unsigned u = __float_as_uint(v);
+  const fa_u32x2 r = D == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false) : __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+  return fmaxf(v, __shfl_xor(v, D, 64));
+#endif
+}
+
 // mean and 1/sqrt(var + eps) of the 96-value row this lane shares with its 3 kq partners (two-pass, like nn.LayerNorm)
 __device__ __forceinline__ void row_stats(const f32x4 (&x)[6], float eps, float& mean, float& rstd) {
   float s0 = 0.f, s1 = 0.f;
 #pragma unroll
   for (int c = 0; c < 6; ++c) { s0 += x[c][0] + x[c][1]; s1 += x[c][2] + x[c][3]; }
   float s = s0 + s1;
-  s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+  s = fa_xor_sum<16>(s); s = fa_xor_sum<32>(s);
   mean = s * (1.0f / FC);
   float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;      // four independent chains
 #pragma unroll
@@ -57,7 +87,7 @@ __device__ __forceinline__ void row_stats(const f32x4 (&x)[6], float eps, float&
     q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
   }
   float q = (q0 + q1) + (q2 + q3);
-  q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+  q = fa_xor_sum<16>(q); q = fa_xor_sum<32>(q);
   rstd = 1.0f / sqrtf(q * (1.0f / FC) + eps);
 }
 

@@ -292,8 +292,8 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
           sacc[kt][r] = v;
           mx = fmaxf(mx, v);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fa_xor_max<16>(mx);
+      mx = fa_xor_max<32>(mx);
       float den = 0.f;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
@@ -303,8 +303,8 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
           sacc[kt][r] = p;
           den += p;
         }
-      den += __shfl_xor(den, 16, 64);
-      den += __shfl_xor(den, 32, 64);
+      den = fa_xor_sum<16>(den);
+      den = fa_xor_sum<32>(den);
       const float inv = 1.0f / den;
       if (TRAIN) {
         // attn_drop on the probabilities (the denominator is over the undropped row); element index of (b, g, h, query t, key m)

@@ -268,8 +268,8 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
           sacc[kt][r] = v;
           mx = fmaxf(mx, v);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fa_xor_max<16>(mx);
+      mx = fa_xor_max<32>(mx);
       float den = 0.f;
 #pragma unroll
       for (int kt = 0; kt < KT; ++kt)
@@ -279,8 +279,8 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
           sacc[kt][r] = p;
           den += p;
         }
-      den += __shfl_xor(den, 16, 64);
-      den += __shfl_xor(den, 32, 64);
+      den = fa_xor_sum<16>(den);
+      den = fa_xor_sum<32>(den);
       const float inv = 1.0f / den;
       if (DROP) {                          // dP = (V dO^T) o M with the forward's masks (0 or 1 / (1 - p))
         const unsigned long long e0 = ((((unsigned long long)b * 3 + g) * 2 + h) * L + t) * N;
@@ -297,8 +297,8 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
       for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { sacc[kt][r] *= inv; dlt = fmaf(sacc[kt][r], dpt[kt][r], dlt); }
-      dlt += __shfl_xor(dlt, 16, 64);
-      dlt += __shfl_xor(dlt, 32, 64);
+      dlt = fa_xor_sum<16>(dlt);
+      dlt = fa_xor_sum<32>(dlt);
       if (kq == 0) {
         stat[(3 * h + 0) * 64 + 16 * wave + lr] = mx;
         stat[(3 * h + 1) * 64 + 16 * wave + lr] = inv;
