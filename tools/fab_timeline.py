@@ -28,17 +28,21 @@ lib.dpmn_fab_timing_dump(buf.ctypes.data_as(ctypes.c_void_p))
 t = buf.astype(np.int64)
 names = ["stats+proj", "sync(prev B)", "tiles->LDS+sync", "pass A", "sync", "pass B"]
 T0 = min(int(x) for x in t.reshape(-1) if x > 0)
-print("per block of XCD 0 (j = blockIdx / 8): units, [start, weights staged, loop end, flush end] in ticks (10 ns) since the first stamp")
-for j in range(64):
-    nu = int((t[8 * j][:8, 0] > 0).sum())
-    print("  j=%2d units %d %s" % (j, nu, [int(x) - T0 if x else None for x in t[8 * j][8][:4]]))
-for blk in (0, 8 * 10, 8 * 31, 8 * 33, 8 * 47, 8 * 50, 8 * 63):
+# per class of block (by unit count): median cycles of each phase, of a unit, of the staging, the loop and the flush; end times
+import collections
+cls = collections.defaultdict(list)
+for blk in range(512):
     tb = t[blk]
-    t0 = int(tb[8][0])
-    print("block %d:" % blk)
-    for uidx in range(8):
-        r = tb[uidx]
-        if r[0] == 0:
-            continue
-        d = [int(r[k + 1]) - int(r[k]) for k in range(6)]
-        print("  unit %d start %6d: " % (uidx, int(r[0]) - t0) + "  ".join("%s %d" % (n, x) for n, x in zip(names, d)) + "   total %d" % (int(r[6]) - int(r[0])))
+    nu = int((tb[:8, 0] > 0).sum())
+    if nu == 0 or tb[8][0] == 0:
+        continue
+    ph = [[int(tb[u_][k + 1]) - int(tb[u_][k]) for k in range(6)] for u_ in range(nu)]
+    cls[nu].append(dict(ph=np.median(np.array(ph), axis=0), unit=np.median([int(tb[u_][6]) - int(tb[u_][0]) for u_ in range(nu)]),
+                        stage=int(tb[8][1]) - int(tb[8][0]), loop=int(tb[8][2]) - int(tb[8][1]), flush=int(tb[8][3]) - int(tb[8][2]),
+                        start=int(tb[8][0]) - T0, end=int(tb[8][3]) - T0))
+for nu, rows in sorted(cls.items()):
+    med = lambda k: float(np.median([r[k] for r in rows]))
+    ph = np.median(np.array([r["ph"] for r in rows]), axis=0)
+    print("blocks with %d units (%d blocks): unit %.0f cycles [%s]; staging %.0f, loop %.0f, flush %.0f; start %.0f .. end median %.0f max %.0f" % (
+        nu, len(rows), med("unit"), "  ".join("%s %.0f" % (n, x) for n, x in zip(names, ph)), med("stage"), med("loop"), med("flush"), med("start"),
+        med("end"), max(r["end"] for r in rows)))
