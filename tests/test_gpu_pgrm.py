@@ -428,6 +428,41 @@ def test_fused_attention_training_variant_vs_oracle_and_unfused(dev, B, shifts, 
     assert_close(cat, unf, 2e-5, 2e-5, "fused vs unfused DROP kernels on the saved q / kv")
 
 
+@pytest.mark.parametrize("B,H,W,shifts", [(1, 8, 8, [1, 2, 0]), (2, 8, 16, [0, 0, 0]), (9, 8, 8, [1, 2, 4]), (2, 32, 32, [1, 2, 4])])
+def test_fused_attention_token_grids(dev, B, H, W, shifts):
+    """Other token grids of the fused attention kernels (forward + recomputing backward): one slab per image (8 x 8: the block ranges
+    span window sizes -- the contiguous schedule), fewer images than XCDs, a square 32 x 32 grid; against the oracle's attention core
+    and torch autograd through it."""
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    C = 96
+    g = load_golden("wattn_shifted")
+    sd = sd_from_manifest(g["manifest"], 21)
+    ln = [u("g_lnq_w", (C,), 0.5, 1.5), u("g_lnq_b", (C,), -0.5, 0.5), u("g_lnk_w", (C,), 0.5, 1.5), u("g_lnk_b", (C,), -0.5, 0.5)]
+    tq, tkv = u("g_tq%d%d" % (B, H), (B, H * W, C), -2, 3), u("g_tkv%d%d" % (B, H), (B, H * W, C), -3, 2)
+    dout = u("g_dout%d%d" % (B, H), (B, H * W, C), -1, 1)
+    assert ops.ln_qkv_window_attn_supported(C, [2, 4, 8], 2, H, W)
+    q = F.linear(F.layer_norm(tq, (C,), ln[0], ln[1]), sd["q.weight"], sd["q.bias"]).requires_grad_(True)
+    kv = F.linear(F.layer_norm(tkv, (C,), ln[2], ln[3]), sd["kv.weight"], sd["kv.bias"]).requires_grad_(True)
+    sdg = dict(sd)
+    for i in range(3):
+        sdg["relative_position_bias_table_%d" % i] = sd["relative_position_bias_table_%d" % i].clone().requires_grad_(True)
+    ref = o.window_attention_core(q, kv[..., :C], kv[..., C:], sdg, "", H, W, [2, 4, 8], shifts, 2)
+    (ref * dout).sum().backward()
+    d = cu(sd, dev)
+    tables = [d["relative_position_bias_table_%d" % i] for i in range(3)]
+    args = (tq.to(dev), tkv.to(dev), *[x.to(dev) for x in ln], d["q.weight"], d["q.bias"], d["kv.weight"], d["kv.bias"], tables, [2, 4, 8], shifts, 2, H, W)
+    got = ops.ln_qkv_window_attn(*args)
+    assert_close(got, ref.detach(), 1.5e-5, 1.5e-5, "fused attention forward on a %d x %d grid" % (H, W))
+    dq, dkv, parts = ops.ln_qkv_window_attn_bwd(*args, dout.to(dev))
+    assert_close(dq, q.grad.reshape(-1, C), 7e-6, 7e-6, "fused attention backward dq on a %d x %d grid" % (H, W))
+    assert_close(dkv, kv.grad.reshape(-1, 2 * C), 7e-6, 7e-6, "fused attention backward dkv on a %d x %d grid" % (H, W))
+    for i in range(3):
+        want = sdg["relative_position_bias_table_%d" % i].grad
+        got_t = parts[i].double().sum(0).float().reshape(want.shape)
+        assert_close(got_t, want, 1.5e-6 * max(1.0, float(want.abs().max())), 1e-4, "fused attention backward table %d on a %d x %d grid" % (i, H, W))
+
+
 @pytest.mark.parametrize("B,shifts", [(1, [0, 0, 0]), (3, [1, 2, 4]), (5, [0, 0, 0]), (48, [1, 2, 4])])
 def test_fused_attention_backward_vs_oracle(dev, B, shifts):
     """The recomputing backward of the fused kernel (attn_fused_bwd.hip: one launch, q / k / v rebuilt from the token rows, all three
