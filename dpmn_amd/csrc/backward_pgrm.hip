@@ -543,101 +543,163 @@ __device__ __forceinline__ float gelu_grad(float x) {
   const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
   return cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
-__global__ __launch_bounds__(256) void k_dwconv_bwd(const float* __restrict__ P, const float* __restrict__ dg,
+// GELU(x) and GELU'(x) from ONE erf evaluation: the Abramowitz-Stegun erf of common.h already holds exp(-x^2 / 2), which is the
+// Gaussian of the derivative too (gelu_erf + gelu_grad cost 3 v_exp + 2 v_rcp; this is 1 + 1).  g is bitwise gelu_erf(x).
+#ifndef DWB_SKIP
+#define DWB_SKIP 0        // timing ablations only: 1 no GELU arithmetic, 2 no stencil arithmetic
+#endif
+__device__ __forceinline__ void gelu_both(float x, float& g, float& d) {
+  if (DWB_SKIP & 1) { g = x; d = 1.0f; return; }
+  const float ax = fabsf(x * 0.70710678118654752440f);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float e = __expf(-ax * ax);
+  const float er = copysignf(fmaf(-poly, e, 1.0f), x);
+  g = 0.5f * x * (1.0f + er);
+  d = 0.5f * (1.0f + er) + x * 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_grad1(float x) {      // GELU'(x) alone, one v_exp
+  float g, d;
+  gelu_both(x, g, d);
+  return d;
+}
+// KEEP: in_gelu && out_gelu_bwd && gpre && 32 x 32 planes (the Mlp of the 16 x 64 -> 32 x 128 stacks) -- GELU'(P) of the lane's 16 pixels stays in registers from the load
+// loop to the store loop (same pixel -> lane map in both) instead of a second read of P and a second erf + exp per pixel
+template <bool KEEP>
+__global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* __restrict__ P, const float* __restrict__ dg,
                                                      const float* __restrict__ w, float* __restrict__ dP, float* __restrict__ dw,
                                                      float* __restrict__ db, int Ch, int r, long planes,
                                                      const float* __restrict__ gpre = nullptr, int in_gelu = 0, int out_gelu_bwd = 0,
                                                      float p_drop = 0.f, unsigned long long seed = 0ull, float* __restrict__ part = nullptr) {
   // p_drop > 0: the forward input was dropout(GELU(P)) -- the same mask on load, and again on dP before GELU'
   const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-  // per wave: P tile and dg tile, (r+2) rows x LD = r+8 floats, plane starting at column 4 (16-byte aligned rows, r % 4 == 0)
+  // per wave: P tile and dg tile, (r+2) rows x LD = r+8 floats, plane starting at column 4 (16-byte aligned rows, r % 4 == 0).
+  // The tiles are private to the wave (LDS operations of one wave execute in order): no block barrier anywhere.
+  // KEEP: persistent waves, plane = 4 blockIdx + wave, + 4 gridDim, ...; the next plane's 12 x 16 bytes per lane are in flight
+  // while this plane's GELUs and stencils run.  (One plane per wave, load -> compute -> store, ran the whole chip in lockstep --
+  // every block loading, then every block computing: the kernel took memory time PLUS arithmetic time, 47 + 21 + 26 us.)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long plane = (long)blockIdx.x * 4 + wave;
-  const bool valid = plane < planes;
-  const int c = valid ? (int)(plane % Ch) : 0;
-  const int LD = r + 8, r4 = r >> 2, TS = (r + 2) * LD;
+  const int LD = r + 8, r4 = r >> 2, TS = (r + 2) * LD, npix4 = r * r4;
   float* tp = sm + wave * 2 * TS;
   float* tg = tp + TS;
-  if (valid) {
+  long plane = (long)blockIdx.x * 4 + wave;
+  if (plane >= planes) return;
+  const long pstep = KEEP ? (long)gridDim.x * 4 : planes;
+  // zero halo of both tiles: written once, the interior stores never touch it
+  for (int i = lane; i < LD; i += 64) { tp[i] = 0.f; tp[(r + 1) * LD + i] = 0.f; tg[i] = 0.f; tg[(r + 1) * LD + i] = 0.f; }
+  for (int i = lane; i < r; i += 64) {
+    tp[(i + 1) * LD + 3] = 0.f; tp[(i + 1) * LD + 4 + r] = 0.f;
+    tg[(i + 1) * LD + 3] = 0.f; tg[(i + 1) * LD + 4 + r] = 0.f;
+  }
+  float4 pre_p[KEEP ? 4 : 1], pre_g[KEEP ? 4 : 1], pre_q[KEEP ? 4 : 1], gpk[KEEP ? 4 : 1];
+  auto prefetch = [&](long pl) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      // KEEP <=> r == 32 and gpre given: 256 float4 per plane = exactly 4 per lane, no predicate and no branch around a load
+      // (hipcc drains vmcnt(0) at the join of a branch that contains one)
+      const long o = pl * 1024 + 4 * (lane + 64 * it);
+      pre_p[KEEP ? it : 0] = *reinterpret_cast<const float4*>(P + o);
+      pre_g[KEEP ? it : 0] = *reinterpret_cast<const float4*>(dg + o);
+      pre_q[KEEP ? it : 0] = *reinterpret_cast<const float4*>(gpre + o);
+    }
+  };
+  if (KEEP) prefetch(plane);
+  for (; plane < planes; plane += pstep) {
+    const int c = (int)(plane % Ch);
     const float* ps = P + plane * r * r;
     const float* gs = dg + plane * r * r;
-    for (int i = lane; i < r * r4; i += 64) {
+    // the channel's 9 weights BEFORE the next plane's prefetch is issued: vmcnt retires in order, a load behind the prefetch
+    // would wait for all of it
+    float k[9], aw[9], ab = 0.f;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { k[i] = w[c * 9 + i]; aw[i] = 0.f; }
+#pragma unroll 4
+    for (int it = 0; it < (KEEP ? 4 : (npix4 + 63) / 64); ++it) {
+      const int i = lane + 64 * it;
+      if (!KEEP && i >= npix4) break;
       const int yy = i / r4, x4 = (i - yy * r4) * 4;
-      float4 pv = *reinterpret_cast<const float4*>(ps + yy * r + x4), gv = *reinterpret_cast<const float4*>(gs + yy * r + x4);
-      if (in_gelu) { pv.x = gelu_erf(pv.x); pv.y = gelu_erf(pv.y); pv.z = gelu_erf(pv.z); pv.w = gelu_erf(pv.w); }
+      float4 pv, gv;
+      if (KEEP) { pv = pre_p[it]; gv = pre_g[it]; }
+      else { pv = *reinterpret_cast<const float4*>(ps + yy * r + x4); gv = *reinterpret_cast<const float4*>(gs + yy * r + x4); }
+      if (KEEP) {
+        float4 d;
+        gelu_both(pv.x, pv.x, d.x); gelu_both(pv.y, pv.y, d.y); gelu_both(pv.z, pv.z, d.z); gelu_both(pv.w, pv.w, d.w);
+        gpk[it] = d;
+      } else if (in_gelu) { pv.x = gelu_erf(pv.x); pv.y = gelu_erf(pv.y); pv.z = gelu_erf(pv.z); pv.w = gelu_erf(pv.w); }
       if (p_drop > 0.f) {
         const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
         pv.x *= drop_scale(seed, e0, p_drop, inv_keep); pv.y *= drop_scale(seed, e0 + 1, p_drop, inv_keep);
         pv.z *= drop_scale(seed, e0 + 2, p_drop, inv_keep); pv.w *= drop_scale(seed, e0 + 3, p_drop, inv_keep);
       }
-      if (gpre) {
-        const float4 q = *reinterpret_cast<const float4*>(gpre + plane * r * r + yy * r + x4);
-        gv.x *= gelu_grad(q.x); gv.y *= gelu_grad(q.y); gv.z *= gelu_grad(q.z); gv.w *= gelu_grad(q.w);
+      if (KEEP || gpre) {
+        const float4 q = KEEP ? pre_q[it] : *reinterpret_cast<const float4*>(gpre + plane * r * r + yy * r + x4);
+        gv.x *= gelu_grad1(q.x); gv.y *= gelu_grad1(q.y); gv.z *= gelu_grad1(q.z); gv.w *= gelu_grad1(q.w);
       }
       *reinterpret_cast<float4*>(tp + (yy + 1) * LD + 4 + x4) = pv;
       *reinterpret_cast<float4*>(tg + (yy + 1) * LD + 4 + x4) = gv;
     }
-    for (int i = lane; i < LD; i += 64) { tp[i] = 0.f; tp[(r + 1) * LD + i] = 0.f; tg[i] = 0.f; tg[(r + 1) * LD + i] = 0.f; }
-    for (int i = lane; i < r; i += 64) {
-      tp[(i + 1) * LD + 3] = 0.f; tp[(i + 1) * LD + 4 + r] = 0.f;
-      tg[(i + 1) * LD + 3] = 0.f; tg[(i + 1) * LD + 4 + r] = 0.f;
-    }
-  }
-  __syncthreads();
-  if (!valid) return;
-  float k[9], aw[9], ab = 0.f;
+    if (KEEP) prefetch(plane + pstep < planes ? plane + pstep : plane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    float* dst = dP + plane * r * r;
+#pragma unroll 4
+    for (int it = 0; it < (KEEP ? 4 : (npix4 + 63) / 64); ++it) {
+      const int i = lane + 64 * it;
+      if (!KEEP && i >= npix4) break;
+      const int yy = i / r4, x4 = (i - yy * r4) * 4;
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      const float4 gc = *reinterpret_cast<const float4*>(tg + (yy + 1) * LD + 4 + x4);     // dg at the 4 output pixels
+      if (DWB_SKIP & 2) { a[0] = gc.x; a[1] = gc.y; a[2] = gc.z; a[3] = gc.w; aw[0] += gc.x; }
+      else
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { k[i] = w[c * 9 + i]; aw[i] = 0.f; }
-  float* dst = dP + plane * r * r;
-  for (int i = lane; i < r * r4; i += 64) {
-    const int yy = i / r4, x4 = (i - yy * r4) * 4;
-    float a[4] = {0.f, 0.f, 0.f, 0.f};
-    const float4 gc = *reinterpret_cast<const float4*>(tg + (yy + 1) * LD + 4 + x4);     // dg at the 4 output pixels
+      for (int ky = 0; ky < 3; ++ky) {
+        // dP[y][x] = sum_k dg[y - ky + 1][x - kx + 1] w[ky][kx] : dg row (yy + 2 - ky) of the halo tile, columns x4 - 1 .. x4 + 4
+        const float* pg = tg + (yy + 2 - ky) * LD + 4 + x4;
+        const float4 gm = *reinterpret_cast<const float4*>(pg);
+        const float gl = pg[-1], gr = pg[4];
+        const float k0 = k[ky * 3], k1 = k[ky * 3 + 1], k2 = k[ky * 3 + 2];
+        a[0] += k0 * gm.y + k1 * gm.x + k2 * gl;
+        a[1] += k0 * gm.z + k1 * gm.y + k2 * gm.x;
+        a[2] += k0 * gm.w + k1 * gm.z + k2 * gm.y;
+        a[3] += k0 * gr + k1 * gm.w + k2 * gm.z;
+        // dW[ky][kx] += dg[y][x] P[y + ky - 1][x + kx - 1] : P row (yy + ky) of the halo tile
+        const float* pp = tp + (yy + ky) * LD + 4 + x4;
+        const float4 pm = *reinterpret_cast<const float4*>(pp);
+        const float pl = pp[-1], pr = pp[4];
+        aw[ky * 3] += gc.x * pl + gc.y * pm.x + gc.z * pm.y + gc.w * pm.z;
+        aw[ky * 3 + 1] += gc.x * pm.x + gc.y * pm.y + gc.z * pm.z + gc.w * pm.w;
+        aw[ky * 3 + 2] += gc.x * pm.y + gc.y * pm.z + gc.z * pm.w + gc.w * pr;
+      }
+      ab += (gc.x + gc.y) + (gc.z + gc.w);
+      if (p_drop > 0.f) {
+        const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      // dP[y][x] = sum_k dg[y - ky + 1][x - kx + 1] w[ky][kx] : dg row (yy + 2 - ky) of the halo tile, columns x4 - 1 .. x4 + 4
-      const float* pg = tg + (yy + 2 - ky) * LD + 4 + x4;
-      const float4 gm = *reinterpret_cast<const float4*>(pg);
-      const float gl = pg[-1], gr = pg[4];
-      const float k0 = k[ky * 3], k1 = k[ky * 3 + 1], k2 = k[ky * 3 + 2];
-      a[0] += k0 * gm.y + k1 * gm.x + k2 * gl;
-      a[1] += k0 * gm.z + k1 * gm.y + k2 * gm.x;
-      a[2] += k0 * gm.w + k1 * gm.z + k2 * gm.y;
-      a[3] += k0 * gr + k1 * gm.w + k2 * gm.z;
-      // dW[ky][kx] += dg[y][x] P[y + ky - 1][x + kx - 1] : P row (yy + ky) of the halo tile
-      const float* pp = tp + (yy + ky) * LD + 4 + x4;
-      const float4 pm = *reinterpret_cast<const float4*>(pp);
-      const float pl = pp[-1], pr = pp[4];
-      aw[ky * 3] += gc.x * pl + gc.y * pm.x + gc.z * pm.y + gc.w * pm.z;
-      aw[ky * 3 + 1] += gc.x * pm.x + gc.y * pm.y + gc.z * pm.z + gc.w * pm.w;
-      aw[ky * 3 + 2] += gc.x * pm.y + gc.y * pm.z + gc.z * pm.w + gc.w * pr;
+        for (int q = 0; q < 4; ++q) a[q] *= drop_scale(seed, e0 + q, p_drop, inv_keep);
+      }
+      if (KEEP) {
+        const float4 d = gpk[it];
+        a[0] *= d.x; a[1] *= d.y; a[2] *= d.z; a[3] *= d.w;
+      } else if (out_gelu_bwd) {
+        const float4 q = *reinterpret_cast<const float4*>(P + plane * r * r + yy * r + x4);
+        a[0] *= gelu_grad1(q.x); a[1] *= gelu_grad1(q.y); a[2] *= gelu_grad1(q.z); a[3] *= gelu_grad1(q.w);
+      }
+      *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
     }
-    ab += (gc.x + gc.y) + (gc.z + gc.w);
-    if (p_drop > 0.f) {
-      const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) a[q] *= drop_scale(seed, e0 + q, p_drop, inv_keep);
+    for (int i = 0; i < 9; ++i) {
+      const float s = wave_sum(aw[i]);
+      if (lane == 0) {
+        // part: image b's row [Ch * 9 weight sums | Ch bias sums], added over the images in order by dpmn_rows_reduce_f32 (no atomics)
+        if (part) part[(plane / Ch) * (long)(Ch * 10) + c * 9 + i] = s;
+        else atomicAdd(dw + c * 9 + i, s);
+      }
     }
-    if (out_gelu_bwd) {
-      const float4 q = *reinterpret_cast<const float4*>(P + plane * r * r + yy * r + x4);
-      a[0] *= gelu_grad(q.x); a[1] *= gelu_grad(q.y); a[2] *= gelu_grad(q.z); a[3] *= gelu_grad(q.w);
-    }
-    *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
-  }
-#pragma unroll
-  for (int i = 0; i < 9; ++i) {
-    const float s = wave_sum(aw[i]);
+    ab = wave_sum(ab);
     if (lane == 0) {
-      // part: image b's row [Ch * 9 weight sums | Ch bias sums], added over the images in order by dpmn_rows_reduce_f32 (no atomics)
-      if (part) part[(plane / Ch) * (long)(Ch * 10) + c * 9 + i] = s;
-      else atomicAdd(dw + c * 9 + i, s);
+      if (part) part[(plane / Ch) * (long)(Ch * 10) + Ch * 9 + c] = ab;
+      else atomicAdd(db + c, ab);
     }
-  }
-  ab = wave_sum(ab);
-  if (lane == 0) {
-    if (part) part[(plane / Ch) * (long)(Ch * 10) + Ch * 9 + c] = ab;
-    else atomicAdd(db + c, ab);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next plane's tile stores come after this plane's reads
   }
 }
 
@@ -1086,13 +1148,26 @@ int dpmn_sk_feats_grad_f32(const float* dout, const float* feats, const float* d
   return DPMN_OK;
 }
 
+// KEEP variant: persistent, 2 blocks per CU (256 registers per wave for the prefetch), never more blocks than planes / 4
+static long dwconv_bwd_grid(long planes) {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  static const int bpc = getenv("DPMN_DWB_BPC") ? atoi(getenv("DPMN_DWB_BPC")) : 2;
+  const long want = (long)bpc * n_cu, need = (planes + 3) / 4;
+  return want < need ? want : need;
+}
+
 int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, float* dP, float* dw, float* db, int B, int Ch, int r,
                            dpmn_stream_t stream) {
   DPMN_REQUIRE(P && dg && w && dP && dw && db && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_bwd: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -1105,8 +1180,11 @@ int dpmn_dwconv3x3_bwd_fused_f32(const float* P, const float* dg, const float* g
   DPMN_REQUIRE(!out_gelu_bwd || in_gelu, "dwconv_bwd_fused: out_gelu_bwd needs P to be the pre-activation (in_gelu)");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+  const bool keep = in_gelu && out_gelu_bwd && gpre && r == 32;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (keep) hipLaunchKernelGGL(k_dwconv_bwd<true>, dim3((unsigned)dwconv_bwd_grid(planes)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+                     planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed);
+  else hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -1121,8 +1199,11 @@ int dpmn_dwconv3x3_bwd_fused_det_f32(const float* P, const float* dg, const floa
   if ((size_t)B * Ch * 10 * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "dwconv_bwd_fused_det: workspace too small");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k_dwconv_bwd, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+  const bool keep = in_gelu && out_gelu_bwd && gpre && r == 32;
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (keep) hipLaunchKernelGGL(k_dwconv_bwd<true>, dim3((unsigned)dwconv_bwd_grid(planes)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+                     planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, ws);
+  else hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, ws);
   DPMN_CHECK_LAUNCH();
   return dpmn_rows_reduce_f32(ws, dw, db, Ch * 9, Ch, B, stream);

@@ -36,9 +36,9 @@ __global__ __launch_bounds__(256) void k_to_mask(const float* __restrict__ img, 
 // decodes and resizes with PIL (the reference's own library) and uploads the uint8 HWC pixels -- 3 bytes per pixel instead of the
 // 16 of a float CHW + mask tensor -- and this kernel does ToTensor (/255, HWC -> CHW) and the mask channel:
 // L = PIL's RGB -> L, threshold = mean(L) of the image (`np.array(mask).mean()`), channel 3 = (L > mean ? 0 : 255) / 255.
-// One workgroup per image, L kept in LDS, exact integer mean test L * HW <= sum(L).
+// One workgroup per image, L (0..255) kept in LDS as bytes (16 KB at the 64 x 256 HR size), exact integer mean test L * HW <= sum(L).
 __global__ __launch_bounds__(256) void k_collate_u8(const unsigned char* __restrict__ img, float* __restrict__ out, int HW, int with_mask) {
-  extern __shared__ int Ls[];
+  extern __shared__ unsigned char Lb[];
   __shared__ long long wsum[4];
   const int b = blockIdx.x, tid = threadIdx.x;
   const unsigned char* p = img + (size_t)b * HW * 3;
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_collate_u8(const unsigned char* __restr
     o[i] = (float)r / 255.0f; o[HW + i] = (float)g / 255.0f; o[2 * HW + i] = (float)bl / 255.0f;   // ToTensor: .div(255)
     if (with_mask) {
       const int L = (r * 19595 + g * 38470 + bl * 7471 + 0x8000) >> 16;   // PIL ImagingConvert RGB -> L
-      Ls[i] = L;
+      Lb[i] = (unsigned char)L;
       s += L;
     }
   }
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_collate_u8(const unsigned char* __restr
   if ((tid & 63) == 0) wsum[tid >> 6] = s;
   __syncthreads();
   const long long total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  for (int i = tid; i < HW; i += 256) o[3 * HW + i] = ((long long)Ls[i] * HW <= total) ? 1.0f : 0.0f;
+  for (int i = tid; i < HW; i += 256) o[3 * HW + i] = ((long long)Lb[i] * HW <= total) ? 1.0f : 0.0f;
 }
 
 // torch_rotate_img (utils/util.py:37-58): theta = [[cos, sin*r, 0], [-sin/r, cos, 0]] with r = H/W + (2*rand-1)*off_range,
@@ -167,8 +167,8 @@ int dpmn_to_mask_f32(const float* img, long img_stride, float* out, int B, int H
 }
 
 int dpmn_collate_u8_f32(const unsigned char* img, float* out, int B, int H, int W, int with_mask, dpmn_stream_t stream) {
-  DPMN_REQUIRE(img && out && B > 0 && H > 0 && W > 0 && H * W * 4 <= 64 * 1024, "collate_u8: bad arguments (image must fit 64 KB of LDS as ints)");
-  hipLaunchKernelGGL(k_collate_u8, dim3(B), dim3(256), with_mask ? (size_t)H * W * 4 : 0, as_stream(stream), img, out, H * W, with_mask);
+  DPMN_REQUIRE(img && out && B > 0 && H > 0 && W > 0 && (size_t)H * W <= 60 * 1024, "collate_u8: bad arguments (one byte of luma per pixel must fit 60 KB of LDS)");
+  hipLaunchKernelGGL(k_collate_u8, dim3(B), dim3(256), with_mask ? (((size_t)H * W + 15) & ~(size_t)15) : 0, as_stream(stream), img, out, H * W, with_mask);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

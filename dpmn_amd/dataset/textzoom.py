@@ -163,10 +163,15 @@ class alignCollate_realWTLAMask(object):
         return images_HR, None, images_lr, None, None, label_strs, label_rebatches, torch.tensor(weighted_masks).long(), torch.tensor(weighted_tics)
 
 
-def sr_batches(loader, device=None, mask=True):
+def sr_batches(loader, device=None, mask=None):
     """Adapter for TextSR.train / eval / test: (images_hr, images_lr, label_vecs, label_strs) per batch.  label_vecs is None: for
     --arch tatt the reference derives them from a CRNN on the LR image (super_resolution.py:165-169), not from the dataset.
-    Batches of a gpu_finish collate (uint8 pixels) are finished on `device` here."""
+    Batches of a gpu_finish collate (uint8 pixels) are finished on `device` here (default: the current GPU); mask=None takes the
+    collate function's own setting."""
+    if mask is None:
+        mask = bool(getattr(getattr(loader, "collate_fn", None), "mask", True))
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
     for data in loader:
         hr, lr = data[0], data[2]
         if hr.dtype == torch.uint8:

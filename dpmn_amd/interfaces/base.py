@@ -59,7 +59,7 @@ class TextBase(object):
         self.drop_path_rate = parse_list(self.args.drop_path_rate)
 
     # ------------------------------------------------------------------ data (base.py:85-125)
-    def _loader(self, dirs, test, shuffle, drop_last, shard=False):
+    def _loader(self, dirs, test, shuffle, drop_last, shard=False, gpu_finish=True):
         """shard=True (training under torch.distributed): every rank walks its own 1/world of a per-epoch permutation
         (DistributedSampler, call `self.train_sampler.set_epoch(epoch)`) with batch_size // world samples per step, so the
         GLOBAL batch stays config.TRAIN.batch_size at the configured learning rate -- nn.DataParallel's scatter of one batch
@@ -79,7 +79,9 @@ class TextBase(object):
             ds, batch_size=bs, shuffle=shuffle and sampler is None, sampler=sampler, num_workers=int(cfg.workers), pin_memory=True,
             drop_last=drop_last,
             collate_fn=tz.alignCollate_realWTLAMask(imgH=cfg.height, imgW=cfg.width, down_sample_scale=cfg.down_sample_scale, mask=self.mask,
-                                                    gpu_finish=True))      # ToTensor + mask channel on the GPU (dataset/textzoom.py)
+                                                    gpu_finish=gpu_finish))      # True: ToTensor + mask channel on the GPU by sr_batches
+        # (dataset/textzoom.py; uint8 pixels in the batch); False: the reference's float (B, 3 + mask, H, W) tensors for consumers that
+        # iterate the loader themselves
         if shard:
             self.train_sampler = sampler
         return ds, loader
