@@ -125,6 +125,7 @@ SIGNATURES = {
     "dpmn_reduce_defer_pending": (_i, []),
     "dpmn_reduce_defer_flush": (_i, [_i, fp]),
     "dpmn_xred_fallbacks": (_i, [C.POINTER(C.c_uint), _i]),
+    "dpmn_selftest_xshfl": (_i, [C.POINTER(C.c_uint)]),
     "dpmn_xred_test_force_recompute": (_i, [_i]),
     "dpmn_xred_enable": (_i, [_i]),
     "dpmn_nchw_to_nhwc_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),

@@ -215,8 +215,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       float v = sb[i];
-      v += __shfl_xor(v, 16, 64);
-      v += __shfl_xor(v, 32, 64);
+      v += xshfl<16>(v);
+      v += xshfl<32>(v);
       const int n = n_w + 3 * lr + i;
       if (kq == 0 && n < N) pz[(size_t)N * K + n] = v;
     }
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-      for (int u = 0; u < R; ++u) s[u] += __shfl_xor(s[u], o, 64);
+      for (int u = 0; u < R; ++u) s[u] += xshfl_v(s[u], o);
     float q[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-      for (int u = 0; u < R; ++u) q[u] += __shfl_xor(q[u], o, 64);
+      for (int u = 0; u < R; ++u) q[u] += xshfl_v(q[u], o);
     float s1[R], s2[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1)
 #pragma unroll
-      for (int u = 0; u < R; ++u) { s1[u] += __shfl_xor(s1[u], o, 64); s2[u] += __shfl_xor(s2[u], o, 64); }
+      for (int u = 0; u < R; ++u) { s1[u] += xshfl_v(s1[u], o); s2[u] += xshfl_v(s2[u], o); }
 #pragma unroll
     for (int u = 0; u < R; ++u) {
       const long row = row0 + u * stride;
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, 
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1)
 #pragma unroll
-      for (int u = 0; u < R; ++u) s[u] += __shfl_xor(s[u], o, 64);
+      for (int u = 0; u < R; ++u) s[u] += xshfl_v(s[u], o);
     float q[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, 
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1)
 #pragma unroll
-      for (int u = 0; u < R; ++u) q[u] += __shfl_xor(q[u], o, 64);
+      for (int u = 0; u < R; ++u) q[u] += xshfl_v(q[u], o);
     float s1[R], s2[R];
 #pragma unroll
     for (int u = 0; u < R; ++u) {
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, 
 #pragma unroll
     for (int o = 4; o > 0; o >>= 1)
 #pragma unroll
-      for (int u = 0; u < R; ++u) { s1[u] += __shfl_xor(s1[u], o, 64); s2[u] += __shfl_xor(s2[u], o, 64); }
+      for (int u = 0; u < R; ++u) { s1[u] += xshfl_v(s1[u], o); s2[u] += xshfl_v(s2[u], o); }
 #pragma unroll
     for (int u = 0; u < R; ++u) {
       const long row = row0 + u * stride;
@@ -621,7 +621,7 @@ __global__ void k_image_loss_final(const float* __restrict__ part, int nblocks, 
                                    float inv_n_grad, float* __restrict__ loss) {
   double se = 0.0, l1 = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 64) { se += part[2 * i]; l1 += part[2 * i + 1]; }
-  for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); l1 += __shfl_xor(l1, o, 64); }
+  for (int o = 32; o > 0; o >>= 1) { se += xshfl_v(se, o); l1 += xshfl_v(l1, o); }
   if (threadIdx.x == 0) loss[0] = (float)(w_mse * se * inv_n_mse + w_grad * l1 * inv_n_grad);
 }
 // grad_out = gscale * ( w_mse*2(o-t)/N + w_grad/N3 * (U[x-1] - U[x+1] + V[y+1] - V[y-1]) )   (c < 3 for the second term)

@@ -270,15 +270,15 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
           ps[t][qt][r] = a;
           mx = fmaxf(mx, a);
         }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = fmaxf(mx, xshfl<16>(mx));
+      mx = fmaxf(mx, xshfl<32>(mx));
       float den = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float p = __expf(ps[t][qt][r] - mx); ps[t][qt][r] = p; den += p; }
-      den += __shfl_xor(den, 16, 64);
-      den += __shfl_xor(den, 32, 64);
+      den += xshfl<16>(den);
+      den += xshfl<32>(den);
       const float inv = 1.0f / den;
       if (DROP) {    // dP = (dO V^T) o M with the forward's mask (0 or 1/(1-p)); delta = sum_k P dP is unchanged in form
         const unsigned long long mrow = (mrow0 + t0 + nq) * N;
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(128) void k_window_attn8_bwd_mfma(const float* __re
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { ps[t][qt][r] *= inv; dlt += ps[t][qt][r] * dp[t][qt][r]; }
-      dlt += __shfl_xor(dlt, 16, 64);
-      dlt += __shfl_xor(dlt, 32, 64);
+      dlt += xshfl<16>(dlt);
+      dlt += xshfl<32>(dlt);
       if (kq == 0) { smax[nq] = mx; sinv[nq] = inv; sdel[nq] = dlt; }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -545,6 +545,24 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 // GELU(x) and GELU'(x) from ONE erf evaluation: the Abramowitz-Stegun erf of common.h already holds exp(-x^2 / 2), which is the
 // Gaussian of the derivative too (gelu_erf + gelu_grad cost 3 v_exp + 2 v_rcp; this is 1 + 1).  g is bitwise gelu_erf(x).
+// all-lanes wave sum without the LDS pipe: four DPP adds inside a row of 16 lanes (quad swaps, half mirror, mirror), then the
+// gfx950 row / half-wave swaps.  (__shfl_xor = ds_bpermute + its address arithmetic: ~90 instructions per reduced value in this
+// kernel's epilogue, 45 % of its vector instructions.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  v += dpp_mov<0xB1>(v);       // quad_perm [1, 0, 3, 2]
+  v += dpp_mov<0x4E>(v);       // quad_perm [2, 3, 0, 1]
+  v += dpp_mov<0x141>(v);      // row_half_mirror
+  v += dpp_mov<0x140>(v);      // row_mirror
+  u32x2_ r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 #ifndef DWB_SKIP
 #define DWB_SKIP 0        // timing ablations only: 1 no GELU arithmetic, 2 no stencil arithmetic
 #endif
@@ -685,19 +703,17 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* _
       }
       *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
     }
+    // part: image b's row [Ch * 9 weight sums | Ch bias sums], added over the images in order by dpmn_rows_reduce_f32 (no atomics)
+    float* prow = part ? part + (plane / Ch) * (long)(Ch * 10) : nullptr;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      const float s = wave_sum(aw[i]);
-      if (lane == 0) {
-        // part: image b's row [Ch * 9 weight sums | Ch bias sums], added over the images in order by dpmn_rows_reduce_f32 (no atomics)
-        if (part) part[(plane / Ch) * (long)(Ch * 10) + c * 9 + i] = s;
-        else atomicAdd(dw + c * 9 + i, s);
-      }
-    }
-    ab = wave_sum(ab);
-    if (lane == 0) {
-      if (part) part[(plane / Ch) * (long)(Ch * 10) + Ch * 9 + c] = ab;
-      else atomicAdd(db + c, ab);
+    for (int i = 0; i < 9; ++i) aw[i] = wave_sum_dpp(aw[i]);
+    ab = wave_sum_dpp(ab);
+    if (lane < 10) {             // lane i < 9 stores weight sum i, lane 9 the bias sum (every lane holds all ten totals)
+      float v = ab;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v = lane == i ? aw[i] : v;
+      if (prow) prow[lane < 9 ? c * 9 + lane : Ch * 9 + c] = v;
+      else atomicAdd(lane < 9 ? dw + c * 9 + lane : db + c, v);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the next plane's tile stores come after this plane's reads
   }
@@ -749,13 +765,13 @@ __global__ __launch_bounds__(256) void k_ln_fwd(const float* __restrict__ x, con
 #pragma unroll
   for (int i = 0; i < PER; ++i) { xv[i] = x[row * C + t + 32 * i]; s += xv[i]; }
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int o = 16; o > 0; o >>= 1) s += xshfl_v(s, o);
   const float mean = s * (1.0f / C);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < PER; ++i) { const float d = xv[i] - mean; q += d * d; }
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  for (int o = 16; o > 0; o >>= 1) q += xshfl_v(q, o);
   const float rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
 #pragma unroll
   for (int i = 0; i < PER; ++i) y[row * C + t + 32 * i] = (xv[i] - mean) * rstd * gamma[t + 32 * i] + beta[t + 32 * i];
@@ -914,12 +930,12 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
     o[i] = a;
     s += a;
   }
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+  s += xshfl<1>(s); s += xshfl<2>(s);
   const float mean = s * (1.0f / C);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < CQ; ++i) { const float d = o[i] - mean; q += d * d; }
-  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+  q += xshfl<1>(q); q += xshfl<2>(q);
   const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
   float dg[CQ], xh[CQ], s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -932,16 +948,16 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
     s2 += dg[i] * xh[i];
     if (lnpart) {
       float a = d * xh[i], bsum = d;            // sum over the wave's 16 tokens (lanes with the same channel quarter)
-      a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64); a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
-      bsum += __shfl_xor(bsum, 4, 64); bsum += __shfl_xor(bsum, 8, 64); bsum += __shfl_xor(bsum, 16, 64); bsum += __shfl_xor(bsum, 32, 64);
+      a += xshfl<4>(a); a += xshfl<8>(a); a += xshfl<16>(a); a += xshfl<32>(a);
+      bsum += xshfl<4>(bsum); bsum += xshfl<8>(bsum); bsum += xshfl<16>(bsum); bsum += xshfl<32>(bsum);
       if (lane < 4) { wsum[threadIdx.x >> 6][c] = a; wsum[threadIdx.x >> 6][C + c] = bsum; }
     } else {
       atomicAdd(&rg[c], d * xh[i]);
       atomicAdd(&rb[c], d);
     }
   }
-  s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
-  s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+  s1 += xshfl<1>(s1); s1 += xshfl<2>(s1);
+  s2 += xshfl<1>(s2); s2 += xshfl<2>(s2);
   s1 *= (1.0f / C); s2 *= (1.0f / C);
   if (valid) {
 #pragma unroll

@@ -93,14 +93,65 @@ __device__ __forceinline__ void apply_act4(float (&v)[4], int act, float slope) 
   }
 }
 
+// v[lane ^ O] for a compile-time O without the LDS pipe (__shfl_xor = ds_bpermute_b32 plus its address arithmetic and an LDS round
+// trip per exchange): DPP inside a row of 16 lanes -- quad_perm for 1 / 2, row_shl:4 | row_shr:4 under bank masks for 4, row_ror:8
+// for 8 -- and the gfx950 v_permlane16_swap / v_permlane32_swap for 16 / 32.  Exactly the partner's value, so every butterfly built
+// on it gives bitwise the sums and maxima of the __shfl_xor version (checked on the device by dpmn_selftest_xshfl).
+__device__ __forceinline__ unsigned wave_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+template <int CTRL, int BANK>
+__device__ __forceinline__ unsigned dpp_mov_u(unsigned old, unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, 0xF, BANK, false);
+}
+template <int O>
+__device__ __forceinline__ unsigned xshfl_u(unsigned v) {
+  typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+  if constexpr (O == 1) return dpp_mov_u<0xB1, 0xF>(v, v);               // quad_perm [1, 0, 3, 2]
+  else if constexpr (O == 2) return dpp_mov_u<0x4E, 0xF>(v, v);          // quad_perm [2, 3, 0, 1]
+  else if constexpr (O == 4) {
+    const unsigned t = dpp_mov_u<0x104, 0x5>(v, v);                      // row_shl:4 into lanes 0-3, 8-11 of every row
+    return dpp_mov_u<0x114, 0xA>(t, v);                                  // row_shr:4 into lanes 4-7, 12-15
+  } else if constexpr (O == 8) return dpp_mov_u<0x128, 0xF>(v, v);       // row_ror:8
+  else if constexpr (O == 16) {
+    const u32x2_ r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return (wave_lane() & 16) ? r[0] : r[1];                             // odd rows: the partner landed in the first result
+  } else {
+    static_assert(O == 32, "xshfl: O must be 1, 2, 4, 8, 16 or 32");
+    const u32x2_ r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return (wave_lane() & 32) ? r[0] : r[1];
+  }
+}
+template <int O> __device__ __forceinline__ float xshfl(float v) { return __uint_as_float(xshfl_u<O>(__float_as_uint(v))); }
+template <int O> __device__ __forceinline__ int xshfl(int v) { return (int)xshfl_u<O>((unsigned)v); }
+template <int O> __device__ __forceinline__ unsigned xshfl(unsigned v) { return xshfl_u<O>(v); }
+template <int O> __device__ __forceinline__ unsigned long long xshfl(unsigned long long u) {
+  const unsigned lo = xshfl_u<O>((unsigned)u), hi = xshfl_u<O>((unsigned)(u >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <int O> __device__ __forceinline__ long long xshfl(long long v) { return (long long)xshfl<O>((unsigned long long)v); }
+template <int O> __device__ __forceinline__ double xshfl(double v) {
+  return __longlong_as_double((long long)xshfl<O>((unsigned long long)__double_as_longlong(v)));
+}
+// the same with the offset as an argument (a constant after unrolling; anything else falls back to ds_bpermute)
+template <typename T>
+__device__ __forceinline__ T xshfl_v(T v, int o) {
+  switch (o) {
+    case 1: return xshfl<1>(v);
+    case 2: return xshfl<2>(v);
+    case 4: return xshfl<4>(v);
+    case 8: return xshfl<8>(v);
+    case 16: return xshfl<16>(v);
+    case 32: return xshfl<32>(v);
+    default: return __shfl_xor(v, o, 64);
+  }
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 32; o > 0; o >>= 1) v += xshfl_v(v, o);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, xshfl_v(v, o));
   return v;
 }
 

@@ -767,7 +767,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
         for (int r = 0; r < 4; ++r) {
           float s_ = ssum[q][r], q_ = ssq[q][r];
 #pragma unroll
-          for (int o = 1; o < 32; o <<= 1) { s_ += __shfl_xor(s_, o, 64); q_ += __shfl_xor(q_, o, 64); }
+          for (int o = 1; o < 32; o <<= 1) { s_ += xshfl_v(s_, o); q_ += xshfl_v(q_, o); }
           if (l31 == 0 && n + r < a.Cout) {
             double* st = reinterpret_cast<double*>(a.stats) + (size_t)(bx % STAT_SLOTS) * 2 * a.Cout;
             atomicAdd(st + n + r, (double)(s_));
@@ -818,8 +818,8 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s = ssum[i][r], q = ssq[i][r];
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+        s += xshfl<1>(s); s += xshfl<2>(s); s += xshfl<4>(s); s += xshfl<8>(s);
+        q += xshfl<1>(q); q += xshfl<2>(q); q += xshfl<4>(q); q += xshfl<8>(q);
         if (lr == 0 && n + r < a.Cout) {
           double* st = reinterpret_cast<double*>(a.stats) + (size_t)(bx % STAT_SLOTS) * 2 * a.Cout;   // slotted: spreads same-address atomics
           atomicAdd(st + n + r, (double)(s));
@@ -1168,8 +1168,8 @@ __global__ __launch_bounds__(256) void k_conv_igemm_sk(ConvArgs a, SkArgs sk) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float s = ssum[i][r], q = ssq[i][r];
-          s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
-          q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+          s += xshfl<1>(s); s += xshfl<2>(s); s += xshfl<4>(s); s += xshfl<8>(s);
+          q += xshfl<1>(q); q += xshfl<2>(q); q += xshfl<4>(q); q += xshfl<8>(q);
           if (lr == 0 && n + r < a.Cout) {
             double* st = reinterpret_cast<double*>(a.stats) + (size_t)(bx % STAT_SLOTS) * 2 * a.Cout;
             atomicAdd(st + n + r, (double)(s));
@@ -1450,8 +1450,8 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s_ = ssum[i][r], q = ssq[i][r];
-        s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64); s_ += __shfl_xor(s_, 8, 64);
-        q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64); q += __shfl_xor(q, 8, 64);
+        s_ += xshfl<1>(s_); s_ += xshfl<2>(s_); s_ += xshfl<4>(s_); s_ += xshfl<8>(s_);
+        q += xshfl<1>(q); q += xshfl<2>(q); q += xshfl<4>(q); q += xshfl<8>(q);
         if (lr == 0 && n + r < a.Cout) {
           double* st = reinterpret_cast<double*>(a.stats) + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
           atomicAdd(st + n + r, (double)(s_)); atomicAdd(st + a.Cout + n + r, (double)(q));
@@ -1594,8 +1594,8 @@ __global__ __launch_bounds__(256) void k_conv_halo_c4(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       float s_ = ssum[r], q_ = ssq[r];     // only kq == 0 lanes hold non-zero partials
-      s_ += __shfl_xor(s_, 1, 64); s_ += __shfl_xor(s_, 2, 64); s_ += __shfl_xor(s_, 4, 64); s_ += __shfl_xor(s_, 8, 64);
-      q_ += __shfl_xor(q_, 1, 64); q_ += __shfl_xor(q_, 2, 64); q_ += __shfl_xor(q_, 4, 64); q_ += __shfl_xor(q_, 8, 64);
+      s_ += xshfl<1>(s_); s_ += xshfl<2>(s_); s_ += xshfl<4>(s_); s_ += xshfl<8>(s_);
+      q_ += xshfl<1>(q_); q_ += xshfl<2>(q_); q_ += xshfl<4>(q_); q_ += xshfl<8>(q_);
       if (lane == 0 && r < a.Cout) {
         double* st = reinterpret_cast<double*>(a.stats) + (size_t)(blockIdx.x % STAT_SLOTS) * 2 * a.Cout;
         atomicAdd(st + r, (double)(s_)); atomicAdd(st + a.Cout + r, (double)(q_));
@@ -1684,7 +1684,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(ConvArgs a) {
       for (int r = 0; r < 4; ++r) {
         float s_ = ssum[g][r], q = ssq[g][r];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { s_ += __shfl_xor(s_, o, 64); q += __shfl_xor(q, o, 64); }
+        for (int o = 1; o < 64; o <<= 1) { s_ += xshfl_v(s_, o); q += xshfl_v(q, o); }
         if (lane == 0) { red[wave][g * 8 + r] = s_; red[wave][g * 8 + 4 + r] = q; }
       }
     __syncthreads();

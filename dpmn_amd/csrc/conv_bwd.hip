@@ -745,7 +745,7 @@ __global__ __launch_bounds__(256) void k_l1_partial(const float* __restrict__ a,
 __global__ void k_sum_final(const float* __restrict__ part, int n, float mul, float* __restrict__ out) {
   double s = 0.0;
   for (int i = threadIdx.x; i < n; i += 64) s += part[i];
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int o = 32; o > 0; o >>= 1) s += xshfl_v(s, o);
   if (threadIdx.x == 0) out[0] = (float)(s * mul);
 }
 // da = gs*c*sign(a-b) (+ extra) ; db = -gs*c*sign(a-b)

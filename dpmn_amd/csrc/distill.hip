@@ -27,7 +27,7 @@ __device__ __forceinline__ void stage_w(DistillW& w, const DistillWPtr& p) {
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  for (int o = 32; o > 0; o >>= 1) v += xshfl_v(v, o);
   return v;
 }
 
@@ -39,7 +39,7 @@ __device__ __forceinline__ void block_rows(const T (&val)[NV], T* __restrict__ r
   for (int v = 0; v < NV; ++v) {
     T s = val[v];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    for (int o = 32; o > 0; o >>= 1) s += xshfl_v(s, o);
     if (lane == 0) sm[wave][v] = s;
   }
   __syncthreads();

@@ -107,7 +107,7 @@ __device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, i
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float s = cs[r];
-        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        s += xshfl<1>(s); s += xshfl<2>(s); s += xshfl<4>(s); s += xshfl<8>(s);
         cs[r] = s;
       }
       if (lm == 0) {
@@ -165,7 +165,7 @@ __device__ __forceinline__ void epilogue_fast(f32x4 (&acc)[3][1], int m0, int n0
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float c = gelu_erf(v[r]);
-        c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 8, 64);
+        c += xshfl<1>(c); c += xshfl<2>(c); c += xshfl<4>(c); c += xshfl<8>(c);
         if (lm == 0) red[wave * bn_cols + (n0 - n_block0) + nt * 16 + lq * 4 + r] = c;
       }
     }
@@ -271,12 +271,12 @@ __global__ __launch_bounds__(TH) void k_gemm_wstat(const float* __restrict__ x, 
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < VPT * 4; ++i) s += vals[i];
-      s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+      s += xshfl<1>(s); s += xshfl<2>(s); s += xshfl<4>(s);
       const float mean = s * (1.0f / K);
       float q = 0.f;
 #pragma unroll
       for (int i = 0; i < VPT * 4; ++i) { const float d = vals[i] - mean; q += d * d; }
-      q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+      q += xshfl<1>(q); q += xshfl<2>(q); q += xshfl<4>(q);
       const float rstd = 1.0f / sqrtf(q * (1.0f / K) + p.eps);
 #pragma unroll
       for (int i = 0; i < VPT * 4; ++i) vals[i] = (vals[i] - mean) * rstd * lng[scol + i] + lng[K + scol + i];
@@ -928,7 +928,7 @@ __global__ __launch_bounds__(256, ((K <= 96 && !(PRO == PRO_SKSEL && K > 32)) ? 
 #pragma unroll
         for (int c = 0; c < KC; ++c) { s0 += xb[c][0] + xb[c][1]; s1 += xb[c][2] + xb[c][3]; }
         float s_ = s0 + s1;
-        s_ += __shfl_xor(s_, 16, 64); s_ += __shfl_xor(s_, 32, 64);
+        s_ += xshfl<16>(s_); s_ += xshfl<32>(s_);
         mean = s_ * (1.0f / K);
         float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
@@ -937,7 +937,7 @@ __global__ __launch_bounds__(256, ((K <= 96 && !(PRO == PRO_SKSEL && K > 32)) ? 
           q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
         }
         float q = (q0 + q1) + (q2 + q3);
-        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        q += xshfl<16>(q); q += xshfl<32>(q);
         rstd = 1.0f / sqrtf(q * (1.0f / K) + p.eps);
       }
     }
@@ -993,7 +993,7 @@ __global__ __launch_bounds__(256, ((K <= 96 && !(PRO == PRO_SKSEL && K > 32)) ? 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float c = cs[nt][r];
-          c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64); c += __shfl_xor(c, 8, 64);
+          c += xshfl<1>(c); c += xshfl<2>(c); c += xshfl<4>(c); c += xshfl<8>(c);
           c4[r] = c;
         }
         if (lr == 0) *reinterpret_cast<f32x4*>(e.colsum + (size_t)(tile / SUB) * N + n_blk + 16 * nt + 4 * kq) = c4;
@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(256, OCC) void k_sk_mlp_in(const float* __restrict_
 #pragma unroll
       for (int c = 0; c < KC; ++c) { s0 += x1r[c][0] + x1r[c][1]; s1 += x1r[c][2] + x1r[c][3]; }
       float s_ = s0 + s1;
-      s_ += __shfl_xor(s_, 16, 64); s_ += __shfl_xor(s_, 32, 64);
+      s_ += xshfl<16>(s_); s_ += xshfl<32>(s_);
       mean = s_ * (1.0f / C);
       float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f;
 #pragma unroll
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(256, OCC) void k_sk_mlp_in(const float* __restrict_
         q0 = fmaf(d0, d0, q0); q1 = fmaf(d1, d1, q1); q2 = fmaf(d2, d2, q2); q3 = fmaf(d3, d3, q3);
       }
       float q = (q0 + q1) + (q2 + q3);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      q += xshfl<16>(q); q += xshfl<32>(q);
       rstd = 1.0f / sqrtf(q * (1.0f / C) + eps);
     }
     if (SAVE) {

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void k_to_mask(const float* __restrict__ img, 
     Ls[i] = L;
     s += L;
   }
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  for (int o = 32; o > 0; o >>= 1) s += xshfl_v(s, o);
   if ((tid & 63) == 0) wsum[tid >> 6] = s;
   __syncthreads();
   const long long total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_collate_u8(const unsigned char* __restr
     }
   }
   if (!with_mask) return;
-  for (int o_ = 32; o_ > 0; o_ >>= 1) s += __shfl_xor(s, o_, 64);
+  for (int o_ = 32; o_ > 0; o_ >>= 1) s += xshfl_v(s, o_);
   if ((tid & 63) == 0) wsum[tid >> 6] = s;
   __syncthreads();
   const long long total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_psnr_ssim_partial(const float* __restri
 __global__ void k_psnr_ssim_final(const float* __restrict__ partial, int nblocks, float inv_count, float* __restrict__ out2) {
   double se = 0.0, sm = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 64) { se += partial[2 * i]; sm += partial[2 * i + 1]; }
-  for (int o = 32; o > 0; o >>= 1) { se += __shfl_xor(se, o, 64); sm += __shfl_xor(sm, o, 64); }
+  for (int o = 32; o > 0; o >>= 1) { se += xshfl_v(se, o); sm += xshfl_v(sm, o); }
   if (threadIdx.x == 0) {
     const double mse = se * inv_count;
     out2[0] = (float)(20.0 * log10(255.0 / sqrt(mse)));
@@ -155,9 +155,45 @@ __global__ void k_psnr_ssim_final(const float* __restrict__ partial, int nblocks
   }
 }
 
+// device self-test of common.h xshfl<O>: every offset against __shfl_xor on a 2-D block (lane != threadIdx.x & 63 there)
+__global__ void k_selftest_xshfl(unsigned* mismatches) {
+  const unsigned tid = threadIdx.y * blockDim.x + threadIdx.x;
+  const float v = __uint_as_float(0x3f800000u + 977u * tid + 13u * blockIdx.x);
+  unsigned bad = 0;
+  bad += xshfl<1>(v) != __shfl_xor(v, 1, 64);
+  bad += xshfl<2>(v) != __shfl_xor(v, 2, 64);
+  bad += xshfl<4>(v) != __shfl_xor(v, 4, 64);
+  bad += xshfl<8>(v) != __shfl_xor(v, 8, 64);
+  bad += xshfl<16>(v) != __shfl_xor(v, 16, 64);
+  bad += xshfl<32>(v) != __shfl_xor(v, 32, 64);
+  float s = v, s2 = v;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  s = wave_sum(s);
+  bad += s != s2;
+  const double dv = (double)v * 1.000000119 + 1e-9 * tid;      // 64-bit payload: both words must travel
+  bad += xshfl<4>(dv) != __shfl_xor(dv, 4, 64);
+  bad += xshfl<16>(dv) != __shfl_xor(dv, 16, 64);
+  bad += xshfl<32>(dv) != __shfl_xor(dv, 32, 64);
+  if (bad) atomicAdd(mismatches, bad);
+}
+
 }  // namespace
 
 extern "C" {
+
+int dpmn_selftest_xshfl(unsigned* mismatches_out) {
+  DPMN_REQUIRE(mismatches_out, "selftest_xshfl: null pointer");
+  unsigned* d = nullptr;
+  if (hipMalloc(&d, sizeof(unsigned)) != hipSuccess) return dpmn_set_error(DPMN_ERR_LAUNCH, "selftest_xshfl: hipMalloc failed");
+  (void)hipMemset(d, 0, sizeof(unsigned));
+  hipLaunchKernelGGL(k_selftest_xshfl, dim3(4), dim3(32, 8), 0, nullptr, d);
+  hipLaunchKernelGGL(k_selftest_xshfl, dim3(4), dim3(256, 1), 0, nullptr, d);
+  const hipError_t e = hipMemcpy(mismatches_out, d, sizeof(unsigned), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return dpmn_set_error(DPMN_ERR_LAUNCH, hipGetErrorString(e));
+  return DPMN_OK;
+}
 
 int dpmn_to_mask_f32(const float* img, long img_stride, float* out, int B, int H, int W, dpmn_stream_t stream) {
   DPMN_REQUIRE(img && out && B > 0 && H * W * 4 <= 64 * 1024, "to_mask: bad arguments (image must fit 64 KB of LDS as ints)");

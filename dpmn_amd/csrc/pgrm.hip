@@ -84,12 +84,12 @@ __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict_
     o[i] = a;
     s += a;
   }
-  s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+  s += xshfl<1>(s); s += xshfl<2>(s);
   const float mean = s * (1.0f / C);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < CQ; ++i) { const float d = o[i] - mean; q += d * d; }
-  q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+  q += xshfl<1>(q); q += xshfl<2>(q);
   const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
   if (!valid) return;
   float* dst = tok + (size_t)token * C + part * CQ;
@@ -342,8 +342,8 @@ __global__ __launch_bounds__(256) void k_window_attn8_mfma(const float* __restri
         sacc[t][qt][r] = a;
         mx = fmaxf(mx, a);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, xshfl<16>(mx));
+    mx = fmaxf(mx, xshfl<32>(mx));
     float den = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -353,8 +353,8 @@ __global__ __launch_bounds__(256) void k_window_attn8_mfma(const float* __restri
         sacc[t][qt][r] = p;
         den += p;
       }
-    den += __shfl_xor(den, 16, 64);
-    den += __shfl_xor(den, 32, 64);
+    den += xshfl<16>(den);
+    den += xshfl<32>(den);
     inv[qt] = 1.0f / den;
     if (DROP) {      // attn_drop (pgrm.py:248): same mask index as k_window_attn -- query row base + key
       const unsigned long long mrow = (((unsigned long long)((size_t)b * (C / CG) + g) * 2 + head) * L + t0 + nq) * N;
@@ -506,8 +506,8 @@ __global__ __launch_bounds__((WS == 16 ? 512 : 256)) void k_window_attn_mfma(con
         mx = fmaxf(mx, a);
         if (KT > 4 && r == 3) __builtin_amdgcn_sched_barrier(0);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, xshfl<16>(mx));
+    mx = fmaxf(mx, xshfl<32>(mx));
     float den = 0.f;
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt)
@@ -517,8 +517,8 @@ __global__ __launch_bounds__((WS == 16 ? 512 : 256)) void k_window_attn_mfma(con
         sacc[kt][r] = pexp;
         den += pexp;
       }
-    den += __shfl_xor(den, 16, 64);
-    den += __shfl_xor(den, 32, 64);
+    den += xshfl<16>(den);
+    den += xshfl<32>(den);
     const float inv = 1.0f / den;
     // O^T = V^T . P: A = V^T[d = 16 dt + lr][key], B = P (the accumulator registers)
     f32x4 oacc[DC];
@@ -605,7 +605,7 @@ __global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image
     float a = 0.f;
     if (j < dmid)
       for (int c = part; c < C; c += 8) a += fc1_w[j * C + c] * S[c];
-    a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64);
+    a += xshfl<1>(a); a += xshfl<2>(a); a += xshfl<4>(a);
     if (j < dmid && part == 0) Z[j] = gelu_erf(a + fc1_b[j]);
   }
   __syncthreads();

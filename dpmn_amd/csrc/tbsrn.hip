@@ -64,8 +64,8 @@ __global__ __launch_bounds__(256) void k_mha(const float* __restrict__ qkv, floa
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, xshfl<16>(mx));
+    mx = fmaxf(mx, xshfl<32>(mx));
     const float m_new = fmaxf(m_run, mx);
     const float corr = __expf(m_run - m_new);
     float psum = 0.f;
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void k_mha(const float* __restrict__ qkv, floa
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const float pv = __expf(s[kt][r] - m_new); s[kt][r] = pv; psum += pv; }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    psum += xshfl<16>(psum);
+    psum += xshfl<32>(psum);
     l_run = l_run * corr + psum;
     m_run = m_new;
 #pragma unroll

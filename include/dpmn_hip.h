@@ -193,6 +193,9 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream);
  * that were therefore recomputed by the last-arriving workgroup (bitwise-equal result, slower).  0 on the observed round-robin
  * placement.  Synchronises the device.  reset != 0 zeroes the counter. */
 int dpmn_xred_fallbacks(unsigned* count_out, int reset);
+/* Device self-test of the DPP / permlane-swap lane exchanges the reductions are built on (csrc/common.h xshfl): *mismatches_out = the
+ * number of lanes whose exchange differs from __shfl_xor (0 on a correct build).  Test hook; no reference counterpart. */
+int dpmn_selftest_xshfl(unsigned* mismatches_out);
 /* 1 / 0: use / do not use the in-L2 split-K reduction for the layers that qualify; -1: the DPMN_CONV_XRED environment variable
  * (default 0: on MI355X the reduce launch measured faster, DESIGN.md "Measured and rejected", round 4). */
 int dpmn_xred_enable(int on);
