@@ -21,7 +21,7 @@ FAMILIES = [("k_conv_igemm<128, 128", "k_conv_igemm<128,128>"), ("k_conv_igemm<6
             ("k_conv_splitk_reduce", "k_conv_splitk_reduce"), ("k_conv_halo_c4", "k_conv_halo_c4"), ("k_conv_halo<", "k_conv_halo"),
             ("k_gemm_pw", "k_gemm_pw"), ("k_gemm_wstat<96, 1", "k_gemm_wstat<LN prologue>"), ("k_gemm_wstat<192, 1", "k_gemm_wstat<LN prologue>"),
             ("k_gemm_wstat", "k_gemm_wstat"), ("k_gemm_kloop", "k_gemm_kloop"), ("k_dwconv_gelu", "k_dwconv_gelu"),
-            ("k_window_attn8_mfma", "k_window_attn8_mfma"), ("k_window_attn<", "k_window_attn<2|4|16>"), ("k_ln_qkv_window_attn", "k_ln_qkv_window_attn"),
+            ("k_window_attn8_mfma", "k_window_attn8_mfma"), ("k_window_attn<", "k_window_attn<2|4|16>"), ("k_ln_qkv_window_attn_bwd", "k_ln_qkv_window_attn_bwd"), ("k_ln_qkv_window_attn", "k_ln_qkv_window_attn"),
             ("k_bigru", "k_bigru"), ("k_mha32", "k_mha32")]
 
 
