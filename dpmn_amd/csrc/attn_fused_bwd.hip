@@ -31,6 +31,9 @@ namespace {
 #ifndef FAB_HB
 #define FAB_HB 1          // scheduling barrier between the two heads of a pass
 #endif
+#ifndef FAB_HBB
+#define FAB_HBB 1         // the same in pass B
+#endif
 #ifndef FAB_QB
 #define FAB_QB 0          // 8x8: scheduling barrier between the query tiles of pass B (measured: 75.7 us with, 73.3 us without)
 #endif
@@ -346,7 +349,7 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
     if (!(FAB_SKIP & 2))
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      if (FAB_HB) __builtin_amdgcn_sched_barrier(0);
+      if (FAB_HBB) __builtin_amdgcn_sched_barrier(0);
       f32x4 dva0 = (f32x4){0.f, 0.f, 0.f, 0.f}, dka0 = dva0, dva1 = dva0, dka1 = dva0;
 #pragma unroll
       for (int qt = 0; qt < KT; ++qt) {

@@ -513,7 +513,7 @@ def backward(m, sv, dout, need_dx_kv=True):
                                                    dptr(dypre), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
                                                    1, 1, float(pd), int(sb[2]), B, Ch, r, stream()))
         dn2 = linear_bwd(dypre, s["n2"], mlp.fc1.weight, gr[mlp.fc1.weight], gr[mlp.fc1.bias])
-        dx1 = dx2.clone()
+        dx1 = dx2      # in place: every reader of dx2 (fc2's two backward GEMMs, the dropout copy) is already queued on this stream
         layernorm_bwd(s["x1"], dn2, blk.norm2.weight, dx1, True, gr[blk.norm2.weight], gr[blk.norm2.bias])
         # x1 = tkv_in + DropPath(feats + V Wh^T + bh)
         dat = ops.dropout(dx1, p_row=dpb, seed_row=sb[1], row_len=L * Cd, out=torch.empty_like(dx1)) if dpb > 0 else dx1
