@@ -22,6 +22,7 @@ from ..utils import synth
 TRAIN_BRANCH_STREAMS = os.environ.get("DPMN_TRAIN_BRANCH_STREAMS", "1") != "0"
 BRANCH_STREAMS = os.environ.get("DPMN_BRANCH_STREAMS", "1") != "0"      # 0: branch 1 and branch 2 of refine() on one stream
 EVAL_PIPELINE = os.environ.get("DPMN_EVAL_PIPELINE", "1") != "0"        # 0: TextSR.eval / test run one batch at a time
+DISTILL_ON_BRANCH = os.environ.get("DPMN_DISTILL_ON_BRANCH", "1") != "0"      # 0: the DistillModules run on the main stream before the CMM
 
 
 _SIDE_STREAMS = {}
@@ -332,6 +333,15 @@ class TextSR(base.TextBase):
                 cascade = sr
                 part[1] = part[1] + crit(sr, hr3).mean() * 100
 
+        dl = [0, 0]
+
+        def run_distill(branch):
+            imgs, off = (br1, 0) if branch == 0 else (br2, b1 - 1)
+            feat = imgs[-1]
+            for k in range(len(imgs) - 1, 0, -1):
+                ld, feat = distill[k - 1 + off](feat, imgs[k - 1])
+                dl[branch] = dl[branch] + ld.sum() * 100
+
         # two HIP streams for the two branches (see refine()); autograd runs each node's backward on its forward's stream and joins
         # the streams at the end of backward().  The step's weight packs are refreshed on the main stream before the fork.
         forked = TRAIN_BRANCH_STREAMS and not share and images_lr.is_cuda and not torch.cuda.is_current_stream_capturing()
@@ -343,12 +353,23 @@ class TextSR(base.TextBase):
             s1, s2 = self._side_streams = side_streams(images_lr.device)
             s1.wait_stream(cur)
             s2.wait_stream(cur)
+            # the distillation chain of a branch (super_resolution.py:219-236) needs that branch's images only: it stays on the
+            # branch's stream BEHIND the event the CMM waits for, so it -- and, since autograd runs a node's backward on its forward's
+            # stream, its backward -- overlaps the CMM's single-stream forward / backward instead of preceding it
             with torch.cuda.stream(s1):
                 run_branch1()
+                e1 = torch.cuda.Event()
+                e1.record(s1)
+                if DISTILL_ON_BRANCH:
+                    run_distill(0)
             with torch.cuda.stream(s2):
                 run_branch2()
-            cur.wait_stream(s1)
-            cur.wait_stream(s2)
+                e2 = torch.cuda.Event()
+                e2.record(s2)
+                if DISTILL_ON_BRANCH:
+                    run_distill(1)
+            cur.wait_event(e1)
+            cur.wait_event(e2)
             for t_ in br1 + br2:
                 t_.record_stream(cur)
         else:
@@ -357,17 +378,18 @@ class TextSR(base.TextBase):
         self.psn_prefetched = None
         if prefetch is not None and not getattr(self.args, "rotate_train", 0) and not torch.cuda.is_current_stream_capturing():
             self.psn_prefetched = self.prefetch_psn(psn, *prefetch)      # overlaps the CMM forward, the backward and the optimizer
-        loss = part[0] + part[1]
-        feat = br1[-1]
-        for k in range(b1 - 1, 0, -1):
-            ld, feat = distill[k - 1](feat, br1[k - 1])
-            loss = loss + ld.sum() * 100
-        feat = br2[-1]
-        for k in range(b2 - 1, 0, -1):
-            ld, feat = distill[k + b1 - 2](feat, br2[k - 1])
-            loss = loss + ld.sum() * 100
+        if not (forked and DISTILL_ON_BRANCH):
+            run_distill(0)
+            run_distill(1)
         sr = models[-1](br1[-1], br2[-1])
-        loss = loss + crit(sr, hr3).mean() * 100
+        lc = crit(sr, hr3).mean() * 100
+        if forked and DISTILL_ON_BRANCH:
+            cur.wait_stream(s1)
+            cur.wait_stream(s2)
+            for t_ in dl:
+                if torch.is_tensor(t_):
+                    t_.record_stream(cur)
+        loss = (part[0] + part[1]) + (dl[0] + dl[1]) + lc
         loss = loss / (b1 + b2 + 1)
         loss.backward()
         if forked:
