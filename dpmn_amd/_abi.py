@@ -288,7 +288,14 @@ def int_array(vals):
     return (C.c_int * len(vals))(*[int(v) for v in vals])
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object: ~7 us per
+    call, times ~1400 launches per training step -- a third of the step's host time; the raw query is ~0.3 us.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -22,6 +22,7 @@ from ..utils import synth
 TRAIN_BRANCH_STREAMS = os.environ.get("DPMN_TRAIN_BRANCH_STREAMS", "1") != "0"
 BRANCH_STREAMS = os.environ.get("DPMN_BRANCH_STREAMS", "1") != "0"      # 0: branch 1 and branch 2 of refine() on one stream
 EVAL_PIPELINE = os.environ.get("DPMN_EVAL_PIPELINE", "1") != "0"        # 0: TextSR.eval / test run one batch at a time
+GRAPH_MULTISTREAM = os.environ.get("DPMN_GRAPH_MULTISTREAM", "1") != "0"    # 0: graphed_train_step captures the step on ONE stream
 DISTILL_ON_BRANCH = os.environ.get("DPMN_DISTILL_ON_BRANCH", "1") != "0"      # 0: the DistillModules run on the main stream before the CMM
 
 
@@ -344,7 +345,7 @@ class TextSR(base.TextBase):
 
         # two HIP streams for the two branches (see refine()); autograd runs each node's backward on its forward's stream and joins
         # the streams at the end of backward().  The step's weight packs are refreshed on the main stream before the fork.
-        forked = TRAIN_BRANCH_STREAMS and not share and images_lr.is_cuda and not torch.cuda.is_current_stream_capturing()
+        forked = TRAIN_BRANCH_STREAMS and not share and images_lr.is_cuda and (GRAPH_MULTISTREAM or not torch.cuda.is_current_stream_capturing())
         if forked:
             from ..model import packing
             if packing.ACTIVE is not None:

@@ -15,7 +15,7 @@ import torch
 from .. import ops
 from .._abi import dptr, lib, check, stream
 from ..model import packing
-from .pgrm_train import colsum, conv_wgrad_into, grad_targets, finish_grads
+from .pgrm_train import colsum, conv_wgrad_into, grad_targets, finish_grads, params_of
 
 ACT = ops.ACT
 
@@ -215,7 +215,7 @@ _SIDE = {}
 def wgrad_stream(dev):
     """The side stream of the CMM weight gradients (one per device), or None: switched off, or the step is being captured into
     a hipGraph (graphed_train_step keeps the single-stream order)."""
-    if not WGRAD_STREAM or torch.cuda.is_current_stream_capturing():
+    if not WGRAD_STREAM or (torch.cuda.is_current_stream_capturing() and os.environ.get("DPMN_GRAPH_MULTISTREAM", "1") == "0"):
         return None
     key = (dev.type, dev.index)
     if key not in _SIDE:
@@ -346,4 +346,4 @@ class CMMFunction(torch.autograd.Function):
 def apply(m, x1, x2):
     if getattr(m, "_dpmn_bucket", None) is not None:
         m._dpmn_bucket.note_use()
-    return CMMFunction.apply(m, x1, x2, *list(m.parameters()))
+    return CMMFunction.apply(m, x1, x2, *params_of(m))
