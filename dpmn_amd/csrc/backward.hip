@@ -254,17 +254,55 @@ struct TnMulti {
   dpmn_tn_pending d[16];
   int first_block[17];
   int n;
+  unsigned vec;       // bit i: descriptor i goes through the 16-byte path (rows, destinations and lengths are multiples of 4 floats)
 };
 __global__ __launch_bounds__(256) void k_tn_reduce_multi(TnMulti m) {
-  __shared__ float red[4][64];
+  __shared__ float4 red[4][64];
   int i = 0;
   while (i + 1 < m.n && (int)blockIdx.x >= m.first_block[i + 1]) ++i;
   const dpmn_tn_pending& d = m.d[i];
   const float* part = d.part;
   const int NK = d.NK, N = d.N, splits = d.splits;
-  const int e = ((int)blockIdx.x - m.first_block[i]) * 64 + (threadIdx.x & 63), zg = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
   const int tot = NK + (d.db ? N : 0);
   const size_t zs = (size_t)NK + N;
+  if ((m.vec >> i) & 1u) {
+    // four consecutive elements per thread: the same per-element order of additions as the scalar path below (split z goes to
+    // accumulator (z / 4) % 4 of split group z % 4), 16 bytes per load and eight loads in flight per thread
+    const int e = (((int)blockIdx.x - m.first_block[i]) * 64 + lane) * 4;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    auto add = [](float4& a_, const float4& b_) { a_.x += b_.x; a_.y += b_.y; a_.z += b_.z; a_.w += b_.w; };
+    if (e < tot) {
+      const float* p = part + e;
+      int z = zg;
+      for (; z + 28 < splits; z += 32) {
+        const float4 a0 = *reinterpret_cast<const float4*>(p + (size_t)z * zs), a1 = *reinterpret_cast<const float4*>(p + (size_t)(z + 4) * zs);
+        const float4 a2 = *reinterpret_cast<const float4*>(p + (size_t)(z + 8) * zs), a3 = *reinterpret_cast<const float4*>(p + (size_t)(z + 12) * zs);
+        const float4 a4 = *reinterpret_cast<const float4*>(p + (size_t)(z + 16) * zs), a5 = *reinterpret_cast<const float4*>(p + (size_t)(z + 20) * zs);
+        const float4 a6 = *reinterpret_cast<const float4*>(p + (size_t)(z + 24) * zs), a7 = *reinterpret_cast<const float4*>(p + (size_t)(z + 28) * zs);
+        add(s0, a0); add(s1, a1); add(s2, a2); add(s3, a3);
+        add(s0, a4); add(s1, a5); add(s2, a6); add(s3, a7);
+      }
+      for (; z + 12 < splits; z += 16) {
+        add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * zs)); add(s1, *reinterpret_cast<const float4*>(p + (size_t)(z + 4) * zs));
+        add(s2, *reinterpret_cast<const float4*>(p + (size_t)(z + 8) * zs)); add(s3, *reinterpret_cast<const float4*>(p + (size_t)(z + 12) * zs));
+      }
+      for (; z < splits; z += 4) add(s0, *reinterpret_cast<const float4*>(p + (size_t)z * zs));
+    }
+    red[zg][lane] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (zg == 0 && e < tot) {
+      const float4 r0 = red[0][lane], r1 = red[1][lane], r2 = red[2][lane], r3 = red[3][lane];
+      float4* dst = reinterpret_cast<float4*>(e < NK ? d.dw + e : d.db + (e - NK));
+      float4 o = *dst;
+      o.x += (r0.x + r1.x) + (r2.x + r3.x); o.y += (r0.y + r1.y) + (r2.y + r3.y);
+      o.z += (r0.z + r1.z) + (r2.z + r3.z); o.w += (r0.w + r1.w) + (r2.w + r3.w);
+      *dst = o;
+    }
+    return;
+  }
+  float* reds = reinterpret_cast<float*>(&red[0][0]);      // [4][64] floats
+  const int e = ((int)blockIdx.x - m.first_block[i]) * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (e < tot) {
     int z = zg;
@@ -274,11 +312,11 @@ __global__ __launch_bounds__(256) void k_tn_reduce_multi(TnMulti m) {
     }
     for (; z < splits; z += 4) s0 += part[(size_t)z * zs + e];
   }
-  red[zg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  reds[zg * 64 + lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (zg == 0 && e < tot) {
-    const int c = threadIdx.x;
-    const float v = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+    const int c = lane;
+    const float v = (reds[c] + reds[64 + c]) + (reds[128 + c] + reds[192 + c]);
     if (e < NK) d.dw[e] += v; else d.db[e - NK] += v;
   }
 }
@@ -711,6 +749,7 @@ int dpmn_gemm_tn_partial_f32(const float* dy, const float* x, float* dw, float* 
 
 int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending, int n, dpmn_stream_t stream) {
   DPMN_REQUIRE(pending && n >= 0, "tn_reduce_multi: bad arguments");
+  static const bool tn_vec = !(getenv("DPMN_TN_REDUCE_VEC") && atoi(getenv("DPMN_TN_REDUCE_VEC")) == 0);
   int i0 = 0;
   while (i0 < n) {
     // one launch = up to 16 descriptors with pairwise DIFFERENT destinations (two sums into one tensor inside a launch would race:
@@ -725,7 +764,10 @@ int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending, int n, dpmn_stream_
       if (clash) break;
       m.d[cnt] = d;
       m.first_block[cnt] = nb;
-      nb += cdiv(d.NK + (d.db ? d.N : 0), 64);
+      const bool vec = tn_vec && d.NK % 4 == 0 && d.N % 4 == 0 && ((uintptr_t)d.part & 15) == 0 && ((uintptr_t)d.dw & 15) == 0 &&
+                       (!d.db || ((uintptr_t)d.db & 15) == 0);
+      if (vec) m.vec |= 1u << cnt;
+      nb += cdiv(d.NK + (d.db ? d.N : 0), vec ? 256 : 64);
     }
     m.n = cnt;
     m.first_block[cnt] = nb;

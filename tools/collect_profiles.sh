@@ -26,7 +26,7 @@ timeout 600 python bench.py --mode train 2>/dev/null | tail -1 > $OUT/bench_trai
 if [ "${1:-}" != "quick" ]; then
   timeout 600 python bench.py --mode train --drop 0.1 2>/dev/null | tail -1 > $OUT/bench_train_drop.json
   timeout 600 python bench.py --workload cfg3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg3.json
-  timeout 900 python bench.py --workload cfg4 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg4.json
+  timeout 900 python bench.py --workload cfg4 --steps 5 --warmup 6 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg4.json
 fi
 # keep the merge-back small: the per-dispatch traces are reduced on the box, only summaries travel
 python tools/collect_profiles.py --reduce $OUT > $OUT/reduce.log 2>&1
