@@ -631,6 +631,9 @@ __global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image
 // apply_gelu: 0 = g holds the conv output, 1 = g holds GELU(conv), 2 = g holds the conv output AND g2 holds GELU(conv) (the
 // training forward keeps the pre-activation for the backward: one pass instead of conv + a separate activation kernel);
 // in_gelu: the input is a pre-activation, GELU is applied on the way into the LDS tile (fc1's GELU, pgrm.py:33)
+// R32: 32 x 32 planes (the Mlp of the 16 x 64 -> 32 x 128 stacks) -- exactly four float4 per lane: all four loads are issued before the
+// first GELU, no tail predicate
+template <bool R32>
 __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ g, int Ch, int r,
                                                       long planes, int apply_gelu, float* __restrict__ g2 = nullptr, int in_gelu = 0,
@@ -649,9 +652,17 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
   float* t = sm + wave * (r + 2) * LD;
   if (valid) {
     const float* src = y + plane * r * r;
-    for (int i = lane; i < r * r4; i += 64) {
+    float4 pre[R32 ? 4 : 1];
+    if (R32) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) pre[it] = *reinterpret_cast<const float4*>(src + 4 * (lane + 64 * it));
+    }
+#pragma unroll 4
+    for (int it = 0; it < (R32 ? 4 : (r * r4 + 63) / 64); ++it) {
+      const int i = lane + 64 * it;
+      if (!R32 && i >= r * r4) break;
       const int yy = i / r4, x4 = (i - yy * r4) * 4;
-      float4 v = *reinterpret_cast<const float4*>(src + yy * r + x4);
+      float4 v = R32 ? pre[R32 ? it : 0] : *reinterpret_cast<const float4*>(src + yy * r + x4);
       if (in_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
       if (p_drop > 0.f) {
         const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
@@ -663,7 +674,8 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
     for (int i = lane; i < LD; i += 64) { t[i] = 0.f; t[(r + 1) * LD + i] = 0.f; }       // top / bottom halo rows
     for (int i = lane; i < r; i += 64) { t[(i + 1) * LD + 3] = 0.f; t[(i + 1) * LD + 4 + r] = 0.f; }   // left / right halo columns
   }
-  __syncthreads();
+  // the tile is private to the wave (LDS operations of one wave execute in order): no block barrier
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   if (!valid) return;
   float k[9];
 #pragma unroll
@@ -868,9 +880,10 @@ int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, f
   DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   ProfScope prof(PT_DWCONV_GELU, as_stream(stream), 18.0 * planes * r * r, 8.0 * planes * r * r);
-  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
+  if (r == 32) hipLaunchKernelGGL(k_dwconv_gelu<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
+  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -881,9 +894,11 @@ int dpmn_dwconv3x3_gelu_in_f32(const float* y, const float* w, const float* bias
   DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   ProfScope prof(PT_DWCONV_GELU, as_stream(stream), 18.0 * planes * r * r, 8.0 * planes * r * r);
-  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1,
+  if (r == 32) hipLaunchKernelGGL(k_dwconv_gelu<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1,
+                     static_cast<float*>(nullptr), 1, 0.f, 0ull);
+  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1,
                      static_cast<float*>(nullptr), 1, 0.f, 0ull);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -893,8 +908,9 @@ int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float*
   DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (r == 32) hipLaunchKernelGGL(k_dwconv_gelu<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
+  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -904,8 +920,10 @@ int dpmn_dwconv3x3_train_f32(const float* y, const float* w, const float* bias, 
   DPMN_REQUIRE(y && w && bias && gpre && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_train: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
-  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k_dwconv_gelu, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, gpre, Ch, r, planes, 2, g,
+  if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (r == 32) hipLaunchKernelGGL(k_dwconv_gelu<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, gpre, Ch, r, planes, 2, g,
+                     in_gelu, p_drop, seed);
+  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, gpre, Ch, r, planes, 2, g,
                      in_gelu, p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
