@@ -53,11 +53,16 @@ __device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r)
 template <int BN_, int BKT, bool P2 = false>
 __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
   constexpr int BMc = 32, NI = BN_ / 16, NJ = BKT / 64, LDY = BN_ + 4, LDX = BKT + 4;
+  // two LDS stages for the 128 x 128 tile only (107 -> 101 us): the other shapes lose more to the lower occupancy than they gain
+  constexpr int WG_STAGES = (BN_ == 128 && BKT == 128) ? 2 : 1;
   constexpr int YC4 = BN_ / 4, XC4 = BKT / 4;             // float4 columns
   constexpr int YRS = 256 / YC4, XRS = 256 / XC4;         // row stride between a thread's loads
   constexpr int YP = (BMc + YRS - 1) / YRS, XP = BMc / XRS;
-  __shared__ __attribute__((aligned(16))) float Ys[BMc * LDY];
-  __shared__ __attribute__((aligned(16))) float Xs[BMc * LDX];
+  // two LDS stages: chunk i+1 is stored while (other waves still run) the MFMAs of chunk i -- ONE barrier per chunk instead of two
+  __shared__ __attribute__((aligned(16))) float Ys2[WG_STAGES][BMc * LDY];
+  __shared__ __attribute__((aligned(16))) float Xs2[WG_STAGES][BMc * LDX];
+  float* Ys = Ys2[0];
+  float* Xs = Xs2[0];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware decode: workgroups are dealt round-robin to the 8 XCDs; keep the tiles of one pixel range (which share
   // dY and the input rows) on one XCD's L2.
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (m_lo < m_hi) { gload(m_lo); sstore(); }
   __syncthreads();
+  int stage = 0;
   for (int m0 = m_lo; m0 < m_hi; m0 += BMc) {
 #ifdef WG_NOLOAD
     const bool more = false;
@@ -244,9 +250,17 @@ __global__ __launch_bounds__(256) void k_conv_wgrad(WgArgs a) {
     }
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    if (more) sstore();
-    __syncthreads();
+    if (WG_STAGES == 2) {
+      // sstore writes the OTHER stage (its last readers passed the barrier of the previous chunk); the MFMA loop above read `stage`
+      stage ^= 1;
+      Ys = Ys2[stage]; Xs = Xs2[stage];
+      if (more) sstore();
+      __syncthreads();
+    } else {
+      __syncthreads();
+      if (more) sstore();
+      __syncthreads();
+    }
   }
   if (a.excl) {
     // the block owns tile (n_blk, k_blk) of slot bz: a lane's NJ consecutive k values go out as one vector store, 16 lanes
