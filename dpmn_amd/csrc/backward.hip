@@ -711,6 +711,7 @@ static int gemm_tn_impl(const float* dy, const float* x, float* dw, float* db, i
   // operands straight from global memory into the MFMA registers when a wave's 48 columns tile N and K (every Linear of the
   // PGRM block: 96 / 192 / 384) and the byte offsets fit the buffer instructions
   static const int reg_on = getenv("DPMN_TN_REG") ? atoi(getenv("DPMN_TN_REG")) : 1;
+  ProfScope prof(PT_GEMM_TN, as_stream(stream), 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K + (double)splits * ((double)N * K + N)));
   if (reg_on && part && N % 48 == 0 && K % 48 == 0 && (size_t)rows * (N > K ? N : K) * 4 < (1ull << 31))
     hipLaunchKernelGGL(k_gemm_tn_reg<8>, grid, dim3(256), 0, as_stream(stream), dy, x, dw, M, N, K, rows, db, part);
   else
@@ -771,6 +772,9 @@ int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending, int n, dpmn_stream_
     }
     m.n = cnt;
     m.first_block[cnt] = nb;
+    double rbytes = 0.0;
+    for (int j = 0; j < cnt; ++j) rbytes += 4.0 * ((double)m.d[j].splits + 2.0) * (m.d[j].NK + (m.d[j].db ? m.d[j].N : 0));
+    ProfScope prof(PT_TN_REDUCE, as_stream(stream), 0.0, rbytes);
     hipLaunchKernelGGL(k_tn_reduce_multi, dim3(nb), dim3(256), 0, as_stream(stream), m);
     DPMN_CHECK_LAUNCH();
     i0 += cnt;

@@ -1031,6 +1031,10 @@ __global__ __launch_bounds__(256) void k_prior_fusion_wgrad(const float* __restr
 
 }  // namespace
 
+int dpmn_wattn_bwd_mfma(int ws, int D, const float* q, const float* kv, const float* tbl, const float* dout, float* dq, float* dkv,
+                        float* dtable, int B, int H, int W, int C, int g, int shift, float p_drop, unsigned long long seed,
+                        hipStream_t st, int part_mode, int* rows);      // wattn_bwd_mfma.hip
+
 extern "C" {
 
 int dpmn_window_attn_bwd_f32(const float* q, const float* kv, const float* const* bias_tables, const int* windows,
@@ -1064,6 +1068,13 @@ static int window_attn_bwd_impl(const float* q, const float* kv, const float* co
         hipLaunchKernelGGL((k_window_attn8_bwd_mfma<false>), dim3((unsigned)slabs), dim3(128), 0, st, q, kv, bias_tables[g],
                            dout, dq, dkv, dtables[g], H, W, C, g, sh, 0.f, 0ull, part_mode);
       DPMN_CHECK_LAUNCH();
+      continue;
+    }
+    if (wb_mfma && ((ws == 16 && (D == 32 || D == 16)) || (ws == 8 && D == 32))) {
+      // 256- / 64-token windows on the matrix cores (wattn_bwd_mfma.hip): one block per (window, head)
+      rc = dpmn_wattn_bwd_mfma(ws, D, q, kv, bias_tables[g], dout, dq, dkv, dtables[g], B, H, W, C, g, sh, p_drop, seed, st, part_mode,
+                               rows_out ? rows_out + g : nullptr);
+      if (rc != DPMN_OK) return rc;
       continue;
     }
     if (rows_out) rows_out[g] = (int)((slabs + 1) / 2);

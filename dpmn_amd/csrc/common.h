@@ -177,7 +177,8 @@ static inline hipStream_t as_stream(dpmn_stream_t s) { return (hipStream_t)s; }
 // load and one branch.
 enum ProfTag { PT_CONV_IGEMM_128 = 0, PT_CONV_IGEMM_64, PT_CONV_IGEMM_NARROW, PT_CONV_SPLITK_REDUCE, PT_CONV_HALO, PT_CONV_HALO_C4,
                PT_GEMM_PW, PT_GEMM_WSTAT, PT_GEMM_KLOOP, PT_DWCONV_GELU, PT_WATTN8, PT_WATTN_SCALAR, PT_ATTN_FUSED, PT_BIGRU,
-               PT_MHA32, PT_PATCH_EMBED, PT_SK_GATE, PT_TAIL, PT_DWPW_FUSED, PT_GEMM_WSTAT_LN, PT_CONV_IGEMM_SK, PT_ATTN_FUSED_BWD, PT_COUNT };
+               PT_MHA32, PT_PATCH_EMBED, PT_SK_GATE, PT_TAIL, PT_DWPW_FUSED, PT_GEMM_WSTAT_LN, PT_CONV_IGEMM_SK, PT_ATTN_FUSED_BWD, PT_WATTN_BWD,
+               PT_CONV_WGRAD, PT_GEMM_TN, PT_TN_REDUCE, PT_DWCONV_BWD, PT_WGRAD_UNPACK, PT_CONV_PACK, PT_AFFINE_ACT_BWD, PT_LN_BWD, PT_WATTN_MFMA32, PT_COUNT };
 extern unsigned long long g_dpmn_prof_mask;
 extern int g_dpmn_bf16;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));

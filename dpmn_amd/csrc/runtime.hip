@@ -16,8 +16,9 @@ int g_dpmn_bf16 = 0;      // dpmn_set_compute_dtype: 1 = bf16 MFMA operands (fp3
 namespace {
 const char* const kTagNames[PT_COUNT] = {
     "k_conv_igemm<128,128>", "k_conv_igemm<64,64>", "k_conv_igemm<128,16|32>", "k_conv_splitk_reduce", "k_conv_halo", "k_conv_halo_c4",
-    "k_gemm_pw", "k_gemm_wstat", "k_gemm_kloop", "k_dwconv_gelu", "k_window_attn8_mfma", "k_window_attn<2|4|16>", "k_ln_qkv_window_attn",
-    "k_bigru", "k_mha32", "k_patch_embed_ln", "k_sk_gate", "k_tail_conv2", "k_mlp_dw_pw", "k_gemm_wstat<LN prologue>", "k_conv_igemm_sk", "k_ln_qkv_window_attn_bwd"};
+    "k_gemm_pw", "k_gemm_wstat|rowreg", "k_gemm_kloop", "k_dwconv_gelu", "k_window_attn8_mfma", "k_window_attn<2|4|16>", "k_ln_qkv_window_attn",
+    "k_bigru", "k_mha32", "k_patch_embed_ln", "k_sk_gate", "k_tail_conv2", "k_mlp_dw_pw", "k_gemm_wstat|rowreg<LN prologue>", "k_conv_igemm_sk", "k_ln_qkv_window_attn_bwd", "k_window_attn_bwd_mfma",
+    "k_conv_wgrad", "k_gemm_tn_reg", "k_tn_reduce_multi", "k_dwconv_bwd", "k_wgrad_unpack_multi", "k_conv_pack_multi", "k_affine_act_bwd", "k_ln_bwd", "k_window_attn_mfma<4|8|16,32>"};
 struct Rec { int tag; double flops, bytes; };
 struct Prof {
   int cap = 0, count = 0;
