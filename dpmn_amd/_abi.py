@@ -224,6 +224,7 @@ SIGNATURES = {
     "dpmn_ln_qkv_window_attn_bwd_part_rows": (_i, [_i, _i, _i]),
     "dpmn_collate_u8_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_profile_tag_count": (_i, []),
+    "dpmn_profile_hint_bytes": (_i, [C.c_double]),
     "dpmn_profile_tag_name": (C.c_char_p, [_i]),
     "dpmn_profile_begin": (_i, [C.c_ulonglong, _i]),
     "dpmn_profile_end": (_i, [C.c_void_p, _i]),

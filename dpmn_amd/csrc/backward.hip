@@ -853,6 +853,7 @@ static int layernorm_bwd_impl(const float* x, const float* dy, const float* gamm
   const unsigned blocks = (unsigned)(M / 8 < cap ? (M + 7) / 8 : cap);
   unsigned nblk = blocks;
   static const int v4 = getenv("DPMN_LNB_V4") ? atoi(getenv("DPMN_LNB_V4")) : 1;
+  ProfScope prof(PT_LN_BWD, as_stream(stream), 0.0, 4.0 * (accumulate_dx ? 4 : 3) * (double)M * C);
   if (C == 96 && v4) {
     // in-pipeline sweep of the vector kernel at M = 49152: 256 blocks 20.2 us, 384: 21.2, 512: 24.3, 768: 27.6, 1024: 33.3
     // (the scalar kernel it replaces: 36.8 us) -- one block per CU, the same-address dgamma / dbeta atomics set the slope

@@ -1208,6 +1208,8 @@ int dpmn_dwconv3x3_bwd_fused_f32(const float* P, const float* dg, const float* g
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
   const bool keep = in_gelu && out_gelu_bwd && gpre && r == 32;
+  // dP (9 taps) + dw (9 taps) = 36 FLOPs per element; P, dg (, gpre) read, dP written
+  ProfScope prof(PT_DWCONV_BWD, as_stream(stream), 36.0 * planes * r * r, 4.0 * (gpre ? 4 : 3) * (double)planes * r * r);
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (keep) hipLaunchKernelGGL(k_dwconv_bwd<true>, dim3((unsigned)dwconv_bwd_grid(planes)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed);
@@ -1227,12 +1229,15 @@ int dpmn_dwconv3x3_bwd_fused_det_f32(const float* P, const float* dg, const floa
   const long planes = (long)B * Ch;
   const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
   const bool keep = in_gelu && out_gelu_bwd && gpre && r == 32;
+  // dP (9 taps) + dw (9 taps) = 36 FLOPs per element; P, dg (, gpre) read, dP written
+  ProfScope prof(PT_DWCONV_BWD, as_stream(stream), 36.0 * planes * r * r, 4.0 * (gpre ? 4 : 3) * (double)planes * r * r);
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (keep) hipLaunchKernelGGL(k_dwconv_bwd<true>, dim3((unsigned)dwconv_bwd_grid(planes)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, ws);
   else hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, ws);
   DPMN_CHECK_LAUNCH();
+  prof.close();      // (the row reduction below is not part of the family)
   return dpmn_rows_reduce_f32(ws, dw, db, Ch * 9, Ch, B, stream);
 }
 

@@ -180,6 +180,7 @@ enum ProfTag { PT_CONV_IGEMM_128 = 0, PT_CONV_IGEMM_64, PT_CONV_IGEMM_NARROW, PT
                PT_MHA32, PT_PATCH_EMBED, PT_SK_GATE, PT_TAIL, PT_DWPW_FUSED, PT_GEMM_WSTAT_LN, PT_CONV_IGEMM_SK, PT_ATTN_FUSED_BWD, PT_WATTN_BWD,
                PT_CONV_WGRAD, PT_GEMM_TN, PT_TN_REDUCE, PT_DWCONV_BWD, PT_WGRAD_UNPACK, PT_CONV_PACK, PT_AFFINE_ACT_BWD, PT_LN_BWD, PT_WATTN_MFMA32, PT_COUNT };
 extern unsigned long long g_dpmn_prof_mask;
+extern double g_dpmn_prof_hint_bytes;      // bytes of the next multi-descriptor launch (its descriptors live on the device)
 extern int g_dpmn_bf16;
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -199,13 +200,16 @@ struct ProfScope {
   hipStream_t st;
   ProfScope(int tag, hipStream_t s, double flops, double bytes);
   ~ProfScope();
+  void close();      // end the bracket before the scope does (further launches of the function are not part of the family)
 };
 int dpmn_prof_open(int tag, hipStream_t st, double flops, double bytes);
 void dpmn_prof_close(int slot, hipStream_t st);
 inline ProfScope::ProfScope(int tag, hipStream_t s, double flops, double bytes) : slot(-1), st(s) {
   if ((g_dpmn_prof_mask >> tag) & 1ull) slot = dpmn_prof_open(tag, s, flops, bytes);
 }
-inline ProfScope::~ProfScope() {
+inline void ProfScope::close() {
   if (slot >= 0) dpmn_prof_close(slot, st);
+  slot = -1;
 }
+inline ProfScope::~ProfScope() { close(); }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

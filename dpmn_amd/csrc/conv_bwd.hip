@@ -869,6 +869,9 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
   }
   a.pix_per_block = ppb; a.gz = splits;
   const dim3 grid((unsigned)(tiles * splits));
+  // 2 M Cout K FLOPs; bytes: the input and dY read once, one (Cout, Kp) partial tile set written per split (exclusive slots)
+  ProfScope prof(PT_CONV_WGRAD, as_stream(stream), 2.0 * M * (double)a.Cout * a.K,
+                 4.0 * ((double)a.B * a.Hin * a.Win * cin + (double)a.B * a.Hout * a.Wout * a.Cout + (double)(a.excl ? splits : 1) * a.Cout * a.K));
   static const int p2_on = getenv("DPMN_WG_P2") ? atoi(getenv("DPMN_WG_P2")) : 1;
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
   bool p2 = p2_on && pow2(a.Hp) && pow2(a.Wp) && (a.pro_act == ACT_NONE || a.pro_act == ACT_RELU || a.pro_act == ACT_LEAKY02) &&
@@ -929,6 +932,7 @@ int dpmn_conv_pack_f32(const float* w, float* wp, int Cout, int cin, int KH, int
                        long s_ky, long s_kx, long base, dpmn_stream_t stream) {
   DPMN_REQUIRE(w && wp && Cout > 0 && cin > 0 && KH > 0 && KW > 0 && KH * KW <= 2304, "conv_pack: bad arguments");
   const PackDesc d = make_pack_desc(w, wp, Cout, cin, KH, KW, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base);
+  ProfScope prof(PT_CONV_PACK, as_stream(stream), 0.0, 4.0 * ((double)d.n_elems + (double)d.co_lim * d.ci_lim * KH * KW));
   hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)pack_tile_blocks(d)), dim3(256), 0, as_stream(stream), d);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -942,6 +946,7 @@ int dpmn_conv_pack_tile_shape(int Cout, int cin, int taps, long s_co, long s_ci,
 
 int dpmn_conv_pack_multi_f32(const void* descs, const int* block_prefix, int n_desc, int n_blocks, dpmn_stream_t stream) {
   DPMN_REQUIRE(descs && block_prefix && n_desc > 0 && n_blocks > 0, "conv_pack_multi: bad arguments");
+  ProfScope prof(PT_CONV_PACK, as_stream(stream), 0.0, g_dpmn_prof_hint_bytes);      // (descriptors live on the device: dpmn_profile_hint_bytes)
   hipLaunchKernelGGL(k_conv_pack_multi, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const PackDesc*>(descs),
                      block_prefix, n_desc);
   DPMN_CHECK_LAUNCH();
@@ -952,6 +957,7 @@ int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int K
                                  long s_ci, long s_ky, long s_kx, long base, int clear, int nslots, dpmn_stream_t stream) {
   DPMN_REQUIRE(dwp && dw && Cout > 0 && cin > 0 && KH > 0 && KW > 0 && KH * KW <= 2304, "conv2d_wgrad_unpack: bad arguments");
   const PackDesc d = make_pack_desc(dw, dwp, Cout, cin, KH, KW, co_lim, ci_lim, s_co, s_ci, s_ky, s_kx, base);
+  ProfScope prof(PT_WGRAD_UNPACK, as_stream(stream), 0.0, 4.0 * ((double)(nslots > 1 ? nslots : 1) * (clear ? 2 : 1) * d.n_elems + (double)d.co_lim * d.ci_lim * KH * KW));
   hipLaunchKernelGGL(k_wgrad_unpack, dim3((unsigned)pack_tile_blocks(d)), dim3(256), 0, as_stream(stream), d, clear, nslots > 1 ? nslots : 1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -959,6 +965,7 @@ int dpmn_conv2d_wgrad_unpack_f32(float* dwp, float* dw, int Cout, int cin, int K
 
 int dpmn_conv2d_wgrad_unpack_multi_f32(const void* descs, const int* block_prefix, int n_desc, int n_blocks, dpmn_stream_t stream) {
   DPMN_REQUIRE(descs && block_prefix && n_desc > 0 && n_blocks > 0, "conv2d_wgrad_unpack_multi: bad arguments");
+  ProfScope prof(PT_WGRAD_UNPACK, as_stream(stream), 0.0, g_dpmn_prof_hint_bytes);
   hipLaunchKernelGGL(k_wgrad_unpack_multi, dim3((unsigned)n_blocks), dim3(256), 0, as_stream(stream), reinterpret_cast<const PackDesc*>(descs),
                      block_prefix, n_desc);
   DPMN_CHECK_LAUNCH();
@@ -985,6 +992,7 @@ int dpmn_affine_act_bwd_f32(const float* dA, const float* r, const float* scale,
   DPMN_REQUIRE(dA && r && G && pixels > 0 && C > 0, "affine_act_bwd: bad arguments");
   const long total = pixels * C;
   const bool lin = act == ACT_NONE || act == ACT_RELU || act == ACT_LEAKY02 || act == ACT_LEAKY001;      // (the only ones the old kernel handles too)
+  ProfScope prof(PT_AFFINE_ACT_BWD, as_stream(stream), 0.0, 4.0 * (accumulate ? 4 : 3) * (double)total);
   if (C % 4 == 0 && lin)
     hipLaunchKernelGGL(k_affine_act_bwd_v4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, as_stream(stream), dA, r, scale, shift,
                        act, G, accumulate, total / 4, C / 4);
@@ -1004,6 +1012,7 @@ int dpmn_affine_act_bwd_stats_f32(const float* dA, const float* r, const float* 
   int ppb = (int)((pixels + 2047) / 2048);       // <= 2048 blocks: one fp64 atomic pair per channel and block
   const int pl = 256 / (C / 4);
   if (ppb < 8 * pl) ppb = 8 * pl;                // two 4-pixel rounds per thread at least
+  ProfScope prof(PT_AFFINE_ACT_BWD, as_stream(stream), 0.0, 4.0 * (accumulate ? 4 : 3) * (double)pixels * C);
   hipLaunchKernelGGL(k_affine_act_bwd_stats, dim3((unsigned)((pixels + ppb - 1) / ppb)), dim3(256), 0, as_stream(stream), dA, r, scale,
                      shift, act, G, accumulate, pixels, C, mean, rstd, sums, ppb);
   DPMN_CHECK_LAUNCH();

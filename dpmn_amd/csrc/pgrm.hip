@@ -551,7 +551,7 @@ int launch_window_attn_mfma(const float* q, const float* kv, const float* table,
     attr_set = true;
   }
   const long sets = (long)B * (H * W / ROWS);
-  ProfScope prof(PT_WATTN_SCALAR, st, 4.0 * N * D * 2 * (double)B * H * W, 4.0 * 4 * CG * (double)B * H * W);
+  ProfScope prof(PT_WATTN_MFMA32, st, 4.0 * N * D * 2 * (double)B * H * W, 4.0 * 4 * CG * (double)B * H * W);
   hipLaunchKernelGGL((k_window_attn_mfma<WS, D>), dim3((unsigned)((sets + SETS - 1) / SETS)), dim3(WS == 16 ? 512 : 256), smem, st, q, kv, table,
                      out, B, H, W, C, g, shift);
   DPMN_CHECK_LAUNCH();

@@ -12,6 +12,7 @@ int dpmn_set_error(int code, const char* msg) {
 
 // ------------------------------------------------------------------ in-pipeline kernel profiler (common.h ProfScope)
 unsigned long long g_dpmn_prof_mask = 0ull;
+double g_dpmn_prof_hint_bytes = 0.0;
 int g_dpmn_bf16 = 0;      // dpmn_set_compute_dtype: 1 = bf16 MFMA operands (fp32 accumulation) in the kernels that have the variant
 namespace {
 const char* const kTagNames[PT_COUNT] = {
@@ -43,6 +44,7 @@ int dpmn_get_compute_dtype(void) { return g_dpmn_bf16; }
 const char* dpmn_last_error(void) { return g_err; }
 
 int dpmn_profile_tag_count(void) { return PT_COUNT; }
+int dpmn_profile_hint_bytes(double bytes) { g_dpmn_prof_hint_bytes = bytes; return DPMN_OK; }
 const char* dpmn_profile_tag_name(int tag) { return tag >= 0 && tag < PT_COUNT ? kTagNames[tag] : ""; }
 
 int dpmn_profile_begin(unsigned long long tag_mask, int max_launches) {

@@ -130,9 +130,11 @@ class PackCache:
                 raise RuntimeError("dpmn_amd PackCache: the descriptor table must be built before hipGraph capture (it uploads from "
                                    "the host); run at least two eager steps first (graphed_train_step warmup >= 2)")
             raw, prefix, nb = bytearray(), [], 0
+            self.bytes = 0.0       # compulsory bytes of the launch (bench.py's per-family table: dpmn_profile_hint_bytes)
             shape = (ctypes.c_int * 3)()
             for key in self.order:
                 out, w, (cout_p, cin_p, kh, kw, co_lim, ci_lim, st) = self.entries[key]
+                self.bytes += 4.0 * (out.numel() + min(co_lim, cout_p) * min(ci_lim, cin_p) * kh * kw)
                 K = kh * kw * cin_p
                 kp = out.shape[1]
                 check(lib.dpmn_conv_pack_tile_shape(cout_p, cin_p, kh * kw, st[0], st[1], ctypes.cast(shape, ctypes.c_void_p)))
@@ -146,6 +148,7 @@ class PackCache:
             descs = torch.frombuffer(raw, dtype=torch.uint8).to(dev)
             self.table = (descs, torch.tensor(prefix, dtype=torch.int32, device=dev), nb)
         descs, prefix, nb = self.table
+        lib.dpmn_profile_hint_bytes(self.bytes)
         check(lib.dpmn_conv_pack_multi_f32(descs.data_ptr(), prefix.data_ptr(), len(self.order), nb, stream()))
         self.fresh = self.epoch
 

@@ -276,9 +276,11 @@ class UnpackQueue:
             return
         if self.table is None:
             raw, prefix, nb = bytearray(), [], 0
+            self.bytes = 0.0       # compulsory bytes of the launch: every slot read once, the parameter-layout gradient read + written
             shape = (C.c_int * 3)()
             for key in self.order:
                 ws, dw, (cout, cin, kh, kw, co, ci, st), slots = self.entries[key]
+                self.bytes += 4.0 * (ws.numel() + 2 * min(co, cout) * min(ci, cin) * kh * kw)
                 K = kh * kw * cin
                 kp = (K + 31) // 32 * 32
                 check(lib.dpmn_conv_pack_tile_shape(cout, cin, kh * kw, st[0], st[1], C.cast(shape, C.c_void_p)))
@@ -291,6 +293,7 @@ class UnpackQueue:
             dev = self.entries[self.order[0]][0].device
             self.table = (torch.frombuffer(raw, dtype=torch.uint8).to(dev), torch.tensor(prefix, dtype=torch.int32, device=dev), nb)
         descs, prefix, nb = self.table
+        lib.dpmn_profile_hint_bytes(self.bytes)
         check(lib.dpmn_conv2d_wgrad_unpack_multi_f32(descs.data_ptr(), prefix.data_ptr(), len(self.order), nb, stream()))
         self.touched.clear()
 

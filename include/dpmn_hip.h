@@ -135,6 +135,9 @@ typedef struct {
   double bytes;     /* compulsory HBM bytes (inputs read once + outputs written once) */
 } dpmn_profile_row;
 int dpmn_profile_tag_count(void);
+/* compulsory bytes of the NEXT multi-descriptor pack / unpack launches (their descriptor tables live on the device, the host
+ * side that built them knows the sizes); only read while that family is armed */
+int dpmn_profile_hint_bytes(double bytes);
 const char* dpmn_profile_tag_name(int tag);
 int dpmn_profile_begin(unsigned long long tag_mask, int max_launches);
 int dpmn_profile_end(dpmn_profile_row* rows, int max_rows);

@@ -19,8 +19,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = [("k_conv_igemm<128, 128", "k_conv_igemm<128,128>"), ("k_conv_igemm<64, 64", "k_conv_igemm<64,64>"),
             ("k_conv_igemm<128, 16", "k_conv_igemm<128,16|32>"), ("k_conv_igemm<128, 32", "k_conv_igemm<128,16|32>"),
             ("k_conv_splitk_reduce", "k_conv_splitk_reduce"), ("k_conv_halo_c4", "k_conv_halo_c4"), ("k_conv_halo<", "k_conv_halo"),
-            ("k_gemm_pw", "k_gemm_pw"), ("k_gemm_wstat<96, 1", "k_gemm_wstat<LN prologue>"), ("k_gemm_wstat<192, 1", "k_gemm_wstat<LN prologue>"),
-            ("k_gemm_wstat", "k_gemm_wstat"), ("k_gemm_kloop", "k_gemm_kloop"), ("k_dwconv_gelu", "k_dwconv_gelu"),
+            ("k_gemm_pw", "k_gemm_pw"), ("k_gemm_wstat<96, 1", "k_gemm_wstat|rowreg<LN prologue>"), ("k_gemm_wstat<192, 1", "k_gemm_wstat|rowreg<LN prologue>"),
+            ("k_gemm_rowreg<96, 1", "k_gemm_wstat|rowreg<LN prologue>"), ("k_gemm_rowreg<192, 1", "k_gemm_wstat|rowreg<LN prologue>"),
+            ("k_gemm_wstat", "k_gemm_wstat|rowreg"), ("k_gemm_rowreg", "k_gemm_wstat|rowreg"), ("k_gemm_kloop", "k_gemm_kloop"),
+            ("k_gemm_tn", "k_gemm_tn_reg"), ("k_affine_act_bwd", "k_affine_act_bwd"), ("k_ln_bwd", "k_ln_bwd"),
+            ("k_window_attn_mfma<", "k_window_attn_mfma<4|8|16,32>"), ("k_conv_pack", "k_conv_pack_multi"), ("k_wgrad_unpack", "k_wgrad_unpack_multi"), ("k_dwconv_gelu", "k_dwconv_gelu"),
             ("k_window_attn8_mfma", "k_window_attn8_mfma"), ("k_window_attn<", "k_window_attn<2|4|16>"), ("k_ln_qkv_window_attn_bwd", "k_ln_qkv_window_attn_bwd"), ("k_ln_qkv_window_attn", "k_ln_qkv_window_attn"),
             ("k_bigru", "k_bigru"), ("k_mha32", "k_mha32")]
 
@@ -75,7 +78,10 @@ def do_collect(tag):
         if f:
             shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, name)))
     B = 48
-    for name in ("bench_default", "bench_train", "bench_train_drop", "bench_cfg3", "bench_cfg4"):
+    f = os.path.join(src, "pmc_pgrm_mfma_util.csv")
+    if os.path.exists(f):
+        shutil.copy(f, os.path.join(dst, "%s_pmc_pgrm_mfma_util.csv" % tag))
+    for name in ("bench_default", "bench_train", "bench_train_drop", "bench_train_nodrop", "bench_cfg3", "bench_cfg4", "bench_cfg4_train"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p) and open(p).read().strip().startswith("{"):
             shutil.copy(p, os.path.join(dst, "%s_%s.json" % (tag, name)))

@@ -14,6 +14,9 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $B --steps 3 --warmup 2 > $OUT/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $B --steps 3 --warmup 2 > $OUT/pmc_write.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma -- $B --steps 3 --warmup 2 > $OUT/pmc_mfma.log 2>&1
+# BASELINE.json's second metric: MFMA-busy over PGRM forwards only (bench.py pgrm_mfma_util reads the TOTAL row)
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_pgrm -- python $R/tools/prof_pgrm.py 48 > $OUT/pmc_mfma_pgrm.log 2>&1
+python $R/tools/pmc_pgrm_util.py $OUT/pmc_mfma_pgrm $OUT/pmc_pgrm_mfma_util.csv > /dev/null 2>&1
 if [ "${1:-}" != "quick" ]; then
   T="$B --mode train --steps 3 --warmup 2"
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_train -- $T > $OUT/pmc_fetch_train.log 2>&1
@@ -24,7 +27,8 @@ cd $R
 timeout 900 python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 timeout 600 python bench.py --mode train 2>/dev/null | tail -1 > $OUT/bench_train.json
 if [ "${1:-}" != "quick" ]; then
-  timeout 600 python bench.py --mode train --drop 0.1 2>/dev/null | tail -1 > $OUT/bench_train_drop.json
+  timeout 600 python bench.py --mode train --drop 0 2>/dev/null | tail -1 > $OUT/bench_train_nodrop.json
+  timeout 900 python bench.py --workload cfg4 --mode train --steps 5 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg4_train.json
   timeout 600 python bench.py --workload cfg3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg3.json
   timeout 900 python bench.py --workload cfg4 --steps 5 --warmup 6 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg4.json
 fi
