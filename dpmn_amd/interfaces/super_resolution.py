@@ -210,11 +210,32 @@ class TextSR(base.TextBase):
         fn = text_prior_fn or self.default_text_prior()
         psnr, ssim, n = [], [], 0
         n_correct, n_labelled = 0, 0
-        # the batches of an evaluation pass are independent: two of them in flight (RefinePipeline); the metrics of a batch are
-        # queued on this stream behind the lane that produced it
+        # the batches of an evaluation pass are independent: two of them in flight (RefinePipeline).  The loop is software-pipelined:
+        # batch i + 1 is prepared and SUBMITTED before this stream waits for batch i and queues its metrics -- a lane is ordered
+        # behind this stream at submit time, so metrics queued before the submit would chain the lanes one after the other
         # (not with the recogniser-driven prior: the VisionLAN mirrors keep one set of activations per module, not per stream)
-        pipe = RefinePipeline(self, model_list, model_psn, 2) if (EVAL_PIPELINE and self.device.type == "cuda" and not self.args.sr_share and
-                                                                   not hasattr(fn, "recognizers")) else None
+        pipe = None
+        if EVAL_PIPELINE and self.device.type == "cuda" and not self.args.sr_share and not hasattr(fn, "recognizers"):
+            key = (tuple(id(m) for m in model_list), id(model_psn))
+            cached = getattr(self, "_eval_pipe", None)
+            if cached is None or cached[0] != key:      # one pipeline (lane + branch streams, hence one workspace set) per model list
+                cached = self._eval_pipe = (key, RefinePipeline(self, model_list, model_psn, 2))
+            pipe = cached[1]
+
+        def finish(sr, images_hr, labels):
+            nonlocal n, n_correct, n_labelled
+            if pipe is not None:
+                RefinePipeline.wait(sr)
+            p, s = ops.psnr_ssim(sr, images_hr)
+            psnr.append(p)
+            ssim.append(s)
+            n += sr.shape[0]
+            if callable(rec) and labels is not None:
+                for pred, target in zip(rec(sr[:, :3]), labels):
+                    n_correct += int(pred == str_filt(target, 'lower'))
+                n_labelled += len(labels)
+
+        pending = None
         for data in val_loader:
             images_hr, images_lr = data[0].to(self.device), data[1].to(self.device)
             label_vecs = data[2].to(self.device) if len(data) > 2 and data[2] is not None else None
@@ -222,18 +243,16 @@ class TextSR(base.TextBase):
                 label_vecs = self.label_vecs_from_crnn(images_lr)
             if getattr(self.args, "rotate_test", 0):      # super_resolution.py:358-365 (angle range from rotate_train, as there)
                 images_lr, images_hr = self.rotate_pair(images_lr, images_hr, self.args.rotate_train)
+            labels = data[3] if len(data) > 3 else None
             if pipe is not None:
-                sr = RefinePipeline.wait(pipe.submit(images_lr, label_vecs, text_prior_fn=fn))
+                sr = pipe.submit(images_lr, label_vecs, text_prior_fn=fn)
+                if pending is not None:
+                    finish(*pending)
+                pending = (sr, images_hr, labels)
             else:
-                sr = self.refine(model_list, model_psn, images_lr, label_vecs, fn)
-            p, s = ops.psnr_ssim(sr, images_hr)
-            psnr.append(p)
-            ssim.append(s)
-            n += images_lr.shape[0]
-            if callable(rec) and len(data) > 3 and data[3] is not None:
-                for pred, target in zip(rec(sr[:, :3]), data[3]):
-                    n_correct += int(pred == str_filt(target, 'lower'))
-                n_labelled += len(data[3])
+                finish(self.refine(model_list, model_psn, images_lr, label_vecs, fn), images_hr, labels)
+        if pending is not None:
+            finish(*pending)
         psnr_avg = float(torch.stack(psnr).mean().item())
         ssim_avg = float(torch.stack(ssim).mean().item())
         accuracy = round(n_correct / n_labelled, 4) if n_labelled else None
@@ -479,6 +498,14 @@ class TextSR(base.TextBase):
         val_int = getattr(getattr(cfg, "VAL", None), "valInterval", None) or 80
         log_path = os.path.join(getattr(cfg, "ckpt_dir", None) or ".", "log.csv")
         best, best_info, converge = None, {}, []
+        best_hist = {}         # best_history_acc[data_name] of the reference (super_resolution.py:299-313)
+        # validation subsets: {data_name: loader | callable -> loader}; a bare loader / callable is one subset named "val"
+        if val_loader is None:
+            val_sets = []
+        elif isinstance(val_loader, dict):
+            val_sets = list(val_loader.items())
+        else:
+            val_sets = [("val", val_loader)]
         if callable(loader):
             passes = loader
             n_epochs = epochs if epochs is not None else int(getattr(cfg, "epochs", 1) or 1)
@@ -489,9 +516,15 @@ class TextSR(base.TextBase):
             passes = lambda _e: loader
             n_epochs = epochs if epochs is not None else int(getattr(cfg, "epochs", 1) or 1)
 
-        def save(epoch, it, is_best):
+        def save(epoch, it, is_best, metric="sum"):
             if rank == 0:
-                self.save_checkpoint(models, epoch, it, {'score': best}, best_info, is_best, converge, None, trainer=trainer)
+                self.save_checkpoint(models, epoch, it, dict(best_hist, score=best), best_info, is_best, converge, None, metric=metric, trainer=trainer)
+
+        def log_row(row):
+            if rank == 0:
+                os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
+                with open(log_path, "a+", newline="") as out:
+                    csv.writer(out).writerow(row)
 
         it, epoch, saved_at = 0, 0, -1
         for epoch in range(n_epochs):
@@ -509,30 +542,48 @@ class TextSR(base.TextBase):
             handle = None
             while nxt is not None:
                 hr, lr, lv = nxt
-                nxt = next(batches, None)                  # one batch of look-ahead: its frozen-PSN image is computed during this step
+                # one batch of look-ahead (its frozen-PSN image is computed during this step) -- fetched before the step is issued only
+                # when the prefetch can be used: not past the last requested step (a one-shot loader would lose the batch), not with
+                # rotate_train (the PSN sees the rotated batch, which does not exist yet)
+                ahead = (steps is None or it + 1 < steps) and not getattr(self.args, "rotate_train", 0)
+                nxt = next(batches, None) if ahead else None
                 nxt = on_device(nxt) if nxt is not None else None
                 loss = self.train_step(models, psn, distill, crit, trainer, lr, hr, lv, text_prior_fn=fn, psn_out=handle,
                                        prefetch=None if nxt is None else (nxt[1], nxt[2]))
                 handle = self.psn_prefetched
+                if not ahead and not (steps is not None and it + 1 >= steps):      # no look-ahead: fetch the next batch after the step was issued
+                    nxt = next(batches, None)
+                    nxt = on_device(nxt) if nxt is not None else None
                 it += 1
                 if it % cfg.displayInterval == 0 and rank == 0:
                     print('Epoch: [%d] iter %d | Loss: %f' % (epoch, it, float(loss)))
-                if val_loader is not None and it % val_int == 0:
+                if val_sets and it % val_int == 0:
+                    # super_resolution.py:293-330: every validation subset on its own -- a log.csv row and a best-so-far checkpoint
+                    # per data_name -- and the best model overall by the SUM of the subsets' scores (score = recognition accuracy
+                    # when `rec` computes one, as in the reference; PSNR otherwise: the recognisers are out of scope)
                     trainer.sync_params()
-                    md = self.eval(models, val_loader() if callable(val_loader) else val_loader, epoch, rec=rec, model_psn=psn, text_prior_fn=fn)
+                    current, psnr_d, ssim_d = {}, {}, {}
+                    for data_name, vl in val_sets:
+                        md = self.eval(models, vl() if callable(vl) else vl, epoch, rec=rec, model_psn=psn, text_prior_fn=fn)
+                        converge.append({'iterator': it, 'acc': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']})
+                        score = md['accuracy'] if md['accuracy'] is not None else md['psnr_avg']
+                        current[data_name], psnr_d[data_name], ssim_d[data_name] = float(score), md['psnr_avg'], md['ssim_avg']
+                        new_best = data_name not in best_hist or score > best_hist[data_name]
+                        if new_best:
+                            best_hist[data_name] = float(score)
+                            best_hist['epoch'] = epoch
+                            best_info = {'accuracy': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']}
+                            if len(val_sets) > 1:
+                                save(epoch, it, True, data_name)
+                        log_row([epoch, data_name, md['accuracy'], md['psnr_avg'], md['ssim_avg']] + (["best_%s" % data_name] if new_best else []))
                     for m_ in models + distill:
                         m_.train()
-                    converge.append({'iterator': it, 'acc': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']})
-                    score = md['accuracy'] if md['accuracy'] is not None else md['psnr_avg']
-                    is_best = best is None or score > best
-                    if is_best:
-                        best = score
-                        best_info = {'accuracy': md['accuracy'], 'psnr': md['psnr_avg'], 'ssim': md['ssim_avg']}
+                    total = sum(current.values())
+                    if best is None or total > best:
+                        best = total
+                        best_info = {'accuracy': dict(current, epoch=epoch), 'psnr': psnr_d, 'ssim': ssim_d}
                         save(epoch, it, True)
-                    if rank == 0:
-                        os.makedirs(os.path.dirname(log_path) or ".", exist_ok=True)
-                        with open(log_path, "a+", newline="") as out:
-                            csv.writer(out).writerow([epoch, "val", md['accuracy'], md['psnr_avg'], md['ssim_avg'], "", "best_sum" if is_best else ""])
+                        log_row([epoch, "", "", "", "", "", "best_sum"])
                 if it % cfg.saveInterval == 0:
                     save(epoch, it, False)
                     saved_at = it

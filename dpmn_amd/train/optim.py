@@ -83,6 +83,11 @@ class FlatBucket:
             for p in self.params:
                 p._dpmn_sink = p.grad
             module._dpmn_bucket = self
+        # caches keyed by the OLD gradient sinks / parameter list (train/pgrm_train.py UnpackQueue, params_of): a second Trainer or
+        # bucket for the same module must not inherit them -- stale sink keys would keep the one-launch unpack from ever matching
+        # again and hold the old slot workspaces alive
+        module.__dict__.pop("_unpack_queue", None)
+        module.__dict__.pop("_dpmn_plist", None)
         self.n = n
         self.normsq = torch.zeros(1, device=dev)
         self.part = torch.empty(1024, device=dev)

@@ -82,7 +82,9 @@ def main(config, args):
             val_dirs = (config.TRAIN.VAL or {}).get("val_data_dir") or []
             val_dls = mission.get_val_data()[1] if val_dirs and all(os.path.isdir(d) for d in val_dirs) else []
             # eval every VAL.valInterval over every validation subset + best-model checkpoints (super_resolution.py:283-337)
-            val_loader = (lambda: (b for vdl in val_dls for b in sr_batches(vdl, mission.device, mission.mask))) if val_dls else None
+            # one entry per validation subset (easy / medium / hard): evaluated, logged and check-pointed separately, best model by the sum
+            val_loader = {os.path.basename(os.path.normpath(d)): (lambda v=vdl: sr_batches(v, mission.device, mission.mask))
+                          for d, vdl in zip(val_dirs, val_dls)} if val_dls else None
             mission.train(lambda epoch: sr_batches(dl, mission.device, mission.mask), epochs=config.TRAIN.epochs,
                           sampler=getattr(mission, "train_sampler", None), val_loader=val_loader)
         else:

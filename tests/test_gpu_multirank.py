@@ -108,7 +108,7 @@ def _train_worker(rank, world, port, out_dir, q):
                 yield hr, lr
         vb = synth.synth_batch(4, seed=5)
         val = [(vb["images_hr"][:2], vb["images_lr"][:2]), (vb["images_hr"][2:], vb["images_lr"][2:])]
-        models, distill = sr.train(passes, val_loader=lambda: val, sampler=sampler)
+        models, distill = sr.train(passes, val_loader={"easy": lambda: val[:1], "hard": lambda: val[1:]}, sampler=sampler)
         trainer = sr.trainer
         torch.cuda.synchronize()
         p1 = trainer.flat_p.clone()
@@ -163,5 +163,10 @@ def test_train_loop_world2_two_epochs_eval_checkpoint_reload(tmp_path):
     assert [b for e, b in res[0][3] if e == 0] != [b for e, b in res[0][3] if e == 1], "DistributedSampler.set_epoch was not applied"
     ck = os.listdir(os.path.join(out, "ckpt"))
     assert "checkpoint.pth" in ck and any(f.startswith("model_best_sum_") for f in ck), ck
+    # super_resolution.py:293-330: every validation subset is evaluated, logged and check-pointed on its own (evals at iterations
+    # 4 and 8, written by rank 0 only), the best model overall goes by the sum over the subsets
+    assert any(f.startswith("model_best_easy_") for f in ck) and any(f.startswith("model_best_hard_") for f in ck), ck
     rows = open(os.path.join(out, "log.csv")).read().strip().splitlines()
-    assert len(rows) == 2 and all(",val," in r_ for r_ in rows), rows          # evals at iterations 4 and 8, written by rank 0 only
+    assert sum(",easy," in r_ for r_ in rows) == 2 and sum(",hard," in r_ for r_ in rows) == 2, rows
+    assert any(r_.endswith("best_easy") for r_ in rows) and any(r_.endswith("best_hard") for r_ in rows) and any(r_.endswith("best_sum") for r_ in rows), rows
+    assert len(rows) <= 6, rows

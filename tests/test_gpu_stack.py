@@ -202,3 +202,40 @@ def test_refine_pipeline_two_lanes_equals_sequential():
     got = RefinePipeline.wait(pipe.submit(*batches[0][:2], text_priors=batches[0][2]))
     assert torch.equal(got + 0, seq[0])
     assert torch.equal(sr.refine(models, psn, batches[1][0], batches[1][1], text_priors=batches[1][2]), seq[1])
+
+
+def test_eval_loop_keeps_two_batches_in_flight_and_equals_one_at_a_time(monkeypatch):
+    """TextSR.eval (super_resolution.py:340-513) with the software-pipelined loop: batch i + 1 is submitted to its lane before
+    the metrics of batch i are queued, so two batches really are in flight -- bitwise the PSNR / SSIM of the one-at-a-time
+    loop, in less wall time at the bench batch (the overlap bench.py's --pipeline 2 line measures), one cached pipeline per
+    model list (no new lane / branch streams, hence no new workspace sets, per eval call)."""
+    import time
+    from dpmn_amd import workload
+    from dpmn_amd.interfaces import super_resolution as srm
+    from helpers import record
+    dev = torch.device("cuda:0")
+    sr, models, psn, inp = workload.build("cfg1")
+    B = inp["images_lr"].shape[0]
+    batches = []
+    for i in range(8):
+        b = synth.synth_batch(B, seed=80 + i)
+        batches.append((b["images_hr"].to(dev), b["images_lr"].to(dev), b["label_vecs"].to(dev)))
+
+    def run(on):
+        monkeypatch.setattr(srm, "EVAL_PIPELINE", on)
+        sr.eval(models, batches[:2], model_psn=psn)      # warm-up (workspaces of the lanes)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = sr.eval(models, batches, model_psn=psn)
+        torch.cuda.synchronize()
+        return res, time.perf_counter() - t0
+
+    seq, t_seq = run(False)
+    pipe, t_pipe = run(True)
+    assert len(pipe["psnr"]) == len(seq["psnr"]) == 8
+    assert all(torch.equal(a, b) for a, b in zip(pipe["psnr"], seq["psnr"])) and all(torch.equal(a, b) for a, b in zip(pipe["ssim"], seq["ssim"]))
+    p1 = sr._eval_pipe[1]
+    sr.eval(models, batches[:2], model_psn=psn)
+    assert sr._eval_pipe[1] is p1, "a second eval of the same model list must reuse the pipeline"
+    record("eval_loop_pipeline", "wall time two-in-flight / one-at-a-time (8 batches of %d)" % B, t_pipe / t_seq, 1.0)
+    assert t_pipe < t_seq, "two batches in flight must beat one at a time: %.2f vs %.2f ms per batch" % (t_pipe / 8 * 1e3, t_seq / 8 * 1e3)
