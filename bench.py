@@ -55,9 +55,11 @@ def parse():
     ap.add_argument("--prior", default="synthetic", choices=["synthetic", "visionlan"],
                     help="branch-1 text priors: precomputed synthetic tensors (default) or the in-loop batched VisionLAN + glyph-atlas "
                          "pipeline inside the timed step (BASELINE.json configs[3]: 'VisionLAN text-prior branch enabled')")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "x3"],
                     help="arithmetic of the GEMM-shaped kernels: f32 (the reference's precision, the headline) or bf16 MFMA operands with fp32 "
-                         "accumulation (BASELINE.json configs[2..4] name bf16; a separate line, never the headline)")
+                         "accumulation (BASELINE.json configs[2..4] name bf16; a separate line, never the headline); x3 = fp32 products as six "
+                         "bf16 MFMAs of an exact three-term operand split in the kernels that have the variant (fp32-class results; "
+                         "a separate line until its parity record is accepted)")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="fwd mode: batches in flight (interfaces/super_resolution.py RefinePipeline: batch i runs on lane i %% N, so the "
                          "single-stream PSN / CMM phases of one batch overlap the next batch's work); 1 = one batch at a time")
@@ -461,7 +463,7 @@ def main():
         else:
             dist.init_process_group(backend)
     from dpmn_amd import workload, _abi
-    _abi.check(_abi.lib.dpmn_set_compute_dtype(1 if args.dtype == "bf16" else 0))
+    _abi.check(_abi.lib.dpmn_set_compute_dtype({"f32": 0, "bf16": 1, "x3": 2}[args.dtype]))
     spec = workload.describe(args.workload)
     arch, b1, b2 = spec["arch"], spec["b1"], spec["b2"]
     if args.mode == "train":
@@ -506,7 +508,8 @@ def main():
             "value": round(world * B * args.steps / elapsed, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16 MFMA operands in the implicit-GEMM convs / pointwise GEMM, fp32 accumulation, storage and statistics",
+            "dtype": {"f32": "f32", "bf16": "bf16 MFMA operands in the implicit-GEMM convs / pointwise GEMM, fp32 accumulation, storage and statistics",
+                      "x3": "f32 via bf16x3 (pointwise GEMM: six bf16 MFMAs of an exact three-term operand split, fp32-class products; every other kernel plain f32)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": "%s: %s, %s" % (
                 args.workload, spec["text"],

@@ -182,6 +182,7 @@ enum ProfTag { PT_CONV_IGEMM_128 = 0, PT_CONV_IGEMM_64, PT_CONV_IGEMM_NARROW, PT
 extern unsigned long long g_dpmn_prof_mask;
 extern double g_dpmn_prof_hint_bytes;      // bytes of the next multi-descriptor launch (its descriptors live on the device)
 extern int g_dpmn_bf16;
+extern int g_dpmn_x3;       // dpmn_set_compute_dtype(2): fp32 products as six bf16 MFMAs of a three-term operand split (kernels that have the variant)
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // four fp32 -> four bf16 (round to nearest even, v_cvt_pk_bf16_f32) as two dwords

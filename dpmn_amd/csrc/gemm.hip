@@ -814,6 +814,166 @@ __global__ __launch_bounds__(256, 2) void k_gemm_pw_bf16(const float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------- pointwise GEMM, fp32 through three bf16 terms
+// dpmn_set_compute_dtype(2) ("f32 via bf16x3"): the fp32 pipe of gfx950 (v_mfma_f32_16x16x4_f32, 157 TFLOP/s) is the roof k_gemm_pw has
+// sat under for four rounds (0.76-0.78); the bf16 pipe is 16 x wider.  An fp32 value splits EXACTLY into three bf16 terms,
+//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)   (8 + 8 + 8 mantissa bits, round to nearest),
+// and a product keeps the six terms of weight >= 2^-16:  x y ~= x0 y0 + (x0 y1 + x1 y0) + (x0 y2 + x1 y1 + x2 y0); the three dropped
+// ones are <= 2^-23 |x y| -- the rounding class of one fp32 multiply.  Accumulation stays fp32 inside the MFMA.  Six
+// v_mfma_f32_16x16x32_bf16 per (tile, 32-deep chunk): 2500 / 6 = 417 TFLOP/s of fp32-equivalent work at the bf16 peak.
+// Same 128 x BC tile and staging layouts as k_gemm_pw_bf16, one LDS buffer holding the three planes of both operands (71 KB at
+// BC = 192, two blocks per CU) with the next chunk's rows prefetched into registers; the split (11 vector instructions per pair of
+// values) runs once per staged element, between the two barriers of a chunk -- the other resident block's MFMAs cover it.
+__device__ __forceinline__ unsigned x3_pack2(float a, float b) {
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2));
+}
+// (a, b) -> three dwords of bf16 pairs (low half = a's term)
+#ifndef X3_ABLATE_SPLIT
+#define X3_ABLATE_SPLIT 0      // timing experiment only: 1 = no split arithmetic (all three planes = the rounded value)
+#endif
+__device__ __forceinline__ void x3_split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  h = x3_pack2(a, b);
+  if (X3_ABLATE_SPLIT) { m = h; l = h; return; }
+  float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
+  m = x3_pack2(ra, rb);
+  ra -= __uint_as_float(m << 16); rb -= __uint_as_float(m & 0xffff0000u);
+  l = x3_pack2(ra, rb);
+}
+// Persistent: one 512-thread block per CU walks its tiles (768 tiles of 128 x 192 at B = 48, Ch = 384 = exactly 3 per CU; a
+// 2-blocks-per-CU launch of the same tiles needs two rounds, the second half empty).  Both LDS buffers fit (2 x 71 KB): chunk
+// k + 1 is split and stored while the other waves still multiply chunk k -- one barrier per chunk; its rows are loaded BEFORE the
+// MFMA block of chunk k (scheduling barriers keep hipcc from sinking the loads to their use).  Wave (ws_, wc_) = 64 (s) x 48 (co)
+// of the tile.  Tile order: the co blocks of one (image, s tile) run side by side on one XCD (they share the G rows).
+template <int BC>
+__global__ __launch_bounds__(512, 1) void k_gemm_pw_bf16x3(const float* g, const float* w, const float* __restrict__ bias, float* z, int Ch,
+                                                            int L, int B) {
+  constexpr int BS = 128, BK = 32, LDP = BS + 4, LDWB = BK + 8, NJ = BC / 64, TH = 512;
+  constexpr int GPL = (BK / 2) * LDP, WPL = BC * LDWB;            // one plane of G (dwords) / of W (bf16)
+  constexpr int BUF = 3 * GPL + 3 * WPL / 2;                      // dwords per buffer
+  constexpr int WQ = BC * BK / 4 / TH;                            // float4 of the W chunk per thread (3 at BC = 192, 2 at 128)
+  static_assert(BC * BK / 4 % TH == 0 && WQ <= 3, "W chunk: whole float4 per thread");
+  extern __shared__ __attribute__((aligned(16))) unsigned x3smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ns = L / BS, nco = Ch / BC;
+  const int tiles = ns * nco * B;
+  const int gp_ = tid >> 5, gcol = (tid & 31) * 4;      // pair row gp_ (channels 2 gp_, 2 gp_ + 1), 4 consecutive s
+  const int wrow = tid >> 3, wcol = (tid & 7) * 4;      // W rows wrow (+64 per pass), 4 consecutive k
+  const int ws_ = wave & 1, wc_ = wave >> 1;            // 2 (s) x 4 (co) waves
+  const int lr = lane & 15, kq = lane >> 4;
+  typedef unsigned u32x4__ __attribute__((ext_vector_type(4)));
+  const int nk = Ch / BK;
+  const int go = gp_ * LDP + gcol;                       // LDS offsets of this thread's stores
+  const int wo = wrow * LDWB + wcol;
+  const bool xcd_order = tiles % 8 == 0 && gridDim.x % 8 == 0;
+  int round = 0;
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x, ++round) {
+    // XCD x takes a contiguous eighth of the (image, s tile, co block) list
+    const int lt = xcd_order ? (int)(blockIdx.x & 7) * (tiles / 8) + round * (int)(gridDim.x / 8) + (int)(blockIdx.x >> 3) : t;
+    const int cb = lt % nco, sb = (lt / nco) % ns, b = lt / (nco * ns);
+    const int s_blk = sb * BS, c_blk = cb * BC;
+    const float* gsrc = g + (size_t)b * Ch * L + (size_t)(2 * gp_) * L + s_blk + gcol;      // + k0 * L
+    const float* wsrc = w + (size_t)(c_blk + wrow) * Ch + wcol;                              // + k0 (+ 64 q rows)
+    float* zb = z + (size_t)b * Ch * L;
+    // two named register sets (a, b) hold the chunks kt + 1 and kt + 2: a set is loaded right after the split + store that frees it,
+    // a whole barrier + MFMA block before it is consumed, so the split / LDS stores of chunk kt + 1 can be dealt into the MFMA block
+    // of chunk kt (no scheduling barrier between them) instead of running, exposed, between the last MFMA and the barrier
+    float4 ag0, ag1, aw0, aw1, aw2, bg0, bg1, bw0, bw1, bw2;
+#define X3_GLOAD(P, k0)                                                                           \
+    do {                                                                                          \
+      P##g0 = *reinterpret_cast<const float4*>(gsrc + (size_t)(k0) * L);                          \
+      P##g1 = *reinterpret_cast<const float4*>(gsrc + (size_t)((k0) + 1) * L);                    \
+      P##w0 = *reinterpret_cast<const float4*>(wsrc + (k0));                                      \
+      P##w1 = *reinterpret_cast<const float4*>(wsrc + (size_t)64 * Ch + (k0));                    \
+      if (WQ > 2) P##w2 = *reinterpret_cast<const float4*>(wsrc + (size_t)128 * Ch + (k0));       \
+    } while (0)
+#define X3_WST(buf, q, V)                                                                         \
+    do {                                                                                          \
+      uint2 h2, m2, l2;                                                                           \
+      x3_split2(V.x, V.y, h2.x, m2.x, l2.x);                                                      \
+      x3_split2(V.z, V.w, h2.y, m2.y, l2.y);                                                      \
+      unsigned short* d_ = reinterpret_cast<unsigned short*>((buf) + 3 * GPL) + wo + (q) * 64 * LDWB; \
+      *reinterpret_cast<uint2*>(d_) = h2;                                                         \
+      *reinterpret_cast<uint2*>(d_ + WPL) = m2;                                                   \
+      *reinterpret_cast<uint2*>(d_ + 2 * WPL) = l2;                                               \
+    } while (0)
+#define X3_SSTORE(P, buf)                                                                         \
+    do {                                                                                          \
+      uint4 h4, m4, l4;                                                                           \
+      x3_split2(P##g0.x, P##g1.x, h4.x, m4.x, l4.x);                                              \
+      x3_split2(P##g0.y, P##g1.y, h4.y, m4.y, l4.y);                                              \
+      x3_split2(P##g0.z, P##g1.z, h4.z, m4.z, l4.z);                                              \
+      x3_split2(P##g0.w, P##g1.w, h4.w, m4.w, l4.w);                                              \
+      *reinterpret_cast<uint4*>((buf) + go) = h4;                                                 \
+      *reinterpret_cast<uint4*>((buf) + GPL + go) = m4;                                           \
+      *reinterpret_cast<uint4*>((buf) + 2 * GPL + go) = l4;                                       \
+      X3_WST(buf, 0, P##w0); X3_WST(buf, 1, P##w1);                                               \
+      if (WQ > 2) X3_WST(buf, 2, P##w2);                                                          \
+    } while (0)
+#define X3_TERM(PA, PW)                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                 \
+          _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16_bf16(a3[i][PA], wf[PW][j], acc[i][j]);
+#define X3_MMA(cur)                                                                               \
+    do {                                                                                          \
+      const unsigned short* Wb = reinterpret_cast<const unsigned short*>((cur) + 3 * GPL);        \
+      bf16x8 wf[3][NJ];                                                                           \
+      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                            \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                            \
+          wf[pl][j] = *reinterpret_cast<const bf16x8*>(Wb + pl * WPL + (wc_ * (BC / 4) + j * 16 + lr) * LDWB + kq * 8); \
+      const unsigned* gp = (cur) + (kq * 4) * LDP + ws_ * 64 + lr;                                \
+      bf16x8 a3[4][3];                                                                            \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
+        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                        \
+          const unsigned* q = gp + pl * GPL + i * 16;                                             \
+          const u32x4__ av = {q[0], q[LDP], q[2 * LDP], q[3 * LDP]};                              \
+          a3[i][pl] = __builtin_bit_cast(bf16x8, av);                                             \
+        }                                                                                         \
+      /* six terms, smallest first; consecutive MFMAs go to different accumulators */             \
+      X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 2) X3_TERM(1, 0) X3_TERM(0, 1) X3_TERM(0, 0)         \
+    } while (0)
+    f32x4 acc[4][NJ];   // [s tile][co tile]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned* buf0 = x3smem;
+    unsigned* buf1 = x3smem + BUF;
+    __syncthreads();                       // the previous tile's last chunk is consumed
+    X3_GLOAD(a, 0);
+    X3_SSTORE(a, buf0);
+    X3_GLOAD(a, min(1, nk - 1) * BK);      // (past the end: clamped re-reads / a spare store, never a conditional load)
+    X3_GLOAD(b, min(2, nk - 1) * BK);
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+      X3_MMA(buf0);
+      X3_SSTORE(a, buf1);                  // chunk kt + 1; buf1's readers passed the previous barrier
+      X3_GLOAD(a, min(kt + 3, nk - 1) * BK);
+      __syncthreads();
+      if (kt + 1 >= nk) break;
+      X3_MMA(buf1);
+      X3_SSTORE(b, buf0);                  // chunk kt + 2
+      X3_GLOAD(b, min(kt + 4, nk - 1) * BK);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int co = c_blk + wc_ * (BC / 4) + j * 16 + lr;
+      const float bv = bias[co];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int s_ = s_blk + ws_ * 64 + i * 16 + kq * 4;
+        *reinterpret_cast<float4*>(zb + (size_t)co * L + s_) =
+            make_float4(acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
+      }
+    }
+  }
+#undef X3_GLOAD
+#undef X3_WST
+#undef X3_SSTORE
+#undef X3_TERM
+#undef X3_MMA
+}
+
 // ---------------------------------------------------------------------------------- whole-K, rows straight into the B operand
 // The scheme of the fused attention kernel's projection (attn_fused.hip) for the K <= 192 token GEMMs: a WAVE owns a 16-token
 // tile; lane (j = l & 15, kq = l >> 4) loads x[token j][16 c + 4 kq .. + 3] straight from global memory into the MFMA B-operand
@@ -1540,12 +1700,59 @@ int dpmn_pointwise_wgrad_det_f32(const float* dz, const float* g, float* dw, int
   return dpmn_rows_reduce_f32(ws, dw, nullptr, Ch * Ch, 0, S, stream);
 }
 
+// per-stream device scratch of the bf16x3 variants (weight planes): grows on demand, never shrinks; stream-ordered reuse
+static void* x3_scratch(hipStream_t st, size_t bytes) {
+  struct Ent { hipStream_t st; void* p; size_t n; };
+  static Ent tab[16];
+  static int cnt = 0;
+  for (int i = 0; i < cnt; ++i)
+    if (tab[i].st == st) {
+      if (tab[i].n >= bytes) return tab[i].p;
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(tab[i].p);
+      tab[i].p = nullptr; tab[i].n = 0;
+      if (hipMalloc(&tab[i].p, bytes) != hipSuccess) return nullptr;
+      tab[i].n = bytes;
+      return tab[i].p;
+    }
+  if (cnt >= 16) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  tab[cnt++] = Ent{st, p, bytes};
+  return p;
+}
+static int x3_cu_count() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+  }
+  return n_cu;
+}
+
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
                        dpmn_stream_t stream) {
   DPMN_REQUIRE(g && w && bias && z && Ch % 128 == 0 && L % 128 == 0, "pointwise: Ch and L must be multiples of 128");
   static const int pw_bc = getenv("DPMN_PW_BC") ? atoi(getenv("DPMN_PW_BC")) : 192;
   ProfScope prof(PT_GEMM_PW, as_stream(stream), 2.0 * Ch * Ch * (double)L * B, 4.0 * (2.0 * B * Ch * (double)L + (double)Ch * Ch + Ch));
-  if (g_dpmn_bf16 && Ch % 192 == 0)
+  if (g_dpmn_x3) {
+    // fp32 product through six bf16 MFMAs of a three-term operand split (dpmn_set_compute_dtype(2))
+    constexpr int LDP_ = 132, LDWB_ = 40;
+    const int bc = Ch % 192 == 0 ? 192 : 128;
+    const size_t smem = (size_t)2 * 3 * (16 * LDP_ * 4 + bc * LDWB_ * 2);
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pw_bf16x3<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (16 * LDP_ * 4 + 192 * LDWB_ * 2));
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pw_bf16x3<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (16 * LDP_ * 4 + 128 * LDWB_ * 2));
+      attr_set = true;
+    }
+    const long tiles = (long)(L / 128) * (Ch / bc) * B;
+    const int n_cu = x3_cu_count();
+    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
+    if (bc == 192) hipLaunchKernelGGL((k_gemm_pw_bf16x3<192>), dim3(grid), dim3(512), smem, as_stream(stream), g, w, bias, z, Ch, L, B);
+    else hipLaunchKernelGGL((k_gemm_pw_bf16x3<128>), dim3(grid), dim3(512), smem, as_stream(stream), g, w, bias, z, Ch, L, B);
+  } else if (g_dpmn_bf16 && Ch % 192 == 0)
     hipLaunchKernelGGL((k_gemm_pw_bf16<192>), dim3(L / 128, Ch / 192, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
   else if (g_dpmn_bf16)
     hipLaunchKernelGGL((k_gemm_pw_bf16<128>), dim3(L / 128, Ch / 128, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);

@@ -13,6 +13,7 @@ int dpmn_set_error(int code, const char* msg) {
 // ------------------------------------------------------------------ in-pipeline kernel profiler (common.h ProfScope)
 unsigned long long g_dpmn_prof_mask = 0ull;
 double g_dpmn_prof_hint_bytes = 0.0;
+int g_dpmn_x3 = 0;
 int g_dpmn_bf16 = 0;      // dpmn_set_compute_dtype: 1 = bf16 MFMA operands (fp32 accumulation) in the kernels that have the variant
 namespace {
 const char* const kTagNames[PT_COUNT] = {
@@ -39,8 +40,13 @@ void dpmn_prof_close(int slot, hipStream_t st) { (void)hipEventRecord(g_prof.ev[
 
 extern "C" {
 int dpmn_abi_version(void) { return 5; }
-int dpmn_set_compute_dtype(int bf16) { g_dpmn_bf16 = bf16 ? 1 : 0; return DPMN_OK; }
-int dpmn_get_compute_dtype(void) { return g_dpmn_bf16; }
+int dpmn_set_compute_dtype(int mode) {
+  DPMN_REQUIRE(mode >= 0 && mode <= 2, "set_compute_dtype: 0 = f32, 1 = bf16 operands, 2 = f32 via three bf16 terms");
+  g_dpmn_bf16 = mode == 1;
+  g_dpmn_x3 = mode == 2;
+  return DPMN_OK;
+}
+int dpmn_get_compute_dtype(void) { return g_dpmn_x3 ? 2 : g_dpmn_bf16; }
 const char* dpmn_last_error(void) { return g_err; }
 
 int dpmn_profile_tag_count(void) { return PT_COUNT; }

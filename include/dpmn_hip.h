@@ -33,10 +33,13 @@ enum { DPMN_ACT_NONE = 0, DPMN_ACT_GELU = 1, DPMN_ACT_RELU = 2, DPMN_ACT_LEAKY02
 int dpmn_abi_version(void);
 const char* dpmn_last_error(void);
 /* Arithmetic of the GEMM-shaped kernels (BASELINE.json configs[2..4] name bf16; the reference itself is fp32 and fp32 is the
- * default and the headline): bf16 != 0 -> the kernels that have the variant (implicit-GEMM conv, pointwise GEMM) round their MFMA
- * operands to bf16 on the way into LDS and run v_mfma_f32_16x16x32_bf16 with fp32 accumulation; tensors in HBM, LayerNorm /
- * softmax / BatchNorm statistics and every epilogue stay fp32.  Process-wide switch, not thread-safe. */
-int dpmn_set_compute_dtype(int bf16);
+ * default and the headline).  mode 0: v_mfma_f32_16x16x4_f32 on fp32 operands.  mode 1: the kernels that have the variant
+ * (implicit-GEMM conv, pointwise GEMM) round their MFMA operands to bf16 on the way into LDS and run v_mfma_f32_16x16x32_bf16
+ * with fp32 accumulation.  mode 2 ("f32 via bf16x3"): the kernels that have the variant split every fp32 operand EXACTLY into
+ * three bf16 terms and keep the six product terms of weight >= 2^-16 -- fp32-class products (relative error <= 2^-23 each)
+ * on the bf16 pipe, 6 MFMAs per 16x16x32 step; kernels without the variant stay on mode 0.  Tensors in HBM, LayerNorm / softmax /
+ * BatchNorm statistics and every epilogue are fp32 in all modes.  Process-wide switch, not thread-safe. */
+int dpmn_set_compute_dtype(int mode);
 int dpmn_get_compute_dtype(void);
 
 /* ------------------------------------------------------------------ GEMM family (gemm.hip) */
