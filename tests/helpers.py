@@ -51,14 +51,15 @@ def assert_close(a, b, atol, rtol=0.0, what=""):
 # ---------------------------------------------------------------------------------------------------------------------
 # Gradient fixtures: a gradient tensor is stored in full up to 4096 elements; larger ones as a digest -- float64 norm and
 # sum, 64 evenly strided samples, and one projection onto a seeded probe vector (tools/gen_golden.py gen_grads/gen_step).
-def grad_digest(name, g):
+def grad_digest(name, g, f64=False):
+    """f64: keep the digest entries in float64 (the float64 "truth" fixtures, tools/gen_golden.py gen_f64)"""
     g = g.detach().double().reshape(-1)
     n = g.numel()
     if n <= 4096:
-        return {"full": g.float().numpy()}
+        return {"full": g.numpy() if f64 else g.float().numpy()}
     probe = synth.uniform("probe::" + name, (n,), -1.0, 1.0, 77).double()
     step = n // 64
-    return {"norm": np.array(float(g.norm())), "sum": np.array(float(g.sum())), "samples": g[::step][:64].float().numpy(),
+    return {"norm": np.array(float(g.norm())), "sum": np.array(float(g.sum())), "samples": g[::step][:64].numpy() if f64 else g[::step][:64].float().numpy(),
             "proj": np.array(float((g * probe).sum())), "absmax": np.array(float(g.abs().max()))}
 
 
@@ -87,6 +88,34 @@ def grad_error_vs_fixture(npz, key, g):
     n = g.numel()
     e_proj = abs(float(d["proj"]) - float(npz[key + "::proj"])) / (norm * (n / 3.0) ** 0.5 / n ** 0.5 + 1e-30)
     return max(e_norm, e_smp, e_proj), amax
+
+
+def check_vs_f64(test, z, named, prefix="", factor=3.0, floor=1e-5):
+    """Adjudicated gradient check against a float64 fixture (tools/gen_golden.py gen_f64).  Per tensor t (relative error metric of
+    grad_error_vs_fixture): e_ours[t] = our gradient vs the float64 result, e_ref[t] = the REFERENCE's own fp32 gradient vs it (stored
+    in the fixture).  fp32 round-off is order-dependent, so single tensors scatter by several x either way (the CPU oracle -- the
+    reference's arithmetic in another operation order -- has per-tensor ratios from 0.1 to 12); the statement that holds and is
+    asserted is per MODEL: our worst tensor and our RMS over the tensors are within `factor` of the reference's own worst / RMS
+    (floor: models fp32 gets right to 1e-5 anyway).  The oracle measures 2.2 (worst) / 2.1 (RMS) at most.
+    Exactly-zero true gradients (|f64| < 2e-3: conv biases in front of a batch-statistics BatchNorm, quirk Q11's unused weight_list)
+    must stay at round-off level.  Returns (worst ratio, rms ratio)."""
+    ours, ref, names = [], [], []
+    for n in fixture_grad_names(z, prefix):
+        err, amax = grad_error_vs_fixture(z, prefix + n, named[n])
+        if amax < 2e-3:
+            assert float(torch.as_tensor(named[n]).abs().max()) < 5e-3, n
+            continue
+        ours.append(err); ref.append(float(z[prefix + n + "::ref32_err"])); names.append(n)
+    ours, ref = np.array(ours), np.array(ref)
+    iw = int(ours.argmax())
+    r_worst = float(ours.max() / max(ref.max(), floor))
+    r_rms = float(np.sqrt((ours ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), floor))
+    record(test, "%sworst tensor vs float64: ours %.2e (%s) / reference fp32 %.2e" % (prefix, ours.max(), names[iw], ref.max()), r_worst, factor)
+    record(test, "%sRMS over %d tensors vs float64: ours %.2e / reference fp32 %.2e" % (prefix, len(names), float(np.sqrt((ours ** 2).mean())),
+                                                                                     float(np.sqrt((ref ** 2).mean()))), r_rms, factor)
+    assert r_worst <= factor and r_rms <= factor, "%s%s: gradients are %.1fx (worst tensor %s) / %.1fx (RMS) as far from the float64 result as the reference's own fp32 gradients (allowed %.1fx)" % (
+        test, prefix, r_worst, names[iw], r_rms, factor)
+    return r_worst, r_rms
 
 
 # ---------------------------------------------------------------------------------------------------------------------

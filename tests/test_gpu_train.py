@@ -636,7 +636,14 @@ def test_cmm_backward_vs_reference_gradient_fixture(dev, cnum):
     (out * cot).sum().backward()
     named = {"x1": x1.grad, "x2": x2.grad}
     named.update({n: p.grad for n, p in m.named_parameters()})
-    _fixture_check("cmm_grads_cnum%d" % cnum, g, named, tol=1e-5 if cnum == 8 else 3e-2)      # B = 2: 8-sample BatchNorm statistics at the bottleneck
+    if cnum == 8:
+        _fixture_check("cmm_grads_cnum8", g, named, tol=1e-5)
+    else:
+        # B = 2: 8-sample BatchNorm statistics at the 1 x 4 bottleneck -- the reference's OWN fp32 gradients are up to 6.6e-3 away from
+        # a float64 run of the same modules (tests/golden/grads_cmm_cnum64_f64.npz, tools/gen_golden.py gen_f64), so a tolerance
+        # against the fp32 fixture says nothing: the float64 result arbitrates (helpers.check_vs_f64)
+        from helpers import check_vs_f64
+        check_vs_f64("cmm_grads_cnum64_f64", load_golden("grads_cmm_cnum64_f64"), named)
 
 
 def test_training_step_vs_reference_step_fixture(dev):
@@ -663,18 +670,22 @@ def test_training_step_vs_reference_step_fixture(dev):
     le = abs(float(loss) - float(g["loss"])) / abs(float(g["loss"]))
     record("step_fixture", "loss rel err vs reference", le, 1e-5)
     assert le < 1e-5
+    # gradients: adjudicated by the float64 run of the same step (tests/golden/step_tsrn_2p2_f64.npz): per model, our worst tensor /
+    # RMS error against float64 within helpers.check_vs_f64's factor of the reference's own fp32 gradients' (which are up to 5.6e-3
+    # off at this batch of 2); the clip norm likewise against the float64 norm
+    from helpers import check_vs_f64
+    z = load_golden("step_tsrn_2p2_f64")
+    l64 = abs(float(loss) - float(z["loss"])) / abs(float(z["loss"]))
+    record("step_fixture_f64", "loss rel err vs float64 (reference fp32: %.1e)" % float(z["loss_ref32_err"]), l64, 3.0 * float(z["loss_ref32_err"]) + 2e-7)
+    assert l64 <= 3.0 * float(z["loss_ref32_err"]) + 2e-7
     for i, m in enumerate(models + distill):
         named = {n: p.grad for n, p in m.named_parameters()}
         norm = float(torch.sqrt(sum((v.double() ** 2).sum() for v in named.values())))
-        ne = abs(norm - float(g["grad_norms"][i])) / float(g["grad_norms"][i])
-        # 3x the recorded errors (r03l), floor 1e-5.  Clip norm: PGRMs 1.1e-4, CMM 1.4e-6, DistillModules 2.9e-7 / 3.3e-5; worst
-        # tensor vs the reference's own gradients: PGRMs 4.2e-3, CMM 6e-3 (the fp32-conditioned 1 x 4 BatchNorm levels, see
-        # tests/test_oracle_grads.py), DistillModules 2.6e-6 / 7.5e-4
-        ntol = 3.3e-4 if i < b1 + b2 else 1e-5 if i <= b1 + b2 + 1 else 1e-4
-        gtol = 1.25e-2 if i < b1 + b2 else 2e-2 if i == b1 + b2 else 1e-5 if i == b1 + b2 + 1 else 2.5e-3
-        record("step_fixture", "model %d clip-norm rel err" % i, ne, ntol)
-        assert ne < ntol, "model %d: the norm clip_grad_norm_ sees differs from the reference's by %.2e" % (i, ne)
-        _fixture_check("step_fixture", g, named, "m%d/" % i, tol=gtol)
+        ne = abs(norm - float(z["grad_norms"][i])) / float(z["grad_norms"][i])
+        ntol = 3.0 * float(z["grad_norms_ref32_err"][i]) + 1e-5
+        record("step_fixture_f64", "model %d clip-norm rel err vs float64 (reference fp32: %.1e)" % (i, float(z["grad_norms_ref32_err"][i])), ne, ntol)
+        assert ne < ntol, "model %d: the norm clip_grad_norm_ sees is %.2e from the float64 norm (reference fp32: %.2e)" % (i, ne, float(z["grad_norms_ref32_err"][i]))
+        check_vs_f64("step_fixture_f64", z, named, "m%d/" % i)
 
 
 def test_test_mode_loads_every_checkpoint_including_cmm(dev, tmp_path):

@@ -166,3 +166,32 @@ def test_oracle_train_loss_equals_reference_step_fixture():
     n = b1 + b2
     loss = odpmn.train_loss(sd0[0], sd0[1:1 + n], sd0[2 + n:], sd0[1 + n], "tsrn", b1, b2, batch["images_lr"], batch["images_hr"], None, priors)
     assert abs(float(loss) - float(g["loss"])) < 2e-5 * abs(float(g["loss"]))
+
+
+def test_oracle_gradients_are_as_close_to_float64_as_the_reference_fp32():
+    """The two loose gradient fixtures adjudicated by float64 runs of the imported reference (tests/golden/*_f64.npz,
+    tools/gen_golden.py gen_f64): at B = 2 the CMM's 1 x 4 bottleneck BatchNorm sees 8 samples and the reference's OWN fp32
+    gradients are up to 6.6e-3 (cnum-64 CMM) / 5.6e-3 (step) away from the float64 result.  The oracle -- the same arithmetic in
+    another operation order -- must stay within helpers.check_vs_f64's per-model factor of that (measured: <= 2.2)."""
+    from oracle import cmm as ocmm
+    from helpers import check_vs_f64
+    B = 2
+    z = load_golden("grads_cmm_cnum64_f64")
+    x1 = synth.uniform("cmm_x1", (B, 3, 32, 128), 0, 1, 7).requires_grad_(True)
+    x2 = synth.uniform("cmm_x2", (B, 3, 32, 128), 0, 1, 7).requires_grad_(True)
+    cot = synth.uniform("cmm_cot", (B, 3, 32, 128), -1, 1, 7)
+    sd = _leaf_sd(sd_from_manifest(load_golden("cmm_cnum64")["manifest"], 31))
+    out = ocmm.cmm_forward(sd, x1, x2, True)
+    (out * cot).sum().backward()
+    named = {"x1": x1.grad, "x2": x2.grad}
+    named.update({k: v.grad for k, v in sd.items() if v.requires_grad})
+    check_vs_f64("oracle_cmm_cnum64_f64", z, named)
+    z = load_golden("step_tsrn_2p2_f64")
+    b1 = b2 = 2
+    sd0 = step_state_dicts(b1, b2)
+    batch = synth.synth_batch(B, seed=4)
+    priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)) for k in range(b1)]
+    loss, imgs, grads = oracle_step(sd0, batch, priors, b1, b2)
+    assert abs(float(loss) - float(z["loss"])) / float(z["loss"]) <= 1.5 * float(z["loss_ref32_err"]) + 2e-7
+    for i, g in enumerate(grads):
+        check_vs_f64("oracle_step_f64", z, g, "m%d/" % i)

@@ -420,6 +420,109 @@ def gen_step():
         arrs["grad_norms"] = np.array(norms)
         save("step_tsrn_2p2", **arrs)
 
+# ------------------------------------------------------------------------------------ float64 adjudication of the gradient fixtures
+def f64_arrays(prefix, named64, named32):
+    """Digests of the float64 gradients plus, per tensor, `ref32_err`: how far the reference's OWN fp32 gradient is from that
+    float64 result under the metric the tests use (helpers.grad_error_vs_fixture) -- the yardstick for the HIP path's error."""
+    from tests.helpers import grad_digest, grad_error_vs_fixture
+    out = {}
+    for name, g in named64:
+        for k, v in grad_digest(name, g, f64=True).items():
+            out["%s%s::%s" % (prefix, name, k)] = v
+
+    class _Npz(dict):
+        files = property(lambda self: list(self.keys()))
+    z = _Npz(out)
+    for name, g32 in named32:
+        err, _ = grad_error_vs_fixture(z, prefix + name, g32)
+        out["%s%s::ref32_err" % (prefix, name)] = np.array(err)
+    return out
+
+
+def gen_f64():
+    """The reference modules in float64 (`.double()`, the SAME fp32 synthetic weights and inputs, exactly representable) as the
+    arbiter of the two loose gradient fixtures: grads_cmm_cnum64 (B = 2: 8-sample BatchNorm statistics at the 1 x 4 bottleneck
+    make the fp32 gradients ill-conditioned) and step_tsrn_2p2.  A fixture holds float64 digests and, per tensor, the error of
+    the reference's own fp32 gradient against them; the GPU tests require err(HIP, f64) <= 1.5 x err(reference fp32, f64)."""
+    from model import tsrn, pgrm, cmm, distill_module
+    from loss import image_loss
+    from oracle import cmm as ocmm
+    with torch.enable_grad():
+        B = 2
+        x1 = synth.uniform("cmm_x1", (B, 3, 32, 128), 0, 1, 7)
+        x2 = synth.uniform("cmm_x2", (B, 3, 32, 128), 0, 1, 7)
+        cot = synth.uniform("cmm_cot", (B, 3, 32, 128), -1, 1, 7)
+        named = {}
+        for dt in (torch.float32, torch.float64):
+            m = cmm.ComplementationModulationModule(cnum=64).train()
+            sd = m.state_dict()
+            synth.synth_fill_(sd, seed=31)
+            m.load_state_dict({k: v.clone() for k, v in sd.items()})
+            m = m.to(dt)
+            a, b = x1.detach().clone().to(dt).requires_grad_(True), x2.detach().clone().to(dt).requires_grad_(True)
+            out = m(a, b)
+            (out * cot.to(dt)).sum().backward()
+            named[dt] = [("x1", a.grad), ("x2", b.grad)] + [(n, p.grad) for n, p in m.named_parameters()]
+            if dt == torch.float64:
+                out64 = out.detach()
+        save("grads_cmm_cnum64_f64", out=out64.numpy(), **f64_arrays("", named[torch.float64], named[torch.float32]))
+
+        b1 = b2 = 2
+        batch = synth.synth_batch(B, seed=4)
+        priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)) for k in range(b1)]
+        res, masks = {}, None
+        for dt in (torch.float32, torch.float64):
+            psn = tsrn.TSRN(scale_factor=2, width=128, height=32, STN=False, mask=True, srb_nums=5, hidden_units=32).eval()
+            mods = [pgrm.PGRM(iter=k, mode=False, hidden_size=3, **pgrm_args(4)).train() for k in range(b1)]
+            mods += [pgrm.PGRM(iter=k, mode=True, hidden_size=3, **pgrm_args(4)).train() for k in range(b1, b1 + b2)]
+            mods.append(cmm.ComplementationModulationModule().train())
+            distill = [distill_module.DistillModule().train() for _ in range(b1 + b2 - 2)]
+            for i, m in enumerate([psn] + mods + distill):
+                sd = m.state_dict()
+                synth.synth_fill_(sd, seed=300 + i)
+                m.load_state_dict({k: v.clone() for k, v in sd.items()})
+                m.to(dt)
+            crit = image_loss.ImageLoss(gradient=True, loss_weight=[1, 1])
+            hr = batch["images_hr"].to(dt)
+            with torch.no_grad():
+                lr_psn = psn(batch["images_lr"].to(dt))
+            loss = 0
+            casc, l1 = lr_psn, []
+            for k in range(b1):
+                sr = mods[k](priors[k].to(dt), casc[:, :3, :], l1[:k]); l1.append(sr); casc = sr
+                loss = loss + crit(sr, hr[:, :3, :]).mean() * 100
+            casc, l2 = lr_psn, []
+            new_masks = []
+            for k in range(b1, b1 + b2):
+                # the mask prior is a threshold (discontinuous): the float64 run takes the fp32 run's masks, so that both
+                # differentiate the same function
+                mk = ocmm.to_mask(casc.detach()[:, :3].float()) if masks is None else masks[k - b1]
+                new_masks.append(mk)
+                sr = mods[k](mk.to(dt), casc[:, :3, :], l2[:(k - b2)]); l2.append(sr); casc = sr
+                loss = loss + crit(sr, hr[:, :3, :]).mean() * 100
+            masks = masks or new_masks
+            feat = l1[-1]
+            for k in range(b1 - 1, 0, -1):
+                ld, feat = distill[k - 1](feat, l1[k - 1]); loss = loss + ld.sum() * 100
+            feat = l2[-1]
+            for k in range(b2 - 1, 0, -1):
+                ld, feat = distill[k + b1 - 2](feat, l2[k - 1]); loss = loss + ld.sum() * 100
+            out = mods[-1](l1[-1], l2[-1])
+            loss = (loss + crit(out, hr[:, :3, :]).mean() * 100) / (b1 + b2 + 1)
+            loss.backward()
+            res[dt] = (float(loss.detach()), [[(n, p.grad if p.grad is not None else torch.zeros_like(p)) for n, p in m.named_parameters()]
+                                              for m in mods + distill])
+        arrs = dict(loss=np.array(res[torch.float64][0]), loss_ref32_err=np.array(abs(res[torch.float32][0] - res[torch.float64][0]) / abs(res[torch.float64][0])))
+        norms, norm_err = [], []
+        for i, (n64, n32) in enumerate(zip(res[torch.float64][1], res[torch.float32][1])):
+            arrs.update(f64_arrays("m%d/" % i, n64, n32))
+            a = float(torch.sqrt(sum((g.double() ** 2).sum() for _, g in n64)))
+            b_ = float(torch.sqrt(sum((g.double() ** 2).sum() for _, g in n32)))
+            norms.append(a); norm_err.append(abs(a - b_) / a)
+        arrs["grad_norms"] = np.array(norms)
+        arrs["grad_norms_ref32_err"] = np.array(norm_err)
+        save("step_tsrn_2p2_f64", **arrs)
+
 
 def gen_visionlan():
     """VisionLAN (the branch-1 text-prior recogniser) in eval mode through the imported reference: per-step logits captured at
@@ -470,7 +573,7 @@ def gen_visionlan():
          manifest=manifest(sd), checksum=checksum(sd))
 
 
-GENS = {"tpgsr": gen_tpgsr, "visionlan": gen_visionlan, "grads": gen_grads, "step": gen_step, "stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
+GENS = {"f64": gen_f64, "tpgsr": gen_tpgsr, "visionlan": gen_visionlan, "grads": gen_grads, "step": gen_step, "stack": gen_stack, "psn": gen_psn, "pgrm": gen_pgrm, "parts": gen_parts, "cmm": gen_cmm, "distill": gen_distill, "loss": gen_loss, "rotate": gen_rotate, "stn": gen_stn_layout, "stn_fwd": gen_stn_fwd}
 
 
 
