@@ -414,10 +414,12 @@ int launch_window_attn8_mfma(const float* q, const float* kv, const float* table
 //   * a wave = (64-query slab, head) walks its 4 query tiles; per tile S^T = K Q^T over the KT key tiles the tile's windows
 //     cover (1, 4, 16), Q read straight from global memory in operand order, P kept in the accumulator registers, O^T = V^T P.
 // Relative-position bias and shift mask are looked up per logit like in the scalar kernel (pgrm.py:234-243).
-template <int WS, int D>
+// DROP: attn_drop (pgrm.py:248) on the normalised probabilities, as in the other window-attention kernels (counter-based masks).
+template <int WS, int D, bool DROP = false>
 __global__ __launch_bounds__((WS == 16 ? 512 : 256)) void k_window_attn_mfma(const float* __restrict__ q, const float* __restrict__ kv,
                                                                              const float* __restrict__ bias_table, float* __restrict__ out,
-                                                                             int B, int H, int W, int C, int g, int shift) {
+                                                                             int B, int H, int W, int C, int g, int shift, float p_drop = 0.f,
+                                                                             unsigned long long seed = 0ull) {
   constexpr int N = WS * WS, CG = 2 * D, DC = D / 16, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1);
   constexpr int ROWS = WS == 16 ? 256 : 64;            // tokens of one key set
   constexpr int SETS = WS == 16 ? 1 : 2;               // key sets per block
@@ -520,6 +522,14 @@ __global__ __launch_bounds__((WS == 16 ? 512 : 256)) void k_window_attn_mfma(con
     den += xshfl<16>(den);
     den += xshfl<32>(den);
     const float inv = 1.0f / den;
+    if (DROP) {      // mask element ((((b G + g) 2 + head) L + window-major query token) N + key row in the window), include/dpmn_hip.h
+      const float inv_keep = 1.0f / (1.0f - p_drop);
+      const unsigned long long mrow = ((((unsigned long long)b * (C / CG) + g) * 2 + head) * L + t0 + rq) * N;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sacc[kt][r] *= drop_scale(seed, mrow + (kbase + 16 * kt + 4 * kq + r) % N, p_drop, inv_keep);
+    }
     // O^T = V^T . P: A = V^T[d = 16 dt + lr][key], B = P (the accumulator registers)
     f32x4 oacc[DC];
 #pragma unroll
@@ -540,20 +550,20 @@ __global__ __launch_bounds__((WS == 16 ? 512 : 256)) void k_window_attn_mfma(con
   }
 }
 
-template <int WS, int D>
+template <int WS, int D, bool DROP = false>
 int launch_window_attn_mfma(const float* q, const float* kv, const float* table, float* out, int B, int H, int W, int C, int g,
-                            int shift, hipStream_t st) {
+                            int shift, hipStream_t st, float p_drop = 0.f, unsigned long long seed = 0ull) {
   constexpr int N = WS * WS, CG = 2 * D, LDR = CG + 4, TBL = (2 * WS - 1) * (2 * WS - 1), ROWS = WS == 16 ? 256 : 64, SETS = WS == 16 ? 1 : 2;
   const size_t smem = (size_t)(((TBL * 2 + 3) & ~3) + SETS * 2 * ROWS * LDR) * 4 + (size_t)SETS * ROWS * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn_mfma<WS, D>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_window_attn_mfma<WS, D, DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     attr_set = true;
   }
   const long sets = (long)B * (H * W / ROWS);
   ProfScope prof(PT_WATTN_MFMA32, st, 4.0 * N * D * 2 * (double)B * H * W, 4.0 * 4 * CG * (double)B * H * W);
-  hipLaunchKernelGGL((k_window_attn_mfma<WS, D>), dim3((unsigned)((sets + SETS - 1) / SETS)), dim3(WS == 16 ? 512 : 256), smem, st, q, kv, table,
-                     out, B, H, W, C, g, shift);
+  hipLaunchKernelGGL((k_window_attn_mfma<WS, D, DROP>), dim3((unsigned)((sets + SETS - 1) / SETS)), dim3(WS == 16 ? 512 : 256), smem, st, q, kv, table,
+                     out, B, H, W, C, g, shift, p_drop, seed);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -845,7 +855,12 @@ int dpmn_window_attn_drop_f32(const float* q, const float* kv, const float* cons
       if (rc != DPMN_OK) return rc;
       continue;
     }
-    if (D == 32 && wa_mfma && p_drop == 0.f && (ws == 4 || ws == 8 || ws == 16) && (H * W) % (ws == 16 ? 256 : 64) == 0) {
+    if (D == 32 && wa_mfma && (ws == 4 || ws == 8 || ws == 16) && (H * W) % (ws == 16 ? 256 : 64) == 0) {
+      if (p_drop > 0.f)
+        rc = ws == 4 ? launch_window_attn_mfma<4, 32, true>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st, p_drop, seed)
+                     : (ws == 8 ? launch_window_attn_mfma<8, 32, true>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st, p_drop, seed)
+                                : launch_window_attn_mfma<16, 32, true>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st, p_drop, seed));
+      else
       rc = ws == 4 ? launch_window_attn_mfma<4, 32>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st)
                    : (ws == 8 ? launch_window_attn_mfma<8, 32>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st)
                               : launch_window_attn_mfma<16, 32>(q, kv, bias_tables[g], out, B, H, W, C, g, sh, st));

@@ -96,6 +96,24 @@ def test_window_attention_backward_head_dim32_windows_4_8_16_vs_oracle_autograd(
         assert_close(got, want, 1e-6 * max(1.0, float(want.abs().max())), 1e-4, "%s table %d (partial rows)" % (tag, i))
 
 
+@pytest.mark.parametrize("shifted", [False, True])
+def test_window_attention_forward_head_dim32_with_attn_drop_vs_oracle(dev, shifted):
+    """Training forward of the head-dim-32 groups with attn_drop on the matrix cores (k_window_attn_mfma<4|8|16, 32, DROP>): the same
+    counter-based masks as the oracle (pgrm.py:248), windows 4 / 8 / 16 on a 32 x 128 token grid."""
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    B, H, W, C = 2, 32, 128, DIM
+    shifts = [w // 2 for w in WINS] if shifted else [0, 0, 0]
+    q, kv = u("f_q", (B, H * W, C), -2, 2), u("f_kv", (B, H * W, 2 * C), -2, 2)
+    sd = {"relative_position_bias_table_%d" % i: u("f_tb%d" % i, ((2 * w - 1) ** 2, 2)) for i, w in enumerate(WINS)}
+    for p_drop, seed in ((0.1, 99), (0.5, 7)):
+        ref = o.window_attention_core(q, kv[..., :C], kv[..., C:], sd, "", H, W, WINS, shifts, 2, p_attn=p_drop, seed=seed)
+        got = ops.window_attn(q.to(dev), kv.to(dev), [sd["relative_position_bias_table_%d" % i].to(dev) for i in range(3)], WINS, shifts, 2, H, W,
+                              p_drop=p_drop, seed=seed)
+        record("wattn_fwd_d32_drop%g_%s" % (p_drop, "shifted" if shifted else "shift0"), "max|err| vs oracle", max_abs_err(got, ref), 1e-5)
+        assert_close(got, ref, 1e-5, 1e-5, "window attention forward with attn_drop %g" % p_drop)
+
+
 def test_window_attention_backward_16x16_head_dim16_vs_oracle_autograd(dev):
     """the 256-token window at head dim 16 (dim 96 with windows 4 / 8 / 16: k_window_attn_bwd_mfma<16, 16>)"""
     from oracle import pgrm as o
