@@ -219,6 +219,9 @@ SIGNATURES = {
     "dpmn_ln_qkv_window_attn_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_train_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _f, _u64, fp, _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_workspace_bytes": (_sz, []),
+    "dpmn_ln_qkv_window_attn_d32_supported": (_i, [_i, _i, _i, _IP, _i, _i]),
+    "dpmn_ln_qkv_window_attn_d32_workspace_bytes": (_sz, []),
+    "dpmn_ln_qkv_window_attn_d32_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, _i, _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_bwd_f32": (_i, [fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _f, _u64, fp, _i,
                                               _i, _i, _i, _i, fp]),
     "dpmn_ln_qkv_window_attn_bwd_part_rows": (_i, [_i, _i, _i]),

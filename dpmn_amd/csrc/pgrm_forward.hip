@@ -33,7 +33,8 @@ Ws carve(const dpmn_pgrm_weights* w, int B, char* base) {
   s.partial = take((size_t)B * ((L + 31) / 32) * C);
   s.avec = take((size_t)B * C);
   s.mid = take(B * L * (size_t)w->hidden_size * w->patch * w->patch + (size_t)16 * (9 * C + 32));
-  s.fold = take(2 * dpmn_ln_qkv_window_attn_workspace_bytes() / sizeof(float));     // folded attention weights of the two blocks
+  // folded attention weights of the two blocks (dim 96: attn_fused.hip; dim 192: attn_fused192.hip)
+  s.fold = take(2 * (w->dim == 192 ? dpmn_ln_qkv_window_attn_d32_workspace_bytes() : dpmn_ln_qkv_window_attn_workspace_bytes()) / sizeof(float));
   s.total = off;
   return s;
 }
@@ -83,6 +84,11 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
                                       p.kv_b, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat,
                                       s.fold + blk * (dpmn_ln_qkv_window_attn_workspace_bytes() / sizeof(float)), w->reuse_folded ? 0 : 1,
                                       B, H, Wd, C, stream));
+    } else if (dpmn_ln_qkv_window_attn_d32_supported(C, w->n_groups, w->heads_per_group, win, H, Wd)) {
+      RUN(dpmn_ln_qkv_window_attn_d32_f32(s.tq, s.tkv, p.norm1_q_w, p.norm1_q_b, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, p.q_w, p.q_b, p.kv_w,
+                                          p.kv_b, p.bias_table, win, shift, w->n_groups, w->heads_per_group, s.cat,
+                                          s.fold + blk * (dpmn_ln_qkv_window_attn_d32_workspace_bytes() / sizeof(float)), w->reuse_folded ? 0 : 1,
+                                          B, H, Wd, C, stream));
     } else {
       RUN(dpmn_ln_linear_f32(s.tq, p.norm1_q_w, p.norm1_q_b, 1e-5f, p.q_w, p.q_b, s.q, M, C, C, DPMN_ACT_NONE, stream));
       RUN(dpmn_ln_linear_f32(s.tkv, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, p.kv_w, p.kv_b, s.kv, M, 2 * C, C, DPMN_ACT_NONE, stream));

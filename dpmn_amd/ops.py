@@ -84,6 +84,21 @@ def ln_qkv_window_attn(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, 
     return out
 
 
+def ln_qkv_window_attn_d32_supported(Cd, windows, heads_per_group, H, W):
+    return bool(lib.dpmn_ln_qkv_window_attn_d32_supported(Cd, len(windows), heads_per_group, _abi.int_array(windows), H, W))
+
+
+def ln_qkv_window_attn_d32(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, tables, windows, shifts, heads_per_group, H, W, eps=1e-5):
+    """ln_qkv_window_attn at embed_dim 192 = 3 groups x 2 heads x 32, windows in {4, 8, 16} (csrc/attn_fused192.hip)."""
+    B, L, Cd = tq.shape
+    out = torch.empty_like(tq)
+    ws = torch.empty(lib.dpmn_ln_qkv_window_attn_d32_workspace_bytes() // 4, device=tq.device)
+    check(lib.dpmn_ln_qkv_window_attn_d32_f32(dptr(tq), dptr(tkv), dptr(lnq_w), dptr(lnq_b), dptr(lnkv_w), dptr(lnkv_b), float(eps),
+                                              dptr(wq), dptr(bq), dptr(wkv), dptr(bkv), _abi.ptr_array(tables), _abi.int_array(windows),
+                                              _abi.int_array(shifts), len(windows), heads_per_group, dptr(out), dptr(ws), 1, B, H, W, Cd, stream()))
+    return out
+
+
 def ln_qkv_window_attn_train(tq, tkv, lnq_w, lnq_b, lnkv_w, lnkv_b, wq, bq, wkv, bkv, tables, windows, shifts, heads_per_group, H, W,
                              p_drop=0.0, seed=0, eps=1e-5, save_qkv=True, fold_out=None):
     """Training forward of ln_qkv_window_attn: returns (cat, q, kv) -- q (B, L, C) and kv (B, L, 2C) are what the unfused backward

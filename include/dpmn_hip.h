@@ -96,6 +96,16 @@ int dpmn_ln_qkv_window_attn_f32(const float* tq, const float* tkv, const float* 
  * refold = 0: the caller vouches that the workspace still holds the fold of THESE weights and bias tables (frozen weights in
  * evaluation: the fold kernel then runs once per module, not once per call). */
 size_t dpmn_ln_qkv_window_attn_workspace_bytes(void);
+/* The same fused operator at embed_dim 192 = 3 groups x 2 heads x head dim 32 with windows in {4, 8, 16} (BASELINE.json configs[4];
+ * csrc/attn_fused192.hip): same arguments and result as dpmn_ln_qkv_window_attn_f32, own workspace size (the folded weights of the
+ * three groups, 3 x 160 KB).  Token grid sides powers of two >= 16, H W a multiple of 256 (one unit = 256 window-major tokens). */
+int dpmn_ln_qkv_window_attn_d32_supported(int C, int n_groups, int heads_per_group, const int* windows, int H, int W);
+size_t dpmn_ln_qkv_window_attn_d32_workspace_bytes(void);
+int dpmn_ln_qkv_window_attn_d32_f32(const float* tq, const float* tkv, const float* lnq_w, const float* lnq_b, const float* lnkv_w,
+                                    const float* lnkv_b, float eps, const float* wq, const float* bq, const float* wkv,
+                                    const float* bkv, const float* const* bias_tables, const int* windows, const int* shifts,
+                                    int n_groups, int heads_per_group, float* out, void* workspace, int refold, int B, int H, int W,
+                                    int C, dpmn_stream_t stream);
 /* Training forward of the same fused kernel (interfaces/super_resolution.py:140-278 runs the PGRMs in .train()): also writes
  * the projections q_out (B L, C) and kv_out (B L, 2 C) in raster token order -- the tensors a.q(norm1_q(x_q)) and
  * a.kv(norm1_kv(x_kv)) of pgrm.py:188,194, which the backward kernels read -- and applies attn_drop (pgrm.py:248) with the

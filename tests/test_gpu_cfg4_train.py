@@ -277,3 +277,37 @@ def test_cfg4_training_step_vs_oracle_autograd(dev, B):
         if e >= CFG4_STEP_TOL[kind]:
             fails.append((i, kind, e))
     assert not fails, "model gradients differ from oracle autograd: %r" % (fails,)
+
+
+@pytest.mark.parametrize("B,shifted", [(1, False), (3, True), (2, False)])
+def test_fused_ln_qkv_window_attention_dim192_vs_oracle_and_unfused(dev, B, shifted):
+    """dpmn_ln_qkv_window_attn_d32_f32 (csrc/attn_fused192.hip): norm1_q / norm1_kv + q / kv Linear + the head-dim-32 window attention
+    of windows 4 / 8 / 16 in one kernel (pgrm.py:322-323, 188-194, 197-266) against the oracle's LayerNorm + Linear +
+    window_attention_core, and against the unfused kernels it replaces on the stress stack."""
+    import torch.nn.functional as F
+    from dpmn_amd import ops
+    from oracle import pgrm as o
+    H, W, C = 32, 128, DIM
+    shifts = [w // 2 for w in WINS] if shifted else [0, 0, 0]
+    assert ops.ln_qkv_window_attn_d32_supported(C, WINS, 2, H, W)
+    tq, tkv = u("g_tq%d" % B, (B, H * W, C), -2, 3), u("g_tkv%d" % B, (B, H * W, C), -3, 2)
+    tkv = tkv + u("g_off%d" % B, (B, H * W, 1), -20, 20)            # rows with |mean| >> spread: the one-pass LayerNorm statistics
+    ln = [u("g_lnq_w", (C,), 0.5, 1.5), u("g_lnq_b", (C,), -0.5, 0.5), u("g_lnk_w", (C,), 0.5, 1.5), u("g_lnk_b", (C,), -0.5, 0.5)]
+    wq, bq = u("g_wq", (C, C), -0.2, 0.2), u("g_bq", (C,))
+    wkv, bkv = u("g_wkv", (2 * C, C), -0.2, 0.2), u("g_bkv", (2 * C,))
+    sd = {"relative_position_bias_table_%d" % i: u("g_tb%d" % i, ((2 * w - 1) ** 2, 2)) for i, w in enumerate(WINS)}
+    q = F.linear(F.layer_norm(tq, (C,), ln[0], ln[1]), wq, bq)
+    kv = F.linear(F.layer_norm(tkv, (C,), ln[2], ln[3]), wkv, bkv)
+    ref = o.window_attention_core(q, kv[..., :C], kv[..., C:], sd, "", H, W, WINS, shifts, 2)
+    tables = [sd["relative_position_bias_table_%d" % i].to(dev) for i in range(3)]
+    args = (tq.to(dev), tkv.to(dev), *[x.to(dev) for x in ln], wq.to(dev), bq.to(dev), wkv.to(dev), bkv.to(dev), tables, WINS, shifts, 2, H, W)
+    got = ops.ln_qkv_window_attn_d32(*args)
+    tag = "fused_attn192_B%d_%s" % (B, "shifted" if shifted else "shift0")
+    record(tag, "max|err| vs oracle", max_abs_err(got, ref), 1e-4)
+    assert_close(got, ref, 1e-4, 1e-4, tag)
+    qd = ops.ln_linear(tq.to(dev).reshape(-1, C), ln[0].to(dev), ln[1].to(dev), wq.to(dev), bq.to(dev)).reshape(B, H * W, C)
+    kvd = ops.ln_linear(tkv.to(dev).reshape(-1, C), ln[2].to(dev), ln[3].to(dev), wkv.to(dev), bkv.to(dev)).reshape(B, H * W, 2 * C)
+    unf = ops.window_attn(qd, kvd, tables, WINS, shifts, 2, H, W)
+    record(tag, "max|err| vs the unfused kernels", max_abs_err(got, unf), 1e-4)
+    assert_close(got, unf, 1e-4, 1e-4, tag + " vs unfused")
+    assert torch.equal(got, ops.ln_qkv_window_attn_d32(*args)), "two launches must agree bit for bit"
