@@ -311,13 +311,12 @@ __device__ __forceinline__ void run_units(const FusedAttnArgs& a, int slot, int 
         // as documented for dpmn_window_attn_f32: ((((b G + g) heads + h) L + t) N + m)
         if (a.p_drop > 0.f) {
           const unsigned long long e0 = ((((unsigned long long)b * 3 + g) * 2 + h) * L + t) * N;
+          const unsigned long long z0 = drop_z0(a.seed, e0 + (WS == 2 ? 0 : 4 * kq));      // + (16 kt + r) * PHI: constant adds
 #pragma unroll
           for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int mkey = WS == 8 ? 16 * kt + 4 * kq + r : (WS == 4 ? 4 * kq + r : r);
-              sacc[kt][r] *= drop_scale(a.seed, e0 + mkey, a.p_drop, a.inv_keep);
-            }
+            for (int r = 0; r < 4; ++r)
+              sacc[kt][r] *= drop_scale_z(z0 + (unsigned long long)((WS == 8 ? 16 * kt : 0) + r) * DROP_PHI, a.p_drop, a.inv_keep);
         }
       }
       // O^T = V^T . P: two accumulator chains

@@ -287,13 +287,12 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
       const float inv = 1.0f / den;
       if (DROP) {                          // dP = (V dO^T) o M with the forward's masks (0 or 1 / (1 - p))
         const unsigned long long e0 = ((((unsigned long long)b * 3 + g) * 2 + h) * L + t) * N;
+        const unsigned long long z0 = drop_z0(a.seed, e0 + (WS == 2 ? 0 : 4 * kq));      // + (16 kt + r) * PHI: constant adds
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int mkey = WS == 8 ? 16 * kt + 4 * kq + r : (WS == 4 ? 4 * kq + r : r);
-            dpt[kt][r] *= drop_scale(a.seed, e0 + mkey, a.p_drop, a.inv_keep);
-          }
+          for (int r = 0; r < 4; ++r)
+            dpt[kt][r] *= drop_scale_z(z0 + (unsigned long long)((WS == 8 ? 16 * kt : 0) + r) * DROP_PHI, a.p_drop, a.inv_keep);
       }
       float dlt = 0.f;
 #pragma unroll
@@ -346,6 +345,14 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
         maskedB |= ((qr.x != my_reg ? 1u : 0u) | (qr.y != my_reg ? 2u : 0u) | (qr.z != my_reg ? 4u : 0u) | (qr.w != my_reg ? 8u : 0u)) << (4 * qt);
       }
     }
+    // attn_drop mask index of (head h, query t0 + q0 + 4 kq + r, my key): linear in (qt, r) -> one 64-bit multiply per head here, constant
+    // adds per element below
+    unsigned long long zB[2] = {0ull, 0ull};
+    if (DROP) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        zB[h] = drop_z0(a.seed, ((((unsigned long long)b * 3 + g) * 2 + h) * L + (t0 + (WS == 8 ? 0 : 16 * wave) + 4 * kq)) * N + (16 * wave + lr) % N);
+    }
     if (!(FAB_SKIP & 2))
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -370,10 +377,7 @@ __device__ __forceinline__ void run_units_bwd(const FusedAttnArgs& a, int slot, 
           if ((maskedB >> (4 * qt + r)) & 1u) v += -100.0f * LOG2E;
           const float p = __builtin_amdgcn_exp2f(v - mx4[r]) * iv4[r];
           float m = 1.0f;
-          if (DROP) {
-            const unsigned long long e0 = ((((unsigned long long)b * 3 + g) * 2 + h) * L + (t0 + q0 + 4 * kq + r)) * N;
-            m = drop_scale(a.seed, e0 + (16 * wave + lr) % N, a.p_drop, a.inv_keep);
-          }
+          if (DROP) m = drop_scale_z(zB[h] + (unsigned long long)(((WS == 8 ? 16 * qt : 0) + r) * N) * DROP_PHI, a.p_drop, a.inv_keep);
           pm[r] = p * m;                                  // P o M: what multiplies V in the forward
           ds[r] = p * (dp[r] * m - dl4[r]);               // dS[query][key]
         }

@@ -159,13 +159,19 @@ __device__ __forceinline__ float wave_max(float v) {
 // from torch's Philox stream, which no other implementation can replay; here a mask element is a pure function of
 // (seed, element index) -- splitmix64 finaliser, top 24 bits as a uniform in [0,1) -- so forward, backward and the CPU
 // oracle (oracle/pgrm.py drop_mask) regenerate identical masks without storing them.  Returns 0 or 1/(1-p).
-__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-  unsigned long long z = idx * 0x9E3779B97F4A7C15ull + seed;
+constexpr unsigned long long DROP_PHI = 0x9E3779B97F4A7C15ull;
+// the hash in two halves: z0 = idx * PHI + seed is linear in idx, so a kernel that walks idx = base + c with compile-time c pays
+// ONE 64-bit multiply per base (drop_z0) and a 64-bit constant add per element (z0 + c * DROP_PHI) instead of a multiply each
+__device__ __forceinline__ unsigned long long drop_z0(unsigned long long seed, unsigned long long idx) { return idx * DROP_PHI + seed; }
+__device__ __forceinline__ float drop_scale_z(unsigned long long z, float p, float inv_keep) {
   z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull;
   z ^= z >> 27; z *= 0x94D049BB133111EBull;
   z ^= z >> 31;
   const float u = (float)(unsigned)(z >> 40) * 5.9604644775390625e-8f;   // 2^-24
   return u >= p ? inv_keep : 0.0f;
+}
+__device__ __forceinline__ float drop_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  return drop_scale_z(drop_z0(seed, idx), p, inv_keep);
 }
 
 static inline hipStream_t as_stream(dpmn_stream_t s) { return (hipStream_t)s; }

@@ -32,6 +32,11 @@ struct EpiArgs {
   int atomic;          // 1: y += acc with fp32 atomics (split-K weight gradients); bias/act/res ignored
   long zstride;        // k-loop split launches: != 0: split z STORES its partial result at y + z * zstride (no atomics; the caller adds
                        // the splits in order)
+  // train-mode Dropout / DropPath on the Linear's output before the residual (Mlp.drop + DropPath, pgrm.py:40,330): k_gemm_kloop's
+  // bias + one-residual epilogue only; y = res1 + (acc + bias) * m_elem(flat index) * m_row(flat index / row_len)
+  float p_elem = 0.f, p_row = 0.f;
+  unsigned long long seed_elem = 0ull, seed_row = 0ull;
+  long row_len = 0;
 };
 
 struct ProArgs {
@@ -489,6 +494,30 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
         rr[nt][mt] = *reinterpret_cast<const float4*>(e.res1 + (size_t)(m_blk + wm * 32 + mt * 16 + lm) * ldy + n_blk + wn * 48 + nt * 16 + lq * 4);
+    if (e.p_elem > 0.f || e.p_row > 0.f) {
+      // the masks dpmn_dropout_f32 would apply to the stored Linear output (same element indices, same order of the two factors)
+      const float ike = 1.0f / (1.0f - e.p_elem), ikr = 1.0f / (1.0f - e.p_row);
+#pragma unroll
+      for (int nt = 0; nt < 3; ++nt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(e.bias + n_blk + wn * 48 + nt * 16 + lq * 4);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const size_t off = (size_t)(m_blk + wm * 32 + mt * 16 + lm) * ldy + n_blk + wn * 48 + nt * 16 + lq * 4;
+          float o[4] = {acc[nt][mt][0] + b4.x, acc[nt][mt][1] + b4.y, acc[nt][mt][2] + b4.z, acc[nt][mt][3] + b4.w};
+          if (e.p_elem > 0.f) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= drop_scale(e.seed_elem, (unsigned long long)(off + r), e.p_elem, ike);
+          }
+          if (e.p_row > 0.f) {
+            const float mr = drop_scale(e.seed_row, (unsigned long long)(off / (size_t)e.row_len), e.p_row, ikr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= mr;
+          }
+          *reinterpret_cast<float4*>(y + off) = make_float4(o[0] + rr[nt][mt].x, o[1] + rr[nt][mt].y, o[2] + rr[nt][mt].z, o[3] + rr[nt][mt].w);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 3; ++nt) {
       const float4 b4 = *reinterpret_cast<const float4*>(e.bias + n_blk + wn * 48 + nt * 16 + lq * 4);
@@ -1184,7 +1213,10 @@ __global__ __launch_bounds__(256, OCC) void k_sk_mlp_in(const float* __restrict_
                                                       const float* __restrict__ feats, const float* __restrict__ shortcut, float* __restrict__ x1,
                                                       const float* __restrict__ ln_w, const float* __restrict__ ln_b, float eps,
                                                       const float* __restrict__ w_fc1, const float* __restrict__ b_fc1, float* __restrict__ y,
-                                                      int M, int N, float* __restrict__ v_out, float* __restrict__ n2_out) {
+                                                      int M, int N, float* __restrict__ v_out, float* __restrict__ n2_out, float p_row,
+                                                      unsigned long long seed_row) {
+  // p_row > 0 (training): timm DropPath on the attention branch (pgrm.py:329) -- x1 = shortcut + m_b (proj_head(sel) + b_head + feats),
+  // one counter-based draw m_b in {0, 1 / (1 - p)} per batch sample, the mask the unfused dpmn_dropout_f32 applies
   constexpr int KC = C / 16, KV = C / 4, LDW = C + PAD, BN = 96, NT = 6, G = C / CG, HC = CG / 16, LDH = CG + PAD;
   static_assert(C == 96 && G == 3, "built for dim 96, three window groups");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1308,6 +1340,7 @@ __global__ __launch_bounds__(256, OCC) void k_sk_mlp_in(const float* __restrict_
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 2 * BN + 16 * nt + 4 * kq);
       f32x4 v = x1r[nt] + b4;
       v += r1[nt];
+      if (p_row > 0.f) v *= drop_scale(seed_row, (unsigned long long)(m / rows_per_image), p_row, 1.0f / (1.0f - p_row));
       v += r2[nt];
       x1r[nt] = v;
     }
@@ -1564,6 +1597,23 @@ int dpmn_linear_f32(const float* x, const float* w, const float* bias, const flo
   return DPMN_OK;
 }
 
+// y = res + Dropout(x w^T + bias) with the masks of dpmn_dropout_f32 (element dropout p_elem and / or per-sample DropPath p_row, row_len =
+// elements per sample): Mlp.fc2 -> Mlp.drop -> DropPath -> + shortcut (pgrm.py:39-40, 330) in the GEMM's epilogue.  Whole 64 x 96
+// tiles only (the k-loop kernel's interior epilogue); returns DPMN_ERR_ARG otherwise (the caller composes Linear + dropout).
+int dpmn_linear_drop_f32(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N, int K, float p_elem,
+                         unsigned long long seed_elem, float p_row, unsigned long long seed_row, long row_len, dpmn_stream_t stream) {
+  DPMN_REQUIRE(x && w && bias && res && y && M > 0 && M % 64 == 0 && N % 96 == 0 && K % 32 == 0 && K > 192,
+               "linear_drop: whole 64 x 96 tiles, K a multiple of 32 above 192 (the k-loop GEMM)");
+  DPMN_REQUIRE(p_elem >= 0.f && p_elem < 1.f && p_row >= 0.f && p_row < 1.f && (p_row == 0.f || row_len > 0), "linear_drop: bad rates");
+  EpiArgs e{bias, res, nullptr, nullptr, ACT_NONE, 0.f};
+  e.p_elem = p_elem; e.p_row = p_row; e.seed_elem = seed_elem; e.seed_row = seed_row; e.row_len = row_len;
+  dim3 grid(cdiv(M, 64), cdiv(N, 96));
+  ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N * 2 + (double)N * K));
+  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
 int dpmn_add_linear_f32(const float* x, const float* addv, const float* w, const float* bias, float* y, int M, int N,
                         int K, int act, dpmn_stream_t stream) {
   DPMN_REQUIRE(x && addv && w && y && M > 0 && N % 4 == 0, "add_linear: bad arguments");
@@ -1613,6 +1663,15 @@ int dpmn_sk_mlp_in_f32(const float* cat, const float* attn_vec, const float* w_h
                        const float* shortcut, float* x1, const float* ln_w, const float* ln_b, float eps, const float* w_fc1,
                        const float* b_fc1, float* y, float* v_out, float* n2_out, int M, int rows_per_image, int C, int groups, int N,
                        dpmn_stream_t stream) {
+  return dpmn_sk_mlp_in_drop_f32(cat, attn_vec, w_head, b_head, feats, shortcut, x1, ln_w, ln_b, eps, w_fc1, b_fc1, y, v_out, n2_out, M,
+                                 rows_per_image, C, groups, N, 0.f, 0ull, stream);
+}
+
+int dpmn_sk_mlp_in_drop_f32(const float* cat, const float* attn_vec, const float* w_head, const float* b_head, const float* feats,
+                            const float* shortcut, float* x1, const float* ln_w, const float* ln_b, float eps, const float* w_fc1,
+                            const float* b_fc1, float* y, float* v_out, float* n2_out, int M, int rows_per_image, int C, int groups, int N,
+                            float p_row, unsigned long long seed_row, dpmn_stream_t stream) {
+  DPMN_REQUIRE(p_row >= 0.f && p_row < 1.f, "sk_mlp_in: DropPath rate in [0, 1)");
   DPMN_REQUIRE(cat && attn_vec && w_head && feats && shortcut && x1 && ln_w && ln_b && w_fc1 && y, "sk_mlp_in: null pointer");
   DPMN_REQUIRE((v_out == nullptr) == (n2_out == nullptr), "sk_mlp_in: the two training outputs go together");
   DPMN_REQUIRE(C == 96 && groups == 3 && N % 96 == 0 && M % 16 == 0 && rows_per_image % 16 == 0 && M >= 1024,
@@ -1638,7 +1697,7 @@ int dpmn_sk_mlp_in_f32(const float* cat, const float* attn_vec, const float* w_h
   ProfScope prof(PT_GEMM_WSTAT_LN, st, 2.0 * M * ((double)N * Cc + (double)Cc * CG),
                  4.0 * ((double)M * Cc * 4 + (double)M * N + (double)N * Cc + (double)Cc * CG));
 #define SKMLP_LAUNCH(SAVE_, OCC_) hipLaunchKernelGGL((k_sk_mlp_in<Cc, CG, SAVE_, OCC_>), dim3(gx, ny), dim3(256), smem, st, cat, attn_vec, rows_per_image, \
-                                                    w_head, b_head, feats, shortcut, x1, ln_w, ln_b, eps, w_fc1, b_fc1, y, M, N, v_out, n2_out)
+                                                    w_head, b_head, feats, shortcut, x1, ln_w, ln_b, eps, w_fc1, b_fc1, y, M, N, v_out, n2_out, p_row, seed_row)
   if (v_out) { if (occ >= 3) SKMLP_LAUNCH(true, 3); else SKMLP_LAUNCH(true, 2); }
   else { if (occ >= 3) SKMLP_LAUNCH(false, 3); else SKMLP_LAUNCH(false, 2); }
 #undef SKMLP_LAUNCH

@@ -208,16 +208,18 @@ def sk_mlp_in_supported(M, L, Cd, groups, N):
     return bool(lib.dpmn_sk_mlp_in_supported(M, L, Cd, groups, N))
 
 
-def sk_mlp_in(cat, avec, head_w, head_b, feats, shortcut, ln_w, ln_b, fc1_w, fc1_b, L, save=False, eps=1e-5):
+def sk_mlp_in(cat, avec, head_w, head_b, feats, shortcut, ln_w, ln_b, fc1_w, fc1_b, L, save=False, eps=1e-5, p_row=0.0, seed_row=0):
     """One launch for x1 = proj_head(sum_g avec_g cat_g) + b + feats + shortcut and y = fc1(LayerNorm(x1)) on (M, C) rows.
-    Returns (x1, y) or, save=True (training forward), (x1, y, V, n2)."""
+    Returns (x1, y) or, save=True (training forward), (x1, y, V, n2).  p_row > 0: DropPath (one draw per sample) on the
+    attention branch, x1 = shortcut + m_b (proj_head(...) + b + feats)."""
     M, Cd = cat.shape
     G, N = avec.shape[1], fc1_w.shape[0]
     x1, y = torch.empty_like(cat), torch.empty(M, N, device=cat.device)
     V = torch.empty(M, Cd // G, device=cat.device) if save else None
     n2 = torch.empty_like(cat) if save else None
-    check(lib.dpmn_sk_mlp_in_f32(dptr(cat), dptr(avec), dptr(head_w), dptr(head_b), dptr(feats), dptr(shortcut), dptr(x1), dptr(ln_w), dptr(ln_b),
-                                 eps, dptr(fc1_w), dptr(fc1_b, True), dptr(y), dptr(V, True), dptr(n2, True), M, L, Cd, G, N, stream()))
+    check(lib.dpmn_sk_mlp_in_drop_f32(dptr(cat), dptr(avec), dptr(head_w), dptr(head_b), dptr(feats), dptr(shortcut), dptr(x1), dptr(ln_w), dptr(ln_b),
+                                      eps, dptr(fc1_w), dptr(fc1_b, True), dptr(y), dptr(V, True), dptr(n2, True), M, L, Cd, G, N, float(p_row),
+                                      int(seed_row), stream()))
     return (x1, y, V, n2) if save else (x1, y)
 
 

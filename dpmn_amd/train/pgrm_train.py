@@ -406,11 +406,12 @@ def forward(m, x_q, x_kv, residuals, drop=None):
         s["avec"] = _e(B, G, Cd // G, like=tkv)
         check(lib.dpmn_sk_gate_f32(dptr(s["partial"]), parts, L, dptr(sk.fc1.weight), dptr(sk.fc1.bias), dptr(sk.fc2.weight),
                                    dptr(sk.fc2.bias), dptr(s["avec"]), B, Cd, G, sk.fc1.weight.shape[0], stream()))
-        if FUSED_SKMLP and dpb <= 0 and ops.sk_mlp_in_supported(M, L, Cd, G, Ch):
-            # select + proj_head + both residuals -> x1 -> LayerNorm2 -> fc1 in one launch (gemm.hip k_sk_mlp_in), V and n2 written
-            # on the way for the backward's weight-gradient GEMMs: replaces four launches
+        if FUSED_SKMLP and ops.sk_mlp_in_supported(M, L, Cd, G, Ch):
+            # select + proj_head + both residuals (DropPath on the attention branch included) -> x1 -> LayerNorm2 -> fc1 in one launch
+            # (gemm.hip k_sk_mlp_in), V and n2 written on the way for the backward's weight-gradient GEMMs: replaces four / five launches
             s["x1"], s["ypre"], s["V"], s["n2"] = ops.sk_mlp_in(s["cat"], s["avec"], sk.proj_head.weight, sk.proj_head.bias, s["feats"], tkv,
-                                                                 blk.norm2.weight, blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, L, save=True)
+                                                                 blk.norm2.weight, blk.norm2.bias, mlp.fc1.weight, mlp.fc1.bias, L, save=True,
+                                                                 p_row=dpb, seed_row=sb[1])
         else:
             s["V"] = _e(M, Cd // G, like=tkv)
             check(lib.dpmn_sk_select_only_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(s["V"]), M, L, Cd, G, stream()))
@@ -427,7 +428,12 @@ def forward(m, x_q, x_kv, residuals, drop=None):
         check(lib.dpmn_dwconv3x3_train_f32(dptr(s["ypre"]), dptr(mlp.depthwise_conv.weight), dptr(mlp.depthwise_conv.bias),
                                            dptr(s["gpre"]), dptr(s["g"]), 1, float(pd), int(sb[2]), B, Ch, r, stream()))
         s["z"] = ops.pointwise(s["g"].reshape(B, L, Ch), mlp.pointwise_conv.weight.reshape(Ch, Ch), mlp.pointwise_conv.bias).reshape(M, Ch)
-        if pd > 0 or dpb > 0:      # x_kv = x1 + DropPath(Dropout(fc2(z)))
+        if (pd > 0 or dpb > 0) and M % 64 == 0 and Cd % 96 == 0 and Ch % 32 == 0 and Ch > 192:
+            # x_kv = x1 + DropPath(Dropout(fc2(z))): both masks in the GEMM's epilogue
+            tkv = torch.empty(M, Cd, device=tkv.device)
+            check(lib.dpmn_linear_drop_f32(dptr(s["z"]), dptr(mlp.fc2.weight), dptr(mlp.fc2.bias), dptr(s["x1"]), dptr(tkv), M, Cd, Ch, float(pd),
+                                           int(sb[3]), float(dpb), int(sb[4]), L * Cd, stream()))
+        elif pd > 0 or dpb > 0:
             branch = ops.linear(s["z"], mlp.fc2.weight, mlp.fc2.bias)
             tkv = ops.dropout(branch, pd, sb[3], dpb, sb[4], row_len=L * Cd, res=s["x1"])
         else:

@@ -47,6 +47,11 @@ int dpmn_get_compute_dtype(void);
  * pgrm.py:39 (Mlp.fc2 + residual 330), tatt.py:209, transformer_v2.py:453/785 FFNs. */
 int dpmn_linear_f32(const float* x, const float* w, const float* bias, const float* res1, const float* res2,
                     float* y, int M, int N, int K, int act, float slope, dpmn_stream_t stream);
+/* y = res + Dropout(x w^T + bias): element dropout (p_elem, seed_elem) and / or per-sample DropPath (p_row, seed_row, row_len elements per
+ * sample) on the Linear's output before the residual, the masks of dpmn_dropout_f32 -- Mlp.fc2 -> Mlp.drop -> DropPath -> + shortcut
+ * (pgrm.py:39-40, 330) in one launch.  M % 64 == 0, N % 96 == 0, K % 32 == 0, K > 192. */
+int dpmn_linear_drop_f32(const float* x, const float* w, const float* bias, const float* res, float* y, int M, int N, int K, float p_elem,
+                         unsigned long long seed_elem, float p_row, unsigned long long seed_row, long row_len, dpmn_stream_t stream);
 /* y = act((x + addv) . w^T + bias): with_pos_embed + in-projection, transformer_v2.py:462,826-828 */
 int dpmn_add_linear_f32(const float* x, const float* addv, const float* w, const float* bias, float* y, int M,
                         int N, int K, int act, dpmn_stream_t stream);
@@ -75,6 +80,12 @@ int dpmn_sk_mlp_in_f32(const float* cat, const float* attn_vec, const float* w_h
                        const float* shortcut, float* x1, const float* ln_w, const float* ln_b, float eps, const float* w_fc1,
                        const float* b_fc1, float* y, float* v_out, float* n2_out, int M, int rows_per_image, int C, int groups, int N,
                        dpmn_stream_t stream);
+/* the same with timm DropPath on the attention branch (training, pgrm.py:329): x1 = shortcut + m_b (proj_head(sel) + b_head + feats),
+ * m_b the per-sample mask of dpmn_dropout_f32(p_row, seed_row) */
+int dpmn_sk_mlp_in_drop_f32(const float* cat, const float* attn_vec, const float* w_head, const float* b_head, const float* feats,
+                       const float* shortcut, float* x1, const float* ln_w, const float* ln_b, float eps, const float* w_fc1,
+                       const float* b_fc1, float* y, float* v_out, float* n2_out, int M, int rows_per_image, int C, int groups, int N,
+                       float p_row, unsigned long long seed_row, dpmn_stream_t stream);
 int dpmn_sk_mlp_in_supported(int M, int rows_per_image, int C, int groups, int N);
 /* z[b] = w (Ch,Ch) . g[b] (Ch,L) + bias : Mlp.pointwise_conv on the raw (B,Ch,r,r) view (pgrm.py:34,37) */
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
