@@ -647,8 +647,9 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* _
       } else if (in_gelu) { pv.x = gelu_erf(pv.x); pv.y = gelu_erf(pv.y); pv.z = gelu_erf(pv.z); pv.w = gelu_erf(pv.w); }
       if (p_drop > 0.f) {
         const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
-        pv.x *= drop_scale(seed, e0, p_drop, inv_keep); pv.y *= drop_scale(seed, e0 + 1, p_drop, inv_keep);
-        pv.z *= drop_scale(seed, e0 + 2, p_drop, inv_keep); pv.w *= drop_scale(seed, e0 + 3, p_drop, inv_keep);
+        const unsigned long long z0 = drop_z0(seed, e0);      // one 64-bit multiply per 4 elements, constant adds for the rest
+        pv.x *= drop_scale_z(z0, p_drop, inv_keep); pv.y *= drop_scale_z(z0 + DROP_PHI, p_drop, inv_keep);
+        pv.z *= drop_scale_z(z0 + 2 * DROP_PHI, p_drop, inv_keep); pv.w *= drop_scale_z(z0 + 3 * DROP_PHI, p_drop, inv_keep);
       }
       if (KEEP || gpre) {
         const float4 q = KEEP ? pre_q[it] : *reinterpret_cast<const float4*>(gpre + plane * r * r + yy * r + x4);
@@ -692,7 +693,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* _
       if (p_drop > 0.f) {
         const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) a[q] *= drop_scale(seed, e0 + q, p_drop, inv_keep);
+        for (int q = 0; q < 4; ++q) a[q] *= drop_scale_z(drop_z0(seed, e0) + (unsigned long long)q * DROP_PHI, p_drop, inv_keep);
       }
       if (KEEP) {
         const float4 d = gpk[it];
@@ -740,7 +741,7 @@ __global__ void k_dropout(const float* __restrict__ x, const float* __restrict__
   if (p_elem > 0.f) {
     const float ik = 1.0f / (1.0f - p_elem);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] *= drop_scale(seed_elem, (unsigned long long)(i * 4 + r), p_elem, ik);
+    for (int r = 0; r < 4; ++r) o[r] *= drop_scale_z(drop_z0(seed_elem, (unsigned long long)(i * 4)) + (unsigned long long)r * DROP_PHI, p_elem, ik);
   }
   if (p_row > 0.f) {
     const float m = drop_scale(seed_row, (unsigned long long)((i * 4) / row_len), p_row, 1.0f / (1.0f - p_row));

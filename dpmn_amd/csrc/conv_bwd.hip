@@ -5,6 +5,7 @@
 //   k_bn_bwd_*        BatchNorm backward through batch statistics: dgamma, dbeta, d(raw conv output)
 //   k_se_gate_bwd     backward of the CMM channel gate (cmm.py:135-147)
 // Data gradients are ordinary convolutions of dY with re-packed weights and run through k_conv_igemm / k_conv_halo.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -1009,7 +1010,8 @@ int dpmn_affine_act_bwd_stats_f32(const float* dA, const float* r, const float* 
   DPMN_REQUIRE(dA && r && G && mean && rstd && sums && pixels > 0, "affine_act_bwd_stats: bad arguments");
   DPMN_REQUIRE(C % 4 == 0 && C / 4 <= 256 && 256 % (C / 4) == 0, "affine_act_bwd_stats: C/4 must divide 256");
   DPMN_REQUIRE(act == ACT_NONE || act == ACT_RELU || act == ACT_LEAKY02 || act == ACT_LEAKY001, "affine_act_bwd_stats: piecewise-linear activations");
-  int ppb = (int)((pixels + 2047) / 2048);       // <= 2048 blocks: one fp64 atomic pair per channel and block
+  static const long aab_blocks = getenv("DPMN_AAB_BLOCKS") ? atol(getenv("DPMN_AAB_BLOCKS")) : 512;      // (2048: 28.1 us per launch on average, 512: 25.0 -- same-address fp64 atomics)
+  int ppb = (int)((pixels + aab_blocks - 1) / aab_blocks);       // <= 2048 blocks: one fp64 atomic pair per channel and block
   const int pl = 256 / (C / 4);
   if (ppb < 8 * pl) ppb = 8 * pl;                // two 4-pixel rounds per thread at least
   ProfScope prof(PT_AFFINE_ACT_BWD, as_stream(stream), 0.0, 4.0 * (accumulate ? 4 : 3) * (double)pixels * C);

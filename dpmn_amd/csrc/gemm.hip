@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void k_gemm_kloop(const float* __restrict__ x,
           float o[4] = {acc[nt][mt][0] + b4.x, acc[nt][mt][1] + b4.y, acc[nt][mt][2] + b4.z, acc[nt][mt][3] + b4.w};
           if (e.p_elem > 0.f) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] *= drop_scale(e.seed_elem, (unsigned long long)(off + r), e.p_elem, ike);
+            for (int r = 0; r < 4; ++r) o[r] *= drop_scale_z(drop_z0(e.seed_elem, (unsigned long long)off) + (unsigned long long)r * DROP_PHI, e.p_elem, ike);
           }
           if (e.p_row > 0.f) {
             const float mr = drop_scale(e.seed_row, (unsigned long long)(off / (size_t)e.row_len), e.p_row, ikr);

@@ -676,8 +676,9 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
       if (in_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
       if (p_drop > 0.f) {
         const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
-        v.x *= drop_scale(seed, e0, p_drop, inv_keep); v.y *= drop_scale(seed, e0 + 1, p_drop, inv_keep);
-        v.z *= drop_scale(seed, e0 + 2, p_drop, inv_keep); v.w *= drop_scale(seed, e0 + 3, p_drop, inv_keep);
+        const unsigned long long z0 = drop_z0(seed, e0);
+        v.x *= drop_scale_z(z0, p_drop, inv_keep); v.y *= drop_scale_z(z0 + DROP_PHI, p_drop, inv_keep);
+        v.z *= drop_scale_z(z0 + 2 * DROP_PHI, p_drop, inv_keep); v.w *= drop_scale_z(z0 + 3 * DROP_PHI, p_drop, inv_keep);
       }
       *reinterpret_cast<float4*>(t + (yy + 1) * LD + 4 + x4) = v;
     }
