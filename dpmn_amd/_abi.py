@@ -110,6 +110,7 @@ SIGNATURES = {
     "dpmn_sk_proj_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, fp]),
     "dpmn_sk_select_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_mlp_in_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_dwconv3x3_bwd_det_bytes": (_sz, [_i, _i, _i]),
     "dpmn_linear_drop_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _f, _u64, _f, _u64, _l, fp]),
     "dpmn_sk_mlp_in_drop_f32": (_i, [fp, fp, fp, fp, fp, fp, fp, fp, fp, _f, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_sk_mlp_in_supported": (_i, [_i, _i, _i, _i, _i]),

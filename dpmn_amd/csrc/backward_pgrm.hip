@@ -588,7 +588,9 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* _
                                                      const float* __restrict__ w, float* __restrict__ dP, float* __restrict__ dw,
                                                      float* __restrict__ db, int Ch, int r, long planes,
                                                      const float* __restrict__ gpre = nullptr, int in_gelu = 0, int out_gelu_bwd = 0,
-                                                     float p_drop = 0.f, unsigned long long seed = 0ull, float* __restrict__ part = nullptr) {
+                                                     float p_drop = 0.f, unsigned long long seed = 0ull, float* __restrict__ part = nullptr, int rb = 0) {
+  // !KEEP: a wave takes a BAND of rb rows of a plane (rb = r: the whole plane), the halo rows above / below re-read and re-activated
+  // from the neighbouring bands (64 x 64 planes as whole-plane tiles: 38 KB of LDS per wave, 4 waves per CU, 0.20 of the HBM rate)
   // p_drop > 0: the forward input was dropout(GELU(P)) -- the same mask on load, and again on dP before GELU'
   const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
   // per wave: P tile and dg tile, (r+2) rows x LD = r+8 floats, plane starting at column 4 (16-byte aligned rows, r % 4 == 0).
@@ -598,17 +600,22 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* _
   // every block loading, then every block computing: the kernel took memory time PLUS arithmetic time, 47 + 21 + 26 us.)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int LD = r + 8, r4 = r >> 2, TS = (r + 2) * LD, npix4 = r * r4;
+  if (KEEP || rb <= 0) rb = r;
+  const int nb = r / rb;
+  const int LD = r + 8, r4 = r >> 2, TS = (rb + 2) * LD, npix4 = rb * r4;
   float* tp = sm + wave * 2 * TS;
   float* tg = tp + TS;
-  long plane = (long)blockIdx.x * 4 + wave;
-  if (plane >= planes) return;
-  const long pstep = KEEP ? (long)gridDim.x * 4 : planes;
-  // zero halo of both tiles: written once, the interior stores never touch it
-  for (int i = lane; i < LD; i += 64) { tp[i] = 0.f; tp[(r + 1) * LD + i] = 0.f; tg[i] = 0.f; tg[(r + 1) * LD + i] = 0.f; }
-  for (int i = lane; i < r; i += 64) {
-    tp[(i + 1) * LD + 3] = 0.f; tp[(i + 1) * LD + 4 + r] = 0.f;
-    tg[(i + 1) * LD + 3] = 0.f; tg[(i + 1) * LD + 4 + r] = 0.f;
+  long plane = (long)blockIdx.x * 4 + wave;      // (!KEEP: virtual plane = plane * nb + band)
+  const long nvp = planes * nb;
+  if (plane >= nvp) return;
+  const long pstep = KEEP ? (long)gridDim.x * 4 : nvp;
+  // zero halo: KEEP -- rows 0 and r + 1 and the two halo columns, written once (the interior stores never touch them); bands -- the
+  // halo columns only (the halo rows are loaded, zero outside the plane)
+  if (KEEP)
+    for (int i = lane; i < LD; i += 64) { tp[i] = 0.f; tp[(r + 1) * LD + i] = 0.f; tg[i] = 0.f; tg[(r + 1) * LD + i] = 0.f; }
+  for (int i = lane; i < rb + 2; i += 64) {
+    tp[i * LD + 3] = 0.f; tp[i * LD + 4 + r] = 0.f;
+    tg[i * LD + 3] = 0.f; tg[i * LD + 4 + r] = 0.f;
   }
   float4 pre_p[KEEP ? 4 : 1], pre_g[KEEP ? 4 : 1], pre_q[KEEP ? 4 : 1], gpk[KEEP ? 4 : 1];
   auto prefetch = [&](long pl) {
@@ -623,44 +630,50 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* _
     }
   };
   if (KEEP) prefetch(plane);
-  for (; plane < planes; plane += pstep) {
-    const int c = (int)(plane % Ch);
-    const float* ps = P + plane * r * r;
-    const float* gs = dg + plane * r * r;
+  for (; plane < nvp; plane += pstep) {
+    const long pl_ = KEEP ? plane : plane / nb;                 // the real plane
+    const int y0 = KEEP ? 0 : (int)(plane % nb) * rb;          // first row of the band
+    const int c = (int)(pl_ % Ch);
+    const float* ps = P + pl_ * r * r;
+    const float* gs = dg + pl_ * r * r;
     // the channel's 9 weights BEFORE the next plane's prefetch is issued: vmcnt retires in order, a load behind the prefetch
     // would wait for all of it
     float k[9], aw[9], ab = 0.f;
 #pragma unroll
     for (int i = 0; i < 9; ++i) { k[i] = w[c * 9 + i]; aw[i] = 0.f; }
+    const int nld = KEEP ? 256 : (rb + 2) * r4;                // bands: tile row j holds plane row y0 - 1 + j
 #pragma unroll 4
-    for (int it = 0; it < (KEEP ? 4 : (npix4 + 63) / 64); ++it) {
+    for (int it = 0; it < (KEEP ? 4 : (nld + 63) / 64); ++it) {
       const int i = lane + 64 * it;
-      if (!KEEP && i >= npix4) break;
-      const int yy = i / r4, x4 = (i - yy * r4) * 4;
-      float4 pv, gv;
+      if (!KEEP && i >= nld) break;
+      const int j = i / r4, x4 = (i - j * r4) * 4;
+      const int yy = KEEP ? j : y0 - 1 + j;
+      float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), gv = pv;
       if (KEEP) { pv = pre_p[it]; gv = pre_g[it]; }
-      else { pv = *reinterpret_cast<const float4*>(ps + yy * r + x4); gv = *reinterpret_cast<const float4*>(gs + yy * r + x4); }
-      if (KEEP) {
-        float4 d;
-        gelu_both(pv.x, pv.x, d.x); gelu_both(pv.y, pv.y, d.y); gelu_both(pv.z, pv.z, d.z); gelu_both(pv.w, pv.w, d.w);
-        gpk[it] = d;
-      } else if (in_gelu) { pv.x = gelu_erf(pv.x); pv.y = gelu_erf(pv.y); pv.z = gelu_erf(pv.z); pv.w = gelu_erf(pv.w); }
-      if (p_drop > 0.f) {
-        const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
-        const unsigned long long z0 = drop_z0(seed, e0);      // one 64-bit multiply per 4 elements, constant adds for the rest
-        pv.x *= drop_scale_z(z0, p_drop, inv_keep); pv.y *= drop_scale_z(z0 + DROP_PHI, p_drop, inv_keep);
-        pv.z *= drop_scale_z(z0 + 2 * DROP_PHI, p_drop, inv_keep); pv.w *= drop_scale_z(z0 + 3 * DROP_PHI, p_drop, inv_keep);
+      else if (yy >= 0 && yy < r) { pv = *reinterpret_cast<const float4*>(ps + yy * r + x4); gv = *reinterpret_cast<const float4*>(gs + yy * r + x4); }
+      if (KEEP || (yy >= 0 && yy < r)) {
+        if (KEEP) {
+          float4 d;
+          gelu_both(pv.x, pv.x, d.x); gelu_both(pv.y, pv.y, d.y); gelu_both(pv.z, pv.z, d.z); gelu_both(pv.w, pv.w, d.w);
+          gpk[it] = d;
+        } else if (in_gelu) { pv.x = gelu_erf(pv.x); pv.y = gelu_erf(pv.y); pv.z = gelu_erf(pv.z); pv.w = gelu_erf(pv.w); }
+        if (p_drop > 0.f) {
+          const unsigned long long e0 = (unsigned long long)(pl_ * r * r + yy * r + x4);
+          const unsigned long long z0 = drop_z0(seed, e0);      // one 64-bit multiply per 4 elements, constant adds for the rest
+          pv.x *= drop_scale_z(z0, p_drop, inv_keep); pv.y *= drop_scale_z(z0 + DROP_PHI, p_drop, inv_keep);
+          pv.z *= drop_scale_z(z0 + 2 * DROP_PHI, p_drop, inv_keep); pv.w *= drop_scale_z(z0 + 3 * DROP_PHI, p_drop, inv_keep);
+        }
+        if (KEEP || gpre) {
+          const float4 q = KEEP ? pre_q[it] : *reinterpret_cast<const float4*>(gpre + pl_ * r * r + yy * r + x4);
+          gv.x *= gelu_grad1(q.x); gv.y *= gelu_grad1(q.y); gv.z *= gelu_grad1(q.z); gv.w *= gelu_grad1(q.w);
+        }
       }
-      if (KEEP || gpre) {
-        const float4 q = KEEP ? pre_q[it] : *reinterpret_cast<const float4*>(gpre + plane * r * r + yy * r + x4);
-        gv.x *= gelu_grad1(q.x); gv.y *= gelu_grad1(q.y); gv.z *= gelu_grad1(q.z); gv.w *= gelu_grad1(q.w);
-      }
-      *reinterpret_cast<float4*>(tp + (yy + 1) * LD + 4 + x4) = pv;
-      *reinterpret_cast<float4*>(tg + (yy + 1) * LD + 4 + x4) = gv;
+      *reinterpret_cast<float4*>(tp + (KEEP ? j + 1 : j) * LD + 4 + x4) = pv;
+      *reinterpret_cast<float4*>(tg + (KEEP ? j + 1 : j) * LD + 4 + x4) = gv;
     }
     if (KEEP) prefetch(plane + pstep < planes ? plane + pstep : plane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    float* dst = dP + plane * r * r;
+    float* dst = dP + pl_ * r * r + (size_t)y0 * r;
 #pragma unroll 4
     for (int it = 0; it < (KEEP ? 4 : (npix4 + 63) / 64); ++it) {
       const int i = lane + 64 * it;
@@ -691,7 +704,7 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* _
       }
       ab += (gc.x + gc.y) + (gc.z + gc.w);
       if (p_drop > 0.f) {
-        const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
+        const unsigned long long e0 = (unsigned long long)(pl_ * r * r + (y0 + yy) * r + x4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] *= drop_scale_z(drop_z0(seed, e0) + (unsigned long long)q * DROP_PHI, p_drop, inv_keep);
       }
@@ -699,13 +712,13 @@ __global__ __launch_bounds__(256, KEEP ? 2 : 1) void k_dwconv_bwd(const float* _
         const float4 d = gpk[it];
         a[0] *= d.x; a[1] *= d.y; a[2] *= d.z; a[3] *= d.w;
       } else if (out_gelu_bwd) {
-        const float4 q = *reinterpret_cast<const float4*>(P + plane * r * r + yy * r + x4);
+        const float4 q = *reinterpret_cast<const float4*>(P + pl_ * r * r + (y0 + yy) * r + x4);
         a[0] *= gelu_grad1(q.x); a[1] *= gelu_grad1(q.y); a[2] *= gelu_grad1(q.z); a[3] *= gelu_grad1(q.w);
       }
       *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
     }
-    // part: image b's row [Ch * 9 weight sums | Ch bias sums], added over the images in order by dpmn_rows_reduce_f32 (no atomics)
-    float* prow = part ? part + (plane / Ch) * (long)(Ch * 10) : nullptr;
+    // part: row (image b, band) = [Ch * 9 weight sums | Ch bias sums], added over the rows in order by dpmn_rows_reduce_f32 (no atomics)
+    float* prow = part ? part + ((pl_ / Ch) * nb + (KEEP ? 0 : plane % nb)) * (long)(Ch * 10) : nullptr;
 #pragma unroll
     for (int i = 0; i < 9; ++i) aw[i] = wave_sum_dpp(aw[i]);
     ab = wave_sum_dpp(ab);
@@ -1177,6 +1190,14 @@ int dpmn_sk_feats_grad_f32(const float* dout, const float* feats, const float* d
 }
 
 // KEEP variant: persistent, 2 blocks per CU (256 registers per wave for the prefetch), never more blocks than planes / 4
+// rows per band of the generic (non-KEEP) kernel: whole planes up to 32 x 32, 16-row bands above; DPMN_DW_BAND overrides (pgrm.hip has the twin)
+static int dwconv_bwd_band_rows(int r) {
+  static const int env = getenv("DPMN_DW_BAND") ? atoi(getenv("DPMN_DW_BAND")) : -1;
+  int rb = env >= 0 ? env : (r > 32 && r % 16 == 0 ? 16 : r);
+  if (rb <= 0 || rb > r || r % rb != 0) rb = r;
+  return rb;
+}
+
 static long dwconv_bwd_grid(long planes) {
   static int n_cu = 0;
   if (!n_cu) {
@@ -1193,10 +1214,11 @@ int dpmn_dwconv3x3_bwd_f32(const float* P, const float* dg, const float* w, floa
                            dpmn_stream_t stream) {
   DPMN_REQUIRE(P && dg && w && dP && dw && db && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_bwd: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
-  const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
+  const int rb = dwconv_bwd_band_rows(r);
+  const size_t smem = (size_t)8 * (rb + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
-                     planes);
+  hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes * (r / rb) + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+                     planes, static_cast<const float*>(nullptr), 0, 0, 0.f, 0ull, static_cast<float*>(nullptr), rb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -1207,39 +1229,48 @@ int dpmn_dwconv3x3_bwd_fused_f32(const float* P, const float* dg, const float* g
   DPMN_REQUIRE(P && dg && w && dP && dw && db && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_bwd_fused: plane side must be a multiple of 4 in [4, 64]");
   DPMN_REQUIRE(!out_gelu_bwd || in_gelu, "dwconv_bwd_fused: out_gelu_bwd needs P to be the pre-activation (in_gelu)");
   const long planes = (long)B * Ch;
-  const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
   const bool keep = in_gelu && out_gelu_bwd && gpre && r == 32;
+  const int rb = keep ? r : dwconv_bwd_band_rows(r);
+  const size_t smem = (size_t)8 * (rb + 2) * (r + 8) * 4;
   // dP (9 taps) + dw (9 taps) = 36 FLOPs per element; P, dg (, gpre) read, dP written
   ProfScope prof(PT_DWCONV_BWD, as_stream(stream), 36.0 * planes * r * r, 4.0 * (gpre ? 4 : 3) * (double)planes * r * r);
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (keep) hipLaunchKernelGGL(k_dwconv_bwd<true>, dim3((unsigned)dwconv_bwd_grid(planes)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed);
-  else hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
-                     planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed);
+  else hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes * (r / rb) + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+                     planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, static_cast<float*>(nullptr), rb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
 
-// the same without atomics: per-image [Ch * 9 | Ch] partial rows in ws (B * Ch * 10 floats), added in image order -- bitwise reproducible
+// workspace of the atomics-free variant: one [Ch * 9 | Ch] partial row per (image, band)
+size_t dpmn_dwconv3x3_bwd_det_bytes(int B, int Ch, int r) {
+  if (B <= 0 || Ch <= 0 || r <= 0) return 0;
+  const int rb = dwconv_bwd_band_rows(r);      // (the whole-plane KEEP kernel of the 32 x 32 planes needs B rows: never more than this)
+  return (size_t)B * (r / rb) * Ch * 10 * sizeof(float);
+}
+
+// the same without atomics: per-(image, band) [Ch * 9 | Ch] partial rows in ws (dpmn_dwconv3x3_bwd_det_bytes), added in row order -- bitwise reproducible
 int dpmn_dwconv3x3_bwd_fused_det_f32(const float* P, const float* dg, const float* gpre, const float* w, float* dP, float* dw, float* db,
                                      int in_gelu, int out_gelu_bwd, float p_drop, unsigned long long seed, int B, int Ch, int r,
                                      float* ws, size_t ws_bytes, dpmn_stream_t stream) {
   DPMN_REQUIRE(P && dg && w && dP && dw && db && ws && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_bwd_fused_det: bad arguments");
   DPMN_REQUIRE(!out_gelu_bwd || in_gelu, "dwconv_bwd_fused_det: out_gelu_bwd needs P to be the pre-activation (in_gelu)");
-  if ((size_t)B * Ch * 10 * sizeof(float) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "dwconv_bwd_fused_det: workspace too small");
+  if (dpmn_dwconv3x3_bwd_det_bytes(B, Ch, r) > ws_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "dwconv_bwd_fused_det: workspace too small (dpmn_dwconv3x3_bwd_det_bytes)");
   const long planes = (long)B * Ch;
-  const size_t smem = (size_t)8 * (r + 2) * (r + 8) * 4;
   const bool keep = in_gelu && out_gelu_bwd && gpre && r == 32;
+  const int rb = keep ? r : dwconv_bwd_band_rows(r);
+  const size_t smem = (size_t)8 * (rb + 2) * (r + 8) * 4;
   // dP (9 taps) + dw (9 taps) = 36 FLOPs per element; P, dg (, gpre) read, dP written
   ProfScope prof(PT_DWCONV_BWD, as_stream(stream), 36.0 * planes * r * r, 4.0 * (gpre ? 4 : 3) * (double)planes * r * r);
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_bwd<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (keep) hipLaunchKernelGGL(k_dwconv_bwd<true>, dim3((unsigned)dwconv_bwd_grid(planes)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
                      planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, ws);
-  else hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
-                     planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, ws);
+  else hipLaunchKernelGGL(k_dwconv_bwd<false>, dim3((unsigned)((planes * (r / rb) + 3) / 4)), dim3(256), smem, as_stream(stream), P, dg, w, dP, dw, db, Ch, r,
+                     planes, gpre, in_gelu, out_gelu_bwd, p_drop, seed, ws, rb);
   DPMN_CHECK_LAUNCH();
   prof.close();      // (the row reduction below is not part of the family)
-  return dpmn_rows_reduce_f32(ws, dw, db, Ch * 9, Ch, B, stream);
+  return dpmn_rows_reduce_f32(ws, dw, db, Ch * 9, Ch, B * (r / rb), stream);
 }
 
 int dpmn_rowsum_mod_det_f32(const float* x, float* out, long rows, int cols, int mod, float* ws, size_t ws_bytes, dpmn_stream_t stream) {

@@ -643,23 +643,30 @@ __global__ void k_sk_gate(const float* __restrict__ partial, int parts_per_image
 // in_gelu: the input is a pre-activation, GELU is applied on the way into the LDS tile (fc1's GELU, pgrm.py:33)
 // R32: 32 x 32 planes (the Mlp of the 16 x 64 -> 32 x 128 stacks) -- exactly four float4 per lane: all four loads are issued before the
 // first GELU, no tail predicate
+// generic path (!R32): a wave takes a BAND of rb rows of a plane (rb = r: the whole plane) with one halo row above and below,
+// re-read (and re-activated) from the neighbouring bands -- 64 x 64 planes (the stress stack) as whole-plane tiles need 19 KB of LDS per
+// wave, 8 waves per CU, and ran at 0.34 of the HBM rate; 16-row bands need 5 KB
 template <bool R32>
 __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y, const float* __restrict__ w,
                                                       const float* __restrict__ bias, float* __restrict__ g, int Ch, int r,
                                                       long planes, int apply_gelu, float* __restrict__ g2 = nullptr, int in_gelu = 0,
-                                                      float p_drop = 0.f, unsigned long long seed = 0ull) {
+                                                      float p_drop = 0.f, unsigned long long seed = 0ull, int rb = 0) {
   // p_drop > 0 (with in_gelu): nn.Dropout between fc1's GELU and the conv (pgrm.py:34) -- the mask is a pure function of
   // (seed, element index), so it is applied on load instead of through a materialised activated tensor
   const float inv_keep = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-  // per wave: one r x r plane in an LDS tile of (r+2) rows x LD = r+8 floats; the plane starts at column 4 so that rows are
+  // per wave: one band in an LDS tile of (rb+2) rows x LD = r+8 floats; the plane starts at column 4 so that rows are
   // 16-byte aligned for float4 traffic (global loads / stores and the centre taps); r % 4 == 0
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long plane = (long)blockIdx.x * 4 + wave;
+  if (R32 || rb <= 0) rb = r;
+  const int nb = r / rb;
+  const long vplane = (long)blockIdx.x * 4 + wave;
+  const long plane = R32 ? vplane : vplane / nb;
+  const int y0 = R32 ? 0 : (int)(vplane % nb) * rb;
   const bool valid = plane < planes;
   const int c = valid ? (int)(plane % Ch) : 0;
   const int LD = r + 8, r4 = r >> 2;
-  float* t = sm + wave * (r + 2) * LD;
+  float* t = sm + wave * (rb + 2) * LD;
   if (valid) {
     const float* src = y + plane * r * r;
     float4 pre[R32 ? 4 : 1];
@@ -667,23 +674,30 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
 #pragma unroll
       for (int it = 0; it < 4; ++it) pre[it] = *reinterpret_cast<const float4*>(src + 4 * (lane + 64 * it));
     }
+    // R32: tile rows 1 .. r hold the plane, rows 0 and r + 1 the zero halo; bands: tile row j holds plane row y0 - 1 + j
+    const int nld = R32 ? 256 : (rb + 2) * r4;
 #pragma unroll 4
-    for (int it = 0; it < (R32 ? 4 : (r * r4 + 63) / 64); ++it) {
+    for (int it = 0; it < (R32 ? 4 : (nld + 63) / 64); ++it) {
       const int i = lane + 64 * it;
-      if (!R32 && i >= r * r4) break;
-      const int yy = i / r4, x4 = (i - yy * r4) * 4;
-      float4 v = R32 ? pre[R32 ? it : 0] : *reinterpret_cast<const float4*>(src + yy * r + x4);
-      if (in_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
-      if (p_drop > 0.f) {
-        const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
-        const unsigned long long z0 = drop_z0(seed, e0);
-        v.x *= drop_scale_z(z0, p_drop, inv_keep); v.y *= drop_scale_z(z0 + DROP_PHI, p_drop, inv_keep);
-        v.z *= drop_scale_z(z0 + 2 * DROP_PHI, p_drop, inv_keep); v.w *= drop_scale_z(z0 + 3 * DROP_PHI, p_drop, inv_keep);
+      if (!R32 && i >= nld) break;
+      const int j = i / r4, x4 = (i - j * r4) * 4;
+      const int yy = R32 ? j : y0 - 1 + j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (R32 || (yy >= 0 && yy < r)) {
+        v = R32 ? pre[R32 ? it : 0] : *reinterpret_cast<const float4*>(src + yy * r + x4);
+        if (in_gelu) { v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w); }
+        if (p_drop > 0.f) {
+          const unsigned long long e0 = (unsigned long long)(plane * r * r + yy * r + x4);
+          const unsigned long long z0 = drop_z0(seed, e0);
+          v.x *= drop_scale_z(z0, p_drop, inv_keep); v.y *= drop_scale_z(z0 + DROP_PHI, p_drop, inv_keep);
+          v.z *= drop_scale_z(z0 + 2 * DROP_PHI, p_drop, inv_keep); v.w *= drop_scale_z(z0 + 3 * DROP_PHI, p_drop, inv_keep);
+        }
       }
-      *reinterpret_cast<float4*>(t + (yy + 1) * LD + 4 + x4) = v;
+      *reinterpret_cast<float4*>(t + (R32 ? j + 1 : j) * LD + 4 + x4) = v;
     }
-    for (int i = lane; i < LD; i += 64) { t[i] = 0.f; t[(r + 1) * LD + i] = 0.f; }       // top / bottom halo rows
-    for (int i = lane; i < r; i += 64) { t[(i + 1) * LD + 3] = 0.f; t[(i + 1) * LD + 4 + r] = 0.f; }   // left / right halo columns
+    if (R32)
+      for (int i = lane; i < LD; i += 64) { t[i] = 0.f; t[(r + 1) * LD + i] = 0.f; }       // top / bottom halo rows
+    for (int i = lane; i < rb + 2; i += 64) { t[i * LD + 3] = 0.f; t[i * LD + 4 + r] = 0.f; }   // left / right halo columns
   }
   // the tile is private to the wave (LDS operations of one wave execute in order): no block barrier
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -692,8 +706,8 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
 #pragma unroll
   for (int i = 0; i < 9; ++i) k[i] = w[c * 9 + i];
   const float bv = bias[c];
-  float* dst = g + plane * r * r;
-  for (int i = lane; i < r * r4; i += 64) {
+  float* dst = g + plane * r * r + (size_t)y0 * r;
+  for (int i = lane; i < rb * r4; i += 64) {
     const int yy = i / r4, x4 = (i - yy * r4) * 4;
     float a[4] = {bv, bv, bv, bv};
 #pragma unroll
@@ -709,7 +723,7 @@ __global__ __launch_bounds__(256) void k_dwconv_gelu(const float* __restrict__ y
     }
     if (apply_gelu == 2) {
       *reinterpret_cast<float4*>(dst + yy * r + x4) = make_float4(a[0], a[1], a[2], a[3]);
-      *reinterpret_cast<float4*>(g2 + plane * r * r + yy * r + x4) = make_float4(gelu_erf(a[0]), gelu_erf(a[1]), gelu_erf(a[2]), gelu_erf(a[3]));
+      *reinterpret_cast<float4*>(g2 + plane * r * r + (size_t)(y0 + yy) * r + x4) = make_float4(gelu_erf(a[0]), gelu_erf(a[1]), gelu_erf(a[2]), gelu_erf(a[3]));
       continue;
     }
     if (apply_gelu) {
@@ -804,6 +818,14 @@ __global__ void k_pack_conv_w(const float* __restrict__ w, float* __restrict__ w
 }  // namespace
 
 // ================================================================================== C ABI
+// rows per band of the generic depthwise kernels: whole planes up to 32 x 32, 16-row bands above (r a multiple of 16), DPMN_DW_BAND overrides
+static int dwconv_band_rows(int r) {
+  static const int env = getenv("DPMN_DW_BAND") ? atoi(getenv("DPMN_DW_BAND")) : -1;
+  int rb = env >= 0 ? env : (r > 32 && r % 16 == 0 ? 16 : r);
+  if (rb <= 0 || rb > r || r % rb != 0) rb = r;
+  return rb;
+}
+
 extern "C" {
 
 int dpmn_patch_embed_ln_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
@@ -895,11 +917,14 @@ int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, f
                             dpmn_stream_t stream) {
   DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
-  const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
+  const int rb = dwconv_band_rows(r);
+  const long vplanes = planes * (r / rb);
+  const size_t smem = (size_t)4 * (rb + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   ProfScope prof(PT_DWCONV_GELU, as_stream(stream), 18.0 * planes * r * r, 8.0 * planes * r * r);
   if (r == 32) hipLaunchKernelGGL(k_dwconv_gelu<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
-  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1);
+  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((vplanes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1,
+                     static_cast<float*>(nullptr), 0, 0.f, 0ull, rb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -909,13 +934,15 @@ int dpmn_dwconv3x3_gelu_f32(const float* y, const float* w, const float* bias, f
 int dpmn_dwconv3x3_gelu_in_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream) {
   DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
-  const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
+  const int rb = dwconv_band_rows(r);
+  const long vplanes = planes * (r / rb);
+  const size_t smem = (size_t)4 * (rb + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   ProfScope prof(PT_DWCONV_GELU, as_stream(stream), 18.0 * planes * r * r, 8.0 * planes * r * r);
   if (r == 32) hipLaunchKernelGGL(k_dwconv_gelu<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1,
                      static_cast<float*>(nullptr), 1, 0.f, 0ull);
-  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1,
-                     static_cast<float*>(nullptr), 1, 0.f, 0ull);
+  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((vplanes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 1,
+                     static_cast<float*>(nullptr), 1, 0.f, 0ull, rb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -923,10 +950,13 @@ int dpmn_dwconv3x3_gelu_in_f32(const float* y, const float* w, const float* bias
 int dpmn_dwconv3x3_f32(const float* y, const float* w, const float* bias, float* g, int B, int Ch, int r, dpmn_stream_t stream) {
   DPMN_REQUIRE(y && w && bias && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
-  const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
+  const int rb = dwconv_band_rows(r);
+  const long vplanes = planes * (r / rb);
+  const size_t smem = (size_t)4 * (rb + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (r == 32) hipLaunchKernelGGL(k_dwconv_gelu<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
-  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 0);
+  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((vplanes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, g, Ch, r, planes, 0,
+                     static_cast<float*>(nullptr), 0, 0.f, 0ull, rb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -935,12 +965,14 @@ int dpmn_dwconv3x3_train_f32(const float* y, const float* w, const float* bias, 
                              unsigned long long seed, int B, int Ch, int r, dpmn_stream_t stream) {
   DPMN_REQUIRE(y && w && bias && gpre && g && r >= 4 && r <= 64 && r % 4 == 0, "dwconv_train: plane side must be a multiple of 4 in [4, 64]");
   const long planes = (long)B * Ch;
-  const size_t smem = (size_t)4 * (r + 2) * (r + 8) * 4;
+  const int rb = dwconv_band_rows(r);
+  const long vplanes = planes * (r / rb);
+  const size_t smem = (size_t)4 * (rb + 2) * (r + 8) * 4;
   if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_gelu<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (r == 32) hipLaunchKernelGGL(k_dwconv_gelu<true>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, gpre, Ch, r, planes, 2, g,
                      in_gelu, p_drop, seed);
-  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((planes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, gpre, Ch, r, planes, 2, g,
-                     in_gelu, p_drop, seed);
+  else hipLaunchKernelGGL(k_dwconv_gelu<false>, dim3((unsigned)((vplanes + 3) / 4)), dim3(256), smem, as_stream(stream), y, w, bias, gpre, Ch, r, planes, 2, g,
+                     in_gelu, p_drop, seed, rb);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -521,7 +521,7 @@ def backward(m, sv, dout, need_dx_kv=True):
         dypre = torch.empty_like(dg)
         r = int(round(L ** 0.5))
         if DET_SMALL:
-            ptr, nb = _ws(dz.device, B * Ch * 10 * 4)
+            ptr, nb = _ws(dz.device, lib.dpmn_dwconv3x3_bwd_det_bytes(B, Ch, r))
             check(lib.dpmn_dwconv3x3_bwd_fused_det_f32(dptr(s["ypre"]), dptr(dg), dptr(s["gpre"]), dptr(mlp.depthwise_conv.weight),
                                                        dptr(dypre), dptr(gr[mlp.depthwise_conv.weight]), dptr(gr[mlp.depthwise_conv.bias]),
                                                        1, 1, float(pd), int(sb[2]), B, Ch, r, ptr, nb, stream()))

@@ -433,6 +433,7 @@ int dpmn_rowsum_mod_f32(const float* x, float* out, long rows, int cols, int mod
 int dpmn_rows_reduce_f32(const float* part, float* dw, float* db, int NK, int N, int rows, dpmn_stream_t stream);
 int dpmn_rowsum_mod_det_f32(const float* x, float* out, long rows, int cols, int mod, float* ws /* rows floats */, size_t ws_bytes,
                             dpmn_stream_t stream);
+size_t dpmn_dwconv3x3_bwd_det_bytes(int B, int Ch, int r);      /* workspace bytes of dpmn_dwconv3x3_bwd_fused_det_f32 */
 int dpmn_dwconv3x3_bwd_fused_det_f32(const float* P, const float* dg, const float* gpre, const float* w, float* dP, float* dw, float* db,
                                      int in_gelu, int out_gelu_bwd, float p_drop, unsigned long long seed, int B, int Ch, int r,
                                      float* ws /* B * Ch * 10 floats */, size_t ws_bytes, dpmn_stream_t stream);
