@@ -485,7 +485,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, 
     gam[i] = *reinterpret_cast<const float4*>(gamma + (t + 8 * i) * 4);
     ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  constexpr int R = 2;
+  constexpr int R = C > 96 ? 1 : 2;      // rows per thread group in flight (C = 192: 6 float4 per stream and row already)
   const long stride = (long)gridDim.x * 32;
   for (long row0 = (long)blockIdx.x * 32 + sub; row0 < M; row0 += stride * R) {
     float4 xv[R][V], dv[R][V], dxo[R][V];
@@ -854,12 +854,13 @@ static int layernorm_bwd_impl(const float* x, const float* dy, const float* gamm
   unsigned nblk = blocks;
   static const int v4 = getenv("DPMN_LNB_V4") ? atoi(getenv("DPMN_LNB_V4")) : 1;
   ProfScope prof(PT_LN_BWD, as_stream(stream), 0.0, 4.0 * (accumulate_dx ? 4 : 3) * (double)M * C);
-  if (C == 96 && v4) {
+  if ((C == 96 || C == 192) && v4) {
     // in-pipeline sweep of the vector kernel at M = 49152: 256 blocks 20.2 us, 384: 21.2, 512: 24.3, 768: 27.6, 1024: 33.3
     // (the scalar kernel it replaces: 36.8 us) -- one block per CU, the same-address dgamma / dbeta atomics set the slope
     static const long cap4 = getenv("DPMN_LNB_BLOCKS") ? atol(getenv("DPMN_LNB_BLOCKS")) : 256;
     const unsigned b4 = (unsigned)(M / 32 < cap4 ? (M + 31) / 32 : cap4);
-    hipLaunchKernelGGL((k_ln_bwd_v4<96>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
+    if (C == 96) hipLaunchKernelGGL((k_ln_bwd_v4<96>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
+    else hipLaunchKernelGGL((k_ln_bwd_v4<192>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
     nblk = b4;
   } else if (C == 96)
     hipLaunchKernelGGL((k_ln_bwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
