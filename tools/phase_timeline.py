@@ -21,6 +21,7 @@ for m in models + distill:
     for p in m.parameters():
         p.requires_grad = True
 trainer = Trainer(models + distill, lr=1e-3, beta1=0.5, max_norm=0.25)
+import time
 REC = []
 ON = [False]
 
@@ -32,9 +33,11 @@ def wrap(fn, name):
         st = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
+        h0 = time.perf_counter()
         out = fn(*a, **k)
+        h1 = time.perf_counter()
         e1.record(st)
-        REC.append((name, st.cuda_stream, e0, e1))
+        REC.append((name, st.cuda_stream, e0, e1, h0, h1))
         return out
     return inner
 
@@ -66,6 +69,10 @@ t1 = torch.cuda.Event(enable_timing=True); t1.record()
 torch.cuda.synchronize()
 print("step %.2f ms on the GPU; the host thread needed %.2f ms to issue it" % (t0.elapsed_time(t1), (c1 - c0) * 1e3))
 streams = {}
-for name, sid, e0, e1 in sorted(REC, key=lambda r: t0.elapsed_time(r[2])):
+# GPU window of every phase next to the HOST window in which its launches were issued (same origin: the step's start).  A phase whose
+# GPU end trails its host end by less than a launch or two is issue-bound: the GPU ran out of queued work while the host was still in it.
+for name, sid, e0, e1, h0, h1 in sorted(REC, key=lambda r: t0.elapsed_time(r[2])):
     s_ = streams.setdefault(sid, len(streams))
-    print("  stream %d  %-22s %7.2f .. %7.2f  (%5.2f ms)" % (s_, name, t0.elapsed_time(e0), t0.elapsed_time(e1), e0.elapsed_time(e1)))
+    print("  stream %d  %-22s GPU %7.2f .. %7.2f  (%5.2f ms)   host issue %7.2f .. %7.2f  (%5.2f ms)   GPU end - host end %6.2f" % (
+        s_, name, t0.elapsed_time(e0), t0.elapsed_time(e1), e0.elapsed_time(e1), (h0 - c0) * 1e3, (h1 - c0) * 1e3, (h1 - h0) * 1e3,
+        t0.elapsed_time(e1) - (h1 - c0) * 1e3))

@@ -25,7 +25,7 @@ for r in csv.DictReader(open(f)):
         seen.add(key)
         cnt[n] += 1
         dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-nfwd = cnt.get("k_dwconv_gelu", 2) / 2.0          # two Mlp blocks per PGRM forward
+nfwd = sum(v for k_, v in cnt.items() if k_.startswith("k_dwconv_gelu")) / 2.0 or 1.0          # two Mlp blocks per PGRM forward
 rows, tot_busy, tot_avail, tot_ms = [], 0.0, 0.0, 0.0
 for n, c in per.items():
     if not n.startswith("k_"):
