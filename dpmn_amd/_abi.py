@@ -40,6 +40,19 @@ class PgrmWeights(C.Structure):
         ("weight_list", fp * 16), ("reuse_folded", C.c_int)]
 
 
+class PgrmSavedBlock(C.Structure):
+    NAMES = ("cat", "fold", "feats", "partial", "avec", "x1", "ypre", "V", "n2", "gpre", "g", "z", "tkv_out")
+    _fields_ = [(n, fp) for n in NAMES]
+
+
+class PgrmSaved(C.Structure):
+    _fields_ = [("tq", fp), ("tkv0", fp), ("blk", PgrmSavedBlock * 2), ("c0", fp), ("c1", fp)]
+
+
+class PgrmDrop(C.Structure):
+    _fields_ = [("p", C.c_float), ("pa", C.c_float), ("dp", C.c_float * 2), ("seeds", C.c_ulonglong * 12)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("inp", fp * 3), ("in_scale", fp * 3), ("in_shift", fp * 3), ("cseg", C.c_int * 3)] + [
         (n, C.c_int) for n in ("B", "Hin", "Win", "KH", "KW", "stride", "dil_y", "dil_x", "pad_y", "pad_x", "Hp", "Wp",
@@ -249,6 +262,9 @@ SIGNATURES = {
     "dpmn_cmm_forward_f32": (_i, [C.POINTER(CmmWeights), fp, fp, fp, fp, _sz, C.POINTER(CmmScratch), _i, fp]),
     "dpmn_pgrm_workspace_bytes": (_sz, [C.POINTER(PgrmWeights), _i]),
     "dpmn_pgrm_forward_f32": (_i, [C.POINTER(PgrmWeights), fp, _i, fp, _PP, _i, fp, fp, _sz, _i, fp]),
+    "dpmn_pgrm_forward_train_supported": (_i, [C.POINTER(PgrmWeights), _i]),
+    "dpmn_pgrm_forward_train_f32": (_i, [C.POINTER(PgrmWeights), fp, _i, fp, _PP, _i, fp, fp, C.POINTER(PgrmDrop), C.POINTER(PgrmSaved),
+                                         C.POINTER(CmmScratch), fp, _i, fp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

@@ -216,7 +216,9 @@ class PGRM(nn.Module):
 
     # ------------------------------------------------------------------ C-ABI weight table
     def _weights(self):
-        params = list(self.parameters())
+        params = self.__dict__.get("_param_list")      # the module tree is fixed after construction: walk it once
+        if params is None:
+            params = self.__dict__["_param_list"] = list(self.parameters())
         key = tuple(p.data_ptr() for p in params)
         if self._packed is not None and self._packed[0] == key:
             return self._packed[1]

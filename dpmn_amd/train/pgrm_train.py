@@ -349,6 +349,82 @@ def drop_config(m):
     return dict(p=p, pa=pa, dp=tuple(dp), seeds=draw_seeds())
 
 
+NATIVE_FWD = os.environ.get("DPMN_PGRM_NATIVE_TRAIN", "1") != "0"     # 0: issue the training forward op by op from Python (A/B switch)
+
+
+def _saved_layout(m, B):
+    """Offsets (floats, 64-float aligned) of every tensor the backward reads inside one slab: [(key, block or None, offset, shape)]."""
+    H, Wd = m.patches_resolution
+    L, Cd, G = H * Wd, m.embed_dim, len(m.window_size)
+    M, Ch = B * L, int(m.embed_dim * m.mlp_ratio)
+    Cm = m.hidden_size * m.patch * m.patch
+    fold = lib.dpmn_ln_qkv_window_attn_workspace_bytes() // 4
+    per_block = [("cat", (M, Cd)), ("fold", (fold,)), ("feats", (M, Cd)), ("partial", (B * ((L + 31) // 32), Cd)), ("avec", (B, G, Cd // G)),
+                 ("x1", (M, Cd)), ("ypre", (M, Ch)), ("V", (M, Cd // G)), ("n2", (M, Cd)), ("gpre", (M, Ch)), ("g", (M, Ch)), ("z", (M, Ch)),
+                 ("tkv_out", (M, Cd))]
+    items = [("tq", None, (M, Cd)), ("tkv0", None, (M, Cd))]
+    for bi in range(2):
+        items += [(k, bi, shp) for k, shp in per_block]
+    items += [("c0", None, (B, H, Wd, Cm)), ("c1", None, (B, H, Wd, Cm))]
+    out, off = [], 0
+    for key, bi, shp in items:
+        n = 1
+        for v in shp:
+            n *= v
+        out.append((key, bi, off, n, shp))
+        off += (n + 63) // 64 * 64
+    return out, off
+
+
+def _forward_native(m, x_q, x_kv, residuals, drop, w):
+    """forward() below as ONE native call (csrc/pgrm_forward.hip dpmn_pgrm_forward_train_f32): same kernels, same order, same saved
+    tensors -- carved out of one slab -- without the host time of ~45 ctypes calls and tensor allocations per module."""
+    import ctypes as C
+    B = x_kv.shape[0]
+    H, Wd = m.patches_resolution
+    lay = m.__dict__.setdefault("_train_layout", {})
+    if B not in lay:
+        lay[B] = _saved_layout(m, B)
+    items, total = lay[B]
+    slab = torch.empty(total, device=x_kv.device)
+    base = slab.data_ptr()
+    cs = _abi.PgrmSaved()
+    sv = dict(x_q=x_q, x_kv=x_kv, residuals=list(residuals), blocks=[{}, {}], drop=drop)
+    for key, bi, off, n, shp in items:
+        t = slab.narrow(0, off, n).view(shp)
+        if bi is None:
+            setattr(cs, key, base + 4 * off)
+            sv[key] = t
+        else:
+            setattr(cs.blk[bi], key, base + 4 * off)
+            sv["blocks"][bi][key] = t
+    for bi, blk in enumerate(m.layers[0].blocks):
+        s = sv["blocks"][bi]
+        s["tkv_in"] = sv["tkv0"] if bi == 0 else sv["blocks"][bi - 1]["tkv_out"]
+        s["win"] = [min(H, Wd) if min(H, Wd) <= ws else ws for ws in m.window_size]
+        s["shift"] = [0 if (bi == 0 or min(H, Wd) <= ws) else ws // 2 for ws in m.window_size]
+        s["tables"] = [getattr(blk.attn, "relative_position_bias_table_%d" % g) for g in range(len(m.window_size))]
+        s["q"] = s["kv"] = s["nq"] = s["nkv"] = None
+    sv["tkv_out"] = sv["blocks"][1]["tkv_out"]
+    cd = None
+    if drop:
+        cd = _abi.PgrmDrop()
+        cd.p, cd.pa = drop["p"], drop["pa"]
+        cd.dp[0], cd.dp[1] = drop["dp"]
+        for i, v in enumerate(drop["seeds"]):
+            cd.seeds[i] = v
+    d = _abi.ConvDesc()
+    ops._attach_workspace(d, x_kv.device)
+    sc = _abi.CmmScratch(d.splitk_ws, d.splitk_ws_bytes, d.arrive_cnt, d.arrive_cnt_len)
+    t0 = packing.tpack_conv(m.conv_before_upsample[0].weight)
+    t1 = packing.tpack_conv(m.conv_before_upsample[1].weight)
+    out = torch.empty(B, m.hidden_size, m.img_size[0], m.img_size[1], device=x_kv.device)
+    check(lib.dpmn_pgrm_forward_train_f32(C.byref(w), dptr(x_q), x_q.shape[1], dptr(x_kv), _abi.ptr_array(residuals), len(residuals), dptr(t0),
+                                          dptr(t1), C.byref(cd) if cd is not None else None, C.byref(cs), C.byref(sc), dptr(out), B, stream()))
+    sv["_slab"] = slab
+    return out, sv
+
+
 def forward(m, x_q, x_kv, residuals, drop=None):
     """Returns (out, saved).  m: dpmn_amd.model.pgrm.PGRM; drop: drop_config(m)."""
     B = x_kv.shape[0]
@@ -360,6 +436,11 @@ def forward(m, x_q, x_kv, residuals, drop=None):
     fuse = x_q.shape[1] == 2          # pgrm.py:547-548: prior_fusion runs iff the prior has 2 channels, whatever `mode` is
     if fuse and m.mode:
         raise _abi.DpmnError("PGRM(mode=True) has no prior_fusion: x_q must have 3 channels (pgrm.py:470,547)")
+    if NATIVE_FWD and FUSED_ATTN and FUSED_ATTN_BWD and FUSED_SKMLP and x_q.dtype == torch.float32 and x_kv.dtype == torch.float32:
+        import ctypes as C
+        w = m._weights()
+        if lib.dpmn_pgrm_forward_train_supported(C.byref(w), B):
+            return _forward_native(m, x_q, x_kv, residuals, drop, w)
     pf = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
     tq = ops.patch_embed_ln(x_q, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch, *pf).reshape(M, Cd)
     tkv = ops.patch_embed_ln(x_kv, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch).reshape(M, Cd)

@@ -661,6 +661,34 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
                           const float* const* residuals, int n_residuals, float* out, void* workspace,
                           size_t workspace_bytes, int B, dpmn_stream_t stream);
 
+/* PGRM.forward in TRAINING mode as one call (pgrm.py:546-565 with pos_drop / attn_drop / Mlp.drop / DropPath active, and every
+ * activation the hand-written backward of dpmn_amd/train/pgrm_train.py reads written out).  Replaces the ~22 per-op calls of
+ * train/pgrm_train.py::forward: the host issue time of those (~0.5 ms against 0.8 ms of GPU work per module at B=48) made the forward
+ * phase of the training step host-bound.  The caller owns every buffer:
+ *   saved.tq, saved.tkv0                       (B L, C)   patch-embedded (+pos_drop) token streams
+ *   per block: cat, feats, x1, n2, tkv_out     (B L, C);  ypre, gpre, g, z (B L, Ch);  V (B L, C / groups);  avec (B, groups, C / groups);
+ *              partial (B ceil(L / 32), C);  fold: dpmn_ln_qkv_window_attn_workspace_bytes() bytes (folded LayerNorm + q / kv weights,
+ *              reused by dpmn_ln_qkv_window_attn_bwd_f32)
+ *   saved.c0, saved.c1                         (B, H, W, hidden_size patch^2) NHWC outputs of conv_before_upsample[0] / [1]
+ * tail0_packed / tail1_packed: conv_before_upsample weights in the packed layout of dpmn_conv2d_nhwc_f32 (dpmn_conv_pack_f32).
+ * drop == NULL: all rates zero.  seeds: [0] pos_drop(x_q) [1] pos_drop(x_kv); block b at 2 + 5 b: attn_drop, DropPath(attention),
+ * Mlp.drop after act_1, Mlp.drop after fc2, DropPath(mlp) -- the masks the backward regenerates.
+ * dpmn_pgrm_forward_train_supported: 1 when the geometry runs on the fused training kernels (dim 96 / head dim 16 / windows
+ * <= 8 / hidden_size 3 / patch 2); otherwise callers keep the per-op sequence. */
+typedef struct {
+  float *cat, *fold, *feats, *partial, *avec, *x1, *ypre, *V, *n2, *gpre, *g, *z, *tkv_out;
+} dpmn_pgrm_saved_block;
+typedef struct {
+  float *tq, *tkv0;
+  dpmn_pgrm_saved_block blk[2];
+  float *c0, *c1;
+} dpmn_pgrm_saved;
+typedef struct {
+  float p, pa, dp[2];               /* drop_rate, attn_drop_rate, DropPath rate of block 0 / 1 */
+  unsigned long long seeds[12];
+} dpmn_pgrm_drop;
+int dpmn_pgrm_forward_train_supported(const dpmn_pgrm_weights* w, int B);
+
 /* ------------------------------------------------------------------ native CMM forward (cmm_forward.hip) */
 /* ComplementationModulationModule.forward(x1, x2) in eval mode (cmm.py:120-161) as ONE call: 2 layout kernels, 10 grouped
  * encoder convs (the twin branches of cmm.py:86-99 share a launch), the channel gate, 5 phase-fused transposed convs and
@@ -682,6 +710,11 @@ typedef struct {            /* the per-stream conv scratch of dpmn_conv_desc (sp
   unsigned* arrive_cnt;
   int arrive_cnt_len;
 } dpmn_cmm_scratch;
+/* see dpmn_pgrm_saved above; scratch: the per-stream conv scratch (may be NULL: no split-K) */
+int dpmn_pgrm_forward_train_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_channels, const float* x_kv,
+                                const float* const* residuals, int n_residuals, const float* tail0_packed, const float* tail1_packed,
+                                const dpmn_pgrm_drop* drop, const dpmn_pgrm_saved* saved, const dpmn_cmm_scratch* scratch, float* out,
+                                int B, dpmn_stream_t stream);
 size_t dpmn_cmm_workspace_bytes(const dpmn_cmm_weights* w, int B);
 /* x1, x2 (B, c_img, H, W) NCHW; out (B, c_img, H, W) NCHW; workspace >= dpmn_cmm_workspace_bytes (activations; contents are
  * scratch).  H, W multiples of 32. */

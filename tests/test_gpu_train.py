@@ -247,6 +247,59 @@ def test_pgrm_train_dropout_vs_oracle_same_masks(dev, rates):
     assert float((out2 - out.detach()).abs().max()) > 1e-4, "fresh masks per call"
 
 
+@pytest.mark.parametrize("rates", [(0.0, 0.0, 0.0), (0.1, 0.1, 0.6)])
+@pytest.mark.parametrize("mode", [True, False])
+def test_pgrm_native_training_forward_equals_per_op_forward(dev, rates, mode, monkeypatch):
+    """dpmn_pgrm_forward_train_f32 (one native call per module) issues the same kernels in the same order as the per-op sequence of
+    train/pgrm_train.py::forward: the output and every tensor saved for the backward are bitwise equal, with and without dropout,
+    with the mask prior (mode=True, 3 channels) and the text prior through prior_fusion (mode=False, 2 channels)."""
+    import ctypes as C
+    from dpmn_amd.model.pgrm import PGRM
+    from dpmn_amd.train import pgrm_train
+    from dpmn_amd import _abi
+    B, it = 4, 2
+    pd, pa, pp = rates
+    args = _pgrm_args()
+    args.update(drop_rate=[pd] * 6, attn_drop_rate=[pa] * 6, drop_path_rate=[pp] * 6)
+    m = PGRM(iter=it, mode=mode, hidden_size=3, **args)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 96)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    x_q = (u("xq", (B, 1, 32, 128), 0, 1) > 0.5).float().repeat(1, 3 if mode else 2, 1, 1).to(dev)
+    x_kv = u("xkv", (B, 3, 32, 128), 0, 1).to(dev)
+    res = [u("r%d" % i, (B, 3, 32, 128), 0, 1).to(dev) for i in range(it)]
+    assert _abi.lib.dpmn_pgrm_forward_train_supported(C.byref(m._weights()), B) == 1
+    torch.manual_seed(77)
+    drop = pgrm_train.drop_config(m)
+    assert (drop is None) == (max(rates) == 0)
+    outs = {}
+    for native in (True, False):
+        monkeypatch.setattr(pgrm_train, "NATIVE_FWD", native)
+        out, sv = pgrm_train.forward(m, x_q, x_kv, res, drop)
+        assert ("_slab" in sv) == native
+        outs[native] = (out, sv)
+    (o1, s1), (o0, s0) = outs[True], outs[False]
+    assert torch.equal(o1, o0)
+    for key in ("tq", "tkv_out", "c0", "c1"):
+        assert torch.equal(s1[key].reshape(-1), s0[key].reshape(-1)), key
+    for bi in range(2):
+        for key, t0 in s0["blocks"][bi].items():
+            t1 = s1["blocks"][bi][key]
+            if torch.is_tensor(t0):
+                assert torch.equal(t1.reshape(-1), t0.reshape(-1)[:t1.numel()]), "block %d %s" % (bi, key)
+            elif key == "tables":
+                assert all(a is b for a, b in zip(t0, t1))
+            else:
+                assert t1 == t0, "block %d %s" % (bi, key)
+    # empty saved-tensor slots fail loudly before anything is launched
+    with pytest.raises(_abi.DpmnError):
+        w = m._weights()
+        bad = _abi.PgrmSaved()
+        _abi.check(_abi.lib.dpmn_pgrm_forward_train_f32(C.byref(w), _abi.dptr(x_q), x_q.shape[1], _abi.dptr(x_kv), _abi.ptr_array(res), len(res),
+                                                        _abi.dptr(x_kv), _abi.dptr(x_kv), None, C.byref(bad), None, _abi.dptr(o1), B, _abi.stream()))
+
+
 @pytest.mark.parametrize("cnum", [8, 16])
 def test_cmm_train_forward_backward_vs_oracle_autograd(dev, cnum):
     from dpmn_amd.model.cmm import ComplementationModulationModule
