@@ -2073,6 +2073,15 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
                          : (sk_mode >= 2 ? launch_conv_sk<128, 128, 2, 2>(a, ws, wsb, d->arrive_cnt, d->arrive_cnt_len, st) : -1);
     if (r >= 0) return r;
     if (a.groups == 2 && mg % 128 != 0) return split_groups();
+    {
+      // 64-pixel row tiles WITHOUT a K split where the 128 x 128 tiling would split K only to fill the CUs (no partial-sum slabs, no
+      // reduce launch): DPMN_CONV_ALT64 = minimum number of 64 x 128 tiles (0 = off)
+      static const int alt64 = getenv("DPMN_CONV_ALT64") ? atoi(getenv("DPMN_CONV_ALT64")) : 0;
+      const int nph = a.nphase > 1 ? a.nphase : 1;
+      const int t128 = cdiv(M, 128) * cdiv(a.Cout, 128) * nph, t64 = cdiv(M, 64) * cdiv(a.Cout, 128) * nph;
+      if (alt64 > 0 && ws && t128 < 384 && a.Kp / 32 >= 16 && t64 >= alt64 && (a.groups != 2 || mg % 64 == 0))
+        return launch_conv<64, 128, 1, 4>(a, nullptr, 0, st);
+    }
     return launch_conv<128, 128, 2, 2>(a, ws, wsb, st, d->arrive_cnt, d->arrive_cnt_len);
   }
   return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
