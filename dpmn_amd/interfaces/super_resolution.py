@@ -411,6 +411,8 @@ class TextSR(base.TextBase):
                     t_.record_stream(cur)
         loss = (part[0] + part[1]) + (dl[0] + dl[1]) + lc
         loss = loss / (b1 + b2 + 1)
+        if hasattr(trainer, "arm_early_step"):
+            trainer.arm_early_step()      # trainer.step() follows: a model's clip + Adam may run as soon as its backward has finished
         loss.backward()
         if forked:
             # the PGRMs' backward kernels ran on the side streams and wrote the gradient arena directly (no AccumulateGrad node the

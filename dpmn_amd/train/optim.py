@@ -28,12 +28,16 @@ zero-fills or adds a per-parameter gradient tensor.  A module invoked several ti
 call; the bucket is ready when as many backward calls have finished as forward calls were made.  Every other module
 keeps ordinary post-accumulate-grad hooks.
 """
+import os
 import torch
 import torch.distributed as dist
 
 from .._abi import lib, check, dptr, stream
 
 ALIGN = 64          # floats: every parameter / gradient view starts on a 256-byte boundary (float4 + atomics friendly)
+
+
+EARLY_OPT = os.environ.get("DPMN_EARLY_OPT", "1") != "0"      # 0: every optimizer launch at the end of the step (A/B switch)
 
 
 def _padded(n, a=ALIGN):
@@ -138,7 +142,7 @@ class FlatBucket:
         self.ready = True
         # the backward of the two refinement branches runs on two HIP streams (interfaces/super_resolution.py): the group's
         # collective is enqueued behind the stream of its LAST reporter only, so every member leaves an event for it to wait on
-        if self.group is not None and self.group.multi and self.flat_g.is_cuda:
+        if self.group is not None and (self.group.multi or self.group.early_cb is not None) and self.flat_g.is_cuda:
             self.ready_event = torch.cuda.Event()
             self.ready_event.record()
         if self.group is not None:
@@ -203,6 +207,8 @@ class CommGroup:
         self.normsq = torch.zeros(len(buckets), device=dev)
         self.part = torch.empty(1024, device=dev)
         self.launched = False
+        self.early_cb = None         # Trainer: called when the last member reports (single-process early optimizer step)
+        self.stepped = False
         self.grad_work = None
         self.param_work = None
         self._post_scale = None
@@ -214,6 +220,8 @@ class CommGroup:
     def member_ready(self):
         if not self.launched and all(b.ready for b in self.buckets):
             self.launch()
+            if self.early_cb is not None:
+                self.early_cb(self)
 
     def launch(self):
         self.launched = True
@@ -350,6 +358,14 @@ class Trainer:
             off += gs
         if multi:
             broadcast_replicas(models, self.flat_p, group)
+        # single process: clip + Adam of a group run on a stream of their own as soon as its last member's backward has reported,
+        # under the backward of the models that are still to come (the clip is per model, super_resolution.py:272-278: nothing of
+        # another model is needed); Trainer.step() then only handles what is left and joins the stream
+        self.early = EARLY_OPT and not multi and dev.type == "cuda"
+        self.opt_stream = None
+        if self.early:
+            for g in self.groups:
+                g.early_cb = self._early_step
 
     @staticmethod
     def _backward_order(models):
@@ -404,12 +420,38 @@ class Trainer:
             g.v.copy_(v)
         self.invalidate_packs()
 
+    def arm_early_step(self):
+        """The caller promises that Trainer.step() follows the backward pass it is about to start (TextSR.train_step): groups may
+        then be stepped as soon as their gradients are complete.  Without this call a backward never touches the parameters."""
+        self._armed = self.early
+
+    def _early_step(self, g):
+        if not getattr(self, "_armed", False) or self.t_dev is not None or torch.cuda.is_current_stream_capturing():
+            return          # hipGraph capture / device-side step counter: the step stays in Trainer.step()
+        if self.opt_stream is None:
+            self.opt_stream = torch.cuda.Stream(self.flat_p.device)
+        for b in g.buckets:
+            ev = getattr(b, "ready_event", None)
+            if ev is not None:
+                self.opt_stream.wait_event(ev)
+                b.ready_event = None
+        with torch.cuda.stream(self.opt_stream):
+            g.step(self.t + 1, self.lr, self.beta1, max_norm=self.max_norm, step_dev=None)
+        g.stepped = True
+
     def step(self):
         from ..model import packing
         self.t += 1
         if self.t_dev is not None:
             self.t_dev.add_(1.0)
+        early = False
         for g in self.groups:
+            if g.stepped:
+                g.stepped, early = False, True
+                continue
             g.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
+        self._armed = False
+        if early:
+            torch.cuda.current_stream(self.flat_p.device).wait_stream(self.opt_stream)
         packing.ACTIVE = None       # the packs are stale from here on
         self.invalidate_packs()
