@@ -37,7 +37,10 @@ from .._abi import lib, check, dptr, stream
 ALIGN = 64          # floats: every parameter / gradient view starts on a 256-byte boundary (float4 + atomics friendly)
 
 
-EARLY_OPT = os.environ.get("DPMN_EARLY_OPT", "1") != "0"      # 0: every optimizer launch at the end of the step (A/B switch)
+# 1: clip + Adam of a model group on a side stream as soon as its backward has reported.  Measured (B = 48, two runs each): 28.30 / 28.26 ms
+# against 28.24 / 28.08 ms with every optimizer launch at the end of the step -- the optimizer leaves the tail (0.44 -> 0.01 ms) but
+# its HBM-bound kernels slow the concurrent backward by as much: the GPU is full.  Kept as a switch, default off.
+EARLY_OPT = os.environ.get("DPMN_EARLY_OPT", "0") != "0"
 
 
 def _padded(n, a=ALIGN):
