@@ -100,6 +100,7 @@ class DistillModule(nn.Module):
         if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or x_deep.requires_grad or x_shallow.requires_grad):
             if getattr(self, "_dpmn_bucket", None) is not None:
                 self._dpmn_bucket.note_use()
-            return _DistillFn.apply(self, x_deep, x_shallow, *list(self.parameters()))
+            from ..train.pgrm_train import fn_inputs
+            return _DistillFn.apply(self, x_deep, x_shallow, *fn_inputs(self))
         loss, feat, _ = _forward(self, x_deep, x_shallow, self.training)
         return loss[0], feat

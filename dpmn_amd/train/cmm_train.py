@@ -15,7 +15,7 @@ import torch
 from .. import ops
 from .._abi import dptr, lib, check, stream
 from ..model import packing
-from .pgrm_train import colsum, conv_wgrad_into, grad_targets, finish_grads, params_of
+from .pgrm_train import colsum, conv_wgrad_into, grad_targets, finish_grads, params_of, fn_inputs
 
 ACT = ops.ACT
 
@@ -346,4 +346,4 @@ class CMMFunction(torch.autograd.Function):
 def apply(m, x1, x2):
     if getattr(m, "_dpmn_bucket", None) is not None:
         m._dpmn_bucket.note_use()
-    return CMMFunction.apply(m, x1, x2, *params_of(m))
+    return CMMFunction.apply(m, x1, x2, *fn_inputs(m))

@@ -90,6 +90,7 @@ class FlatBucket:
             for p in self.params:
                 p._dpmn_sink = p.grad
             module._dpmn_bucket = self
+            self.anchor = torch.zeros(1, device=dev, requires_grad=True)      # train/pgrm_train.py fn_inputs
         # caches keyed by the OLD gradient sinks / parameter list (train/pgrm_train.py UnpackQueue, params_of): a second Trainer or
         # bucket for the same module must not inherit them -- stale sink keys would keep the one-launch unpack from ever matching
         # again and hold the old slot workspaces alive

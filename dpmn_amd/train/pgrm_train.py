@@ -179,6 +179,15 @@ def params_of(m):
     return ps
 
 
+def fn_inputs(m):
+    """What a module's autograd Function takes besides its activations: the parameters -- or, in direct mode (the backward kernels
+    write the flat bucket's gradient views themselves and return None for every parameter), ONE anchor tensor that keeps the node in
+    the graph: ~100 parameters per module as Function inputs cost one AccumulateGrad node each per step (569 of them, ~3 ms of the
+    autograd thread's time) for gradients that are never handed to them."""
+    b = getattr(m, "_dpmn_bucket", None)
+    return [b.anchor] if b is not None else params_of(m)
+
+
 def grad_targets(m):
     """{param: tensor the backward kernels accumulate into}, direct?  Direct mode (train/optim.py FlatBucket(direct=True)):
     the targets are the flat bucket's zeroed gradient views; otherwise freshly zeroed tensors handed back to autograd."""
@@ -192,7 +201,7 @@ def finish_grads(m, gr, direct):
     """tuple of per-parameter gradients for autograd (None in direct mode, after signalling the bucket)."""
     if direct:
         m._dpmn_bucket.grads_ready()
-        return (None,) * len(params_of(m))
+        return (None,)          # the anchor (fn_inputs)
     return tuple(gr[p] for p in params_of(m))
 
 
@@ -759,5 +768,4 @@ class PGRMFunction(torch.autograd.Function):
 def apply(m, x_q, x_kv, residual_list):
     if getattr(m, "_dpmn_bucket", None) is not None and torch.is_grad_enabled():
         m._dpmn_bucket.note_use()       # a shared module (--sr_share) reports ready after as many backward calls
-    params = params_of(m)
-    return PGRMFunction.apply(m, x_q, x_kv, len(residual_list), *residual_list, *params)
+    return PGRMFunction.apply(m, x_q, x_kv, len(residual_list), *residual_list, *fn_inputs(m))
