@@ -30,6 +30,15 @@ def _decode_block(cin, cout):
 NATIVE_FORWARD = os.environ.get("DPMN_CMM_NATIVE", "1") != "0"      # eval forward through dpmn_cmm_forward_f32 (one native call)
 
 
+
+def _plist(m):
+    """list(m.parameters()), walked once per module (Parameter objects are never replaced on this path; same cache as
+    train/pgrm_train.py params_of)."""
+    ps = m.__dict__.get("_dpmn_plist")
+    if ps is None:
+        ps = m.__dict__["_dpmn_plist"] = list(m.parameters())
+    return ps
+
 class _Holder(nn.Module):
     def __init__(self, seq, name):
         super().__init__()
@@ -126,7 +135,7 @@ class ComplementationModulationModule(nn.Module):
                 return cmm_train.apply(self, x1, x2)
             with torch.no_grad():
                 return cmm_train.build(self, x1, x2)[0]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in _plist(self)):
             raise NotImplementedError("dpmn_amd CMM: gradients in eval mode (running-stat BatchNorm) are not built; use .train()")
         P = self._packed()
         c = self.cnum

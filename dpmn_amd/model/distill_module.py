@@ -53,6 +53,15 @@ def _forward(m, x_deep, x_shallow, training):
     return loss, feat, (xd, xs, r, state)
 
 
+
+def _plist(m):
+    """list(m.parameters()), walked once per module (Parameter objects are never replaced on this path; same cache as
+    train/pgrm_train.py params_of)."""
+    ps = m.__dict__.get("_dpmn_plist")
+    if ps is None:
+        ps = m.__dict__["_dpmn_plist"] = list(m.parameters())
+    return ps
+
 class _DistillFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, m, x_deep, x_shallow, *params):
@@ -97,7 +106,7 @@ class DistillModule(nn.Module):
         self.bn_2 = nn.BatchNorm2d(3)
 
     def forward(self, x_deep, x_shallow):
-        if torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or x_deep.requires_grad or x_shallow.requires_grad):
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in _plist(self)) or x_deep.requires_grad or x_shallow.requires_grad):
             if getattr(self, "_dpmn_bucket", None) is not None:
                 self._dpmn_bucket.note_use()
             from ..train.pgrm_train import fn_inputs

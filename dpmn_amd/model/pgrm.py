@@ -14,6 +14,15 @@ import torch.nn as nn
 from .. import _abi, ops
 
 
+
+def _plist(m):
+    """list(m.parameters()), walked once per module (Parameter objects are never replaced on this path; same cache as
+    train/pgrm_train.py params_of)."""
+    ps = m.__dict__.get("_dpmn_plist")
+    if ps is None:
+        ps = m.__dict__["_dpmn_plist"] = list(m.parameters())
+    return ps
+
 class _Affine(nn.Module):
     """weight/bias holder standing in for nn.Linear / nn.Conv2d / nn.LayerNorm key names."""
 
@@ -260,7 +269,7 @@ class PGRM(nn.Module):
 
     def forward(self, x_q, x_kv, residual_list):
         dropping = self.training and (self.drop_probs[0] > 0 or self.drop_probs[1] > 0 or max(self.drop_probs[2]) > 0)
-        if dropping or (torch.is_grad_enabled() and (any(p.requires_grad for p in self.parameters()) or x_kv.requires_grad)):
+        if dropping or (torch.is_grad_enabled() and (any(p.requires_grad for p in _plist(self)) or x_kv.requires_grad)):
             from ..train import pgrm_train           # explicit HIP forward + backward behind torch.autograd
             return pgrm_train.apply(self, x_q, x_kv, list(residual_list))
         B = x_kv.shape[0]
