@@ -312,13 +312,14 @@ def int_array(vals):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None) or torch.cuda.current_device
 
 
 def stream():
     """hipStream_t of torch's current stream on the current device.  (torch.cuda.current_stream() builds a Stream object: ~7 us per
     call, times ~1400 launches per training step -- a third of the step's host time; the raw query is ~0.3 us.)"""
     if _raw_stream is not None:
-        return _raw_stream(torch.cuda.current_device())
+        return _raw_stream(_get_device())       # (torch.cuda.current_device() = _lazy_init() + this call)
     return torch.cuda.current_stream().cuda_stream
 
 

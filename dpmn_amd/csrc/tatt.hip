@@ -14,81 +14,116 @@ namespace {
 // ---------------------------------------------------------------------------------- BiGRU recurrence
 // gi: (pixels, 2*3*HID) = [dir0: r z n | dir1: r z n] precomputed input projection (bias folded)
 // seq s -> base pixel = (s / inner) * outer_stride + (s % inner) * inner_stride ; step t adds t*step_stride (pixels)
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int HID>
-__global__ __launch_bounds__(256) void k_bigru(const float* __restrict__ gi, const float* __restrict__ w_hh /*(2,3H,H)*/,
-                                                const float* __restrict__ b_hh /*(2,3H)*/, const float* __restrict__ res,
-                                                float* __restrict__ out, int nseq, int T, int inner, long outer_stride,
+__global__ __launch_bounds__(256) void k_bigru(const float* gi, const float* w_hh /*(2,3H,H)*/,
+                                                const float* b_hh /*(2,3H)*/, const float* res,
+                                                float* out, int nseq, int T, int inner, long outer_stride,
                                                 long inner_stride, long step_stride) {
   static_assert(HID == 32, "lane mapping assumes 32 hidden units per direction");
   __shared__ __attribute__((aligned(16))) float hs[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int dir = lane >> 5, j = lane & 31;
   const long s = (long)blockIdx.x * 4 + wave;
-  const bool active = s < nseq;
-  float wr[HID], wz[HID], wn[HID];
+  if (s >= nseq) return;      // whole wave (no block-level barrier below: the hidden state goes through a wave-private LDS row)
+  // W_hh rows of this lane's hidden unit as PACKED pairs: (r, z) share the h_k operand (v_pk_fma_f32 with a broadcast), the n row is
+  // paired over k against (h_k, h_k+1): 48 packed fmas per step instead of 96 scalar ones on the step's critical path
+  v2f wrz[HID], wnn[HID / 2];
   const float* wb = w_hh + (size_t)dir * 3 * HID * HID;
 #pragma unroll
-  for (int k = 0; k < HID; ++k) {
-    wr[k] = wb[(size_t)j * HID + k];
-    wz[k] = wb[(size_t)(HID + j) * HID + k];
-    wn[k] = wb[(size_t)(2 * HID + j) * HID + k];
-  }
+  for (int k = 0; k < HID; ++k) wrz[k] = v2f{wb[(size_t)j * HID + k], wb[(size_t)(HID + j) * HID + k]};
+#pragma unroll
+  for (int k = 0; k < HID / 2; ++k) wnn[k] = v2f{wb[(size_t)(2 * HID + j) * HID + 2 * k], wb[(size_t)(2 * HID + j) * HID + 2 * k + 1]};
   const float br = b_hh[dir * 3 * HID + j], bz = b_hh[dir * 3 * HID + HID + j], bn = b_hh[dir * 3 * HID + 2 * HID + j];
-  const long base = active ? (s / inner) * outer_stride + (s % inner) * inner_stride : 0;
+  // the weights are IN their registers before the first gate prefetch is issued (hipcc otherwise sinks these loads to their first
+  // use inside the loop, behind the prefetches, and the static s_waitcnt it then needs there drains the ring on every iteration;
+  // w_hh / b_hh are not __restrict__ so that the loads may not cross the clobber)
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+  asm volatile("" ::: "memory");
+  const long base = (s / inner) * outer_stride + (s % inner) * inner_stride;
   float h = 0.f;
   // the recurrence is a pure latency chain (one wave per sequence, at most one wave per SIMD at these sizes): the hidden
-  // state goes through a wave-private LDS row (in-order within a wave: no block barrier), and the next step's gate
-  // pre-activations are fetched while the current step computes
-  // ping-pong gate registers (A / B), loop unrolled by two: a "cur = next" copy at the end of a step would make the
-  // compiler wait for the prefetch it just issued
-  float gA[4] = {0.f, 0.f, 0.f, 0.f}, gB[4] = {0.f, 0.f, 0.f, 0.f};     // r, z, n pre-activations + residual
-  // branch-free (a conditional load makes the compiler drain every outstanding load at the join): steps past the end and
-  // idle waves re-read a valid element, the residual pointer falls back to gi when there is no residual
+  // state goes through a wave-private LDS row (in-order within a wave: no block barrier), and the gate pre-activations of the
+  // next THREE steps are in flight while a step computes (a ring of four register sets, the loop unrolled by four: a step takes
+  // ~0.3 us, an L2 / HBM load ~1 us -- one step of look-ahead left every step waiting for its gates; a "cur = next" copy at the end
+  // of a step would make the compiler wait for the prefetch it just issued)
+  float g0[4], g1[4], g2[4], g3[4];     // r, z, n pre-activations + residual
+  // branch-free (a conditional load makes the compiler drain every outstanding load at the join): steps past the end
+  // re-read a valid element, the residual pointer falls back to gi when there is no residual
   const float* rp = res ? res : gi;
   const float rmul = res ? 1.f : 0.f;
-  auto fetch = [&](float (&g4)[4], int t) {
-    const int tc = t < T ? t : T - 1;
-    const long pn = base + (long)(dir ? T - 1 - tc : tc) * step_stride;
-    const float* g = gi + pn * (6 * HID) + dir * 3 * HID + j;
-    g4[0] = g[0]; g4[1] = g[HID]; g4[2] = g[2 * HID];
-    g4[3] = rp[pn * (2 * HID) + dir * HID + j] * rmul;   // the residual too: a load feeding this step's store would stall it
+  // running pointers (one 64-bit add per step instead of the index arithmetic: fewer temporaries for the register allocator to
+  // park in a gate register whose load it then has to wait for)
+  const long p_first = base + (dir ? (long)(T - 1) * step_stride : 0);
+  const long dpix = dir ? -step_stride : step_stride;
+  const float* gp = gi + p_first * (6 * HID) + dir * 3 * HID + j;
+  const float* rq = rp + p_first * (2 * HID) + dir * HID + j;
+  float* op = out + p_first * (2 * HID) + dir * HID + j;
+  const long gd = dpix * (6 * HID), rd = dpix * (2 * HID);
+  int tf = 0;      // index of the step the next fetch is for (wave-uniform)
+  auto fetch = [&](float (&g4)[4]) {
+    g4[0] = gp[0]; g4[1] = gp[HID]; g4[2] = gp[2 * HID];
+    asm volatile("" ::: "memory");                // (pins the four loads HERE: hipcc sinks a load to its first use, three steps later)
+    g4[3] = rq[0];   // the residual too: a load feeding this step's store would stall it (x rmul at the use: an arithmetic op on
+                     // the loaded value HERE makes the compiler wait for the load at the loop's back-edge)
+    asm volatile("" ::: "memory");
+    ++tf;
+    const bool more = tf < T;      // fetches past the last step re-read it
+    gp += more ? gd : 0;
+    rq += more ? rd : 0;
   };
   auto step = [&](const float (&g4)[4], int t) {
     hs[wave][lane] = h;
     __builtin_amdgcn_wave_barrier();
-    float ar0 = br, az0 = bz, an0 = bn, ar1 = 0.f, az1 = 0.f, an1 = 0.f;
+    v2f rz0 = {br, bz}, rz1 = {0.f, 0.f}, n0 = {bn, 0.f}, n1 = {0.f, 0.f};
     const float* hp = &hs[wave][dir * HID];
 #pragma unroll
     for (int k = 0; k < HID; k += 8) {
       const float4 h0 = *reinterpret_cast<const float4*>(hp + k);
       const float4 h1 = *reinterpret_cast<const float4*>(hp + k + 4);
-      // explicit fmas (the file is built with -ffp-contract=off): 96 instead of 192 vector instructions on the step's critical path
-      ar0 = fmaf(wr[k + 3], h0.w, fmaf(wr[k + 2], h0.z, fmaf(wr[k + 1], h0.y, fmaf(wr[k], h0.x, ar0))));
-      az0 = fmaf(wz[k + 3], h0.w, fmaf(wz[k + 2], h0.z, fmaf(wz[k + 1], h0.y, fmaf(wz[k], h0.x, az0))));
-      an0 = fmaf(wn[k + 3], h0.w, fmaf(wn[k + 2], h0.z, fmaf(wn[k + 1], h0.y, fmaf(wn[k], h0.x, an0))));
-      ar1 = fmaf(wr[k + 7], h1.w, fmaf(wr[k + 6], h1.z, fmaf(wr[k + 5], h1.y, fmaf(wr[k + 4], h1.x, ar1))));
-      az1 = fmaf(wz[k + 7], h1.w, fmaf(wz[k + 6], h1.z, fmaf(wz[k + 5], h1.y, fmaf(wz[k + 4], h1.x, az1))));
-      an1 = fmaf(wn[k + 7], h1.w, fmaf(wn[k + 6], h1.z, fmaf(wn[k + 5], h1.y, fmaf(wn[k + 4], h1.x, an1))));
+      rz0 = __builtin_elementwise_fma(wrz[k], v2f{h0.x, h0.x}, rz0);
+      rz1 = __builtin_elementwise_fma(wrz[k + 1], v2f{h0.y, h0.y}, rz1);
+      n0 = __builtin_elementwise_fma(wnn[k / 2], v2f{h0.x, h0.y}, n0);
+      rz0 = __builtin_elementwise_fma(wrz[k + 2], v2f{h0.z, h0.z}, rz0);
+      rz1 = __builtin_elementwise_fma(wrz[k + 3], v2f{h0.w, h0.w}, rz1);
+      n1 = __builtin_elementwise_fma(wnn[k / 2 + 1], v2f{h0.z, h0.w}, n1);
+      rz0 = __builtin_elementwise_fma(wrz[k + 4], v2f{h1.x, h1.x}, rz0);
+      rz1 = __builtin_elementwise_fma(wrz[k + 5], v2f{h1.y, h1.y}, rz1);
+      n0 = __builtin_elementwise_fma(wnn[k / 2 + 2], v2f{h1.x, h1.y}, n0);
+      rz0 = __builtin_elementwise_fma(wrz[k + 6], v2f{h1.z, h1.z}, rz0);
+      rz1 = __builtin_elementwise_fma(wrz[k + 7], v2f{h1.w, h1.w}, rz1);
+      n1 = __builtin_elementwise_fma(wnn[k / 2 + 3], v2f{h1.z, h1.w}, n1);
     }
     __builtin_amdgcn_wave_barrier();
     // v_exp / v_rcp gates: libm expf / tanhf and the IEEE divisions were ~100 dependent instructions per step of a pure latency chain
-    const float r = sigmoid_fast(g4[0] + ar0 + ar1);
-    const float z = sigmoid_fast(g4[1] + az0 + az1);
-    const float n = tanh_fast(g4[2] + r * (an0 + an1));
+    const float r = sigmoid_fast(g4[0] + (rz0.x + rz1.x));
+    const float z = sigmoid_fast(g4[1] + (rz0.y + rz1.y));
+    const float n = tanh_fast(g4[2] + r * ((n0.x + n1.x) + (n0.y + n1.y)));
     h = (1.f - z) * n + z * h;
-    if (active) {
-      const long pix = base + (long)(dir ? T - 1 - t : t) * step_stride;
-      out[pix * (2 * HID) + dir * HID + j] = h + g4[3];
-    }
+    op[0] = fmaf(g4[3], rmul, h);      // (one fma that needs h: as `h + g4[3] * rmul` the multiply is hoisted three steps up, and the wait for its load with it)
+    op += rd;
   };
-  fetch(gA, 0);
-  for (int t = 0; t < T; t += 2) {
-    fetch(gB, t + 1);
-    step(gA, t);
-    if (t + 1 >= T) break;
-    fetch(gA, t + 2);
-    step(gB, t + 1);
+  fetch(g0);
+  fetch(g1);
+  fetch(g2);
+  // whole groups of four steps without an exit inside the body: a `break` between the steps routes through the loop latch in the
+  // structurised CFG, and the static path "fetch(g0) -> break -> header -> step(g0)" made hipcc wait for all but 5 loads there
+  int t = 0;
+  for (; t + 3 < T; t += 4) {
+    fetch(g3);
+    step(g0, t);
+    fetch(g0);
+    step(g1, t + 1);
+    fetch(g1);
+    step(g2, t + 2);
+    fetch(g2);
+    step(g3, t + 3);
   }
+  if (t < T) step(g0, t);              // T % 4 leftover steps: their gates are already in the ring
+  if (t + 1 < T) step(g1, t + 1);
+  if (t + 2 < T) step(g2, t + 2);
 }
 
 // ---------------------------------------------------------------------------------- tiny linear

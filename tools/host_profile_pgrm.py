@@ -35,3 +35,24 @@ for native in (True, False):
     pr.disable()
     torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats("tottime").print_stats(14)
+
+# ---- the backward's issue cost, called directly in this thread (autograd runs it in its device thread, invisible to cProfile)
+from dpmn_amd.train.optim import Trainer
+tr = Trainer([m], lr=1e-3, beta1=0.5, max_norm=0.25)
+pgrm_train.NATIVE_FWD = True
+dout = torch.rand(B, 3, 32, 128, device=dev)
+for label in ("warm", "timed"):
+    tr.zero_grad()
+    svs = [pgrm_train.forward(m, x_q, x_kv.detach(), res, pgrm_train.drop_config(m))[1] for _ in range(N)]
+    torch.cuda.synchronize()
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable()
+    for sv in svs:
+        pgrm_train.backward_deferred(m, sv, dout, True)
+    pr.disable()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    del svs
+print("backward: host %.1f us per call (under cProfile)" % ((t1 - t0) / N * 1e6))
+pstats.Stats(pr).sort_stats("tottime").print_stats(25)
