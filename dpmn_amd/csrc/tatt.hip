@@ -7,6 +7,7 @@
 //     and the gate step of the query-embedding GRU (batch_first quirk Q5).
 // Token tensors here are (N, L, E) row-major (N = image, L = 26 text slots or 1024 pixels, E = 64):
 // the reference's (L, N, E) differs only by a transpose no kernel needs.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -140,6 +141,52 @@ __global__ void k_small_linear(const float* __restrict__ x, const float* __restr
   float a = b ? b[n] : 0.f;
   for (int k = 0; k < K; ++k) a += (xr[k] + (ar ? ar[k] : 0.f)) * wr[k];
   y[idx] = apply_act(a, act, slope);
+}
+
+// The same product staged through LDS: a block owns 32 rows x 64 columns, x (+ add) and w arrive with coalesced loads in 64-deep
+// K chunks, a thread accumulates 8 rows of one column.  Every output is the same chain of multiply-then-add over k = 0 .. K-1 that
+// k_small_linear runs (bitwise-equal results); that kernel's per-thread walk over a weight ROW made every wave load 64 different
+// cache lines per k: 8 - 105 us per call on the 1248 x 64 x 64 products of the TATT interpreter (5 calls per batch).
+__global__ __launch_bounds__(256) void k_small_linear_tiled(const float* __restrict__ x, const float* __restrict__ add, int add_rows,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             float* __restrict__ y, int M, int N, int K, int act, float slope) {
+  __shared__ float xs[32][64];
+  __shared__ float ws[64][65];
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 64;
+  const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = (b && n0 + c < N) ? b[n0 + c] : 0.f;
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int kc = K - k0 < 64 ? K - k0 : 64;
+    for (int e = threadIdx.x; e < 32 * 64; e += 256) {
+      const int row = e >> 6, k = e & 63, m = m0 + row;
+      float v = 0.f;
+      if (m < M && k < kc) {
+        v = x[(size_t)m * K + k0 + k];
+        if (add) v = v + add[(size_t)(m % add_rows) * K + k0 + k];
+      }
+      xs[row][k] = v;
+    }
+    for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+      const int col = e >> 6, k = e & 63;
+      ws[col][k] = (n0 + col < N && k < kc) ? w[(size_t)(n0 + col) * K + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    for (int k = 0; k < kc; ++k) {
+      const float wv = ws[c][k];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += xs[r + 4 * i][k] * wv;
+    }
+    __syncthreads();
+  }
+  if (n0 + c < N) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0 + r + 4 * i;
+      if (m < M) y[(size_t)m * N + n0 + c] = apply_act(acc[i], act, slope);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------- encoder layer (L <= 32 tokens)
@@ -399,9 +446,13 @@ int dpmn_bigru_f32(const float* gi, const float* w_hh, const float* b_hh, const 
 int dpmn_small_linear_f32(const float* x, const float* add, int add_rows, const float* w, const float* b, float* y, int M,
                           int N, int K, int act, float slope, dpmn_stream_t stream) {
   DPMN_REQUIRE(x && w && y && M > 0 && N > 0 && K > 0, "small_linear: bad arguments");
-  const long total = (long)M * N;
-  hipLaunchKernelGGL(k_small_linear, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), x, add,
-                     add_rows > 0 ? add_rows : 1, w, b, y, M, N, K, act, slope);
+  static const int tiled = getenv("DPMN_SMALL_LINEAR_TILED") ? atoi(getenv("DPMN_SMALL_LINEAR_TILED")) : 1;
+  if (tiled)
+    hipLaunchKernelGGL(k_small_linear_tiled, dim3((unsigned)((M + 31) / 32), (unsigned)((N + 63) / 64)), dim3(256), 0, as_stream(stream), x,
+                       add, add_rows > 0 ? add_rows : 1, w, b, y, M, N, K, act, slope);
+  else
+    hipLaunchKernelGGL(k_small_linear, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, as_stream(stream), x, add,
+                       add_rows > 0 ? add_rows : 1, w, b, y, M, N, K, act, slope);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -223,8 +223,10 @@ def test_cfg4_pgrm_backward_bench_batch_rows_equal_small_batch(dev):
 
 
 # 3x the errors recorded on the MI355X (profiles/r05a_parity_errors.json: loss 8.8e-8, text-prior PGRMs <= 6.8e-5, mask-prior PGRMs
-# <= 1.7e-4, CMM 2.0e-4, DistillModules <= 1.2e-4), floor 5e-7 on the loss
-CFG4_STEP_TOL = dict(loss=5e-7, pgrm=2.1e-4, pgrm_b2=5.1e-4, cmm=6e-4, distill=3.6e-4)
+# <= 1.7e-4, CMM 2.0e-4, DistillModules <= 1.2e-4).  The loss is ONE fp32 number (4.45e4 here: 1 ulp = 8.8e-8 relative): 8.8e-8 with the
+# round-4 BiGRU, 7.0e-7 = 8 ulp after the frozen PSN's recurrence changed its summation order (packed fmas, csrc/tatt.hip) -- the loss
+# bar is 2e-6 (~ 20 ulp of a reduction over 3.1 M pixels x 13 images), not 3x one particular rounding
+CFG4_STEP_TOL = dict(loss=2e-6, pgrm=2.1e-4, pgrm_b2=5.1e-4, cmm=6e-4, distill=3.6e-4)
 
 
 @pytest.mark.parametrize("B", [2])

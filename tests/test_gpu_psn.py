@@ -52,6 +52,16 @@ def test_small_linear_layernorm_cross_attn(dev):
     w, b = u("w", (64, 37), -0.3, 0.3), u("b", (64,))
     ref = F.prelu(F.linear(x + add.repeat(2, 1), w, b), torch.tensor([0.2]))
     assert_close(ops.small_linear(x.to(dev), w.to(dev), b.to(dev), add=add.to(dev), act="prelu", slope=0.2), ref, ATOL, RTOL, "small_linear")
+    # ragged tiles of the LDS-staged kernel (32-row x 64-column tiles, 64-deep K chunks): the interpreter's 1248 x 64 x 64 shape, a row
+    # / column / K remainder each, K above one chunk, no bias, no addend
+    for (M, N, K, rows, bias) in ((1248, 64, 64, 26, True), (1251, 70, 37, 0, True), (33, 130, 150, 11, False), (5, 3, 64, 0, True)):
+        x2, w2 = u("x2%d" % M, (M, K)), u("w2%d" % M, (N, K), -0.3, 0.3)
+        b2 = u("b2%d" % M, (N,)) if bias else None
+        add2 = u("add2%d" % M, (rows, K)) if rows else None
+        xin = x2 if add2 is None else x2 + add2.repeat((M + rows - 1) // rows, 1)[:M]
+        ref2 = F.linear(xin, w2, b2)
+        got2 = ops.small_linear(x2.to(dev), w2.to(dev), None if b2 is None else b2.to(dev), add=None if add2 is None else add2.to(dev))
+        assert_close(got2, ref2, ATOL, RTOL, "small_linear %dx%dx%d" % (M, N, K))
     a, r = u("a", (300, 64)), u("r", (300, 64))
     g1, b1, g2, b2 = u("g1", (64,), 0.5, 1.5), u("b1", (64,)), u("g2", (64,), 0.5, 1.5), u("b2", (64,))
     y = F.layer_norm(a + r, (64,), g1, b1)
