@@ -129,10 +129,11 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
 // Training forward of one PGRM as ONE call: the launches of train/pgrm_train.py::forward (patch embedding x 2, pos_drop x 2, per
 // block fused LayerNorm + q / kv + window attention (+ attn_drop), SK projection, SK gate, select + proj_head + DropPath + LayerNorm2
 // + fc1, depthwise conv with both GELUs and the Mlp dropout, pointwise conv, fc2 + Dropout + DropPath + residual; the two tail
-// convs and the pixel-shuffle / weight_list epilogue) issued from native code.  The host thread needed ~0.5 ms to issue these ~22
-// launches through ctypes / torch allocations against 0.8 ms of GPU time, which made the forward phase of the training step
-// host-bound (tools/phase_timeline.py); here the issue takes ~0.1 ms.  Every tensor the backward reads is written into the caller's
-// dpmn_pgrm_saved slots.
+// convs and the pixel-shuffle / weight_list epilogue) issued from native code.  The host thread needed 0.39 ms per module to issue
+// these ~22 launches through ctypes / torch allocations, 0.29 ms through this call (tools/host_profile_pgrm.py; what is left is the
+// ~5 us per hipLaunchKernel plus the saved-tensor views).  The step time did not move: the forward phase is bound by the GPU (six
+// modules x 0.81 ms back to back; two of them side by side take as long as one after the other), the gain is host head-room.
+// Every tensor the backward reads is written into the caller's dpmn_pgrm_saved slots.
 int dpmn_pgrm_forward_train_supported(const dpmn_pgrm_weights* w, int B) {
   if (!w || B < 1 || w->n_groups < 1 || w->n_groups > 4) return 0;
   const int H = w->img_h / w->patch, Wd = w->img_w / w->patch, L = H * Wd, C = w->dim, Ch = w->mlp_hidden;

@@ -663,8 +663,8 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
 
 /* PGRM.forward in TRAINING mode as one call (pgrm.py:546-565 with pos_drop / attn_drop / Mlp.drop / DropPath active, and every
  * activation the hand-written backward of dpmn_amd/train/pgrm_train.py reads written out).  Replaces the ~22 per-op calls of
- * train/pgrm_train.py::forward: the host issue time of those (~0.5 ms against 0.8 ms of GPU work per module at B=48) made the forward
- * phase of the training step host-bound.  The caller owns every buffer:
+ * train/pgrm_train.py::forward (host issue time 0.39 -> 0.29 ms per module at B = 48; the GPU time is unchanged).  The caller owns
+ * every buffer:
  *   saved.tq, saved.tkv0                       (B L, C)   patch-embedded (+pos_drop) token streams
  *   per block: cat, feats, x1, n2, tkv_out     (B L, C);  ypre, gpre, g, z (B L, Ch);  V (B L, C / groups);  avec (B, groups, C / groups);
  *              partial (B ceil(L / 32), C);  fold: dpmn_ln_qkv_window_attn_workspace_bytes() bytes (folded LayerNorm + q / kv weights,
