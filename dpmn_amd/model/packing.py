@@ -236,12 +236,12 @@ def tpack_convT_s2k4(wt):
     return _gpu_pack_phases(wt, o, i, lambda py, px: (16, o * 16, 8, 2, (1 - py) * 4 + (1 - px)))
 
 
-def tpack_dgrad_conv_s1(w, c0, cs):
+def tpack_dgrad_conv_s1(w, c0, cs, out=None):
     """== pack_convT_s1(w[:, c0:c0+cs])[0]: data gradient of a stride-1 nn.Conv2d (O, I, KH, KW) w.r.t. input channels
     [c0, c0+cs) as a conv of dY with the flipped, transposed kernel."""
     o, i, kh, kw = w.shape
     kk = kh * kw
-    return _gpu_pack(w, cs, o, kh, kw, cs, o, (kk, i * kk, -kw, -1, c0 * kk + kk - 1))
+    return _gpu_pack(w, cs, o, kh, kw, cs, o, (kk, i * kk, -kw, -1, c0 * kk + kk - 1), out=out)
 
 
 def tpack_dgrad_convT(wt, c0, cs, cin_pad=None):
@@ -259,8 +259,8 @@ def tpack_dgrad_conv_s2k4(w, c0, cs):
     return _gpu_pack_phases(w, cs, o, lambda py, px: (16, i * 16, 8, 2, c0 * 16 + (1 - py) * 4 + (1 - px)))
 
 
-def tpack_dgrad_generic(w, c0, cs):
+def tpack_dgrad_generic(w, c0, cs, out=None):
     """== pack_bwd_data_generic(w[:, c0:c0+cs])[0]: (Cin-seg, KH*KW*Cout), taps not flipped (used with dil = -1)."""
     o, i, kh, kw = w.shape
     kk = kh * kw
-    return _gpu_pack(w, cs, o, kh, kw, cs, o, (kk, i * kk, kw, 1, c0 * kk))
+    return _gpu_pack(w, cs, o, kh, kw, cs, o, (kk, i * kk, kw, 1, c0 * kk), out=out)

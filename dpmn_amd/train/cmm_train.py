@@ -104,6 +104,13 @@ class Unit:
     def backward(self, gr, side=None):
         """Consumes self.out.G; accumulates parameter grads into gr; pushes gradients to the inputs' G buffers.
         side: a stream for the weight gradient (the caller joins it before anything reads gr), or None = in stream order."""
+        dr, cout = self.bwd_output(gr)
+        self.bwd_weight(dr, cout, gr, side)
+        self.bwd_inputs(dr, cout)
+
+    def bwd_output(self, gr, dr_out=None):
+        """dL/d(raw conv output) from self.out.G: BatchNorm backward through the batch statistics (+ the bias gradient of a conv
+        without BatchNorm).  dr_out: where to write it (one half of a twin pair's buffer, backward_pair)."""
         o = self.out
         w, b = self.conv.weight, self.conv.bias
         transposed = self.kind in ("convT3", "convT4s2")
@@ -111,7 +118,7 @@ class Unit:
         G = o.G
         pixels = G.numel() // cout
         if self.bn is not None:
-            dr = torch.empty_like(G)
+            dr = torch.empty_like(G) if dr_out is None else dr_out
             ws = torch.empty(2, cout, device=G.device)
             if getattr(o, "gsums_done", False):
                 # the consumer that completed G already reduced (sum G, sum G * xhat) per channel: no pass over G and r here
@@ -134,10 +141,12 @@ class Unit:
         # else: a conv bias in front of a train-mode BatchNorm has an identically zero gradient (the batch mean removes it;
         # sum over pixels of dr is exactly 0 in exact arithmetic) -- autograd in the reference only accumulates round-off
         # there (<= 3e-4 at these sizes), so the bias gradient stays at its zero fill instead of costing a reduction
+        return dr, cout
+
+    def bwd_weight(self, dr, cout, gr, side=None):
+        w = self.conv.weight
         xs = [t.r for t in self.inputs]
         aff = [t.aff for t in self.inputs]
-        cin = sum(x.shape[3] for x in xs)
-        dev = dr.device
         # ---- weight gradient: a leaf of the backward graph (nothing downstream reads it before the optimizer), so it runs on a
         # side stream beside the data-gradient chain that the next unit waits for; backward() joins the streams at its end
         def wgrad():
@@ -159,7 +168,11 @@ class Unit:
                 side.wait_event(ready)
                 wgrad()
             dr.record_stream(side)       # dr dies with this call: its memory must not be reused before the side stream read it
+
+    def bwd_inputs(self, dr, cout):
         # ---- data gradients, one launch per input segment, then activation backward through the producer's affine
+        w = self.conv.weight
+        dev = dr.device
         c0 = 0
         for t in self.inputs:
             cs = t.r.shape[3]
@@ -188,23 +201,91 @@ class Unit:
                 ops.conv2d([dr], wt, None, cs, 4, out=dA, geom=geom)
             else:
                 raise ValueError(self.kind)
-            sc, sh = (t.scale, t.shift) if t.scale is not None else (None, None)
-            first = t.G is None          # first consumer writes, later ones accumulate: no zero fill of the activation
-            if first:
-                t.G = torch.empty_like(t.r)
-            t.n_done = getattr(t, "n_done", 0) + 1
-            if (getattr(t, "gsums", None) is not None and t.n_done == t.n_cons and cs % 4 == 0 and 256 % (cs // 4) == 0
-                    and self.pro_act in ("none", "relu", "leaky02", "leaky001")):
-                # last consumer of a BatchNorm output: G is complete after this call -- fold the producer's BatchNorm-backward
-                # reduction into it (csrc/conv_bwd.hip k_affine_act_bwd_stats)
-                check(lib.dpmn_affine_act_bwd_stats_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
-                                                        0 if first else 1, t.r.numel() // cs, cs, dptr(t.mean), dptr(t.rstd), t.gsums.data_ptr(),
-                                                        stream()))
-                t.gsums_done = True
-            else:
-                check(lib.dpmn_affine_act_bwd_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
-                                                  0 if first else 1, t.r.numel() // cs, cs, stream()))
+            self.push_grad(t, dA)
             c0 += cs
+
+    def push_grad(self, t, dA):
+        """Activation backward through the producer's affine: t.G (+)= dA * act'(scale * r + shift)."""
+        cs = t.r.shape[3]
+        sc, sh = (t.scale, t.shift) if t.scale is not None else (None, None)
+        first = t.G is None          # first consumer writes, later ones accumulate: no zero fill of the activation
+        if first:
+            t.G = torch.empty_like(t.r)
+        t.n_done = getattr(t, "n_done", 0) + 1
+        if (getattr(t, "gsums", None) is not None and t.n_done == t.n_cons and cs % 4 == 0 and 256 % (cs // 4) == 0
+                and self.pro_act in ("none", "relu", "leaky02", "leaky001")):
+            # last consumer of a BatchNorm output: G is complete after this call -- fold the producer's BatchNorm-backward
+            # reduction into it (csrc/conv_bwd.hip k_affine_act_bwd_stats)
+            check(lib.dpmn_affine_act_bwd_stats_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
+                                                    0 if first else 1, t.r.numel() // cs, cs, dptr(t.mean), dptr(t.rstd), t.gsums.data_ptr(),
+                                                    stream()))
+            t.gsums_done = True
+        else:
+            check(lib.dpmn_affine_act_bwd_f32(dptr(dA), dptr(t.r), dptr(sc, True), dptr(sh, True), ACT[self.pro_act], dptr(t.G),
+                                              0 if first else 1, t.r.numel() // cs, cs, stream()))
+
+
+# 1 (default): the data gradients of the twin encoder branches (cmm.py:86-99: same geometry, own weights) as ONE grouped launch per
+# level (groups = 2 of dpmn_conv2d_nhwc_f32, the launch the eval forward uses for the twins) instead of two half-batch launches with
+# twice the split-K; 0: every unit on its own
+GROUP_BWD = os.environ.get("DPMN_CMM_GROUP_BWD", "1") != "0"
+GROUP_BWD_MAXPIX = int(os.environ.get("DPMN_CMM_GROUP_BWD_MAXPIX", "12288"))      # pair only levels with at most this many pixels per branch
+
+
+def _pair_pack(fn, u1, u2, cs):
+    """(2, cs, Kp): the two branches' data-gradient packs in ONE buffer (w_group_stride apart), kept on the first branch's conv module
+    so that the step's multi-descriptor pack launch (model/packing.py PackCache) refreshes it in place."""
+    w1, w2 = u1.conv.weight, u2.conv.weight
+    store = u1.conv.__dict__.setdefault("_dpmn_pair_packs", {})
+    key = (fn.__name__, cs, w1.data_ptr(), w2.data_ptr())
+    buf = store.get(key)
+    if buf is None:
+        o, _i, kh, kw = w1.shape
+        store.clear()       # (a new Trainer moved the parameters: drop the buffers of the old addresses)
+        buf = store[key] = torch.empty(2, cs, (kh * kw * o + 31) // 32 * 32, device=w1.device)
+    p1, p2 = fn(w1, 0, cs, out=buf[0]), fn(w2, 0, cs, out=buf[1])
+    if p1.data_ptr() != buf[0].data_ptr() or p2.data_ptr() != buf[1].data_ptr():
+        return torch.stack([p1, p2])      # the pack cache already held separate tensors for these weights
+    return buf
+
+
+def pair_ok(u1, u2):
+    """Can the data gradients of these two twin units share a grouped launch?  Same kind and shapes, one input each with >= 32
+    channels (the 4-channel leaf of en_1 runs on the Cout <= 4 kernel, which has no grouped form), both inputs want a gradient, the
+    BatchNorm backward writes dL/d(raw output) of each branch into its half of one buffer, and the pixels of one half fill whole row
+    tiles of the grouped launch."""
+    if not GROUP_BWD or u1.kind != u2.kind or u1.kind not in ("conv3", "conv4s2d2") or len(u1.inputs) != 1 or len(u2.inputs) != 1:
+        return False
+    t1, t2 = u1.inputs[0], u2.inputs[0]
+    if t1.G is False or t2.G is False or t1.r.shape != t2.r.shape or t1.r.shape[3] < 32 or u1.out.r.shape != u2.out.r.shape:
+        return False
+    if u1.out.G is None or u2.out.G is None or u1.conv.weight.shape != u2.conv.weight.shape or (u1.bn is None) != (u2.bn is None):
+        return False
+    B, Hi, Wi, _ = t1.r.shape
+    pix = B * Hi * Wi if u1.kind == "conv3" else B * (Hi // 2) * (Wi // 2)
+    if pix % (64 if pix <= 512 else 128) != 0 or pix > GROUP_BWD_MAXPIX:
+        return False
+    return u1.bn is not None      # (a unit without BatchNorm hands its G on as dr: the halves would have to share a buffer already)
+
+
+def backward_pair(u1, u2, gr, side=None):
+    """Unit.backward of two twin encoder units with the data gradient as one grouped launch."""
+    B = u1.out.r.shape[0]
+    drp = torch.empty(2 * B, *u1.out.r.shape[1:], device=u1.out.r.device)      # the BatchNorm backward of each branch fills its half
+    dr1, cout = u1.bwd_output(gr, drp[:B])
+    dr2, _ = u2.bwd_output(gr, drp[B:])
+    u1.bwd_weight(dr1, cout, gr, side)
+    u2.bwd_weight(dr2, cout, gr, side)
+    t1, t2 = u1.inputs[0], u2.inputs[0]
+    _, Hi, Wi, cs = t1.r.shape
+    if u1.kind == "conv3":
+        dAp = ops.conv2d([drp], _pair_pack(packing.tpack_dgrad_conv_s1, u1, u2, cs), None, cs, 3, pad=1, groups=2)
+    else:       # conv4s2d2: the odd-pixel scatter of Unit.bwd_inputs
+        dAp = torch.zeros(2 * B, Hi, Wi, cs, device=drp.device)
+        geom = dict(stride=1, dil_y=-1, dil_x=-1, pad_y=-2, pad_x=-2, Hp=Hi // 2, Wp=Wi // 2, Hout=Hi, Wout=Wi, ostep=2, ooy=1, oox=1)
+        ops.conv2d([drp], _pair_pack(packing.tpack_dgrad_generic, u1, u2, cs), None, cs, 4, out=dAp, geom=geom, groups=2)
+    u1.push_grad(t1, dAp[:B])
+    u2.push_grad(t2, dAp[B:])
 
 
 WGRAD_STREAM = os.environ.get("DPMN_WGRAD_STREAM", "1") != "0"
@@ -235,8 +316,9 @@ def build(m, x1, x2):
         units.append(u)
         return u.forward()
 
-    enc, leaves = [], []
+    enc, leaves, enc_units = [], [], []
     for br, x in (("1", x1), ("2", x2)):
+        n_before = len(units)
         leaf = T(ops.nchw_to_nhwc(x.contiguous().float(), 4))
         leaves.append(leaf)
         o = [run("conv3", getattr(m, "en_1_" + br), None, [leaf], "none", cin_pad=4)]
@@ -246,6 +328,7 @@ def build(m, x1, x2):
             o.append(run("conv3", seq[4], seq[5], [t], "leaky02"))
         o.append(run("conv4s2", getattr(m, "en_6_" + br)[1], None, [o[-1]], "leaky02"))
         enc.append(o)
+        enc_units.append(units[n_before:])
     a, b = enc
     bott = torch.cat([a[5].r, b[5].r], dim=3)
     gated = T(ops.se_gate(bott, m.fc_1.weight, m.fc_1.bias, m.fc_2.weight, m.fc_2.bias))
@@ -259,7 +342,7 @@ def build(m, x1, x2):
     wp, bp = packing.tpack_convT_s1(m.de_1[1].weight), m.de_1[1].bias
     out = ops.conv2d([d.r, a[0].r, b[0].r], wp, bp, m.c_img, 3, pad=1, pro_act="relu", affine=[d.aff, a[0].aff, b[0].aff], out_nchw=True)
     last.out = T(None)
-    return out, dict(units=units, bott=bott, gated=gated, enc=enc, leaves=leaves, last=last)
+    return out, dict(units=units, bott=bott, gated=gated, enc=enc, leaves=leaves, last=last, twins=list(zip(*enc_units)))
 
 
 def backward(m, graph, dout, need_dx=(True, True)):
@@ -285,6 +368,11 @@ def backward(m, graph, dout, need_dx=(True, True)):
         for t in bn_outs:
             n = 2 * t.r.shape[3]
             t.gsums, off = slab[off:off + n], off + n
+    partner, second = {}, set()
+    if GROUP_BWD:
+        for u1, u2 in graph.get("twins", ()):
+            partner[id(u2)], partner[id(u1)] = u1, u2
+            second.add(id(u2))
     side = wgrad_stream(dout.device)
     # every conv's weight-gradient unpack in ONE launch at the end (train/pgrm_train.py UnpackQueue; per module: the descriptor
     # table holds this module's gradient sinks)
@@ -296,7 +384,23 @@ def backward(m, graph, dout, need_dx=(True, True)):
             uq = m._unpack_queue = _pt.UnpackQueue()
         _pt.UNPACK_QUEUE = uq
     try:
+      # reverse execution order; the units of the second encoder branch wait for their twins (branch 1 comes later in this order): a
+      # twin pair runs when its FIRST-branch unit is reached, after both units' consumers (decoder, next encoder level) are done
+      waiting = set()
       for u in reversed(units):
+          tw = partner.get(id(u))
+          if tw is not None and id(u) in second:
+              waiting.add(id(u))      # branch-2 unit: deferred until its branch-1 twin comes up
+              continue
+          if tw is not None and id(tw) in waiting:
+              if tw.out.G is not None and u.out.G is not None and pair_ok(u, tw):
+                  backward_pair(u, tw, gr, side)
+              else:
+                  if tw.out.G is not None:
+                      tw.backward(gr, side)
+                  if u.out.G is not None:
+                      u.backward(gr, side)
+              continue
           if u is last or u.out.G is not None:
               u.backward(gr, side)
           if u.inputs and u.inputs[0] is graph["gated"]:

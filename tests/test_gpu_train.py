@@ -347,6 +347,51 @@ def test_cmm_train_forward_backward_vs_oracle_autograd(dev, cnum):
     assert int(bn.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("B", [2, 48])
+def test_cmm_grouped_twin_data_gradients_equal_per_branch_launches(dev, B, monkeypatch):
+    """The data gradients of the twin encoder branches as one grouped launch per level (train/cmm_train.py backward_pair) against one
+    launch per branch: same sums up to the order of the split-K partial sums (fewer splits over twice the pixels), every parameter and
+    input gradient within 1e-5 relative L2 (measured: 2.1e-6 on the first conv's bias, a sum over 4.7 M pixels); with the switch off no level
+    is paired."""
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    from dpmn_amd.train import cmm_train
+    m = ComplementationModulationModule(cnum=64)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 98)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    x1, x2 = u("gx1", (B, 3, 32, 128), 0, 1).to(dev), u("gx2", (B, 3, 32, 128), 0, 1).to(dev)
+    cot = u("gcot", (B, 3, 32, 128), -1, 1).to(dev)
+    calls = []
+    orig = cmm_train.backward_pair
+    monkeypatch.setattr(cmm_train, "backward_pair", lambda *a, **k: (calls.append(a[0].kind), orig(*a, **k))[1])
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(cmm_train, "GROUP_BWD", on)
+        monkeypatch.setattr(cmm_train, "GROUP_BWD_MAXPIX", 1 << 30)
+        del calls[:]
+        for p in m.parameters():
+            p.grad = None
+        a, b = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+        (m(a, b) * cot).sum().backward()
+        torch.cuda.synchronize()
+        res[on] = ([a.grad.clone(), b.grad.clone()] + [p.grad.clone() for p in m.parameters()], list(calls))
+    assert res[False][1] == []
+    # B = 48: all four levels of (dilated stride-2 conv, 3 x 3 conv) fill whole row tiles; B = 2: the two launches of the deepest level
+    # (2 x 16 = 32 pixels per branch) do not and fall back to per-branch launches
+    assert len(res[True][1]) == (8 if B == 48 else 6), res[True][1]
+    names = ["dx1", "dx2"] + [n for n, _ in m.named_parameters()]
+    worst = 0.0
+    for n, g1, g0 in zip(names, res[True][0], res[False][0]):
+        if float(g0.abs().max()) < 2e-3:
+            continue      # bias in front of a train-mode BatchNorm: zero fill
+        e = l2_err(g1, g0)
+        worst = max(worst, e)
+        assert e < 1e-5, (n, e)
+    from helpers import record
+    record("cmm_grouped_dgrad_B%d" % B, "worst gradient rel L2, grouped vs per-branch data gradients", worst, 1e-5)
+
+
 @pytest.mark.parametrize("cnum,B", [(64, 4), (64, 6)])
 def test_cmm_backward_is_bitwise_reproducible(dev, cnum, B):
     """Every gradient of the CMM's training step -- conv weight gradients (exclusive slots), BatchNorm backward (fp64 per-channel
