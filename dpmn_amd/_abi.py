@@ -254,6 +254,7 @@ SIGNATURES = {
     "dpmn_sk_gate_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_dwconv3x3_gelu_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_pgrm_tail_f32": (_i, [fp, fp, fp, fp, fp, _PP, _PP, _i, fp, fp, _i, _i, _i, _i, _i, _i, fp]),
+    "dpmn_pgrm_tail_reuse_f32": (_i, [fp, fp, fp, fp, fp, _PP, _PP, _i, fp, fp, _i, _i, _i, _i, _i, _i, _i, fp]),
     "dpmn_tatt_interpreter_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpmn_tatt_interpreter_f32": (_i, [C.POINTER(TattInterpWeights), fp, _i, fp, fp, fp, fp, fp, fp, _sz, _i, _i, _i, fp]),
     "dpmn_psn_trunk_workspace_bytes": (_sz, [C.POINTER(PsnWeights), _i, _i, _i]),

@@ -980,6 +980,12 @@ int dpmn_dwconv3x3_train_f32(const float* y, const float* w, const float* bias, 
 int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, const float* w1, const float* b1,
                        const float* const* weight_list, const float* const* residuals, int n_residuals, float* mid_ws,
                        float* out, int B, int H, int W, int C, int hidden, int patch, dpmn_stream_t stream) {
+  return dpmn_pgrm_tail_reuse_f32(tokens, w0, b0, w1, b1, weight_list, residuals, n_residuals, mid_ws, out, B, H, W, C, hidden, patch, 0, stream);
+}
+
+int dpmn_pgrm_tail_reuse_f32(const float* tokens, const float* w0, const float* b0, const float* w1, const float* b1,
+                             const float* const* weight_list, const float* const* residuals, int n_residuals, float* mid_ws,
+                             float* out, int B, int H, int W, int C, int hidden, int patch, int reuse_pack, dpmn_stream_t stream) {
   DPMN_REQUIRE(tokens && w0 && b0 && w1 && b1 && weight_list && mid_ws && out, "tail: null pointer");
   DPMN_REQUIRE(n_residuals >= 0 && n_residuals <= 8, "tail: at most 8 residuals");
   DPMN_REQUIRE(hidden == 3 && patch == 2 && C % 4 == 0, "tail: built for hidden_size=3, patch_size=2 (super_resolution.py:38-53)");
@@ -987,8 +993,10 @@ int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, co
   const int Kp = ((9 * C + 31) / 32) * 32;
   // mid_ws layout: [B*H*W*Cm mid activations][Cm*Kp packed conv0 weights]
   float* wp = mid_ws + (size_t)B * H * W * Cm;
-  hipLaunchKernelGGL(k_pack_conv_w, dim3((Cm * Kp + 255) / 256), dim3(256), 0, as_stream(stream), w0, wp, Cm, C, 9, Kp);
-  DPMN_CHECK_LAUNCH();
+  if (!reuse_pack) {     // (frozen weights, same workspace: the pack of the previous call is still there, dpmn_pgrm_weights.reuse_folded)
+    hipLaunchKernelGGL(k_pack_conv_w, dim3((Cm * Kp + 255) / 256), dim3(256), 0, as_stream(stream), w0, wp, Cm, C, 9, Kp);
+    DPMN_CHECK_LAUNCH();
+  }
   dpmn_conv_desc d{};
   d.in[0] = tokens; d.cseg[0] = C; d.B = B; d.Hin = H; d.Win = W;
   d.KH = 3; d.KW = 3; d.stride = 1; d.dil_y = 1; d.dil_x = 1; d.pad_y = 1; d.pad_x = 1;

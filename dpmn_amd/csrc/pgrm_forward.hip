@@ -119,8 +119,8 @@ int dpmn_pgrm_forward_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_
     RUN(dpmn_pointwise_f32(s.g, p.pw_w, p.pw_b, s.y, B, Ch, L, stream));
     RUN(dpmn_linear_f32(s.y, p.fc2_w, p.fc2_b, s.x1, nullptr, s.tkv, M, C, Ch, DPMN_ACT_NONE, 0.f, stream));
   }
-  RUN(dpmn_pgrm_tail_f32(s.tkv, w->tail0_w, w->tail0_b, w->tail1_w, w->tail1_b, w->weight_list, residuals, n_residuals,
-                         s.mid, out, B, H, Wd, C, w->hidden_size, w->patch, stream));
+  RUN(dpmn_pgrm_tail_reuse_f32(s.tkv, w->tail0_w, w->tail0_b, w->tail1_w, w->tail1_b, w->weight_list, residuals, n_residuals,
+                               s.mid, out, B, H, Wd, C, w->hidden_size, w->patch, w->reuse_folded ? 1 : 0, stream));
 #undef RUN
   return DPMN_OK;
 }

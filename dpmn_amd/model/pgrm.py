@@ -288,7 +288,7 @@ class PGRM(nn.Module):
         # the LayerNorm-folded attention weights in the workspace stay valid while nothing touched the parameters: torch-side
         # writes bump _version, the optimizer kernels (raw pointers) reset self._pack through Trainer.invalidate_packs()
         # (code that writes parameters through raw pointers outside Trainer.step must set module._pack = None itself)
-        fkey = (ws.data_ptr(), B, tuple((p.data_ptr(), p._version) for p in self.layers[0].parameters()))
+        fkey = (ws.data_ptr(), B, tuple((p.data_ptr(), p._version) for p in _plist(self)))      # (every parameter: the tail conv's pack is reused too)
         if self._pack is None or not isinstance(self._fold_key, dict):
             self._fold_key = {}
         w.reuse_folded = int(self._fold_key.get(sid) == fkey)

@@ -326,6 +326,10 @@ int dpmn_pgrm_tail_f32(const float* tokens, const float* w0, const float* b0, co
                        const float* const* weight_list, const float* const* residuals, int n_residuals,
                        float* mid_ws, float* out, int B, int H, int W, int C, int hidden, int patch,
                        dpmn_stream_t stream);
+/* reuse_pack != 0: mid_ws still holds conv_before_upsample[0]'s packed weights of a previous call with the same (unchanged) weights */
+int dpmn_pgrm_tail_reuse_f32(const float* tokens, const float* w0, const float* b0, const float* w1, const float* b1,
+                             const float* const* weight_list, const float* const* residuals, int n_residuals, float* mid_ws,
+                             float* out, int B, int H, int W, int C, int hidden, int patch, int reuse_pack, dpmn_stream_t stream);
 
 /* ------------------------------------------------------------------ image-space helpers (misc.hip) */
 /* toMask (utils/util.py:27-35) for a batch: img NCHW, first 3 channels used, img_stride = floats between images;

@@ -484,6 +484,16 @@ def test_pgrm_eval_after_training_refolds_the_attention_weights(dev):
         r0 = opgrm.pgrm_forward(cpu_sd(), xq.cpu(), xkv.cpu(), [])
     assert torch.equal(e0, e0b)
     assert_close(e0, r0, 1e-4, 1e-4, "eval before training")
+    # the packed conv_before_upsample[0] weights are reused with the folded attention weights: a torch-side write to that conv (version
+    # counter bump) must repack them
+    with torch.no_grad():
+        m.conv_before_upsample[0].weight.mul_(1.5)
+        e0c = m(xq, xkv, [])
+        r0c = opgrm.pgrm_forward(cpu_sd(), xq.cpu(), xkv.cpu(), [])
+        assert max_abs_err(r0c, r0) > 1e-3
+        assert_close(e0c, r0c, 1e-4, 1e-4, "eval after a torch-side write to the tail conv")
+        m.conv_before_upsample[0].weight.div_(1.5)
+        r0 = opgrm.pgrm_forward(cpu_sd(), xq.cpu(), xkv.cpu(), [])
     tr = Trainer([m], lr=1e-2, beta1=0.5, max_norm=0.25)
     m.train()
     for p in m.parameters():
