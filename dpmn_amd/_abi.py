@@ -199,6 +199,7 @@ SIGNATURES = {
     "dpmn_patch_scatter_f32": (_i, [fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_prior_fusion_wgrad_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_patch_embed_bwd_det_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_patch_embed_bwd_det_drop_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_prior_fusion_wgrad_det_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), fp, fp, _i, fp]),
     "dpmn_conv_pack_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, fp]),
@@ -218,6 +219,7 @@ SIGNATURES = {
     "dpmn_sumsq_f32": (_i, [fp, fp, fp, C.c_long, fp]),
     "dpmn_adam_clip_f32": (_i, [fp, fp, fp, fp, fp, _f, _f, _f, _f, _f, _i, fp, C.c_long, fp]),
     "dpmn_patch_embed_ln_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, fp]),
+    "dpmn_patch_embed_ln_drop_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_window_attn_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, fp]),
     "dpmn_window_attn_drop_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_window_attn_drop_bwd_f32": (_i, [fp, fp, _PP, _IP, _IP, _i, _i, fp, fp, fp, _PP, _i, _i, _i, _i, _f, _u64, fp]),

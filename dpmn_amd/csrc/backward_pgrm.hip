@@ -881,7 +881,10 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
                                                           const float* __restrict__ pe_b, const float* __restrict__ ln_w,
                                                           const float* __restrict__ dtok, float* __restrict__ dconv,
                                                           float* __restrict__ patches, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, int B, int Hi, int Wi, float* __restrict__ lnpart) {
+                                                          float* __restrict__ dbeta, int B, int Hi, int Wi, float* __restrict__ lnpart,
+                                                          float p_drop, unsigned long long seed) {
+  // p_drop > 0: dtok is the gradient BEHIND pos_drop (pgrm.py:550-551): the forward's mask (dpmn_dropout_f32's, regenerated from
+  // the seed) is applied as it is loaded -- the same product as a dropout launch over dtok in front of this kernel
   // lnpart != null: the block STORES its [dgamma (C) | dbeta (C)] partial as row blockIdx.x (added in block order by the caller);
   // the 16 tokens of a wave are summed by shuffles, the four waves' sums in wave order -- no atomics, bitwise reproducible
   constexpr int CQ = C / 4, KP = 12;
@@ -955,7 +958,8 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
 #pragma unroll
   for (int i = 0; i < CQ; ++i) {
     const int c = part * CQ + i;
-    const float d = valid ? dtok[(size_t)token * C + c] : 0.f;
+    float d = valid ? dtok[(size_t)token * C + c] : 0.f;
+    if (p_drop > 0.f) d *= drop_scale(seed, (unsigned long long)token * C + c, p_drop, 1.0f / (1.0f - p_drop));
     xh[i] = (o[i] - mean) * rstd;
     dg[i] = d * ln_w[c];
     s1 += dg[i];
@@ -1355,12 +1359,14 @@ int dpmn_pgrm_tail_elem_bwd_f32(const float* dout, const float* c1, const float*
 
 static int patch_embed_bwd_impl(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
                                 const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
-                                float* dgamma, float* dbeta, float* part, int B, int Hi, int Wi, int C, dpmn_stream_t stream) {
+                                float* dgamma, float* dbeta, float* part, int B, int Hi, int Wi, int C, dpmn_stream_t stream,
+                                float p_drop = 0.f, unsigned long long seed = 0ull) {
+  DPMN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "patch_embed_bwd: drop probability must be in [0, 1)");
   DPMN_REQUIRE(img && pe_w && pe_b && ln_w && dtok && dconv && patches && ((dgamma && dbeta) || part), "patch_embed_bwd: null pointer");
   const long tokens_n = (long)B * (Hi / 2) * (Wi / 2);
   dim3 grid((unsigned)((tokens_n + 63) / 64));
   hipStream_t st = as_stream(stream);
-#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi, part)
+#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi, part, p_drop, seed)
   if (C == 96 && pf_w) PB_LAUNCH(96, true);
   else if (C == 96) PB_LAUNCH(96, false);
   else if (C == 192 && pf_w) PB_LAUNCH(192, true);
@@ -1383,6 +1389,15 @@ int dpmn_patch_embed_bwd_det_f32(const float* img, int cin, const float* pf_w, c
                                  float* ln_part, int B, int Hi, int Wi, int C, dpmn_stream_t stream) {
   DPMN_REQUIRE(ln_part, "patch_embed_bwd_det: null pointer");
   return patch_embed_bwd_impl(img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, nullptr, nullptr, ln_part, B, Hi, Wi, C, stream);
+}
+
+int dpmn_patch_embed_bwd_det_drop_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                      const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
+                                      float* ln_part, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
+                                      dpmn_stream_t stream) {
+  DPMN_REQUIRE(ln_part, "patch_embed_bwd_det: null pointer");
+  return patch_embed_bwd_impl(img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, nullptr, nullptr, ln_part, B, Hi, Wi, C, stream,
+                              p_drop, seed);
 }
 
 int dpmn_patch_scatter_f32(const float* din, float* dimg, int cimg, int B, int Hi, int Wi, dpmn_stream_t stream) {

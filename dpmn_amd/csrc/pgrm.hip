@@ -23,7 +23,9 @@ __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict_
                                                          const float* __restrict__ pf_b, const float* __restrict__ pe_w,
                                                          const float* __restrict__ pe_b, const float* __restrict__ ln_w,
                                                          const float* __restrict__ ln_b, float* __restrict__ tok, int B,
-                                                         int Hi, int Wi) {
+                                                         int Hi, int Wi, float p_drop, unsigned long long seed) {
+  // p_drop > 0: pos_drop (pgrm.py:550-551) on the way out -- the mask of dpmn_dropout_f32(tokens, n = M C, p_drop, seed) applied to the
+  // finished LayerNorm output (same product, bitwise), one launch and one pass over the tokens less per stream
   constexpr int CQ = C / 4, KP = 3 * PATCH * PATCH;
   static_assert(!FUSE || PATCH == 2, "fused prior conv assumes 2x2 patches (one pixel per lane of the token quad)");
   __shared__ float wt[KP * C];
@@ -93,13 +95,18 @@ __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict_
   const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
   if (!valid) return;
   float* dst = tok + (size_t)token * C + part * CQ;
+  const float ik = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.f;
 #pragma unroll
   for (int i = 0; i < CQ; i += 4) {
     const int c = part * CQ + i;
-    *reinterpret_cast<float4*>(dst + i) = make_float4((o[i] - mean) * rstd * ln_w[c] + ln_b[c],
-                                                      (o[i + 1] - mean) * rstd * ln_w[c + 1] + ln_b[c + 1],
-                                                      (o[i + 2] - mean) * rstd * ln_w[c + 2] + ln_b[c + 2],
-                                                      (o[i + 3] - mean) * rstd * ln_w[c + 3] + ln_b[c + 3]);
+    float v[4] = {(o[i] - mean) * rstd * ln_w[c] + ln_b[c], (o[i + 1] - mean) * rstd * ln_w[c + 1] + ln_b[c + 1],
+                  (o[i + 2] - mean) * rstd * ln_w[c + 2] + ln_b[c + 2], (o[i + 3] - mean) * rstd * ln_w[c + 3] + ln_b[c + 3]};
+    if (p_drop > 0.f) {
+      const unsigned long long z0 = drop_z0(seed, (unsigned long long)token * C + c);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] *= drop_scale_z(z0 + (unsigned long long)r * DROP_PHI, p_drop, ik);
+    }
+    *reinterpret_cast<float4*>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -831,6 +838,13 @@ extern "C" {
 int dpmn_patch_embed_ln_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
                             const float* pe_b, const float* ln_w, const float* ln_b, float* tokens, int B, int Hi, int Wi,
                             int patch, int C, dpmn_stream_t stream) {
+  return dpmn_patch_embed_ln_drop_f32(img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, ln_b, tokens, B, Hi, Wi, patch, C, 0.f, 0ull, stream);
+}
+
+int dpmn_patch_embed_ln_drop_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                 const float* pe_b, const float* ln_w, const float* ln_b, float* tokens, int B, int Hi, int Wi,
+                                 int patch, int C, float p_drop, unsigned long long seed, dpmn_stream_t stream) {
+  DPMN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "patch_embed: drop probability must be in [0, 1)");
   DPMN_REQUIRE(img && pe_w && pe_b && ln_w && ln_b && tokens, "patch_embed: null pointer");
   DPMN_REQUIRE(patch >= 1 && patch <= 4 && Hi % patch == 0 && Wi % patch == 0, "patch_embed: bad patch size");
   DPMN_REQUIRE((pf_w != nullptr) || cin >= 3, "patch_embed: need 3 input channels without prior_fusion");
@@ -839,7 +853,7 @@ int dpmn_patch_embed_ln_f32(const float* img, int cin, const float* pf_w, const 
   DPMN_REQUIRE(patch == 2, "patch_embed: built for patch_size=2 (the --patch_size the DPMN recipe uses, README.md:34)");
   DPMN_REQUIRE(pf_w == nullptr || cin == 2, "patch_embed: prior_fusion expects a 2-channel text prior");
   hipStream_t st = as_stream(stream);
-#define PE_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_ln<CV, 2, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, ln_b, tokens, B, Hi, Wi)
+#define PE_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_ln<CV, 2, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, ln_b, tokens, B, Hi, Wi, p_drop, seed)
   if (C == 96 && pf_w) PE_LAUNCH(96, true);
   else if (C == 96) PE_LAUNCH(96, false);
   else if (C == 192 && pf_w) PE_LAUNCH(192, true);

@@ -168,14 +168,12 @@ int dpmn_pgrm_forward_train_f32(const dpmn_pgrm_weights* w, const float* x_q, in
   int rc;
 #define RUN(call) do { rc = (call); if (rc != DPMN_OK) return rc; } while (0)
   const bool fuse = (x_q_channels == 2);
-  RUN(dpmn_patch_embed_ln_f32(x_q, x_q_channels, fuse ? w->prior_fusion_w : nullptr, fuse ? w->prior_fusion_b : nullptr,
-                              w->pe_w, w->pe_b, w->pe_norm_w, w->pe_norm_b, sv->tq, B, w->img_h, w->img_w, w->patch, C, stream));
-  RUN(dpmn_patch_embed_ln_f32(x_kv, 3, nullptr, nullptr, w->pe_w, w->pe_b, w->pe_norm_w, w->pe_norm_b, sv->tkv0, B, w->img_h,
-                              w->img_w, w->patch, C, stream));
-  if (pd > 0.f) {    // pos_drop (pgrm.py:550-551), in place
-    RUN(dpmn_dropout_f32(sv->tq, nullptr, sv->tq, (long)M * C, 0, pd, sd[0], 0.f, 0, stream));
-    RUN(dpmn_dropout_f32(sv->tkv0, nullptr, sv->tkv0, (long)M * C, 0, pd, sd[1], 0.f, 0, stream));
-  }
+  // pos_drop (pgrm.py:550-551) rides in the patch embedding's epilogue
+  RUN(dpmn_patch_embed_ln_drop_f32(x_q, x_q_channels, fuse ? w->prior_fusion_w : nullptr, fuse ? w->prior_fusion_b : nullptr,
+                                   w->pe_w, w->pe_b, w->pe_norm_w, w->pe_norm_b, sv->tq, B, w->img_h, w->img_w, w->patch, C, pd, sd[0],
+                                   stream));
+  RUN(dpmn_patch_embed_ln_drop_f32(x_kv, 3, nullptr, nullptr, w->pe_w, w->pe_b, w->pe_norm_w, w->pe_norm_b, sv->tkv0, B, w->img_h,
+                                   w->img_w, w->patch, C, pd, sd[1], stream));
   const float* tkv = sv->tkv0;
   for (int blk = 0; blk < 2; ++blk) {
     const dpmn_pgrm_block& p = w->blocks[blk];

@@ -48,12 +48,13 @@ def ln_linear(x, ln_w, ln_b, w, bias, act="none", eps=1e-5):
     return y
 
 
-def patch_embed_ln(img, pe_w, pe_b, ln_w, ln_b, patch, pf_w=None, pf_b=None):
+def patch_embed_ln(img, pe_w, pe_b, ln_w, ln_b, patch, pf_w=None, pf_b=None, p_drop=0.0, seed=0):
+    """p_drop > 0: pos_drop (pgrm.py:550-551) in the kernel's epilogue, the mask of dropout(tokens, p_drop, seed)."""
     B, cin, Hi, Wi = img.shape
     Cd = pe_w.shape[0]
     tok = torch.empty(B, (Hi // patch) * (Wi // patch), Cd, device=img.device)
-    check(lib.dpmn_patch_embed_ln_f32(dptr(img), cin, dptr(pf_w, True), dptr(pf_b, True), dptr(pe_w), dptr(pe_b),
-                                      dptr(ln_w), dptr(ln_b), dptr(tok), B, Hi, Wi, patch, Cd, stream()))
+    check(lib.dpmn_patch_embed_ln_drop_f32(dptr(img), cin, dptr(pf_w, True), dptr(pf_b, True), dptr(pe_w), dptr(pe_b),
+                                           dptr(ln_w), dptr(ln_b), dptr(tok), B, Hi, Wi, patch, Cd, float(p_drop), int(seed), stream()))
     return tok
 
 

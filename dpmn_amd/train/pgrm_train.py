@@ -451,14 +451,12 @@ def forward(m, x_q, x_kv, residuals, drop=None):
         if lib.dpmn_pgrm_forward_train_supported(C.byref(w), B):
             return _forward_native(m, x_q, x_kv, residuals, drop, w)
     pf = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
-    tq = ops.patch_embed_ln(x_q, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch, *pf).reshape(M, Cd)
-    tkv = ops.patch_embed_ln(x_kv, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch).reshape(M, Cd)
     pd = drop["p"] if drop else 0.0
     pa = drop["pa"] if drop else 0.0
     sd = drop["seeds"] if drop else [0] * N_SEEDS
-    if pd > 0:
-        ops.dropout(tq, pd, sd[0])
-        ops.dropout(tkv, pd, sd[1])
+    # pos_drop (pgrm.py:550-551) in the patch embedding's epilogue
+    tq = ops.patch_embed_ln(x_q, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch, *pf, p_drop=pd, seed=sd[0]).reshape(M, Cd)
+    tkv = ops.patch_embed_ln(x_kv, pe.proj.weight, pe.proj.bias, pe.norm.weight, pe.norm.bias, m.patch, p_drop=pd, seed=sd[1]).reshape(M, Cd)
     sv = dict(x_q=x_q, x_kv=x_kv, tq=tq, residuals=list(residuals), blocks=[], drop=drop)
     parts = (L + 31) // 32
     for bi, blk in enumerate(m.layers[0].blocks):
@@ -686,7 +684,7 @@ def backward(m, sv, dout, need_dx_kv=True):
         del nkv
         layernorm_bwd(s["tkv_in"], dnkv, blk.norm1_kv.weight, dx1, True, gr[blk.norm1_kv.weight], gr[blk.norm1_kv.bias])
         dtkv = dx1
-    if pd > 0:       # pos_drop on both token streams (pgrm.py:554-555)
+    if pd > 0 and not DET_SMALL:       # pos_drop on both token streams (pgrm.py:554-555); DET_SMALL: applied by the patch-embed backward on load
         ops.dropout(dtq, pd, sd[0])
         ops.dropout(dtkv, pd, sd[1])
     # patch embeddings (shared weights): kv path gives the image gradient, q path the prior_fusion gradients
@@ -703,10 +701,10 @@ def backward(m, sv, dout, need_dx_kv=True):
             nr = (M + 63) // 64
             if which == "kv":
                 lnp = torch.empty(2 * nr, 2 * Cd, device=dout.device)
-            check(lib.dpmn_patch_embed_bwd_det_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
-                                                   dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
-                                                   lnp.data_ptr() + (0 if which == "kv" else nr * 2 * Cd * 4), B, img.shape[2], img.shape[3], Cd,
-                                                   stream()))
+            check(lib.dpmn_patch_embed_bwd_det_drop_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
+                                                        dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
+                                                        lnp.data_ptr() + (0 if which == "kv" else nr * 2 * Cd * 4), B, img.shape[2], img.shape[3], Cd,
+                                                        float(pd), int(sd[1] if which == "kv" else sd[0]), stream()))
             if which == "q":
                 defer_rows(lnp, gr[pe.norm.weight], gr[pe.norm.bias], Cd, Cd, 2 * nr)
         else:

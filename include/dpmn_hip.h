@@ -306,6 +306,11 @@ int dpmn_gru_gate_f32(const float* gi, const float* gh, float* h, float* hist, l
 int dpmn_patch_embed_ln_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
                             const float* pe_b, const float* ln_w, const float* ln_b, float* tokens, int B, int Hi,
                             int Wi, int patch, int C, dpmn_stream_t stream);
+/* + pos_drop (pgrm.py:550-551) in the epilogue: tokens = dropout(PatchEmbed(img)) with the mask of
+ * dpmn_dropout_f32(tokens, n = B L C, p_drop, seed) -- bitwise that launch sequence */
+int dpmn_patch_embed_ln_drop_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                 const float* pe_b, const float* ln_w, const float* ln_b, float* tokens, int B, int Hi, int Wi,
+                                 int patch, int C, float p_drop, unsigned long long seed, dpmn_stream_t stream);
 /* multi-window cross attention core (pgrm.py:197-266): q (B,L,C), kv (B,L,2C) -> out (B,L,C) in
  * window-major order per group (quirk Q1).  bias_tables / windows / shifts are HOST arrays of length
  * n_groups (the table pointers themselves are device pointers). */
@@ -558,6 +563,11 @@ int dpmn_prior_fusion_wgrad_f32(const float* din, const float* prior, float* dpf
 int dpmn_patch_embed_bwd_det_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
                                  const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
                                  float* ln_part, int B, int Hi, int Wi, int C, dpmn_stream_t stream);
+/* dtok is the gradient behind pos_drop: the forward's mask (p_drop, seed) is applied on load */
+int dpmn_patch_embed_bwd_det_drop_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                      const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
+                                      float* ln_part, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
+                                      dpmn_stream_t stream);
 int dpmn_prior_fusion_wgrad_det_f32(const float* din, const float* prior, float* part, int B, int Hi, int Wi, dpmn_stream_t stream);
 /* conv weight gradient in the packed (Cout, Kp) layout, train-mode BatchNorm plumbing, CMM gate backward (conv_bwd.hip) */
 int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp,

@@ -165,6 +165,27 @@ def test_patch_embed(dev):
     got = ops.patch_embed_ln(prior.to(dev), d["patch_embed.proj.weight"], d["patch_embed.proj.bias"],
                              d["patch_embed.norm.weight"], d["patch_embed.norm.bias"], 2, pfw.to(dev), pfb.to(dev))
     assert_close(got, ref, 2e-4, RTOL, "patch_embed + prior_fusion")
+    # pos_drop in the epilogue / on the backward's load == a dropout launch behind / in front of the plain kernel (bitwise)
+    from dpmn_amd import _abi
+    w4 = [d["patch_embed.proj.weight"], d["patch_embed.proj.bias"], d["patch_embed.norm.weight"], d["patch_embed.norm.bias"]]
+    seed = 0x1234567890ABCDEF % (2 ** 62)
+    for im, pf in ((img.to(dev), (None, None)), (prior.to(dev), (pfw.to(dev), pfb.to(dev)))):
+        plain = ops.patch_embed_ln(im, *w4, 2, *pf)
+        fused = ops.patch_embed_ln(im, *w4, 2, *pf, p_drop=0.1, seed=seed)
+        two = ops.dropout(plain.clone(), 0.1, seed)
+        assert torch.equal(fused, two) and not torch.equal(fused, plain)
+        M = plain.shape[0] * plain.shape[1]
+        dtok = u("dtok", (M, 96), -1, 1).to(dev)
+        outs = []
+        for fused_bwd in (True, False):
+            dconv, patches = torch.empty(M, 96, device=dev), torch.empty(M, 16, device=dev)
+            lnp = torch.empty((M + 63) // 64, 192, device=dev)
+            dt = dtok if fused_bwd else ops.dropout(dtok.clone(), 0.1, seed)
+            _abi.check(_abi.lib.dpmn_patch_embed_bwd_det_drop_f32(_abi.dptr(im), im.shape[1], _abi.dptr(pf[0], True), _abi.dptr(pf[1], True), _abi.dptr(w4[0]),
+                                                                  _abi.dptr(w4[1]), _abi.dptr(w4[2]), _abi.dptr(dt), _abi.dptr(dconv), _abi.dptr(patches),
+                                                                  lnp.data_ptr(), B, 32, 128, 96, 0.1 if fused_bwd else 0.0, seed, _abi.stream()))
+            outs.append((dconv, patches, lnp))
+        assert all(torch.equal(a, b) for a, b in zip(*outs))
 
 
 @pytest.mark.parametrize("tag,shifts", [("shift0", [0, 0, 0]), ("shifted", [1, 2, 4])])
