@@ -1486,32 +1486,61 @@ __global__ __launch_bounds__(256) void k_conv_halo_c4(ConvArgs a) {
   const int c01 = a.cseg[0] + a.cseg[1];
   const int nchunks = a.cin / BK;
 
-  auto stage_halo = [&](int chunk) {
+  // The halo tile of the NEXT 32-channel chunk is requested into registers before this chunk's MFMAs and written to LDS behind
+  // them (the weights were already double-buffered; the halo was loaded between two barriers, its global latency exposed once per
+  // chunk: 6 chunks x ~2 us against 0.7 us of MFMAs per chunk on the 192 -> 3 output conv).  Affine / activation at the commit.
+  constexpr int HV = (NPX * 8 + 255) / 256;
+  float4 hraw[HV];
+  unsigned hvalid = 0;
+  auto chunk_seg = [&](int chunk, int& seg, int& cl0) {
     const int c0 = chunk * BK;
-    int seg = 0, cl0 = c0;
+    seg = 0; cl0 = c0;
     if (c0 >= c01) { seg = 2; cl0 = c0 - c01; }
     else if (c0 >= a.cseg[0]) { seg = 1; cl0 = c0 - a.cseg[0]; }
+  };
+  auto issue_halo = [&](int chunk) {
+    int seg, cl0;
+    chunk_seg(chunk, seg, cl0);
     const float* src = a.in[seg];
     const int cs = a.cseg[seg];
-    const float* sc = a.in_scale[seg];
-    const float* sh = a.in_shift[seg];
-    for (int i = tid; i < NPX * 8; i += 256) {
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    hvalid = 0;
+#pragma unroll
+    for (int v = 0; v < HV; ++v) {
+      const int i = tid + v * 256;
       const int px = i >> 3, c4 = (i & 7) * 4;
       const int iy = ty0 + px / HW_ - padk, ix = tx0 + px % HW_ - padk;
-      if (iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win) {
-        val = *reinterpret_cast<const float4*>(src + (((size_t)b * a.Hin + iy) * a.Win + ix) * cs + cl0 + c4);
-        if (sc) {
-          const float4 s4 = *reinterpret_cast<const float4*>(sc + cl0 + c4);
-          const float4 h4 = *reinterpret_cast<const float4*>(sh + cl0 + c4);
-          val.x = val.x * s4.x + h4.x; val.y = val.y * s4.y + h4.y; val.z = val.z * s4.z + h4.z; val.w = val.w * s4.w + h4.w;
-        }
-        if (a.pro_act != ACT_NONE) {
-          val.x = apply_act(val.x, a.pro_act, 0.f); val.y = apply_act(val.y, a.pro_act, 0.f);
-          val.z = apply_act(val.z, a.pro_act, 0.f); val.w = apply_act(val.w, a.pro_act, 0.f);
-        }
+      const bool ok = i < NPX * 8 && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+      hraw[v] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        hraw[v] = *reinterpret_cast<const float4*>(src + (((size_t)b * a.Hin + iy) * a.Win + ix) * cs + cl0 + c4);
+        hvalid |= 1u << v;
       }
-      *reinterpret_cast<float4*>(halo + px * LDK + c4) = val;
+    }
+  };
+  auto commit_halo = [&](int chunk) {
+    int seg, cl0;
+    chunk_seg(chunk, seg, cl0);
+    const float* sc = a.in_scale[seg];
+    const float* sh = a.in_shift[seg];
+#pragma unroll
+    for (int v = 0; v < HV; ++v) {
+      const int i = tid + v * 256;
+      if (i < NPX * 8) {
+        float4 val = hraw[v];
+        const int px = i >> 3, c4 = (i & 7) * 4;
+        if ((hvalid >> v) & 1u) {
+          if (sc) {
+            const float4 s4 = *reinterpret_cast<const float4*>(sc + cl0 + c4);
+            const float4 h4 = *reinterpret_cast<const float4*>(sh + cl0 + c4);
+            val.x = val.x * s4.x + h4.x; val.y = val.y * s4.y + h4.y; val.z = val.z * s4.z + h4.z; val.w = val.w * s4.w + h4.w;
+          }
+          if (a.pro_act != ACT_NONE) {
+            val.x = apply_act(val.x, a.pro_act, 0.f); val.y = apply_act(val.y, a.pro_act, 0.f);
+            val.z = apply_act(val.z, a.pro_act, 0.f); val.w = apply_act(val.w, a.pro_act, 0.f);
+          }
+        }
+        *reinterpret_cast<float4*>(halo + px * LDK + c4) = val;
+      }
     }
   };
   // group g of chunk: taps t = 3g .. 3g+2 ; tap -> (ky, q) = (t / Q, t % Q) ; LDS row n = 4*co + dx
@@ -1543,13 +1572,15 @@ __global__ __launch_bounds__(256) void k_conv_halo_c4(ConvArgs a) {
   f32x4 acc[MR];
 #pragma unroll
   for (int j = 0; j < MR; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  static_assert(HV <= 32, "halo validity mask");
   issue_w(0, 0);
   commit_w(0);
+  issue_halo(0);
+  commit_halo(0);
   int wb = 0;
   for (int chunk = 0; chunk < nchunks; ++chunk) {
-    __syncthreads();                 // previous chunk's halo fully consumed
-    stage_halo(chunk);
-    __syncthreads();
+    __syncthreads();                 // this chunk's halo (and the first weight group) visible
+    if (chunk + 1 < nchunks) issue_halo(chunk + 1);
     for (int g = 0; g < NG; ++g) {
       const bool lastg = g == NG - 1, more = chunk + 1 < nchunks;
       if (!lastg) issue_w(chunk, g + 1);
@@ -1575,6 +1606,8 @@ __global__ __launch_bounds__(256) void k_conv_halo_c4(ConvArgs a) {
       __syncthreads();
       wb ^= 1;
     }
+    // (the barrier that closed the last tap group: every wave is done with this chunk's halo)
+    if (chunk + 1 < nchunks) commit_halo(chunk + 1);
   }
   // lane (lr, kq = co): acc[j][r] = U_r[co][row j][x' = tx0 + lr].  out[x] = sum_r U_r[x + r]: shift within the 16-lane row.
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
