@@ -53,6 +53,11 @@ class PgrmDrop(C.Structure):
     _fields_ = [("p", C.c_float), ("pa", C.c_float), ("dp", C.c_float * 2), ("seeds", C.c_ulonglong * 12)]
 
 
+class PgrmBlockT(C.Structure):
+    NAMES = ("fc2_t", "pw_t", "fc1_t", "head_t", "proj_t", "q_t", "kv_t")
+    _fields_ = [(n, fp) for n in NAMES]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [("inp", fp * 3), ("in_scale", fp * 3), ("in_shift", fp * 3), ("cseg", C.c_int * 3)] + [
         (n, C.c_int) for n in ("B", "Hin", "Win", "KH", "KW", "stride", "dil_y", "dil_x", "pad_y", "pad_x", "Hp", "Wp",
@@ -266,6 +271,10 @@ SIGNATURES = {
     "dpmn_pgrm_workspace_bytes": (_sz, [C.POINTER(PgrmWeights), _i]),
     "dpmn_pgrm_forward_f32": (_i, [C.POINTER(PgrmWeights), fp, _i, fp, _PP, _i, fp, fp, _sz, _i, fp]),
     "dpmn_pgrm_forward_train_supported": (_i, [C.POINTER(PgrmWeights), _i]),
+    "dpmn_pgrm_blocks_backward_scratch_bytes": (_sz, [C.POINTER(PgrmWeights), _i, C.POINTER(C.c_int)]),
+    "dpmn_pgrm_blocks_backward_f32": (_i, [C.POINTER(PgrmWeights), C.POINTER(PgrmBlock), C.POINTER(PgrmBlockT), C.POINTER(PgrmSaved),
+                                           C.POINTER(PgrmDrop), C.POINTER(C.c_int), fp, fp, _PP, fp, fp, _sz, fp, _sz, C.POINTER(C.c_size_t),
+                                           _i, fp]),
     "dpmn_pgrm_forward_train_f32": (_i, [C.POINTER(PgrmWeights), fp, _i, fp, _PP, _i, fp, fp, C.POINTER(PgrmDrop), C.POINTER(PgrmSaved),
                                          C.POINTER(CmmScratch), fp, _i, fp]),
 }

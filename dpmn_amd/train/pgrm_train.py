@@ -430,7 +430,7 @@ def _forward_native(m, x_q, x_kv, residuals, drop, w):
     out = torch.empty(B, m.hidden_size, m.img_size[0], m.img_size[1], device=x_kv.device)
     check(lib.dpmn_pgrm_forward_train_f32(C.byref(w), dptr(x_q), x_q.shape[1], dptr(x_kv), _abi.ptr_array(residuals), len(residuals), dptr(t0),
                                           dptr(t1), C.byref(cd) if cd is not None else None, C.byref(cs), C.byref(sc), dptr(out), B, stream()))
-    sv["_slab"] = slab
+    sv["_slab"], sv["_cs"] = slab, cs
     return out, sv
 
 
@@ -537,6 +537,91 @@ def forward(m, x_q, x_kv, residuals, drop=None):
     return out, sv
 
 
+NATIVE_BWD = os.environ.get("DPMN_PGRM_NATIVE_BWD", "1") != "0"      # 0: the Swin-block loop of the backward op by op from Python
+
+
+def _native_blocks_ok(m, sv, B):
+    """The two-block loop of backward() as one native call (csrc/pgrm_backward.hip)?  Needs the fused training geometry, the
+    atomics-free forms (the only ones the driver issues), deferred reductions (their arena is where its partial rows go) and the
+    recomputing attention backward (q / kv not saved)."""
+    if not (NATIVE_BWD and DET_SMALL and LNB_DET and FUSED_ATTN_BWD and _tn_pending is not None):
+        return False
+    if any(s.get("q") is not None or s.get("fold") is None for s in sv["blocks"]) or not sv["tq"].is_cuda:
+        return False
+    import ctypes as C
+    return bool(lib.dpmn_pgrm_forward_train_supported(C.byref(m._weights()), B))
+
+
+def _blocks_backward_native(m, sv, gr, drop, dtkv, dtq, dcat, B):
+    import ctypes as C
+    w = m._weights()
+    G = len(m.window_size)
+    blocks = m.layers[0].blocks
+    # gradient sinks in the layout of the weight table; in direct mode (flat gradient arena) they never move: built once per module
+    cached = m.__dict__.get("_bwd_sinks")
+    key = tuple(gr[p].data_ptr() for p in (blocks[0].mlp.fc2.weight, blocks[1].attn.q.bias))
+    if cached is None or cached[0] != key:
+        gs = (_abi.PgrmBlock * 2)()
+        for bi, blk in enumerate(blocks):
+            a, sk, mlp, g = blk.attn, blk.attn.sknet, blk.mlp, gs[bi]
+            d = lambda p: dptr(gr[p])
+            g.norm1_q_w, g.norm1_q_b, g.norm1_kv_w, g.norm1_kv_b = d(blk.norm1_q.weight), d(blk.norm1_q.bias), d(blk.norm1_kv.weight), d(blk.norm1_kv.bias)
+            g.q_w, g.q_b, g.kv_w, g.kv_b = d(a.q.weight), d(a.q.bias), d(a.kv.weight), d(a.kv.bias)
+            for k in range(G):
+                g.bias_table[k] = d(getattr(a, "relative_position_bias_table_%d" % k))
+            g.sk_proj_w, g.sk_proj_b = d(sk.proj.weight), d(sk.proj.bias)
+            g.sk_fc1_w, g.sk_fc1_b, g.sk_fc2_w, g.sk_fc2_b = d(sk.fc1.weight), d(sk.fc1.bias), d(sk.fc2.weight), d(sk.fc2.bias)
+            g.sk_head_w, g.sk_head_b = d(sk.proj_head.weight), d(sk.proj_head.bias)
+            g.norm2_w, g.norm2_b = d(blk.norm2.weight), d(blk.norm2.bias)
+            g.fc1_w, g.fc1_b, g.fc2_w, g.fc2_b = d(mlp.fc1.weight), d(mlp.fc1.bias), d(mlp.fc2.weight), d(mlp.fc2.bias)
+            g.dw_w, g.dw_b = d(mlp.depthwise_conv.weight), d(mlp.depthwise_conv.bias)
+            g.pw_w, g.pw_b = d(mlp.pointwise_conv.weight), d(mlp.pointwise_conv.bias)
+        cached = (key, gs)
+        if getattr(m, "_dpmn_bucket", None) is not None:
+            m.__dict__["_bwd_sinks"] = cached
+    gs = cached[1]
+    # transposed weights of the data-gradient products (the step's pack cache refreshes them in its one launch)
+    ts, keep = (_abi.PgrmBlockT * 2)(), []
+    Ch = int(m.embed_dim * m.mlp_ratio)
+    for bi, blk in enumerate(blocks):
+        a, sk, mlp = blk.attn, blk.attn.sknet, blk.mlp
+        for name, wgt in (("fc2_t", mlp.fc2.weight), ("pw_t", mlp.pointwise_conv.weight.reshape(Ch, Ch)), ("fc1_t", mlp.fc1.weight),
+                          ("head_t", sk.proj_head.weight), ("proj_t", sk.proj.weight), ("q_t", a.q.weight), ("kv_t", a.kv.weight)):
+            t_ = packing.transposed(wgt)
+            keep.append(t_)
+            setattr(ts[bi], name, dptr(t_))
+    cs = sv.get("_cs")
+    if cs is None:      # the per-op forward's dictionary: the same tensors, as the struct
+        cs = _abi.PgrmSaved()
+        cs.tq, cs.tkv0 = dptr(sv["tq"]), dptr(sv["blocks"][0]["tkv_in"])
+        for bi in range(2):
+            s = sv["blocks"][bi]
+            for name in _abi.PgrmSavedBlock.NAMES:
+                if name == "tkv_out":
+                    t_ = sv["blocks"][1]["tkv_in"] if bi == 0 else sv["tkv_out"]
+                else:
+                    t_ = s[name]
+                setattr(cs.blk[bi], name, dptr(t_))
+    cd = None
+    if drop:
+        cd = _abi.PgrmDrop()
+        cd.p, cd.pa = drop["p"], drop["pa"]
+        cd.dp[0], cd.dp[1] = drop["dp"]
+        for i, v in enumerate(drop["seeds"]):
+            cd.seeds[i] = v
+    numel = _abi.int_array([t.numel() for t in sv["blocks"][0]["tables"]])
+    need = lib.dpmn_pgrm_blocks_backward_scratch_bytes(C.byref(w), B, numel)
+    scratch = torch.empty(need // 4, device=dtkv.device)
+    arena = _tn_pending[0]
+    used = C.c_size_t(_tn_pending[1])
+    _tn_pending[2].append(scratch)       # holds partial rows of queued reductions: alive until the flush
+    check(lib.dpmn_pgrm_blocks_backward_f32(C.byref(w), gs, ts, C.byref(cs), C.byref(cd) if cd is not None else None, numel, dptr(dtkv), dptr(dtq),
+                                            _abi.ptr_array(dcat), dptr(_zero_bias(Ch, dtkv.device)), scratch.data_ptr(), need, arena.data_ptr(),
+                                            arena.numel() * 4, C.byref(used), B, stream()))
+    _tn_pending[1] = used.value
+    del keep
+
+
 def backward(m, sv, dout, need_dx_kv=True):
     """Returns (dx_kv or None, [dresidual_i or None], {param: grad}, direct) -- see grad_targets."""
     B = sv["x_kv"].shape[0]
@@ -579,7 +664,10 @@ def backward(m, sv, dout, need_dx_kv=True):
     pd = drop["p"] if drop else 0.0
     pa = drop["pa"] if drop else 0.0
     sd = drop["seeds"] if drop else [0] * N_SEEDS
-    for bi in (1, 0):
+    native = _native_blocks_ok(m, sv, B)
+    if native:
+        _blocks_backward_native(m, sv, gr, drop, dtkv, dtq, [zeros(M, Cd), zeros(M, Cd)], B)      # dtkv updated in place
+    for bi in (() if native else (1, 0)):
         blk = m.layers[0].blocks[bi]
         a, sk, mlp = blk.attn, blk.attn.sknet, blk.mlp
         s = sv["blocks"][bi]

@@ -724,6 +724,23 @@ typedef struct {            /* the per-stream conv scratch of dpmn_conv_desc (sp
   unsigned* arrive_cnt;
   int arrive_cnt_len;
 } dpmn_cmm_scratch;
+/* The Swin-block part of one PGRM backward as ONE call (csrc/pgrm_backward.hip): the two-block loop of
+ * dpmn_amd/train/pgrm_train.py::backward -- SwinTransformerBlock.forward reversed (pgrm.py:315-331) -- on the activations
+ * dpmn_pgrm_forward_train_f32 saved.  grads[2]: the gradient sinks, laid out as dpmn_pgrm_block (every pointer is WRITTEN: += of the
+ * parameter gradient); wt[2]: the transposed (in, out) copies of the seven Linear / pointwise weights the data gradients multiply by;
+ * table_numel[g]: elements of relative_position_bias_table_g; dtkv: in dL/d(tokens behind block 1), out dL/d(tokens in front of
+ * block 0); dtq: zero-filled, out dL/d(query tokens); dcat_zero[2]: two zero-filled (B L, C) buffers; zero_bias: mlp_hidden zeros.
+ * scratch >= dpmn_pgrm_blocks_backward_scratch_bytes and must stay untouched until the caller's dpmn_reduce_defer_flush (it holds
+ * partial rows of queued ordered reductions); arena / arena_used: the slice allocator of those reductions (*arena_used advances; a
+ * request that does not fit flushes the queue and starts the arena over).  Requires dpmn_pgrm_forward_train_supported(w, B). */
+typedef struct {
+  const float *fc2_t, *pw_t, *fc1_t, *head_t, *proj_t, *q_t, *kv_t;
+} dpmn_pgrm_block_t;
+size_t dpmn_pgrm_blocks_backward_scratch_bytes(const dpmn_pgrm_weights* w, int B, const int* table_numel);
+int dpmn_pgrm_blocks_backward_f32(const dpmn_pgrm_weights* w, const dpmn_pgrm_block* grads, const dpmn_pgrm_block_t* wt,
+                                  const dpmn_pgrm_saved* sv, const dpmn_pgrm_drop* drop, const int* table_numel, float* dtkv, float* dtq,
+                                  float* const* dcat_zero, const float* zero_bias, void* scratch, size_t scratch_bytes, void* arena,
+                                  size_t arena_bytes, size_t* arena_used, int B, dpmn_stream_t stream);
 /* see dpmn_pgrm_saved above; scratch: the per-stream conv scratch (may be NULL: no split-K) */
 int dpmn_pgrm_forward_train_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_channels, const float* x_kv,
                                 const float* const* residuals, int n_residuals, const float* tail0_packed, const float* tail1_packed,

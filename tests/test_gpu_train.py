@@ -300,6 +300,55 @@ def test_pgrm_native_training_forward_equals_per_op_forward(dev, rates, mode, mo
                                                         _abi.dptr(x_kv), _abi.dptr(x_kv), None, C.byref(bad), None, _abi.dptr(o1), B, _abi.stream()))
 
 
+@pytest.mark.parametrize("rates", [(0.0, 0.0, 0.0), (0.1, 0.1, 0.6)])
+@pytest.mark.parametrize("mode", [True, False])
+@pytest.mark.parametrize("native_fwd", [True, False])
+def test_pgrm_native_block_backward_equals_per_op_backward(dev, rates, mode, native_fwd, monkeypatch):
+    """dpmn_pgrm_blocks_backward_f32 (the Swin-block loop of the PGRM backward as one native call) issues the kernels of the per-op
+    loop in the same order with the same arguments: every parameter gradient, dL/dx_kv and the residual gradients are bitwise
+    equal -- with and without dropout, with the mask prior and the text prior (prior_fusion), behind the native and behind the per-op
+    training forward (the saved tensors arrive as the forward's struct or are gathered from its dictionary)."""
+    from dpmn_amd.model.pgrm import PGRM
+    from dpmn_amd.train import pgrm_train
+    B, it = 4, 2
+    pd, pa, pp = rates
+    args = _pgrm_args()
+    args.update(drop_rate=[pd] * 6, attn_drop_rate=[pa] * 6, drop_path_rate=[pp] * 6)
+    m = PGRM(iter=it, mode=mode, hidden_size=3, **args)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 94)
+    m.load_state_dict(sd)
+    m = m.to(dev).train()
+    x_q = (u("xq", (B, 1, 32, 128), 0, 1) > 0.5).float().repeat(1, 3 if mode else 2, 1, 1).to(dev)
+    x_kv = u("xkv", (B, 3, 32, 128), 0, 1).to(dev)
+    res = [u("r%d" % i, (B, 3, 32, 128), 0, 1).to(dev) for i in range(it)]
+    cot = u("cot", (B, 3, 32, 128), -1, 1).to(dev)
+    monkeypatch.setattr(pgrm_train, "NATIVE_FWD", native_fwd)
+    used = []
+    orig = pgrm_train._blocks_backward_native
+    monkeypatch.setattr(pgrm_train, "_blocks_backward_native", lambda *a, **k: (used.append(1), orig(*a, **k))[1])
+    runs = {}
+    for native in (True, False):
+        monkeypatch.setattr(pgrm_train, "NATIVE_BWD", native)
+        del used[:]
+        for p in m.parameters():
+            p.grad = None
+        xk = x_kv.clone().requires_grad_(True)
+        rs = [r.clone().requires_grad_(True) for r in res]
+        torch.manual_seed(31)       # the same dropout seeds in both runs
+        out = m(x_q, xk, rs)
+        (out * cot).sum().backward()
+        torch.cuda.synchronize()
+        assert bool(used) == native
+        runs[native] = [out.detach().clone(), xk.grad.clone()] + [None if r.grad is None else r.grad.clone() for r in rs] + \
+                       [p.grad.clone() for p in m.parameters()]
+    names = ["out", "dx_kv"] + ["dres%d" % i for i in range(it)] + [n for n, _ in m.named_parameters()]
+    for n, a, b in zip(names, runs[True], runs[False]):
+        assert (a is None) == (b is None), n
+        if a is not None:
+            assert torch.equal(a, b), n
+
+
 @pytest.mark.parametrize("cnum", [8, 16])
 def test_cmm_train_forward_backward_vs_oracle_autograd(dev, cnum):
     from dpmn_amd.model.cmm import ComplementationModulationModule
