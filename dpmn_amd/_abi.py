@@ -335,6 +335,14 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def stream_of(device):
+    """hipStream_t of torch's current stream on `device`, as an integer (workspace-cache keys); same raw query as stream()."""
+    if _raw_stream is not None:
+        idx = getattr(device, "index", None)
+        return _raw_stream(_get_device() if idx is None else idx)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
 # ------------------------------------------------------------------ in-pipeline kernel profiler (dpmn_profile_*)
 class ProfileRow(C.Structure):
     _fields_ = [("tag", C.c_int), ("launches", C.c_int), ("total_ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]

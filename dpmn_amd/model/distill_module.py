@@ -7,6 +7,7 @@ torch.autograd.Function.  Gradients go straight into the trainer's flat gradient
 import ctypes as C
 
 import torch
+from .._abi import stream_of as _abi_stream_of
 import torch.nn as nn
 
 from .. import _abi
@@ -17,7 +18,7 @@ _WS = {}
 
 def _workspace(dev, B, H, W):
     """one scratch per (device, stream, shape): statistics / loss rows, the raw-output gradient, the weight-gradient rows"""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B, H, W)
+    key = (dev.index, _abi_stream_of(dev), B, H, W)
     ws = _WS.get(key)
     if ws is None:
         ws = _WS[key] = torch.empty(lib.dpmn_distill_workspace_bytes(B, H, W) // 4 + 64, device=dev)

@@ -9,6 +9,7 @@ import ctypes as C
 import math
 
 import torch
+from .._abi import stream_of as _abi_stream_of
 import torch.nn as nn
 
 from .. import _abi, ops
@@ -280,7 +281,7 @@ class PGRM(nn.Module):
         res = [r.contiguous().float() for r in residual_list]
         w = self._weights()
         need = _abi.lib.dpmn_pgrm_workspace_bytes(C.byref(w), B)
-        sid = torch.cuda.current_stream(x_kv.device).cuda_stream
+        sid = _abi_stream_of(x_kv.device)
         ws = self._wss.get(sid)
         if ws is None or ws.numel() < need or ws.device != x_kv.device:
             ws = self._wss[sid] = torch.empty(need, dtype=torch.uint8, device=x_kv.device)

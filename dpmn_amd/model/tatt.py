@@ -9,6 +9,7 @@ BatchNorm fold -- it is evaluated when the weights are packed and reused until t
 import math
 
 import torch
+from .._abi import stream_of as _abi_stream_of
 import torch.nn as nn
 
 from .. import ops
@@ -174,7 +175,7 @@ class TSRN_TL_TRANS(_PSNBase):
             pw = torch.empty(B, L, S, device=b1.device) if self.need_pr_weights else None
             if not hasattr(self, "_interp_ws"):
                 self._interp_ws = {}
-            key = (B, L, S, torch.cuda.current_stream(b1.device).cuda_stream)
+            key = (B, L, S, _abi_stream_of(b1.device))
             if key not in self._interp_ws:
                 self._interp_ws[key] = torch.empty(lib.dpmn_tatt_interpreter_workspace_bytes(B, L, S) // 4, device=b1.device)
             ws = self._interp_ws[key]

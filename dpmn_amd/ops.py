@@ -5,6 +5,7 @@ drivers.  Every wrapper allocates its output with torch (device memory plumbing 
 enqueues on the current HIP stream.
 """
 import torch
+from ._abi import stream_of as _abi_stream_of
 
 from . import _abi
 from ._abi import dptr, lib, check, stream
@@ -275,7 +276,7 @@ _SPLITK_WS = {}
 def splitk_workspace(device, floats=24 << 20):
     """One 96 MB scratch per (device, stream) for split-K partial sums (stream-ordered reuse: every conv consumes it before
     the next launch on the same stream; the two refinement branches run on two streams, interfaces/super_resolution.py)."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _abi_stream_of(device))
     if key not in _SPLITK_WS:
         _SPLITK_WS[key] = torch.empty(floats, device=device)
     return _SPLITK_WS[key]
@@ -294,7 +295,7 @@ def _attach_workspace(d, device):
     if not STREAM_K:
         d.arrive_cnt, d.arrive_cnt_len = None, 0
         return
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _abi_stream_of(device))
     if key not in _ARRIVE_CNT:
         _ARRIVE_CNT[key] = torch.zeros(ARRIVE_CNT_LEN, dtype=torch.int32, device=device)
     d.arrive_cnt, d.arrive_cnt_len = _ARRIVE_CNT[key].data_ptr(), ARRIVE_CNT_LEN
@@ -306,7 +307,7 @@ def cmm_forward(weights, keep, x1, x2, c_img, workspaces):
     import ctypes as _C
     B, _, H, W = x1.shape
     x1, x2 = x1.contiguous().float(), x2.contiguous().float()
-    key = (B, H, W, torch.cuda.current_stream(x1.device).cuda_stream)
+    key = (B, H, W, _abi_stream_of(x1.device))
     if key not in workspaces:
         workspaces[key] = torch.empty(lib.dpmn_cmm_workspace_bytes(_C.byref(weights), B) // 4, device=x1.device)
     ws = workspaces[key]
@@ -323,7 +324,7 @@ def psn_trunk(weights, keep, b1, tp, in_planes, workspaces):
     tp: TATT's NHWC text-prior map or None; returns the NCHW image (B, in_planes, 2H, 2W)."""
     import ctypes as _C
     B, H, W, _ = b1.shape
-    key = (B, H, W, torch.cuda.current_stream(b1.device).cuda_stream)
+    key = (B, H, W, _abi_stream_of(b1.device))
     if key not in workspaces:
         workspaces[key] = torch.empty(lib.dpmn_psn_trunk_workspace_bytes(_C.byref(weights), B, H, W) // 4, device=b1.device)
     ws = workspaces[key]

@@ -11,6 +11,7 @@ import ctypes as C
 import os
 
 import torch
+from .._abi import stream_of as _abi_stream_of
 
 from .. import ops
 from .._abi import dptr, lib, check, stream
@@ -44,7 +45,7 @@ def stats_buffer(cout, device):
     """(32, 2, cout) zeroed fp64 BatchNorm-statistics slots for ONE convolution (order-independent sums: conv.hip STAT_SLOTS).  A single persistent buffer per device: the conv that
     fills it and the _bn_finalize that reads it are stream-ordered, and the finalize kernel zeroes what it read, so the next
     convolution gets the same memory back clean (33 memsets per step otherwise)."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _abi_stream_of(device))
     buf = _STATS.get(key)
     if buf is None or buf.numel() < 128 * cout:
         buf = _STATS[key] = torch.zeros(128 * max(cout, 1024), device=device)

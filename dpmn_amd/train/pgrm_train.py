@@ -14,6 +14,7 @@ import ctypes as C
 import os
 
 import torch
+from .._abi import stream_of as _abi_stream_of
 
 from .. import _abi, ops
 from .._abi import dptr, lib, check, stream
@@ -88,7 +89,7 @@ def _tn_workspace(device):
     """Arena of one PGRM backward (per device and stream): every partial-row buffer of its atomics-free reductions -- the split
     partials of the 14 Linear weight gradients (~120 MB at B = 48), the pointwise-conv weight gradient's 32 splits (19 MB per
     block), column / row sums, LayerNorm parameter gradients -- lives here until the backward's ONE reduce launch."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.type, device.index, _abi_stream_of(device))
     if key not in _TN_WS:
         _TN_WS[key] = torch.empty(80 << 20, device=device)      # 320 MB
     return _TN_WS[key]
@@ -231,7 +232,7 @@ def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
         check(lib.dpmn_conv2d_wgrad_excl_slots(C.byref(d), C.cast(C.pointer(slots), C.c_void_p)))
     if slots.value == 0:      # (the library advises the slotted-atomic path for tiny gradients over many pixels)
         nslots = 32 if d.Cout * kp <= 12288 else 1     # small gradients: spread the pixel splits' atomics over 32 copies
-        key = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream, d.Cout, kp, nslots)
+        key = (dy.device, _abi_stream_of(dy.device), d.Cout, kp, nslots)
         ws = _WGRAD_WS.get(key)
         if ws is None:
             ws = _WGRAD_WS[key] = torch.zeros(nslots, d.Cout, kp, device=dy.device)
@@ -246,7 +247,7 @@ def conv_wgrad_into(d, dy, dweight, layout="conv", phase=None):
                                  slots.value)
         check(lib.dpmn_conv2d_wgrad_excl_f32(C.byref(d), dptr(dy), dptr(ws), slots.value, stream()))
         return
-    skey = (dy.device, torch.cuda.current_stream(dy.device).cuda_stream)
+    skey = (dy.device, _abi_stream_of(dy.device))
     ws = _WGRAD_WS.get(skey)
     if ws is None or ws.numel() < n:       # one workspace per (device, stream): wgrad -> unpack pairs are stream-ordered
         ws = _WGRAD_WS[skey] = torch.empty(max(n, 16 << 20), device=dy.device)
