@@ -169,6 +169,10 @@ class Unit:
                 side.wait_event(ready)
                 wgrad()
             dr.record_stream(side)       # dr dies with this call: its memory must not be reused before the side stream read it
+            for t in self.inputs:        # (the saved activations die with the graph at the end of the backward, which no longer waits
+                t.r.record_stream(side)  #  for the side stream: LAZY_WGRAD_JOIN)
+                if t.scale is not None:
+                    t.scale.record_stream(side)
 
     def bwd_inputs(self, dr, cout):
         # ---- data gradients, one launch per input segment, then activation backward through the producer's affine
@@ -290,6 +294,7 @@ def backward_pair(u1, u2, gr, side=None):
 
 
 WGRAD_STREAM = os.environ.get("DPMN_WGRAD_STREAM", "1") != "0"
+LAZY_WGRAD_JOIN = os.environ.get("DPMN_LAZY_WGRAD_JOIN", "1") != "0"      # 0: the backward's stream waits for the weight-gradient stream at its end
 FUSE_BN_REDUCE = os.environ.get("DPMN_BN_BWD_FUSED", "1") != "0"      # 0: dpmn_bn_bwd_f32 with its own reduction pass
 _SIDE = {}
 
@@ -429,7 +434,19 @@ def backward(m, graph, dout, need_dx=(True, True)):
     for leaf, need in zip(graph["leaves"], need_dx):
         dxs.append(ops.nhwc_to_nchw(leaf.G)[:, :3].contiguous() if need else None)
     if side is not None:
-        torch.cuda.current_stream(dout.device).wait_stream(side)      # every weight gradient is in place before the bucket is signalled
+        cur = torch.cuda.current_stream(dout.device)
+        if direct and LAZY_WGRAD_JOIN and not torch.cuda.is_current_stream_capturing():
+            # the data gradients go on to the PGRM backwards on THIS stream; the weight gradients (and their 0.4 ms unpack launch at the
+            # end of the side stream) are only needed by the optimizer / the gradient exchange: the bucket gets an event that covers both
+            # streams (FlatBucket._mark_ready) instead of this stream waiting here
+            here = torch.cuda.Event()
+            here.record(cur)
+            side.wait_event(here)
+            done = torch.cuda.Event()
+            done.record(side)
+            m._dpmn_grads_done = done
+        else:
+            cur.wait_stream(side)      # every weight gradient is in place before the gradients are handed to autograd / the bucket
     return dxs, gr, direct
 
 

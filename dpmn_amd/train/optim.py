@@ -146,7 +146,12 @@ class FlatBucket:
         self.ready = True
         # the backward of the two refinement branches runs on two HIP streams (interfaces/super_resolution.py): the group's
         # collective is enqueued behind the stream of its LAST reporter only, so every member leaves an event for it to wait on
-        if self.group is not None and (self.group.multi or self.group.early_cb is not None) and self.flat_g.is_cuda:
+        done = self.module.__dict__.pop("_dpmn_grads_done", None)
+        if done is not None:
+            # the module's backward left part of its gradients on a side stream (train/cmm_train.py: the conv weight gradients and their
+            # unpack) and did NOT make the calling stream wait for it: whoever consumes the bucket waits for this event instead
+            self.ready_event = done
+        elif self.group is not None and (self.group.multi or self.group.early_cb is not None) and self.flat_g.is_cuda:
             self.ready_event = torch.cuda.Event()
             self.ready_event.record()
         if self.group is not None:
@@ -281,6 +286,12 @@ class CommGroup:
     def step(self, step, lr, beta1, beta2=0.999, eps=1e-8, max_norm=0.25, step_dev=None):
         self.wait_grads()
         self.wait_params()
+        if self.flat_g.is_cuda:      # single process: events that launch() (multi only) did not consume -- a member's side-stream gradients
+            for b in self.buckets:
+                ev = getattr(b, "ready_event", None)
+                if ev is not None:
+                    torch.cuda.current_stream(self.flat_g.device).wait_event(ev)
+                    b.ready_event = None
         owned = [self._owned(i) for i in range(len(self.buckets))]
         if self.zero1:
             self.normsq.zero_()
