@@ -435,7 +435,7 @@ def backward(m, graph, dout, need_dx=(True, True)):
         dxs.append(ops.nhwc_to_nchw(leaf.G)[:, :3].contiguous() if need else None)
     if side is not None:
         cur = torch.cuda.current_stream(dout.device)
-        if direct and LAZY_WGRAD_JOIN and not torch.cuda.is_current_stream_capturing():
+        if direct and LAZY_WGRAD_JOIN and getattr(m._dpmn_bucket, "lazy_join", False) and not torch.cuda.is_current_stream_capturing():
             # the data gradients go on to the PGRM backwards on THIS stream; the weight gradients (and their 0.4 ms unpack launch at the
             # end of the side stream) are only needed by the optimizer / the gradient exchange: the bucket gets an event that covers both
             # streams (FlatBucket._mark_ready) instead of this stream waiting here

@@ -165,6 +165,14 @@ class FlatBucket:
     def wait(self):
         if self.group is not None:
             self.group.wait_grads()
+        self._wait_ready_event()
+
+    def _wait_ready_event(self):
+        """Order the current stream behind gradients the module's backward left on a side stream (_mark_ready)."""
+        ev = getattr(self, "ready_event", None)
+        if ev is not None and self.flat_g.is_cuda:
+            torch.cuda.current_stream(self.flat_g.device).wait_event(ev)
+            self.ready_event = None
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -177,6 +185,7 @@ class FlatBucket:
         if self.m is None:
             self.m = torch.zeros_like(self.flat_p)
             self.v = torch.zeros_like(self.flat_p)
+        self._wait_ready_event()
         _sumsq(self.flat_g, self.normsq, self.part)
         _adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.normsq, max_norm, lr, beta1, beta2, eps, step, step_dev)
 
@@ -437,8 +446,13 @@ class Trainer:
 
     def arm_early_step(self):
         """The caller promises that Trainer.step() follows the backward pass it is about to start (TextSR.train_step): groups may
-        then be stepped as soon as their gradients are complete.  Without this call a backward never touches the parameters."""
+        then be stepped as soon as their gradients are complete (DPMN_EARLY_OPT), and a module's backward may return while its leaf
+        gradients are still being written on a side stream (the bucket's ready_event covers them; Trainer.step / the gradient
+        exchange wait for it).  Without this call a backward never touches the parameters and every gradient is complete in the
+        order of the stream the backward ran on."""
         self._armed = self.early
+        for b in self.buckets:
+            b.lazy_join = True      # a backward may leave leaf gradients on a side stream behind bucket.ready_event (train/cmm_train.py)
 
     def _early_step(self, g):
         if not getattr(self, "_armed", False) or self.t_dev is not None or torch.cuda.is_current_stream_capturing():
@@ -466,6 +480,8 @@ class Trainer:
                 continue
             g.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
         self._armed = False
+        for b in self.buckets:
+            b.lazy_join = False
         if early:
             torch.cuda.current_stream(self.flat_p.device).wait_stream(self.opt_stream)
         packing.ACTIVE = None       # the packs are stale from here on
