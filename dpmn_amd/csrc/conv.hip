@@ -848,18 +848,21 @@ __global__ __launch_bounds__(256, 3) void k_conv_igemm_o3(ConvArgs a) {
 
 // sum the split-K partials and run the epilogue.  Block = 64 channel-quads x 4 row lanes, 64 rows per block, so the
 // BatchNorm statistics are reduced over 64 rows in registers / LDS before one (slotted) atomic per channel.
-__global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows) {
-  __shared__ float red[4][64][8];
+__global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows, int cq_lanes) {
+  // cq_lanes (64 / 32 / 16: the channel quads of a row, capped at 64) x 256 / cq_lanes row lanes: with the fixed 64 x 4 mapping half
+  // of every block sat idle on the 128-channel layers (32 quads), three quarters on 64 channels
+  __shared__ float red[256][8];
   const PhaseSel ph = conv_select_phase(a, blockIdx.z * a.ksplit);
   const int M = a.B * a.Hp * a.Wp;
   const int n4 = a.npad / 4;
-  const int cq = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int cl = threadIdx.x & (cq_lanes - 1), rl = threadIdx.x / cq_lanes, RL = 256 / cq_lanes;
+  const int cq = blockIdx.x * cq_lanes + cl;
   const int n = cq * 4;
   const int m_lo = blockIdx.y * rows;
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   const size_t zs = (size_t)M * a.npad;
   if (cq < n4) {
-    for (int m = m_lo + rl; m < m_lo + rows && m < M; m += 4) {
+    for (int m = m_lo + rl; m < m_lo + rows && m < M; m += RL) {
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       const float* pp = ph.partial + (size_t)m * a.npad + n;
       int z = 0;
@@ -880,16 +883,17 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows
   }
   if (a.stats) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { red[rl][threadIdx.x & 63][r] = ssum[r]; red[rl][threadIdx.x & 63][4 + r] = ssq[r]; }
+    for (int r = 0; r < 4; ++r) { red[threadIdx.x][r] = ssum[r]; red[threadIdx.x][4 + r] = ssq[r]; }
     __syncthreads();
     if (rl == 0 && cq < n4) {
       double* st = reinterpret_cast<double*>(a.stats) + (size_t)(blockIdx.y % STAT_SLOTS) * 2 * a.Cout;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (n + r < a.Cout) {
-          const int c = threadIdx.x & 63;
-          atomicAdd(st + n + r, (double)(red[0][c][r] + red[1][c][r] + red[2][c][r] + red[3][c][r]));
-          atomicAdd(st + a.Cout + n + r, (double)(red[0][c][4 + r] + red[1][c][4 + r] + red[2][c][4 + r] + red[3][c][4 + r]));
+          float s_ = 0.f, q_ = 0.f;
+          for (int l = 0; l < RL; ++l) { s_ += red[l * cq_lanes + cl][r]; q_ += red[l * cq_lanes + cl][4 + r]; }      // fixed order
+          atomicAdd(st + n + r, (double)s_);
+          atomicAdd(st + a.Cout + n + r, (double)q_);
         }
     }
   }
@@ -1972,9 +1976,12 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st, unsigned
   if (S > 1) {
     ProfScope prof(PT_CONV_SPLITK_REDUCE, st, 0.0, 4.0 * (double)(S + 1) * nph * M * a.npad);
     // rows per block: 64 amortises the BatchNorm-statistics atomics on big outputs; small outputs need the parallelism
-    const int cb = cdiv(a.npad / 4, 64);
-    const int rows = cb * cdiv(M, 64) >= 1024 ? 64 : (cb * cdiv(M, 16) >= 1024 ? 16 : 4);
-    hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(cb, cdiv(M, rows), nph), dim3(256), 0, st, a, rows);
+    const int n4 = a.npad / 4;
+    const int cql = n4 >= 64 ? 64 : (n4 >= 32 ? 32 : 16);
+    const int cb = cdiv(n4, cql);
+    int rows = cb * cdiv(M, 64) >= 1024 ? 64 : (cb * cdiv(M, 16) >= 1024 ? 16 : 4);
+    if (rows < 256 / cql) rows = 256 / cql;      // at least one row per row lane
+    hipLaunchKernelGGL(k_conv_splitk_reduce, dim3(cb, cdiv(M, rows), nph), dim3(256), 0, st, a, rows, cql);
     DPMN_CHECK_LAUNCH();
   }
   return DPMN_OK;
