@@ -173,6 +173,7 @@ SIGNATURES = {
     "dpmn_colsum_det_f32": (_i, [fp, fp, C.c_long, _i, fp, _sz, fp]),
     "dpmn_layernorm_bwd_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp]),
     "dpmn_layernorm_bwd_det_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp, _sz, fp]),
+    "dpmn_layernorm_bwd_det_drop_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp, _sz, fp, _f, _u64, _f, _u64, _l, fp]),
     "dpmn_layernorm_f32": (_i, [fp, fp, fp, _f, fp, C.c_long, _i, fp]),
     "dpmn_act_bwd_f32": (_i, [fp, fp, fp, _i, _f, C.c_long, fp]),
     "dpmn_act_fwd_f32": (_i, [fp, fp, _i, _f, C.c_long, fp]),

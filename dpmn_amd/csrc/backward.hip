@@ -471,11 +471,22 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
 // LayerNorm backward, vector form: 8 threads per row (C/32 float4 each, the row reductions are 3 xor-shuffles), 32 rows per
 // block pass, R rows per thread group in flight; every load is unconditional (rows past M are clamped and masked), so the
 // loads of a pass are issued back to back instead of one `s_waitcnt vmcnt(0)` per predicated load.
+struct LnDrop {       // optional masked second output of the LayerNorm backward (k_ln_bwd_v4)
+  float* out2 = nullptr;
+  float p_elem = 0.f;
+  unsigned long long seed_elem = 0;
+  float p_row = 0.f;
+  unsigned long long seed_row = 0;
+  long row_len = 1;
+};
 template <int C>
 __global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, const float* __restrict__ dy,
                                                     const float* __restrict__ gamma, float eps, float* __restrict__ dx,
                                                     int accumulate_dx, float* __restrict__ dgamma, float* __restrict__ dbeta, long M,
-                                                 float* __restrict__ part = nullptr) {
+                                                 float* __restrict__ part = nullptr, LnDrop dr = LnDrop{}) {
+  // dr.out2 != null: a second output out2 = dx_final * m_elem * m_row, the masks of dpmn_dropout_f32(dx, n = M C, row_len, p_elem,
+  // seed_elem, p_row, seed_row) -- the masked copy of the gradient that the NEXT Linear's backward wants (Mlp.fc2 behind Dropout +
+  // DropPath, SKConv behind DropPath: pgrm.py:329-330), written here instead of by a dropout launch re-reading dx
   constexpr int V = C / 32;                 // float4 per thread
   __shared__ float red_g[32][C + 4], red_b[32][C + 4];
   const int sub = threadIdx.x >> 3, t = threadIdx.x & 7;      // 32 row groups per block, 8 threads per row
@@ -563,6 +574,22 @@ __global__ __launch_bounds__(256) void k_ln_bwd_v4(const float* __restrict__ x, 
         gq.z = q[u] * (dv[u][i].z - m1 - xv[u][i].z * m2); gq.w = q[u] * (dv[u][i].w - m1 - xv[u][i].w * m2);
         if (accumulate_dx) { gq.x += dxo[u][i].x; gq.y += dxo[u][i].y; gq.z += dxo[u][i].z; gq.w += dxo[u][i].w; }
         *reinterpret_cast<float4*>(dx + row * C + (t + 8 * i) * 4) = gq;
+        if (dr.out2) {
+          const unsigned long long idx = (unsigned long long)(row * C + (t + 8 * i) * 4);
+          float o[4] = {gq.x, gq.y, gq.z, gq.w};
+          if (dr.p_elem > 0.f) {
+            const float ik = 1.0f / (1.0f - dr.p_elem);
+            const unsigned long long z0 = drop_z0(dr.seed_elem, idx);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] *= drop_scale_z(z0 + (unsigned long long)c * DROP_PHI, dr.p_elem, ik);
+          }
+          if (dr.p_row > 0.f) {
+            const float mr = drop_scale(dr.seed_row, idx / (unsigned long long)dr.row_len, dr.p_row, 1.0f / (1.0f - dr.p_row));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] *= mr;
+          }
+          *reinterpret_cast<float4*>(dr.out2 + row * C + (t + 8 * i) * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
       }
     }
   }
@@ -844,8 +871,11 @@ int dpmn_colsum_det_f32(const float* dy, float* db, long M, int N, float* ws, si
 }
 
 static int layernorm_bwd_impl(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
-                              float* dgamma, float* dbeta, long M, int C, float* part, size_t part_bytes, dpmn_stream_t stream) {
+                              float* dgamma, float* dbeta, long M, int C, float* part, size_t part_bytes, dpmn_stream_t stream,
+                              LnDrop dr = LnDrop{}) {
   DPMN_REQUIRE(x && dy && gamma && dx && dgamma && dbeta && M > 0, "layernorm_bwd: bad arguments");
+  DPMN_REQUIRE(!dr.out2 || ((C == 96 || C == 192) && dr.row_len > 0 && dr.p_elem >= 0.f && dr.p_elem < 1.f && dr.p_row >= 0.f && dr.p_row < 1.f),
+               "layernorm_bwd: the masked second output needs C = 96 / 192 and drop rates in [0, 1)");
   DPMN_REQUIRE(!part || part_bytes >= (size_t)512 * 2 * C * sizeof(float), "layernorm_bwd_det: workspace of 512 * 2 C floats");
   // every block ends with 2*C same-address atomics (dgamma, dbeta), which serialise: few, fat blocks (4 rows in flight per
   // 32-thread group).  In-pipeline sweep at M = 49152: 256 blocks 46.6 us, 512: 36.9, 1024: 41.9, 2048: 59.9
@@ -854,13 +884,13 @@ static int layernorm_bwd_impl(const float* x, const float* dy, const float* gamm
   unsigned nblk = blocks;
   static const int v4 = getenv("DPMN_LNB_V4") ? atoi(getenv("DPMN_LNB_V4")) : 1;
   ProfScope prof(PT_LN_BWD, as_stream(stream), 0.0, 4.0 * (accumulate_dx ? 4 : 3) * (double)M * C);
-  if ((C == 96 || C == 192) && v4) {
+  if ((C == 96 || C == 192) && (v4 || dr.out2)) {
     // in-pipeline sweep of the vector kernel at M = 49152: 256 blocks 20.2 us, 384: 21.2, 512: 24.3, 768: 27.6, 1024: 33.3
     // (the scalar kernel it replaces: 36.8 us) -- one block per CU, the same-address dgamma / dbeta atomics set the slope
     static const long cap4 = getenv("DPMN_LNB_BLOCKS") ? atol(getenv("DPMN_LNB_BLOCKS")) : 256;
     const unsigned b4 = (unsigned)(M / 32 < cap4 ? (M + 31) / 32 : cap4);
-    if (C == 96) hipLaunchKernelGGL((k_ln_bwd_v4<96>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
-    else hipLaunchKernelGGL((k_ln_bwd_v4<192>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
+    if (C == 96) hipLaunchKernelGGL((k_ln_bwd_v4<96>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part, dr);
+    else hipLaunchKernelGGL((k_ln_bwd_v4<192>), dim3(b4), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part, dr);
     nblk = b4;
   } else if (C == 96)
     hipLaunchKernelGGL((k_ln_bwd<96>), dim3(blocks), dim3(256), 0, as_stream(stream), x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, part);
@@ -889,6 +919,16 @@ int dpmn_layernorm_bwd_det_f32(const float* x, const float* dy, const float* gam
                                float* dgamma, float* dbeta, long M, int C, float* ws, size_t ws_bytes, dpmn_stream_t stream) {
   DPMN_REQUIRE(ws, "layernorm_bwd_det: null workspace");
   return layernorm_bwd_impl(x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, C, ws, ws_bytes, stream);
+}
+
+int dpmn_layernorm_bwd_det_drop_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
+                                    float* dgamma, float* dbeta, long M, int C, float* ws, size_t ws_bytes, float* masked_out,
+                                    float p_elem, unsigned long long seed_elem, float p_row, unsigned long long seed_row, long row_len,
+                                    dpmn_stream_t stream) {
+  DPMN_REQUIRE(ws && masked_out, "layernorm_bwd_det_drop: null pointer");
+  LnDrop dr;
+  dr.out2 = masked_out; dr.p_elem = p_elem; dr.seed_elem = seed_elem; dr.p_row = p_row; dr.seed_row = seed_row; dr.row_len = row_len;
+  return layernorm_bwd_impl(x, dy, gamma, eps, dx, accumulate_dx, dgamma, dbeta, M, C, ws, ws_bytes, stream, dr);
 }
 
 int dpmn_act_bwd_f32(const float* dy, const float* pre, float* dpre, int act, float slope, long n, dpmn_stream_t stream) {

@@ -10,6 +10,7 @@
 //             must survive until the caller's ordered-reduction flush (dpmn_reduce_defer_flush): dpmn_pgrm_blocks_backward_scratch_bytes
 //   arena     the slice allocator of the deferred reductions (train/pgrm_train.py _ws): *arena_used is advanced; when a request does
 //             not fit, the queued reductions are flushed (dpmn_reduce_defer_flush(0)) and the arena starts over, as the host code does
+#include <cstdlib>
 #include "common.h"
 #include <math.h>
 
@@ -104,6 +105,15 @@ int dpmn_pgrm_blocks_backward_f32(const dpmn_pgrm_weights* w, const dpmn_pgrm_bl
     RUN(take((size_t)512 * 2 * C * 4));                                                                             \
     RUN(dpmn_layernorm_bwd_det_f32((x), (dy), (gamma), 1e-5f, (dx), 1, (dgamma), (dbeta), M, C, ws_ptr, ws_n, stream)); \
   } while (0)
+  // the same with the masked copy of the finished gradient as a second output (instead of a dropout launch re-reading dx)
+#define LN_BWD_DROP(x, dy, gamma, dx, dgamma, dbeta, out2, pe, se, pr, sr)                                            \
+  do {                                                                                                             \
+    RUN(take((size_t)512 * 2 * C * 4));                                                                             \
+    RUN(dpmn_layernorm_bwd_det_drop_f32((x), (dy), (gamma), 1e-5f, (dx), 1, (dgamma), (dbeta), M, C, ws_ptr, ws_n, (out2), (pe), (se), (pr), \
+                                        (sr), (long)L * C, stream));                                                 \
+  } while (0)
+  static const int fuse_masks = getenv("DPMN_BWD_FUSE_MASKS") ? atoi(getenv("DPMN_BWD_FUSE_MASKS")) : 1;
+  bool dbr_ready = false;      // block 0's masked fc2 gradient was written by block 1's last LayerNorm backward
   float* dx2 = dtkv;
   for (int bi = 1; bi >= 0; --bi) {
     const dpmn_pgrm_block& p = w->blocks[bi];
@@ -117,7 +127,7 @@ int dpmn_pgrm_blocks_backward_f32(const dpmn_pgrm_weights* w, const dpmn_pgrm_bl
     // fc2 (+ residual x1); with dropout the branch gradient is dx2 under the forward's masks
     const float* dbr = dx2;
     if (pd > 0.f || dpb > 0.f) {
-      RUN(dpmn_dropout_f32(dx2, nullptr, s.dbr, (long)M * C, (long)L * C, pd, sb[3], dpb, sb[4], stream));
+      if (!dbr_ready) RUN(dpmn_dropout_f32(dx2, nullptr, s.dbr, (long)M * C, (long)L * C, pd, sb[3], dpb, sb[4], stream));
       dbr = s.dbr;
     }
     LINEAR_BWD(dbr, b.z, t.fc2_t, sink(g.fc2_w), sink(g.fc2_b), C, Ch, s.dz);
@@ -133,12 +143,17 @@ int dpmn_pgrm_blocks_backward_f32(const dpmn_pgrm_weights* w, const dpmn_pgrm_bl
                                          ws_n, stream));
     LINEAR_BWD(s.dypre, b.n2, t.fc1_t, sink(g.fc1_w), sink(g.fc1_b), Ch, C, s.dn2);
     float* dx1 = dx2;       // in place: every reader of dx2 is already queued on this stream
-    LN_BWD(b.x1, s.dn2, p.norm2_w, dx1, sink(g.norm2_w), sink(g.norm2_b));
-    // x1 = tkv_in + DropPath(feats + V Wh^T + bh)
+    // x1 = tkv_in + DropPath(feats + V Wh^T + bh): the DropPath-masked gradient rides out of the LayerNorm2 backward
     const float* dat = dx1;
-    if (dpb > 0.f) {
-      RUN(dpmn_dropout_f32(dx1, nullptr, s.dat, (long)M * C, (long)L * C, 0.f, 0ull, dpb, sb[1], stream));
+    if (dpb > 0.f && fuse_masks) {
+      LN_BWD_DROP(b.x1, s.dn2, p.norm2_w, dx1, sink(g.norm2_w), sink(g.norm2_b), s.dat, 0.f, 0ull, dpb, sb[1]);
       dat = s.dat;
+    } else {
+      LN_BWD(b.x1, s.dn2, p.norm2_w, dx1, sink(g.norm2_w), sink(g.norm2_b));
+      if (dpb > 0.f) {
+        RUN(dpmn_dropout_f32(dx1, nullptr, s.dat, (long)M * C, (long)L * C, 0.f, 0ull, dpb, sb[1], stream));
+        dat = s.dat;
+      }
     }
     LINEAR_BWD(dat, b.V, t.head_t, sink(g.sk_head_w), sink(g.sk_head_b), C, cg, s.dV);
     float* dcat = dcat_zero[bi];
@@ -168,9 +183,18 @@ int dpmn_pgrm_blocks_backward_f32(const dpmn_pgrm_weights* w, const dpmn_pgrm_bl
     LN_BWD(sv->tq, s.dnrm, p.norm1_q_w, dtq, sink(g.norm1_q_w), sink(g.norm1_q_b));
     RUN(dpmn_layernorm_f32(tkv_in, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, s.nrm, M, C, stream));
     LINEAR_BWD(s.dkv, s.nrm, t.kv_t, sink(g.kv_w), sink(g.kv_b), 2 * C, C, s.dnrm);
-    LN_BWD(tkv_in, s.dnrm, p.norm1_kv_w, dx1, sink(g.norm1_kv_w), sink(g.norm1_kv_b));
+    // block 1's last step finishes dL/d(tokens behind block 0) = block 0's dx2: its Dropout / DropPath-masked copy (block 0's masks)
+    // comes out of the same kernel
+    const float dpb0 = drop ? drop->dp[0] : 0.f;
+    if (bi == 1 && fuse_masks && (pd > 0.f || dpb0 > 0.f)) {
+      LN_BWD_DROP(tkv_in, s.dnrm, p.norm1_kv_w, dx1, sink(g.norm1_kv_w), sink(g.norm1_kv_b), s.dbr, pd, sd[2 + 3], dpb0, sd[2 + 4]);
+      dbr_ready = true;
+    } else {
+      LN_BWD(tkv_in, s.dnrm, p.norm1_kv_w, dx1, sink(g.norm1_kv_w), sink(g.norm1_kv_b));
+    }
     dx2 = dx1;
   }
+#undef LN_BWD_DROP
 #undef LN_BWD
 #undef LINEAR_BWD
 #undef RUN

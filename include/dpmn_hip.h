@@ -428,6 +428,12 @@ int dpmn_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, 
 /* the same without atomics: per-block [dgamma | dbeta] partials in ws (>= 512 * 2 C floats), added in block order */
 int dpmn_layernorm_bwd_det_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
                                float* dgamma, float* dbeta, long M, int C, float* ws, size_t ws_bytes, dpmn_stream_t stream);
+/* + a second output masked_out = dx_final * Dropout mask * DropPath mask (the masks of dpmn_dropout_f32(dx, n = M C, row_len, p_elem,
+ * seed_elem, p_row, seed_row)): the masked copy the next Linear's backward consumes (pgrm.py:329-330 reversed), C = 96 / 192 */
+int dpmn_layernorm_bwd_det_drop_f32(const float* x, const float* dy, const float* gamma, float eps, float* dx, int accumulate_dx,
+                                    float* dgamma, float* dbeta, long M, int C, float* ws, size_t ws_bytes, float* masked_out,
+                                    float p_elem, unsigned long long seed_elem, float p_row, unsigned long long seed_row, long row_len,
+                                    dpmn_stream_t stream);
 int dpmn_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, long M, int C,
                        dpmn_stream_t stream);
 /* dpre = dy * act'(pre) ; y = act(x) */
