@@ -882,7 +882,10 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
                                                           const float* __restrict__ dtok, float* __restrict__ dconv,
                                                           float* __restrict__ patches, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, int B, int Hi, int Wi, float* __restrict__ lnpart,
-                                                          float p_drop, unsigned long long seed) {
+                                                          float p_drop, unsigned long long seed, float* __restrict__ wpart) {
+  // wpart != null (C = 96): the block also STORES its partial of the conv's weight and bias gradient -- row blockIdx.x of (blocks,
+  // 12 C + C): sum over the block's 64 tokens of dconv[c] * patch[k] | dconv[c] -- and writes no `patches`: the caller adds the rows
+  // in block order (dpmn_rows_reduce_f32) instead of running dW = dconv^T . patches as a separate skinny GEMM + reduce + add
   // p_drop > 0: dtok is the gradient BEHIND pos_drop (pgrm.py:550-551): the forward's mask (dpmn_dropout_f32's, regenerated from
   // the seed) is applied as it is loaded -- the same product as a dropout launch over dtok in front of this kernel
   // lnpart != null: the block STORES its [dgamma (C) | dbeta (C)] partial as row blockIdx.x (added in block order by the caller);
@@ -977,12 +980,43 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
   s1 += xshfl<1>(s1); s1 += xshfl<2>(s1);
   s2 += xshfl<1>(s2); s2 += xshfl<2>(s2);
   s1 *= (1.0f / C); s2 *= (1.0f / C);
+  float dcv[CQ];
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) dcv[i] = valid ? rstd * (dg[i] - s1 - xh[i] * s2) : 0.f;
   if (valid) {
 #pragma unroll
-    for (int i = 0; i < CQ; ++i) dconv[(size_t)token * C + part * CQ + i] = rstd * (dg[i] - s1 - xh[i] * s2);
-    if (part == 0) {
+    for (int i = 0; i < CQ; ++i) dconv[(size_t)token * C + part * CQ + i] = dcv[i];
+    if (part == 0 && !wpart) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) patches[(size_t)token * 16 + k] = k < KP ? in[k] : 0.f;
+    }
+  }
+  if constexpr (C == 96) {
+    if (wpart) {
+      __shared__ float sdc[64][C + 1];
+      __shared__ float sin_[64][KP + 1];
+      const int tl = (threadIdx.x >> 6) * 16 + (lane >> 2);      // token slot of the block
+#pragma unroll
+      for (int i = 0; i < CQ; ++i) sdc[tl][part * CQ + i] = dcv[i];
+      if (part == 0) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) sin_[tl][k] = valid ? in[k] : 0.f;
+      }
+      __syncthreads();
+      if (threadIdx.x < 2 * C) {          // thread -> (channel c, half of the 12 patch inputs)
+        const int c = threadIdx.x % C, kg = threadIdx.x / C;
+        float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bsum = 0.f;
+        for (int tk = 0; tk < 64; ++tk) {      // tokens in slot order: a fixed summation order
+          const float dv_ = sdc[tk][c];
+          bsum += dv_;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) acc[k] = fmaf(dv_, sin_[tk][kg * 6 + k], acc[k]);
+        }
+        float* row = wpart + (size_t)blockIdx.x * (KP * C + C);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) row[c * KP + kg * 6 + k] = acc[k];
+        if (kg == 0) row[KP * C + c] = bsum;
+      }
     }
   }
   __syncthreads();
@@ -1360,13 +1394,14 @@ int dpmn_pgrm_tail_elem_bwd_f32(const float* dout, const float* c1, const float*
 static int patch_embed_bwd_impl(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
                                 const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
                                 float* dgamma, float* dbeta, float* part, int B, int Hi, int Wi, int C, dpmn_stream_t stream,
-                                float p_drop = 0.f, unsigned long long seed = 0ull) {
+                                float p_drop = 0.f, unsigned long long seed = 0ull, float* wpart = nullptr) {
+  DPMN_REQUIRE(!wpart || C == 96, "patch_embed_bwd: the in-kernel weight-gradient partials exist for embed_dim 96");
   DPMN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "patch_embed_bwd: drop probability must be in [0, 1)");
   DPMN_REQUIRE(img && pe_w && pe_b && ln_w && dtok && dconv && patches && ((dgamma && dbeta) || part), "patch_embed_bwd: null pointer");
   const long tokens_n = (long)B * (Hi / 2) * (Wi / 2);
   dim3 grid((unsigned)((tokens_n + 63) / 64));
   hipStream_t st = as_stream(stream);
-#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi, part, p_drop, seed)
+#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi, part, p_drop, seed, wpart)
   if (C == 96 && pf_w) PB_LAUNCH(96, true);
   else if (C == 96) PB_LAUNCH(96, false);
   else if (C == 192 && pf_w) PB_LAUNCH(192, true);
@@ -1398,6 +1433,15 @@ int dpmn_patch_embed_bwd_det_drop_f32(const float* img, int cin, const float* pf
   DPMN_REQUIRE(ln_part, "patch_embed_bwd_det: null pointer");
   return patch_embed_bwd_impl(img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, nullptr, nullptr, ln_part, B, Hi, Wi, C, stream,
                               p_drop, seed);
+}
+
+int dpmn_patch_embed_bwd_det_wgrad_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                       const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* ln_part,
+                                       float* w_part, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
+                                       dpmn_stream_t stream) {
+  DPMN_REQUIRE(ln_part && w_part, "patch_embed_bwd_det_wgrad: null pointer");
+  return patch_embed_bwd_impl(img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, /* patches: not written */ dconv, nullptr, nullptr, ln_part, B,
+                              Hi, Wi, C, stream, p_drop, seed, w_part);
 }
 
 int dpmn_patch_scatter_f32(const float* din, float* dimg, int cimg, int B, int Hi, int Wi, dpmn_stream_t stream) {

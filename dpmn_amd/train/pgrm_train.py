@@ -538,6 +538,7 @@ def forward(m, x_q, x_kv, residuals, drop=None):
     return out, sv
 
 
+PE_WGRAD_IN_KERNEL = os.environ.get("DPMN_PE_WGRAD_IN_KERNEL", "1") != "0"      # 0: PatchEmbed weight gradient as dconv^T . patches (gemm_tn)
 NATIVE_BWD = os.environ.get("DPMN_PGRM_NATIVE_BWD", "1") != "0"      # 0: the Swin-block loop of the backward op by op from Python
 
 
@@ -783,8 +784,25 @@ def backward(m, sv, dout, need_dx_kv=True):
         fuse = which == "q" and img.shape[1] == 2
         pfw, pfb = (m.prior_fusion.weight, m.prior_fusion.bias) if fuse else (None, None)
         dconv = torch.empty(M, Cd, device=dout.device)
-        patches = torch.empty(M, 16, device=dout.device)
-        if DET_SMALL:      # LayerNorm parameter gradients as per-block partial rows, added in block order at the end of the backward
+        patches = None if (DET_SMALL and PE_WGRAD_IN_KERNEL and Cd == 96) else torch.empty(M, 16, device=dout.device)
+        pe_wg = DET_SMALL and PE_WGRAD_IN_KERNEL and Cd == 96
+        if pe_wg:
+            # as the branch below, with the conv's weight / bias gradient as per-block partial rows out of the same kernel (no `patches`
+            # tensor, no skinny dconv^T . patches GEMM with its own reduce launch and the torch add behind it): one (2 nr, 13 C) buffer
+            # and one pending sum for both token streams
+            nr = (M + 63) // 64
+            if which == "kv":
+                lnp = torch.empty(2 * nr, 2 * Cd, device=dout.device)
+                pew = torch.empty(2 * nr, 13 * Cd, device=dout.device)
+            off = 0 if which == "kv" else nr
+            check(lib.dpmn_patch_embed_bwd_det_wgrad_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
+                                                         dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv),
+                                                         lnp.data_ptr() + off * 2 * Cd * 4, pew.data_ptr() + off * 13 * Cd * 4, B, img.shape[2],
+                                                         img.shape[3], Cd, float(pd), int(sd[1] if which == "kv" else sd[0]), stream()))
+            if which == "q":
+                defer_rows(lnp, gr[pe.norm.weight], gr[pe.norm.bias], Cd, Cd, 2 * nr)
+                defer_rows(pew, gr[pe.proj.weight], gr[pe.proj.bias], 12 * Cd, Cd, 2 * nr)
+        elif DET_SMALL:      # LayerNorm parameter gradients as per-block partial rows, added in block order at the end of the backward
             # (ONE buffer and one pending sum for both token streams: the patch embedding is shared, and two pending sums into the
             #  same tensor would race in the multi-descriptor reduce launch)
             nr = (M + 63) // 64
@@ -800,9 +818,10 @@ def backward(m, sv, dout, need_dx_kv=True):
             check(lib.dpmn_patch_embed_bwd_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
                                                dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv), dptr(patches),
                                                dptr(gr[pe.norm.weight]), dptr(gr[pe.norm.bias]), B, img.shape[2], img.shape[3], Cd, stream()))
-        dw16 = zeros(Cd, 16)
-        gemm_tn(dconv, patches, dw16, gr[pe.proj.bias], leaf=False)      # dw16 is read right below
-        gr[pe.proj.weight] += dw16[:, :12].reshape(pe.proj.weight.shape)
+        if not pe_wg:
+            dw16 = zeros(Cd, 16)
+            gemm_tn(dconv, patches, dw16, gr[pe.proj.bias], leaf=False)      # dw16 is read right below
+            gr[pe.proj.weight] += dw16[:, :12].reshape(pe.proj.weight.shape)
         need_din = fuse or (which == "kv" and need_dx_kv)
         if need_din:
             w16 = zeros(16, Cd)

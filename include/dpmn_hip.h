@@ -574,6 +574,13 @@ int dpmn_patch_embed_bwd_det_drop_f32(const float* img, int cin, const float* pf
                                       const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
                                       float* ln_part, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
                                       dpmn_stream_t stream);
+/* the same (embed_dim 96) with the PatchEmbed conv's weight / bias gradient as per-block partial rows instead of the `patches` output:
+ * w_part is (ceil(tokens / 64), 12 C + C) rows of [dW (C, 3, 2, 2) flattened | db (C)], one row per block, to be added in row order
+ * (dpmn_rows_reduce_f32 with NK = 12 C, N = C) -- replaces dW = dconv^T . patches as a separate skinny GEMM */
+int dpmn_patch_embed_bwd_det_wgrad_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
+                                       const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* ln_part,
+                                       float* w_part, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
+                                       dpmn_stream_t stream);
 int dpmn_prior_fusion_wgrad_det_f32(const float* din, const float* prior, float* part, int B, int Hi, int Wi, dpmn_stream_t stream);
 /* conv weight gradient in the packed (Cout, Kp) layout, train-mode BatchNorm plumbing, CMM gate backward (conv_bwd.hip) */
 int dpmn_conv2d_wgrad_f32(const dpmn_conv_desc* d, const float* dy, float* dwp,
