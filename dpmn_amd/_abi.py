@@ -206,7 +206,7 @@ SIGNATURES = {
     "dpmn_prior_fusion_wgrad_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_patch_embed_bwd_det_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_patch_embed_bwd_det_drop_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _f, _u64, fp]),
-    "dpmn_patch_embed_bwd_det_wgrad_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _f, _u64, fp]),
+    "dpmn_patch_embed_bwd_det_wgrad_f32": (_i, [fp, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, _f, _u64, fp]),
     "dpmn_prior_fusion_wgrad_det_f32": (_i, [fp, fp, fp, _i, _i, _i, fp]),
     "dpmn_conv2d_wgrad_f32": (_i, [C.POINTER(ConvDesc), fp, fp, _i, fp]),
     "dpmn_conv_pack_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, _i, _l, _l, _l, _l, _l, fp]),

@@ -882,7 +882,11 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
                                                           const float* __restrict__ dtok, float* __restrict__ dconv,
                                                           float* __restrict__ patches, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta, int B, int Hi, int Wi, float* __restrict__ lnpart,
-                                                          float p_drop, unsigned long long seed, float* __restrict__ wpart) {
+                                                          float p_drop, unsigned long long seed, float* __restrict__ wpart,
+                                                          float* __restrict__ dimg) {
+  // dimg != null (with wpart, no prior_fusion): the gradient of the 3-channel input image (B, 3, Hi, Wi), written directly -- every
+  // pixel belongs to exactly one 2 x 2 patch: din[k] = sum_c dconv[c] W[c][k], four lanes per token reduced by shuffles (instead of
+  // a (M, 96) x (96, 16) Linear launch on a freshly transposed weight and a scatter launch into a zero-filled image)
   // wpart != null (C = 96): the block also STORES its partial of the conv's weight and bias gradient -- row blockIdx.x of (blocks,
   // 12 C + C): sum over the block's 64 tokens of dconv[c] * patch[k] | dconv[c] -- and writes no `patches`: the caller adds the rows
   // in block order (dpmn_rows_reduce_f32) instead of running dW = dconv^T . patches as a separate skinny GEMM + reduce + add
@@ -989,6 +993,26 @@ __global__ __launch_bounds__(256) void k_patch_embed_bwd(const float* __restrict
     if (part == 0 && !wpart) {
 #pragma unroll
       for (int k = 0; k < 16; ++k) patches[(size_t)token * 16 + k] = k < KP ? in[k] : 0.f;
+    }
+  }
+  if (dimg) {
+    float dk[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < CQ; ++i) a = fmaf(dcv[i], wt[k * C + part * CQ + i], a);
+      a += xshfl<1>(a); a += xshfl<2>(a);
+      dk[k] = a;
+    }
+    if (valid && part == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+          float2 v2 = make_float2(dk[(c * 2 + dy) * 2], dk[(c * 2 + dy) * 2 + 1]);
+          *reinterpret_cast<float2*>(dimg + (((size_t)b * 3 + c) * Hi + th * 2 + dy) * Wi + tw * 2) = v2;
+        }
     }
   }
   if constexpr (C == 96) {
@@ -1394,14 +1418,15 @@ int dpmn_pgrm_tail_elem_bwd_f32(const float* dout, const float* c1, const float*
 static int patch_embed_bwd_impl(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
                                 const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* patches,
                                 float* dgamma, float* dbeta, float* part, int B, int Hi, int Wi, int C, dpmn_stream_t stream,
-                                float p_drop = 0.f, unsigned long long seed = 0ull, float* wpart = nullptr) {
+                                float p_drop = 0.f, unsigned long long seed = 0ull, float* wpart = nullptr, float* dimg = nullptr) {
   DPMN_REQUIRE(!wpart || C == 96, "patch_embed_bwd: the in-kernel weight-gradient partials exist for embed_dim 96");
+  DPMN_REQUIRE(!dimg || (cin == 3 && !pf_w && Wi % 2 == 0), "patch_embed_bwd: the direct image gradient is for a 3-channel input without prior_fusion");
   DPMN_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "patch_embed_bwd: drop probability must be in [0, 1)");
   DPMN_REQUIRE(img && pe_w && pe_b && ln_w && dtok && dconv && patches && ((dgamma && dbeta) || part), "patch_embed_bwd: null pointer");
   const long tokens_n = (long)B * (Hi / 2) * (Wi / 2);
   dim3 grid((unsigned)((tokens_n + 63) / 64));
   hipStream_t st = as_stream(stream);
-#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi, part, p_drop, seed, wpart)
+#define PB_LAUNCH(CV, FV) hipLaunchKernelGGL((k_patch_embed_bwd<CV, FV>), grid, dim3(256), 0, st, img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, patches, dgamma, dbeta, B, Hi, Wi, part, p_drop, seed, wpart, dimg)
   if (C == 96 && pf_w) PB_LAUNCH(96, true);
   else if (C == 96) PB_LAUNCH(96, false);
   else if (C == 192 && pf_w) PB_LAUNCH(192, true);
@@ -1437,11 +1462,11 @@ int dpmn_patch_embed_bwd_det_drop_f32(const float* img, int cin, const float* pf
 
 int dpmn_patch_embed_bwd_det_wgrad_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
                                        const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* ln_part,
-                                       float* w_part, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
+                                       float* w_part, float* dimg, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
                                        dpmn_stream_t stream) {
   DPMN_REQUIRE(ln_part && w_part, "patch_embed_bwd_det_wgrad: null pointer");
   return patch_embed_bwd_impl(img, cin, pf_w, pf_b, pe_w, pe_b, ln_w, dtok, dconv, /* patches: not written */ dconv, nullptr, nullptr, ln_part, B,
-                              Hi, Wi, C, stream, p_drop, seed, w_part);
+                              Hi, Wi, C, stream, p_drop, seed, w_part, dimg);
 }
 
 int dpmn_patch_scatter_f32(const float* din, float* dimg, int cimg, int B, int Hi, int Wi, dpmn_stream_t stream) {

@@ -795,10 +795,15 @@ def backward(m, sv, dout, need_dx_kv=True):
                 lnp = torch.empty(2 * nr, 2 * Cd, device=dout.device)
                 pew = torch.empty(2 * nr, 13 * Cd, device=dout.device)
             off = 0 if which == "kv" else nr
+            # the image gradient of the kv stream straight out of the kernel (3 input channels, no prior_fusion)
+            direct_dx = which == "kv" and need_dx_kv and img.shape[1] == 3
+            if direct_dx:
+                dx_kv = torch.empty_like(img)
             check(lib.dpmn_patch_embed_bwd_det_wgrad_f32(dptr(img), img.shape[1], dptr(pfw, True), dptr(pfb, True), dptr(pe.proj.weight),
                                                          dptr(pe.proj.bias), dptr(pe.norm.weight), dptr(dtok), dptr(dconv),
-                                                         lnp.data_ptr() + off * 2 * Cd * 4, pew.data_ptr() + off * 13 * Cd * 4, B, img.shape[2],
-                                                         img.shape[3], Cd, float(pd), int(sd[1] if which == "kv" else sd[0]), stream()))
+                                                         lnp.data_ptr() + off * 2 * Cd * 4, pew.data_ptr() + off * 13 * Cd * 4,
+                                                         dptr(dx_kv) if direct_dx else None, B, img.shape[2], img.shape[3], Cd, float(pd),
+                                                         int(sd[1] if which == "kv" else sd[0]), stream()))
             if which == "q":
                 defer_rows(lnp, gr[pe.norm.weight], gr[pe.norm.bias], Cd, Cd, 2 * nr)
                 defer_rows(pew, gr[pe.proj.weight], gr[pe.proj.bias], 12 * Cd, Cd, 2 * nr)
@@ -823,7 +828,7 @@ def backward(m, sv, dout, need_dx_kv=True):
             gemm_tn(dconv, patches, dw16, gr[pe.proj.bias], leaf=False)      # dw16 is read right below
             gr[pe.proj.weight] += dw16[:, :12].reshape(pe.proj.weight.shape)
         need_din = fuse or (which == "kv" and need_dx_kv)
-        if need_din:
+        if need_din and not (pe_wg and which == "kv" and img.shape[1] == 3):
             w16 = zeros(16, Cd)
             w16[:12] = pe.proj.weight.reshape(Cd, 12).t()
             din = ops.linear(dconv, w16)

@@ -576,10 +576,12 @@ int dpmn_patch_embed_bwd_det_drop_f32(const float* img, int cin, const float* pf
                                       dpmn_stream_t stream);
 /* the same (embed_dim 96) with the PatchEmbed conv's weight / bias gradient as per-block partial rows instead of the `patches` output:
  * w_part is (ceil(tokens / 64), 12 C + C) rows of [dW (C, 3, 2, 2) flattened | db (C)], one row per block, to be added in row order
- * (dpmn_rows_reduce_f32 with NK = 12 C, N = C) -- replaces dW = dconv^T . patches as a separate skinny GEMM */
+ * (dpmn_rows_reduce_f32 with NK = 12 C, N = C) -- replaces dW = dconv^T . patches as a separate skinny GEMM.
+ * dimg (optional; 3-channel img, no prior_fusion): the gradient of img, (B, 3, Hi, Wi), written directly (replaces the
+ * dconv . W Linear + dpmn_patch_scatter_f32 into a zero-filled image) */
 int dpmn_patch_embed_bwd_det_wgrad_f32(const float* img, int cin, const float* pf_w, const float* pf_b, const float* pe_w,
                                        const float* pe_b, const float* ln_w, const float* dtok, float* dconv, float* ln_part,
-                                       float* w_part, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
+                                       float* w_part, float* dimg, int B, int Hi, int Wi, int C, float p_drop, unsigned long long seed,
                                        dpmn_stream_t stream);
 int dpmn_prior_fusion_wgrad_det_f32(const float* din, const float* prior, float* part, int B, int Hi, int Wi, dpmn_stream_t stream);
 /* conv weight gradient in the packed (Cout, Kp) layout, train-mode BatchNorm plumbing, CMM gate backward (conv_bwd.hip) */
