@@ -461,26 +461,38 @@ __global__ void k_sk_gate_bwd(const float* __restrict__ partial, int parts_per_i
   float* dz = dl + C;        // [dmid] grad wrt pre-GELU
   float* dAs = dz + dmid;    // [C] (nparts > 0)
   const int b = blockIdx.x, cg = C / G;
-  if (nparts > 0) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      float s = 0.f;
-      for (int p = 0; p < nparts; ++p) s += dA[((size_t)p * gridDim.x + b) * C + c];
-      dAs[c] = s;
-    }
-    __syncthreads();
-  }
-  auto dA_at = [&](int g, int c) { return nparts > 0 ? dAs[g * cg + c] : dA[((size_t)b * G + g) * cg + c]; };
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  // (this kernel is one latency chain per image on 48 blocks: the two partial-row sums share a phase, and the two matrix-vector
+  //  products of the gate MLP are spread over eight lanes per output instead of one lane walking all C inputs: 32 -> see DESIGN)
+  // partial rows: eight loads in flight, added in row order (a one-load-per-iteration loop waits out a cache latency per row)
+  auto row_sum = [&](const float* base, size_t stride, int n) {
     float s = 0.f;
-    for (int p = 0; p < parts_per_image; ++p) s += partial[((size_t)b * parts_per_image + p) * C + c];
-    S[c] = s / (float)L;
+    int p = 0;
+    for (; p + 8 <= n; p += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(p + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; p < n; ++p) s += base[(size_t)p * stride];
+    return s;
+  };
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    if (nparts > 0) dAs[c] = row_sum(dA + (size_t)b * C + c, (size_t)gridDim.x * C, nparts);
+    S[c] = row_sum(partial + (size_t)b * parts_per_image * C + c, C, parts_per_image) / (float)L;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < dmid; j += blockDim.x) {
-    float a = fc1_b[j];
-    for (int c = 0; c < C; ++c) a += fc1_w[j * C + c] * S[c];
-    zp[j] = a;
-    Z[j] = gelu_erf(a);
+  auto dA_at = [&](int g, int c) { return nparts > 0 ? dAs[g * cg + c] : dA[((size_t)b * G + g) * cg + c]; };
+  const int sub = threadIdx.x & 7;
+  for (int j = threadIdx.x >> 3; j < dmid; j += blockDim.x >> 3) {      // 8 lanes per output (blockDim is a multiple of 64)
+    float a = 0.f;
+    for (int c = sub; c < C; c += 8) a += fc1_w[j * C + c] * S[c];
+    a += xshfl<1>(a); a += xshfl<2>(a); a += xshfl<4>(a);
+    if (sub == 0) {
+      a += fc1_b[j];
+      zp[j] = a;
+      Z[j] = gelu_erf(a);
+    }
   }
   for (int c = threadIdx.x; c < cg; c += blockDim.x) {
     float dot = 0.f;
@@ -499,12 +511,15 @@ __global__ void k_sk_gate_bwd(const float* __restrict__ partial, int parts_per_i
   for (int i = threadIdx.x; i < C * dmid; i += blockDim.x) atomicAdd(dfc2_w + i, dl[i / dmid] * Z[i % dmid]);
   for (int c = threadIdx.x; c < C; c += blockDim.x) atomicAdd(dfc2_b + c, dl[c]);
   }
-  for (int j = threadIdx.x; j < dmid; j += blockDim.x) {
+  for (int j = threadIdx.x >> 3; j < dmid; j += blockDim.x >> 3) {
     float a = 0.f;
-    for (int c = 0; c < C; ++c) a += dl[c] * fc2_w[c * dmid + j];
-    const float x = zp[j];
-    const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
-    dz[j] = a * (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x));
+    for (int c = sub; c < C; c += 8) a += dl[c] * fc2_w[c * dmid + j];
+    a += xshfl<1>(a); a += xshfl<2>(a); a += xshfl<4>(a);
+    if (sub == 0) {
+      const float x = zp[j];
+      const float cdf = 0.5f * (1.0f + erf_as(x * 0.70710678118654752440f));
+      dz[j] = a * (cdf + x * 0.3989422804014327f * __expf(-0.5f * x * x));
+    }
   }
   __syncthreads();
   if (wpart1) {
