@@ -190,6 +190,7 @@ SIGNATURES = {
     "dpmn_sk_select_bwd_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_bwd_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_select_bwd_det_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
+    "dpmn_sk_select_bwd_det_set_f32": (_i, [fp, fp, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_gate_bwd_det_f32": (_i, [fp, _i, _i, fp, fp, fp, fp, fp, _i, fp, fp, fp, _i, _i, _i, _i, fp]),
     "dpmn_sk_feats_grad_f32": (_i, [fp, fp, fp, fp, C.c_long, _i, _i, fp]),
     "dpmn_dwconv3x3_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp]),

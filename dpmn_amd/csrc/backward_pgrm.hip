@@ -425,20 +425,39 @@ __global__ void k_sk_select(const float* __restrict__ cat, const float* __restri
 // dcat[m][g*cg+c] (+)= A[b][g][c] * dV[m][c] ; dA[b][g][c] += sum over the block's tokens of cat * dV
 __global__ __launch_bounds__(256) void k_sk_select_bwd(const float* __restrict__ cat, const float* __restrict__ A,
                                                         const float* __restrict__ dV, float* __restrict__ dcat,
-                                                        float* __restrict__ dA, int L, int C, int G, int rows_per_block, int part_mode) {
+                                                        float* __restrict__ dA, int L, int C, int G, int rows_per_block, int part_mode,
+                                                        int overwrite) {
   // part_mode 1: dA is (gridDim.x, B, C) -- every block STORES its partial row, the gate backward adds them in block order (no atomics)
+  // overwrite 1: dcat = A dV (the caller's buffer is fresh: no zero fill of it before, no read-modify-write here)
   const int cg = C / G;
   const int b = blockIdx.y;
   const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(L, r0 + rows_per_block);
   for (int col = threadIdx.x; col < C; col += blockDim.x) {
     const int g = col / cg, c = col % cg;
     const float a = A[((size_t)b * G + g) * cg + c];
     float acc = 0.f;
-    for (int r = r0; r < r0 + rows_per_block && r < L; ++r) {
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {        // four rows' loads in flight, sums in row order
+      float dv[4], cv[4], ov[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t m = (size_t)b * L + r + u;
+        dv[u] = dV[m * cg + c];
+        cv[u] = cat[m * C + col];
+        ov[u] = overwrite ? 0.f : dcat[m * C + col];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc += cv[u] * dv[u];
+        dcat[((size_t)b * L + r + u) * C + col] = overwrite ? a * dv[u] : ov[u] + a * dv[u];
+      }
+    }
+    for (; r < r1; ++r) {
       const size_t m = (size_t)b * L + r;
       const float dv = dV[m * cg + c];
       acc += cat[m * C + col] * dv;
-      dcat[m * C + col] += a * dv;
+      dcat[m * C + col] = overwrite ? a * dv : dcat[m * C + col] + a * dv;
     }
     if (part_mode) dA[((size_t)blockIdx.x * gridDim.y + b) * C + col] = acc;
     else atomicAdd(dA + ((size_t)b * G + g) * cg + c, acc);
@@ -1216,7 +1235,7 @@ int dpmn_sk_select_bwd_f32(const float* cat, const float* attn_vec, const float*
                            int G, dpmn_stream_t stream) {
   DPMN_REQUIRE(cat && attn_vec && dV && dcat && dA && B > 0, "sk_select_bwd: bad arguments");
   const int rows = 32;
-  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA, L, C, G, rows, 0);
+  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA, L, C, G, rows, 0, 0);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -1226,7 +1245,17 @@ int dpmn_sk_select_bwd_det_f32(const float* cat, const float* attn_vec, const fl
                                int G, dpmn_stream_t stream) {
   DPMN_REQUIRE(cat && attn_vec && dV && dcat && dA_part && B > 0, "sk_select_bwd_det: bad arguments");
   const int rows = 32;
-  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA_part, L, C, G, rows, 1);
+  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA_part, L, C, G, rows, 1, 0);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
+
+// the same with dcat WRITTEN (= A dV) instead of accumulated into: for a caller whose buffer is fresh (no zero fill, no read)
+int dpmn_sk_select_bwd_det_set_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA_part, int B, int L, int C,
+                                   int G, dpmn_stream_t stream) {
+  DPMN_REQUIRE(cat && attn_vec && dV && dcat && dA_part && B > 0, "sk_select_bwd_det_set: bad arguments");
+  const int rows = 32;
+  hipLaunchKernelGGL(k_sk_select_bwd, dim3(cdiv(L, rows), B), dim3(128), 0, as_stream(stream), cat, attn_vec, dV, dcat, dA_part, L, C, G, rows, 1, 1);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

@@ -157,7 +157,7 @@ int dpmn_pgrm_blocks_backward_f32(const dpmn_pgrm_weights* w, const dpmn_pgrm_bl
     }
     LINEAR_BWD(dat, b.V, t.head_t, sink(g.sk_head_w), sink(g.sk_head_b), C, cg, s.dV);
     float* dcat = dcat_zero[bi];
-    RUN(dpmn_sk_select_bwd_det_f32(b.cat, b.avec, s.dV, dcat, s.dA, B, L, C, G, stream));
+    RUN(dpmn_sk_select_bwd_det_set_f32(b.cat, b.avec, s.dV, dcat, s.dA, B, L, C, G, stream));      // dcat written: the buffer needs no fill
     RUN(dpmn_sk_gate_bwd_det_f32(b.partial, parts, L, p.sk_fc1_w, p.sk_fc1_b, p.sk_fc2_w, b.avec, s.dA, parts, s.dS, s.wp2[bi], s.wp1[bi], B, C, G,
                                  dmid, stream));
     RUN(dpmn_rows_reduce_f32(s.wp2[bi], sink(g.sk_fc2_w), sink(g.sk_fc2_b), C * dmid, C, B, stream));

@@ -636,7 +636,7 @@ def backward(m, sv, dout, need_dx_kv=True):
     residuals = sv["residuals"]
     # every zero-initialised accumulator of this call comes out of ONE zero-filled slab (one memset instead of ~12 fills)
     img = sv["x_kv"]
-    sizes = [r.numel() for r in residuals[1:]] + [M * Cd] + [M * Cd, B * Cd] * 2 + [Cd * 16, 16 * Cd] * 2 + [img.numel()]
+    sizes = [r.numel() for r in residuals[1:]] + [M * Cd] + ([] if DET_SMALL else [M * Cd, B * Cd] * 2) + [Cd * 16, 16 * Cd] * 2 + [img.numel()]
     slab = torch.zeros(sum((n + 63) // 64 * 64 for n in sizes), device=dout.device)
     _off = [0]
 
@@ -668,7 +668,7 @@ def backward(m, sv, dout, need_dx_kv=True):
     sd = drop["seeds"] if drop else [0] * N_SEEDS
     native = _native_blocks_ok(m, sv, B)
     if native:
-        _blocks_backward_native(m, sv, gr, drop, dtkv, dtq, [zeros(M, Cd), zeros(M, Cd)], B)      # dtkv updated in place
+        _blocks_backward_native(m, sv, gr, drop, dtkv, dtq, [torch.empty(M, Cd, device=dout.device) for _ in range(2)], B)      # dtkv updated in place
     for bi in (() if native else (1, 0)):
         blk = m.layers[0].blocks[bi]
         a, sk, mlp = blk.attn, blk.attn.sknet, blk.mlp
@@ -714,7 +714,7 @@ def backward(m, sv, dout, need_dx_kv=True):
         # x1 = tkv_in + DropPath(feats + V Wh^T + bh)
         dat = ops.dropout(dx1, p_row=dpb, seed_row=sb[1], row_len=L * Cd, out=torch.empty_like(dx1)) if dpb > 0 else dx1
         dV = linear_bwd(dat, s["V"], sk.proj_head.weight, gr[sk.proj_head.weight], gr[sk.proj_head.bias])
-        dcat = zeros(M, Cd)
+        dcat = torch.empty(M, Cd, device=dout.device) if DET_SMALL else zeros(M, Cd)      # DET_SMALL: written by the select backward
         dS = torch.empty(B, Cd, device=dout.device)
         dmid = sk.fc1.weight.shape[0]
         if DET_SMALL:
@@ -722,7 +722,7 @@ def backward(m, sv, dout, need_dx_kv=True):
             # with atomics every gradient upstream of this block differed from run to run), the gate's weight gradients as
             # per-image rows added in image order by the backward's one reduce launch
             dA = torch.empty(parts, B, Cd, device=dout.device)
-            check(lib.dpmn_sk_select_bwd_det_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(dV), dptr(dcat), dptr(dA), B, L, Cd, G, stream()))
+            check(lib.dpmn_sk_select_bwd_det_set_f32(dptr(s["cat"]), dptr(s["avec"]), dptr(dV), dptr(dcat), dptr(dA), B, L, Cd, G, stream()))
             wp2, wp1 = torch.empty(B, Cd * dmid + Cd, device=dout.device), torch.empty(B, dmid * Cd + dmid, device=dout.device)
             check(lib.dpmn_sk_gate_bwd_det_f32(dptr(s["partial"]), parts, L, dptr(sk.fc1.weight), dptr(sk.fc1.bias), dptr(sk.fc2.weight),
                                                dptr(s["avec"]), dptr(dA), parts, dptr(dS), dptr(wp2), dptr(wp1), B, Cd, G, dmid, stream()))

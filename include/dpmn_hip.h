@@ -520,6 +520,9 @@ int dpmn_sk_gate_bwd_f32(const float* colsum_partials, int parts_per_image, int 
  * [dfc1_w | dfc1_b] for dpmn_rows_reduce_f32 (pgrm.py:86-93 backward) */
 int dpmn_sk_select_bwd_det_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA_part, int B, int L,
                                int C, int G, dpmn_stream_t stream);
+/* dcat = A dV written, not accumulated (fresh buffer: no zero fill, no read-modify-write) */
+int dpmn_sk_select_bwd_det_set_f32(const float* cat, const float* attn_vec, const float* dV, float* dcat, float* dA_part, int B, int L,
+                                   int C, int G, dpmn_stream_t stream);
 int dpmn_sk_gate_bwd_det_f32(const float* colsum_partials, int parts_per_image, int L, const float* fc1_w, const float* fc1_b,
                              const float* fc2_w, const float* attn_vec, const float* dA_part, int nparts, float* dS, float* wpart2,
                              float* wpart1, int B, int C, int G, int dmid, dpmn_stream_t stream);
@@ -744,7 +747,8 @@ typedef struct {            /* the per-stream conv scratch of dpmn_conv_desc (sp
  * dpmn_pgrm_forward_train_f32 saved.  grads[2]: the gradient sinks, laid out as dpmn_pgrm_block (every pointer is WRITTEN: += of the
  * parameter gradient); wt[2]: the transposed (in, out) copies of the seven Linear / pointwise weights the data gradients multiply by;
  * table_numel[g]: elements of relative_position_bias_table_g; dtkv: in dL/d(tokens behind block 1), out dL/d(tokens in front of
- * block 0); dtq: zero-filled, out dL/d(query tokens); dcat_zero[2]: two zero-filled (B L, C) buffers; zero_bias: mlp_hidden zeros.
+ * block 0); dtq: zero-filled, out dL/d(query tokens); dcat_zero[2]: two (B L, C) scratch buffers (written, need no fill); zero_bias:
+ * mlp_hidden zeros.
  * scratch >= dpmn_pgrm_blocks_backward_scratch_bytes and must stay untouched until the caller's dpmn_reduce_defer_flush (it holds
  * partial rows of queued ordered reductions); arena / arena_used: the slice allocator of those reductions (*arena_used advances; a
  * request that does not fit flushes the queue and starts the arena over).  Requires dpmn_pgrm_forward_train_supported(w, B). */
