@@ -862,8 +862,9 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   const size_t zs = (size_t)M * a.npad;
   if (cq < n4) {
-    for (int m = m_lo + rl; m < m_lo + rows && m < M; m += RL) {
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const int m_hi = min(M, m_lo + rows);
+    auto sum_row = [&](int m, float (&v)[4]) {
+      v[0] = v[1] = v[2] = v[3] = 0.f;
       const float* pp = ph.partial + (size_t)m * a.npad + n;
       int z = 0;
       for (; z + 4 <= a.ksplit; z += 4) {     // 4 independent loads in flight
@@ -878,7 +879,21 @@ __global__ __launch_bounds__(256) void k_conv_splitk_reduce(ConvArgs a, int rows
         const float4 p = *reinterpret_cast<const float4*>(pp + (size_t)z * zs);
         v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
       }
-      conv_store(a, m, n, v, ssum, ssq, ph.ooy, ph.oox);
+    };
+    // two rows per iteration: a layer split in two has only two loads per row -- the second row's are in flight under the first's
+    // epilogue (same per-row arithmetic, same order of the statistics sums: row m, then row m + RL)
+    int m = m_lo + rl;
+    for (; m + RL < m_hi; m += 2 * RL) {
+      float v0[4], v1[4];
+      sum_row(m, v0);
+      sum_row(m + RL, v1);
+      conv_store(a, m, n, v0, ssum, ssq, ph.ooy, ph.oox);
+      conv_store(a, m + RL, n, v1, ssum, ssq, ph.ooy, ph.oox);
+    }
+    if (m < m_hi) {
+      float v0[4];
+      sum_row(m, v0);
+      conv_store(a, m, n, v0, ssum, ssq, ph.ooy, ph.oox);
     }
   }
   if (a.stats) {
