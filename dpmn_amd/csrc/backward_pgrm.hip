@@ -888,10 +888,46 @@ __global__ void k_tail_elem_bwd(const float* __restrict__ dout, const float* __r
   float a0 = 0.f, ai[8];
   float wli[8];
   for (int i = 0; i < t.n; ++i) { ai[i] = 0.f; wli[i] = t.wl[i][pos]; }
-  for (int b = 0; b < B; ++b) {
-    const long idx = (long)b * 3 * Ho * Wo + pos;
+  // four images per iteration, every load of the four issued before the first store (the pointers in `t` are not restrict: a
+  // one-image-per-iteration loop was a chain of ~5 cache latencies per image, 48 images deep); sums in image order as before
+  const long istride = (long)3 * Ho * Wo;
+  const size_t cstride = (size_t)H * W * 12;
+  const size_t cbase = ((size_t)(Y / 2) * W + X / 2) * 12 + ch;
+  int b = 0;
+  for (; b + 4 <= B; b += 4) {
+    float g[4], pre[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      g[u] = dout[(long)(b + u) * istride + pos];
+      pre[u] = c1[(size_t)(b + u) * cstride + cbase];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a0 += g[u] * (pre[u] > 0.f ? pre[u] : 0.01f * pre[u]);
+      dc1[(size_t)(b + u) * cstride + cbase] = g[u] * w0 * (pre[u] > 0.f ? 1.f : 0.01f);
+    }
+    for (int i = 0; i < t.n; ++i) {        // one residual at a time: its four images' loads, then its four stores
+      float rv[4], dv[4];
+      const float* rp = t.res[i];
+      float* dp = t.dres[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        rv[u] = rp[(long)(b + u) * istride + pos];
+        dv[u] = dp ? dp[(long)(b + u) * istride + pos] : 0.f;
+      }
+      float acc = ai[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        acc += g[u] * rv[u];
+        if (dp) dp[(long)(b + u) * istride + pos] = dv[u] + g[u] * wli[i];
+      }
+      ai[i] = acc;
+    }
+  }
+  for (; b < B; ++b) {
+    const long idx = (long)b * istride + pos;
     const float g = dout[idx];
-    const size_t ci = (((size_t)b * H + Y / 2) * W + X / 2) * 12 + ch;
+    const size_t ci = (size_t)b * cstride + cbase;
     const float pre = c1[ci];
     a0 += g * (pre > 0.f ? pre : 0.01f * pre);
     dc1[ci] = g * w0 * (pre > 0.f ? 1.f : 0.01f);
