@@ -14,10 +14,25 @@ __global__ __launch_bounds__(256) void k_to_mask(const float* __restrict__ img, 
   const int b = blockIdx.x, tid = threadIdx.x;
   const float* p = img + (size_t)b * img_stride;
   long long s = 0;
-  for (int i = tid; i < HW; i += 256) {
+  auto lum = [](float rf, float gf, float bf) {
     // ToPILImage: mul(255).byte() -> truncate toward zero, wrap modulo 256 (quirk Q13)
-    const int r = ((int)(p[i] * 255.0f)) & 255, g = ((int)(p[HW + i] * 255.0f)) & 255, bl = ((int)(p[2 * HW + i] * 255.0f)) & 255;
-    const int L = (r * 19595 + g * 38470 + bl * 7471 + 0x8000) >> 16;   // PIL ImagingConvert RGB -> L
+    const int r = ((int)(rf * 255.0f)) & 255, g = ((int)(gf * 255.0f)) & 255, bl = ((int)(bf * 255.0f)) & 255;
+    return (r * 19595 + g * 38470 + bl * 7471 + 0x8000) >> 16;   // PIL ImagingConvert RGB -> L
+  };
+  int i = tid;
+  for (; i + 768 < HW; i += 1024) {      // four pixels' twelve loads in flight (one block per image: the kernel is its load latency)
+    float v[4][3];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v[u][0] = p[i + 256 * u]; v[u][1] = p[HW + i + 256 * u]; v[u][2] = p[2 * HW + i + 256 * u]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int L = lum(v[u][0], v[u][1], v[u][2]);
+      Ls[i + 256 * u] = L;
+      s += L;
+    }
+  }
+  for (; i < HW; i += 256) {
+    const int L = lum(p[i], p[HW + i], p[2 * HW + i]);
     Ls[i] = L;
     s += L;
   }
