@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict_
   // finished LayerNorm output (same product, bitwise), one launch and one pass over the tokens less per stream
   constexpr int CQ = C / 4, KP = 3 * PATCH * PATCH;
   static_assert(!FUSE || PATCH == 2, "fused prior conv assumes 2x2 patches (one pixel per lane of the token quad)");
-  __shared__ float wt[KP * C];
+  __shared__ __attribute__((aligned(16))) float wt[KP * C];
   __shared__ float pfw[3 * 2 * 9 + 3];
   for (int i = threadIdx.x; i < KP * C; i += 256) wt[(i % KP) * C + i / KP] = pe_w[i];   // pe_w (C, KP) -> [k][c]
   if (FUSE && threadIdx.x < 57) pfw[threadIdx.x] = threadIdx.x < 54 ? pf_w[threadIdx.x] : pf_b[threadIdx.x - 54];
@@ -75,17 +75,24 @@ __global__ __launch_bounds__(256) void k_patch_embed_ln(const float* __restrict_
         for (int dx = 0; dx < PATCH; ++dx)
           in[(c * PATCH + dy) * PATCH + dx] = img[(((size_t)b * cin + c) * Hi + th * PATCH + dy) * Wi + tw * PATCH + dx];
   }
-  float o[CQ];
-  float s = 0.f;
+  // k outermost: a lane's CQ channels are contiguous in wt[k][:], so the weights arrive as 16-byte LDS reads (CQ / 4 per k) instead
+  // of one ds_read_b32 per multiply; every output still adds its products in the order k = 0 .. KP - 1 (same bits)
+  float o[CQ], s = 0.f;
 #pragma unroll
-  for (int i = 0; i < CQ; ++i) {
-    const int c = part * CQ + i;
-    float a = pe_b[c];
-#pragma unroll
-    for (int k = 0; k < KP; ++k) a += wt[k * C + c] * in[k];
-    o[i] = a;
-    s += a;
+  for (int i = 0; i < CQ; i += 4) {
+    const float4 b4 = *reinterpret_cast<const float4*>(pe_b + part * CQ + i);
+    o[i] = b4.x; o[i + 1] = b4.y; o[i + 2] = b4.z; o[i + 3] = b4.w;
   }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+#pragma unroll
+    for (int i = 0; i < CQ; i += 4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(wt + k * C + part * CQ + i);
+      o[i] += w4.x * in[k]; o[i + 1] += w4.y * in[k]; o[i + 2] += w4.z * in[k]; o[i + 3] += w4.w * in[k];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) s += o[i];
   s += xshfl<1>(s); s += xshfl<2>(s);
   const float mean = s * (1.0f / C);
   float q = 0.f;
