@@ -483,9 +483,16 @@ __global__ void k_bn_finalize(float* __restrict__ stats, const float* __restrict
   if (c >= C) return;
   double* sd = reinterpret_cast<double*>(stats);      // (32, 2, C) doubles (conv.hip STAT_SLOTS)
   double s1 = 0.0, s2 = 0.0;
-  for (int slot = 0; slot < 32; ++slot) {   // STAT_SLOTS
-    s1 += sd[(size_t)slot * 2 * C + c]; s2 += sd[(size_t)slot * 2 * C + C + c];
-    if (clear) { sd[(size_t)slot * 2 * C + c] = 0.0; sd[(size_t)slot * 2 * C + C + c] = 0.0; }
+  for (int s0 = 0; s0 < 32; s0 += 8) {   // STAT_SLOTS; eight slots' loads in flight, then their clears (a store between two loads of
+    double a[8], q[8];                     // the same array orders them: 64 dependent latencies on the CMM forward's main chain)
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[u] = sd[(size_t)(s0 + u) * 2 * C + c]; q[u] = sd[(size_t)(s0 + u) * 2 * C + C + c]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s1 += a[u]; s2 += q[u]; }
+    if (clear) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { sd[(size_t)(s0 + u) * 2 * C + c] = 0.0; sd[(size_t)(s0 + u) * 2 * C + C + c] = 0.0; }
+    }
   }
   const double mean_d = s1 / (double)count;
   const float mean = (float)mean_d;
