@@ -8,7 +8,9 @@ Storage: ONE parameter arena and ONE gradient arena for the whole trainer.  Each
     reference) and Adam(lr, betas=(beta1, 0.999)) one fused kernel (clip coefficient applied on the fly, no host sync).
 Buckets are packed into `CommGroup`s, the unit of the RCCL exchange: consecutive models (in the trainer's order, CMM first
 because its backward runs first) are coalesced until a group holds >= `group_mb` of gradients -- CMM's 214 MB is its own
-group, the 2.3 MB PGRMs and the 1 KB DistillModules share groups, so no latency-bound small collective is issued.
+group, the six 2.3 MB PGRMs and the 1 KB DistillModules share ONE (group_mb = 16: measured with the collectives forced at world
+size 1, RCCL + ZeRO-1: 11 groups of >= 6 MB 30.2 ms, 2 groups 28.3 ms, plain step 27.0 -- every collective costs ~0.2 ms of launch /
+stream hand-over whatever its size, and the PGRMs' 14 MB are exchanged in ~0.1 ms over xGMI even when issued after the last backward).
 A group's collective is launched the moment the LAST gradient of its LAST member has been accumulated in the current
 backward (async, on RCCL's stream, overlapping the rest of the backward) and is waited for right before its optimizer
 kernels.  Two exchange modes:
@@ -190,6 +192,19 @@ class FlatBucket:
         _adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.normsq, max_norm, lr, beta1, beta2, eps, step, step_dev)
 
 
+# 1: gradient collectives issued from a stream of their own that waits for the members' ready events, instead of the stream of the last
+# reporting member.  Measured with the collectives forced at world size 1 (RCCL, ZeRO-1): 30.10 / 30.07 vs 29.90 / 29.95 ms -- off.
+COMM_STREAM = os.environ.get("DPMN_COMM_STREAM", "0") != "0"
+_COMM = {}
+
+
+def _comm_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _COMM:
+        _COMM[key] = torch.cuda.Stream(device=dev)
+    return _COMM[key]
+
+
 class CommGroup:
     """Several buckets adjacent in the arenas, exchanged with one collective."""
 
@@ -245,13 +260,24 @@ class CommGroup:
         self.launched = True
         if not self.multi:
             return
+        comm = None
         if self.flat_g.is_cuda:
-            cur = torch.cuda.current_stream()
+            # the collective is issued from a stream of its own that waits for every member's ready event: the stream the last member's
+            # backward runs on goes straight on to the next module's backward instead of waiting here for the other members' streams
+            # (and, for a module with side-stream gradients, for that side stream: the CMM's weight-gradient unpack)
+            comm = _comm_stream(self.flat_g.device) if COMM_STREAM else torch.cuda.current_stream()
             for b in self.buckets:
                 ev = getattr(b, "ready_event", None)
                 if ev is not None:
-                    cur.wait_event(ev)
+                    comm.wait_event(ev)
                     b.ready_event = None
+        if comm is not None and COMM_STREAM:
+            with torch.cuda.stream(comm):
+                self._issue()
+        else:
+            self._issue()
+
+    def _issue(self):
         avg = dist.ReduceOp.AVG
         self._post_scale = None
         if dist.get_backend(self.pg) != "nccl":        # test hook (gloo): no AVG / reduce-scatter guarantee on every build
@@ -293,6 +319,14 @@ class CommGroup:
         return (a - self.lo, b - a) if b > a else (0, 0)
 
     def step(self, step, lr, beta1, beta2=0.999, eps=1e-8, max_norm=0.25, step_dev=None):
+        self.step_norms()
+        if self.zero1:
+            dist.all_reduce(self.normsq, op=dist.ReduceOp.SUM, group=self.pg)     # len(buckets) floats
+        self.step_update(step, lr, beta1, beta2, eps, max_norm, step_dev)
+
+    def step_norms(self, zero=True):
+        """First half of step(): wait for the exchanged gradients, ||g||^2 of the part of every member this rank owns into self.normsq
+        (ZeRO-1: a partial sum, to be all-reduced -- by step(), or by the Trainer for ALL groups in one collective)."""
         self.wait_grads()
         self.wait_params()
         if self.flat_g.is_cuda:      # single process: events that launch() (multi only) did not consume -- a member's side-stream gradients
@@ -302,13 +336,15 @@ class CommGroup:
                     torch.cuda.current_stream(self.flat_g.device).wait_event(ev)
                     b.ready_event = None
         owned = [self._owned(i) for i in range(len(self.buckets))]
-        if self.zero1:
+        if self.zero1 and zero:
             self.normsq.zero_()
         for i, (o, k) in enumerate(owned):
             if k:
                 _sumsq(self.g_shard[o:o + k], self.normsq[i:i + 1], self.part)
-        if self.zero1:
-            dist.all_reduce(self.normsq, op=dist.ReduceOp.SUM, group=self.pg)     # len(buckets) floats
+
+    def step_update(self, step, lr, beta1, beta2=0.999, eps=1e-8, max_norm=0.25, step_dev=None):
+        """Second half of step(): clip + Adam on the owned shard with the (all-reduced) norms, then the parameter all-gather."""
+        owned = [self._owned(i) for i in range(len(self.buckets))]
         p_shard = self.flat_p[self.lo:self.lo + self.shard_n]
         for i, (o, k) in enumerate(owned):
             if k:
@@ -330,11 +366,12 @@ def broadcast_replicas(models, flat_p, pg=None):
 class Trainer:
     """zero_grad / gradient exchange / clip+Adam over a list of models, in the reference's order."""
 
-    def __init__(self, models, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=1, group=None, zero1=None, group_mb=6.0,
+    def __init__(self, models, lr=1e-3, beta1=0.5, max_norm=0.25, world_size=1, group=None, zero1=None, group_mb=16.0,
                  force_collectives=False):
         self.lr, self.beta1, self.max_norm = lr, beta1, max_norm
         self.world = world_size
         multi = world_size > 1 or force_collectives      # force_collectives: run the RCCL calls at world size 1 (1-GPU box check)
+        group_mb = float(os.environ.get("DPMN_GROUP_MB", group_mb))      # experiment knob: size at which an exchange group is closed
         zero1 = multi if zero1 is None else (bool(zero1) and multi)
         self.zero1 = zero1
         self.t = 0
@@ -380,6 +417,15 @@ class Trainer:
             self.groups.append(CommGroup(members, world_size, group, zero1, arena=(self.flat_p[off:off + gs], self.flat_g[off:off + gs]),
                                          force=force_collectives))
             off += gs
+        # the clip norms of every group as slices of ONE vector: under ZeRO-1 the partial sums of all groups are all-reduced by one
+        # collective in Trainer.step() (a tiny all-reduce per group between its norm and its Adam kernel was a stream round trip each:
+        # 11 of them, ~1 ms of the step's serial tail)
+        nb = sum(len(g.buckets) for g in self.groups)
+        self.normsq_all = torch.zeros(nb, device=dev)
+        o = 0
+        for g in self.groups:
+            g.normsq = self.normsq_all[o:o + len(g.buckets)]
+            o += len(g.buckets)
         if multi:
             broadcast_replicas(models, self.flat_p, group)
         # single process: clip + Adam of a group run on a stream of their own as soon as its last member's backward has reported,
@@ -474,11 +520,23 @@ class Trainer:
         if self.t_dev is not None:
             self.t_dev.add_(1.0)
         early = False
+        pending = []
         for g in self.groups:
             if g.stepped:
                 g.stepped, early = False, True
-                continue
-            g.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
+            else:
+                pending.append(g)
+        if self.zero1 and len(pending) == len(self.groups):
+            # norms of all groups, ONE all-reduce, then every group's clip + Adam + parameter all-gather
+            self.normsq_all.zero_()
+            for g in pending:
+                g.step_norms(zero=False)
+            dist.all_reduce(self.normsq_all, op=dist.ReduceOp.SUM, group=pending[0].pg)
+            for g in pending:
+                g.step_update(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
+        else:
+            for g in pending:
+                g.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
         self._armed = False
         for b in self.buckets:
             b.lazy_join = False
