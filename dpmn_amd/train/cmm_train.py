@@ -304,10 +304,8 @@ def wgrad_stream(dev):
     a hipGraph (graphed_train_step keeps the single-stream order)."""
     if not WGRAD_STREAM or (torch.cuda.is_current_stream_capturing() and os.environ.get("DPMN_GRAPH_MULTISTREAM", "1") == "0"):
         return None
-    key = (dev.type, dev.index)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
-    return _SIDE[key]
+    from .. import _streams
+    return _streams.pool(dev)["wgrad"]
 
 
 def build(m, x1, x2):
