@@ -420,14 +420,20 @@ class TextSR(base.TextBase):
         loss = loss / (b1 + b2 + 1)
         if hasattr(trainer, "arm_early_step"):
             trainer.arm_early_step()      # trainer.step() follows: a model's clip + Adam may run as soon as its backward has finished
-        loss.backward()
-        if forked:
-            # the PGRMs' backward kernels ran on the side streams and wrote the gradient arena directly (no AccumulateGrad node the
-            # autograd engine would join on): the optimizer kernels on this stream must wait for them explicitly
-            cur = torch.cuda.current_stream()
-            cur.wait_stream(self._side_streams[0])
-            cur.wait_stream(self._side_streams[1])
-        trainer.step()
+        try:
+            loss.backward()
+            if forked:
+                # the PGRMs' backward kernels ran on the side streams and wrote the gradient arena directly (no AccumulateGrad node the
+                # autograd engine would join on): the optimizer kernels on this stream must wait for them explicitly
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(self._side_streams[0])
+                cur.wait_stream(self._side_streams[1])
+            trainer.step()
+        finally:
+            # the promise made by arm_early_step() ends with this call whatever happened: if step() was not reached the gradients a
+            # backward left on a side stream are joined here, so a caller that inspects p.grad or retries sees complete buffers
+            if hasattr(trainer, "disarm"):
+                trainer.disarm()
         return loss.detach()
 
     def graphed_train_step(self, models, psn, distill, crit, trainer, images_lr, images_hr, label_vecs=None, text_priors=None,

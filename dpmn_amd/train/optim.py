@@ -177,6 +177,10 @@ class FlatBucket:
             self.ready_event = None
 
     def zero_grad(self):
+        # a backward that was never followed by step() (an exception, a skipped step) may have left leaf gradients in flight on a
+        # side stream behind ready_event: the zero fill must not overtake them, and the promise of arm_early_step() ends here
+        self._wait_ready_event()
+        self.lazy_join = False
         self.flat_g.zero_()
         self.reset_step()
         if self.group is not None:
@@ -447,6 +451,7 @@ class Trainer:
 
     def zero_grad(self):
         from ..model import packing
+        self.disarm()       # a previous backward whose step() never came: join its side-stream gradients before the zero fill
         self.flat_g.zero_()
         for b in self.buckets:
             b.reset_step()
@@ -500,6 +505,15 @@ class Trainer:
         for b in self.buckets:
             b.lazy_join = True      # a backward may leave leaf gradients on a side stream behind bucket.ready_event (train/cmm_train.py)
 
+    def disarm(self):
+        """End the promise of arm_early_step() without a step (an exception after the backward, a caller that wants to read the
+        gradients): the current stream waits for every gradient a backward left on a side stream, and later backwards join their
+        side streams themselves again.  Trainer.step() and zero_grad() call it; it is idempotent."""
+        self._armed = False
+        for b in self.buckets:
+            b._wait_ready_event()
+            b.lazy_join = False
+
     def _early_step(self, g):
         if not getattr(self, "_armed", False) or self.t_dev is not None or torch.cuda.is_current_stream_capturing():
             return          # hipGraph capture / device-side step counter: the step stays in Trainer.step()
@@ -537,9 +551,7 @@ class Trainer:
         else:
             for g in pending:
                 g.step(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
-        self._armed = False
-        for b in self.buckets:
-            b.lazy_join = False
+        self.disarm()       # (every ready_event was consumed by the group steps above: nothing left to wait for)
         if early:
             torch.cuda.current_stream(self.flat_p.device).wait_stream(self.opt_stream)
         packing.ACTIVE = None       # the packs are stale from here on

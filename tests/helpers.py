@@ -90,32 +90,48 @@ def grad_error_vs_fixture(npz, key, g):
     return max(e_norm, e_smp, e_proj), amax
 
 
-def check_vs_f64(test, z, named, prefix="", factor=3.0, floor=1e-5):
+def check_vs_f64(test, z, named, prefix="", factor=3.0, floor=1e-5, per_tensor=10.0):
     """Adjudicated gradient check against a float64 fixture (tools/gen_golden.py gen_f64).  Per tensor t (relative error metric of
     grad_error_vs_fixture): e_ours[t] = our gradient vs the float64 result, e_ref[t] = the REFERENCE's own fp32 gradient vs it (stored
     in the fixture).  fp32 round-off is order-dependent, so single tensors scatter by several x either way (the CPU oracle -- the
-    reference's arithmetic in another operation order -- has per-tensor ratios from 0.1 to 12); the statement that holds and is
-    asserted is per MODEL: our worst tensor and our RMS over the tensors are within `factor` of the reference's own worst / RMS
-    (floor: models fp32 gets right to 1e-5 anyway).  Measured (profiles/r05*_parity_errors.json): the oracle 2.2 (worst) / 2.1 (RMS) at most;
-    the HIP path 0.0004 ... 1.5 on the seven models of the step fixture -- as close to float64 as the reference's fp32 or closer.
-    Exactly-zero true gradients (|f64| < 2e-3: conv biases in front of a batch-statistics BatchNorm, quirk Q11's unused weight_list)
-    must stay at round-off level.  Returns (worst ratio, rms ratio)."""
-    ours, ref, names = [], [], []
+    reference's arithmetic in another operation order -- has per-tensor ratios from 0.1 to 12).  Two statements are asserted:
+    * per MODEL: our worst tensor and our RMS over the tensors are within `factor` of the reference's own worst / RMS (floor: models
+      fp32 gets right to 1e-5 anyway);
+    * per TENSOR: e_ours[t] <= per_tensor * max(e_ref[t], 0.3 * RMS_t e_ref, floor) -- no single tensor may hide inside the model
+      statistics (a wrong gradient is off by O(1), i.e. 10^2 ... 10^5 x these bounds).
+    Tensors whose float64 gradient is exactly zero by construction (|f64| < 1e-9: conv biases in front of a batch-statistics
+    BatchNorm, quirk Q11's unused weight_list -- every such tensor of the fixtures is listed by this rule, none is merely small)
+    must stay at round-off level RELATIVE to the model's largest gradient entry; any other tensor, however small, takes the relative
+    checks above.  Returns (worst ratio, rms ratio)."""
+    ours, ref, names, zeros = [], [], [], []
+    gmax = 0.0
     for n in fixture_grad_names(z, prefix):
         err, amax = grad_error_vs_fixture(z, prefix + n, named[n])
-        if amax < 2e-3:
-            assert float(torch.as_tensor(named[n]).abs().max()) < 5e-3, n
+        gmax = max(gmax, amax)
+        if amax < 1e-9:
+            zeros.append((n, float(torch.as_tensor(named[n]).abs().max())))
             continue
         ours.append(err); ref.append(float(z[prefix + n + "::ref32_err"])); names.append(n)
     ours, ref = np.array(ours), np.array(ref)
+    if zeros:
+        zworst = max(zeros, key=lambda t: t[1])
+        record(test, "%slargest entry of a gradient that is exactly zero in float64 (%s), relative to the model's largest gradient entry" % (prefix, zworst[0]),
+               zworst[1] / max(gmax, 1e-30), 1e-5)
+        assert zworst[1] <= 1e-5 * gmax, "%s%s: %s should be zero, has |g| up to %.3e (largest gradient entry of the model %.3e)" % (test, prefix, zworst[0], zworst[1], gmax)
     iw = int(ours.argmax())
+    rms_ref = float(np.sqrt((ref ** 2).mean()))
     r_worst = float(ours.max() / max(ref.max(), floor))
-    r_rms = float(np.sqrt((ours ** 2).mean()) / max(np.sqrt((ref ** 2).mean()), floor))
+    r_rms = float(np.sqrt((ours ** 2).mean()) / max(rms_ref, floor))
+    r_each = ours / np.maximum(np.maximum(ref, 0.3 * rms_ref), floor)
+    ie = int(r_each.argmax())
     record(test, "%sworst tensor vs float64: ours %.2e (%s) / reference fp32 %.2e" % (prefix, ours.max(), names[iw], ref.max()), r_worst, factor)
     record(test, "%sRMS over %d tensors vs float64: ours %.2e / reference fp32 %.2e" % (prefix, len(names), float(np.sqrt((ours ** 2).mean())),
-                                                                                     float(np.sqrt((ref ** 2).mean()))), r_rms, factor)
+                                                                                     rms_ref), r_rms, factor)
+    record(test, "%sworst per-tensor ratio vs float64 (%s: ours %.2e / reference fp32 %.2e)" % (prefix, names[ie], ours[ie], ref[ie]), float(r_each[ie]), per_tensor)
     assert r_worst <= factor and r_rms <= factor, "%s%s: gradients are %.1fx (worst tensor %s) / %.1fx (RMS) as far from the float64 result as the reference's own fp32 gradients (allowed %.1fx)" % (
         test, prefix, r_worst, names[iw], r_rms, factor)
+    assert r_each[ie] <= per_tensor, "%s%s: tensor %s is %.1fx as far from the float64 result as the reference's own fp32 gradient of it (allowed %.1fx)" % (
+        test, prefix, names[ie], float(r_each[ie]), per_tensor)
     return r_worst, r_rms
 
 
