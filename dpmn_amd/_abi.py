@@ -300,6 +300,13 @@ def check(rc):
         raise DpmnError("libdpmn_hip error %d: %s" % (rc, lib.dpmn_last_error().decode()))
 
 
+# DPMN_COMPUTE_DTYPE = f32 | bf16 | x3 (or 0 | 1 | 2): the process-wide arithmetic mode of the MFMA kernels that have variants
+# (dpmn_set_compute_dtype, include/dpmn_hip.h) for tools and whole-suite test passes; the default is fp32 MFMA
+_mode = os.environ.get("DPMN_COMPUTE_DTYPE")
+if _mode:
+    check(lib.dpmn_set_compute_dtype({"f32": 0, "bf16": 1, "x3": 2}[_mode] if _mode in ("f32", "bf16", "x3") else int(_mode)))
+
+
 def dptr(t, allow_none=False):
     """Device pointer of a contiguous fp32 CUDA tensor (the only thing the C ABI accepts)."""
     if t is None:

@@ -202,6 +202,28 @@ __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
 __device__ __forceinline__ f32x4 mfma16_bf16(bf16x8 a, bf16x8 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
+// ---- "f32 via bf16x3" (dpmn_set_compute_dtype(2)): an fp32 value splits EXACTLY into three bf16 terms by truncation,
+//   x = h + m + l,  h = x with the low 16 bits cleared, m = (x - h) with the low 16 bits cleared, l = x - h - m   (8 + 8 + <= 8 bits),
+// and a product keeps the six terms of weight >= 2^-16:  x y ~= h h' + (h m' + m h') + (h l' + m m' + l h'); the three dropped ones
+// are < 2^-21 |x y| in the worst case, ~2^-25 |x y| on average (uniform mantissas) -- the rounding class of one fp32 multiply.  The
+// products run as six v_mfma_f32_16x16x32_bf16 (bf16 x bf16 is exact in fp32, accumulation fp32): 2500 / 6 = 417 TFLOP/s of
+// fp32-equivalent work against the 157 TFLOP/s of v_mfma_f32_16x16x4_f32.  Truncation instead of round-to-nearest: the same 11
+// vector instructions per pair of values, no overflow to inf for finite |x| up to FLT_MAX (rounding |x| > 3.39e38 to bf16 gives inf,
+// and inf - inf a NaN in the lower planes).  Non-finite inputs give non-finite outputs (NaN, where the fp32 pipe would keep an inf).
+// (a, b) -> three dwords of bf16 pairs (low half = a's term)
+__device__ __forceinline__ void x3_split2t(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  h = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                    // (hi16(b) << 16) | hi16(a)
+  const float ra = a - __uint_as_float(ua & 0xffff0000u), rb = b - __uint_as_float(ub & 0xffff0000u);      // exact
+  const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+  m = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+  const float sa = ra - __uint_as_float(va & 0xffff0000u), sb = rb - __uint_as_float(vb & 0xffff0000u);    // exact, <= 8 significant bits
+  l = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+}
+__device__ __forceinline__ void x3_split4t(const float4& v, uint2& h, uint2& m, uint2& l) {
+  x3_split2t(v.x, v.y, h.x, m.x, l.x);
+  x3_split2t(v.z, v.w, h.y, m.y, l.y);
+}
 struct ProfScope {
   int slot;
   hipStream_t st;

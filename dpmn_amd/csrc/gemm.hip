@@ -15,114 +15,9 @@
 // Reference call sites replaced: pgrm.py:188,194 (q/kv Linear after norm1_q/norm1_kv 322-323),
 // pgrm.py:82 (SKConv.proj), 92-95 (select + proj_head + residual), 30-31 (fc1+GELU after norm2 330),
 // 39 (fc2), tatt.py:209 / transformer_v2.py linears.
-#include <cstdlib>
-#include "common.h"
+#include "gemm_body.h"
 
 namespace {
-
-constexpr int PAD = 4;
-
-struct EpiArgs {
-  const float* bias;   // (N) or null
-  const float* res1;   // (M,N) or null, added after activation
-  const float* res2;   // (M,N) or null
-  float* colsum;       // (gridDim.x, N) per-block column sums of GELU(y) (SKConv GAP partials) or null
-  int act;             // ACT_*
-  float slope;         // PReLU slope
-  int atomic;          // 1: y += acc with fp32 atomics (split-K weight gradients); bias/act/res ignored
-  long zstride;        // k-loop split launches: != 0: split z STORES its partial result at y + z * zstride (no atomics; the caller adds
-                       // the splits in order)
-  // train-mode Dropout / DropPath on the Linear's output before the residual (Mlp.drop + DropPath, pgrm.py:40,330): k_gemm_kloop's
-  // bias + one-residual epilogue only; y = res1 + (acc + bias) * m_elem(flat index) * m_row(flat index / row_len)
-  float p_elem = 0.f, p_row = 0.f;
-  unsigned long long seed_elem = 0ull, seed_row = 0ull;
-  long row_len = 0;
-};
-
-struct ProArgs {
-  const float* ln_w;   // LayerNorm affine (K) -- PRO_LN
-  const float* ln_b;
-  float eps;
-  const float* sel;    // PRO_SKSEL: attention vectors A (B, G, K) ; x is (M, G*K)
-  int rows_per_image;  // PRO_SKSEL: L
-  int groups;          // PRO_SKSEL: G
-  const float* addv;   // PRO_ADD: second (M,K) operand added to x before the GEMM (pos-embed add)
-  const float* x2;     // PRO_CAT2: x = [x (M,k1) | x2 (M,K-k1)] channel concat read in place
-  int k1;
-};
-
-enum { PRO_NONE = 0, PRO_LN = 1, PRO_SKSEL = 2, PRO_ADD = 3, PRO_CAT2 = 4 };
-
-// ---------------------------------------------------------------------------------- epilogue
-// tile (nt, mt): lane holds y[m = m_base + (l&15)][n = n_base + (l>>4)*4 + r]
-// FULL: the caller guarantees that the whole tile lies inside (M, N) -- no edge predicates, i.e. no per-row / per-column
-// branches around the stores (with branches hipcc cannot count its memory operations and drains vmcnt(0), which on gfx9
-// also waits for the stores of the previous tile).
-template <int NT, int MT, bool FULL = false>
-__device__ __forceinline__ void epilogue(f32x4 (&acc)[NT][MT], int m0, int n0, int M, int N, int ldy, float* y,
-                                         const EpiArgs& e, float* red /*LDS >= 4*BN floats or null*/, int bn_cols,
-                                         int n_block0) {
-  const int lane = threadIdx.x & 63;
-  const int lm = lane & 15, lq = lane >> 4;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + nt * 16 + lq * 4;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool nfull = FULL || (n + 3 < N);
-    if (e.bias) {
-      if (nfull) b4 = *reinterpret_cast<const float4*>(e.bias + n);
-      else {
-        float t[4] = {0, 0, 0, 0};
-        for (int r = 0; r < 4; ++r) if (n + r < N) t[r] = e.bias[n + r];
-        b4 = make_float4(t[0], t[1], t[2], t[3]);
-      }
-    }
-    float cs[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int m = m0 + mt * 16 + lm;
-      float v[4] = {acc[nt][mt][0] + b4.x, acc[nt][mt][1] + b4.y, acc[nt][mt][2] + b4.z, acc[nt][mt][3] + b4.w};
-      const bool min_ = FULL || m < M;
-      if (min_ && e.atomic) {
-        for (int r = 0; r < 4; ++r)
-          if (n + r < N) atomicAdd(y + (size_t)m * ldy + n + r, acc[nt][mt][r]);
-      } else if (min_) {
-        if (e.colsum) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cs[r] += gelu_erf(v[r]);
-        }
-        apply_act4(v, e.act, e.slope);
-        const size_t off = (size_t)m * ldy + n;
-        if (nfull) {
-          if (e.res1) { float4 q = *reinterpret_cast<const float4*>(e.res1 + off); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
-          if (e.res2) { float4 q = *reinterpret_cast<const float4*>(e.res2 + off); v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w; }
-          *reinterpret_cast<float4*>(y + off) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-          for (int r = 0; r < 4; ++r) if (n + r < N) {
-            float o = v[r];
-            if (e.res1) o += e.res1[off + r];
-            if (e.res2) o += e.res2[off + r];
-            y[off + r] = o;
-          }
-        }
-      }
-    }
-    if (e.colsum) {
-      // reduce over the 16 token lanes of each quad (xor 1,2,4,8 stays inside l&15), then over waves via LDS
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = cs[r];
-        s += xshfl<1>(s); s += xshfl<2>(s); s += xshfl<4>(s); s += xshfl<8>(s);
-        cs[r] = s;
-      }
-      if (lm == 0) {
-        const int wave = threadIdx.x >> 6;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave * bn_cols + (n - n_block0) + r] = cs[r];
-      }
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------- whole-K, W-stationary
 // Persistent blocks: the (BN=96 x K) weight tile is loaded into LDS ONCE per block; the block then walks over
@@ -843,166 +738,6 @@ __global__ __launch_bounds__(256, 2) void k_gemm_pw_bf16(const float* __restrict
   }
 }
 
-// ---------------------------------------------------------------------------------- pointwise GEMM, fp32 through three bf16 terms
-// dpmn_set_compute_dtype(2) ("f32 via bf16x3"): the fp32 pipe of gfx950 (v_mfma_f32_16x16x4_f32, 157 TFLOP/s) is the roof k_gemm_pw has
-// sat under for four rounds (0.76-0.78); the bf16 pipe is 16 x wider.  An fp32 value splits EXACTLY into three bf16 terms,
-//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)   (8 + 8 + 8 mantissa bits, round to nearest),
-// and a product keeps the six terms of weight >= 2^-16:  x y ~= x0 y0 + (x0 y1 + x1 y0) + (x0 y2 + x1 y1 + x2 y0); the three dropped
-// ones are <= 2^-23 |x y| -- the rounding class of one fp32 multiply.  Accumulation stays fp32 inside the MFMA.  Six
-// v_mfma_f32_16x16x32_bf16 per (tile, 32-deep chunk): 2500 / 6 = 417 TFLOP/s of fp32-equivalent work at the bf16 peak.
-// Same 128 x BC tile and staging layouts as k_gemm_pw_bf16, one LDS buffer holding the three planes of both operands (71 KB at
-// BC = 192, two blocks per CU) with the next chunk's rows prefetched into registers; the split (11 vector instructions per pair of
-// values) runs once per staged element, between the two barriers of a chunk -- the other resident block's MFMAs cover it.
-__device__ __forceinline__ unsigned x3_pack2(float a, float b) {
-  typedef float f32x2_ __attribute__((ext_vector_type(2)));
-  return __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2_){a, b}, bf16x2));
-}
-// (a, b) -> three dwords of bf16 pairs (low half = a's term)
-#ifndef X3_ABLATE_SPLIT
-#define X3_ABLATE_SPLIT 0      // timing experiment only: 1 = no split arithmetic (all three planes = the rounded value)
-#endif
-__device__ __forceinline__ void x3_split2(float a, float b, unsigned& h, unsigned& m, unsigned& l) {
-  h = x3_pack2(a, b);
-  if (X3_ABLATE_SPLIT) { m = h; l = h; return; }
-  float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xffff0000u);
-  m = x3_pack2(ra, rb);
-  ra -= __uint_as_float(m << 16); rb -= __uint_as_float(m & 0xffff0000u);
-  l = x3_pack2(ra, rb);
-}
-// Persistent: one 512-thread block per CU walks its tiles (768 tiles of 128 x 192 at B = 48, Ch = 384 = exactly 3 per CU; a
-// 2-blocks-per-CU launch of the same tiles needs two rounds, the second half empty).  Both LDS buffers fit (2 x 71 KB): chunk
-// k + 1 is split and stored while the other waves still multiply chunk k -- one barrier per chunk; its rows are loaded BEFORE the
-// MFMA block of chunk k (scheduling barriers keep hipcc from sinking the loads to their use).  Wave (ws_, wc_) = 64 (s) x 48 (co)
-// of the tile.  Tile order: the co blocks of one (image, s tile) run side by side on one XCD (they share the G rows).
-template <int BC>
-__global__ __launch_bounds__(512, 1) void k_gemm_pw_bf16x3(const float* g, const float* w, const float* __restrict__ bias, float* z, int Ch,
-                                                            int L, int B) {
-  constexpr int BS = 128, BK = 32, LDP = BS + 4, LDWB = BK + 8, NJ = BC / 64, TH = 512;
-  constexpr int GPL = (BK / 2) * LDP, WPL = BC * LDWB;            // one plane of G (dwords) / of W (bf16)
-  constexpr int BUF = 3 * GPL + 3 * WPL / 2;                      // dwords per buffer
-  constexpr int WQ = BC * BK / 4 / TH;                            // float4 of the W chunk per thread (3 at BC = 192, 2 at 128)
-  static_assert(BC * BK / 4 % TH == 0 && WQ <= 3, "W chunk: whole float4 per thread");
-  extern __shared__ __attribute__((aligned(16))) unsigned x3smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ns = L / BS, nco = Ch / BC;
-  const int tiles = ns * nco * B;
-  const int gp_ = tid >> 5, gcol = (tid & 31) * 4;      // pair row gp_ (channels 2 gp_, 2 gp_ + 1), 4 consecutive s
-  const int wrow = tid >> 3, wcol = (tid & 7) * 4;      // W rows wrow (+64 per pass), 4 consecutive k
-  const int ws_ = wave & 1, wc_ = wave >> 1;            // 2 (s) x 4 (co) waves
-  const int lr = lane & 15, kq = lane >> 4;
-  typedef unsigned u32x4__ __attribute__((ext_vector_type(4)));
-  const int nk = Ch / BK;
-  const int go = gp_ * LDP + gcol;                       // LDS offsets of this thread's stores
-  const int wo = wrow * LDWB + wcol;
-  const bool xcd_order = tiles % 8 == 0 && gridDim.x % 8 == 0;
-  int round = 0;
-  for (int t = blockIdx.x; t < tiles; t += gridDim.x, ++round) {
-    // XCD x takes a contiguous eighth of the (image, s tile, co block) list
-    const int lt = xcd_order ? (int)(blockIdx.x & 7) * (tiles / 8) + round * (int)(gridDim.x / 8) + (int)(blockIdx.x >> 3) : t;
-    const int cb = lt % nco, sb = (lt / nco) % ns, b = lt / (nco * ns);
-    const int s_blk = sb * BS, c_blk = cb * BC;
-    const float* gsrc = g + (size_t)b * Ch * L + (size_t)(2 * gp_) * L + s_blk + gcol;      // + k0 * L
-    const float* wsrc = w + (size_t)(c_blk + wrow) * Ch + wcol;                              // + k0 (+ 64 q rows)
-    float* zb = z + (size_t)b * Ch * L;
-    // two named register sets (a, b) hold the chunks kt + 1 and kt + 2: a set is loaded right after the split + store that frees it,
-    // a whole barrier + MFMA block before it is consumed, so the split / LDS stores of chunk kt + 1 can be dealt into the MFMA block
-    // of chunk kt (no scheduling barrier between them) instead of running, exposed, between the last MFMA and the barrier
-    float4 ag0, ag1, aw0, aw1, aw2, bg0, bg1, bw0, bw1, bw2;
-#define X3_GLOAD(P, k0)                                                                           \
-    do {                                                                                          \
-      P##g0 = *reinterpret_cast<const float4*>(gsrc + (size_t)(k0) * L);                          \
-      P##g1 = *reinterpret_cast<const float4*>(gsrc + (size_t)((k0) + 1) * L);                    \
-      P##w0 = *reinterpret_cast<const float4*>(wsrc + (k0));                                      \
-      P##w1 = *reinterpret_cast<const float4*>(wsrc + (size_t)64 * Ch + (k0));                    \
-      if (WQ > 2) P##w2 = *reinterpret_cast<const float4*>(wsrc + (size_t)128 * Ch + (k0));       \
-    } while (0)
-#define X3_WST(buf, q, V)                                                                         \
-    do {                                                                                          \
-      uint2 h2, m2, l2;                                                                           \
-      x3_split2(V.x, V.y, h2.x, m2.x, l2.x);                                                      \
-      x3_split2(V.z, V.w, h2.y, m2.y, l2.y);                                                      \
-      unsigned short* d_ = reinterpret_cast<unsigned short*>((buf) + 3 * GPL) + wo + (q) * 64 * LDWB; \
-      *reinterpret_cast<uint2*>(d_) = h2;                                                         \
-      *reinterpret_cast<uint2*>(d_ + WPL) = m2;                                                   \
-      *reinterpret_cast<uint2*>(d_ + 2 * WPL) = l2;                                               \
-    } while (0)
-#define X3_SSTORE(P, buf)                                                                         \
-    do {                                                                                          \
-      uint4 h4, m4, l4;                                                                           \
-      x3_split2(P##g0.x, P##g1.x, h4.x, m4.x, l4.x);                                              \
-      x3_split2(P##g0.y, P##g1.y, h4.y, m4.y, l4.y);                                              \
-      x3_split2(P##g0.z, P##g1.z, h4.z, m4.z, l4.z);                                              \
-      x3_split2(P##g0.w, P##g1.w, h4.w, m4.w, l4.w);                                              \
-      *reinterpret_cast<uint4*>((buf) + go) = h4;                                                 \
-      *reinterpret_cast<uint4*>((buf) + GPL + go) = m4;                                           \
-      *reinterpret_cast<uint4*>((buf) + 2 * GPL + go) = l4;                                       \
-      X3_WST(buf, 0, P##w0); X3_WST(buf, 1, P##w1);                                               \
-      if (WQ > 2) X3_WST(buf, 2, P##w2);                                                          \
-    } while (0)
-#define X3_TERM(PA, PW)                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                 \
-          _Pragma("unroll") for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16_bf16(a3[i][PA], wf[PW][j], acc[i][j]);
-#define X3_MMA(cur)                                                                               \
-    do {                                                                                          \
-      const unsigned short* Wb = reinterpret_cast<const unsigned short*>((cur) + 3 * GPL);        \
-      bf16x8 wf[3][NJ];                                                                           \
-      _Pragma("unroll") for (int pl = 0; pl < 3; ++pl)                                            \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                            \
-          wf[pl][j] = *reinterpret_cast<const bf16x8*>(Wb + pl * WPL + (wc_ * (BC / 4) + j * 16 + lr) * LDWB + kq * 8); \
-      const unsigned* gp = (cur) + (kq * 4) * LDP + ws_ * 64 + lr;                                \
-      bf16x8 a3[4][3];                                                                            \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                               \
-        _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                        \
-          const unsigned* q = gp + pl * GPL + i * 16;                                             \
-          const u32x4__ av = {q[0], q[LDP], q[2 * LDP], q[3 * LDP]};                              \
-          a3[i][pl] = __builtin_bit_cast(bf16x8, av);                                             \
-        }                                                                                         \
-      /* six terms, smallest first; consecutive MFMAs go to different accumulators */             \
-      X3_TERM(2, 0) X3_TERM(1, 1) X3_TERM(0, 2) X3_TERM(1, 0) X3_TERM(0, 1) X3_TERM(0, 0)         \
-    } while (0)
-    f32x4 acc[4][NJ];   // [s tile][co tile]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    unsigned* buf0 = x3smem;
-    unsigned* buf1 = x3smem + BUF;
-    __syncthreads();                       // the previous tile's last chunk is consumed
-    X3_GLOAD(a, 0);
-    X3_SSTORE(a, buf0);
-    X3_GLOAD(a, min(1, nk - 1) * BK);      // (past the end: clamped re-reads / a spare store, never a conditional load)
-    X3_GLOAD(b, min(2, nk - 1) * BK);
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-      X3_MMA(buf0);
-      X3_SSTORE(a, buf1);                  // chunk kt + 1; buf1's readers passed the previous barrier
-      X3_GLOAD(a, min(kt + 3, nk - 1) * BK);
-      __syncthreads();
-      if (kt + 1 >= nk) break;
-      X3_MMA(buf1);
-      X3_SSTORE(b, buf0);                  // chunk kt + 2
-      X3_GLOAD(b, min(kt + 4, nk - 1) * BK);
-      __syncthreads();
-    }
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int co = c_blk + wc_ * (BC / 4) + j * 16 + lr;
-      const float bv = bias[co];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int s_ = s_blk + ws_ * 64 + i * 16 + kq * 4;
-        *reinterpret_cast<float4*>(zb + (size_t)co * L + s_) =
-            make_float4(acc[i][j][0] + bv, acc[i][j][1] + bv, acc[i][j][2] + bv, acc[i][j][3] + bv);
-      }
-    }
-  }
-#undef X3_GLOAD
-#undef X3_WST
-#undef X3_SSTORE
-#undef X3_TERM
-#undef X3_MMA
-}
-
 // ---------------------------------------------------------------------------------- whole-K, rows straight into the B operand
 // The scheme of the fused attention kernel's projection (attn_fused.hip) for the K <= 192 token GEMMs: a WAVE owns a 16-token
 // tile; lane (j = l & 15, kq = l >> 4) loads x[token j][16 c + 4 kq .. + 3] straight from global memory into the MFMA B-operand
@@ -1592,7 +1327,8 @@ int dpmn_linear_f32(const float* x, const float* w, const float* bias, const flo
   DPMN_REQUIRE(K % 32 == 0, "linear: K must be a multiple of 32");
   dim3 grid(cdiv(M, 64), cdiv(N, 96));
   ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N * (res1 ? 2 : 1) + (double)N * K));
-  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
+  if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop(x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L, grid, as_stream(stream));
+  else hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -1609,7 +1345,8 @@ int dpmn_linear_drop_f32(const float* x, const float* w, const float* bias, cons
   e.p_elem = p_elem; e.p_row = p_row; e.seed_elem = seed_elem; e.seed_row = seed_row; e.row_len = row_len;
   dim3 grid(cdiv(M, 64), cdiv(N, 96));
   ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N * 2 + (double)N * K));
-  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
+  if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop(x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L, grid, as_stream(stream));
+  else hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }
@@ -1714,7 +1451,9 @@ int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, 
   DPMN_REQUIRE(dz && g && dw && L % 32 == 0 && Ch % 4 == 0, "pointwise_wgrad: bad arguments");
   EpiArgs e{nullptr, nullptr, nullptr, nullptr, ACT_NONE, 0.f, 1};   // split over (b, s), atomic accumulation
   dim3 grid(cdiv(Ch, 64), cdiv(Ch, 96), 32);
-  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, dw, Ch, Ch, Ch, B * L, e, L,
+  if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop(dz, L, g, L, dw, Ch, Ch, Ch, B * L, e, L,
+                     (long)Ch * L, (long)Ch * L, grid, as_stream(stream));
+  else hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, dw, Ch, Ch, Ch, B * L, e, L,
                      (long)Ch * L, (long)Ch * L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -1746,48 +1485,20 @@ int dpmn_pointwise_wgrad_det_f32(const float* dz, const float* g, float* dw, int
   if (s128) {
     const int nchunks = B * (L / 32);
     ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * Ch * (double)Ch * B * L, 4.0 * (2.0 * B * Ch * (double)L + (double)Ch * Ch));
-    hipLaunchKernelGGL(k_gemm_kloop128, dim3((Ch / 128) * (Ch / 128) * S), dim3(256), 0, as_stream(stream), dz, g, ws, Ch, Ch, L, nchunks, S,
+    if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop128(dz, g, ws, Ch, Ch, L, nchunks, S, (long)Ch * L, (long)Ch * Ch, as_stream(stream));
+    else hipLaunchKernelGGL(k_gemm_kloop128, dim3((Ch / 128) * (Ch / 128) * S), dim3(256), 0, as_stream(stream), dz, g, ws, Ch, Ch, L, nchunks, S,
                        (long)Ch * L, (long)Ch * Ch);
     DPMN_CHECK_LAUNCH();
     return dpmn_rows_reduce_f32(ws, dw, nullptr, Ch * Ch, 0, S, stream);
   }
   EpiArgs e{nullptr, nullptr, nullptr, nullptr, ACT_NONE, 0.f, 0, (long)Ch * Ch};
   dim3 grid(cdiv(Ch, 64), cdiv(Ch, 96), S);
-  hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, ws, Ch, Ch, Ch, B * L, e, L,
+  if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop(dz, L, g, L, ws, Ch, Ch, Ch, B * L, e, L,
+                     (long)Ch * L, (long)Ch * L, grid, as_stream(stream));
+  else hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, ws, Ch, Ch, Ch, B * L, e, L,
                      (long)Ch * L, (long)Ch * L);
   DPMN_CHECK_LAUNCH();
   return dpmn_rows_reduce_f32(ws, dw, nullptr, Ch * Ch, 0, S, stream);
-}
-
-// per-stream device scratch of the bf16x3 variants (weight planes): grows on demand, never shrinks; stream-ordered reuse
-static void* x3_scratch(hipStream_t st, size_t bytes) {
-  struct Ent { hipStream_t st; void* p; size_t n; };
-  static Ent tab[16];
-  static int cnt = 0;
-  for (int i = 0; i < cnt; ++i)
-    if (tab[i].st == st) {
-      if (tab[i].n >= bytes) return tab[i].p;
-      (void)hipStreamSynchronize(st);
-      (void)hipFree(tab[i].p);
-      tab[i].p = nullptr; tab[i].n = 0;
-      if (hipMalloc(&tab[i].p, bytes) != hipSuccess) return nullptr;
-      tab[i].n = bytes;
-      return tab[i].p;
-    }
-  if (cnt >= 16) return nullptr;
-  void* p = nullptr;
-  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
-  tab[cnt++] = Ent{st, p, bytes};
-  return p;
-}
-static int x3_cu_count() {
-  static int n_cu = 0;
-  if (!n_cu) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
-  }
-  return n_cu;
 }
 
 int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L,
@@ -1796,21 +1507,8 @@ int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float*
   static const int pw_bc = getenv("DPMN_PW_BC") ? atoi(getenv("DPMN_PW_BC")) : 192;
   ProfScope prof(PT_GEMM_PW, as_stream(stream), 2.0 * Ch * Ch * (double)L * B, 4.0 * (2.0 * B * Ch * (double)L + (double)Ch * Ch + Ch));
   if (g_dpmn_x3) {
-    // fp32 product through six bf16 MFMAs of a three-term operand split (dpmn_set_compute_dtype(2))
-    constexpr int LDP_ = 132, LDWB_ = 40;
-    const int bc = Ch % 192 == 0 ? 192 : 128;
-    const size_t smem = (size_t)2 * 3 * (16 * LDP_ * 4 + bc * LDWB_ * 2);
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pw_bf16x3<192>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (16 * LDP_ * 4 + 192 * LDWB_ * 2));
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_pw_bf16x3<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 3 * (16 * LDP_ * 4 + 128 * LDWB_ * 2));
-      attr_set = true;
-    }
-    const long tiles = (long)(L / 128) * (Ch / bc) * B;
-    const int n_cu = x3_cu_count();
-    const unsigned grid = (unsigned)(tiles < n_cu ? tiles : n_cu);
-    if (bc == 192) hipLaunchKernelGGL((k_gemm_pw_bf16x3<192>), dim3(grid), dim3(512), smem, as_stream(stream), g, w, bias, z, Ch, L, B);
-    else hipLaunchKernelGGL((k_gemm_pw_bf16x3<128>), dim3(grid), dim3(512), smem, as_stream(stream), g, w, bias, z, Ch, L, B);
+    // fp32 product through six bf16 MFMAs of a three-term operand split (dpmn_set_compute_dtype(2), gemm_x3.hip)
+    if (dpmn_gemm::x3_launch_pw(g, w, bias, z, B, Ch, L, as_stream(stream)) != 0) return dpmn_set_error(DPMN_ERR_LAUNCH, "pointwise: bf16x3 launch failed");
   } else if (g_dpmn_bf16 && Ch % 192 == 0)
     hipLaunchKernelGGL((k_gemm_pw_bf16<192>), dim3(L / 128, Ch / 192, B), dim3(256), 0, as_stream(stream), g, w, bias, z, Ch, L);
   else if (g_dpmn_bf16)

@@ -14,6 +14,47 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Every GPU parity test runs twice: in the library's default arithmetic (fp32 MFMA, v_mfma_f32_16x16x4_f32) and in mode 2, "f32 via
+# bf16x3" (dpmn_set_compute_dtype(2): fp32 products as six bf16 MFMAs of an exact three-term operand split in the kernels that have
+# the variant) -- same tests, same tolerances.  Modules that switch the mode themselves, spawn their own processes or hold no MFMA
+# kernel with a variant run once.  DPMN_TEST_MODES=f32 | x3 | f32,x3 restricts the passes.
+X3_EXEMPT = ("test_gpu_x3.py", "test_gpu_bf16.py", "test_gpu_multirank.py", "test_gpu_dataset.py", "test_gpu_stn.py", "test_gpu_dp.py")
+
+
+def _modes():
+    m = [t for t in os.environ.get("DPMN_TEST_MODES", "f32,x3").split(",") if t in ("f32", "x3")]
+    return m or ["f32"]
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.definition.get_closest_marker("gpu") is None:
+        return
+    if os.path.basename(str(metafunc.definition.fspath)) in X3_EXEMPT:
+        return
+    if "_compute_mode" not in metafunc.fixturenames:
+        metafunc.fixturenames.append("_compute_mode")
+    metafunc.parametrize("_compute_mode", _modes(), indirect=True, scope="function")
+
+
+@pytest.fixture
+def _compute_mode(request):
+    mode = getattr(request, "param", "f32")
+    if mode == "f32":
+        yield mode
+        return
+    from dpmn_amd import _abi
+    import helpers
+    _abi.check(_abi.lib.dpmn_set_compute_dtype(2))
+    n0 = len(helpers.RECORD)
+    try:
+        yield mode
+    finally:
+        _abi.lib.dpmn_set_compute_dtype(0)
+        for r in helpers.RECORD[n0:]:
+            r["test"] = "x3:" + r["test"]
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

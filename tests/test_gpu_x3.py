@@ -71,3 +71,107 @@ def test_pointwise_gemm_x3_is_fp32_class(x3_mode, B, Ch, L):
     assert torch.isfinite(got).all()
     ref64 = (w.double() @ g2.reshape(B, Ch, L).double() + b.double()[None, :, None]).reshape(B, L, Ch)
     assert rel(got, ref64) <= 2.0 * rel(ref32, ref64) + 1e-9
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("segs,cout,k,stride,pad,dil,H,W,B,aff", [
+    ((64,), 128, 4, 2, 3, 2, 32, 128, 4, False),       # EncodeBlock first conv (cmm.py:44): implicit GEMM, 128 x 128 tiles
+    ((128,), 256, 4, 2, 3, 2, 16, 64, 4, True),        # the same with the BatchNorm affine on load (training forward)
+    ((256, 256, 256), 128, 3, 1, 1, 1, 4, 16, 3, False),   # deep decoder conv: split-K partial slabs + reduce launch
+    ((256, 256), 256, 3, 1, 1, 1, 2, 8, 6, True),      # split-K with affine, M = 96 (ragged row tile)
+    ((64,), 64, 4, 2, 1, 1, 32, 128, 2, False),        # 64 x 64 tiles
+    ((32, 32), 96, 4, 2, 1, 1, 6, 10, 3, True),        # 64 x 64 tiles, two segments, odd plane, Cout not a multiple of 64
+    ((64,), 64, 3, 1, 1, 1, 16, 64, 4, False),         # halo kernel, 8-row tiles
+    ((64, 64), 128, 3, 1, 1, 1, 32, 128, 2, True),     # halo kernel, two segments, affine
+    ((32,), 64, 3, 1, 1, 1, 8, 16, 2, False),          # halo kernel, 4-row tiles (few blocks)
+    ((96,), 64, 1, 1, 0, 1, 7, 9, 3, False),           # 1 x 1
+])
+def test_conv_x3_is_fp32_class(x3_mode, segs, cout, k, stride, pad, dil, H, W, B, aff):
+    """Implicit-GEMM and halo convs (cmm.py:38-77, tsrn.py:83-110) in mode 2 vs fp32-MFMA vs float64 on the same fp32 operands."""
+    import torch.nn.functional as F
+    from dpmn_amd import ops
+    from dpmn_amd.model import packing
+    xs = [u("s%d" % i, (B, c, H, W), -2, 2) for i, c in enumerate(segs)]
+    cin = sum(segs)
+    w = u("w", (cout, cin, k, k)) * (1.0 / (cin * k * k) ** 0.5)
+    b = u("b", (cout,))
+    sc = [u("sc%d" % i, (c,), 0.5, 1.5) for i, c in enumerate(segs)]
+    sh = [u("sh%d" % i, (c,), -0.3, 0.3) for i, c in enumerate(segs)]
+    if aff:      # the kernel's fp32 affine (mul, then add) is part of the operand: reproduce it in fp32, then go to float64
+        xa = torch.cat([x * s_[None, :, None, None] + h[None, :, None, None] for x, s_, h in zip(xs, sc, sh)], 1)
+    else:
+        xa = torch.cat(xs, 1)
+    ref64 = F.conv2d(F.leaky_relu(xa, 0.2).double(), w.double(), b.double(), stride=stride, padding=pad, dilation=dil)
+    wp, bp = packing.pack_conv(w.to(dev), b.to(dev))
+    run = lambda: ops.conv2d([nhwc(x).to(dev) for x in xs], wp, bp, cout, k, stride=stride, pad=pad, dil=dil, pro_act="leaky02",
+                             affine=[(s_.to(dev), h.to(dev)) for s_, h in zip(sc, sh)] if aff else None).permute(0, 3, 1, 2)
+    ref32 = run()
+    with x3_mode:
+        got = run()
+        got_again = run()
+    assert torch.equal(got, got_again)
+    e32, e3, d = rel(ref32, ref64), rel(got, ref64), rel(got, ref32)
+    tag = "x3_conv_%s_%d_k%d" % ("+".join(map(str, segs)), cout, k)
+    record(tag, "fp32-MFMA kernel rel L2 vs float64", e32)
+    record(tag, "bf16x3 kernel rel L2 vs float64", e3, 2.0 * e32)
+    record(tag, "bf16x3 vs fp32-MFMA kernel rel L2", d, 2e-6)
+    assert e3 <= 2.0 * e32 + 1e-8, "bf16x3 conv is further from float64 (%.2e) than twice the fp32 kernel (%.2e)" % (e3, e32)
+    assert d < 2e-6
+
+
+def test_conv_x3_transposed_phases_groups_and_extreme_operands(x3_mode):
+    """ConvTranspose2d(4, 2, 1) as four fused phases, the grouped twin-encoder launch, and operands at the corners of the split
+    (exact bf16 values, 1e-30 / 1e+20 scales, zeros, near-FLT_MAX finite values): finite results, fp32-class errors."""
+    import torch.nn.functional as F
+    from dpmn_amd import ops
+    from dpmn_amd.model import packing
+    B, cin, cout, H, W = 4, 128, 128, 8, 32
+    x = u("xt", (B, cin, H, W), -2, 2)
+    w4 = u("w4", (cin, cout, 4, 4)) * (1.0 / (cin * 4) ** 0.5)
+    b = u("bt", (cout,))
+    ref64 = F.conv_transpose2d(F.relu(x).double(), w4.double(), b.double(), stride=2, padding=1)
+    xd = nhwc(x).to(dev)
+    packs = packing.pack_convT_s2k4(w4.to(dev), b.to(dev))
+    ref32 = ops.convT_s2k4([xd], packs, cout, pro_act="relu").permute(0, 3, 1, 2)
+    with x3_mode:
+        got = ops.convT_s2k4([xd], packs, cout, pro_act="relu").permute(0, 3, 1, 2)
+    assert rel(got, ref64) <= 2.0 * rel(ref32, ref64) + 1e-8 and rel(got, ref32) < 2e-6
+    # grouped launch: images [B/2, B) use the second weight set
+    ws = [u("wg%d" % g, (cout, cin, 4, 4)) * (1.0 / (cin * 16) ** 0.5) for g in range(2)]
+    bs = [u("bg%d" % g, (cout,)) for g in range(2)]
+    x2 = u("xg", (B, cin, 16, 64), -2, 2)
+    pk = [packing.pack_conv(ws[g].to(dev), bs[g].to(dev)) for g in range(2)]
+    wp, bp = torch.stack([p[0] for p in pk]).contiguous(), torch.stack([p[1] for p in pk]).contiguous()
+    ref64 = torch.cat([F.conv2d(F.leaky_relu(x2[g * 2:(g + 1) * 2], 0.2).double(), ws[g].double(), bs[g].double(), stride=2, padding=1)
+                       for g in range(2)], 0)
+    run = lambda: ops.conv2d([nhwc(x2).to(dev)], wp, bp, cout, 4, stride=2, pad=1, pro_act="leaky02", groups=2).permute(0, 3, 1, 2)
+    ref32 = run()
+    with x3_mode:
+        got = run()
+    assert rel(got, ref64) <= 2.0 * rel(ref32, ref64) + 1e-8 and rel(got, ref32) < 2e-6
+    # corners of the split
+    x3 = u("xc", (2, 64, 16, 64), -2, 2)
+    x3[:, 0::4] = x3[:, 0::4].bfloat16().float()
+    x3[:, 1::4] *= 1e-30
+    x3[:, 2::4] *= 1e+20
+    x3[0, :, :3] = 0.0
+    w = u("wc", (64, 64, 3, 3)) * (1.0 / 24.0)
+    ref64 = F.conv2d(x3.double(), w.double(), None, padding=1)
+    wpc, _ = packing.pack_conv(w.to(dev), None)
+    run = lambda: ops.conv2d([nhwc(x3).to(dev)], wpc, None, 64, 3, pad=1).permute(0, 3, 1, 2)
+    ref32 = run()
+    with x3_mode:
+        got = run()
+    assert torch.isfinite(got).all()
+    assert rel(got, ref64) <= 2.0 * rel(ref32, ref64) + 1e-9
+    # finite operands next to FLT_MAX stay finite in every plane (truncation never rounds up to inf): 1 x 1 conv with one-hot weights
+    big = torch.full((1, 32, 8, 16), 3.4e38)
+    eye = torch.zeros(64, 32, 1, 1)
+    eye[torch.arange(32), torch.arange(32)] = 1.0
+    wpe, _ = packing.pack_conv(eye.to(dev), None)
+    with x3_mode:
+        got = ops.conv2d([nhwc(big).to(dev)], wpe, None, 64, 1)
+    assert torch.isfinite(got).all() and torch.equal(got[..., :32].cpu(), nhwc(big))
