@@ -34,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 MFMA (v_mfma_f32_16x16x4_f32), no TF32 on gfx950
+BF16X3_PEAK_TFLOPS = 2500.0 / 6   # "f32 via bf16x3": six v_mfma_f32_16x16x32_bf16 per fp32-class product at the ~2.5 PFLOP/s dense bf16 peak
 HBM_PEAK_GBS = 8000.0             # HBM3E spec (6.3 TB/s is the measured streaming ceiling)
 RIDGE = FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)   # FLOP per byte above which the MFMA roof bounds a kernel
 
@@ -67,6 +68,7 @@ def parse():
                     help="train mode: run the frozen PSN inside the step instead of prefetching the next batch's PSN image during it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="fwd mode: skip the `train` object (configs[2] step timed after the forward region)")
+    ap.add_argument("--no-x3", action="store_true", help="default line: skip the `x3` object (the same forward / training legs in mode 2, f32 via bf16x3)")
     ap.add_argument("--train-steps", type=int, default=10, help="timed steps of the `train` object")
     ap.add_argument("--no-kernel-profile", action="store_true", help="skip the per-kernel event timing (roofline = null)")
     ap.add_argument("--cpu-sample", type=int, default=None, help="images in the CPU-baseline sample (default: the per-GPU batch)")
@@ -434,6 +436,25 @@ def train_object(args, workload, world, rank, force_dist, dist, torch, _abi):
     return out
 
 
+def x3_rows(kernels):
+    """per-family rows of a mode-2 leg: the fraction of the fp32 pipe's peak stays (it can exceed 1: the products run on the bf16
+    pipe), plus the fraction of the bf16x3 ceiling (2500 / 6 = 417 TFLOP/s of fp32-equivalent work) for the MFMA-bound families"""
+    out = []
+    for k in kernels:
+        k = dict(k)
+        if k["bound"] == "mfma":
+            k["frac_of_bf16x3_peak"] = round(k["tflops"] / BF16X3_PEAK_TFLOPS, 4)
+        out.append(k)
+    return out
+
+
+X3_WHAT = ("mode 2, 'f32 via bf16x3' (dpmn_set_compute_dtype(2)): fp32 tensors everywhere; in the kernel families that have the variant "
+           "(implicit-GEMM conv 128 x 128, 3 x 3 halo conv on 8-row tiles, conv weight gradient 128 x 128, pointwise GEMM, k-loop GEMMs) every "
+           "operand is split exactly into three bf16 terms on the way into LDS and a product is six v_mfma_f32_16x16x32_bf16 with fp32 "
+           "accumulation (dropped terms < 2^-21 |x y|: the rounding class of an fp32 multiply); every other kernel is the fp32 one.  The whole "
+           "-m gpu parity suite runs in this mode too, same tolerances (tests/conftest.py).  `value` of the line stays the plain-fp32 number.")
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-baseline-worker":
         return cpu_baseline_worker(sys.argv[2], int(sys.argv[3]), sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "fwd")
@@ -501,6 +522,37 @@ def main():
         torch.cuda.synchronize()
         latency_ms = (time.perf_counter() - t0) / n_lat * 1e3
         PIPE_ON[0] = True
+    # the same forward in mode 2 (f32 via bf16x3), same process, same models and inputs: the `x3` object of the default line
+    want_x3 = (args.mode == "fwd" and args.workload == "cfg1" and args.prior == "synthetic" and not args.graph and args.dtype == "f32" and not args.no_x3)
+    x3 = None
+    if want_x3:
+        _abi.check(_abi.lib.dpmn_set_compute_dtype(2))
+        e3, live3, k3 = timed_leg(step, args.steps, max(2, args.warmup), profiling, torch, dist, _abi, unforked=() if pipelined else UNFORKED_FAMILIES)
+        lat3 = None
+        if pipelined:
+            PIPE_ON[0] = False
+            n_lat = max(4, args.steps // 2)
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n_lat):
+                step()
+            torch.cuda.synchronize()
+            lat3 = (time.perf_counter() - t0) / n_lat * 1e3
+            PIPE_ON[0] = True
+        _abi.check(_abi.lib.dpmn_set_compute_dtype(0))
+        if rank == 0:
+            roof3 = roofline_of(live3, args.steps, B, "fwd")
+            if roof3 and roof3["bound"] == "mfma":
+                roof3["frac_of_bf16x3_peak"] = round(roof3["achieved"] / BF16X3_PEAK_TFLOPS, 4)
+                roof3["traffic"], roof3["traffic_kind"] = None, None      # the committed PMC passes are fp32-mode runs
+            x3 = {"what": X3_WHAT, "dtype": "f32 (products as six bf16 MFMAs of a three-term operand split, fp32 accumulation)",
+                  "value": round(world * B * args.steps / e3, 2), "unit": "images/s", "ms_per_step": round(e3 / args.steps * 1e3, 3),
+                  "steps": args.steps, "batches_in_flight": max(1, args.pipeline),
+                  "one_batch_at_a_time": None if lat3 is None else {"ms_per_step": round(lat3, 3), "images_per_s": round(world * B / lat3 * 1e3, 2)},
+                  "peaks_tflops": {"fp32_mfma": FP32_MFMA_PEAK_TFLOPS, "bf16x3": round(BF16X3_PEAK_TFLOPS, 1)},
+                  "roofline": roof3, "kernels": x3_rows(k3)}
     if rank == 0:
         what = "forward" if args.mode == "fwd" else "training step"
         line = {
@@ -509,7 +561,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16": "bf16 MFMA operands in the implicit-GEMM convs / pointwise GEMM, fp32 accumulation, storage and statistics",
-                      "x3": "f32 via bf16x3 (pointwise GEMM: six bf16 MFMAs of an exact three-term operand split, fp32-class products; every other kernel plain f32)"}[args.dtype],
+                      "x3": "f32 via bf16x3 (implicit-GEMM / halo convs, conv weight gradients, pointwise and k-loop GEMMs: six bf16 MFMAs of an exact three-term operand split, fp32-class products; every other kernel plain f32)"}[args.dtype],
             "data": "synthetic",
             "config": {"workload": "%s: %s, %s" % (
                 args.workload, spec["text"],
@@ -535,8 +587,16 @@ def main():
     if args.mode == "fwd" and args.workload == "cfg1" and args.prior == "synthetic" and not args.no_train and not args.graph and args.dtype == "f32":
         del step
         train = train_object(args, workload, world, rank, force_dist, dist, torch, _abi)
+        if want_x3:
+            _abi.check(_abi.lib.dpmn_set_compute_dtype(2))
+            t3 = train_object(args, workload, world, rank, force_dist, dist, torch, _abi)
+            _abi.check(_abi.lib.dpmn_set_compute_dtype(0))
+            if rank == 0 and x3 is not None:
+                t3["kernels"] = x3_rows(t3.get("kernels", []))
+                x3["train"] = t3
     if rank == 0:
         line["train"] = train
+        line["x3"] = x3
         line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1 or args.mode != "fwd") else cpu_baseline(args.workload, args.cpu_sample or B, train=train is not None) if args.prior == "synthetic" else None   # N=1 only
         if train is not None and line["cpu_baseline"] and "train_step" in line["cpu_baseline"]:
             train["cpu_baseline"] = line["cpu_baseline"].pop("train_step")

@@ -676,10 +676,10 @@ int launch_halo_c4(const ConvArgs& a, hipStream_t st) {
 }
 
 template <int KS, int BN, int TH, bool BF = false>
-int launch_halo_th(const ConvArgs& a, hipStream_t st) {
+int launch_halo_th(const ConvArgs& a, hipStream_t st, bool x3 = false) {
   if constexpr (!BF && KS == 3 && BN == 64) {
     if (g_dpmn_bf16) return launch_halo_th<KS, BN, TH, true>(a, st);
-    if (g_dpmn_x3) {
+    if (x3) {
       ProfScope prof(PT_CONV_HALO, st, conv_flops(a), conv_bytes(a));
       if (dpmn_conv::x3_launch_halo(KS, BN, TH, a, dim3(a.B * (a.Hin / TH) * (a.Win / 16), cdiv(a.Cout, BN)), st) != 0)
         return dpmn_set_error(DPMN_ERR_LAUNCH, "conv2d: bf16x3 halo launch failed");
@@ -709,7 +709,13 @@ int launch_halo(const ConvArgs& a, hipStream_t st) {
   static const int force = getenv("DPMN_HALO_TH") ? atoi(getenv("DPMN_HALO_TH")) : 0;
   const long blocks8 = (long)a.B * (a.Hin / 8) * (a.Win / 16) * cdiv(a.Cout, BN);
   const bool small = force ? force == 4 : blocks8 < 768;
-  if (KS == 3 && small) return launch_halo_th<KS, BN, 4>(a, st);
+  // mode 2 ("f32 via bf16x3", conv_x3.hip): 8-row tiles only -- with one output row per wave the split of a tap's weight slice costs
+  // more vector time than the tap has MFMA time (measured: the 4-row variant is SLOWER than the fp32 kernel) -- and only where
+  // those tiles fill the chip (DPMN_X3_HALO_MIN blocks); the other layers keep the fp32 kernel
+  static const int x3_min = getenv("DPMN_X3_HALO_MIN") ? atoi(getenv("DPMN_X3_HALO_MIN")) : 384;
+  static const int x3_th4 = getenv("DPMN_X3_HALO_TH4") ? atoi(getenv("DPMN_X3_HALO_TH4")) : 0;
+  if (g_dpmn_x3 && KS == 3 && BN == 64 && blocks8 >= x3_min) return launch_halo_th<KS, BN, 8>(a, st, true);
+  if (KS == 3 && small) return launch_halo_th<KS, BN, 4>(a, st, g_dpmn_x3 && x3_th4);
   return launch_halo_th<KS, BN, 8>(a, st);
 }
 
@@ -833,8 +839,9 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st, unsigned
                ((size_t)a.B * a.Hin * a.Win + (size_t)(abs(a.pad_y) + a.KH * abs(a.dil_y) + 2) * a.Win) * a.cseg[i] * 4 < (1ull << 31);
     }
     simple = simple && (n_aff == 0 || n_aff == n_seg);       // mixed segments: the general UNI path
-  if (g_dpmn_x3 && simple && BM == BN && (BM == 128 || BM == 64)) {
-    if (dpmn_conv::x3_launch_igemm(BM, n_aff != 0, a, grid, st) != 0) return dpmn_set_error(DPMN_ERR_LAUNCH, "conv2d: bf16x3 launch failed");
+  static const int x3_t64 = getenv("DPMN_X3_TILE64") ? atoi(getenv("DPMN_X3_TILE64")) : 0;      // the 64 x 64 tile in mode 2: measured 93 vs 88 us (forward), 65 vs 60 (training step) -- off
+  if (g_dpmn_x3 && simple && ((BM == BN && (BM == 128 || (BM == 64 && x3_t64))) || (BM == 128 && BN == 64))) {
+    if (dpmn_conv::x3_launch_igemm(BM == BN ? BM : 12864, n_aff != 0, a, grid, st) != 0) return dpmn_set_error(DPMN_ERR_LAUNCH, "conv2d: bf16x3 launch failed");
   } else
   if (g_dpmn_bf16 && simple && BM == BN && (BM == 128 || BM == 64)) {
     if (n_aff) hipLaunchKernelGGL((k_conv_igemm<BM, BN, WM, WN, true, 32, true, true, true>), grid, dim3(256), 0, st, a);
@@ -1048,6 +1055,10 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
     }
     return launch_conv<128, 128, 2, 2>(a, ws, wsb, st, d->arrive_cnt, d->arrive_cnt_len);
   }
+  // mode 2 ("f32 via bf16x3"): 128-pixel row tiles -- the operand split of a 64 x 64 tile costs as many vector instructions as the
+  // tile has MFMA cycles (conv_x3.hip); the fp32 kernels keep the 64 x 64 tile (more blocks for the small maps)
+  static const int x3_rows128 = getenv("DPMN_X3_ROWS128") ? atoi(getenv("DPMN_X3_ROWS128")) : 0;      // measured: 73.7 vs 60.1 us (fp32 64 x 64) over the 18 launches of the training step -- off
+  if (g_dpmn_x3 && x3_rows128 && M >= 128 * 256 && (a.groups != 2 || a.m_per_group % 128 == 0)) return launch_conv<128, 64, 2, 2>(a, ws, wsb, st);
   return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
 }
 

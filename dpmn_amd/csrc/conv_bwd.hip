@@ -6,32 +6,11 @@
 //   k_se_gate_bwd     backward of the CMM channel gate (cmm.py:135-147)
 // Data gradients are ordinary convolutions of dY with re-packed weights and run through k_conv_igemm / k_conv_halo.
 #include <cstdlib>
-#include "common.h"
+#include "conv_wgrad.h"
 
 namespace {
 
-struct WgArgs {
-  const float* in[3];
-  const float* in_scale[3];
-  const float* in_shift[3];
-  int cseg[3];
-  int cin;
-  int B, Hin, Win, KH, KW, stride, dil_y, dil_x, pad_y, pad_x, Hp, Wp;
-  int Hout, Wout, ostep, ooy, oox;
-  int pro_act;
-  const float* dy;      // NHWC (B, Hout, Wout, Cout)
-  int Cout, K;          // K = KH*KW*cin
-  float* dw;            // dw[base + co*s_co + ci*s_ci + ky*s_ky + kx*s_kx] += ..., for co < co_lim, ci < ci_lim
-  long s_co, s_ci, s_ky, s_kx, base;
-  int co_lim, ci_lim;
-  int pix_per_block;
-  int gx, gy, gz;       // logical grid (co tiles, k tiles, pixel splits)
-  int nslots;           // > 1: split z accumulates into copy (z % nslots) of dw, copies slot_stride floats apart
-  long slot_stride;
-  int excl;             // packed destination with one slot PER split: plain stores, no atomics, slots need no zero-init
-  float inv_hw, inv_w;
-  int lgW, lgHW;        // P2 kernels: log2(Wp), log2(Hp * Wp)
-};
+using dpmn_conv::WgArgs;
 
 // exact m / d for 0 <= m < 2^24 through one float multiply and a +-1 fix-up
 __device__ __forceinline__ void fdivmod(int m, int d, float inv, int& q, int& r) {
@@ -891,6 +870,7 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
     if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256, true>), grid, dim3(256), 0, as_stream(stream), a);
     else if (bn == 64 && bk == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128, true>), grid, dim3(256), 0, as_stream(stream), a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_wgrad<64, 256, true>), grid, dim3(256), 0, as_stream(stream), a);
+    else if (g_dpmn_x3 && dpmn_conv::x3_wgrad_ok(a)) (void)dpmn_conv::x3_launch_wgrad(a, grid, as_stream(stream));
     else hipLaunchKernelGGL((k_conv_wgrad<128, 128, true>), grid, dim3(256), 0, as_stream(stream), a);
   } else
   if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256>), grid, dim3(256), 0, as_stream(stream), a);

@@ -6,13 +6,13 @@
 
 namespace {
 template <int BM, int BN, int WM, int WN, bool AFF>
-__global__ __launch_bounds__(256, 2) void k_conv_igemm_x3(ConvArgs a) {      // two resident blocks per CU
+__global__ __launch_bounds__(256, (BM * BN > 128 * 64 ? 2 : 3)) void k_conv_igemm_x3(ConvArgs a) {      // two (128 x 128: 61 KB) / three resident blocks per CU
   conv_igemm_body<BM, BN, WM, WN, true, 32, true, AFF, false, false, false, true>(a);
 }
 template <int KS, int BN, int TH>
 int halo_x3(const ConvArgs& a, dim3 grid, hipStream_t st) {
   constexpr int NPX = (TH + KS - 1) * (16 + KS - 1);
-  const size_t smem = (size_t)(3 * NPX + 2 * 3 * BN) * ((BK + 8) / 2) * sizeof(float);
+  const size_t smem = (size_t)(3 * NPX + 2 * 3 * BN) * ((BK + 16) / 2) * sizeof(float);      // 96-byte rows (conv_body.h LDH)
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_halo_x3<KS, BN, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -28,6 +28,9 @@ int x3_launch_igemm(int tile, bool aff, const ConvArgs& a, dim3 grid, hipStream_
   if (tile == 128) {
     if (aff) hipLaunchKernelGGL((k_conv_igemm_x3<128, 128, 2, 2, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_igemm_x3<128, 128, 2, 2, false>), grid, dim3(256), 0, st, a);
+  } else if (tile == 12864) {      // 128 pixels x 64 channels: Cout <= 64 (a 64 x 64 tile splits as many weight values as it multiplies)
+    if (aff) hipLaunchKernelGGL((k_conv_igemm_x3<128, 64, 2, 2, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_igemm_x3<128, 64, 2, 2, false>), grid, dim3(256), 0, st, a);
   } else if (tile == 64) {
     if (aff) hipLaunchKernelGGL((k_conv_igemm_x3<64, 64, 2, 2, true>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_conv_igemm_x3<64, 64, 2, 2, false>), grid, dim3(256), 0, st, a);

@@ -20,7 +20,7 @@ namespace {
 template <int BC>
 __global__ __launch_bounds__(512, 1) void k_gemm_pw_bf16x3(const float* g, const float* w, const float* __restrict__ bias, float* z, int Ch,
                                                             int L, int B) {
-  constexpr int BS = 128, BK = 32, LDP = BS + 4, LDWB = BK + 8, NJ = BC / 64, TH = 512;
+  constexpr int BS = 128, BK = 32, LDP = BS + 4, LDWB = BK + 16, NJ = BC / 64, TH = 512;      // W rows 96 bytes: conflict-free ds_read_b128 (conv_body.h)
   constexpr int GPL = (BK / 2) * LDP, WPL = BC * LDWB;            // one plane of G (dwords) / of W (bf16)
   constexpr int BUF = 3 * GPL + 3 * WPL / 2;                      // dwords per buffer
   constexpr int WQ = BC * BK / 4 / TH;                            // float4 of the W chunk per thread (3 at BC = 192, 2 at 128)
@@ -150,11 +150,11 @@ __global__ __launch_bounds__(512, 1) void k_gemm_pw_bf16x3(const float* g, const
 // ---------------------------------------------------------------------------------- k-loop, 64 x 96 tiles
 // k_gemm_kloop's contract (gemm.hip): y = epi(x w^T), x (M, K) / w (N, K) row-major with k contiguous, batched-K mode for reductions
 // that run over several images, split launches that store at y + z * zstride.  One LDS buffer of three planes per operand
-// (160 rows x 80 bytes x 3 = 38 KB: three blocks per CU), the next chunk's rows in registers during the MFMA block.
+// (160 rows x 96 bytes x 3 = 46 KB: three blocks per CU), the next chunk's rows in registers during the MFMA block.
 __global__ __launch_bounds__(256, 3) void k_gemm_kloop_x3(const float* __restrict__ x, int ldx, const float* __restrict__ w, int ldw,
                                                         float* __restrict__ y, int ldy, int M, int N, int K, EpiArgs e, int kb_len,
                                                         long x_bstride, long w_bstride) {
-  constexpr int BM = 64, BN = 96, BK = 32, LDKB = BK + 8, XPL = BM * LDKB, WPL = BN * LDKB;
+  constexpr int BM = 64, BN = 96, BK = 32, LDKB = BK + 16, XPL = BM * LDKB, WPL = BN * LDKB;      // 96-byte rows: conflict-free ds_read_b128 (conv_body.h)
   __shared__ __attribute__((aligned(16))) unsigned short Xs[3 * XPL];
   __shared__ __attribute__((aligned(16))) unsigned short Ws[3 * WPL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -267,10 +267,10 @@ __global__ __launch_bounds__(256, 3) void k_gemm_kloop_x3(const float* __restric
 
 // ---------------------------------------------------------------------------------- k-loop, 128 x 128 tiles (pointwise-conv weight gradient)
 // k_gemm_kloop128's contract: dW (M, N) = sum_b X_b (M, L) . Y_b (N, L)^T over the raw (B, Ch, L) views, the reduction (b, s) cut into
-// `splits` contiguous ranges of 32-wide chunks, split z stores its tile at y + z * zstride.  One LDS buffer (61 KB), two blocks per CU.
+// `splits` contiguous ranges of 32-wide chunks, split z stores its tile at y + z * zstride.  One LDS buffer (74 KB), two blocks per CU.
 __global__ __launch_bounds__(256, 2) void k_gemm_kloop128_x3(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                               int M, int N, int L, int nchunks, int splits, long bstride, long zstride) {
-  constexpr int BM = 128, BN = 128, BK = 32, LDKB = BK + 8, PL = BM * LDKB;
+  constexpr int BM = 128, BN = 128, BK = 32, LDKB = BK + 16, PL = BM * LDKB;
   __shared__ __attribute__((aligned(16))) unsigned short Xs[3 * PL];
   __shared__ __attribute__((aligned(16))) unsigned short Ws[3 * PL];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -380,7 +380,7 @@ int x3_launch_kloop128(const float* x, const float* w, float* y, int M, int N, i
   return 0;
 }
 int x3_launch_pw(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L, hipStream_t st) {
-  constexpr int LDP_ = 132, LDWB_ = 40;
+  constexpr int LDP_ = 132, LDWB_ = 48;
   const int bc = Ch % 192 == 0 ? 192 : 128;
   const size_t smem = (size_t)2 * 3 * (16 * LDP_ * 4 + bc * LDWB_ * 2);
   static bool attr_set = false;

@@ -23,14 +23,14 @@ const char* const kTagNames[PT_COUNT] = {
     "k_conv_wgrad", "k_gemm_tn_reg", "k_tn_reduce_multi", "k_dwconv_bwd", "k_wgrad_unpack_multi", "k_conv_pack_multi", "k_affine_act_bwd", "k_ln_bwd", "k_window_attn_mfma<4|8|16,32>"};
 struct Rec { int tag; double flops, bytes; };
 struct Prof {
-  int cap = 0, count = 0;
+  int cap = 0, count = 0, limit = 0;      // cap: allocated event pairs (only grows); limit: max_launches of the current dpmn_profile_begin
   hipEvent_t* ev = nullptr;
   Rec* rec = nullptr;
 } g_prof;
 }  // namespace
 
 int dpmn_prof_open(int tag, hipStream_t st, double flops, double bytes) {
-  if (g_prof.count >= g_prof.cap) return -1;
+  if (g_prof.count >= g_prof.limit) return -1;
   const int i = g_prof.count++;
   g_prof.rec[i] = Rec{tag, flops, bytes};
   (void)hipEventRecord(g_prof.ev[2 * i], st);
@@ -66,6 +66,7 @@ int dpmn_profile_begin(unsigned long long tag_mask, int max_launches) {
     g_prof.cap = max_launches;
   }
   g_prof.count = 0;
+  g_prof.limit = max_launches;
   g_dpmn_prof_mask = tag_mask;
   return DPMN_OK;
 }

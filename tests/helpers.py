@@ -142,7 +142,17 @@ RECORD = []
 
 
 def record(test, metric, value, tol=None):
-    RECORD.append({"test": test, "metric": metric, "value": float(value), "tol": None if tol is None else float(tol)})
+    """Rows of the mode-2 pass of the suite ("f32 via bf16x3", conftest.py _compute_mode) carry the prefix x3: -- read from the library,
+    so a test that switches the mode itself is labelled by what actually ran."""
+    mode = ""
+    try:
+        import sys
+        abi = sys.modules.get("dpmn_amd._abi")
+        if abi is not None and abi.lib.dpmn_get_compute_dtype() == 2:
+            mode = "x3:"
+    except Exception:
+        pass
+    RECORD.append({"test": mode + test, "metric": metric, "value": float(value), "tol": None if tol is None else float(tol)})
     return value
 
 

@@ -994,6 +994,8 @@ def test_step_that_never_reaches_the_optimizer_leaves_complete_gradients(dev):
             assert all(getattr(b, "ready_event", None) is None for b in trainer.buckets)
             trainer.step = real_step
             trainer.step()                              # finish the interrupted step by hand
+        else:
+            sr_.train_step(models, psn, distill, crit, trainer, *args, text_priors=pri)
         trainer.step = real_step
         l2 = sr_.train_step(models, psn, distill, crit, trainer, *args, text_priors=pri).clone()
         torch.cuda.synchronize()

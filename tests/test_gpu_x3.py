@@ -175,3 +175,38 @@ def test_conv_x3_transposed_phases_groups_and_extreme_operands(x3_mode):
     with x3_mode:
         got = ops.conv2d([nhwc(big).to(dev)], wpe, None, 64, 1)
     assert torch.isfinite(got).all() and torch.equal(got[..., :32].cpu(), nhwc(big))
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,B,H,W", [
+    (64, 128, 3, 1, 1, 1, 4, 16, 64),     # EncodeBlock second conv (cmm.py:49)
+    (128, 256, 4, 2, 3, 2, 4, 16, 64),    # EncodeBlock first conv: stride 2, dilation 2
+    (256, 512, 3, 1, 1, 1, 6, 4, 16),     # deep level: many tiles, few pixel splits
+])
+def test_conv_wgrad_x3_is_fp32_class(x3_mode, cin, cout, k, stride, pad, dil, B, H, W):
+    """Weight gradient of the implicit-GEMM conv (128 x 128 tile of the power-of-two fast path) in mode 2 vs fp32-MFMA vs float64."""
+    import torch.nn.functional as F
+    from dpmn_amd import ops
+    from dpmn_amd.train import pgrm_train
+    x = u("wx", (B, cin, H, W))
+    w = (u("ww", (cout, cin, k, k)) * 0.1).double().requires_grad_(True)
+    y = F.conv2d(F.leaky_relu(x, 0.2).double(), w, None, stride, pad, dil)
+    dy = u("wdy", tuple(y.shape))
+    y.backward(dy.double())
+    ref64 = w.grad
+    xn, dyn = nhwc(x).to(dev), nhwc(dy).to(dev)
+
+    def run():
+        d = ops.conv_desc([xn], k, stride, pad, dil, cout=cout, pro_act="leaky02")
+        dw = torch.zeros(cout, cin, k, k, device=dev)
+        pgrm_train.conv_wgrad_into(d, dyn, dw, "conv")
+        return dw
+    ref32 = run()
+    with x3_mode:
+        got = run()
+        again = run()
+    assert torch.equal(got, again)
+    e32, e3, dd = rel(ref32, ref64), rel(got, ref64), rel(got, ref32)
+    tag = "x3_wgrad_%dx%d_k%d" % (cin, cout, k)
+    record(tag, "fp32-MFMA kernel rel L2 vs float64", e32)
+    record(tag, "bf16x3 kernel rel L2 vs float64", e3, 2.0 * e32)
+    assert e3 <= 2.0 * e32 + 1e-8 and dd < 2e-6, (e32, e3, dd)
