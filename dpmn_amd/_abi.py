@@ -147,6 +147,7 @@ SIGNATURES = {
     "dpmn_reduce_defer_flush": (_i, [_i, fp]),
     "dpmn_xred_fallbacks": (_i, [C.POINTER(C.c_uint), _i]),
     "dpmn_selftest_xshfl": (_i, [C.POINTER(C.c_uint)]),
+    "dpmn_selftest_lds_poison": (_i, [C.c_uint, _i, fp]),
     "dpmn_xred_test_force_recompute": (_i, [_i]),
     "dpmn_xred_enable": (_i, [_i]),
     "dpmn_nchw_to_nhwc_f32": (_i, [fp, fp, _i, _i, _i, _i, _i, fp]),
@@ -278,6 +279,9 @@ SIGNATURES = {
     "dpmn_pgrm_blocks_backward_f32": (_i, [C.POINTER(PgrmWeights), C.POINTER(PgrmBlock), C.POINTER(PgrmBlockT), C.POINTER(PgrmSaved),
                                            C.POINTER(PgrmDrop), C.POINTER(C.c_int), fp, fp, _PP, fp, fp, _sz, fp, _sz, C.POINTER(C.c_size_t),
                                            _i, fp]),
+    "dpmn_pgrm_blocks_backward_leaf_f32": (_i, [C.POINTER(PgrmWeights), C.POINTER(PgrmBlock), C.POINTER(PgrmBlockT), C.POINTER(PgrmSaved),
+                                                C.POINTER(PgrmDrop), C.POINTER(C.c_int), fp, fp, _PP, fp, fp, _sz, fp, _sz, C.POINTER(C.c_size_t),
+                                                _i, fp, fp]),
     "dpmn_pgrm_forward_train_f32": (_i, [C.POINTER(PgrmWeights), fp, _i, fp, _PP, _i, fp, fp, C.POINTER(PgrmDrop), C.POINTER(PgrmSaved),
                                          C.POINTER(CmmScratch), fp, _i, fp]),
 }

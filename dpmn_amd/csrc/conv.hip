@@ -712,10 +712,28 @@ int launch_halo(const ConvArgs& a, hipStream_t st) {
   // mode 2 ("f32 via bf16x3", conv_x3.hip): 8-row tiles only -- with one output row per wave the split of a tap's weight slice costs
   // more vector time than the tap has MFMA time (measured: the 4-row variant is SLOWER than the fp32 kernel) -- and only where
   // those tiles fill the chip (DPMN_X3_HALO_MIN blocks); the other layers keep the fp32 kernel
-  static const int x3_min = getenv("DPMN_X3_HALO_MIN") ? atoi(getenv("DPMN_X3_HALO_MIN")) : 384;
+  // (the rule is per IMAGE -- 8-row tiles x 64-channel blocks of one image, 8 = the 384 blocks of the B = 48 forward -- so that a sample
+  //  meets the same kernel family whatever batch it travels in: the bf16x3 and the fp32 kernel differ by fp32-class round-off, which
+  //  a mask threshold downstream -- toMask, util.py:27-35 -- can turn into a flipped pixel)
+  static const int x3_min_img = getenv("DPMN_X3_HALO_MIN") ? atoi(getenv("DPMN_X3_HALO_MIN")) : 8;
+  const long x3_min = (long)x3_min_img * a.B;
   static const int x3_th4 = getenv("DPMN_X3_HALO_TH4") ? atoi(getenv("DPMN_X3_HALO_TH4")) : 0;
-  if (g_dpmn_x3 && KS == 3 && BN == 64 && blocks8 >= x3_min) return launch_halo_th<KS, BN, 8>(a, st, true);
-  if (KS == 3 && small) return launch_halo_th<KS, BN, 4>(a, st, g_dpmn_x3 && x3_th4);
+  if constexpr (KS == 3 && BN == 64) {
+    // 16 x 16-pixel tiles on eight waves (k_conv_halo_x3w): the small maps, where 8-row tiles do not fill the chip and the 4-row
+    // variant is slower than fp32 -- and, by default, every layer the 8-row x3 kernel would take (half the weight-split work per MFMA)
+    static const int x3_w16 = getenv("DPMN_X3_HALO16") ? atoi(getenv("DPMN_X3_HALO16")) : 0;      // 0 off (default: measured 55.8 vs 54.4 us forward, 79.6 vs 74.3 us training step per launch), 1 only below x3_min, 2 wherever it applies
+    static const int x3_w16_min = getenv("DPMN_X3_HALO16_MIN") ? atoi(getenv("DPMN_X3_HALO16_MIN")) : 96;
+    const long blocks16 = (long)a.B * (a.Hin / 16) * (a.Win / 16) * cdiv(a.Cout, BN);
+    if (x3_on(2) && x3_w16 && a.Hin % 16 == 0 && blocks16 >= x3_w16_min && (x3_w16 >= 2 || blocks8 < x3_min)) {
+      ProfScope prof(PT_CONV_HALO, st, conv_flops(a), conv_bytes(a));
+      if (dpmn_conv::x3_launch_halo(KS, BN, 16, a, dim3(a.B * (a.Hin / 16) * (a.Win / 16), cdiv(a.Cout, BN)), st) != 0)
+        return dpmn_set_error(DPMN_ERR_LAUNCH, "conv2d: bf16x3 halo launch failed");
+      DPMN_CHECK_LAUNCH();
+      return DPMN_OK;
+    }
+  }
+  if (x3_on(2) && KS == 3 && BN == 64 && blocks8 >= x3_min) return launch_halo_th<KS, BN, 8>(a, st, true);
+  if (KS == 3 && small) return launch_halo_th<KS, BN, 4>(a, st, x3_on(2) && x3_th4);
   return launch_halo_th<KS, BN, 8>(a, st);
 }
 
@@ -840,7 +858,7 @@ int launch_conv(ConvArgs a, float* ws, size_t ws_bytes, hipStream_t st, unsigned
     }
     simple = simple && (n_aff == 0 || n_aff == n_seg);       // mixed segments: the general UNI path
   static const int x3_t64 = getenv("DPMN_X3_TILE64") ? atoi(getenv("DPMN_X3_TILE64")) : 0;      // the 64 x 64 tile in mode 2: measured 93 vs 88 us (forward), 65 vs 60 (training step) -- off
-  if (g_dpmn_x3 && simple && ((BM == BN && (BM == 128 || (BM == 64 && x3_t64))) || (BM == 128 && BN == 64))) {
+  if (x3_on(1) && simple && ((BM == BN && (BM == 128 || (BM == 64 && x3_t64))) || (BM == 128 && BN == 64))) {
     if (dpmn_conv::x3_launch_igemm(BM == BN ? BM : 12864, n_aff != 0, a, grid, st) != 0) return dpmn_set_error(DPMN_ERR_LAUNCH, "conv2d: bf16x3 launch failed");
   } else
   if (g_dpmn_bf16 && simple && BM == BN && (BM == 128 || BM == 64)) {
@@ -1058,7 +1076,7 @@ int dpmn_conv2d_nhwc_f32(const dpmn_conv_desc* d, dpmn_stream_t stream) {
   // mode 2 ("f32 via bf16x3"): 128-pixel row tiles -- the operand split of a 64 x 64 tile costs as many vector instructions as the
   // tile has MFMA cycles (conv_x3.hip); the fp32 kernels keep the 64 x 64 tile (more blocks for the small maps)
   static const int x3_rows128 = getenv("DPMN_X3_ROWS128") ? atoi(getenv("DPMN_X3_ROWS128")) : 0;      // measured: 73.7 vs 60.1 us (fp32 64 x 64) over the 18 launches of the training step -- off
-  if (g_dpmn_x3 && x3_rows128 && M >= 128 * 256 && (a.groups != 2 || a.m_per_group % 128 == 0)) return launch_conv<128, 64, 2, 2>(a, ws, wsb, st);
+  if (x3_on(1) && x3_rows128 && M >= 128 * 256 && (a.groups != 2 || a.m_per_group % 128 == 0)) return launch_conv<128, 64, 2, 2>(a, ws, wsb, st);
   return launch_conv<64, 64, 2, 2>(a, ws, wsb, st);
 }
 

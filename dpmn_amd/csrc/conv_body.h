@@ -182,7 +182,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 128 x 128: ONE LDS buffer (61 KB, two blocks per CU as the fp32 kernel): the split + store of chunk k + 1 sits between two
 // barriers while the other resident block multiplies; 64 x 64: both buffers (61 KB).
 template <int BM, int BN, int WM, int WN, bool UNI = false, int BKT = 32, bool SIMPLE = false, bool AFF = false, bool BF = false, bool M32 = false,
-          bool XRED = false, bool X3 = false>
+          bool XRED = false, int X3 = 0>      // X3: 0 off, 1 = 80-byte LDS rows, 2 = 96-byte rows
 __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   static_assert(!X3 || (SIMPLE && !BF && !M32 && !XRED && BKT == 32), "the bf16x3 variant exists for the SIMPLE path with 32-deep chunks");
   static_assert(!XRED || (SIMPLE && !M32 && BKT == 32), "the in-L2 reduction exists for the SIMPLE path");
@@ -207,7 +207,7 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
   // quad with another lane (quad = 5 lr + kq mod 16) and every group takes two LDS cycles -- SQ_LDS_BANK_CONFLICT = 50 % of the
   // active LDS cycles (profiles/r06_pmc_sq.txt) -- while 96-byte rows (quad = 6 lr + kq mod 16) give sixteen different quads for
   // any row base.  The x3 kernels move 1.5 x the LDS bytes of the fp32 kernel in 0.375 x its MFMA time: the conflicts are not free there.
-  constexpr int LDKB = X3 ? BKT + 16 : BKT + 8;
+  constexpr int LDKB = X3 == 2 ? BKT + 16 : BKT + 8;
   constexpr bool B16 = BF || X3;                              // bf16 rows in LDS
   constexpr int NPL = X3 ? 3 : 1;                             // operand planes
   constexpr int NBUF = (X3 && BM * BN > 64 * 64) ? 1 : 2;
@@ -585,8 +585,12 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
     }
   }
   __syncthreads();
+#ifndef DPMN_X3_DBG
+#define DPMN_X3_DBG 0      // debugging builds (tools/build_variants.sh): 1 = an extra barrier + LDS fence at the top of every chunk, 4 = no MFMAs behind the barrier
+#endif
   for (int kt = kt0; kt < nk; ++kt) {
     const int buf = NBUF == 2 ? (kt - kt0) & 1 : 0;
+    if (X3 && (DPMN_X3_DBG & 1)) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __syncthreads(); }
     if (SIMPLE) gload_simple(min(kt + 1, nk - 1));
     else if (UNI) gload_uni(min(kt + 1, nk - 1) * BK);      // unconditional: the refill past the end re-reads the last chunk
     else if (kt + 1 < nk) gload((kt + 1) * BK);
@@ -666,7 +670,9 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
           for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[i][s], xf[j][s], acc[i][j]);
     }
     }
+    if (X3 && (DPMN_X3_DBG & 4)) __builtin_amdgcn_sched_barrier(0);
     if (NBUF == 1) __syncthreads();                           // single buffer: every wave has read chunk kt before it is overwritten
+    if (X3 && (DPMN_X3_DBG & 4)) __builtin_amdgcn_sched_barrier(0);
     if (SIMPLE) sstore_simple(NBUF == 2 ? buf ^ 1 : 0);
     else if (UNI || kt + 1 < nk) sstore(buf ^ 1);
     if (!(ABL & 4)) __syncthreads();
@@ -898,20 +904,26 @@ __device__ __forceinline__ void conv_igemm_body(const ConvArgs& a) {
 // BF: bf16 operands (halo tile and weight slices rounded on the way into LDS, 80-byte rows), one v_mfma_f32_16x16x32_bf16 per tap
 // and tile pair instead of eight fp32 MFMAs; fp32 accumulation and epilogue.
 // X3: "f32 via bf16x3" (common.h x3_split2t): halo tile and weight slices as three bf16 planes each, six bf16 MFMAs per tap and tile pair.
-template <int KS, int BN, int TH, bool BF = false, bool X3 = false>    // TH x 16 output pixels per block (TH = 8: 2 rows per wave, TH = 4: 1 row per wave)
+// NW waves per block (4, or 8 for the 16-row tile of mode 2: the weight slice of a tap is split once per BLOCK, so twice the pixels per
+// block halve the split work per MFMA; LDS for one block per CU, its eight waves = the two blocks of four it replaces) and R96: 96-byte
+// LDS rows (conflict-free ds_read_b128 at any pixel base, conv_igemm_body) where one block per CU leaves the room.
+template <int KS, int BN, int TH, bool BF = false, bool X3 = false, int NW = 4, bool R96 = false>    // TH x 16 output pixels per block: TH / NW rows per wave
 __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
   static_assert(!(BF && X3), "one operand format");
-  constexpr int LDH = X3 ? (BK + 16) / 2 : (BF ? (BK + 8) / 2 : LDK);   // LDS row stride in FLOAT units (bf16 rows: 40 halves = 20 floats = 80 bytes; X3: 96 bytes, conflict-free ds_read_b128 at any pixel base)
+  constexpr int NTH = NW * 64, RPS = NTH / 8;            // threads; pixel rows (8 float4 each) staged per pass
+  static_assert(!R96 || X3, "96-byte rows: the bf16x3 variant");
+  constexpr int LDH = R96 ? (BK + 16) / 2 : (BF || X3) ? (BK + 8) / 2 : LDK;   // LDS row stride in FLOAT units (bf16 rows: 40 halves = 20 floats = 80 bytes; 96-byte rows -- conflict-free
+                                                         // ds_read_b128, conv_igemm_body -- cost the second resident block here: 77.6 vs 54.4 us per launch, measured)
   constexpr int NPL = X3 ? 3 : 1;                        // operand planes
   constexpr int TW = 16, HH = TH + KS - 1, HW_ = TW + KS - 1, NPX = HH * HW_;
-  constexpr int NT = BN / 16, T = KS * KS, MR = TH / 4;
+  constexpr int NT = BN / 16, T = KS * KS, MR = TH / NW;
   constexpr bool PREFETCH = false;
   static_assert(!(BF || X3) || !PREFETCH, "bf16 variants: direct staging only");   // halo staged directly into ONE LDS buffer: 3 blocks per CU hide the staging latency
                                      // (measured: tatt 3x3 60.6 -> 55.3 us, en2b 118 -> 84 us vs the register-prefetch variant;
                                      //  weights straight from L1/L2 to registers instead of LDS measured 76 / 146 us: rejected)
   constexpr int HBUF = PREFETCH ? 2 : 1;
-  constexpr int HV = PREFETCH ? (NPX * 8 + 255) / 256 : 1;   // halo float4 per thread held in registers
-  constexpr int WV = (BN * 8 + 255) / 256;               // weight float4 per thread and tap
+  constexpr int HV = PREFETCH ? (NPX * 8 + NTH - 1) / NTH : 1;   // halo float4 per thread held in registers
+  constexpr int WV = (BN * 8 + NTH - 1) / NTH;               // weight float4 per thread and tap
 #ifndef DPMN_HALO_TPS
 #define DPMN_HALO_TPS 1                                   // 3: the three taps of a kernel row share one weight stage and ONE barrier
 #endif
@@ -974,11 +986,11 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
   // All of a thread's halo elements are fetched first, as raw buffer loads (the range check returns 0 for pixels outside the
   // image: no predicated load, no branch, so the HVD loads are in flight together instead of one wait per element), then
   // transformed and stored.  256 % 8 == 0: every element of a thread has the same channel quad, hence one affine pair.
-  constexpr int HVD = (NPX * 8 + 255) / 256;
-  constexpr bool HALO_BUF = TH == 4;      // (8-row tiles, 6-12 loads per thread: measured slower than the per-element loop)
+  constexpr int HVD = (NPX * 8 + NTH - 1) / NTH;
+  constexpr bool HALO_BUF = TH == 4 || NW == 8;      // (8-row tiles, 6-12 loads per thread: measured slower than the per-element loop)
   auto stage_halo_direct = [&](int chunk) {
     if constexpr (!HALO_BUF) {
-      for (int i = tid; i < NPX * 8; i += 256)
+      for (int i = tid; i < NPX * 8; i += NTH)
         put4(halo, i >> 3, (i & 7) * 4, halo_elem(chunk, i), HPL);
       return;
     }
@@ -994,7 +1006,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
     unsigned inb = 0;
 #pragma unroll
     for (int v = 0; v < HVD; ++v) {
-      const int px = (tid >> 3) + v * 32;
+      const int px = (tid >> 3) + v * RPS;
       const int iy = ty0 + px / HW_ - padk, ix = tx0 + px % HW_ - padk;
       const bool ok = px < NPX && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
       const unsigned off = (unsigned)((((b * a.Hin + iy) * a.Win + ix) * cs + cl) * 4) | (ok ? 0u : 0x80000000u);
@@ -1005,7 +1017,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
     if (sc) { s4 = *reinterpret_cast<const float4*>(sc + cl); h4 = *reinterpret_cast<const float4*>(sh + cl); }
 #pragma unroll
     for (int v = 0; v < HVD; ++v) {
-      const int px = (tid >> 3) + v * 32;
+      const int px = (tid >> 3) + v * RPS;
       float4 val = raw[v];
       if (sc) { val.x = val.x * s4.x + h4.x; val.y = val.y * s4.y + h4.y; val.z = val.z * s4.z + h4.z; val.w = val.w * s4.w + h4.w; }
       if (a.pro_act != ACT_NONE) {
@@ -1013,20 +1025,20 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
         val.z = apply_act(val.z, a.pro_act, 0.f); val.w = apply_act(val.w, a.pro_act, 0.f);
       }
       if (!((inb >> v) & 1u)) val = make_float4(0.f, 0.f, 0.f, 0.f);      // padding stays exactly 0 after the transform
-      if (HVD * 32 == NPX || px < NPX) put4(halo, px, (tid & 7) * 4, val, HPL);
+      if (HVD * RPS == NPX || px < NPX) put4(halo, px, (tid & 7) * 4, val, HPL);
     }
   };
   auto issue_halo = [&](int chunk) {
 #pragma unroll
     for (int v = 0; v < HV; ++v) {
-      const int i = tid + v * 256;
+      const int i = tid + v * NTH;
       hraw[v] = (i < NPX * 8) ? halo_elem(chunk, i) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto commit_halo = [&](int buf) {
 #pragma unroll
     for (int v = 0; v < HV; ++v) {
-      const int i = tid + v * 256;
+      const int i = tid + v * NTH;
       if (i < NPX * 8) put4(halo + (size_t)buf * NPX * LDH, i >> 3, (i & 7) * 4, hraw[v], HPL);
     }
   };
@@ -1036,7 +1048,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
   int wofs_h[WV];
 #pragma unroll
   for (int v = 0; v < WV; ++v) {
-    const int i = tid + v * 256;
+    const int i = tid + v * NTH;
     wofs_h[v] = (i < BN * 8) ? ((n_blk + (i >> 3)) * a.Kp + (i & 7) * 4) * 4 : (int)0x80000000;
   }
   const bool w_buf_ok = (size_t)a.Cout * a.Kp * 4 < (1ull << 31);
@@ -1054,7 +1066,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
       }
 #pragma unroll
       for (int v = 0; v < WV; ++v) {
-        const int i = tid + v * 256;
+        const int i = tid + v * NTH;
         const int r = i >> 3, c4 = (i & 7) * 4;
         wraw[tp * WV + v] = (i < BN * 8 && n_blk + r < a.Cout) ? *reinterpret_cast<const float4*>(wg + (size_t)(n_blk + r) * a.Kp + k0 + c4)
                                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1066,7 +1078,7 @@ __device__ __forceinline__ void conv_halo_body(const ConvArgs& a) {
     for (int tp = 0; tp < TPS; ++tp)
 #pragma unroll
       for (int v = 0; v < WV; ++v) {
-        const int i = tid + v * 256;
+        const int i = tid + v * NTH;
         if (i < BN * 8) put4(Wt + (size_t)(buf * TPS + tp) * NPL * BN * LDH, i >> 3, (i & 7) * 4, wraw[tp * WV + v], WPLH);
       }
   };
@@ -1206,6 +1218,10 @@ __global__ __launch_bounds__(256) void k_conv_halo(ConvArgs a) {
 template <int KS, int BN, int TH>
 __global__ __launch_bounds__(256, 2) void k_conv_halo_x3(ConvArgs a) {
   conv_halo_body<KS, BN, TH, false, true>(a);
+}
+template <int KS, int BN>
+__global__ __launch_bounds__(512, 1) void k_conv_halo_x3w(ConvArgs a) {      // 16 x 16 pixels, eight waves, 96-byte rows
+  conv_halo_body<KS, BN, 16, false, true, 8, true>(a);
 }
 
 static inline double conv_flops(const ConvArgs& a) {

@@ -867,10 +867,10 @@ static int launch_wgrad(const dpmn_conv_desc* d, const float* dy, float* dw, int
   if (p2) {
     for (a.lgW = 0; (1 << a.lgW) < a.Wp; ++a.lgW) {}
     for (a.lgHW = 0; (1 << a.lgHW) < a.Hp * a.Wp; ++a.lgHW) {}
-    if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256, true>), grid, dim3(256), 0, as_stream(stream), a);
+    if (x3_on(16) && bn != 16 && dpmn_conv::x3_wgrad_ok(a, bn, bk)) (void)dpmn_conv::x3_launch_wgrad(a, bn, bk, grid, as_stream(stream));
+    else if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256, true>), grid, dim3(256), 0, as_stream(stream), a);
     else if (bn == 64 && bk == 128) hipLaunchKernelGGL((k_conv_wgrad<64, 128, true>), grid, dim3(256), 0, as_stream(stream), a);
     else if (bn == 64) hipLaunchKernelGGL((k_conv_wgrad<64, 256, true>), grid, dim3(256), 0, as_stream(stream), a);
-    else if (g_dpmn_x3 && dpmn_conv::x3_wgrad_ok(a)) (void)dpmn_conv::x3_launch_wgrad(a, grid, as_stream(stream));
     else hipLaunchKernelGGL((k_conv_wgrad<128, 128, true>), grid, dim3(256), 0, as_stream(stream), a);
   } else
   if (bn == 16) hipLaunchKernelGGL((k_conv_wgrad<16, 256>), grid, dim3(256), 0, as_stream(stream), a);

@@ -26,7 +26,7 @@ struct WgArgs {
   int lgW, lgHW;        // P2 kernels: log2(Wp), log2(Hp * Wp)
 };
 
-// conv_wgrad_x3.hip ("f32 via bf16x3", dpmn_set_compute_dtype(2)): the 128 (co) x 128 (k) tile of the power-of-two fast path
-bool x3_wgrad_ok(const WgArgs& a);
-int x3_launch_wgrad(const WgArgs& a, dim3 grid, hipStream_t st);
+// conv_wgrad_x3.hip ("f32 via bf16x3", dpmn_set_compute_dtype(2)): the 128 x 128, 64 x 256 and 64 x 128 (co x k) tiles of the power-of-two fast path
+bool x3_wgrad_ok(const WgArgs& a, int bn, int bk);
+int x3_launch_wgrad(const WgArgs& a, int bn, int bk, dim3 grid, hipStream_t st);
 }  // namespace dpmn_conv

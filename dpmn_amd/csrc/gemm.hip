@@ -1327,7 +1327,7 @@ int dpmn_linear_f32(const float* x, const float* w, const float* bias, const flo
   DPMN_REQUIRE(K % 32 == 0, "linear: K must be a multiple of 32");
   dim3 grid(cdiv(M, 64), cdiv(N, 96));
   ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N * (res1 ? 2 : 1) + (double)N * K));
-  if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop(x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L, grid, as_stream(stream));
+  if (x3_on(8)) (void)dpmn_gemm::x3_launch_kloop(x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L, grid, as_stream(stream));
   else hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -1345,7 +1345,7 @@ int dpmn_linear_drop_f32(const float* x, const float* w, const float* bias, cons
   e.p_elem = p_elem; e.p_row = p_row; e.seed_elem = seed_elem; e.seed_row = seed_row; e.row_len = row_len;
   dim3 grid(cdiv(M, 64), cdiv(N, 96));
   ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * M * (double)N * K, 4.0 * ((double)M * K + (double)M * N * 2 + (double)N * K));
-  if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop(x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L, grid, as_stream(stream));
+  if (x3_on(8)) (void)dpmn_gemm::x3_launch_kloop(x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L, grid, as_stream(stream));
   else hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), x, K, w, K, y, N, M, N, K, e, 0, 0L, 0L);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -1451,7 +1451,7 @@ int dpmn_pointwise_wgrad_f32(const float* dz, const float* g, float* dw, int B, 
   DPMN_REQUIRE(dz && g && dw && L % 32 == 0 && Ch % 4 == 0, "pointwise_wgrad: bad arguments");
   EpiArgs e{nullptr, nullptr, nullptr, nullptr, ACT_NONE, 0.f, 1};   // split over (b, s), atomic accumulation
   dim3 grid(cdiv(Ch, 64), cdiv(Ch, 96), 32);
-  if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop(dz, L, g, L, dw, Ch, Ch, Ch, B * L, e, L,
+  if (x3_on(8)) (void)dpmn_gemm::x3_launch_kloop(dz, L, g, L, dw, Ch, Ch, Ch, B * L, e, L,
                      (long)Ch * L, (long)Ch * L, grid, as_stream(stream));
   else hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, dw, Ch, Ch, Ch, B * L, e, L,
                      (long)Ch * L, (long)Ch * L);
@@ -1485,7 +1485,7 @@ int dpmn_pointwise_wgrad_det_f32(const float* dz, const float* g, float* dw, int
   if (s128) {
     const int nchunks = B * (L / 32);
     ProfScope prof(PT_GEMM_KLOOP, as_stream(stream), 2.0 * Ch * (double)Ch * B * L, 4.0 * (2.0 * B * Ch * (double)L + (double)Ch * Ch));
-    if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop128(dz, g, ws, Ch, Ch, L, nchunks, S, (long)Ch * L, (long)Ch * Ch, as_stream(stream));
+    if (x3_on(32)) (void)dpmn_gemm::x3_launch_kloop128(dz, g, ws, Ch, Ch, L, nchunks, S, (long)Ch * L, (long)Ch * Ch, as_stream(stream));
     else hipLaunchKernelGGL(k_gemm_kloop128, dim3((Ch / 128) * (Ch / 128) * S), dim3(256), 0, as_stream(stream), dz, g, ws, Ch, Ch, L, nchunks, S,
                        (long)Ch * L, (long)Ch * Ch);
     DPMN_CHECK_LAUNCH();
@@ -1493,7 +1493,7 @@ int dpmn_pointwise_wgrad_det_f32(const float* dz, const float* g, float* dw, int
   }
   EpiArgs e{nullptr, nullptr, nullptr, nullptr, ACT_NONE, 0.f, 0, (long)Ch * Ch};
   dim3 grid(cdiv(Ch, 64), cdiv(Ch, 96), S);
-  if (g_dpmn_x3) (void)dpmn_gemm::x3_launch_kloop(dz, L, g, L, ws, Ch, Ch, Ch, B * L, e, L,
+  if (x3_on(8)) (void)dpmn_gemm::x3_launch_kloop(dz, L, g, L, ws, Ch, Ch, Ch, B * L, e, L,
                      (long)Ch * L, (long)Ch * L, grid, as_stream(stream));
   else hipLaunchKernelGGL(k_gemm_kloop, grid, dim3(256), 0, as_stream(stream), dz, L, g, L, ws, Ch, Ch, Ch, B * L, e, L,
                      (long)Ch * L, (long)Ch * L);
@@ -1506,7 +1506,7 @@ int dpmn_pointwise_f32(const float* g, const float* w, const float* bias, float*
   DPMN_REQUIRE(g && w && bias && z && Ch % 128 == 0 && L % 128 == 0, "pointwise: Ch and L must be multiples of 128");
   static const int pw_bc = getenv("DPMN_PW_BC") ? atoi(getenv("DPMN_PW_BC")) : 192;
   ProfScope prof(PT_GEMM_PW, as_stream(stream), 2.0 * Ch * Ch * (double)L * B, 4.0 * (2.0 * B * Ch * (double)L + (double)Ch * Ch + Ch));
-  if (g_dpmn_x3) {
+  if (x3_on(4)) {
     // fp32 product through six bf16 MFMAs of a three-term operand split (dpmn_set_compute_dtype(2), gemm_x3.hip)
     if (dpmn_gemm::x3_launch_pw(g, w, bias, z, B, Ch, L, as_stream(stream)) != 0) return dpmn_set_error(DPMN_ERR_LAUNCH, "pointwise: bf16x3 launch failed");
   } else if (g_dpmn_bf16 && Ch % 192 == 0)

@@ -195,7 +195,29 @@ __global__ void k_selftest_xshfl(unsigned* mismatches) {
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void k_lds_poison(unsigned pattern, int words) {
+  extern __shared__ unsigned lds_all[];
+  for (int i = threadIdx.x; i < words; i += 256) lds_all[i] = pattern;
+  __syncthreads();
+  if (lds_all[(threadIdx.x * 97) % words] != pattern) __builtin_trap();      // (keeps the stores alive)
+}
+}  // namespace
+
 extern "C" {
+
+int dpmn_selftest_lds_poison(unsigned pattern, int blocks, dpmn_stream_t stream) {
+  DPMN_REQUIRE(blocks > 0, "selftest_lds_poison: blocks > 0");
+  constexpr int bytes = 160 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lds_poison), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_lds_poison, dim3(blocks), dim3(256), bytes, as_stream(stream), pattern, bytes / 4);
+  DPMN_CHECK_LAUNCH();
+  return DPMN_OK;
+}
 
 int dpmn_selftest_xshfl(unsigned* mismatches_out) {
   DPMN_REQUIRE(mismatches_out, "selftest_xshfl: null pointer");

@@ -1,6 +1,7 @@
 // Error plumbing shared by every entry point (thread-local last-error string).
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 static thread_local char g_err[512] = "";
 
@@ -28,6 +29,11 @@ struct Prof {
   Rec* rec = nullptr;
 } g_prof;
 }  // namespace
+
+int dpmn_x3_off_mask() {
+  static const int m = getenv("DPMN_X3_OFF") ? atoi(getenv("DPMN_X3_OFF")) : 0;
+  return m;
+}
 
 int dpmn_prof_open(int tag, hipStream_t st, double flops, double bytes) {
   if (g_prof.count >= g_prof.limit) return -1;

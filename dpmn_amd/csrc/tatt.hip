@@ -17,7 +17,12 @@ namespace {
 // seq s -> base pixel = (s / inner) * outer_stride + (s % inner) * inner_stride ; step t adds t*step_stride (pixels)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int HID>
+// PK: the recurrence's products as v_pk_fma_f32 (default) or, PK = false, as the same sums on scalar v_fma_f32.  The packed form is
+// NOT safe next to bf16 MFMA work of another stream: with a v_mfma_f32_16x16x32_bf16 kernel (mode 2 "f32 via bf16x3", mode 1 bf16)
+// resident on the same SIMDs, 7-25 % of the launches returned a few sequences off by 3e-3 -- never alone, never next to fp32-MFMA
+// kernels, never with scalar fmas (tools/dbg_victim.py: the recurrence on one stream, a bf16x3 conv on another; 0 / 240 vs 28-60 / 240
+// mismatching launches).  The launcher therefore takes the scalar form whenever the library is in a bf16-MFMA mode.
+template <int HID, bool PK = true>
 __global__ __launch_bounds__(256) void k_bigru(const float* gi, const float* w_hh /*(2,3H,H)*/,
                                                 const float* b_hh /*(2,3H)*/, const float* res,
                                                 float* out, int nseq, int T, int inner, long outer_stride,
@@ -75,6 +80,10 @@ __global__ __launch_bounds__(256) void k_bigru(const float* gi, const float* w_h
     gp += more ? gd : 0;
     rq += more ? rd : 0;
   };
+  auto pkfma = [](v2f a, v2f b, v2f c) -> v2f {
+    if (PK) return __builtin_elementwise_fma(a, b, c);
+    return v2f{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)};
+  };
   auto step = [&](const float (&g4)[4], int t) {
     hs[wave][lane] = h;
     __builtin_amdgcn_wave_barrier();
@@ -84,18 +93,18 @@ __global__ __launch_bounds__(256) void k_bigru(const float* gi, const float* w_h
     for (int k = 0; k < HID; k += 8) {
       const float4 h0 = *reinterpret_cast<const float4*>(hp + k);
       const float4 h1 = *reinterpret_cast<const float4*>(hp + k + 4);
-      rz0 = __builtin_elementwise_fma(wrz[k], v2f{h0.x, h0.x}, rz0);
-      rz1 = __builtin_elementwise_fma(wrz[k + 1], v2f{h0.y, h0.y}, rz1);
-      n0 = __builtin_elementwise_fma(wnn[k / 2], v2f{h0.x, h0.y}, n0);
-      rz0 = __builtin_elementwise_fma(wrz[k + 2], v2f{h0.z, h0.z}, rz0);
-      rz1 = __builtin_elementwise_fma(wrz[k + 3], v2f{h0.w, h0.w}, rz1);
-      n1 = __builtin_elementwise_fma(wnn[k / 2 + 1], v2f{h0.z, h0.w}, n1);
-      rz0 = __builtin_elementwise_fma(wrz[k + 4], v2f{h1.x, h1.x}, rz0);
-      rz1 = __builtin_elementwise_fma(wrz[k + 5], v2f{h1.y, h1.y}, rz1);
-      n0 = __builtin_elementwise_fma(wnn[k / 2 + 2], v2f{h1.x, h1.y}, n0);
-      rz0 = __builtin_elementwise_fma(wrz[k + 6], v2f{h1.z, h1.z}, rz0);
-      rz1 = __builtin_elementwise_fma(wrz[k + 7], v2f{h1.w, h1.w}, rz1);
-      n1 = __builtin_elementwise_fma(wnn[k / 2 + 3], v2f{h1.z, h1.w}, n1);
+      rz0 = pkfma(wrz[k], v2f{h0.x, h0.x}, rz0);
+      rz1 = pkfma(wrz[k + 1], v2f{h0.y, h0.y}, rz1);
+      n0 = pkfma(wnn[k / 2], v2f{h0.x, h0.y}, n0);
+      rz0 = pkfma(wrz[k + 2], v2f{h0.z, h0.z}, rz0);
+      rz1 = pkfma(wrz[k + 3], v2f{h0.w, h0.w}, rz1);
+      n1 = pkfma(wnn[k / 2 + 1], v2f{h0.z, h0.w}, n1);
+      rz0 = pkfma(wrz[k + 4], v2f{h1.x, h1.x}, rz0);
+      rz1 = pkfma(wrz[k + 5], v2f{h1.y, h1.y}, rz1);
+      n0 = pkfma(wnn[k / 2 + 2], v2f{h1.x, h1.y}, n0);
+      rz0 = pkfma(wrz[k + 6], v2f{h1.z, h1.z}, rz0);
+      rz1 = pkfma(wrz[k + 7], v2f{h1.w, h1.w}, rz1);
+      n1 = pkfma(wnn[k / 2 + 3], v2f{h1.z, h1.w}, n1);
     }
     __builtin_amdgcn_wave_barrier();
     // v_exp / v_rcp gates: libm expf / tanhf and the IEEE divisions were ~100 dependent instructions per step of a pure latency chain
@@ -437,8 +446,14 @@ int dpmn_bigru_f32(const float* gi, const float* w_hh, const float* b_hh, const 
   DPMN_REQUIRE(gi && w_hh && b_hh && out && nseq > 0 && T > 0 && inner > 0, "bigru: bad arguments");
   DPMN_REQUIRE(hidden == 32, "bigru: built for hidden_units=32 per direction (hd_u default, main.py:47)");
   ProfScope prof(PT_BIGRU, as_stream(stream), 2.0 * 2 * 3 * 32 * 32 * (double)nseq * T, 4.0 * (2 * 96 + 64 + 64) * (double)nseq * T);
-  hipLaunchKernelGGL((k_bigru<32>), dim3((unsigned)((nseq + 3) / 4)), dim3(256), 0, as_stream(stream), gi, w_hh, b_hh, res, out,
-                     nseq, T, inner, outer_stride, inner_stride, step_stride);
+  static const int pk_env = getenv("DPMN_BIGRU_PK") ? atoi(getenv("DPMN_BIGRU_PK")) : -1;      // A/B switch: 1 / 0 force the packed / scalar form
+  const bool pk = pk_env >= 0 ? pk_env != 0 : !(g_dpmn_x3 || g_dpmn_bf16);
+  if (pk)
+    hipLaunchKernelGGL((k_bigru<32, true>), dim3((unsigned)((nseq + 3) / 4)), dim3(256), 0, as_stream(stream), gi, w_hh, b_hh, res, out,
+                       nseq, T, inner, outer_stride, inner_stride, step_stride);
+  else
+    hipLaunchKernelGGL((k_bigru<32, false>), dim3((unsigned)((nseq + 3) / 4)), dim3(256), 0, as_stream(stream), gi, w_hh, b_hh, res, out,
+                       nseq, T, inner, outer_stride, inner_stride, step_stride);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
 }

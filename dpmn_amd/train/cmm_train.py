@@ -378,6 +378,42 @@ def backward(m, graph, dout, need_dx=(True, True)):
             partner[id(u2)], partner[id(u1)] = u1, u2
             second.add(id(u2))
     side = wgrad_stream(dout.device)
+    # gradient exchange in segments (train/optim.py SegmentedBucket; only when collectives run): how many units of each segment are
+    # still to come -- the segment is reported the moment its last unit (and, for the segment that holds fc_1 / fc_2, the channel
+    # gate) has issued its gradients, with an event that covers this stream AND the weight-gradient stream
+    seg = getattr(m, "_dpmn_bucket", None) if direct else None
+    seg = seg if seg is not None and hasattr(seg, "segment_ready") else None
+    seg_left = {}
+    if seg is not None:
+        for u in units:
+            k_ = seg.seg_of[id(u.conv.weight)]
+            seg_left[k_] = seg_left.get(k_, 0) + 1
+        k_gate = seg.seg_of[id(m.fc_1.weight)]
+        seg_left[k_gate] = seg_left.get(k_gate, 0) + 1
+
+    def seg_done(key_param):
+        if seg is None:
+            return
+        k_ = seg.seg_of[id(key_param)]
+        seg_left[k_] -= 1
+        if seg_left[k_] > 0:
+            return
+        cur_ = torch.cuda.current_stream(dout.device)
+        if side is not None and not torch.cuda.is_current_stream_capturing():
+            if uq_holder[0] is not None:
+                with torch.cuda.stream(side):
+                    uq_holder[0].flush()        # this segment's conv weight gradients into the parameter layout
+            here = torch.cuda.Event()
+            here.record(cur_)
+            side.wait_event(here)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            seg.segment_ready(k_, ev)
+        else:
+            if uq_holder[0] is not None:
+                uq_holder[0].flush()
+            seg.segment_ready(k_)
+    uq_holder = [None]
     # every conv's weight-gradient unpack in ONE launch at the end (train/pgrm_train.py UnpackQueue; per module: the descriptor
     # table holds this module's gradient sinks)
     from . import pgrm_train as _pt
@@ -387,6 +423,7 @@ def backward(m, graph, dout, need_dx=(True, True)):
         if uq is None:
             uq = m._unpack_queue = _pt.UnpackQueue()
         _pt.UNPACK_QUEUE = uq
+    uq_holder[0] = uq
     try:
       # reverse execution order; the units of the second encoder branch wait for their twins (branch 1 comes later in this order): a
       # twin pair runs when its FIRST-branch unit is reached, after both units' consumers (decoder, next encoder level) are done
@@ -404,9 +441,12 @@ def backward(m, graph, dout, need_dx=(True, True)):
                       tw.backward(gr, side)
                   if u.out.G is not None:
                       u.backward(gr, side)
+              seg_done(tw.conv.weight)
+              seg_done(u.conv.weight)
               continue
           if u is last or u.out.G is not None:
               u.backward(gr, side)
+          seg_done(u.conv.weight)
           if u.inputs and u.inputs[0] is graph["gated"]:
               # channel gate backward, then split the bottleneck gradient into the two en_6 outputs
               g = graph["gated"]
@@ -420,6 +460,7 @@ def backward(m, graph, dout, need_dx=(True, True)):
               half = dbott.shape[3] // 2
               a[5].G = dbott[..., :half].contiguous()
               b[5].G = dbott[..., half:].contiguous()
+              seg_done(m.fc_1.weight)
     finally:
         _pt.UNPACK_QUEUE = None
     if uq is not None:

@@ -68,12 +68,13 @@ class FlatBucket:
     """One model's parameters / gradients as one contiguous range.  Stand-alone (`FlatBucket(module)`) it owns its storage;
     inside a Trainer the storage is a slice of the trainer's arenas (`storage=(flat_p, flat_g)`)."""
 
-    def __init__(self, module, name="", direct=False, storage=None):
+    def __init__(self, module, name="", direct=False, storage=None, params=None):
+        """params: a subset of the module's parameters (one exchange segment of a large model, see SegmentedBucket); default: all."""
         self.name = name
         self.direct = direct
         self.module = module
-        self.params = [p for p in module.parameters()]
-        n = self.size_of(module)
+        self.params = [p for p in module.parameters()] if params is None else list(params)
+        n = self.size_of_params(self.params)
         dev = self.params[0].device
         if storage is None:
             self.flat_p = torch.zeros(n, device=dev)
@@ -113,6 +114,17 @@ class FlatBucket:
     def size_of(module):
         return sum(_padded(p.numel()) for p in module.parameters())
 
+    @staticmethod
+    def size_of_params(params):
+        return sum(_padded(p.numel()) for p in params)
+
+    def param_slices(self):
+        """(parameter, offset in this bucket's flat range, numel) -- every view starts on an ALIGN boundary"""
+        off = 0
+        for p in self.params:
+            yield p, off, p.numel()
+            off += _padded(p.numel())
+
     # ------------------------------------------------------------------ readiness (when may the exchange start?)
     def install_hooks(self, world_size=1, group=None):
         """Stand-alone use (tests, single bucket): wraps the bucket in its own CommGroup."""
@@ -144,11 +156,14 @@ class FlatBucket:
         if self.done >= max(self.uses, 1):
             self._mark_ready()
 
-    def _mark_ready(self):
+    def _mark_ready(self, done=None):
         self.ready = True
         # the backward of the two refinement branches runs on two HIP streams (interfaces/super_resolution.py): the group's
         # collective is enqueued behind the stream of its LAST reporter only, so every member leaves an event for it to wait on
-        done = self.module.__dict__.pop("_dpmn_grads_done", None)
+        if done is None:
+            done = self.module.__dict__.pop("_dpmn_grads_done", None)
+        elif done is False:       # (a segment of a SegmentedBucket reported without a side-stream event: the module-level event is not its own)
+            done = None
         if done is not None:
             # the module's backward left part of its gradients on a side stream (train/cmm_train.py: the conv weight gradients and their
             # unpack) and did NOT make the calling stream wait for it: whoever consumes the bucket waits for this event instead
@@ -194,6 +209,59 @@ class FlatBucket:
         self._wait_ready_event()
         _sumsq(self.flat_g, self.normsq, self.part)
         _adam_clip(self.flat_p, self.flat_g, self.m, self.v, self.normsq, max_norm, lr, beta1, beta2, eps, step, step_dev)
+
+
+class SegmentedBucket:
+    """ONE direct-mode model whose gradients are exchanged in K collectives instead of one (the CMM: 214 MB, SURVEY.md 5.8 "launched
+    as soon as a bucket is ready, overlapped with the remaining backward").  The model's parameters are laid out in the arenas in
+    BACKWARD order and cut into K segments (the module's `exchange_segments()`: decoder first, then the bottleneck, then the encoder
+    levels deepest first); every segment is a FlatBucket in a CommGroup of its own, and the module's backward reports
+    `segment_ready(k, event)` the moment the last gradient of segment k is in place -- its reduce-scatter / all-reduce then runs
+    under the backward of the segments still to come.  The clip stays per MODEL: the Trainer sums the segments' ||g||^2 slots into
+    one value before any segment's Adam kernel reads it (one norm all-reduce for everything, as before).  Towards the module and the
+    Trainer this object looks like the model's one bucket (note_use / grads_ready / lazy_join / reset_step ...)."""
+
+    def __init__(self, module, segments, name=""):
+        self.module, self.segments, self.name = module, segments, name
+        self.direct = True
+        self.anchor = segments[0].anchor
+        self.params = [p for s_ in segments for p in s_.params]
+        self.n = sum(s_.n for s_ in segments)
+        self.uses = 0
+        self.seg_done = [0] * len(segments)
+        self.lazy_join = False
+        self.seg_of = {id(p): k for k, s_ in enumerate(segments) for p in s_.params}
+        module._dpmn_bucket = self
+
+    flat_g = property(lambda self: self.segments[0].flat_g)
+    ready = property(lambda self: all(s_.ready for s_ in self.segments))
+
+    def note_use(self):
+        self.uses += 1
+
+    def segment_ready(self, k, done=None):
+        """one backward call of the module has every gradient of segment k in place (done: an event that covers the streams they
+        were written on, or None = complete in the calling stream's order)"""
+        self.seg_done[k] += 1
+        if self.seg_done[k] >= max(self.uses, 1) and not self.segments[k].ready:
+            self.segments[k]._mark_ready(done if done is not None else False)
+
+    def grads_ready(self):
+        """whole-module completion: every segment the backward did not report by itself"""
+        done = self.module.__dict__.pop("_dpmn_grads_done", None)
+        for k, s_ in enumerate(self.segments):
+            if not s_.ready:
+                self.segment_ready(k, done)
+
+    def reset_step(self):
+        self.uses = 0
+        self.seg_done = [0] * len(self.segments)
+        for s_ in self.segments:
+            s_.reset_step()
+
+    def _wait_ready_event(self):
+        for s_ in self.segments:
+            s_._wait_ready_event()
 
 
 # 1: gradient collectives issued from a stream of their own that waits for the members' ready events, instead of the stream of the last
@@ -383,22 +451,35 @@ class Trainer:
         dev = next(models[0].parameters()).device
         # exchange order = expected backward order: the model list arrives as [PGRM_0.., CMM, Distill..] and the backward
         # runs CMM first, then the distill modules, then the PGRMs last-to-first
-        sizes = [FlatBucket.size_of(m) for m in models]
-        order = self._backward_order(models)
+        # exchange UNITS: a model, or -- for a direct-mode model that offers `exchange_segments()` and holds >= 4 groups' worth of
+        # gradients (the CMM) when collectives run at all -- its backward-ordered segments (SegmentedBucket)
+        seg_on = os.environ.get("DPMN_SEGMENT_EXCHANGE", "1") != "0"
+        units = []       # (model index, segment index or None, parameter list or None, padded size)
+        for i in self._backward_order(models):
+            m = models[i]
+            segs = None
+            if multi and seg_on and getattr(m, "direct_grad", False) and hasattr(m, "exchange_segments") and FlatBucket.size_of(m) * 4 >= 4 * group_mb * 2 ** 20:
+                segs = m.exchange_segments()
+                assert sorted(id(p) for sg in segs for p in sg) == sorted(id(p) for p in m.parameters()), "exchange_segments must cover every parameter once"
+            if segs and len(segs) > 1:
+                for k, sg in enumerate(segs):
+                    units.append((i, k, sg, FlatBucket.size_of_params(sg)))
+            else:
+                units.append((i, None, None, FlatBucket.size_of(m)))
         plan, cur, cur_n = [], [], 0
-        for i in order:
-            cur.append(i)
-            cur_n += sizes[i]
+        for u in range(len(units)):
+            cur.append(u)
+            cur_n += units[u][3]
             if cur_n * 4 >= group_mb * 2 ** 20:
                 plan.append(cur)
                 cur, cur_n = [], 0
         if cur:
-            if plan and sum(sizes[i] for i in cur) * 4 < 2 ** 20 and len(plan) > 1:
+            if plan and sum(units[u][3] for u in cur) * 4 < 2 ** 20 and len(plan) > 1:
                 plan[-1].extend(cur)        # a sub-megabyte tail joins the previous small-model group
             else:
                 plan.append(cur)
         unit = ALIGN * max(world_size, 1)
-        gsize = [_padded(sum(sizes[i] for i in g), unit) for g in plan]
+        gsize = [_padded(sum(units[u][3] for u in g), unit) for g in plan]
         total = sum(gsize)
         self.flat_p = torch.zeros(total, device=dev)
         self.flat_g = torch.zeros(total, device=dev)
@@ -408,28 +489,41 @@ class Trainer:
             self.pack_cache.before_refresh = self.sync_params
         self.buckets = [None] * len(models)
         self.groups = []
+        seg_parts = {}
         off = 0
         for g, gs in zip(plan, gsize):
             o = off
             members = []
-            for i in g:
-                st = (self.flat_p[o:o + sizes[i]], self.flat_g[o:o + sizes[i]])
-                b = FlatBucket(models[i], "model%d" % i, direct=getattr(models[i], "direct_grad", False), storage=st)
-                self.buckets[i] = b
+            for u in g:
+                i, k, plist, n_u = units[u]
+                st = (self.flat_p[o:o + n_u], self.flat_g[o:o + n_u])
+                b = FlatBucket(models[i], "model%d" % i + ("" if k is None else ".s%d" % k), direct=getattr(models[i], "direct_grad", False), storage=st,
+                               params=plist)
+                if k is None:
+                    self.buckets[i] = b
+                else:
+                    seg_parts.setdefault(i, []).append(b)
                 members.append(b)
-                o += sizes[i]
+                o += n_u
             self.groups.append(CommGroup(members, world_size, group, zero1, arena=(self.flat_p[off:off + gs], self.flat_g[off:off + gs]),
                                          force=force_collectives))
             off += gs
+        for i, parts in seg_parts.items():
+            self.buckets[i] = SegmentedBucket(models[i], parts, "model%d" % i)
         # the clip norms of every group as slices of ONE vector: under ZeRO-1 the partial sums of all groups are all-reduced by one
         # collective in Trainer.step() (a tiny all-reduce per group between its norm and its Adam kernel was a stream round trip each:
         # 11 of them, ~1 ms of the step's serial tail)
         nb = sum(len(g.buckets) for g in self.groups)
         self.normsq_all = torch.zeros(nb, device=dev)
         o = 0
+        slot = {}
         for g in self.groups:
             g.normsq = self.normsq_all[o:o + len(g.buckets)]
+            for j, b in enumerate(g.buckets):
+                slot[id(b)] = o + j
             o += len(g.buckets)
+        # a segmented model's clip needs the norm of the WHOLE model: the slots of its segments, summed in step() before any Adam kernel
+        self.seg_slots = [torch.tensor([slot[id(b)] for b in self.buckets[i].segments], device=dev) for i in sorted(seg_parts)]
         if multi:
             broadcast_replicas(models, self.flat_p, group)
         # single process: clip + Adam of a group run on a stream of their own as soon as its last member's backward has reported,
@@ -448,6 +542,13 @@ class Trainer:
         small = [i for i in idx if type(models[i]).__name__ == "DistillModule"]
         rest = [i for i in idx if i not in big and i not in small]
         return big + small + rest[::-1]
+
+    def leaf_buckets(self):
+        """every FlatBucket, the segments of a SegmentedBucket included (tests, diagnostics)"""
+        out = []
+        for b in self.buckets:
+            out.extend(b.segments if isinstance(b, SegmentedBucket) else [b])
+        return out
 
     def zero_grad(self):
         from ..model import packing
@@ -540,12 +641,15 @@ class Trainer:
                 g.stepped, early = False, True
             else:
                 pending.append(g)
-        if self.zero1 and len(pending) == len(self.groups):
+        if (self.zero1 or self.seg_slots) and len(pending) == len(self.groups):
             # norms of all groups, ONE all-reduce, then every group's clip + Adam + parameter all-gather
             self.normsq_all.zero_()
             for g in pending:
                 g.step_norms(zero=False)
-            dist.all_reduce(self.normsq_all, op=dist.ReduceOp.SUM, group=pending[0].pg)
+            if self.zero1:
+                dist.all_reduce(self.normsq_all, op=dist.ReduceOp.SUM, group=pending[0].pg)
+            for idx in self.seg_slots:       # per-MODEL clip of a model exchanged in segments: every segment reads the model's norm
+                self.normsq_all.index_copy_(0, idx, self.normsq_all.index_select(0, idx).sum().expand(idx.numel()).contiguous())
             for g in pending:
                 g.step_update(self.t, self.lr, self.beta1, max_norm=self.max_norm, step_dev=self.t_dev)
         else:

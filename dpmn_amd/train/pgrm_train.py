@@ -262,35 +262,31 @@ class UnpackQueue:
     whole run); flush() sums the slots of every conv that ran since the last flush into the parameter layout."""
 
     def __init__(self):
-        self.entries, self.order, self.touched, self.table = {}, [], set(), None
+        self.entries, self.order, self.touched, self.tables = {}, [], set(), {}
 
     def region(self, key, n, dweight, geom, slots):
         e = self.entries.get(key)
         if e is None:
             e = self.entries[key] = [torch.empty(n, device=dweight.device), dweight, geom, slots]
             self.order.append(key)
-            self.table = None
         self.touched.add(key)
         return e[0]
 
     def flush(self):
+        """One launch for every conv that ran since the last flush.  The device table is cached per SET of convs: the whole module
+        (one flush per backward) or one exchange segment of it (train/cmm_train.py: a flush per segment when the gradients are
+        exchanged in segments)."""
         import struct
         if not self.touched:
             return
-        if len(self.touched) != len(self.order):      # a partial pass (not every registered conv ran): one launch per conv
-            for key in self.order:
-                if key in self.touched:
-                    ws, dw, (cout, cin, kh, kw, co, ci, st), slots = self.entries[key]
-                    check(lib.dpmn_conv2d_wgrad_unpack_f32(dptr(ws), dptr(dw), cout, cin, kh, kw, co, ci, *st, 0, slots, stream()))
-            self.touched.clear()
-            return
-        if self.table is None:
-            raw, prefix, nb = bytearray(), [], 0
-            self.bytes = 0.0       # compulsory bytes of the launch: every slot read once, the parameter-layout gradient read + written
+        keys = tuple(k for k in self.order if k in self.touched)
+        tab = self.tables.get(keys)
+        if tab is None:
+            raw, prefix, nb, nbytes = bytearray(), [], 0, 0.0
             shape = (C.c_int * 3)()
-            for key in self.order:
+            for key in keys:
                 ws, dw, (cout, cin, kh, kw, co, ci, st), slots = self.entries[key]
-                self.bytes += 4.0 * (ws.numel() + 2 * min(co, cout) * min(ci, cin) * kh * kw)
+                nbytes += 4.0 * (ws.numel() + 2 * min(co, cout) * min(ci, cin) * kh * kw)      # every slot read once, the gradient read + written
                 K = kh * kw * cin
                 kp = (K + 31) // 32 * 32
                 check(lib.dpmn_conv_pack_tile_shape(cout, cin, kh * kw, st[0], st[1], C.cast(shape, C.c_void_p)))
@@ -300,11 +296,11 @@ class UnpackQueue:
                                    min(co, cout), min(ci, cin), co_t, ci_t, order, nci, slots)
                 prefix.append(nb)
                 nb += (cout + co_t - 1) // co_t * nci
-            dev = self.entries[self.order[0]][0].device
-            self.table = (torch.frombuffer(raw, dtype=torch.uint8).to(dev), torch.tensor(prefix, dtype=torch.int32, device=dev), nb)
-        descs, prefix, nb = self.table
-        lib.dpmn_profile_hint_bytes(self.bytes)
-        check(lib.dpmn_conv2d_wgrad_unpack_multi_f32(descs.data_ptr(), prefix.data_ptr(), len(self.order), nb, stream()))
+            dev = self.entries[keys[0]][0].device
+            tab = self.tables[keys] = (torch.frombuffer(raw, dtype=torch.uint8).to(dev), torch.tensor(prefix, dtype=torch.int32, device=dev), nb, nbytes)
+        descs, prefix, nb, nbytes = tab
+        lib.dpmn_profile_hint_bytes(nbytes)
+        check(lib.dpmn_conv2d_wgrad_unpack_multi_f32(descs.data_ptr(), prefix.data_ptr(), len(keys), nb, stream()))
         self.touched.clear()
 
 
@@ -617,11 +613,28 @@ def _blocks_backward_native(m, sv, gr, drop, dtkv, dtq, dcat, B):
     arena = _tn_pending[0]
     used = C.c_size_t(_tn_pending[1])
     _tn_pending[2].append(scratch)       # holds partial rows of queued reductions: alive until the flush
-    check(lib.dpmn_pgrm_blocks_backward_f32(C.byref(w), gs, ts, C.byref(cs), C.byref(cd) if cd is not None else None, numel, dptr(dtkv), dptr(dtq),
-                                            _abi.ptr_array(dcat), dptr(_zero_bias(Ch, dtkv.device)), scratch.data_ptr(), need, arena.data_ptr(),
-                                            arena.numel() * 4, C.byref(used), B, stream()))
+    check(lib.dpmn_pgrm_blocks_backward_leaf_f32(C.byref(w), gs, ts, C.byref(cs), C.byref(cd) if cd is not None else None, numel, dptr(dtkv), dptr(dtq),
+                                                 _abi.ptr_array(dcat), dptr(_zero_bias(Ch, dtkv.device)), scratch.data_ptr(), need, arena.data_ptr(),
+                                                 arena.numel() * 4, C.byref(used), B, stream(), _leaf_stream(dtkv.device)))
     _tn_pending[1] = used.value
     del keep
+
+
+# 1: the weight gradients of the Swin blocks (leaves of the backward graph) go to a second stream (csrc/pgrm_backward.hip).  Which one: a
+# stream that is idle while the PGRM backwards run AND sits on another hardware queue than the calling branch stream (HIP maps streams
+# onto four queues in creation order, dpmn_amd/_streams.py) -- the conv weight-gradient stream of the CMM backward for branch 1 (and for
+# an unforked step), the PSN prefetch lane for branch 2.
+BWD_LEAF_STREAM = os.environ.get("DPMN_BWD_LEAF_STREAM", "0") != "0"
+
+
+def _leaf_stream(device):
+    if not BWD_LEAF_STREAM or torch.cuda.is_current_stream_capturing():
+        return None
+    from .. import _streams
+    p = _streams.pool(device)
+    cur = torch.cuda.current_stream(device)
+    leaf = p["psn"] if cur == p["branch"][1] else p["wgrad"]
+    return None if leaf == cur else leaf.cuda_stream
 
 
 def backward(m, sv, dout, need_dx_kv=True):

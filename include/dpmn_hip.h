@@ -223,6 +223,10 @@ int dpmn_xred_fallbacks(unsigned* count_out, int reset);
 /* Device self-test of the DPP / permlane-swap lane exchanges the reductions are built on (csrc/common.h xshfl): *mismatches_out = the
  * number of lanes whose exchange differs from __shfl_xor (0 on a correct build).  Test hook; no reference counterpart. */
 int dpmn_selftest_xshfl(unsigned* mismatches_out);
+/* Test hook: `blocks` workgroups that fill their CU's whole LDS allocation (160 KB) with `pattern` and exit -- launched next to a kernel
+ * under test it changes what that kernel would find in LDS words it reads without having written them (a kernel must not depend on
+ * LDS contents it did not produce: under stream concurrency they are another kernel's leftovers). */
+int dpmn_selftest_lds_poison(unsigned pattern, int blocks, dpmn_stream_t stream);
 /* 1 / 0: use / do not use the in-L2 split-K reduction for the layers that qualify; -1: the DPMN_CONV_XRED environment variable
  * (default 0: on MI355X the reduce launch measured faster, DESIGN.md "Measured and rejected", round 4). */
 int dpmn_xred_enable(int on);
@@ -760,6 +764,15 @@ int dpmn_pgrm_blocks_backward_f32(const dpmn_pgrm_weights* w, const dpmn_pgrm_bl
                                   const dpmn_pgrm_saved* sv, const dpmn_pgrm_drop* drop, const int* table_numel, float* dtkv, float* dtq,
                                   float* const* dcat_zero, const float* zero_bias, void* scratch, size_t scratch_bytes, void* arena,
                                   size_t arena_bytes, size_t* arena_used, int B, dpmn_stream_t stream);
+/* The same with the LEAVES of the backward graph -- the Linear / pointwise-conv weight gradients and the ordered row reductions of the
+ * gate and bias-table gradients (autograd of pgrm.py:315-331: nothing in the call consumes them) -- issued on `leaf_stream` behind events
+ * recorded on `stream`; `stream` waits for `leaf_stream` before a buffer a leaf reads is overwritten and at the end of the call, so the
+ * caller's view is unchanged: everything is complete in `stream` order on return.  leaf_stream == NULL or == stream: one stream.
+ * Same kernels, same arguments, same reduction order: bitwise the gradients of dpmn_pgrm_blocks_backward_f32. */
+int dpmn_pgrm_blocks_backward_leaf_f32(const dpmn_pgrm_weights* w, const dpmn_pgrm_block* grads, const dpmn_pgrm_block_t* wt,
+                                       const dpmn_pgrm_saved* sv, const dpmn_pgrm_drop* drop, const int* table_numel, float* dtkv, float* dtq,
+                                       float* const* dcat_zero, const float* zero_bias, void* scratch, size_t scratch_bytes, void* arena,
+                                       size_t arena_bytes, size_t* arena_used, int B, dpmn_stream_t stream, dpmn_stream_t leaf_stream);
 /* see dpmn_pgrm_saved above; scratch: the per-stream conv scratch (may be NULL: no split-K) */
 int dpmn_pgrm_forward_train_f32(const dpmn_pgrm_weights* w, const float* x_q, int x_q_channels, const float* x_kv,
                                 const float* const* residuals, int n_residuals, const float* tail0_packed, const float* tail1_packed,

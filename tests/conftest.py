@@ -19,7 +19,8 @@ def pytest_configure(config):
 # bf16x3" (dpmn_set_compute_dtype(2): fp32 products as six bf16 MFMAs of an exact three-term operand split in the kernels that have
 # the variant) -- same tests, same tolerances.  Modules that switch the mode themselves, spawn their own processes or hold no MFMA
 # kernel with a variant run once.  DPMN_TEST_MODES=f32 | x3 | f32,x3 restricts the passes.
-X3_EXEMPT = ("test_gpu_x3.py", "test_gpu_bf16.py", "test_gpu_multirank.py", "test_gpu_dataset.py", "test_gpu_stn.py", "test_gpu_dp.py")
+# (test_gpu_xred.py: the in-L2 split-K reduction is an opt-in fp32 experiment whose tests assert WHICH kernels ran)
+X3_EXEMPT = ("test_gpu_x3.py", "test_gpu_bf16.py", "test_gpu_multirank.py", "test_gpu_dataset.py", "test_gpu_stn.py", "test_gpu_dp.py", "test_gpu_xred.py")
 
 
 def _modes():
@@ -32,13 +33,11 @@ def pytest_generate_tests(metafunc):
         return
     if os.path.basename(str(metafunc.definition.fspath)) in X3_EXEMPT:
         return
-    if "_compute_mode" not in metafunc.fixturenames:
-        metafunc.fixturenames.append("_compute_mode")
     metafunc.parametrize("_compute_mode", _modes(), indirect=True, scope="function")
 
 
-@pytest.fixture
-def _compute_mode(request):
+@pytest.fixture(autouse=True)      # autouse: in every test's fixture closure (a name appended in pytest_generate_tests is pruned again), a no-op
+def _compute_mode(request):        # unless the test was parametrised above; tests/test_gpu_abi.py checks that the [x3] pass runs in mode 2
     mode = getattr(request, "param", "f32")
     if mode == "f32":
         yield mode

@@ -273,3 +273,146 @@ def test_zero1_checkpoint_right_after_step_world2_gloo(tmp_path):
     for rank, worst, same in res:
         assert same, "checkpoints differ between ranks (rank %d)" % rank
         assert worst < 2e-5, (rank, worst)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Segmented exchange (train/optim.py SegmentedBucket): a large direct-mode model is exchanged in K collectives, one per backward-
+# ordered parameter segment, each launched the moment the module's backward reports the segment -- i.e. BEFORE the backward returns --
+# while the clip stays per MODEL (one norm over all segments).
+
+class _SegmentedMLP(torch.nn.Module):
+    """three direct-mode Linear layers; the explicit backward writes each layer's gradient straight into the bucket's sink and
+    reports its segment (the protocol of train/cmm_train.py backward / seg_done)"""
+    direct_grad = True
+
+    def __init__(self):
+        super().__init__()
+        self.l0 = torch.nn.Parameter(torch.randn(600, 6) * 0.2)
+        self.l1 = torch.nn.Parameter(torch.randn(600, 600) * 0.05)
+        self.l2 = torch.nn.Parameter(torch.randn(3, 600) * 0.2)
+        self.launched_inside = []       # per backward call: was segment 0's collective already launched when segment 1 was computed?
+
+    def exchange_segments(self):
+        return [[self.l2], [self.l1], [self.l0]]          # backward order
+
+    def forward(self, x):
+        m = self
+
+        class F(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, anchor):
+                h0 = torch.tanh(x @ m.l0.t())
+                h1 = torch.tanh(h0 @ m.l1.t())
+                ctx.save_for_backward(x, h0, h1)
+                return h1 @ m.l2.t()
+
+            @staticmethod
+            def backward(ctx, dy):
+                x, h0, h1 = ctx.saved_tensors
+                b = getattr(m, "_dpmn_bucket", None)
+                seg = b is not None and hasattr(b, "segment_ready")
+                sink = (lambda p: p._dpmn_sink) if b is not None else None
+                g2 = dy.t() @ h1
+                d1 = (dy @ m.l2.detach()) * (1 - h1 * h1)
+                if b is None:
+                    g1 = d1.t() @ h0
+                    d0 = (d1 @ m.l1.detach()) * (1 - h0 * h0)
+                    m.l2.grad, m.l1.grad, m.l0.grad = g2, g1, d0.t() @ x
+                    return None, None
+                sink(m.l2).add_(g2)
+                if seg:
+                    b.segment_ready(b.seg_of[id(m.l2)])
+                    m.launched_inside.append(b.segments[b.seg_of[id(m.l2)]].group.launched)
+                sink(m.l1).add_(d1.t() @ h0)
+                if seg:
+                    b.segment_ready(b.seg_of[id(m.l1)])
+                d0 = (d1 @ m.l1.detach()) * (1 - h0 * h0)
+                sink(m.l0).add_(d0.t() @ x)
+                if seg:
+                    b.segment_ready(b.seg_of[id(m.l0)])
+                else:
+                    b.grads_ready()
+                return None, None
+        b = getattr(self, "_dpmn_bucket", None)
+        if b is not None:
+            b.note_use()
+            return F.apply(x, b.anchor)
+        return F.apply(x, torch.zeros(1, requires_grad=True))
+
+
+def _seg_worker(rank, world, port, q, zero1):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpmn_amd.train import optim
+    optim._sumsq, optim._adam_clip = _torch_sumsq, _torch_adam_clip
+    torch.manual_seed(500 + rank)
+    big, tail = _SegmentedMLP(), torch.nn.Linear(3, 2)
+    tr = optim.Trainer([big, tail], lr=1e-2, beta1=0.5, max_norm=0.25, world_size=world, zero1=zero1, group_mb=0.005)
+    assert isinstance(tr.buckets[0], optim.SegmentedBucket) and len(tr.buckets[0].segments) == 3
+    assert len({id(s_.group) for s_ in tr.buckets[0].segments}) >= 2, "the segments must not share one collective"
+    # the arena holds the big model in BACKWARD order: l2, l1, l0
+    offs = [s_.flat_g.data_ptr() for s_ in tr.buckets[0].segments]
+    assert offs == sorted(offs)
+    torch.manual_seed(500)
+    rbig, rtail = _SegmentedMLP(), torch.nn.Linear(3, 2)
+    for a_, b_ in ((big, rbig), (tail, rtail)):
+        for p, r in zip(a_.parameters(), b_.parameters()):
+            assert torch.equal(p.detach(), r.detach()), "replicas must start from rank 0's parameters"
+    opts = [torch.optim.Adam(m_.parameters(), lr=1e-2, betas=(0.5, 0.999)) for m_ in (rbig, rtail)]
+    worst = 0.0
+    for step in range(3):
+        xs = [torch.randn(8, 6, generator=torch.Generator().manual_seed(20 * step + r)) for r in range(world)]
+        tr.zero_grad()
+        (tail(big(xs[rank])).pow(2).mean() * 50).backward()
+        assert big.launched_inside[-1], "segment 0's collective must be issued while the backward is still computing segment 1"
+        tr.step()
+        tr.sync_params()
+        for m_ in (rbig, rtail):
+            for p in m_.parameters():
+                p.grad = None
+        for r in range(world):
+            (rtail(rbig(xs[r])).pow(2).mean() * 50 / world).backward()
+            if r == 0:
+                acc = [p.grad.clone() for p in rbig.parameters()]
+            else:
+                for a_, p in zip(acc, rbig.parameters()):
+                    a_ += p.grad            # (the explicit backward of the reference ASSIGNS .grad: accumulate by hand)
+        for a_, p in zip(acc, rbig.parameters()):
+            p.grad = a_
+        for m_, o in zip((rbig, rtail), opts):
+            torch.nn.utils.clip_grad_norm_(m_.parameters(), 0.25)     # per MODEL: one norm over the three segments
+            o.step()
+        for a_, b_ in ((big, rbig), (tail, rtail)):
+            for p, r in zip(a_.parameters(), b_.parameters()):
+                worst = max(worst, float((p.detach() - r.detach()).abs().max()))
+    flat = tr.flat_p.clone()
+    other = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(other, flat)
+    q.put((rank, worst, all(torch.equal(other[0], o) for o in other)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_seg(zero1):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seg_worker, args=(r, 2, port, q, zero1)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, same in res:
+        assert same, "ranks diverged (rank %d)" % rank
+        assert worst < 2e-5, (rank, worst)
+
+
+def test_segmented_exchange_starts_inside_backward_allreduce_world2_gloo():
+    _run_seg(zero1=False)
+
+
+def test_segmented_exchange_starts_inside_backward_zero1_world2_gloo():
+    _run_seg(zero1=True)

@@ -11,3 +11,12 @@ def test_lane_exchange_selftest():
     n = ctypes.c_uint(12345)
     check(lib.dpmn_selftest_xshfl(ctypes.byref(n)))
     assert n.value == 0
+
+
+@pytest.mark.gpu
+def test_compute_mode_pass_sets_the_library_mode(request):
+    """tests/conftest.py runs every GPU test twice: the [x3] instance must really execute in mode 2 (dpmn_set_compute_dtype(2)), the
+    [f32] instance in mode 0 -- a parametrisation that silently ran both in fp32 would double the suite for nothing."""
+    from dpmn_amd import _abi
+    mode = request.node.callspec.params.get("_compute_mode") if hasattr(request.node, "callspec") else "f32"
+    assert _abi.lib.dpmn_get_compute_dtype() == (2 if mode == "x3" else 0), mode

@@ -443,14 +443,19 @@ def test_cmm_grouped_twin_data_gradients_equal_per_branch_launches(dev, B, monke
     assert len(res[True][1]) == (8 if B == 48 else 6), res[True][1]
     names = ["dx1", "dx2"] + [n for n, _ in m.named_parameters()]
     worst = 0.0
+    # fp32: the grouped launch and the two per-branch launches run the SAME kernel on the same operands in another tile order (2e-6).
+    # Mode 2: the grouped 3 x 3 of a level may take the implicit-GEMM kernel (bf16x3) where the per-branch launches take the halo kernel
+    # (fp32 at these sizes): two fp32-class results of different arithmetic, 1.0e-5 at the worst tensor -- the bar is 3x that
+    from dpmn_amd import _abi
+    tol = 3e-5 if _abi.lib.dpmn_get_compute_dtype() == 2 else 1e-5
     for n, g1, g0 in zip(names, res[True][0], res[False][0]):
         if float(g0.abs().max()) < 2e-3:
             continue      # bias in front of a train-mode BatchNorm: zero fill
         e = l2_err(g1, g0)
         worst = max(worst, e)
-        assert e < 1e-5, (n, e)
+        assert e < tol, (n, e)
     from helpers import record
-    record("cmm_grouped_dgrad_B%d" % B, "worst gradient rel L2, grouped vs per-branch data gradients", worst, 1e-5)
+    record("cmm_grouped_dgrad_B%d" % B, "worst gradient rel L2, grouped vs per-branch data gradients", worst, tol)
 
 
 @pytest.mark.parametrize("cnum,B", [(64, 4), (64, 6)])
@@ -798,14 +803,45 @@ def test_cmm_backward_vs_reference_gradient_fixture(dev, cnum):
     if cnum == 8:
         _fixture_check("cmm_grads_cnum8", g, named, tol=1e-5)
     else:
-        # B = 2: 8-sample BatchNorm statistics at the 1 x 4 bottleneck -- the reference's OWN fp32 gradients are up to 6.6e-3 away from
-        # a float64 run of the same modules (tests/golden/grads_cmm_cnum64_f64.npz, tools/gen_golden.py gen_f64), so a tolerance
-        # against the fp32 fixture says nothing: the float64 result arbitrates (helpers.check_vs_f64)
-        from helpers import check_vs_f64
-        # measured: worst tensor 2.4 x, RMS 4.3 x the reference's own fp32 distance (uniform-noise inputs straight into the CMM: one
-        # LeakyReLU derivative that flips at a pre-activation within fp32 round-off of zero moves the early branch-1 tensors by
-        # O(1e-3); inside the step fixture, on cascade images, the same CMM measures 0.94 / 0.86)
-        check_vs_f64("cmm_grads_cnum64_f64", load_golden("grads_cmm_cnum64_f64"), named, factor=6.0)
+        # The reference's OWN fp32 gradients are up to 6.6e-3 away from a float64 run of the same modules -- not because of the
+        # 8-sample BatchNorm statistics at the 1 x 4 bottleneck (the explanation of rounds 4-5) but because one of the 2 M LeakyReLU /
+        # ReLU inputs that lie within fp32 round-off of the kink takes the other derivative branch in its fp32 run (en_2_1); this
+        # library's run flips another one (en_4_1: tools/dbg_cnum64_f64.py).  float64 arbitrates AFTER taking the implementation's
+        # own branch at those 15 listed elements (helpers "Kink-aware float64 adjudication"): both implementations are then within
+        # ~2e-6 of float64 on every tensor, and the common bar applies (worst / RMS within 3x the reference's, every tensor within 10x).
+        from dpmn_amd.train import cmm_train
+        from helpers import cmm_grads_f64, check_adjudicated, rel_l2, record
+        z = load_golden("grads_cmm_cnum64_f64")
+        with torch.no_grad():
+            _, graph = cmm_train.build(m, x1.detach(), x2.detach())
+        names = {id(mod): n for n, mod in m.named_modules()}
+        prod = {"gate": graph["gated"]}
+        for u_ in graph["units"]:
+            if u_.out is not None and u_.out.r is not None:
+                prod[names[id(u_.bn if u_.bn is not None else u_.conv)]] = u_.out
+        forced, flips = [], 0
+        for site, i, y64 in zip(z["kink_site"], z["kink_index"], z["kink_y64"]):
+            tns = prod[str(site).split(">")[0]]
+            Bq, Hq, Wq, Cq = tns.r.shape
+            i = int(i)
+            c_, h_, w_ = (i // (Hq * Wq)) % Cq, (i // Wq) % Hq, i % Wq
+            b_ = i // (Cq * Hq * Wq)
+            y = tns.r[b_, h_, w_, c_]
+            if tns.scale is not None:
+                y = y * tns.scale[c_] + tns.shift[c_]          # mul, then add: the kernels' on-load affine (-ffp-contract=off)
+            forced.append((str(site), i, bool(y > 0)))
+            flips += int(bool(y > 0) != (float(y64) > 0))
+        record("cmm_grads_cnum64_f64", "pre-activations within %g of a kink where this run takes the other branch than float64 (of %d)" % (2e-6, len(forced)), flips)
+        sd_cpu = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+        g64 = cmm_grads_f64(sd_cpu, x1.detach().cpu(), x2.detach().cpu(), cot.cpu(), forced)
+        gmax = max(float(v.abs().max()) for v in g64.values())
+        nm, e_ours, e_ref = [], [], []
+        for n_, g_ in named.items():
+            if float(g64[n_].abs().max()) < 1e-9:          # exactly zero by construction (conv biases in front of a batch-statistics BatchNorm)
+                assert float(g_.abs().max()) <= 1e-5 * gmax, (n_, float(g_.abs().max()))
+                continue
+            nm.append(n_); e_ours.append(rel_l2(g_, g64[n_])); e_ref.append(float(z[n_ + "::ref32_err_adj"]))
+        check_adjudicated("cmm_grads_cnum64_f64", nm, e_ours, e_ref, factor=3.0, per_tensor=10.0)
 
 
 def test_training_step_vs_reference_step_fixture(dev):

@@ -195,3 +195,35 @@ def test_oracle_gradients_are_as_close_to_float64_as_the_reference_fp32():
     assert abs(float(loss) - float(z["loss"])) / float(z["loss"]) <= 1.5 * float(z["loss_ref32_err"]) + 2e-7
     for i, g in enumerate(grads):
         check_vs_f64("oracle_step_f64", z, g, "m%d/" % i)
+
+
+def test_oracle_cmm_float64_is_the_reference_float64_and_reproduces_the_kink_list():
+    """The kink-aware adjudication of the cnum-64 CMM gradient fixture (helpers "Kink-aware float64 adjudication") runs the ORACLE in
+    float64: its gradients equal the imported reference's float64 gradients (fixture digests) to 1e-9, the pre-activations within
+    fp32 round-off of a kink are the ones the fixture lists, and with the reference's own fp32 branch forced at them the float64
+    gradients move by O(1e-3) on the tensors upstream of the flipped element -- the whole of the reference's fp32 'error'."""
+    from helpers import load_golden, cmm_sites, ambiguous_kinks, cmm_grads_f64, grad_error_vs_fixture, fixture_grad_names, sd_from_manifest
+    from dpmn_amd.utils import synth
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    z = load_golden("grads_cmm_cnum64_f64")
+    m = ComplementationModulationModule(cnum=64)
+    sd = m.state_dict()
+    synth.synth_fill_(sd, 31)
+    B = 2
+    x1 = synth.uniform("cmm_x1", (B, 3, 32, 128), 0, 1, 7)
+    x2 = synth.uniform("cmm_x2", (B, 3, 32, 128), 0, 1, 7)
+    cot = synth.uniform("cmm_cot", (B, 3, 32, 128), -1, 1, 7)
+    sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd.items()}
+    kinks = ambiguous_kinks(cmm_sites(sd64, x1.double(), x2.double()))
+    assert [k[0] for k in kinks] == [str(s_) for s_ in z["kink_site"]] and [k[1] for k in kinks] == [int(i) for i in z["kink_index"]]
+    g = cmm_grads_f64(sd, x1, x2, cot)
+    worst = 0.0
+    for n in fixture_grad_names(z):
+        err, amax = grad_error_vs_fixture(z, n, g[n])
+        if amax >= 1e-9:
+            worst = max(worst, err)
+    assert worst < 1e-7, worst          # (digest metric: norms and projections of up to 2 M-element tensors)
+    forced = [(str(s_), int(i), bool(p)) for s_, i, p in zip(z["kink_site"], z["kink_index"], z["kink_ref32_positive"])]
+    g_adj = cmm_grads_f64(sd, x1, x2, cot, forced)
+    moved = float((g_adj["x1"] - g["x1"]).norm() / g["x1"].norm())
+    assert 1e-4 < moved < 5e-2, moved       # the reference's own fp32 run differentiates another branch: 3.4e-3 on dL/dx1

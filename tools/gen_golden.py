@@ -465,7 +465,43 @@ def gen_f64():
             named[dt] = [("x1", a.grad), ("x2", b.grad)] + [(n, p.grad) for n, p in m.named_parameters()]
             if dt == torch.float64:
                 out64 = out.detach()
-        save("grads_cmm_cnum64_f64", out=out64.numpy(), **f64_arrays("", named[torch.float64], named[torch.float32]))
+        # kink-aware adjudication (tests/helpers.py "Kink-aware float64 adjudication"): the pre-activations within fp32 round-off of a
+        # LeakyReLU / ReLU kink, the sign the REFERENCE's fp32 run has there, and the reference's fp32 gradient error against the
+        # float64 gradients that differentiate the same branch at those elements (`ref32_err_adj`)
+        from tests import helpers as th
+        sd32 = {k: v.clone() for k, v in sd.items()}
+        sd64 = {k: (v.double() if torch.is_floating_point(v) else v) for k, v in sd32.items()}
+        sites64 = th.cmm_sites(sd64, x1.double(), x2.double())
+        kinks = th.ambiguous_kinks(sites64)
+        # the reference's fp32 pre-activations: inputs of its activation modules (decoder inputs are channel concatenations of the
+        # oracle's parts, in the oracle's order)
+        m32 = cmm.ComplementationModulationModule(cnum=64).train()
+        m32.load_state_dict({k: v.clone() for k, v in sd32.items()})
+        ins = {}
+        for n_, mod in m32.named_modules():
+            if isinstance(mod, (torch.nn.LeakyReLU, torch.nn.ReLU)):
+                mod.register_forward_pre_hook(lambda _m, a, n_=n_: ins.__setitem__(n_, a[0].detach()))
+        with torch.no_grad():
+            m32(x1, x2)
+        parts32, off = {}, {}
+        for site, x in sites64:
+            cons = site.split(">")[1]
+            o = off.get(cons, 0)
+            parts32[site] = ins[cons][:, o:o + x.shape[1]]
+            off[cons] = o + x.shape[1]
+            assert parts32[site].shape == x.shape, (site, parts32[site].shape, x.shape)
+        forced = [(site, i, float(parts32[site].reshape(-1)[i]) > 0) for site, i, _ in kinks]
+        g64_adj = th.cmm_grads_f64(sd32, x1, x2, cot, forced)
+        g64_plain = th.cmm_grads_f64(sd32, x1, x2, cot)
+        extra = {"kink_site": np.array([k[0] for k in kinks]), "kink_index": np.array([k[1] for k in kinks], dtype=np.int64),
+                 "kink_y64": np.array([k[2] for k in kinks]), "kink_ref32_positive": np.array([f[2] for f in forced])}
+        for name, g32 in named[torch.float32]:
+            extra[name + "::ref32_err_adj"] = np.array(th.rel_l2(g32, g64_adj[name]))
+            # the oracle's float64 gradients ARE the reference's (same float64 math): recorded, and asserted by the tests
+            extra[name + "::oracle64_vs_ref64"] = np.array(th.rel_l2(g64_plain[name], dict(named[torch.float64])[name]))
+        print("cnum64 f64: %d ambiguous pre-activations (|y| < %g); reference fp32 takes the other branch at %d of them; oracle f64 vs reference f64 max %.1e" % (
+            len(kinks), th.KINK_TOL, sum(1 for (s_, i, y), f in zip(kinks, forced) if (y > 0) != f[2]), max(float(v) for k, v in extra.items() if k.endswith("oracle64_vs_ref64"))))
+        save("grads_cmm_cnum64_f64", out=out64.numpy(), **f64_arrays("", named[torch.float64], named[torch.float32]), **extra)
 
         b1 = b2 = 2
         batch = synth.synth_batch(B, seed=4)
