@@ -77,16 +77,21 @@ def _worker(rank, world, port, zero1, q):
         sr_.train_step(models, psn, distill, crit, trainer, lr_, hr_, None, text_priors=pri)
         trainer.sync_params()
         torch.cuda.synchronize()
-        # what was exchanged: zero1 -> my averaged shard per group; else the whole averaged gradient arena
-        per_bucket = {}
+        # what was exchanged: zero1 -> my averaged shard per group; else the whole averaged gradient arena.  Gathered PER PARAMETER in
+        # model order: the CMM's gradients are exchanged in five backward-ordered segments (train/optim.py SegmentedBucket), so its
+        # arena layout differs from the single-process reference's
+        by_param = {}
         for g in trainer.groups:
             full = torch.zeros(g.n, device=dev)
             full[g.lo:g.lo + g.shard_n] = g.g_shard if g.zero1 else g.flat_g[g.lo:g.lo + g.shard_n]
             if g.zero1:
                 dist.all_reduce(full)                        # assemble the shards of both ranks
-            for bkt, off in zip(g.buckets, g.offsets):       # (the arenas are padded per world size: compare bucket by bucket)
-                per_bucket[bkt.name] = full[off:off + bkt.n].clone()
-        got = torch.cat([per_bucket[b_.name] for b_ in trainer.buckets])
+            for bkt, off in zip(g.buckets, g.offsets):       # (the arenas are padded per world size: bucket by bucket)
+                for prm, po, n_ in bkt.param_slices():
+                    by_param[id(prm)] = full[off + po:off + po + n_].clone()
+        from dpmn_amd.train.optim import SegmentedBucket
+        n_seg = sum(len(b_.segments) for b_ in trainer.buckets if isinstance(b_, SegmentedBucket))
+        got = torch.cat([by_param[id(prm)] for m in models + distill for prm in m.parameters()])
         p1 = trainer.flat_p.clone()
         dist.all_gather(others, p1)
         same_end = all(torch.equal(others[0], o) for o in others)
@@ -109,9 +114,9 @@ def _worker(rank, world, port, zero1, q):
             # forward + backward only: reuse train_step with a no-op optimizer
             t2.step = lambda: None
             sr2.train_step(m2, psn2, d2, crit, t2, a, b_, None, text_priors=c)
-            ref += torch.cat([b_.flat_g for b_ in t2.buckets]) / world
+            ref += torch.cat([prm.grad.reshape(-1) for m in m2 + d2 for prm in m.parameters()]) / world
         err = float((got - ref).norm() / (ref.norm() + 1e-30))
-        q.put((rank, same_start, same_end, err, float(ref.norm())))
+        q.put((rank, same_start, same_end, err, float(ref.norm()) if n_seg >= 4 else -2.0))      # (-2: the CMM was not exchanged in segments)
         dist.barrier()
     except Exception as e:      # report instead of leaving the parent waiting for the queue
         import traceback

@@ -22,9 +22,15 @@ for _ in range(3):
     psn.eval()
     batch = synth.synth_batch(B, seed=4)
     priors = [torch.floor(synth.uniform("tp%d" % k, (B, 2, 32, 128), 0, 256, 4)).to(dev) for k in range(b1)]
-    trainer.lr = 0.0
-    lv = batch["label_vecs"].to(dev) if arch == "tatt" else None
-    loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev), lv, text_priors=priors)
+    steps = int(os.environ.get("DBG_STEPS", "1"))      # > 1: real optimisation steps (the reproducibility test's scenario), else lr = 0
+    if steps == 1:
+        trainer.lr = 0.0
+    for st_ in range(steps):
+        if st_:
+            batch = synth.synth_batch(B, seed=4 + st_)
+            priors = [torch.floor(synth.uniform("tp%d_%d" % (k, st_), (B, 2, 32, 128), 0, 256, 4)).to(dev) for k in range(b1)]
+        lv = batch["label_vecs"].to(dev) if arch == "tatt" else None
+        loss = sr_.train_step(models, psn, distill, crit, trainer, batch["images_lr"].to(dev), batch["images_hr"].to(dev), lv, text_priors=priors)
     torch.cuda.synchronize()
     runs.append((float(loss), {("m%d/" % i) + n: p.grad.detach().clone() for i, m in enumerate(models + distill) for n, p in m.named_parameters()}))
 print("losses", [r[0] for r in runs])
