@@ -18,7 +18,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # rocprof kernel name -> the family names bench.py's `kernels` array uses (dpmn_profile tags)
 FAMILIES = [("k_conv_igemm<128, 128", "k_conv_igemm<128,128>"), ("k_conv_igemm<64, 64", "k_conv_igemm<64,64>"),
             ("k_conv_igemm<128, 16", "k_conv_igemm<128,16|32>"), ("k_conv_igemm<128, 32", "k_conv_igemm<128,16|32>"),
-            ("k_conv_splitk_reduce", "k_conv_splitk_reduce"), ("k_conv_halo_c4", "k_conv_halo_c4"), ("k_conv_halo<", "k_conv_halo"),
+            ("k_conv_igemm_x3<128, 128", "k_conv_igemm<128,128>"), ("k_conv_igemm_x3<64, 64", "k_conv_igemm<64,64>"), ("k_conv_igemm_x3<128, 64", "k_conv_igemm<128,64>"),
+            ("k_conv_splitk_reduce", "k_conv_splitk_reduce"), ("k_conv_halo_c4", "k_conv_halo_c4"), ("k_conv_halo<", "k_conv_halo"), ("k_conv_halo_x3", "k_conv_halo"),
+            ("k_conv_wgrad", "k_conv_wgrad"),
             ("k_gemm_pw", "k_gemm_pw"), ("k_gemm_wstat<96, 1", "k_gemm_wstat|rowreg<LN prologue>"), ("k_gemm_wstat<192, 1", "k_gemm_wstat|rowreg<LN prologue>"),
             ("k_gemm_rowreg<96, 1", "k_gemm_wstat|rowreg<LN prologue>"), ("k_gemm_rowreg<192, 1", "k_gemm_wstat|rowreg<LN prologue>"),
             ("k_gemm_wstat", "k_gemm_wstat|rowreg"), ("k_gemm_rowreg", "k_gemm_wstat|rowreg"), ("k_gemm_kloop", "k_gemm_kloop"),
@@ -64,7 +66,7 @@ def latest(base, pattern):
 
 
 def do_reduce(out):
-    for sub in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_fetch_train", "pmc_write_train", "pmc_mfma_train"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_fetch_train", "pmc_write_train", "pmc_mfma_train", "pmc_fetch_x3", "pmc_write_x3", "pmc_mfma_x3"):
         f = latest(out, sub + "/**/*counter_collection.csv")
         if f:
             json.dump(reduce_pmc(f), open(os.path.join(out, sub + ".json"), "w"), indent=1)
@@ -73,7 +75,8 @@ def do_reduce(out):
 
 def do_collect(tag):
     src, dst = os.path.join(ROOT, "gpurun_out", "prof"), os.path.join(ROOT, "profiles")
-    for sub, name in (("fwd", "fwd_cfg1_kernel_stats.csv"), ("train", "train_cfg1_kernel_stats.csv")):
+    for sub, name in (("fwd", "fwd_cfg1_kernel_stats.csv"), ("train", "train_cfg1_kernel_stats.csv"),
+                      ("fwd_x3", "x3_fwd_cfg1_kernel_stats.csv"), ("train_x3", "x3_train_cfg1_kernel_stats.csv")):
         f = latest(src, sub + "/**/*kernel_stats.csv")
         if f:
             shutil.copy(f, os.path.join(dst, "%s_%s" % (tag, name)))
@@ -81,7 +84,7 @@ def do_collect(tag):
     f = os.path.join(src, "pmc_pgrm_mfma_util.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_pmc_pgrm_mfma_util.csv" % tag))
-    for name in ("bench_default", "bench_train", "bench_train_drop", "bench_train_nodrop", "bench_cfg3", "bench_cfg4", "bench_cfg4_train"):
+    for name in ("bench_default", "bench_train", "bench_x3", "bench_train_x3", "bench_train_drop", "bench_train_nodrop", "bench_cfg3", "bench_cfg4", "bench_cfg4_train"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p) and open(p).read().strip().startswith("{"):
             shutil.copy(p, os.path.join(dst, "%s_%s.json" % (tag, name)))
@@ -89,10 +92,11 @@ def do_collect(tag):
                 B = json.load(open(p))["config"]["per_gpu_batch"]
     for suffix, mode, text in (("", "fwd", "cfg1 forward, bench.py --steps 3 --warmup 2 under rocprofv3 --pmc (one counter per pass)"),
                                ("_train", "train", "cfg1 TRAINING step, bench.py --mode train --steps 3 --warmup 2 under rocprofv3 --pmc (one counter group per "
-                                "pass; branch and weight-gradient streams active, so kernels overlap: the per-launch durations are inflated, the byte counts are not)")):
+                                "pass; branch and weight-gradient streams active, so kernels overlap: the per-launch durations are inflated, the byte counts are not)"),
+                               ("_x3", "fwd_x3", "cfg1 forward in mode 2 (f32 via bf16x3), bench.py --dtype x3 --steps 3 --warmup 2 under rocprofv3 --pmc")):
         fe, wr, mf = (json.load(open(os.path.join(src, n + suffix + ".json"))) if os.path.exists(os.path.join(src, n + suffix + ".json")) else {}
                       for n in ("pmc_fetch", "pmc_write", "pmc_mfma"))
-        pre = tag + ("_train" if mode == "train" else "")
+        pre = tag + {"fwd": "", "train": "_train", "fwd_x3": "_x3"}[mode]
         if fe and wr:
             rec = {"per_gpu_batch": B, "mode": mode, "workload": text,
                    "correction": "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",
@@ -107,15 +111,16 @@ def do_collect(tag):
             for fam, c in mf.items():
                 busy, act, mops = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0), c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)
                 avail = act / 8.0 * 1024.0
+                mops16 = c.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0.0)  # same 512-flop unit (checked against the six-product count of k_conv_igemm_x3)
                 rows.append((c["avg_us"] * c["launches"], fam, c["launches"], c["avg_us"], 100.0 * busy / avail if avail else 0.0,
-                             mops * 512 / c["avg_us"] / 1e6 if c["avg_us"] else 0.0))
+                             mops * 512 / c["avg_us"] / 1e6 if c["avg_us"] else 0.0, mops16 * 512 / c["avg_us"] / 1e6 if c["avg_us"] else 0.0))
                 tb += busy * c["launches"]; ta += avail * c["launches"]
             rows.sort(reverse=True)
             with open(os.path.join(dst, pre + "_pmc_mfma_util.csv"), "w") as o:
-                o.write("kernel_family,launches,avg_us,mfma_busy_pct,mfma_tflops\n")
-                for _, fam, n, us, util, tf in rows:
-                    o.write('"%s",%d,%.2f,%.2f,%.2f\n' % (fam, n, us, util, tf))
-                o.write('"ALL dpmn kernels (time-weighted)",,,%.2f,\n' % (100.0 * tb / ta if ta else 0.0))
+                o.write("kernel_family,launches,avg_us,mfma_busy_pct,mfma_f32_tflops,mfma_bf16_tflops\n")
+                for _, fam, n, us, util, tf, tf16 in rows:
+                    o.write('"%s",%d,%.2f,%.2f,%.2f,%.2f\n' % (fam, n, us, util, tf, tf16))
+                o.write('"ALL dpmn kernels (time-weighted)",,,%.2f,,\n' % (100.0 * tb / ta if ta else 0.0))
             print(open(os.path.join(dst, pre + "_pmc_mfma_util.csv")).read())
     pe = os.path.join(ROOT, "gpurun_out", "parity_errors.json")
     if os.path.exists(pe):

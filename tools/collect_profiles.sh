@@ -17,6 +17,13 @@ timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACT
 # BASELINE.json's second metric: MFMA-busy over PGRM forwards only (bench.py pgrm_mfma_util reads the TOTAL row)
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_pgrm -- python $R/tools/prof_pgrm.py 48 > $OUT/pmc_mfma_pgrm.log 2>&1
 python $R/tools/pmc_pgrm_util.py $OUT/pmc_mfma_pgrm $OUT/pmc_pgrm_mfma_util.csv > /dev/null 2>&1
+# mode 2 (f32 via bf16x3): the same forward / training benches, kernel-trace summaries + traffic + MFMA-busy (bf16 MOPS counted too)
+X="$B --dtype x3"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fwd_x3 -- $X --steps 10 --warmup 3 > $OUT/fwd_x3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_x3 -- $X --mode train --steps 5 --warmup 2 > $OUT/train_x3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_x3 -- $X --steps 3 --warmup 2 > $OUT/pmc_fetch_x3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_x3 -- $X --steps 3 --warmup 2 > $OUT/pmc_write_x3.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_x3 -- $X --steps 3 --warmup 2 > $OUT/pmc_mfma_x3.log 2>&1
 if [ "${1:-}" != "quick" ]; then
   T="$B --mode train --steps 3 --warmup 2"
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_train -- $T > $OUT/pmc_fetch_train.log 2>&1
@@ -26,6 +33,8 @@ fi
 cd $R
 timeout 900 python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 timeout 600 python bench.py --mode train 2>/dev/null | tail -1 > $OUT/bench_train.json
+timeout 600 python bench.py --dtype x3 --no-cpu-baseline --no-train 2>/dev/null | tail -1 > $OUT/bench_x3.json
+timeout 600 python bench.py --dtype x3 --mode train --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_train_x3.json
 if [ "${1:-}" != "quick" ]; then
   timeout 600 python bench.py --mode train --drop 0 2>/dev/null | tail -1 > $OUT/bench_train_nodrop.json
   timeout 900 python bench.py --workload cfg4 --mode train --steps 5 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg4_train.json
