@@ -543,10 +543,9 @@ def main():
             PIPE_ON[0] = True
         _abi.check(_abi.lib.dpmn_set_compute_dtype(0))
         if rank == 0:
-            roof3 = roofline_of(live3, args.steps, B, "fwd")
+            roof3 = roofline_of(live3, args.steps, B, "fwd_x3")      # traffic: the mode-2 PMC passes (profiles/*_x3_pmc_traffic.json)
             if roof3 and roof3["bound"] == "mfma":
                 roof3["frac_of_bf16x3_peak"] = round(roof3["achieved"] / BF16X3_PEAK_TFLOPS, 4)
-                roof3["traffic"], roof3["traffic_kind"] = None, None      # the committed PMC passes are fp32-mode runs
             x3 = {"what": X3_WHAT, "dtype": "f32 (products as six bf16 MFMAs of a three-term operand split, fp32 accumulation)",
                   "value": round(world * B * args.steps / e3, 2), "unit": "images/s", "ms_per_step": round(e3 / args.steps * 1e3, 3),
                   "steps": args.steps, "batches_in_flight": max(1, args.pipeline),
@@ -573,7 +572,7 @@ def main():
                                ("dp%d (coalesced gradient groups, RCCL %s overlapped with backward)" % (
                                    world, "reduce-scatter + sharded clip/Adam + all-gather" if trainer.zero1 else "all-reduce"))},
         }
-        roof = roofline_of(live, args.steps, B, args.mode)
+        roof = roofline_of(live, args.steps, B, "fwd_x3" if (args.mode == "fwd" and args.dtype == "x3") else args.mode)
         if latency_ms is not None:
             line["one_batch_at_a_time"] = {"ms_per_step": round(latency_ms, 3), "images_per_s": round(world * B / latency_ms * 1e3, 2),
                                            "what": "the same step with ONE batch in flight (--pipeline 1), timed after the region on rank 0"}

@@ -97,6 +97,10 @@ class TnPending(C.Structure):
     _fields_ = [("part", fp), ("dw", fp), ("db", fp), ("NK", C.c_int), ("N", C.c_int), ("splits", C.c_int)]
 
 
+class TnItem(C.Structure):
+    _fields_ = [("dy", fp), ("x", fp), ("dw", fp), ("db", fp), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("ws", fp), ("ws_bytes", C.c_size_t)]
+
+
 class DistillParams(C.Structure):
     _fields_ = [("conv_cat_w", fp), ("conv_cat_b", fp), ("bn1_w", fp), ("bn1_b", fp), ("bn1_rm", fp), ("bn1_rv", fp), ("bn1_nbt", fp),
                 ("conv_feat_w", fp), ("conv_feat_b", fp), ("bn2_w", fp), ("bn2_b", fp), ("bn2_rm", fp), ("bn2_rv", fp), ("bn2_nbt", fp)]
@@ -170,6 +174,7 @@ SIGNATURES = {
     "dpmn_gemm_tn_partial_bytes": (_sz, [_i, _i, _i]),
     "dpmn_gemm_tn_partial_f32": (_i, [fp, fp, fp, fp, _i, _i, _i, fp, _sz, C.POINTER(TnPending), fp]),
     "dpmn_tn_reduce_multi_f32": (_i, [C.POINTER(TnPending), _i, fp]),
+    "dpmn_gemm_tn_group_f32": (_i, [C.POINTER(TnItem), _i, fp]),
     "dpmn_colsum_f32": (_i, [fp, fp, C.c_long, _i, fp]),
     "dpmn_colsum_det_f32": (_i, [fp, fp, C.c_long, _i, fp, _sz, fp]),
     "dpmn_layernorm_bwd_f32": (_i, [fp, fp, fp, _f, fp, _i, fp, fp, C.c_long, _i, fp]),

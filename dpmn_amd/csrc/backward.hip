@@ -10,6 +10,8 @@
 #include <vector>
 #include "common.h"
 
+#include "gemm_tn.h"
+
 namespace {
 
 // ---------------------------------------------------------------------------------- dW += dY^T X
@@ -147,22 +149,22 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const float* __restrict__ dy, i
 // (k_gemm_tn staged 32-row tiles through LDS with predicated loads and fed every MFMA operand with its own ds_read_b32:
 //  34.5 us per launch on average at M = 24576 -- 13 TFLOP/s, 0.55 TB/s -- against ~5-12 us of HBM time.)
 typedef float f32x3 __attribute__((ext_vector_type(3)));
+// (gx, gy, gz): the product's own grid -- N tiles, K tiles, row splits -- and lid the block's linear id in it (x fastest): the kernel of
+// one product passes its launch grid, the grouped kernel (k_gemm_tn_reg_multi) the descriptor's
 template <int D>
-__global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw,
-                                                      int M, int N, int K, int rows_per_block, float* __restrict__ db,
-                                                      float* __restrict__ part) {
+__device__ __forceinline__ void tn_reg_body(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K, int rows_per_block,
+                                            const float* __restrict__ db, float* __restrict__ part, int gx, int gy, int gz, int lid) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave & 1, wk = wave >> 1;
   const int lr = lane & 15, kq = lane >> 4;
   // the tiles of one row split read the same dY / X rows: XCD c (workgroups are dealt round-robin by linear id) takes the splits
   // z = c, c + 8, ... and runs their tiles back to back, so the shared rows cross the fabric once
-  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-  if ((gridDim.z & 7) == 0 && gridDim.x * gridDim.y > 1) {
-    const int tiles = gridDim.x * gridDim.y;
-    const int lid = bx + gridDim.x * (by + gridDim.y * bz);
+  int bx = lid % gx, by = (lid / gx) % gy, bz = lid / (gx * gy);
+  if ((gz & 7) == 0 && gx * gy > 1) {
+    const int tiles = gx * gy;
     const int c = lid & 7, j = lid >> 3;
     const int zq = j / tiles, t = j - zq * tiles;
-    bz = c + 8 * zq; by = t / (int)gridDim.x; bx = t - by * (int)gridDim.x;
+    bz = c + 8 * zq; by = t / gx; bx = t - by * gx;
   }
   const int n_w = bx * 96 + wn * 48, k_w = by * 96 + wk * 48;
   const int m_lo = bz * rows_per_block;
@@ -221,6 +223,26 @@ __global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ d
       if (kq == 0 && n < N) pz[(size_t)N * K + n] = v;
     }
   }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void k_gemm_tn_reg(const float* __restrict__ dy, const float* __restrict__ x, int M, int N, int K,
+                                                      int rows_per_block, const float* __restrict__ db, float* __restrict__ part) {
+  tn_reg_body<D>(dy, x, M, N, K, rows_per_block, db, part, gridDim.x, gridDim.y, gridDim.z,
+                 blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+}
+
+// Up to 8 products in ONE launch (the Linear weight gradients of a Swin block whose operands are live together, dpmn_gemm_tn_group_f32):
+// a block finds its product by its linear id and runs the body above on the product's own grid -- the partials are the bits the
+// per-product launches write.  A product alone fills the chip with ONE short block per CU (one wave per SIMD: every load latency is
+// exposed); grouped, the CUs hold blocks of several products and run them back to back without launch gaps.
+template <int D>
+__global__ __launch_bounds__(256) void k_gemm_tn_reg_multi(dpmn_gemm::TnGroup g) {
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < 8; ++j) i += (j < g.n && (int)blockIdx.x >= g.first[j]) ? 1 : 0;
+  const dpmn_gemm::TnItem& t = g.it[i];
+  tn_reg_body<D>(t.dy, t.x, t.M, t.N, t.K, t.rows, t.db, t.part, t.gx, t.gy, t.gz, (int)blockIdx.x - g.first[i]);
 }
 
 // dw[e] += sum_z part[z][e] for e < N*K ; db[n] += sum_z part[z][N*K + n].  Block = 64 elements x 4 split groups.
@@ -739,8 +761,11 @@ static int gemm_tn_impl(const float* dy, const float* x, float* dw, float* db, i
   // PGRM block: 96 / 192 / 384) and the byte offsets fit the buffer instructions
   static const int reg_on = getenv("DPMN_TN_REG") ? atoi(getenv("DPMN_TN_REG")) : 1;
   ProfScope prof(PT_GEMM_TN, as_stream(stream), 2.0 * M * (double)N * K, 4.0 * ((double)M * N + (double)M * K + (double)splits * ((double)N * K + N)));
-  if (reg_on && part && N % 48 == 0 && K % 48 == 0 && (size_t)rows * (N > K ? N : K) * 4 < (1ull << 31))
-    hipLaunchKernelGGL(k_gemm_tn_reg<8>, grid, dim3(256), 0, as_stream(stream), dy, x, dw, M, N, K, rows, db, part);
+  const bool reg_ok = reg_on && part && N % 48 == 0 && K % 48 == 0 && (size_t)rows * (N > K ? N : K) * 4 < (1ull << 31);
+  if (reg_ok && x3_on(64))       // mode 2: the same partials on six bf16 MFMAs per tile (gemm_tn_x3.hip)
+    dpmn_gemm::x3_launch_tn(dy, x, M, N, K, rows, db, part, grid, as_stream(stream));
+  else if (reg_ok)
+    hipLaunchKernelGGL(k_gemm_tn_reg<8>, grid, dim3(256), 0, as_stream(stream), dy, x, M, N, K, rows, db, part);
   else
     hipLaunchKernelGGL(k_gemm_tn, grid, dim3(256), 0, as_stream(stream), dy, N, x, K, dw, K, M, N, K, rows, db, part);
   DPMN_CHECK_LAUNCH();
@@ -760,6 +785,64 @@ static int gemm_tn_impl(const float* dy, const float* x, float* dw, float* db, i
 int dpmn_gemm_tn_f32(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
                      dpmn_stream_t stream) {
   return gemm_tn_impl(dy, x, dw, db, M, N, K, ws, ws_bytes, nullptr, stream);
+}
+
+// n Linear weight gradients whose operands are live together: the bits of n dpmn_gemm_tn_f32 calls, with every product that takes the
+// operands-in-registers kernel and has its workspace in ONE launch (k_gemm_tn_reg_multi; up to 8 per launch)
+int dpmn_gemm_tn_group_f32(const dpmn_tn_item* items, int n, dpmn_stream_t stream) {
+  DPMN_REQUIRE(items && n >= 0, "gemm_tn_group: bad arguments");
+  static const int reg_on = getenv("DPMN_TN_REG") ? atoi(getenv("DPMN_TN_REG")) : 1;
+  static const int group_on = getenv("DPMN_TN_GROUP") ? atoi(getenv("DPMN_TN_GROUP")) : 1;
+  dpmn_gemm::TnGroup g{};
+  int idx[8], splits_of[8];
+  double flops = 0.0, bytes = 0.0;
+  auto flush = [&]() -> int {
+    if (g.n == 0) return DPMN_OK;
+    {
+      ProfScope prof(PT_GEMM_TN, as_stream(stream), flops, bytes);
+      if (x3_on(64)) dpmn_gemm::x3_launch_tn_multi(g, as_stream(stream));
+      else hipLaunchKernelGGL(k_gemm_tn_reg_multi<8>, dim3(g.first[g.n]), dim3(256), 0, as_stream(stream), g);
+      DPMN_CHECK_LAUNCH();
+    }
+    for (int j = 0; j < g.n; ++j) {
+      const dpmn_tn_item& t = items[idx[j]];
+      if (!reduce_deferred(g.it[j].part, t.dw, t.db, t.N * t.K, t.N, splits_of[j])) {
+        const int tot = t.N * t.K + (t.db ? t.N : 0);
+        hipLaunchKernelGGL(k_tn_reduce, dim3(cdiv(tot, 64)), dim3(256), 0, as_stream(stream), g.it[j].part, t.dw, t.db, t.N * t.K, t.N, splits_of[j]);
+        DPMN_CHECK_LAUNCH();
+      }
+    }
+    g = dpmn_gemm::TnGroup{};
+    flops = bytes = 0.0;
+    return DPMN_OK;
+  };
+  for (int i = 0; i < n; ++i) {
+    const dpmn_tn_item& t = items[i];
+    DPMN_REQUIRE(t.dy && t.x && t.dw && t.M > 0 && t.N % 4 == 0 && t.K % 4 == 0, "gemm_tn_group: bad item (N, K multiples of 4)");
+    int splits, rows;
+    tn_plan(t.M, t.N, t.K, &splits, &rows);
+    const size_t need = (size_t)splits * ((size_t)t.N * t.K + t.N) * sizeof(float);
+    const bool reg_ok = group_on && reg_on && t.ws && t.ws_bytes >= need && splits > 1 && t.N % 48 == 0 && t.K % 48 == 0 &&
+                        (size_t)rows * (t.N > t.K ? t.N : t.K) * 4 < (1ull << 31);
+    if (!reg_ok) {
+      const int rc = gemm_tn_impl(t.dy, t.x, t.dw, t.db, t.M, t.N, t.K, t.ws, t.ws_bytes, nullptr, stream);
+      if (rc != DPMN_OK) return rc;
+      continue;
+    }
+    // two sums into one tensor must not share a launch's reduce queue position: the deferred queue keeps call order, nothing to do here
+    const int j = g.n;
+    g.it[j] = dpmn_gemm::TnItem{t.dy, t.x, t.ws, t.db, t.M, t.N, t.K, rows, cdiv(t.N, 96), cdiv(t.K, 96), splits};
+    g.first[j + 1] = g.first[j] + g.it[j].gx * g.it[j].gy * splits;
+    idx[j] = i;
+    splits_of[j] = splits;
+    flops += 2.0 * t.M * (double)t.N * t.K;
+    bytes += 4.0 * ((double)t.M * t.N + (double)t.M * t.K + (double)splits * ((double)t.N * t.K + t.N));
+    if (++g.n == 8) {
+      const int rc = flush();
+      if (rc != DPMN_OK) return rc;
+    }
+  }
+  return flush();
 }
 
 size_t dpmn_gemm_tn_partial_bytes(int M, int N, int K) {

@@ -137,10 +137,26 @@ int dpmn_pgrm_blocks_backward_leaf_f32(const dpmn_pgrm_weights* w, const dpmn_pg
   // a slice of the deferred-reduction arena (train/pgrm_train.py _ws): flush and start over when the request does not fit
   float* ws_ptr = nullptr;
   size_t ws_n = 0;
+  // Linear weight gradients collected while their operands stay live, launched as ONE grouped product (dpmn_gemm_tn_group_f32): a
+  // product alone puts one short block on each CU; their arena slices are taken at collection time, so the group goes out before the
+  // arena wraps
+  static const int tn_group = getenv("DPMN_BWD_TN_GROUP") ? atoi(getenv("DPMN_BWD_TN_GROUP")) : 1;
+  dpmn_tn_item tn_items[8];
+  int tn_n = 0;
+  auto tn_flush = [&]() -> int {
+    if (tn_n == 0) return DPMN_OK;
+    dpmn_stream_t ls = fork();
+    if (fork_failed) return dpmn_set_error(DPMN_ERR_LAUNCH, "pgrm_blocks_backward: leaf-stream fork failed");
+    const int e = dpmn_gemm_tn_group_f32(tn_items, tn_n, ls);
+    tn_n = 0;
+    return e;
+  };
   auto take = [&](size_t nbytes) -> int {
     nbytes = (nbytes + 255) / 256 * 256;
     if (nbytes > arena_bytes) return dpmn_set_error(DPMN_ERR_WORKSPACE, "pgrm_blocks_backward: reduction arena smaller than one request");
     if (*arena_used + nbytes > arena_bytes) {
+      const int f = tn_flush();    // collected products own slices of the arena that is about to be handed out again
+      if (f != DPMN_OK) return f;
       const int j = join();        // the queued partial rows were written on the leaf stream
       if (j != DPMN_OK) return j;
       const int e = dpmn_reduce_defer_flush(0, stream);
@@ -156,7 +172,8 @@ int dpmn_pgrm_blocks_backward_leaf_f32(const dpmn_pgrm_weights* w, const dpmn_pg
 #define LINEAR_BWD(dy, x, w_t, dw, db, N_, K_, dx)                                                                   \
   do {                                                                                                             \
     RUN(take(dpmn_gemm_tn_partial_bytes(M, (N_), (K_))));                                                            \
-    { LEAF(ls_); RUN(dpmn_gemm_tn_f32((dy), (x), (dw), (db), M, (N_), (K_), ws_ptr, ws_n, ls_)); }                   \
+    if (tn_group) tn_items[tn_n++] = dpmn_tn_item{(dy), (x), (dw), (db), M, (N_), (K_), ws_ptr, ws_n};                \
+    else { LEAF(ls_); RUN(dpmn_gemm_tn_f32((dy), (x), (dw), (db), M, (N_), (K_), ws_ptr, ws_n, ls_)); }              \
     RUN(dpmn_linear_f32((dy), (w_t), nullptr, nullptr, nullptr, (dx), M, (K_), (N_), DPMN_ACT_NONE, 0.f, stream));     \
   } while (0)
 #define LN_BWD(x, dy, gamma, dx, dgamma, dbeta)                                                                      \
@@ -205,7 +222,8 @@ int dpmn_pgrm_blocks_backward_leaf_f32(const dpmn_pgrm_weights* w, const dpmn_pg
                                          ws_n, stream));
     LINEAR_BWD(s.dypre, b.n2, t.fc1_t, sink(g.fc1_w), sink(g.fc1_b), Ch, C, s.dn2);
     float* dx1 = dx2;       // in place: every reader of dx2 is already queued on this stream ...
-    RUN(join());            // ... or on the leaf stream (the fc2 weight gradient reads dx2 when no mask was applied)
+    RUN(tn_flush());        // (group A = fc2 + fc1: the fc2 weight gradient reads dx2 when no mask was applied)
+    RUN(join());            // ... or on the leaf stream
     // x1 = tkv_in + DropPath(feats + V Wh^T + bh): the DropPath-masked gradient rides out of the LayerNorm2 backward
     const float* dat = dx1;
     if (dpb > 0.f && fuse_masks) {
@@ -230,7 +248,8 @@ int dpmn_pgrm_blocks_backward_leaf_f32(const dpmn_pgrm_weights* w, const dpmn_pg
     }
     RUN(dpmn_sk_feats_grad_f32(dat, b.feats, s.dS, s.dfeats, M, L, C, stream));
     RUN(take(dpmn_gemm_tn_partial_bytes(M, C, C)));
-    { LEAF(ls_); RUN(dpmn_gemm_tn_f32(s.dfeats, b.cat, sink(g.sk_proj_w), sink(g.sk_proj_b), M, C, C, ws_ptr, ws_n, ls_)); }
+    if (tn_group) tn_items[tn_n++] = dpmn_tn_item{s.dfeats, b.cat, sink(g.sk_proj_w), sink(g.sk_proj_b), M, C, C, ws_ptr, ws_n};
+    else { LEAF(ls_); RUN(dpmn_gemm_tn_f32(s.dfeats, b.cat, sink(g.sk_proj_w), sink(g.sk_proj_b), M, C, C, ws_ptr, ws_n, ls_)); }
     RUN(dpmn_linear_f32(s.dfeats, t.proj_t, nullptr, dcat, nullptr, s.dcat2, M, C, C, DPMN_ACT_NONE, 0.f, stream));
     // window attention: q / k / v recomputed, all window sizes on MFMA, bias-table gradients as per-block partial rows
     int win[4], shift[4];
@@ -252,6 +271,7 @@ int dpmn_pgrm_blocks_backward_leaf_f32(const dpmn_pgrm_weights* w, const dpmn_pg
     LN_BWD(sv->tq, s.dnrm, p.norm1_q_w, dtq, sink(g.norm1_q_w), sink(g.norm1_q_b));
     RUN(dpmn_layernorm_f32(tkv_in, p.norm1_kv_w, p.norm1_kv_b, 1e-5f, s.nrm2, M, C, stream));
     LINEAR_BWD(s.dkv, s.nrm2, t.kv_t, sink(g.kv_w), sink(g.kv_b), 2 * C, C, s.dnrm);
+    RUN(tn_flush());        // group B = SKConv head + proj, q, kv
     RUN(join());            // block boundary: the last LayerNorm backward accumulates into the token gradient the SKConv head's weight
                             // gradient may still read, and the next block overwrites the scratch buffers this block's leaves read
     // block 1's last step finishes dL/d(tokens behind block 0) = block 0's dx2: its Dropout / DropPath-masked copy (block 0's masks)

@@ -408,6 +408,18 @@ typedef struct {
   int NK, N, splits;
 } dpmn_tn_pending;
 size_t dpmn_gemm_tn_partial_bytes(int M, int N, int K);
+/* n weight gradients whose operands are live at the same time (the Linears of one Swin block, pgrm.py:315-331): the same bits as n
+ * dpmn_gemm_tn_f32 calls in array order; the products with N, K multiples of 48 and a workspace share ONE partial-sum launch. */
+typedef struct {
+  const float* dy;
+  const float* x;
+  float* dw;
+  float* db;
+  int M, N, K;
+  float* ws;
+  size_t ws_bytes;
+} dpmn_tn_item;
+int dpmn_gemm_tn_group_f32(const dpmn_tn_item* items /* HOST array */, int n, dpmn_stream_t stream);
 int dpmn_gemm_tn_partial_f32(const float* dy, const float* x, float* dw, float* db, int M, int N, int K, float* ws, size_t ws_bytes,
                              dpmn_tn_pending* pending, dpmn_stream_t stream);
 int dpmn_tn_reduce_multi_f32(const dpmn_tn_pending* pending /* HOST array */, int n, dpmn_stream_t stream);

@@ -140,6 +140,49 @@ def test_linear_weight_gradient_vs_torch(dev, M, N, K, with_db):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_grouped_linear_weight_gradients_equal_the_single_calls_bitwise(dev):
+    """dpmn_gemm_tn_group_f32 (the Linear weight gradients of one Swin block in ONE partial-sum launch, csrc/backward.hip
+    k_gemm_tn_reg_multi / gemm_tn_x3.hip in mode 2) == the same products as dpmn_gemm_tn_f32 calls, bit for bit: the shapes of a PGRM
+    block at B = 48 and B = 3 (fc2, fc1, SKConv proj, q, kv; the SKConv head K = 32 and a ragged row count keep their own launches),
+    with and without bias gradients, accumulating into non-zero gradients; two grouped runs equal."""
+    import ctypes as C
+    from dpmn_amd._abi import lib, check, dptr, stream, TnItem
+    shapes = [(49152, 96, 384, True), (49152, 384, 96, True), (49152, 96, 32, True), (49152, 96, 96, False), (49152, 96, 96, True),
+              (49152, 192, 96, True), (3072, 96, 384, True), (1001, 144, 48, True), (515, 16, 96, False)]
+    ops_ = []
+    for i, (M, N, K, with_db) in enumerate(shapes):
+        ops_.append((u("gdy%d" % i, (M, N)).to(dev), u("gx%d" % i, (M, K)).to(dev), u("gdw%d" % i, (N, K)).to(dev),
+                     u("gdb%d" % i, (N,)).to(dev) if with_db else None))
+
+    def single():
+        out = []
+        for dy, x, dw0, db0 in ops_:
+            M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
+            dw, db = dw0.clone(), None if db0 is None else db0.clone()
+            ws = torch.empty(lib.dpmn_gemm_tn_partial_bytes(M, N, K) // 4, device=dev)
+            check(lib.dpmn_gemm_tn_f32(dptr(dy), dptr(x), dptr(dw), dptr(db, True), M, N, K, dptr(ws), ws.numel() * 4, stream()))
+            out.append((dw, db))
+        torch.cuda.synchronize()
+        return out
+
+    def grouped():
+        items, keep, out = (TnItem * len(ops_))(), [], []
+        for i, (dy, x, dw0, db0) in enumerate(ops_):
+            M, N, K = dy.shape[0], dy.shape[1], x.shape[1]
+            dw, db = dw0.clone(), None if db0 is None else db0.clone()
+            ws = torch.empty(lib.dpmn_gemm_tn_partial_bytes(M, N, K) // 4, device=dev)
+            items[i] = TnItem(dptr(dy), dptr(x), dptr(dw), dptr(db, True), M, N, K, dptr(ws), ws.numel() * 4)
+            keep.append(ws)
+            out.append((dw, db))
+        check(lib.dpmn_gemm_tn_group_f32(items, len(ops_), stream()))
+        torch.cuda.synchronize()
+        return out
+    a, b, c = single(), grouped(), grouped()
+    for (M, N, K, _), (w1, b1), (w2, b2), (w3, b3) in zip(shapes, a, b, c):
+        assert torch.equal(w1, w2) and torch.equal(w2, w3), "dW %s" % ((M, N, K),)
+        assert (b1 is None) or (torch.equal(b1, b2) and torch.equal(b2, b3)), "db %s" % ((M, N, K),)
+
+
 @pytest.mark.parametrize("pixels,C,act,accumulate", [(1000, 64, "leaky02", False), (4099, 128, "relu", True), (515, 512, "none", False),
                                                      (196608, 64, "relu", False)])
 def test_batchnorm_backward_with_folded_reduction_vs_torch_autograd(dev, pixels, C, act, accumulate):

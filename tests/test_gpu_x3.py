@@ -210,3 +210,34 @@ def test_conv_wgrad_x3_is_fp32_class(x3_mode, cin, cout, k, stride, pad, dil, B,
     record(tag, "fp32-MFMA kernel rel L2 vs float64", e32)
     record(tag, "bf16x3 kernel rel L2 vs float64", e3, 2.0 * e32)
     assert e3 <= 2.0 * e32 + 1e-8 and dd < 2e-6, (e32, e3, dd)
+
+
+@pytest.mark.parametrize("M,N,K", [(49152, 96, 96), (49152, 384, 96), (24576, 96, 384), (8190, 192, 96), (1001, 144, 48)])
+def test_linear_weight_gradient_x3_is_fp32_class(x3_mode, M, N, K):
+    """dpmn_gemm_tn_f32 in mode 2 (gemm_tn_x3.hip: 32-row steps, the operands split in registers): dW = dY^T X and db vs the fp32-MFMA
+    kernel and float64 -- ragged row counts (the last 32-row step and the last block run past M), 144 = one and a half block tiles,
+    accumulation into a non-zero dW, two runs bitwise equal, operands spanning 30 binades."""
+    from dpmn_amd.train import pgrm_train
+    dy, x = u("tndy", (M, N), -2, 2), u("tnx", (M, K), -2, 2)
+    dy = dy * torch.exp2(torch.randint(-15, 15, (M, 1), generator=torch.Generator().manual_seed(5)).float())
+    dw0, db0 = u("tndw0", (N, K)), u("tndb0", (N,))
+    ref_w = dw0.double() + dy.double().t() @ x.double()
+    ref_b = db0.double() + dy.double().sum(0)
+
+    def run():
+        dw, db = dw0.clone().to(dev), db0.clone().to(dev)
+        pgrm_train.gemm_tn(dy.to(dev), x.to(dev), dw, db)
+        return dw, db
+    w32, b32 = run()
+    with x3_mode:
+        w3, b3 = run()
+        w3b, b3b = run()
+    assert torch.equal(w3, w3b) and torch.equal(b3, b3b)
+    e32, e3, d = rel(w32, ref_w), rel(w3, ref_w), rel(w3, w32)
+    tag = "x3_gemm_tn_M%d_N%d_K%d" % (M, N, K)
+    record(tag, "fp32-MFMA kernel dW rel L2 vs float64", e32)
+    record(tag, "bf16x3 kernel dW rel L2 vs float64", e3, 2.0 * e32)
+    record(tag, "bf16x3 vs fp32-MFMA kernel rel L2", d, 1e-6)
+    record(tag, "bf16x3 db rel L2 vs float64", rel(b3, ref_b), 2e-6)
+    assert e3 <= 2.0 * e32 + 1e-8, "bf16x3 dW is further from float64 (%.2e) than twice the fp32 kernel (%.2e)" % (e3, e32)
+    assert d <= 1e-6 and rel(b3, ref_b) <= 2e-6
