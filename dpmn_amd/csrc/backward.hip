@@ -738,8 +738,10 @@ extern "C" {
 static void tn_plan(int M, int N, int K, int* splits_out, int* rows_out) {
   const int tiles = cdiv(N, 96) * cdiv(K, 96);
   static const int want = getenv("DPMN_TN_BLOCKS") ? atoi(getenv("DPMN_TN_BLOCKS")) : 256;       // experiment knob
-  // (the MFMA-bound 4-tile shapes, fc1 / fc2: two blocks per CU -- 48.2 -> 45.0 us; the 1-tile shapes pay for more partial slots)
-  int splits = cdiv(tiles >= 4 && !getenv("DPMN_TN_BLOCKS") ? 2 * want : want, tiles);
+  // (one block per CU and product: since the products of a Swin block share launches (dpmn_gemm_tn_group_f32) the CUs hold blocks of
+  //  several products anyway, and fewer splits are fewer partial slabs to write and re-read -- 512 blocks for the 4-tile shapes fc1 / fc2
+  //  were 45.0 against 48.2 us per product launched alone, but 23.56 against 23.12 ms per training step grouped; 128: 23.22, 64: 24.14)
+  int splits = cdiv(want, tiles);
   int rows = cdiv(cdiv(M, splits), 32) * 32;      // (multiples of 32: the LDS kernel's chunk; of 4: an MFMA step of the register kernel)
   if (rows < 32) rows = 32;
   *splits_out = cdiv(M, rows);

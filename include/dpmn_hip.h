@@ -37,8 +37,12 @@ const char* dpmn_last_error(void);
  * (implicit-GEMM conv, pointwise GEMM) round their MFMA operands to bf16 on the way into LDS and run v_mfma_f32_16x16x32_bf16
  * with fp32 accumulation.  mode 2 ("f32 via bf16x3"): the kernels that have the variant split every fp32 operand EXACTLY into
  * three bf16 terms and keep the six product terms of weight >= 2^-16 -- fp32-class products (relative error <= 2^-23 each)
- * on the bf16 pipe, 6 MFMAs per 16x16x32 step; kernels without the variant stay on mode 0.  Tensors in HBM, LayerNorm / softmax /
- * BatchNorm statistics and every epilogue are fp32 in all modes.  Process-wide switch, not thread-safe. */
+ * on the bf16 pipe, 6 MFMAs per 16x16x32 step; kernels without the variant stay on mode 0.  Since round 6 the variant exists for the
+ * implicit-GEMM conv (128 x 128 tiles), the 3 x 3 halo conv (layers with >= 8 row tiles per image: a per-image rule, so the kernel choice
+ * does not depend on the batch size), the conv weight gradient, the pointwise GEMM, the k-loop GEMMs and the Linear weight gradient
+ * (dpmn_conv2d_*, dpmn_conv_wgrad_*, dpmn_pointwise_f32, dpmn_linear_f32 with K > 192, dpmn_gemm_tn_*); no kernel of mode 2 owns memory.
+ * Tensors in HBM, LayerNorm / softmax / BatchNorm statistics and every epilogue are fp32 in all modes.  Process-wide switch, not
+ * thread-safe.  The whole parity suite runs in mode 0 and in mode 2 with the same tolerances (tests/conftest.py). */
 int dpmn_set_compute_dtype(int mode);
 int dpmn_get_compute_dtype(void);
 
