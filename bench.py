@@ -401,7 +401,18 @@ def build_train_step(args, workload, world, force_dist, dist, torch, drop):
 
         def step():   # noqa: F811  (same batch every step, like the eager path of this bench)
             return run(inp["images_lr"], inp["images_hr"], inp.get("label_vecs"), inp["text_priors"])
+    freeze_heap()
     return step, trainer, inp["images_lr"].shape[0]
+
+
+def freeze_heap():
+    """The models / buckets just built stay for the whole leg: moved out of the garbage collector's generations (as
+    TextSR.build_training does), so a full collection inside the timed steps has nothing long-lived to walk.  Measured without it:
+    one 65-85 ms host stall at a fixed step of the third in-process training leg -- the step took 44 ms instead of 23 whenever the
+    launch queue ran dry."""
+    import gc
+    gc.collect()
+    gc.freeze()
 
 
 def train_object(args, workload, world, rank, force_dist, dist, torch, _abi):
@@ -413,12 +424,31 @@ def train_object(args, workload, world, rank, force_dist, dist, torch, _abi):
     for drop in (0.1, 0.0):
         torch.cuda.synchronize()
         torch.cuda.empty_cache()            # the forward leg's cached blocks (three streams' pools) otherwise fragment this leg's arena
-        step, trainer, B = build_train_step(args, workload, world, force_dist, dist, torch, drop)
+        step0, trainer, B = build_train_step(args, workload, world, force_dist, dist, torch, drop)
         steps, warmup = args.train_steps, max(8, args.warmup)      # three streams: the caching allocator needs a few steps to settle
+        marks = []
+
+        import gc
+        n_alloc = lambda: torch.cuda.memory_stats().get("num_device_alloc", 0)
+        n_gc = lambda: sum(g["collections"] for g in gc.get_stats())
+        host = []
+
+        def step():            # one event per step on the step's own stream (no synchronisation): the per-step times of the region
+            t_ = time.perf_counter()
+            r = step0()
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+            host.append((time.perf_counter() - t_, n_alloc(), n_gc()))
+            return r
         elapsed, live, kernels = timed_leg(step, steps, warmup, profiling, torch, dist, _abi, post=3, arm_timed=False)
         ms = elapsed / steps * 1e3
+        per_step = [round(marks[i - 1].elapsed_time(marks[i]), 2) for i in range(warmup, warmup + steps)]
         rec = {"ms_per_step": round(ms, 3), "images_per_s": round(world * B * steps / elapsed, 2), "steps": steps, "warmup": warmup,
-               "timed_seconds": round(elapsed, 4), "dropout": drop,
+               "timed_seconds": round(elapsed, 4), "dropout": drop, "per_step_ms": per_step,
+               "host_issue_ms": [round(host[i][0] * 1e3, 2) for i in range(warmup, warmup + steps)],
+               "device_allocs_in_timed_region": host[warmup + steps - 1][1] - host[warmup - 1][1],
+               "gc_collections_in_timed_region": host[warmup + steps - 1][2] - host[warmup - 1][2],
                "whole_step_frac_of_fp32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * 1e9 * B / (ms * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
                "roofline": roofline_of(live, steps, B, "train")}
         if drop > 0.0:
@@ -431,7 +461,7 @@ def train_object(args, workload, world, rank, force_dist, dist, torch, _abi):
             out["kernels"] = kernels[:8]
         else:
             out["without_dropout"] = rec
-        del step, trainer
+        del step, step0, trainer, marks
         torch.cuda.empty_cache()
     return out
 
@@ -449,7 +479,8 @@ def x3_rows(kernels):
 
 
 X3_WHAT = ("mode 2, 'f32 via bf16x3' (dpmn_set_compute_dtype(2)): fp32 tensors everywhere; in the kernel families that have the variant "
-           "(implicit-GEMM conv 128 x 128, 3 x 3 halo conv on 8-row tiles, conv weight gradient 128 x 128, pointwise GEMM, k-loop GEMMs) every "
+           "(implicit-GEMM conv 128 x 128, 3 x 3 halo conv on 8-row tiles, conv weight gradient, pointwise GEMM, k-loop GEMMs, Linear weight gradient, "
+           "the whole-K token GEMMs with their rows in registers incl. the fused SKConv-select + LayerNorm + fc1 kernel) every "
            "operand is split exactly into three bf16 terms on the way into LDS and a product is six v_mfma_f32_16x16x32_bf16 with fp32 "
            "accumulation (dropped terms < 2^-21 |x y|: the rounding class of an fp32 multiply); every other kernel is the fp32 one.  The whole "
            "-m gpu parity suite runs in this mode too, same tolerances (tests/conftest.py).  `value` of the line stays the plain-fp32 number.")
@@ -492,6 +523,7 @@ def main():
     else:
         sr, models, psn, inp = workload.build(args.workload, batch=args.batch)
         B = inp["images_lr"].shape[0]
+        freeze_heap()
     if args.mode == "train":
         pass
     else:

@@ -226,7 +226,7 @@ __device__ __forceinline__ void x3_split4t(const float4& v, uint2& h, uint2& m, 
 }
 // debugging / A-B switch: DPMN_X3_OFF bit mask of kernel families that keep the fp32 kernel in mode 2
 // (1 implicit-GEMM conv, 2 halo conv, 4 pointwise GEMM, 8 k-loop GEMM 64 x 96, 16 conv weight gradient, 32 k-loop GEMM 128 x 128,
-// 64 Linear weight gradient dY^T X)
+// 64 Linear weight gradient dY^T X, 128 whole-K token GEMMs with the rows in registers: k_gemm_rowreg, k_sk_mlp_in)
 int dpmn_x3_off_mask();
 static inline bool x3_on(int family_bit) { return g_dpmn_x3 && !(dpmn_x3_off_mask() & family_bit); }
 struct ProfScope {

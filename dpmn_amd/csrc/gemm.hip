@@ -1181,15 +1181,26 @@ int launch_rowreg(const float* x, int ldx, const float* w, float* y, int ldy, in
   const int tiles = M / (EPI == 4 ? 32 : 16), ny = N / 96;      // work items of a wave (pairs of 16-row tiles under RR_EPI 4)
   // resident waves: LDS-limited blocks per CU x 4; every wave gets the same number of tiles when that divides evenly
   static const int rr_blocks = getenv("DPMN_RR_BLOCKS") ? atoi(getenv("DPMN_RR_BLOCKS")) : 0;
-  const int per_cu = smem <= 40 * 1024 ? 3 : (smem <= 80 * 1024 ? 2 : 1);
+  const bool x3 = (PRO == PRO_NONE || PRO == PRO_LN) && (K == 96 || K == 192) && x3_on(128);
+  // (mode 2: the weight planes are 1.5x the fp32 copy -- two blocks per CU at K = 96, one at K = 192 -- and a tile's MFMAs take 0.4x the
+  //  time, so two tiles per wave are enough to overlap: 96 -> 384 at M = 49152 30.3 vs 33.2 us)
+  const int per_cu = x3 ? (K <= 96 ? 2 : 1) : (smem <= 40 * 1024 ? 3 : (smem <= 80 * 1024 ? 2 : 1));
   int gx = (rr_blocks > 0 ? rr_blocks : 256 * per_cu) / ny;
   if (gx < 1) gx = 1;
   // at least 3 tiles per wave, so that the load / MFMA / store pipeline of a wave has something to overlap
-  static const int rr_tpw = getenv("DPMN_RR_TPW") ? atoi(getenv("DPMN_RR_TPW")) : 3;
+  static const int rr_tpw_env = getenv("DPMN_RR_TPW") ? atoi(getenv("DPMN_RR_TPW")) : 0;
+  const int rr_tpw = rr_tpw_env > 0 ? rr_tpw_env : (x3 ? 2 : 3);
   while (gx > 256 / ny && gx > 1 && (long)gx * 4 * rr_tpw > tiles) gx -= 256 / ny > 0 ? 256 / ny : 1;
   if (gx * 4 > tiles) gx = cdiv(tiles, 4);
   ProfScope prof(PRO == PRO_LN ? PT_GEMM_WSTAT_LN : PT_GEMM_WSTAT, st, 2.0 * M * (double)N * K,
                  4.0 * ((double)M * K * (PRO == PRO_SKSEL ? 3 : 1) + (double)M * N * (1 + (EPI == 3 ? 2 : (EPI == 5 ? 1 : 0))) + (double)N * K));
+  if constexpr ((PRO == PRO_NONE || PRO == PRO_LN) && (K == 96 || K == 192)) {
+    if (x3) {                  // mode 2: weights split once per block into bf16 planes, rows split in registers (gemm_rowreg_x3.hip)
+      (void)dpmn_gemm::x3_launch_rowreg(K, PRO, EPI, x, ldx, w, y, ldy, M, N, p, e, gx, st);
+      DPMN_CHECK_LAUNCH();
+      return DPMN_OK;
+    }
+  }
   hipLaunchKernelGGL((k_gemm_rowreg<K, PRO, EPI>), dim3(gx, ny), dim3(256), smem, st, x, ldx, w, y, ldy, M, N, p, e);
   DPMN_CHECK_LAUNCH();
   return DPMN_OK;
@@ -1435,7 +1446,10 @@ int dpmn_sk_mlp_in_drop_f32(const float* cat, const float* attn_vec, const float
                  4.0 * ((double)M * Cc * 4 + (double)M * N + (double)N * Cc + (double)Cc * CG));
 #define SKMLP_LAUNCH(SAVE_, OCC_) hipLaunchKernelGGL((k_sk_mlp_in<Cc, CG, SAVE_, OCC_>), dim3(gx, ny), dim3(256), smem, st, cat, attn_vec, rows_per_image, \
                                                     w_head, b_head, feats, shortcut, x1, ln_w, ln_b, eps, w_fc1, b_fc1, y, M, N, v_out, n2_out, p_row, seed_row)
-  if (v_out) { if (occ >= 3) SKMLP_LAUNCH(true, 3); else SKMLP_LAUNCH(true, 2); }
+  if (x3_on(128))
+    (void)dpmn_gemm::x3_launch_sk_mlp_in(cat, attn_vec, rows_per_image, w_head, b_head, feats, shortcut, x1, ln_w, ln_b, eps, w_fc1, b_fc1, y, M, N,
+                                         v_out, n2_out, p_row, seed_row, gx, st);
+  else if (v_out) { if (occ >= 3) SKMLP_LAUNCH(true, 3); else SKMLP_LAUNCH(true, 2); }
   else { if (occ >= 3) SKMLP_LAUNCH(false, 3); else SKMLP_LAUNCH(false, 2); }
 #undef SKMLP_LAUNCH
   DPMN_CHECK_LAUNCH();

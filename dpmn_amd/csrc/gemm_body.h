@@ -39,6 +39,13 @@ int x3_launch_kloop(const float* x, int ldx, const float* w, int ldw, float* y, 
 int x3_launch_kloop128(const float* x, const float* w, float* y, int M, int N, int L, int nchunks, int splits, long bstride, long zstride,
                        hipStream_t st);
 int x3_launch_pw(const float* g, const float* w, const float* bias, float* z, int B, int Ch, int L, hipStream_t st);
+// gemm_rowreg_x3.hip: k_gemm_rowreg<K, pro, epi> (K = 96 / 192, PRO_NONE / PRO_LN, RR_EPI 1 .. 5) and k_sk_mlp_in in mode 2, on the fp32
+// launcher's grid (gx blocks of four waves per 96-column group); -1: no such instantiation
+int x3_launch_rowreg(int K, int pro, int epi, const float* x, int ldx, const float* w, float* y, int ldy, int M, int N, const ProArgs& p,
+                     const EpiArgs& e, int gx, hipStream_t st);
+int x3_launch_sk_mlp_in(const float* cat, const float* sel, int rows_per_image, const float* w_head, const float* b_head, const float* feats,
+                        const float* shortcut, float* x1, const float* ln_w, const float* ln_b, float eps, const float* w_fc1, const float* b_fc1,
+                        float* y, int M, int N, float* v_out, float* n2_out, float p_row, unsigned long long seed_row, int gx, hipStream_t st);
 }  // namespace dpmn_gemm
 
 namespace {

@@ -241,3 +241,88 @@ def test_linear_weight_gradient_x3_is_fp32_class(x3_mode, M, N, K):
     record(tag, "bf16x3 db rel L2 vs float64", rel(b3, ref_b), 2e-6)
     assert e3 <= 2.0 * e32 + 1e-8, "bf16x3 dW is further from float64 (%.2e) than twice the fp32 kernel (%.2e)" % (e3, e32)
     assert d <= 1e-6 and rel(b3, ref_b) <= 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(49152, 96, 96, "bias"), (49152, 384, 96, "gelu"), (49152, 96, 192, "res2"), (6144, 192, 192, "res1"),
+                                       (49152, 96, 96, "none"), (1024, 96, 96, "bias")])
+def test_rows_in_registers_linear_x3_is_fp32_class(x3_mode, M, N, K, epi):
+    """dpmn_linear_f32 on the shapes of k_gemm_rowreg (K = 96 / 192, N multiple of 96) in mode 2 (gemm_rowreg_x3.hip: weight planes split
+    once per block, rows split in registers): vs the fp32-MFMA kernel and float64, every epilogue; rows spanning 30 binades."""
+    from dpmn_amd import ops
+    x = u("rrx", (M, K), -2, 2) * torch.exp2(torch.randint(-15, 15, (M, 1), generator=torch.Generator().manual_seed(3)).float())
+    w, b = u("rrw", (N, K), -0.3, 0.3), u("rrb", (N,))
+    r1, r2 = u("rr1", (M, N)), u("rr2", (M, N))
+    kw = dict(bias=None if epi == "none" else b.to(dev), act="gelu" if epi == "gelu" else "none",
+              res1=r1.to(dev) if epi in ("res1", "res2") else None, res2=r2.to(dev) if epi == "res2" else None)
+    xd, wd = x.to(dev), w.to(dev)
+    ref32 = ops.linear(xd, wd, **kw)
+    with x3_mode:
+        got = ops.linear(xd, wd, **kw)
+        got2 = ops.linear(xd, wd, **kw)
+    assert torch.equal(got, got2)
+    ref64 = x.double() @ w.double().t() + (0 if epi == "none" else b.double())
+    if epi == "gelu":
+        ref64 = torch.nn.functional.gelu(ref64)
+    if epi in ("res1", "res2"):
+        ref64 = ref64 + r1.double()
+    if epi == "res2":
+        ref64 = ref64 + r2.double()
+    e32, e3, d = rel(ref32, ref64), rel(got, ref64), rel(got, ref32)
+    tag = "x3_rowreg_M%d_N%d_K%d_%s" % (M, N, K, epi)
+    record(tag, "fp32-MFMA kernel rel L2 vs float64", e32)
+    record(tag, "bf16x3 kernel rel L2 vs float64", e3, 2.0 * e32)
+    record(tag, "bf16x3 vs fp32-MFMA kernel rel L2", d, 1e-6)
+    assert e3 <= 2.0 * e32 + 1e-8 and d <= 1e-6, (e32, e3, d)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(49152, 384, 96, "none"), (49152, 96, 96, "gelu"), (6144, 192, 192, "none")])
+def test_layernorm_linear_x3_is_fp32_class(x3_mode, M, N, K, act):
+    """dpmn_ln_linear_f32 (k_gemm_rowreg<K, PRO_LN>: gamma folded into the weights BEFORE the split, the normalisation behind the MFMAs)
+    in mode 2 vs the fp32 kernel and float64; token rows with a large common offset (the text-prior branch's shape of input)."""
+    from dpmn_amd import ops
+    x = u("lnx", (M, K), -1, 1) + 3.0 * u("lno", (M, 1), -1, 1)
+    g, bt = u("lng", (K,), 0.5, 1.5), u("lnb", (K,), -0.5, 0.5)
+    w, b = u("lnw", (N, K), -0.3, 0.3), u("lnwb", (N,))
+    args = [t.to(dev) for t in (x, g, bt, w, b)]
+    ref32 = ops.ln_linear(*args, act=act)
+    with x3_mode:
+        got = ops.ln_linear(*args, act=act)
+    ref64 = torch.nn.functional.layer_norm(x.double(), (K,), g.double(), bt.double(), 1e-5) @ w.double().t() + b.double()
+    if act == "gelu":
+        ref64 = torch.nn.functional.gelu(ref64)
+    e32, e3, d = rel(ref32, ref64), rel(got, ref64), rel(got, ref32)
+    tag = "x3_ln_linear_M%d_N%d_K%d" % (M, N, K)
+    record(tag, "fp32-MFMA kernel rel L2 vs float64", e32)
+    record(tag, "bf16x3 kernel rel L2 vs float64", e3, 2.0 * e32)
+    record(tag, "bf16x3 vs fp32-MFMA kernel rel L2", d, 2e-6)
+    assert e3 <= 2.0 * e32 + 1e-8 and d <= 2e-6, (e32, e3, d)
+
+
+@pytest.mark.parametrize("save", [False, True])
+def test_sk_select_layernorm_fc1_x3_is_fp32_class(x3_mode, save):
+    """dpmn_sk_mlp_in_f32 in mode 2 (k_sk_mlp_in_x3): x1 (fp32 MFMAs in both modes) is bitwise the fp32 kernel's; y = fc1(LayerNorm2(x1)) vs
+    the fp32 kernel and a float64 restatement of pgrm.py:91-96, 327-331, 31 on the same inputs; eval (folded LayerNorm) and training outputs."""
+    from dpmn_amd import ops
+    B, L, C, G, N = 48, 1024, 96, 3, 384
+    M = B * L
+    cat, avec = u("skc", (M, C), -2, 2), u("ska", (B, G, C // G), 0, 1)
+    hw, hb = u("skhw", (C, C // G), -0.3, 0.3), u("skhb", (C,))
+    feats, short = u("skf", (M, C)), u("sks", (M, C), -1, 1) + 2.0
+    g, bt = u("skg", (C,), 0.5, 1.5), u("skbt", (C,), -0.5, 0.5)
+    fw, fb = u("skfw", (N, C), -0.3, 0.3), u("skfb", (N,))
+    args = [t.to(dev) for t in (cat, avec, hw, hb, feats, short, g, bt, fw, fb)]
+    out32 = ops.sk_mlp_in(*args, L, save=save)
+    with x3_mode:
+        out3 = ops.sk_mlp_in(*args, L, save=save)
+    assert torch.equal(out32[0], out3[0]), "x1 differs between the modes"
+    if save:
+        assert torch.equal(out32[2], out3[2]) and torch.equal(out32[3], out3[3])
+    sel = (cat.double().reshape(B, L, G, C // G) * avec.double()[:, None]).sum(2).reshape(M, C // G)
+    x1 = sel @ hw.double().t() + hb.double() + feats.double() + short.double()
+    y64 = torch.nn.functional.layer_norm(x1, (C,), g.double(), bt.double(), 1e-5) @ fw.double().t() + fb.double()
+    e32, e3, d = rel(out32[1], y64), rel(out3[1], y64), rel(out3[1], out32[1])
+    tag = "x3_sk_mlp_in_%s" % ("train" if save else "eval")
+    record(tag, "fp32-MFMA kernel y rel L2 vs float64", e32)
+    record(tag, "bf16x3 kernel y rel L2 vs float64", e3, 2.0 * e32)
+    record(tag, "bf16x3 vs fp32-MFMA kernel rel L2", d, 2e-6)
+    assert e3 <= 2.0 * e32 + 1e-8 and d <= 2e-6, (e32, e3, d)

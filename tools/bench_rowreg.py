@@ -43,7 +43,7 @@ for name, fn in cases.items():
 if os.environ.get("DPMN_ROWREG") is None:
     torch.save(outs, "/tmp/rowreg_outs.pt")
     subprocess.call([sys.executable, os.path.abspath(__file__)], env=dict(os.environ, DPMN_ROWREG="0"))
-else:
+elif os.path.exists("/tmp/rowreg_outs.pt"):
     ref = torch.load("/tmp/rowreg_outs.pt")
     for k in outs:
         print("max|rowreg - wstat| %-34s %.3e  (|ref| max %.2f)" % (k, float((ref[k] - outs[k]).abs().max()), float(outs[k].abs().max())))
