@@ -90,6 +90,22 @@ class RefinePipeline:
             lane.synchronize()
 
 
+class _CombineLosses(torch.autograd.Function):
+    """100 * sum(terms) / n over 0-d loss terms as ONE autograd node: cat + sum + mul + div forward, div + mul backward (every term gets
+    the same gradient 100 g / n, computed once).  The reference's chain `loss += term.mean() * 100` ... `loss / n`
+    (super_resolution.py:205-262) is three tiny launches per term forward and two to three backward: ~55 of the step's ~115 torch ops."""
+
+    @staticmethod
+    def forward(ctx, n, *terms):
+        ctx.n, ctx.k = n, len(terms)
+        return torch.cat([t.reshape(1) for t in terms]).sum() * 100 / n
+
+    @staticmethod
+    def backward(ctx, g):
+        gt = (g / ctx.n) * 100
+        return (None,) + (gt,) * ctx.k
+
+
 class TextSR(base.TextBase):
     def build_models(self, testing=False):
         """Model list in the reference's order (super_resolution.py:38-76): b1 PGRMs (mode=False), b2 PGRMs
@@ -345,7 +361,7 @@ class TextSR(base.TextBase):
             images_lr_psn.record_stream(cur)
         else:
             images_lr_psn = self.psn_forward(psn, images_lr, label_vecs)
-        br1, br2, part = [], [], [0, 0]
+        br1, br2, part = [], [], [[], []]      # part / dl: the 0-d loss terms of a branch, summed once by _CombineLosses
 
         def run_branch1():
             cascade = images_lr_psn
@@ -354,7 +370,7 @@ class TextSR(base.TextBase):
                 sr = models[0 if share else k](x_q, cascade[:, :3, :], br1[:k])
                 br1.append(sr)
                 cascade = sr
-                part[0] = part[0] + crit(sr, hr3).mean() * 100
+                part[0].append(crit(sr, hr3))
 
         def run_branch2():
             cascade = images_lr_psn
@@ -364,16 +380,16 @@ class TextSR(base.TextBase):
                 sr = models[0 if share else k](x_q, cascade[:, :3, :], br2[:(k - b2)])
                 br2.append(sr)
                 cascade = sr
-                part[1] = part[1] + crit(sr, hr3).mean() * 100
+                part[1].append(crit(sr, hr3))
 
-        dl = [0, 0]
+        dl = [[], []]
 
         def run_distill(branch):
             imgs, off = (br1, 0) if branch == 0 else (br2, b1 - 1)
             feat = imgs[-1]
             for k in range(len(imgs) - 1, 0, -1):
                 ld, feat = distill[k - 1 + off](feat, imgs[k - 1])
-                dl[branch] = dl[branch] + ld.sum() * 100
+                dl[branch].append(ld)
 
         # two HIP streams for the two branches (see refine()); autograd runs each node's backward on its forward's stream and joins
         # the streams at the end of backward().  The step's weight packs are refreshed on the main stream before the fork.
@@ -415,15 +431,22 @@ class TextSR(base.TextBase):
             run_distill(0)
             run_distill(1)
         sr = models[-1](br1[-1], br2[-1])
-        lc = crit(sr, hr3).mean() * 100
+        lc = crit(sr, hr3)
         if forked and DISTILL_ON_BRANCH:
             cur.wait_stream(s1)
             cur.wait_stream(s2)
-            for t_ in dl:
-                if torch.is_tensor(t_):
-                    t_.record_stream(cur)
-        loss = (part[0] + part[1]) + (dl[0] + dl[1]) + lc
-        loss = loss / (b1 + b2 + 1)
+        terms = part[0] + part[1] + dl[0] + dl[1] + [lc]
+        if forked:
+            for t_ in terms[:-1]:
+                t_.record_stream(cur)
+        # loss = (sum_k 100 ImageLoss_k + sum_j 100 distill_j + 100 ImageLoss_cmm) / (b1 + b2 + 1)   (super_resolution.py:205-262)
+        if os.environ.get("DPMN_COMBINE_LOSSES", "1") != "0":
+            loss = _CombineLosses.apply(b1 + b2 + 1, *terms)
+        else:
+            loss = 0
+            for t_ in terms:
+                loss = loss + t_.mean() * 100
+            loss = loss / (b1 + b2 + 1)
         if hasattr(trainer, "arm_early_step"):
             trainer.arm_early_step()      # trainer.step() follows: a model's clip + Adam may run as soon as its backward has finished
         try:

@@ -122,6 +122,9 @@ def do_collect(tag):
                     o.write('"%s",%d,%.2f,%.2f,%.2f,%.2f\n' % (fam, n, us, util, tf, tf16))
                 o.write('"ALL dpmn kernels (time-weighted)",,,%.2f,,\n' % (100.0 * tb / ta if ta else 0.0))
             print(open(os.path.join(dst, pre + "_pmc_mfma_util.csv")).read())
+    rl = os.path.join(src, "rccl_world1.log")
+    if os.path.exists(rl):
+        shutil.copy(rl, os.path.join(dst, tag + "_rccl_world1.log"))
     pe = os.path.join(ROOT, "gpurun_out", "parity_errors.json")
     if os.path.exists(pe):
         shutil.copy(pe, os.path.join(dst, tag + "_parity_errors.json"))

@@ -41,6 +41,13 @@ if [ "${1:-}" != "quick" ]; then
   timeout 600 python bench.py --workload cfg3 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg3.json
   timeout 900 python bench.py --workload cfg4 --steps 5 --warmup 6 --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_cfg4.json
 fi
+if [ "${1:-}" != "quick" ]; then
+  # the RCCL code path priced at world size 1 (ZeRO-1 reduce-scatter / all-gather, segmented CMM exchange), fp32 and mode 2
+  for dt in f32 x3; do
+    DPMN_FORCE_DIST=1 NCCL_DEBUG=VERSION timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 \
+      bench.py --mode train --dtype $dt --no-cpu-baseline >> $OUT/rccl_world1.log 2>&1
+  done
+fi
 # keep the merge-back small: the per-dispatch traces are reduced on the box, only summaries travel
 python tools/collect_profiles.py --reduce $OUT > $OUT/reduce.log 2>&1
 find $OUT -name "*.db" -delete 2>/dev/null
