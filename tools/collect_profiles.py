@@ -84,7 +84,7 @@ def do_collect(tag):
     f = os.path.join(src, "pmc_pgrm_mfma_util.csv")
     if os.path.exists(f):
         shutil.copy(f, os.path.join(dst, "%s_pmc_pgrm_mfma_util.csv" % tag))
-    for name in ("bench_default", "bench_train", "bench_x3", "bench_train_x3", "bench_train_drop", "bench_train_nodrop", "bench_cfg3", "bench_cfg4", "bench_cfg4_train"):
+    for name in ("bench_default", "bench_train", "bench_x3", "bench_train_x3", "bench_cfg4_x3", "bench_cfg4_train_x3", "bench_cfg3_x3", "bench_train_drop", "bench_train_nodrop", "bench_cfg3", "bench_cfg4", "bench_cfg4_train"):
         p = os.path.join(src, name + ".json")
         if os.path.exists(p) and open(p).read().strip().startswith("{"):
             shutil.copy(p, os.path.join(dst, "%s_%s.json" % (tag, name)))
@@ -122,6 +122,9 @@ def do_collect(tag):
                     o.write('"%s",%d,%.2f,%.2f,%.2f,%.2f\n' % (fam, n, us, util, tf, tf16))
                 o.write('"ALL dpmn kernels (time-weighted)",,,%.2f,,\n' % (100.0 * tb / ta if ta else 0.0))
             print(open(os.path.join(dst, pre + "_pmc_mfma_util.csv")).read())
+    for name in ("pmc_sq_f32.txt", "pmc_sq_x3.txt", "torch_ops_per_step.txt"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
     rl = os.path.join(src, "rccl_world1.log")
     if os.path.exists(rl):
         shutil.copy(rl, os.path.join(dst, tag + "_rccl_world1.log"))

@@ -48,6 +48,17 @@ if [ "${1:-}" != "quick" ]; then
       bench.py --mode train --dtype $dt --no-cpu-baseline >> $OUT/rccl_world1.log 2>&1
   done
 fi
+if [ "${1:-}" != "quick" ]; then
+  # where the cycles of the MFMA families go: SQ issue / stall / LDS counters of the forward, fp32 and mode 2
+  bash tools/pmc_sq.sh f32 > /dev/null 2>&1
+  bash tools/pmc_sq.sh x3 DPMN_COMPUTE_DTYPE=x3 BENCH_ARGS="--dtype x3" > /dev/null 2>&1
+  cp gpurun_out/pmc_sq_f32.txt gpurun_out/pmc_sq_x3.txt $OUT/ 2>/dev/null
+  # torch's own device ops per training step
+  timeout 600 python tools/prof_torch_ops.py 2>&1 | grep -v "amdgpu.ids\|Warning\|_warn_once" > $OUT/torch_ops_per_step.txt
+  timeout 900 python bench.py --workload cfg4 --steps 5 --warmup 6 --no-cpu-baseline --dtype x3 2>/dev/null | tail -1 > $OUT/bench_cfg4_x3.json
+  timeout 900 python bench.py --workload cfg4 --mode train --steps 5 --warmup 3 --no-cpu-baseline --dtype x3 2>/dev/null | tail -1 > $OUT/bench_cfg4_train_x3.json
+  timeout 600 python bench.py --workload cfg3 --no-cpu-baseline --dtype x3 2>/dev/null | tail -1 > $OUT/bench_cfg3_x3.json
+fi
 # keep the merge-back small: the per-dispatch traces are reduced on the box, only summaries travel
 python tools/collect_profiles.py --reduce $OUT > $OUT/reduce.log 2>&1
 find $OUT -name "*.db" -delete 2>/dev/null
