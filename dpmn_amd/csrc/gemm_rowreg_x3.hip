@@ -45,24 +45,27 @@ __device__ __forceinline__ void mma_chunk(const unsigned short* Wb, int lr, int 
                                           f32x4 (&acc)[NT]) {
   constexpr int LDB = K + 8, PL = 96 * LDB;
   const unsigned short* wa = Wb + lr * LDB + 32 * C2 + 8 * kq;
+  // product term OUTER, output tile inner: consecutive MFMAs write different accumulators (six back-to-back MFMAs into one accumulator
+  // wait for each other's result: the first form of this loop spent half its matrix time in that chain)
   bf16x8 wh[NT], wm[NT], wl[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    wh[nt] = *reinterpret_cast<const bf16x8*>(wa + 16 * nt * LDB);
-    wm[nt] = *reinterpret_cast<const bf16x8*>(wa + 16 * nt * LDB + PL);
-    wl[nt] = *reinterpret_cast<const bf16x8*>(wa + 16 * nt * LDB + 2 * PL);
-  }
+  for (int nt = 0; nt < NT; ++nt) wl[nt] = *reinterpret_cast<const bf16x8*>(wa + 16 * nt * LDB + 2 * PL);
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    f32x4 c = acc[nt];
-    c = mfma16_bf16(wl[nt], bh, c);
-    c = mfma16_bf16(wh[nt], bl, c);
-    c = mfma16_bf16(wm[nt], bm, c);
-    c = mfma16_bf16(wm[nt], bh, c);
-    c = mfma16_bf16(wh[nt], bm, c);
-    c = mfma16_bf16(wh[nt], bh, c);
-    acc[nt] = c;
-  }
+  for (int nt = 0; nt < NT; ++nt) wh[nt] = *reinterpret_cast<const bf16x8*>(wa + 16 * nt * LDB);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) wm[nt] = *reinterpret_cast<const bf16x8*>(wa + 16 * nt * LDB + PL);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16_bf16(wl[nt], bh, acc[nt]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16_bf16(wh[nt], bl, acc[nt]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16_bf16(wm[nt], bm, acc[nt]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16_bf16(wm[nt], bh, acc[nt]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16_bf16(wh[nt], bm, acc[nt]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = mfma16_bf16(wh[nt], bh, acc[nt]);
 }
 
 // ---------------------------------------------------------------------------------- k_gemm_rowreg in mode 2
