@@ -310,6 +310,7 @@ def test_fused_ln_qkv_window_attention_dim192_vs_oracle_and_unfused(dev, B, shif
     qd = ops.ln_linear(tq.to(dev).reshape(-1, C), ln[0].to(dev), ln[1].to(dev), wq.to(dev), bq.to(dev)).reshape(B, H * W, C)
     kvd = ops.ln_linear(tkv.to(dev).reshape(-1, C), ln[2].to(dev), ln[3].to(dev), wkv.to(dev), bkv.to(dev)).reshape(B, H * W, 2 * C)
     unf = ops.window_attn(qd, kvd, tables, WINS, shifts, 2, H, W)
+    record(tag, "the unfused kernels' max|err| vs oracle", max_abs_err(unf, ref))
     record(tag, "max|err| vs the unfused kernels", max_abs_err(got, unf), 1e-4)
     assert_close(got, unf, 1e-4, 1e-4, tag + " vs unfused")
     assert torch.equal(got, ops.ln_qkv_window_attn_d32(*args)), "two launches must agree bit for bit"
