@@ -314,3 +314,53 @@ def test_fused_ln_qkv_window_attention_dim192_vs_oracle_and_unfused(dev, B, shif
     record(tag, "max|err| vs the unfused kernels", max_abs_err(got, unf), 1e-4)
     assert_close(got, unf, 1e-4, 1e-4, tag + " vs unfused")
     assert torch.equal(got, ops.ln_qkv_window_attn_d32(*args)), "two launches must agree bit for bit"
+
+
+def test_cfg4_cmm_and_distill_backward_bench_batch_rows_equal_small_batch(dev):
+    """The B = 96 launch geometry of the CMM's and a DistillModule's training forward + backward on 64 x 256 images (split-K factors,
+    weight-gradient slot counts, BatchNorm partial rows -- only bench.py ran them so far) against the B = 2 calls the step test above pins.
+    BatchNorm couples the samples, so the big batch is 48 REPETITIONS of the small one: the batch statistics are those of the small batch
+    (up to the rounding of longer sums), every output row equals its B = 2 row, and with the cotangent repeated and divided by 48 the
+    parameter gradients equal the B = 2 gradients and the input-gradient rows are the B = 2 rows / 48.
+    Bars: the forward rows at fp32 round-off (2e-5).  The gradients at 2e-2: the two calls round their BatchNorm sums differently, and among
+    the ~1e7 pre-activations of the compared rows a few lie within that round-off of the ReLU / LeakyReLU kink and take the other
+    derivative branch in one of the calls -- each flip moves every upstream gradient by O(1e-3) (a wrong split
+    factor or slot count is an O(1) error)."""
+    from dpmn_amd.model.cmm import ComplementationModulationModule
+    from dpmn_amd.model.distill_module import DistillModule
+    R, H, W = 48, 64, 256
+
+    def run(m, ins, cot, loss_of):
+        for p in m.parameters():
+            p.grad = None
+        xs = [t.clone().requires_grad_(True) for t in ins]
+        out = m(*xs)
+        loss_of(out, cot).backward()
+        torch.cuda.synchronize()
+        feat = out if torch.is_tensor(out) else out[1]
+        return feat.detach().clone(), [x.grad.clone() for x in xs], {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    cmm = ComplementationModulationModule(cnum=64)
+    _fill(cmm, 311)
+    dm = DistillModule()
+    _fill(dm, 312)
+    # DistillModule returns (loss, feature): the loss is a batch MEAN -- the same number for the repeated batch, its input gradient 1 / 48 per row
+    cases = [("cmm", cmm.to(dev).train(), [u("c4x1", (2, 3, H, W), 0, 1), u("c4x2", (2, 3, H, W), 0, 1)], u("c4cot", (2, 3, H, W), -1, 1),
+              lambda out, cot: (out * cot).sum()),
+             ("distill", dm.to(dev).train(), [u("c4fd", (2, 3, H, W), -1, 1), u("c4fs", (2, 3, H, W), -1, 1)], u("c4dcot", (2, 3, H, W), -1, 1),
+              lambda out, cot: out[0].sum() * 100 + (out[1] * cot).sum())]
+    for name, m, ins, cot, loss_of in cases:
+        ins, cot = [t.to(dev) for t in ins], cot.to(dev)
+        out_s, dx_s, g_s = run(m, ins, cot, loss_of)
+        out_b, dx_b, g_b = run(m, [t.repeat(R, 1, 1, 1) for t in ins], cot.repeat(R, 1, 1, 1) / R, loss_of)
+        tag = "cfg4_%s_bwd_B96_rows" % name
+        rep = lambda t: t.unsqueeze(0).expand(R, *t.shape)
+        e_out = l2_rel(out_b.reshape(R, *out_s.shape), rep(out_s))
+        record(tag, "forward rows rel L2 vs the B = 2 call", e_out, 2e-5)
+        e_dx = max(l2_rel(a.reshape(R, *b.shape) * R, rep(b)) for a, b in zip(dx_b, dx_s))
+        record(tag, "input-gradient rows rel L2 vs the B = 2 call", e_dx, 2e-2)
+        gmax = float(max(t.abs().max() for t in g_s.values()))
+        errs = sorted(((l2_rel(g_b[n], g_s[n]), n) for n in g_s if float(g_s[n].abs().max()) >= 1e-3 * gmax), reverse=True)      # (biases in front of a train-mode BatchNorm: zero up to rounding)
+        record(tag, "worst parameter-gradient rel L2 vs the B = 2 call (%s)" % errs[0][1], errs[0][0], 2e-2)
+        record(tag, "median parameter-gradient rel L2 vs the B = 2 call", errs[len(errs) // 2][0])
+        assert e_out < 2e-5 and e_dx < 2e-2 and errs[0][0] < 2e-2, (name, e_out, e_dx, errs[:4])
