@@ -48,6 +48,17 @@ def test_bench_forward_two_ranks_one_line():
     assert d["cpu_baseline"] is None        # N = 1 only
 
 
+def test_bench_default_line_two_ranks_carries_train_and_x3_objects():
+    """The driver's N > 1 command has no flags beyond --gpus / --steps / --warmup: every rank runs the forward leg, the two training legs
+    (gradient exchange over the process group) and the same legs in mode 2; rank 0 prints one line with the `train` and `x3` objects."""
+    d = _bench(["--train-steps", "2"], timeout=900)
+    assert d["n_gpus"] == 2 and d["dtype"] == "f32" and d["value"] > 0
+    assert d["train"]["ms_per_step"] > 0 and d["train"]["without_dropout"]["ms_per_step"] > 0
+    assert len(d["train"]["per_step_ms"]) == 2
+    x3 = d["x3"]
+    assert x3["value"] > 0 and x3["train"]["ms_per_step"] > 0 and x3["train"]["without_dropout"]["ms_per_step"] > 0
+
+
 @pytest.mark.parametrize("zero1", [1, 0])
 def test_bench_training_step_two_ranks(zero1):
     d = _bench(["--mode", "train", "--zero1", str(zero1)])
