@@ -122,7 +122,7 @@ def do_collect(tag):
                     o.write('"%s",%d,%.2f,%.2f,%.2f,%.2f\n' % (fam, n, us, util, tf, tf16))
                 o.write('"ALL dpmn kernels (time-weighted)",,,%.2f,,\n' % (100.0 * tb / ta if ta else 0.0))
             print(open(os.path.join(dst, pre + "_pmc_mfma_util.csv")).read())
-    for name in ("pmc_sq_f32.txt", "pmc_sq_x3.txt", "torch_ops_per_step.txt"):
+    for name in ("pmc_sq_f32.txt", "pmc_sq_x3.txt", "torch_ops_per_step.txt", "gpu_suite.txt"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
     rl = os.path.join(src, "rccl_world1.log")

@@ -7,6 +7,8 @@ set -u
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
+# the whole GPU suite first (both compute modes): its error record travels as <tag>_parity_errors.json
+(cd $R && timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $OUT/gpu_suite.txt)
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --no-cpu-baseline --no-kernel-profile --no-train"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/fwd -- $B --steps 10 --warmup 3 > $OUT/fwd.log 2>&1
