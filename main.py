@@ -83,12 +83,28 @@ def main(config, args):
             val_dls = mission.get_val_data()[1] if val_dirs and all(os.path.isdir(d) for d in val_dirs) else []
             # eval every VAL.valInterval over every validation subset + best-model checkpoints (super_resolution.py:283-337)
             # one entry per validation subset (easy / medium / hard): evaluated, logged and check-pointed separately, best model by the sum
-            val_loader = {os.path.basename(os.path.normpath(d)): (lambda v=vdl: sr_batches(v, mission.device, mission.mask))
-                          for d, vdl in zip(val_dirs, val_dls)} if val_dls else None
+            val_loader = {name: (lambda v=vdl: sr_batches(v, mission.device, mission.mask))
+                          for name, vdl in zip(subset_names(val_dirs), val_dls)} if val_dls else None
             mission.train(lambda epoch: sr_batches(dl, mission.device, mission.mask), epochs=config.TRAIN.epochs,
                           sampler=getattr(mission, "train_sampler", None), val_loader=val_loader)
         else:
             mission.train(synthetic_loader(bs, args.synthetic_steps, 2000 + rank), steps=args.synthetic_steps)
+
+
+def subset_names(val_dirs):
+    """One key per validation directory: its leaf name (the reference's data_name, super_resolution.py:286), made unique -- two
+    directories with the same leaf get their parent in front, and a leaf that equals one of train()'s bookkeeping keys
+    ('epoch', 'score') gets the parent too -- so that no subset silently replaces another in the per-subset tables."""
+    norm = [os.path.normpath(d) for d in val_dirs]
+    leaf = [os.path.basename(d) for d in norm]
+    names = []
+    for d, name in zip(norm, leaf):
+        if leaf.count(name) > 1 or name in ("epoch", "score", ""):
+            name = (os.path.basename(os.path.dirname(d)) + "_" + name).strip("_") or d
+        while name in names or name in ("epoch", "score"):
+            name += "_"
+        names.append(name)
+    return names
 
 
 if __name__ == '__main__':

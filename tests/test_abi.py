@@ -66,3 +66,17 @@ def test_pgrm_derived_buffers_match_oracle():
         tbl = torch.arange((2 * ws - 1) ** 2 * 2, dtype=torch.float32).reshape(-1, 2)
         assert torch.equal(tbl[_rel_index(ws).reshape(-1)].reshape(ws * ws, ws * ws, 2).permute(2, 0, 1),
                            opgrm.relative_bias(tbl, ws))
+
+
+def test_validation_subset_names_are_unique_and_avoid_the_bookkeeping_keys():
+    """main.py subset_names: the per-subset tables of TextSR.train are keyed by the validation directory's leaf name
+    (super_resolution.py:286 of the reference iterates a list); equal leaves or a leaf called 'epoch' / 'score' must not collapse."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("dpmn_main", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "main.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    names = m.subset_names(["/d/test/easy", "/d/test/medium/", "/d/val/easy", "/x/epoch", "/y/score"])
+    assert names == ["test_easy", "medium", "val_easy", "x_epoch", "y_score"]
+    assert m.subset_names(["/d/test/easy", "/d/test/medium", "/d/test/hard"]) == ["easy", "medium", "hard"]
+    assert len(set(m.subset_names(["/a/easy", "/a/easy"]))) == 2
