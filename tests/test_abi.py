@@ -80,3 +80,34 @@ def test_validation_subset_names_are_unique_and_avoid_the_bookkeeping_keys():
     assert names == ["test_easy", "medium", "val_easy", "x_epoch", "y_score"]
     assert m.subset_names(["/d/test/easy", "/d/test/medium", "/d/test/hard"]) == ["easy", "medium", "hard"]
     assert len(set(m.subset_names(["/a/easy", "/a/easy"]))) == 2
+
+
+def test_library_has_no_packed_fp32_vector_ops():
+    """v_pk_fma_f32 returned wrong sums while a bf16-MFMA kernel of another stream was resident on the CU; the
+    library is built with the packed-fp32 target feature off (csrc/Makefile NOPK).  Guard: disassemble every gfx950 code object of the
+    shipped libdpmn_hip.so -- not one v_pk_{fma,mul,add}_f32 may be left (and the scan must have seen the MFMA kernels)."""
+    import re
+    import subprocess
+    import tempfile
+    from dpmn_amd import _abi
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-objdump")):
+        pytest.skip("ROCm llvm tools not installed")
+    with tempfile.TemporaryDirectory() as tmp:
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.run([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, _abi.LIB_PATH, os.path.join(tmp, "copy.so")], check=True)
+        data = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), data)]
+        assert len(starts) >= 20, "one offload bundle per translation unit expected"
+        packed = mfma = 0
+        for i, s in enumerate(starts):
+            part, co = os.path.join(tmp, "b%d.bin" % i), os.path.join(tmp, "b%d.co" % i)
+            with open(part, "wb") as f:
+                f.write(data[s:starts[i + 1] if i + 1 < len(starts) else len(data)])
+            subprocess.run([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + part,
+                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
+            dis = subprocess.run([llvm + "/llvm-objdump", "-d", co], check=True, capture_output=True, text=True).stdout
+            packed += len(re.findall(r"v_pk_(?:fma|mul|add)_f32", dis))
+            mfma += len(re.findall(r"v_mfma_f32_16x16x32_bf16", dis))
+    assert mfma > 1000, "the scan did not see the bf16 MFMA kernels"
+    assert packed == 0, "%d packed fp32 vector instructions in libdpmn_hip.so: the NOPK flag of csrc/Makefile is gone?" % packed
