@@ -450,7 +450,7 @@ def train_object(args, workload, world, rank, force_dist, dist, torch, _abi):
                "device_allocs_in_timed_region": host[warmup + steps - 1][1] - host[warmup - 1][1],
                "gc_collections_in_timed_region": host[warmup + steps - 1][2] - host[warmup - 1][2],
                "whole_step_frac_of_fp32_mfma_peak": round(TRAIN_GFLOP_PER_IMAGE * 1e9 * B / (ms * 1e-3) / (FP32_MFMA_PEAK_TFLOPS * 1e12), 4),
-               "roofline": roofline_of(live, steps, B, "train")}
+               "roofline": roofline_of(live, steps, B, "train_x3" if _abi.lib.dpmn_get_compute_dtype() == 2 else "train")}
         if drop > 0.0:
             out.update(rec)
             out["psn_prefetch"] = not args.no_psn_prefetch
@@ -604,7 +604,7 @@ def main():
                                ("dp%d (coalesced gradient groups, RCCL %s overlapped with backward)" % (
                                    world, "reduce-scatter + sharded clip/Adam + all-gather" if trainer.zero1 else "all-reduce"))},
         }
-        roof = roofline_of(live, args.steps, B, "fwd_x3" if (args.mode == "fwd" and args.dtype == "x3") else args.mode)
+        roof = roofline_of(live, args.steps, B, (args.mode if args.mode == "fwd" else "train") + ("_x3" if args.dtype == "x3" else "") if args.dtype in ("f32", "x3") else args.mode)
         if latency_ms is not None:
             line["one_batch_at_a_time"] = {"ms_per_step": round(latency_ms, 3), "images_per_s": round(world * B / latency_ms * 1e3, 2),
                                            "what": "the same step with ONE batch in flight (--pipeline 1), timed after the region on rank 0"}

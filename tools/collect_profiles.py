@@ -66,7 +66,8 @@ def latest(base, pattern):
 
 
 def do_reduce(out):
-    for sub in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_fetch_train", "pmc_write_train", "pmc_mfma_train", "pmc_fetch_x3", "pmc_write_x3", "pmc_mfma_x3"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_fetch_train", "pmc_write_train", "pmc_mfma_train", "pmc_fetch_x3", "pmc_write_x3", "pmc_mfma_x3",
+                "pmc_fetch_train_x3", "pmc_write_train_x3", "pmc_mfma_train_x3"):
         f = latest(out, sub + "/**/*counter_collection.csv")
         if f:
             json.dump(reduce_pmc(f), open(os.path.join(out, sub + ".json"), "w"), indent=1)
@@ -93,10 +94,12 @@ def do_collect(tag):
     for suffix, mode, text in (("", "fwd", "cfg1 forward, bench.py --steps 3 --warmup 2 under rocprofv3 --pmc (one counter per pass)"),
                                ("_train", "train", "cfg1 TRAINING step, bench.py --mode train --steps 3 --warmup 2 under rocprofv3 --pmc (one counter group per "
                                 "pass; branch and weight-gradient streams active, so kernels overlap: the per-launch durations are inflated, the byte counts are not)"),
-                               ("_x3", "fwd_x3", "cfg1 forward in mode 2 (f32 via bf16x3), bench.py --dtype x3 --steps 3 --warmup 2 under rocprofv3 --pmc")):
+                               ("_x3", "fwd_x3", "cfg1 forward in mode 2 (f32 via bf16x3), bench.py --dtype x3 --steps 3 --warmup 2 under rocprofv3 --pmc"),
+                               ("_train_x3", "train_x3", "cfg1 TRAINING step in mode 2 (f32 via bf16x3), bench.py --dtype x3 --mode train --steps 3 --warmup 2 under "
+                                "rocprofv3 --pmc (streams overlap: per-launch durations inflated, byte counts not)")):
         fe, wr, mf = (json.load(open(os.path.join(src, n + suffix + ".json"))) if os.path.exists(os.path.join(src, n + suffix + ".json")) else {}
                       for n in ("pmc_fetch", "pmc_write", "pmc_mfma"))
-        pre = tag + {"fwd": "", "train": "_train", "fwd_x3": "_x3"}[mode]
+        pre = tag + {"fwd": "", "train": "_train", "fwd_x3": "_x3", "train_x3": "_x3_train"}[mode]
         if fe and wr:
             rec = {"per_gpu_batch": B, "mode": mode, "workload": text,
                    "correction": "gfx950: FETCH_SIZE counts wide coalesced reads at 1/2 -> hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024",

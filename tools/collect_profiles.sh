@@ -31,6 +31,10 @@ if [ "${1:-}" != "quick" ]; then
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_train -- $T > $OUT/pmc_fetch_train.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_train -- $T > $OUT/pmc_write_train.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_train -- $T > $OUT/pmc_mfma_train.log 2>&1
+  TX="$X --mode train --steps 3 --warmup 2"
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_train_x3 -- $TX > $OUT/pmc_fetch_train_x3.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_train_x3 -- $TX > $OUT/pmc_write_train_x3.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_mfma_train_x3 -- $TX > $OUT/pmc_mfma_train_x3.log 2>&1
 fi
 cd $R
 timeout 900 python bench.py 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
